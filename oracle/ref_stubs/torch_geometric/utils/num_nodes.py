@@ -1,0 +1,2 @@
+def maybe_num_nodes(index, num_nodes=None):
+    return int(index.max()) + 1 if num_nodes is None else num_nodes
