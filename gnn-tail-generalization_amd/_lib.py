@@ -1,0 +1,82 @@
+"""ctypes binding of libcoldbrew_hip.so (the C ABI declared in include/coldbrew_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a tensor is not on an
+MI355X device, the product path raises.  Build with `python __graft_entry__.py` or
+`make -C gnn-tail-generalization_amd/csrc`.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libcoldbrew_hip.so')
+
+_c_i32p = ctypes.c_void_p
+_c_f32p = ctypes.c_void_p
+_I64 = ctypes.c_int64
+_I32 = ctypes.c_int32
+_SZ = ctypes.c_size_t
+_P = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/coldbrew_hip.h one to one
+SIGNATURES = {
+    'cb_version': (ctypes.c_int, []),
+    'cb_last_error': (ctypes.c_char_p, []),
+    'cb_csr_workspace_bytes': (_SZ, [_I64, _I64]),
+    'cb_csr_from_coo_i64': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    'cb_deg_norm_f32': (ctypes.c_int, [_P, _I64, _P, _P]),
+    'cb_spmm_hub_count': (ctypes.c_int, [_P, _I64, _I32, _P, _P]),
+    'cb_spmm_hub_fill': (ctypes.c_int, [_P, _I64, _I32, _I32, _P, _P, _P, _P]),
+    'cb_spmm_workspace_bytes': (_SZ, [_I64, _I64]),
+    'cb_spmm_csr_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_int, _P, _I64,
+                                       _I32, _I32, _I32, _P, _P, _P, _SZ, _P]),
+}
+
+_lib = None
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the shared library once; raises HipExtensionError (never falls back) if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise HipExtensionError(
+            f'{LIB_PATH} not found: the HIP extension is required (no CPU fallback). '
+            'Build it with `python __graft_entry__.py` or `make -C gnn-tail-generalization_amd/csrc`.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().cb_last_error()
+        raise HipExtensionError(f'{what} failed (rc={rc}): {msg.decode() if msg else ""}')
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HipExtensionError('Cold Brew HIP path needs tensors on an MI355X device (got a CPU tensor); '
+                                    'there is no CPU fallback')

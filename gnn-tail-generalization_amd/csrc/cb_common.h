@@ -1,0 +1,45 @@
+// Shared helpers for libcoldbrew_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/coldbrew_hip.h"
+
+namespace cb {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+void set_error(const char* fmt, ...);
+
+#define CB_CHECK_ARG(cond, code, ...)  \
+  do {                                 \
+    if (!(cond)) {                     \
+      cb::set_error(__VA_ARGS__);      \
+      return (code);                   \
+    }                                  \
+  } while (0)
+
+#define CB_HIP(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      cb::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return CB_E_HIP;                                                                      \
+    }                                                                                       \
+  } while (0)
+
+#define CB_LAUNCH_CHECK() CB_HIP(hipGetLastError())
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static inline int blocks_for(int64_t n, int per_block) { return (int)((n + per_block - 1) / per_block); }
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// wave-uniform broadcast helpers (values land in SGPRs)
+__device__ __forceinline__ int bcast_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int bcast_lane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+}  // namespace cb

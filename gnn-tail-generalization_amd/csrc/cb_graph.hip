@@ -1,0 +1,271 @@
+// Graph ingest for the aggregation: edge_index (int64 COO) -> CSR by dst and by src,
+// degree norms, and the hub plan.  Replaces the Python-list DGL graph build of
+// GNN_model/GCN.py:92-95 and the per-layer degree queries of GCN.py:188,206,243.
+//
+// Pipeline (all on the caller's stream, no allocation):
+//   pack    key[e] = major[e] << bits | minor[e]            (uint64, 2*bits significant)
+//   sort    rocPRIM LSD radix sort over the 2*bits key bits (one-off ingest; the only
+//           library primitive in this library — everything per-step is hand-written)
+//   unpack  col[e] = key[e] & mask
+//   rowptr  rowptr[v] = lower_bound(key, v << bits)          (N+1 binary searches)
+// so each row lists its neighbours in ascending id; the result depends only on the
+// edge multiset (bit-exact contract of SURVEY.md §8 a3).
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "cb_common.h"
+
+namespace cb {
+
+__global__ void k_init_flags(int32_t* flags) {
+  if (threadIdx.x == 0) {
+    flags[0] = 0;
+    flags[1] = 0;
+    flags[2] = 1;
+    flags[3] = 0;
+  }
+}
+
+__global__ void k_pack_keys(const int64_t* __restrict__ major, const int64_t* __restrict__ minor, int64_t E, int64_t N,
+                            int bits, uint64_t* __restrict__ keys, int32_t* flags) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int bad = 0;
+  if (i < E) {
+    int64_t a = major[i], b = minor[i];
+    if (a < 0 || a >= N || b < 0 || b >= N) {
+      bad = 1;
+      a = 0;
+      b = 0;
+    }
+    keys[i] = ((uint64_t)a << bits) | (uint64_t)b;
+  }
+  unsigned long long m = __ballot(bad);
+  if (m && lane_id() == 0) atomicAdd(&flags[1], (int)__popcll(m));
+}
+
+__global__ void k_unpack_cols(const uint64_t* __restrict__ keys, int64_t E, uint64_t mask, int32_t* __restrict__ col) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < E) col[i] = (int32_t)(keys[i] & mask);
+}
+
+__global__ void k_rowptr_search(const uint64_t* __restrict__ keys, int64_t E, int64_t N, int bits, int32_t* __restrict__ rowptr) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v > N) return;
+  uint64_t target = (uint64_t)v << bits;
+  int64_t lo = 0, hi = E;  // first index with key >= target
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  rowptr[v] = (int32_t)lo;
+}
+
+__global__ void k_degree_stats(const int32_t* __restrict__ rowptr, int64_t N, int32_t* flags) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int deg = 0, zero = 0;
+  if (v < N) {
+    deg = rowptr[v + 1] - rowptr[v];
+    zero = deg == 0;
+  }
+  unsigned long long m = __ballot(zero);
+  // wave max of deg
+  for (int off = 32; off > 0; off >>= 1) deg = max(deg, __shfl_xor(deg, off));
+  if (lane_id() == 0) {
+    if (m) atomicAdd(&flags[0], (int)__popcll(m));
+    if (deg > 0) atomicMax(&flags[3], deg);
+  }
+}
+
+__global__ void k_compare_i32(const int32_t* __restrict__ a, const int32_t* __restrict__ b, int64_t n, int32_t* flags) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int diff = (i < n) ? (a[i] != b[i]) : 0;
+  if (__ballot(diff) && lane_id() == 0) atomicAnd(&flags[2], 0);
+}
+
+__global__ void k_deg_norm(const int32_t* __restrict__ rowptr, int64_t N, float* __restrict__ norm) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < N) {
+    int deg = rowptr[v + 1] - rowptr[v];
+    float x = (float)max(deg, 1);
+    norm[v] = 1.0f / sqrtf(x);  // degs.float().clamp(min=1) ** -0.5
+  }
+}
+
+__global__ void k_hub_count(const int32_t* __restrict__ rowptr, int64_t N, int T, int32_t* counts) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int hub = 0, chunks = 0;
+  if (v < N) {
+    int deg = rowptr[v + 1] - rowptr[v];
+    if (deg > T) {
+      hub = 1;
+      chunks = (deg + T - 1) / T;
+    }
+  }
+  unsigned long long m = __ballot(hub);
+  if (m) {
+    for (int off = 32; off > 0; off >>= 1) chunks += __shfl_xor(chunks, off);
+    if (lane_id() == 0) {
+      atomicAdd(&counts[0], (int)__popcll(m));
+      atomicAdd(&counts[1], chunks);
+    }
+  }
+}
+
+__global__ void k_hub_collect(const int32_t* __restrict__ rowptr, int64_t N, int T, int cap, int32_t* hub_rows, int32_t* cursor) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < N && rowptr[v + 1] - rowptr[v] > T) {
+    int slot = atomicAdd(cursor, 1);
+    if (slot < cap) hub_rows[slot] = (int32_t)v;
+  }
+}
+
+// Single block: sorts nothing — the order of hub_rows only decides which wavefront takes
+// which chunk; results are reduced per hub in chunk order, so they do not depend on it.
+__global__ void k_hub_scan(const int32_t* __restrict__ rowptr, int T, int n_hubs, const int32_t* __restrict__ hub_rows,
+                           int32_t* __restrict__ hub_chunk_ptr) {
+  __shared__ int s_part[1024];
+  __shared__ int s_base;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (int start = 0; start < n_hubs; start += blockDim.x) {
+    int i = start + threadIdx.x;
+    int c = 0;
+    if (i < n_hubs) {
+      int r = hub_rows[i];
+      c = (rowptr[r + 1] - rowptr[r] + T - 1) / T;
+    }
+    s_part[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 1; off < (int)blockDim.x; off <<= 1) {  // Hillis-Steele inclusive scan
+      int add = (threadIdx.x >= (unsigned)off) ? s_part[threadIdx.x - off] : 0;
+      __syncthreads();
+      s_part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    int incl = s_part[threadIdx.x];
+    int base = s_base;
+    if (i < n_hubs) hub_chunk_ptr[i] = base + incl - c;
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) s_base = base + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) hub_chunk_ptr[n_hubs] = s_base;
+}
+
+static int key_bits(int64_t N) {
+  int b = 1;
+  while (((int64_t)1 << b) < N) ++b;
+  return b;
+}
+
+static size_t sort_temp_bytes(int64_t E, int bits) {
+  size_t bytes = 0;
+  uint64_t* p = nullptr;
+  (void)rocprim::radix_sort_keys(nullptr, bytes, p, p, (size_t)E, 0u, (unsigned)(2 * bits), (hipStream_t)0);
+  return bytes;
+}
+
+static int build_one(const int64_t* major, const int64_t* minor, int64_t E, int64_t N, int bits, int32_t* rowptr,
+                     int32_t* col, int32_t* flags, uint64_t* keys_a, uint64_t* keys_b, void* temp, size_t temp_bytes,
+                     hipStream_t st) {
+  const int B = 256;
+  if (E > 0) {
+    hipLaunchKernelGGL(k_pack_keys, dim3(blocks_for(E, B)), dim3(B), 0, st, major, minor, E, N, bits, keys_a, flags);
+    CB_LAUNCH_CHECK();
+    size_t tb = temp_bytes;
+    CB_HIP(rocprim::radix_sort_keys(temp, tb, keys_a, keys_b, (size_t)E, 0u, (unsigned)(2 * bits), st));
+    uint64_t mask = (((uint64_t)1) << bits) - 1;
+    hipLaunchKernelGGL(k_unpack_cols, dim3(blocks_for(E, B)), dim3(B), 0, st, keys_b, E, mask, col);
+    CB_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_rowptr_search, dim3(blocks_for(N + 1, B)), dim3(B), 0, st, keys_b, E, N, bits, rowptr);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
+}  // namespace cb
+
+using namespace cb;
+
+extern "C" size_t cb_csr_workspace_bytes(int64_t E, int64_t N) {
+  if (E < 0 || N < 0) return 0;
+  int bits = key_bits(N < 2 ? 2 : N);
+  size_t keys = align_up((size_t)(E > 0 ? E : 1) * sizeof(uint64_t), 256);
+  return 2 * keys + align_up(sort_temp_bytes(E > 0 ? E : 1, bits), 256) + 256;
+}
+
+extern "C" int cb_csr_from_coo_i64(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int32_t* rowptr,
+                                   int32_t* col, int32_t* rowptr_t, int32_t* col_t, int32_t* flags, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  CB_CHECK_ARG(E >= 0 && N >= 0, CB_E_INVALID, "cb_csr_from_coo_i64: negative size (E=%lld, N=%lld)", (long long)E, (long long)N);
+  CB_CHECK_ARG(E < INT32_MAX && N < INT32_MAX, CB_E_RANGE, "cb_csr_from_coo_i64: E=%lld / N=%lld exceed the int32 index contract",
+               (long long)E, (long long)N);
+  CB_CHECK_ARG(rowptr && rowptr_t && flags && (E == 0 || (src && dst && col && col_t)), CB_E_INVALID,
+               "cb_csr_from_coo_i64: null pointer");
+  CB_CHECK_ARG(workspace && workspace_bytes >= cb_csr_workspace_bytes(E, N), CB_E_WORKSPACE,
+               "cb_csr_from_coo_i64: workspace %zu < required %zu", workspace_bytes, cb_csr_workspace_bytes(E, N));
+  hipStream_t st = (hipStream_t)stream;
+  int bits = key_bits(N < 2 ? 2 : N);
+  size_t keys = align_up((size_t)(E > 0 ? E : 1) * sizeof(uint64_t), 256);
+  char* w = (char*)workspace;
+  uint64_t* keys_a = (uint64_t*)w;
+  uint64_t* keys_b = (uint64_t*)(w + keys);
+  void* temp = w + 2 * keys;
+  size_t temp_bytes = workspace_bytes - 2 * keys;
+
+  hipLaunchKernelGGL(k_init_flags, dim3(1), dim3(64), 0, st, flags);
+  CB_LAUNCH_CHECK();
+  // by-dst CSR: rows = dst, cols = src (forward aggregation, GCN.py:238)
+  int rc = build_one(dst, src, E, N, bits, rowptr, col, flags, keys_a, keys_b, temp, temp_bytes, st);
+  if (rc) return rc;
+  // by-src CSR: rows = src, cols = dst (reverse graph, backward of the aggregation)
+  rc = build_one(src, dst, E, N, bits, rowptr_t, col_t, flags, keys_a, keys_b, temp, temp_bytes, st);
+  if (rc) return rc;
+  const int B = 256;
+  if (N > 0) {
+    hipLaunchKernelGGL(k_degree_stats, dim3(blocks_for(N, B)), dim3(B), 0, st, rowptr, N, flags);
+    CB_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_compare_i32, dim3(blocks_for(N + 1, B)), dim3(B), 0, st, rowptr, rowptr_t, N + 1, flags);
+  CB_LAUNCH_CHECK();
+  if (E > 0) {
+    hipLaunchKernelGGL(k_compare_i32, dim3(blocks_for(E, B)), dim3(B), 0, st, col, col_t, E, flags);
+    CB_LAUNCH_CHECK();
+  }
+  return CB_OK;
+}
+
+extern "C" int cb_deg_norm_f32(const int32_t* rowptr, int64_t N, float* norm, void* stream) {
+  CB_CHECK_ARG(N >= 0 && (N == 0 || (rowptr && norm)), CB_E_INVALID, "cb_deg_norm_f32: bad argument");
+  if (N == 0) return CB_OK;
+  hipLaunchKernelGGL(k_deg_norm, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, N, norm);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
+extern "C" int cb_spmm_hub_count(const int32_t* rowptr, int64_t N, int32_t T, int32_t* counts, void* stream) {
+  CB_CHECK_ARG(rowptr && counts && N >= 0 && T > 0, CB_E_INVALID, "cb_spmm_hub_count: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  CB_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st));
+  if (N > 0) {
+    hipLaunchKernelGGL(k_hub_count, dim3(blocks_for(N, 256)), dim3(256), 0, st, rowptr, N, T, counts);
+    CB_LAUNCH_CHECK();
+  }
+  return CB_OK;
+}
+
+extern "C" int cb_spmm_hub_fill(const int32_t* rowptr, int64_t N, int32_t T, int32_t n_hubs, int32_t* hub_rows,
+                                int32_t* hub_chunk_ptr, int32_t* cursor, void* stream) {
+  CB_CHECK_ARG(rowptr && hub_chunk_ptr && cursor && N >= 0 && T > 0 && n_hubs >= 0 && (n_hubs == 0 || hub_rows), CB_E_INVALID,
+               "cb_spmm_hub_fill: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  CB_HIP(hipMemsetAsync(cursor, 0, sizeof(int32_t), st));
+  if (n_hubs > 0) {
+    hipLaunchKernelGGL(k_hub_collect, dim3(blocks_for(N, 256)), dim3(256), 0, st, rowptr, N, T, n_hubs, hub_rows, cursor);
+    CB_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_hub_scan, dim3(1), dim3(1024), 0, st, rowptr, T, n_hubs, hub_rows, hub_chunk_ptr);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}

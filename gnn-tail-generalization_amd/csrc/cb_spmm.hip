@@ -1,0 +1,350 @@
+// CSR sum-aggregation for gfx950 — replaces DGL's gspmm behind
+// `graph.update_all(fn.copy_src('h','m'), fn.sum('m','h'))` (GNN_model/GCN.py:198,238)
+// with the `* norm` and `+ bias` of GCN.py:242-253 and the following ReLU (GCN.py:127-128)
+// fused into the store.
+//
+// Bound: HBM.  Algorithmic bytes per launch = E*(d*4 + 4) + N*(d*4 + 4) [+ 4N row scale].
+//
+// Mapping (d = 256 fp32 is the tuned case):
+//   * one 64-lane wavefront owns RPW consecutive destination rows; lane l owns columns
+//     [VEC*l, VEC*l + VEC) of the 64*VEC-wide column tile, so one neighbour row is ONE
+//     fully coalesced 1 KiB global_load_dwordx4 per wavefront (d = 256, VEC = 4);
+//   * the rows' edges are contiguous in CSR, so the wavefront walks them as ONE edge
+//     stream: 64 column ids per coalesced index load, wave-uniform broadcast
+//     (v_readlane -> SGPR base address), U independent gathers in flight before the first
+//     add, row boundaries handled while consuming (wave-uniform scalar compares).  Short
+//     rows therefore do not serialise on the rowptr -> col -> gather latency chain;
+//   * rows longer than the hub threshold (power-law hubs) are skipped here and reduced by
+//     k_spmm_hub_chunks (one wavefront per chunk of T edges -> partial row in the
+//     workspace) + k_spmm_hub_finish (sums a hub's partials in chunk order + epilogue).
+//   * no atomics anywhere: every output element is produced by one lane in a fixed order,
+//     so results are bit-reproducible run to run.
+//   * streaming data (indices, output rows) uses non-temporal accesses so the 4 MiB L2s and
+//     the 256 MiB Infinity Cache keep the re-used neighbour rows (hub sources).
+#include "cb_common.h"
+
+namespace cb {
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<1> {
+  using T = float;
+};
+template <>
+struct Vec<2> {
+  using T = float2;
+};
+template <>
+struct Vec<4> {
+  using T = float4;
+};
+
+template <int VEC>
+__device__ __forceinline__ void zero(float (&a)[VEC]) {
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) a[i] = 0.f;
+}
+
+template <int VEC>
+__device__ __forceinline__ void gather(float (&v)[VEC], const float* __restrict__ p) {
+  using T = typename Vec<VEC>::T;
+  T t = *reinterpret_cast<const T*>(p);
+  if constexpr (VEC == 1) {
+    v[0] = t;
+  } else if constexpr (VEC == 2) {
+    v[0] = t.x;
+    v[1] = t.y;
+  } else {
+    v[0] = t.x;
+    v[1] = t.y;
+    v[2] = t.z;
+    v[3] = t.w;
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_stream(float* __restrict__ p, const float (&v)[VEC]) {
+  // written once, read by a later kernel: keep it out of the caches
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) __builtin_nontemporal_store(v[i], p + i);
+}
+
+struct Epilogue {
+  const float* row_scale;  // [N] or null
+  const float* bias;       // [d] or null
+  int relu;
+};
+
+template <int VEC>
+__device__ __forceinline__ void write_row(float* __restrict__ out_row, const float (&acc)[VEC], float scale,
+                                          const float (&b)[VEC], int relu) {
+  float r[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    float t = acc[i] * scale;   // rst * norm   (GCN.py:250)
+    t = t + b[i];               // rst + bias   (GCN.py:253)
+    r[i] = relu ? fmaxf(t, 0.f) : t;
+  }
+  store_stream<VEC>(out_row, r);
+}
+
+// Walks the contiguous edge range of local rows [rlo, rhi) of this wavefront's row block.
+// my_ptr: lane i holds rowptr[r0 + i] (i <= nr).  All control flow is wave-uniform.
+template <int VEC, int U, bool FULL>
+__device__ __forceinline__ void stream_rows(int rlo, int rhi, int my_ptr, float my_scale, int r0, const int* __restrict__ col,
+                                            const float* __restrict__ h_lane, int64_t ld_h, float* __restrict__ out_lane,
+                                            int64_t ld_out, bool active_in, int relu, const float (&bvec)[VEC]) {
+  const bool active = FULL ? true : active_in;
+  const int lane = lane_id();
+  const int e_begin = bcast_lane(my_ptr, rlo);
+  const int e_end = bcast_lane(my_ptr, rhi);
+  int cur = rlo;
+  int cur_end = bcast_lane(my_ptr, rlo + 1);
+  float acc[VEC];
+  zero<VEC>(acc);
+
+  auto flush = [&]() {
+    if (active) {
+      const float s = __int_as_float(bcast_lane(__float_as_int(my_scale), cur));  // row scale of local row `cur`
+      write_row<VEC>(out_lane + (int64_t)(r0 + cur) * ld_out, acc, s, bvec, relu);
+    }
+    zero<VEC>(acc);
+    ++cur;
+    cur_end = bcast_lane(my_ptr, cur + 1);
+  };
+
+  for (int base = e_begin; base < e_end; base += kWave) {
+    const int cnt = min(kWave, e_end - base);
+    int my_col = 0;
+    if (lane < cnt) my_col = __builtin_nontemporal_load(col + base + lane);
+    int k = 0;
+    for (; k + U <= cnt; k += U) {
+      float v[U][VEC];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = bcast_lane(my_col, k + u);
+        if (active) gather<VEC>(v[u], h_lane + (int64_t)c * ld_h);
+        else zero<VEC>(v[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = base + k + u;
+        while (e == cur_end) flush();
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
+      }
+    }
+    for (; k < cnt; ++k) {
+      const int c = bcast_lane(my_col, k);
+      float v[VEC];
+      if (active) gather<VEC>(v, h_lane + (int64_t)c * ld_h);
+      else zero<VEC>(v);
+      const int e = base + k;
+      while (e == cur_end) flush();
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += v[i];
+    }
+  }
+  while (cur < rhi) flush();  // last row + trailing empty rows
+}
+
+template <int VEC, int RPW, int U, bool FULL>
+__global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                   const float* __restrict__ h, int64_t ld_h, float* __restrict__ out,
+                                                   int64_t ld_out, int n_rows, int d, Epilogue ep, int hub_T) {
+  static_assert(RPW < kWave, "row block must fit the lanes of one wavefront (+1 end pointer)");
+  const int lane = lane_id();
+  const int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int r0 = wave * RPW;
+  if (r0 >= n_rows) return;
+  const int nr = min(RPW, n_rows - r0);
+  const int c0 = (blockIdx.y * kWave + lane) * VEC;  // this lane's first column
+  const bool active = c0 < d;
+
+  int my_ptr = __builtin_nontemporal_load(rowptr + r0 + min(lane, nr));
+  float my_scale = 1.f;  // lane i: row_scale[r0 + i], broadcast at flush time (no load on the flush path)
+  if (ep.row_scale && lane < nr) my_scale = __builtin_nontemporal_load(ep.row_scale + r0 + lane);
+  const int nxt = __shfl_down(my_ptr, 1);
+  const unsigned long long hubmask = __ballot(lane < nr && (nxt - my_ptr) > hub_T);
+
+  float bvec[VEC];
+  zero<VEC>(bvec);
+  if (ep.bias && active) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) bvec[i] = ep.bias[c0 + i];
+  }
+  const float* h_lane = h + c0;
+  float* out_lane = out + c0;
+
+  if (hubmask == 0) {
+    stream_rows<VEC, U, FULL>(0, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec);
+  } else {
+    int r = 0;
+    while (r < nr) {  // maximal hub-free runs; hub rows are written by the hub kernels
+      unsigned long long m = hubmask >> r;
+      int nh = m ? r + (__ffsll((long long)m) - 1) : nr;
+      if (nh > r) stream_rows<VEC, U, FULL>(r, nh, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec);
+      r = nh + 1;
+    }
+  }
+}
+
+// One wavefront per chunk of T edges of a hub row -> one partial row in `partial`.
+template <int VEC, int U>
+__global__ void __launch_bounds__(256) k_spmm_hub_chunks(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                         const float* __restrict__ h, int64_t ld_h, int d, int hub_T,
+                                                         int n_hubs, int n_chunks, const int* __restrict__ hub_rows,
+                                                         const int* __restrict__ hub_chunk_ptr, float* __restrict__ partial,
+                                                         int64_t ld_p) {
+  const int lane = lane_id();
+  const int chunk = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (chunk >= n_chunks) return;
+  const int c0 = (blockIdx.y * kWave + lane) * VEC;
+  const bool active = c0 < d;
+  // hub index: last i with hub_chunk_ptr[i] <= chunk (wave-uniform binary search)
+  int lo = 0, hi = n_hubs;
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (hub_chunk_ptr[mid] <= chunk) lo = mid; else hi = mid;
+  }
+  const int row = hub_rows[lo];
+  const int j = chunk - hub_chunk_ptr[lo];
+  const int e_begin = rowptr[row] + j * hub_T;
+  const int e_end = min(e_begin + hub_T, rowptr[row + 1]);
+  const float* h_lane = h + c0;
+  float acc[VEC];
+  zero<VEC>(acc);
+  for (int base = e_begin; base < e_end; base += kWave) {
+    const int cnt = min(kWave, e_end - base);
+    int my_col = 0;
+    if (lane < cnt) my_col = __builtin_nontemporal_load(col + base + lane);
+    int k = 0;
+    for (; k + U <= cnt; k += U) {
+      float v[U][VEC];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = bcast_lane(my_col, k + u);
+        if (active) gather<VEC>(v[u], h_lane + (int64_t)c * ld_h);
+        else zero<VEC>(v[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
+    }
+    for (; k < cnt; ++k) {
+      const int c = bcast_lane(my_col, k);
+      float v[VEC];
+      if (active) gather<VEC>(v, h_lane + (int64_t)c * ld_h);
+      else zero<VEC>(v);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += v[i];
+    }
+  }
+  if (active) {
+    float* p = partial + (int64_t)chunk * ld_p + c0;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) p[i] = acc[i];
+  }
+}
+
+// One wavefront per hub row: partials summed in chunk order, then the epilogue.
+template <int VEC>
+__global__ void __launch_bounds__(256) k_spmm_hub_finish(int d, int n_hubs, const int* __restrict__ hub_rows,
+                                                         const int* __restrict__ hub_chunk_ptr,
+                                                         const float* __restrict__ partial, int64_t ld_p,
+                                                         float* __restrict__ out, int64_t ld_out, Epilogue ep) {
+  const int lane = lane_id();
+  const int i = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (i >= n_hubs) return;
+  const int c0 = (blockIdx.y * kWave + lane) * VEC;
+  if (c0 >= d) return;
+  const int row = hub_rows[i];
+  float acc[VEC];
+  zero<VEC>(acc);
+  for (int c = hub_chunk_ptr[i]; c < hub_chunk_ptr[i + 1]; ++c) {
+    float v[VEC];
+    gather<VEC>(v, partial + (int64_t)c * ld_p + c0);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] += v[k];
+  }
+  float bvec[VEC];
+  zero<VEC>(bvec);
+  if (ep.bias) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) bvec[k] = ep.bias[c0 + k];
+  }
+  float s = ep.row_scale ? ep.row_scale[row] : 1.f;
+  write_row<VEC>(out + (int64_t)row * ld_out + c0, acc, s, bvec, ep.relu);
+}
+
+static inline int64_t partial_ld(int64_t d) { return (d + 3) / 4 * 4; }
+
+template <int VEC>
+static int launch_spmm(const int32_t* rowptr, const int32_t* col, int64_t N, const float* h, int64_t ld_h, int64_t d,
+                       Epilogue ep, float* out, int64_t ld_out, int hub_T, int n_hubs, int n_chunks,
+                       const int32_t* hub_rows, const int32_t* hub_chunk_ptr, float* partial, hipStream_t st) {
+  constexpr int RPW = 16;
+  constexpr int U = (VEC == 4) ? 8 : 8;
+  const int tile = kWave * VEC;
+  const int ny = (int)((d + tile - 1) / tile);
+  const int waves_per_block = 4;
+  {
+    int64_t n_waves = (N + RPW - 1) / RPW;
+    dim3 grid((unsigned)((n_waves + waves_per_block - 1) / waves_per_block), ny);
+    if (d % tile == 0)
+      hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, true>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h,
+                         out, ld_out, (int)N, (int)d, ep, hub_T);
+    else
+      hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, false>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h,
+                         out, ld_out, (int)N, (int)d, ep, hub_T);
+    CB_LAUNCH_CHECK();
+  }
+  if (n_hubs > 0) {
+    const int64_t ld_p = partial_ld(d);
+    dim3 grid((unsigned)((n_chunks + waves_per_block - 1) / waves_per_block), ny);
+    hipLaunchKernelGGL((k_spmm_hub_chunks<VEC, U>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h, (int)d,
+                       hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, ld_p);
+    CB_LAUNCH_CHECK();
+    dim3 grid2((unsigned)((n_hubs + waves_per_block - 1) / waves_per_block), ny);
+    hipLaunchKernelGGL((k_spmm_hub_finish<VEC>), grid2, dim3(kWave * waves_per_block), 0, st, (int)d, n_hubs, hub_rows,
+                       hub_chunk_ptr, partial, ld_p, out, ld_out, ep);
+    CB_LAUNCH_CHECK();
+  }
+  return CB_OK;
+}
+
+}  // namespace cb
+
+using namespace cb;
+
+extern "C" size_t cb_spmm_workspace_bytes(int64_t n_chunks, int64_t d) {
+  if (n_chunks <= 0 || d <= 0) return 0;
+  return (size_t)n_chunks * (size_t)partial_ld(d) * sizeof(float);
+}
+
+extern "C" int cb_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h,
+                               int64_t d, const float* row_scale, const float* bias, int relu, float* out, int64_t ld_out,
+                               int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
+                               const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(N >= 0 && E >= 0 && d >= 0, CB_E_INVALID, "cb_spmm_csr_f32: negative size");
+  CB_CHECK_ARG(N < INT32_MAX && E < INT32_MAX && d < (1 << 20), CB_E_RANGE, "cb_spmm_csr_f32: size exceeds the int32 contract");
+  if (N == 0 || d == 0) return CB_OK;
+  CB_CHECK_ARG(rowptr && h && out && (E == 0 || col), CB_E_INVALID, "cb_spmm_csr_f32: null pointer");
+  CB_CHECK_ARG(ld_h >= d && ld_out >= d, CB_E_INVALID, "cb_spmm_csr_f32: leading dimension smaller than d");
+  CB_CHECK_ARG(hub_T > 0 && n_hubs >= 0 && n_chunks >= 0, CB_E_INVALID, "cb_spmm_csr_f32: bad hub plan");
+  CB_CHECK_ARG(n_hubs == 0 || (hub_rows && hub_chunk_ptr && ws && ws_bytes >= cb_spmm_workspace_bytes(n_chunks, d)),
+               CB_E_WORKSPACE, "cb_spmm_csr_f32: hub plan given but workspace missing/too small (%zu < %zu)", ws_bytes,
+               cb_spmm_workspace_bytes(n_chunks, d));
+  Epilogue ep{row_scale, bias, relu};
+  hipStream_t st = (hipStream_t)stream;
+  const bool al16 = ((uintptr_t)h % 16 == 0) && ((uintptr_t)out % 16 == 0) && (ld_h % 4 == 0) && (ld_out % 4 == 0) && (d % 4 == 0);
+  const bool al8 = ((uintptr_t)h % 8 == 0) && ((uintptr_t)out % 8 == 0) && (ld_h % 2 == 0) && (ld_out % 2 == 0) && (d % 2 == 0);
+  float* partial = (float*)ws;
+  if (al16 && d >= 256)
+    return launch_spmm<4>(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st);
+  if (al8 && d >= 128)
+    return launch_spmm<2>(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st);
+  return launch_spmm<1>(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st);
+}

@@ -1,0 +1,148 @@
+"""Device-resident graph for the aggregation — the object TricksComb caches in place of the
+reference's `dgl.graph((src_list, dst_list))` (GNN_model/GCN.py:92-95).
+
+Holds both CSR orientations (int32), the two degree-norm vectors (GCN.py:206-208,243-245)
+and the hub plan, all built once on the GPU through the C ABI (include/coldbrew_hip.h).
+The DGL-like query surface that GCNConv.forward touches is kept: in_degrees(),
+out_degrees(), number_of_edges(), number_of_nodes().
+"""
+import torch
+
+from . import _lib
+
+HUB_THRESHOLD = 256
+
+
+class ZeroInDegreeError(RuntimeError):
+    """Stands where the reference raises dgl.base.DGLError (GCN.py:187-197)."""
+
+
+DGLError = ZeroInDegreeError
+
+
+class _Plan:
+    __slots__ = ('n_hubs', 'n_chunks', 'hub_rows', 'hub_chunk_ptr')
+
+
+class CSRGraph:
+    def __init__(self, edge_index, num_nodes=None, hub_threshold=HUB_THRESHOLD):
+        lib = _lib.load()
+        _lib.require_device(edge_index)
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise ValueError(f'edge_index must be [2, E], got {tuple(edge_index.shape)}')
+        ei = edge_index.to(torch.int64).contiguous()      # may arrive as a transposed view (utils.py:745)
+        dev = ei.device
+        E = ei.shape[1]
+        if num_nodes is None:                               # DGL infers max id + 1 (GCN.py:94)
+            num_nodes = int(ei.max().item()) + 1 if E else 0
+        N = int(num_nodes)
+        self.N, self.E, self.device = N, E, dev
+        self.hub_threshold = int(hub_threshold)
+        self.rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        self.col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        self.rowptr_t = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        self.col_t = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        flags = torch.empty(4, dtype=torch.int32, device=dev)
+        ws_bytes = lib.cb_csr_workspace_bytes(E, N)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.cb_csr_from_coo_i64(_lib.ptr(ei[0]), _lib.ptr(ei[1]), E, N, _lib.ptr(self.rowptr),
+                                               _lib.ptr(self.col), _lib.ptr(self.rowptr_t), _lib.ptr(self.col_t),
+                                               _lib.ptr(flags), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
+                       'cb_csr_from_coo_i64')
+            self.norm_out = torch.empty(N, dtype=torch.float32, device=dev)   # a = clamp(out_deg,1)^-1/2
+            self.norm_in = torch.empty(N, dtype=torch.float32, device=dev)    # b = clamp(in_deg,1)^-1/2
+            _lib.check(lib.cb_deg_norm_f32(_lib.ptr(self.rowptr_t), N, _lib.ptr(self.norm_out), _lib.stream_ptr()),
+                       'cb_deg_norm_f32')
+            _lib.check(lib.cb_deg_norm_f32(_lib.ptr(self.rowptr), N, _lib.ptr(self.norm_in), _lib.stream_ptr()),
+                       'cb_deg_norm_f32')
+            f = flags.tolist()                               # the one host sync of the graph build
+        del ws
+        self.n_zero_in_degree, n_bad, sym, self.max_in_degree = f[0], f[1], f[2], f[3]
+        if n_bad:
+            raise ValueError(f'edge_index has {n_bad} edges with an endpoint outside [0, {N})')
+        self.symmetric = bool(sym)
+        if self.symmetric:                                   # A == A^T: one CSR serves forward and backward
+            self.rowptr_t, self.col_t = self.rowptr, self.col
+        self._plan = self._make_plan(self.rowptr)
+        self._plan_t = self._plan if self.symmetric else self._make_plan(self.rowptr_t)
+        self._ws = None
+
+    # -- DGL-like surface (GCN.py:188,200,206,243) --------------------------------------
+    def number_of_nodes(self):
+        return self.N
+
+    def number_of_edges(self):
+        return self.E
+
+    def in_degrees(self):
+        return (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+
+    def out_degrees(self):
+        return (self.rowptr_t[1:] - self.rowptr_t[:-1]).to(torch.int64)
+
+    def check_zero_in_degree(self):
+        """GCN.py:187-197 — evaluated once at build time (the graph is immutable and cached)."""
+        if self.n_zero_in_degree:
+            raise ZeroInDegreeError('There are 0-in-degree nodes in the graph, output for those nodes will be invalid. '
+                                    'Adding self-loop on the input graph will resolve the issue.')
+
+    # -- plan -------------------------------------------------------------------------
+    def _make_plan(self, rowptr):
+        lib = _lib.load()
+        p = _Plan()
+        counts = torch.empty(2, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(lib.cb_spmm_hub_count(_lib.ptr(rowptr), self.N, self.hub_threshold, _lib.ptr(counts),
+                                             _lib.stream_ptr()), 'cb_spmm_hub_count')
+            p.n_hubs, p.n_chunks = counts.tolist()
+            p.hub_rows = torch.empty(max(p.n_hubs, 1), dtype=torch.int32, device=self.device)
+            p.hub_chunk_ptr = torch.empty(p.n_hubs + 1, dtype=torch.int32, device=self.device)
+            cursor = torch.empty(1, dtype=torch.int32, device=self.device)
+            _lib.check(lib.cb_spmm_hub_fill(_lib.ptr(rowptr), self.N, self.hub_threshold, p.n_hubs, _lib.ptr(p.hub_rows),
+                                            _lib.ptr(p.hub_chunk_ptr), _lib.ptr(cursor), _lib.stream_ptr()),
+                       'cb_spmm_hub_fill')
+        return p
+
+    def _workspace(self, nbytes):
+        if nbytes == 0:
+            return None
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # -- the aggregation ----------------------------------------------------------------
+    def spmm(self, h, transpose=False, row_scale=None, bias=None, relu=False, out=None):
+        """out[v] = act(row_scale[v] * sum_{u in row v} h[u] + bias); by-dst CSR unless transpose."""
+        lib = _lib.load()
+        _lib.require_device(h, row_scale, bias, out)
+        if h.dtype != torch.float32:
+            raise TypeError(f'aggregation expects float32 features, got {h.dtype}')
+        if h.dim() != 2 or h.shape[0] != self.N:
+            raise ValueError(f'feature matrix must be [{self.N}, d], got {tuple(h.shape)}')
+        if h.stride(1) != 1 and h.shape[1] > 1:
+            h = h.contiguous()
+        d = h.shape[1]
+        if out is None:
+            out = torch.empty((self.N, d), dtype=torch.float32, device=h.device)
+        rowptr, col, plan = (self.rowptr_t, self.col_t, self._plan_t) if transpose else (self.rowptr, self.col, self._plan)
+        ws_bytes = lib.cb_spmm_workspace_bytes(plan.n_chunks, d)
+        ws = self._workspace(ws_bytes)
+        ld_h = h.stride(0) if h.shape[0] > 1 else d
+        ld_o = out.stride(0) if out.shape[0] > 1 else d
+        with torch.cuda.device(h.device):
+            _lib.check(lib.cb_spmm_csr_f32(_lib.ptr(rowptr), _lib.ptr(col), self.N, self.E, _lib.ptr(h), ld_h, d,
+                                           _lib.ptr(row_scale), _lib.ptr(bias), int(bool(relu)), _lib.ptr(out), ld_o,
+                                           self.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows),
+                                           _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
+                       'cb_spmm_csr_f32')
+        return out
+
+    def algorithmic_bytes(self, d, elem=4, row_scale=True, bias=True):
+        """E*(d*s+4) + N*(d*s+4) [+4N row scale] [+d*s bias]."""
+        b = self.E * (d * elem + 4) + self.N * (d * elem + 4)
+        if row_scale:
+            b += 4 * self.N
+        if bias:
+            b += d * elem
+        return b

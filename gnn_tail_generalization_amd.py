@@ -1,0 +1,13 @@
+"""Import shim: the package directory is named `gnn-tail-generalization_amd` (not a valid
+Python identifier), so this module loads it under the importable name
+`gnn_tail_generalization_amd` and replaces itself in sys.modules."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'gnn-tail-generalization_amd')
+_spec = importlib.util.spec_from_file_location(__name__, os.path.join(_dir, '__init__.py'),
+                                               submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)

@@ -1,0 +1,128 @@
+"""GPU parity (through the C ABI): edge_index -> CSR bit-exact vs the oracle, degree norms, and
+the sum-aggregation kernel vs the oracle on the same seeded inputs.  fp32 tolerance 1e-5 rel
+(north_star: logits within 1e-4)."""
+import numpy as np
+import pytest
+import torch
+
+import coldbrew_oracle as orc
+from conftest import golden_cases, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _graph(ei, n=None, T=256):
+    from gnn_tail_generalization_amd.graph import CSRGraph
+    return CSRGraph(ei.to(DEV), n, hub_threshold=T)
+
+
+GRAPH_CASES = ['case_graph_asym_multi', 'case_graph_example', 'case_graph_powerlaw_d7_d64', 'case_nr_se000_L2',
+               'case_r_initialbn_se111_L3_powerlaw', 'case_graph_zero_in_degree']
+
+
+@pytest.mark.parametrize('name', GRAPH_CASES)
+def test_csr_bit_exact(name):
+    g = load_golden(name)
+    n = g['cfg']['N_nodes']
+    csr = orc.build_csr(g['edge_index'], n)
+    G = _graph(g['edge_index'], n)
+    assert G.N == csr.N and G.E == csr.E
+    assert np.array_equal(G.rowptr.cpu().numpy().astype(np.int64), csr.rowptr)
+    assert np.array_equal(G.col.cpu().numpy()[:csr.E], csr.col)
+    assert np.array_equal(G.rowptr_t.cpu().numpy().astype(np.int64), csr.rowptr_t)
+    assert np.array_equal(G.col_t.cpu().numpy()[:csr.E], csr.col_t)
+    assert G.n_zero_in_degree == int((csr.in_deg == 0).sum())
+    assert G.max_in_degree == int(csr.in_deg.max())
+    sym = np.array_equal(csr.rowptr, csr.rowptr_t) and np.array_equal(csr.col, csr.col_t)
+    assert G.symmetric == sym
+    a, b = orc.degree_norms(csr)
+    np.testing.assert_allclose(G.norm_out.cpu().numpy(), a.numpy(), rtol=1.2e-7)
+    np.testing.assert_allclose(G.norm_in.cpu().numpy(), b.numpy(), rtol=1.2e-7)
+    assert torch.equal(G.in_degrees().cpu(), torch.from_numpy(csr.in_deg))
+    assert torch.equal(G.out_degrees().cpu(), torch.from_numpy(csr.out_deg))
+
+
+def test_edge_order_invariance_and_noncontiguous_view():
+    g = load_golden('case_graph_asym_multi')
+    ei = g['edge_index']
+    G1 = _graph(ei)
+    perm = torch.randperm(ei.shape[1], generator=torch.Generator().manual_seed(0))
+    G2 = _graph(ei[:, perm].t().contiguous().t())   # permuted + transposed (non-contiguous) view, cf. utils.py:745
+    assert torch.equal(G1.rowptr, G2.rowptr) and torch.equal(G1.col, G2.col)
+    assert torch.equal(G1.rowptr_t, G2.rowptr_t) and torch.equal(G1.col_t, G2.col_t)
+
+
+def test_out_of_range_and_empty():
+    from gnn_tail_generalization_amd.graph import CSRGraph
+    with pytest.raises(ValueError):
+        CSRGraph(torch.tensor([[0, 5], [1, 2]], device=DEV), 4)
+    G = CSRGraph(torch.zeros((2, 0), dtype=torch.int64, device=DEV), 5)
+    assert G.E == 0 and G.n_zero_in_degree == 5 and G.rowptr.tolist() == [0] * 6
+    out = G.spmm(torch.randn(5, 8, device=DEV), bias=torch.ones(8, device=DEV))
+    assert torch.equal(out.cpu(), torch.ones(5, 8))
+
+
+def test_zero_in_degree_raises():
+    from gnn_tail_generalization_amd.graph import ZeroInDegreeError
+    g = load_golden('case_graph_zero_in_degree')
+    G = _graph(g['edge_index'], g['cfg']['N_nodes'])
+    with pytest.raises(ZeroInDegreeError):
+        G.check_zero_in_degree()
+
+
+@pytest.mark.parametrize('name', ['case_graph_asym_multi', 'case_graph_powerlaw_d7_d64', 'case_graph_example'])
+@pytest.mark.parametrize('d', [1, 3, 7, 40, 64, 100, 128, 130, 256, 260, 512])
+@pytest.mark.parametrize('T', [256, 4])
+def test_spmm_vs_oracle(name, d, T):
+    g = load_golden(name)
+    n = g['cfg']['N_nodes']
+    csr = orc.build_csr(g['edge_index'], n)
+    G = _graph(g['edge_index'], n, T=T)
+    gen = torch.Generator().manual_seed(d)
+    h = torch.randn(n, d, generator=gen)
+    bias = torch.randn(d, generator=gen)
+    a, b = orc.degree_norms(csr)
+    ref = orc.aggregate_sum_dense_f64(csr, h)
+    # plain sum, forward orientation
+    out = G.spmm(h.to(DEV))
+    torch.testing.assert_close(out.cpu().double(), ref, atol=1e-5, rtol=1e-5)
+    # fused epilogue: * norm_in + bias, relu
+    out = G.spmm(h.to(DEV), row_scale=G.norm_in, bias=bias.to(DEV), relu=True)
+    ref2 = torch.relu(ref * b.double().unsqueeze(1) + bias.double())
+    torch.testing.assert_close(out.cpu().double(), ref2, atol=1e-5, rtol=1e-5)
+    # reverse orientation (the backward of the aggregation): A.h
+    A = np.zeros((n, n))
+    np.add.at(A, (csr.src, csr.dst), 1.0)
+    out_t = G.spmm(h.to(DEV), transpose=True)
+    torch.testing.assert_close(out_t.cpu().double(), torch.from_numpy(A @ h.double().numpy()), atol=1e-5, rtol=1e-5)
+
+
+def test_spmm_strided_rows_and_determinism():
+    g = load_golden('case_graph_powerlaw_d7_d64')
+    n = g['cfg']['N_nodes']
+    G = _graph(g['edge_index'], n, T=8)
+    big = torch.randn(n, 300, device=DEV)
+    h = big[:, 4:260]                     # ld = 300, 16-byte aligned start, d = 256
+    o1 = G.spmm(h)
+    o2 = G.spmm(h.contiguous())
+    assert torch.equal(o1, o2)
+    for _ in range(3):
+        assert torch.equal(G.spmm(h), o1)  # fixed reduction order: bitwise reproducible
+
+
+def test_spmm_linearity_large():
+    """Size-independent property at a scale the dense oracle cannot reach: A^T(x + 2y) = A^T x + 2 A^T y,
+    row sums of A^T.1 equal the in-degrees (checksum of checksums)."""
+    from gnn_tail_generalization_amd.data import synthetic_data
+    d = synthetic_data('S-pl1M', seed=1, device=DEV, n_override=200000)
+    G = _graph(d.edge_index, 200000)
+    x = torch.randn(200000, 256, device=DEV)
+    y = torch.randn(200000, 256, device=DEV)
+    lhs = G.spmm(x + 2 * y)
+    rhs = G.spmm(x) + 2 * G.spmm(y)
+    torch.testing.assert_close(lhs, rhs, atol=2e-3, rtol=1e-4)
+    ones = torch.ones(200000, 4, device=DEV)
+    deg = G.spmm(ones)[:, 0]
+    assert torch.equal(deg.to(torch.int64), G.in_degrees())
+    assert G._plan.n_hubs > 0

@@ -1,0 +1,48 @@
+"""GPU parity of the whole TeacherGNN path against the golden vectors of the unmodified reference:
+eval logits within 1e-4 (north_star), se_reg_all, collect_SE, train-mode loss and every gradient."""
+import pytest
+import torch
+
+from conftest import golden_cases, load_golden
+from helpers import product_model
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.mark.parametrize('name', golden_cases())
+def test_model_matches_reference_golden(name):
+    from gnn_tail_generalization_amd.graph import ZeroInDegreeError
+    g = load_golden(name)
+    args, model = product_model(g['cfg'], g['sd'], DEV)
+    x, ei = g['x'].to(DEV), g['edge_index'].to(DEV)
+    if g.get('raises') == 'zero_in_degree':
+        with pytest.raises(ZeroInDegreeError):
+            model(x, ei)
+        return
+    model.eval()
+    with torch.no_grad():
+        out = model(x, ei)
+        torch.testing.assert_close(out.cpu(), g['eval_out'], atol=1e-4, rtol=1e-4)
+        if g['se_reg_all'] is None:
+            assert model.se_reg_all is None
+        else:
+            torch.testing.assert_close(model.se_reg_all.cpu(), g['se_reg_all'], atol=1e-3, rtol=1e-5)
+        xin = model.embs if args.dim_learnable_input > 0 else (x * 0 if args.TeacherGNN.change_to_featureless else x)
+        les = model.model.model.collect_SE(xin, ei)
+        torch.testing.assert_close(les.cpu(), g['les'], atol=1e-4, rtol=1e-4)
+    model.train()
+    mask, y = g['train_mask'].to(DEV), g['y'].to(DEV)
+    res = model.get_3_embs(x, ei, mask)
+    loss = torch.nn.functional.nll_loss(torch.nn.functional.log_softmax(res.emb4classi, 1), y[mask])
+    if model.se_reg_all is not None:
+        loss = loss + args.se_reg * model.se_reg_all
+    model.zero_grad()
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), g['train_loss'], atol=1e-4, rtol=1e-5)
+    got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == set(g['grads'])
+    for k, ref in g['grads'].items():
+        torch.testing.assert_close(got[k].cpu(), ref, atol=2e-5, rtol=2e-4, msg=lambda m, k=k: f'{k}: {m}')
+    for k, v in g['bn_after'].items():
+        torch.testing.assert_close(model.state_dict()[k].cpu(), v, atol=1e-5, rtol=1e-5)
