@@ -4,7 +4,9 @@ reference's base_options.py (get_arguments :9-171, reset_dataset_dependent_param
 
 Documented deviations:
   * `--exp_mode` defaults to 'coldbrew' (the reference hard-codes 'I2_GTL', :10, which routes
-    to the out-of-scope link-prediction trainer and makes the default lr 0.001);
+    to the out-of-scope link-prediction trainer).  The default `--lr` stays 0.001: the reference
+    derives it from that hard-coded mode (:11-15,19), so 0.001 is what its coldbrew trainer
+    actually runs with when `--exp_mode=coldbrew` is passed;
   * the GPU picker never shells out to nvidia-smi (reference bestGPU :332-350): without
     `--manual_assign_GPU` the device is LOCAL_RANK (one process per GPU) or 0;
   * `--dataset` additionally accepts 'ogbn-products' and the synthetic stand-ins of
@@ -59,7 +61,7 @@ def str2bool(v):
 
 def build_parser():
     _exp_mode = 'coldbrew'
-    _lr = 0.005 if _exp_mode == 'coldbrew' else 0.001
+    _lr = 0.001   # what the reference computes (its _exp_mode is hard-coded to I2_GTL, base_options.py:10-15)
     p = argparse.ArgumentParser(description='Tail and cold start generalization (MI355X TeacherGNN path)')
     a = p.add_argument
     a('--exp_mode', type=str, default=_exp_mode)

@@ -1,0 +1,191 @@
+"""Training harness of the TeacherGNN path — drop-in for the TeacherGNN part of the reference's
+trainer_node_classification.py (trainer.__init__ :252-301, train_teacherGNN :303-369,
+run_trainSet :382-432, run_testSet :453-495, evaluate :672-681, cal_acc_rounded100 :683-687).
+
+Same class/method names, same per-epoch record layout and return shapes; the forward/backward
+runs on the HIP path.  The student / label-propagation modes (SEMLP, StudentBaseMLP, GraphMLP,
+LP) are outside this path and raise NotImplementedError.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import optim as cb_optim
+from .data import load_data
+from .GNN_model.GNN_normalizations import TeacherGNN
+from .utils import (getMLP, join, load_model, save_graph_analyze, save_model, set_arch_configs, toitem)
+
+
+def wzRec(datas, ttl='', want_save_npy=False, npy_dir='', save_history_fig=True):
+    """Record keeper (utils.py:1005-1051): the .npy record is written to wIns/Recs/<npy_dir>/;
+    the matplotlib history figures of the reference are not produced here."""
+    if type(datas) is torch.Tensor:
+        datas = datas.detach().cpu().data.numpy()
+    fname = 'data not saved'
+    if want_save_npy:
+        rec_dir = join('wIns/Recs', npy_dir)
+        os.makedirs(rec_dir, exist_ok=True)
+        fname = f'{rec_dir}/{ttl or "some_arr"}.npy'
+        np.save(fname, datas)
+    return 'fig not saved', fname
+
+
+class trainer:
+    """Loads data in __init__, trains in main() — as the reference's trainer does."""
+
+    def main(self):
+        if self.args.do_deg_analyze:
+            save_graph_analyze(self.args.N_nodes, self.data, self.args.use_special_split)
+        if self.args.train_which in ['TeacherGNN']:
+            return self.train_teacherGNN()
+        raise NotImplementedError(f'--train_which={self.args.train_which}: only the TeacherGNN path is built '
+                                  '(student / label-propagation trainers are out of scope, SURVEY.md §8f)')
+
+    def __init__(self, args, which_run):
+        self.bag = {}
+        self.is_large_dataset = False
+        self.which_run = which_run
+        self.args = args
+        self.dataset = args.dataset
+        if not (args.cuda and torch.cuda.is_available()):
+            raise RuntimeError('the TeacherGNN HIP path needs an MI355X device (torch.cuda.is_available() is False); '
+                               'there is no CPU fallback')
+        self.device = torch.device(f'cuda:{args.cuda_num}')
+        args.device = self.device
+        self.data = load_data(self.dataset, self.which_run, self)
+        if self.dataset in ('ogbn-arxiv', 'ogbn-products', 'S-arxiv', 'S-products', 'S-pl10M', 'S-pl1M') \
+                and args.use_special_split:
+            # trainer_node_classification.py:267-271: the ogbn branch only defines train/test masks without
+            # the special split; with it the run would fail on a missing train_mask.
+            raise ValueError(f'{self.dataset} needs --use_special_split=0 (as in the reference)')
+        self.split_idx = {'train': self.data.train_mask, 'valid': getattr(self.data, 'val_mask', None),
+                          'test': self.data.test_mask}
+        self.data.train_idx = torch.where(self.data.train_mask)[0]
+        self.loss_fn = F.nll_loss
+        self.type_model, self.type_trick = args.type_model, args.type_trick
+        self.epochs, self.num_layers, self.dim_hidden = args.epochs, args.num_layers, args.dim_hidden
+        self.weight_decay = args.weight_decay
+        self.records_path, self.records_desc, self.records_file = args.records_path, args.records_desc, args.records_file
+        self.data.x = self.data.x.float()
+        self.modeldir = f'saved_models/{args.task}/{args.dataset}'
+        self.resdir = f'{self.args.task}/{self.args.dataset}'
+        os.makedirs(self.modeldir, exist_ok=True)
+        self.optfun = cb_optim.resolve(args.optfun)
+        set_arch_configs(args)
+        self.args.data = self.data
+
+    def load_teacherGNN(self, keyw=''):
+        self.proj2class = getMLP(self.args.TeacherGNN.neurons_proj2class).to(self.device) if self.args.has_proj2class else None
+        self.teacherGNN = TeacherGNN(self.args, self.proj2class).to(self.device)
+        if 'best' in keyw:
+            load_model(self.teacherGNN, join(self.modeldir, 'best-teacherGNN'))
+        else:
+            load_model(self.teacherGNN, join(self.modeldir, 'teacherGNN'))
+
+    def train_teacherGNN(self):
+        self.proj2class = getMLP(self.args.TeacherGNN.neurons_proj2class).to(self.device) if self.args.has_proj2class else None
+        self.teacherGNN = TeacherGNN(self.args, self.proj2class).to(self.device)
+        self.optimizer = self.optfun(self.teacherGNN.parameters(), lr=self.args.lr, weight_decay=self.weight_decay)
+        best_train_loss, best_test_acc = 100, 0.
+        results_arr2D = []
+        for epoch in range(self.epochs):
+            self.epoch = epoch
+            acc_train, acc_val, acc_test, loss_train, loss_val, linkp_train, linkp_test = self.train_net()
+            if 'SEMLP' in self.args.train_which and acc_test > best_test_acc:
+                best_test_acc = acc_test
+                save_model(self.teacherGNN, join(self.modeldir, 'best-teacherGNN'))
+            results_arr2D.append([np.log(loss_train), acc_train * 100, acc_test * 100, linkp_train, linkp_test])
+            if self.args.want_headtail:
+                results_arr2D[-1].extend(self.bag['head_tail_iso'])
+            if epoch % 20 == 0:
+                print(f'Ep{epoch:03d}, acc @ train/test: {acc_train * 100:.1f}, {acc_test * 100:.1f} ')
+        print('train_loss: {:.4f},  test_acc:{:.4f}'.format(best_train_loss, best_test_acc))
+        save_model(self.teacherGNN, join(self.modeldir, 'teacherGNN'))
+        results_arr2D = np.array(results_arr2D).T
+        npy_dir = f'{self.resdir}/teacherGNN'
+        tag = npy_dir.replace('/', '@')
+        for row, name in enumerate(['loss_train', 'acc_train', 'acc_test', 'linkp_train', 'linkp_test']):
+            wzRec(results_arr2D[row], f'{name}@{tag}', want_save_npy=1, npy_dir=npy_dir)
+        if not self.args.want_headtail:
+            return results_arr2D[[2]]              # [1, epochs]
+        return results_arr2D[[2, -3, -2, -1]]      # [4, epochs]
+
+    def train_net(self):
+        loss_train, linkp_train, linkp_test = self.run_trainSet()
+        acc_train, acc_val, acc_test, loss_val = self.run_testSet()
+        return acc_train, acc_val, acc_test, loss_train, loss_val, linkp_train, linkp_test
+
+    def training_loss(self):
+        """Forward + loss of run_trainSet (:386-394): nll(log_softmax(out[train])) + se_reg * sum ||E||."""
+        res = self.teacherGNN.get_3_embs(self.data.x, self.data.edge_index, self.data.train_mask)
+        logits = F.log_softmax(res.emb4classi, 1)
+        loss = self.loss_fn(logits, self.data.y[self.data.train_mask]) * self.args.TeacherGNN.lossa_semantic
+        if self.teacherGNN.se_reg_all is not None:
+            loss = loss + self.args.se_reg * self.teacherGNN.se_reg_all
+        return loss
+
+    def train_step(self):
+        """One optimisation step = run_trainSet without the head/tail metrics forward; returns the
+        loss tensor (no host sync) — the unit bench.py times."""
+        self.teacherGNN.train()
+        loss = self.training_loss()
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def run_trainSet(self):
+        self.teacherGNN.train()
+        linkp_train, linkp_test = 0, 0
+        assert self.args.has_loss_component_nodewise or self.args.has_loss_component_edgewise, \
+            'setting no node-wise and no edge-wise loss for teacherGNN! at least set one of them!'
+        if self.args.has_loss_component_edgewise:
+            raise NotImplementedError('edge-wise (link-prediction) loss belongs to the I2_GTL mode (out of scope)')
+        loss = self.training_loss()
+        result = []
+        if self.args.want_headtail:
+            # a second train-mode, autograd-tracked forward purely for metrics, as in the reference (:397-413)
+            all_node_logits = self.teacherGNN.get_3_embs(self.data.x, self.data.edge_index).emb4classi
+            lrn_targ = self.data.y
+            for name in ['large_deg_idx', 'small_deg_idx'] + (['zero_deg_idx'] if self.args.use_special_split else []):
+                batch_idx = getattr(self.data, name)
+                _, test_m = self.eval_headtail__traintest_v2(all_node_logits[batch_idx], lrn_targ[batch_idx], batch_idx,
+                                                             cal_acc_rounded100)
+                result.append(test_m)
+        self.bag['head_tail_iso'] = result
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        return loss.item(), linkp_train, linkp_test
+
+    def eval_headtail__traintest_v2(self, emb2, lrn_targ, subsets, metricfun):
+        actual_train_mask = self.data.train_mask[subsets]
+        on_train = torch.where(actual_train_mask)[0]
+        on_test = torch.where(~actual_train_mask)[0]
+        return metricfun(emb2[on_train], lrn_targ[on_train]), metricfun(emb2[on_test], lrn_targ[on_test])
+
+    def run_testSet(self):
+        self.teacherGNN.eval()
+        with torch.no_grad():
+            raw_logits = self.teacherGNN.get_3_embs(self.data.x, self.data.edge_index).emb4classi
+        logits = F.log_softmax(raw_logits, 1)
+        acc_train = evaluate(logits, self.data.y, self.data.train_mask)
+        acc_test = evaluate(logits, self.data.y, self.data.test_mask)
+        return acc_train, np.nan, acc_test, np.nan
+
+
+def evaluate(output, labels, mask):
+    output = output.to(labels.device)
+    indices = torch.max(output, dim=1)[1]
+    if mask is None:
+        return torch.sum(indices == labels).item() / len(indices)
+    mask = mask.to(labels.device)
+    return torch.sum(indices[mask] == labels[mask]).item() * 1.0 / mask.sum().item()
+
+
+def cal_acc_rounded100(output, labels):
+    indices = torch.max(output, dim=1)[1]
+    correct = torch.sum(indices == labels) / len(labels)
+    return toitem(correct * 100)

@@ -280,6 +280,36 @@ def options_fixture(ns):
     return out
 
 
+def utils_fixture(ns):
+    """Caller-side helpers (utils.py): get_partial_sorted_idx, ensure_symmetric, save_graph_analyze +
+    craft_isolation_v2 on a small power-law graph — the edge_index the path consumes."""
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    arr = torch.randint(0, 40, (500,), generator=g).numpy()
+    out['degs'] = torch.from_numpy(arr)
+    for mode in ['top50', 'top25', 'top12', 'top6', 'top3', 'bottom50', 'bottom25', 'bottom12', 'bottom6', 'bottom3']:
+        out['idx_' + mode] = torch.from_numpy(ns.utils.get_partial_sorted_idx(arr, mode))
+    ei = torch.randint(0, 60, (2, 300), generator=g)
+    out['asym_edge_index'] = ei
+    out['ensure_symmetric'] = ns.utils.ensure_symmetric(ei)
+    Data = sys.modules['torch_geometric.data.data'].Data
+    for special in (0, 1):
+        ei2, n = make_graph('powerlaw', 150, 9)
+        data = Data(x=torch.zeros(n, 3), edge_index=ei2.clone())
+        with ref_import.in_scratch():
+            ns.utils.save_graph_analyze(n, data, special)
+        pre = f'sga{special}_'
+        out[pre + 'edge_index_in'] = ei2
+        out[pre + 'edge_index_out'] = data.edge_index.clone()
+        for k in ['zero_deg_idx', 'small_deg_idx', 'large_deg_idx']:
+            if hasattr(data, k):
+                out[pre + k] = torch.as_tensor(getattr(data, k))
+        for k in ['zero_deg_mask', 'small_deg_mask', 'large_deg_mask']:
+            if hasattr(data, k):
+                out[pre + k] = getattr(data, k).clone()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='')
@@ -287,7 +317,7 @@ def main():
     ns = ref_import.load_reference()
     torch.set_num_threads(1)
     for c in CASES:
-        if a.only and a.only not in c['name']:
+        if a.only and (a.only in ('utils', 'options', 'trainer') or a.only not in c['name']):
             continue
         out = run_case(ns, c)
         torch.save(out, os.path.join(HERE, f'case_{c["name"]}.pt'))
@@ -299,6 +329,9 @@ def main():
             out = run_trainer_case(ns, name, wh, se, ds)
             torch.save(out, os.path.join(HERE, f'{name}.pt'))
             print('wrote', name, out['trajectory'][-1].tolist())
+    if not a.only or 'utils' in a.only:
+        torch.save(utils_fixture(ns), os.path.join(HERE, 'utils_fixture.pt'))
+        print('wrote utils_fixture.pt')
     if not a.only or 'options' in a.only:
         import json
         with open(os.path.join(HERE, 'options.json'), 'w') as f:

@@ -1,0 +1,170 @@
+"""CPU tests of the host logic and the boundary: option pipeline vs the reference's namespace,
+state_dict contract, caller-side utils vs reference fixtures, C-ABI symbol export, loud failure
+without a GPU.  No compute call is made through the HIP library here."""
+import contextlib
+import ctypes
+import io
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, golden_cases, load_golden
+from helpers import product_args
+
+
+def _opts(argv):
+    from gnn_tail_generalization_amd.base_options import BaseOptions
+    from gnn_tail_generalization_amd.utils import set_arch_configs
+    with contextlib.redirect_stdout(io.StringIO()):
+        args = BaseOptions().get_arguments(argv)
+        set_arch_configs(args)
+    return args
+
+
+def test_options_match_reference_namespace():
+    """tests/golden/options.json = the reference's own get_arguments()+set_arch_configs() for README lines."""
+    ref = json.load(open(os.path.join(GOLDEN, 'options.json')))
+    skip = {'argv', 'exp_mode', 'cuda', 'records_file'}
+    for name, want in ref.items():
+        args = _opts(['--manual_assign_GPU=0'] + want['argv'])
+        got = vars(args)
+        for k, v in want.items():
+            if k in skip or '.' in k:
+                continue
+            assert k in got, f'{name}: option {k} missing'
+            assert got[k] == v, f'{name}: {k}: {got[k]!r} != reference {v!r}'
+        assert list(args.TeacherGNN.whetherHasSE) == want['TeacherGNN.whetherHasSE']
+        assert list(args.TeacherGNN.neurons_proj2class) == want['TeacherGNN.neurons_proj2class']
+
+
+def test_best_config_concatenated_names():
+    assert _opts(['--dataset=Cora']).type_trick == 'NoResNodeNorm'
+    assert _opts(['--dataset=Pubmed']).type_trick == 'InitialBatchNorm'
+    assert _opts(['--dataset=ogbn-arxiv']).type_trick == 'InitialBatchNorm'
+    assert _opts(['--dataset=S-pl10M']).type_trick == 'InitialBatchNorm'
+    a = _opts(['--dataset=Cora', '--force_set_to_best_config=0'])
+    assert a.type_trick == 'Initial+BatchNorm' and a.lr == 0.001 and a.exp_mode == 'coldbrew'
+    with pytest.raises(SystemExit):
+        _opts(['--dataset=Cora', '--whetherHasSE=010'])
+
+
+@pytest.mark.parametrize('name', golden_cases())
+def test_state_dict_contract(name):
+    """Parameter names, shapes and order equal the reference's (checkpoint interchange)."""
+    from gnn_tail_generalization_amd.GNN_model import TeacherGNN
+    g = load_golden(name)
+    args = product_args(g['cfg'])
+    model = TeacherGNN(args)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(g['sd'].keys())
+    for k, v in g['sd'].items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+    model.load_state_dict(g['sd'], strict=True)
+
+
+def test_same_seed_same_init_as_reference():
+    """Construction order / initialisers match: with the same torch seed the fresh parameters are
+    bit-identical to the reference's (needs /root/reference; skipped on the GPU box)."""
+    import ref_import
+    if not ref_import.reference_available():
+        pytest.skip('reference tree not present')
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    import make_golden
+    from gnn_tail_generalization_amd.GNN_model import TeacherGNN
+    ns = ref_import.load_reference()
+    for c in make_golden.CASES:
+        if c['name'] not in ('nr_se111_L3', 'r_initialbn_se111_L2', 'r_dense_concat_L3', 'norm_groupnorm',
+                             'r_jumping_attention_L2', 'teacher_learnable_input'):
+            continue
+        with contextlib.redirect_stdout(io.StringIO()):
+            rargs, _, _, _, _, _ = make_golden.build(ns, c)
+            torch.manual_seed(123)
+            ref_model = ns.GNN_normalizations.TeacherGNN(rargs)
+        args = product_args(make_golden.cfg_of(rargs, c))
+        torch.manual_seed(123)
+        mine = TeacherGNN(args)
+        ref_sd = ref_model.state_dict()
+        for k, v in mine.state_dict().items():
+            assert torch.equal(v, ref_sd[k]), f'{c["name"]}: {k}'
+
+
+def test_utils_match_reference_fixture():
+    from gnn_tail_generalization_amd import utils
+    from gnn_tail_generalization_amd.data import Data
+    fx = torch.load(os.path.join(GOLDEN, 'utils_fixture.pt'), weights_only=False)
+    arr = fx['degs'].numpy()
+    for k, v in fx.items():
+        if k.startswith('idx_'):
+            assert np.array_equal(utils.get_partial_sorted_idx(arr, k[4:]), v.numpy()), k
+    assert torch.equal(utils.ensure_symmetric(fx['asym_edge_index']), fx['ensure_symmetric'])
+    for special in (0, 1):
+        pre = f'sga{special}_'
+        ei = fx[pre + 'edge_index_in']
+        data = Data(x=torch.zeros(150, 3), edge_index=ei.clone())
+        utils.save_graph_analyze(150, data, special, verbose=False)
+        assert torch.equal(data.edge_index, fx[pre + 'edge_index_out'])
+        for k in ['zero_deg_idx', 'small_deg_idx', 'large_deg_idx', 'zero_deg_mask', 'small_deg_mask', 'large_deg_mask']:
+            if pre + k in fx:
+                assert torch.equal(torch.as_tensor(getattr(data, k)), fx[pre + k]), k
+
+
+def test_synthetic_data_postconditions():
+    """load_data post-conditions (trainer_node_classification.py:655-662): symmetric, coalesced,
+    self-loops appended last; ogbn family: to_undirected, no self-loops, every degree >= 1."""
+    from gnn_tail_generalization_amd.data import synthetic_data
+    d = synthetic_data('S-tiny', seed=3)
+    n = d.x.shape[0]
+    ei = d.edge_index
+    body, loops = ei[:, :-n], ei[:, -n:]
+    assert torch.equal(loops[0], torch.arange(n)) and torch.equal(loops[1], torch.arange(n))
+    key = body[0] * n + body[1]
+    assert torch.equal(key, torch.unique(key)) and (body[0] != body[1]).all()
+    assert torch.equal(torch.sort(body[1] * n + body[0])[0], key)
+    assert torch.equal(synthetic_data('S-tiny', seed=3).edge_index, ei)          # seeded
+    d2 = synthetic_data('S-arxiv', seed=0, n_override=3000)
+    e2 = d2.edge_index
+    assert (e2[0] != e2[1]).all() and torch.bincount(e2[1], minlength=3000).min() >= 1
+    assert d2.x.shape == (3000, 128) and int(d2.y.max()) < 40
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """Every function declared in include/coldbrew_hip.h is exported by the in-tree .so and bound in _lib."""
+    from gnn_tail_generalization_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'coldbrew_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(cb_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no declarations parsed'
+    assert os.path.isfile(_lib.LIB_PATH), 'build the extension first: python __graft_entry__.py'
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f'{name} declared in the header but not exported'
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.load().cb_version() >= 1
+
+
+def test_product_fails_loudly_without_gpu():
+    """No CPU fallback: CPU tensors are rejected by the product path."""
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from gnn_tail_generalization_amd import _lib
+    from gnn_tail_generalization_amd.GNN_model import TeacherGNN
+    g = load_golden('case_nr_se000_L2')
+    model = TeacherGNN(product_args(g['cfg']))
+    with pytest.raises(_lib.HipExtensionError):
+        model(g['x'], g['edge_index'])
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'gnn-tail-generalization_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'coldbrew_oracle' not in src and 'ref_import' not in src and 'oracle' not in src.replace('oracle/', ''), f
+    for f in ('main.py',):
+        assert 'oracle' not in open(os.path.join(ROOT, f)).read()
