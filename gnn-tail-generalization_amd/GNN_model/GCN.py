@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn import init
 
-from .. import ops
+from .. import gemm, ops
 from ..graph import CSRGraph, DGLError
 from .drop_tricks import DropoutTrick
 from .norm_tricks import AcontainsB, appendNormLayer, run_norm_if_any
@@ -90,12 +90,12 @@ class TricksComb(nn.Module):
         x_list, le_collection, se_reg_all = [], [], None
         new_adjs = self.graph_dropout(edge_index)      # computed and discarded, as in the reference (GCN.py:101,111)
         if self.has_residual_MLP:
-            x = F.dropout(x, p=self.embedding_dropout, training=self.training)
-            x = F.relu(self.layers_MLP[0](x))
+            x = ops.dropout(x, self.embedding_dropout, self.training)
+            x = gemm.linear(x, self.layers_MLP[0].weight, self.layers_MLP[0].bias, relu=True)   # Linear + ReLU, GCN.py:105-106
             x_list.append(x)
         norms_run = self.args.type_trick in ('BatchNorm', 'PairNorm', 'NodeNorm', 'MeanNorm', 'GroupNorm', 'CombNorm')
         for i in range(self.num_layers):
-            x = F.dropout(x, p=self.dropout, training=self.training)
+            x = ops.dropout(x, self.dropout, self.training)
             _unused_edge_index, _ = new_adjs[i]
             act = self.has_residual_MLP or i < self.num_layers - 1
             # the ReLU of GCN.py:127-128 rides in the aggregation epilogue when nothing sits in between
@@ -113,12 +113,12 @@ class TricksComb(nn.Module):
             x_list.append(x)
             if AcontainsB(self.type_trick, ['Initial', 'Dense', 'Residual']):
                 x = self.layers_res[i](x_list)
-        x = F.dropout(x, p=self.args.dropout, training=self.training)   # on the logits in non-residual mode (GCN.py:133)
+        x = ops.dropout(x, self.args.dropout, self.training)   # on the logits in non-residual mode (GCN.py:133)
         if self.has_residual_MLP:
             if AcontainsB(self.type_trick, ['Jumping']):
                 x = self.layers_res[0](x_list)
             else:
-                x = self.layers_MLP[-1](x)
+                x = gemm.linear(x, self.layers_MLP[-1].weight, self.layers_MLP[-1].bias)
         if want_les:
             return x, se_reg_all, th.cat(le_collection, dim=-1)
         return x, se_reg_all

@@ -16,7 +16,8 @@ class _AlphaMix(nn.Module):
         assert len(Xs) >= 1
         if len(Xs) == 1:
             return Xs[-1]
-        return (1 - self.alpha) * Xs[-1] + self.alpha * Xs[self._pick]
+        from ..ops import axpby
+        return axpby(1 - self.alpha, Xs[-1], self.alpha, Xs[self._pick])
 
 
 class ResidualConnection(_AlphaMix):     # res_tricks.py:7-14: mixes with the previous layer

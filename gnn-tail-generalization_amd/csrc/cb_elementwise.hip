@@ -1,0 +1,394 @@
+// HBM-bound elementwise / reduction kernels around the GEMM/SpMM pairs of the TeacherGNN step
+// (TricksComb.forward GNN_model/GCN.py:103-138; run_trainSet trainer_node_classification.py:386-430).
+// All fp32, 16-byte vector accesses when the data allows it, grid-stride loops capped at
+// 256 CUs x 8 blocks, reductions in a fixed two-stage order (no float atomics -> bit-reproducible).
+#include "cb_common.h"
+
+namespace cb {
+
+constexpr int kBlock = 256;
+constexpr int kMaxBlocks = 256 * 8;
+
+static inline int grid_for(int64_t work_items) {
+  int64_t b = (work_items + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  return (int)(b > kMaxBlocks ? kMaxBlocks : b);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based RNG: Philox4x32-10 keyed by (seed), counter = element index / 4.  The mask of an
+// element depends only on (seed, flat index), so forward and backward regenerate it instead of
+// storing it (F.dropout of GCN.py:104,110,133 cannot be matched bit-for-bit on any device; parity
+// is defined with injected masks).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+  uint32_t c2 = 0x243F6A88u, c3 = 0x85A308D3u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ void keep4(uint64_t seed, int64_t quad, uint32_t thresh, float scale, float (&m)[4]) {
+  uint32_t r[4];
+  philox4x32_10((uint32_t)quad, (uint32_t)((uint64_t)quad >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) m[i] = (r[i] >= thresh) ? scale : 0.f;
+}
+
+// out[i] = x[i] * keep(offset + i) / (1 - p).  `offset` is the flat index of x[0] in the logical
+// (unsharded) tensor, so a row shard draws the same mask as the full tensor would.
+__global__ void __launch_bounds__(kBlock) k_dropout(const float* __restrict__ x, float* __restrict__ out, int64_t n,
+                                                    uint32_t thresh, float scale, uint64_t seed, int64_t offset, int vec_ok) {
+  const int64_t nq = (n + 3) / 4;
+  const int sub = (int)(offset & 3);
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    float m[4];
+    const int64_t gq = (offset >> 2) + q;
+    keep4(seed, gq, thresh, scale, m);
+    if (sub) {  // local quad straddles two global quads
+      float m2[4], t[4];
+      keep4(seed, gq + 1, thresh, scale, m2);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] = (k + sub < 4) ? m[(k + sub) & 3] : m2[(k + sub) & 3];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = t[k];
+    }
+    const int64_t i = q * 4;
+    if (vec_ok && i + 4 <= n) {
+      float4 v = *reinterpret_cast<const float4*>(x + i);
+      float4 o = make_float4(v.x * m[0], v.y * m[1], v.z * m[2], v.w * m[3]);
+      *reinterpret_cast<float4*>(out + i) = o;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (i + k < n) out[i + k] = x[i + k] * m[k];
+    }
+  }
+}
+
+// out = a*x + b*y   (res_tricks.py:14,23: (1-alpha)*Xs[-1] + alpha*Xs[k])
+__global__ void __launch_bounds__(kBlock) k_axpby(float a, const float* __restrict__ x, float b, const float* __restrict__ y,
+                                                  float* __restrict__ out, int64_t n, int vec_ok) {
+  const int64_t nq = (n + 3) / 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = q * 4;
+    if (vec_ok && i + 4 <= n) {
+      float4 u = *reinterpret_cast<const float4*>(x + i);
+      float4 w = *reinterpret_cast<const float4*>(y + i);
+      *reinterpret_cast<float4*>(out + i) = make_float4(a * u.x + b * w.x, a * u.y + b * w.y, a * u.z + b * w.z, a * u.w + b * w.w);
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (i + k < n) out[i + k] = a * x[i + k] + b * y[i + k];
+    }
+  }
+}
+
+// Backward of  Y = act(b * R + bias):  gm = g * (act > 0);  colsum(gm) -> dbias partials;  out = gm * row_scale.
+// Block = 256 threads laid out as (rows_per_iter = 256 / tx) x (tx column groups of 4); each thread owns 4
+// fixed columns per column pass so the column sums stay in registers; partial[blockIdx][d] is reduced by k_colsum_finish.
+__global__ void __launch_bounds__(kBlock) k_act_bwd(const float* __restrict__ g, const float* __restrict__ act,
+                                                    const float* __restrict__ row_scale, float* __restrict__ out,
+                                                    int64_t rows, int d, float* __restrict__ partial) {
+  extern __shared__ float s_red[];  // [kBlock][4]
+  const int tx = min(64, (d + 3) / 4);       // threads along columns per pass
+  const int ty = kBlock / tx;                // rows per iteration
+  const int cx = threadIdx.x % tx, ry = threadIdx.x / tx;
+  const bool live = ry < ty;
+  const int64_t rows_per_block = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r_end = min(rows, r_begin + rows_per_block);
+  const bool vec_ok = (d % 4 == 0);
+  for (int c_base = 0; c_base < d; c_base += tx * 4) {
+    const int c = c_base + cx * 4;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live && c < d) {
+      for (int64_t r = r_begin + ry; r < r_end; r += ty) {
+        const int64_t off = r * d + c;
+        const float sc = row_scale ? row_scale[r] : 1.f;
+        float gv[4], av[4];
+        if (vec_ok) {
+          float4 t = *reinterpret_cast<const float4*>(g + off);
+          gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
+          if (act) {
+            float4 u = *reinterpret_cast<const float4*>(act + off);
+            av[0] = u.x; av[1] = u.y; av[2] = u.z; av[3] = u.w;
+          }
+        } else {
+          for (int k = 0; k < 4; ++k) {
+            gv[k] = (c + k < d) ? g[off + k] : 0.f;
+            av[k] = (act && c + k < d) ? act[off + k] : 1.f;
+          }
+        }
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float gm = (!act || av[k] > 0.f) ? gv[k] : 0.f;
+          s[k] += gm;
+          o[k] = gm * sc;
+        }
+        if (out) {
+          if (vec_ok) *reinterpret_cast<float4*>(out + off) = make_float4(o[0], o[1], o[2], o[3]);
+          else
+            for (int k = 0; k < 4; ++k)
+              if (c + k < d) out[off + k] = o[k];
+        }
+      }
+    }
+    if (partial) {  // reduce over ry in a fixed order
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s_red[threadIdx.x * 4 + k] = s[k];
+      __syncthreads();
+      if (ry == 0 && c < d) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < ty; ++j)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) t[k] += s_red[(j * tx + cx) * 4 + k];
+        for (int k = 0; k < 4; ++k)
+          if (c + k < d) partial[(int64_t)blockIdx.x * d + c + k] = t[k];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void k_colsum_finish(const float* __restrict__ partial, int nparts, int d, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * d + c];
+  out[c] = s;
+}
+
+// sum of squares -> partial[block] (double accumulation across the partials in the finish kernel)
+__global__ void __launch_bounds__(kBlock) k_sumsq(const float* __restrict__ x, int64_t n, float* __restrict__ partial, int vec_ok) {
+  __shared__ float s_w[kBlock / kWave];
+  float s = 0.f;
+  const int64_t nq = (n + 3) / 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = q * 4;
+    if (vec_ok && i + 4 <= n) {
+      float4 v = *reinterpret_cast<const float4*>(x + i);
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (i + k < n) s += x[i + k] * x[i + k];
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane_id() == 0) s_w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kBlock / kWave; ++w) t += s_w[w];
+    partial[blockIdx.x] = t;
+  }
+}
+
+// out[0] = sqrt(sum partial) (Frobenius norm, th.norm(self.le) GCN.py:232); out[1] = sum
+__global__ void k_norm_finish(const float* __restrict__ partial, int nparts, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double t = 0.0;
+    for (int p = 0; p < nparts; ++p) t += (double)partial[p];
+    out[0] = (float)sqrt(t);
+    out[1] = (float)t;
+  }
+}
+
+// Fused log_softmax + nll_loss(mean over masked rows) forward AND its gradient
+// (trainer_node_classification.py:390-391).  One lane per row; C is small (<= 256).
+//   loss_partial[block] = sum_{r in block, mask[r]} (logsumexp(z_r) - z_r[y_r])
+//   grad[r, c] = mask[r] ? (softmax(z_r)[c] - [c == y_r]) * inv_count : 0
+__global__ void __launch_bounds__(kBlock) k_nll_fused(const float* __restrict__ z, int64_t ld, const int64_t* __restrict__ y,
+                                                      const uint8_t* __restrict__ mask, int64_t rows, int C, float inv_count,
+                                                      float* __restrict__ grad, float* __restrict__ loss_partial) {
+  __shared__ float s_w[kBlock / kWave];
+  float local = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+    const float* zr = z + r * ld;
+    float* gr = grad ? grad + r * (int64_t)C : nullptr;
+    if (mask && !mask[r]) {
+      if (gr)
+        for (int c = 0; c < C; ++c) gr[c] = 0.f;
+      continue;
+    }
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, zr[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(zr[c] - mx);
+    const float lse = mx + logf(se);
+    const int64_t t = y[r];
+    local += lse - zr[t];
+    if (gr) {
+      const float inv = 1.f / se;
+      for (int c = 0; c < C; ++c) gr[c] = (expf(zr[c] - mx) * inv - (c == t ? 1.f : 0.f)) * inv_count;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
+  if (lane_id() == 0) s_w[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kBlock / kWave; ++w) t += s_w[w];
+    loss_partial[blockIdx.x] = t;
+  }
+}
+
+__global__ void k_loss_finish(const float* __restrict__ partial, int nparts, float inv_count, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double t = 0.0;
+    for (int p = 0; p < nparts; ++p) t += (double)partial[p];
+    out[0] = (float)(t * (double)inv_count);
+  }
+}
+
+// torch.optim.Adam semantics (trainer_node_classification.py:310): g += wd*p; m,v EMA; bias-corrected step
+__global__ void __launch_bounds__(kBlock) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                 float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                 float wd, float bc1, float bc2_sqrt, int vec_ok) {
+  const int64_t nq = (n + 3) / 4;
+  const float step = lr / bc1;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = q * 4;
+    float pv[4], gv[4], mv[4], vv[4];
+    const bool full = vec_ok && i + 4 <= n;
+    if (full) {
+      float4 a = *reinterpret_cast<const float4*>(p + i), b = *reinterpret_cast<const float4*>(g + i);
+      float4 c = *reinterpret_cast<const float4*>(m + i), d = *reinterpret_cast<const float4*>(v + i);
+      pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w;
+      gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
+      mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w;
+      vv[0] = d.x; vv[1] = d.y; vv[2] = d.z; vv[3] = d.w;
+    } else {
+      for (int k = 0; k < 4; ++k) {
+        const bool in = i + k < n;
+        pv[k] = in ? p[i + k] : 0.f; gv[k] = in ? g[i + k] : 0.f; mv[k] = in ? m[i + k] : 0.f; vv[k] = in ? v[i + k] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gg = gv[k] + wd * pv[k];
+      mv[k] = b1 * mv[k] + (1.f - b1) * gg;
+      vv[k] = b2 * vv[k] + (1.f - b2) * gg * gg;
+      const float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
+      pv[k] = pv[k] - step * (mv[k] / denom);
+    }
+    if (full) {
+      *reinterpret_cast<float4*>(p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      *reinterpret_cast<float4*>(m + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+      *reinterpret_cast<float4*>(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (i + k < n) { p[i + k] = pv[k]; m[i + k] = mv[k]; v[i + k] = vv[k]; }
+    }
+  }
+}
+
+static inline int aligned16(const void* a) { return ((uintptr_t)a % 16) == 0; }
+
+}  // namespace cb
+
+using namespace cb;
+
+extern "C" int cb_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t seed, int64_t offset, void* stream) {
+  CB_CHECK_ARG(n >= 0 && offset >= 0 && (n == 0 || (x && out)) && p >= 0.f && p < 1.f, CB_E_INVALID,
+               "cb_dropout_f32: bad argument (p=%f)", p);
+  if (n == 0) return CB_OK;
+  const double t = (double)p * 4294967296.0;
+  const uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  const int vec_ok = aligned16(x) && aligned16(out);
+  hipLaunchKernelGGL(k_dropout, dim3(grid_for((n + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, x, out, n, thresh,
+                     1.f / (1.f - p), seed, offset, vec_ok);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
+extern "C" int cb_axpby_f32(float a, const float* x, float b, const float* y, float* out, int64_t n, void* stream) {
+  CB_CHECK_ARG(n >= 0 && (n == 0 || (x && y && out)), CB_E_INVALID, "cb_axpby_f32: bad argument");
+  if (n == 0) return CB_OK;
+  const int vec_ok = aligned16(x) && aligned16(y) && aligned16(out);
+  hipLaunchKernelGGL(k_axpby, dim3(grid_for((n + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, a, x, b, y, out, n, vec_ok);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
+extern "C" size_t cb_colsum_workspace_bytes(int64_t rows, int64_t d) {
+  if (rows <= 0 || d <= 0) return 0;
+  int64_t nb = (rows + 63) / 64;
+  if (nb > kMaxBlocks) nb = kMaxBlocks;
+  return (size_t)nb * (size_t)d * sizeof(float);
+}
+
+extern "C" int cb_act_bwd_f32(const float* g, const float* act, const float* row_scale, float* out, int64_t rows, int64_t d,
+                              float* colsum, void* ws, size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(rows >= 0 && d >= 0 && d < (1 << 20), CB_E_INVALID, "cb_act_bwd_f32: bad size");
+  if (rows == 0 || d == 0) return CB_OK;
+  CB_CHECK_ARG(g && (out || colsum), CB_E_INVALID, "cb_act_bwd_f32: null pointer");
+  CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_colsum_workspace_bytes(rows, d)), CB_E_WORKSPACE,
+               "cb_act_bwd_f32: workspace too small (%zu < %zu)", ws_bytes, cb_colsum_workspace_bytes(rows, d));
+  CB_CHECK_ARG(d % 4 != 0 || (aligned16(g) && (!act || aligned16(act)) && (!out || aligned16(out))), CB_E_INVALID,
+               "cb_act_bwd_f32: 16-byte alignment required when d %% 4 == 0");
+  int64_t nb = (rows + 63) / 64;
+  if (nb > kMaxBlocks) nb = kMaxBlocks;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_act_bwd, dim3((unsigned)nb), dim3(kBlock), kBlock * 4 * sizeof(float), st, g, act, row_scale, out, rows,
+                     (int)d, colsum ? (float*)ws : nullptr);
+  CB_LAUNCH_CHECK();
+  if (colsum) {
+    hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, (const float*)ws, (int)nb, (int)d, colsum);
+    CB_LAUNCH_CHECK();
+  }
+  return CB_OK;
+}
+
+extern "C" size_t cb_reduce_workspace_bytes(void) { return (size_t)kMaxBlocks * sizeof(float); }
+
+extern "C" int cb_frobenius_norm_f32(const float* x, int64_t n, float* out2, void* ws, size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(n >= 0 && out2 && (n == 0 || x), CB_E_INVALID, "cb_frobenius_norm_f32: bad argument");
+  CB_CHECK_ARG(ws && ws_bytes >= cb_reduce_workspace_bytes(), CB_E_WORKSPACE, "cb_frobenius_norm_f32: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = n ? grid_for((n + 3) / 4) : 0;
+  if (nb) {
+    hipLaunchKernelGGL(k_sumsq, dim3(nb), dim3(kBlock), 0, st, x, n, (float*)ws, aligned16(x));
+    CB_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_norm_finish, dim3(1), dim3(64), 0, st, (const float*)ws, nb, out2);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
+extern "C" int cb_nll_logsoftmax_f32(const float* logits, int64_t ld, const int64_t* y, const uint8_t* mask, int64_t rows,
+                                     int64_t C, int64_t count, float* loss, float* grad, void* ws, size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(rows >= 0 && C > 0 && C <= 4096 && ld >= C && loss && (rows == 0 || (logits && y)), CB_E_INVALID,
+               "cb_nll_logsoftmax_f32: bad argument");
+  CB_CHECK_ARG(ws && ws_bytes >= cb_reduce_workspace_bytes(), CB_E_WORKSPACE, "cb_nll_logsoftmax_f32: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const float inv = count > 0 ? 1.f / (float)count : 0.f;
+  const int nb = rows ? grid_for(rows) : 0;
+  if (nb) {
+    hipLaunchKernelGGL(k_nll_fused, dim3(nb), dim3(kBlock), 0, st, logits, ld, y, mask, rows, (int)C, inv, grad, (float*)ws);
+    CB_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(64), 0, st, (const float*)ws, nb, inv, loss);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
+extern "C" int cb_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                float eps, float weight_decay, int64_t step, void* stream) {
+  CB_CHECK_ARG(n >= 0 && step >= 1 && (n == 0 || (p && g && m && v)), CB_E_INVALID, "cb_adam_step_f32: bad argument");
+  if (n == 0) return CB_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const int vec_ok = aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v);
+  hipLaunchKernelGGL(k_adam, dim3(grid_for((n + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
+                     eps, weight_decay, (float)bc1, (float)sqrt(bc2), vec_ok);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}

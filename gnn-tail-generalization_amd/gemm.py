@@ -1,0 +1,115 @@
+"""Dense stages of the path on the hand-written fp32 MFMA kernels (csrc/cb_gemm.hip) with their
+autograd.  Raw entry points: mm_nn / mm_tn; autograd stages: linear_rowscale (GCNConv transform,
+GNN_model/GCN.py:213,225,231) and linear (nn.Linear + optional ReLU, GCN.py:105-106,138)."""
+import torch
+
+from . import _lib
+
+
+def _rowmajor(t):
+    """A 2-D tensor whose rows are contiguous (stride(1) == 1); copies otherwise."""
+    if t.dim() != 2:
+        raise ValueError('expected a matrix')
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    elif t.shape[0] > 1 and t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+def mm_nn(a, b, rowscale=None, addend=None, bias=None, relu=False):
+    """act(rowscale[:,None] * (a @ b) + addend + bias) in one kernel; a [M,K], b [K,N] float32 on device."""
+    lib = _lib.load()
+    _lib.require_device(a, b, rowscale, addend, bias)
+    a, b = _rowmajor(a), _rowmajor(b)
+    M, K = a.shape
+    K2, N = b.shape
+    if K != K2:
+        raise ValueError(f'shape mismatch: {tuple(a.shape)} @ {tuple(b.shape)}')
+    if a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise TypeError('mm_nn expects float32')
+    if addend is not None:
+        addend = _rowmajor(addend)
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.cb_gemm_nn_f32(_lib.ptr(a), _ld(a), _lib.ptr(b), _ld(b), _lib.ptr(out), N, M, N, K, _lib.ptr(rowscale),
+                                      _lib.ptr(addend), _ld(addend) if addend is not None else 0, _lib.ptr(bias),
+                                      int(bool(relu)), _lib.stream_ptr()), 'cb_gemm_nn_f32')
+    return out
+
+
+def mm_tn(a, g, rowscale=None):
+    """a^T @ (rowscale[:,None] * g): a [M,K1], g [M,K2] -> [K1,K2]; deterministic split reduction over M."""
+    lib = _lib.load()
+    _lib.require_device(a, g, rowscale)
+    a, g = _rowmajor(a), _rowmajor(g)
+    M, K1 = a.shape
+    M2, K2 = g.shape
+    if M != M2:
+        raise ValueError(f'shape mismatch: {tuple(a.shape)}^T @ {tuple(g.shape)}')
+    out = torch.empty((K1, K2), dtype=torch.float32, device=a.device)
+    wsb = lib.cb_gemm_tn_workspace_bytes(M, K1, K2)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.cb_gemm_tn_f32(_lib.ptr(a), _ld(a), _lib.ptr(g), _ld(g), _lib.ptr(rowscale), _lib.ptr(out), M, K1, K2,
+                                      _lib.ptr(ws), wsb, _lib.stream_ptr()), 'cb_gemm_tn_f32')
+    return out
+
+
+class _LinearRowscaleFn(torch.autograd.Function):
+    """Z = rowscale * (X @ W) + E.   dX = rowscale * (dZ @ W^T);  dW = X^T (rowscale * dZ);  dE = dZ."""
+
+    @staticmethod
+    def forward(ctx, x, w, rowscale, addend):
+        ctx.save_for_backward(x, w, rowscale)
+        ctx.has_addend = addend is not None
+        return mm_nn(x, w, rowscale=rowscale, addend=addend)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, rowscale = ctx.saved_tensors
+        g = _rowmajor(g)
+        dx = mm_nn(g, w.t().contiguous(), rowscale=rowscale) if ctx.needs_input_grad[0] else None
+        dw = mm_tn(x, g, rowscale=rowscale) if ctx.needs_input_grad[1] else None
+        de = g if (ctx.has_addend and ctx.needs_input_grad[3]) else None
+        return dx, dw, None, de
+
+
+def linear_rowscale(x, w, rowscale=None, addend=None):
+    return _LinearRowscaleFn.apply(x, w, rowscale, addend)
+
+
+class _LinearFn(torch.autograd.Function):
+    """Y = act(X @ W^T + b) with nn.Linear's weight layout [out, in]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        y = mm_nn(x, weight.t().contiguous(), bias=bias, relu=relu)
+        ctx.relu, ctx.has_bias = relu, bias is not None
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from .ops import act_bwd
+        x, weight, y = ctx.saved_tensors
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        g = _rowmajor(g)
+        if ctx.relu or need_b:
+            gm, db = act_bwd(g, y if ctx.relu else None, None, want_out=ctx.relu, want_colsum=need_b)
+            if gm is None:
+                gm = g
+        else:
+            gm, db = g, None
+        dx = mm_nn(gm, weight) if ctx.needs_input_grad[0] else None       # [M,out] @ [out,in]
+        dw = mm_tn(gm, x) if ctx.needs_input_grad[1] else None            # [out,in]
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, relu=False):
+    _lib.require_device(x, weight)
+    return _LinearFn.apply(x, weight, bias, bool(relu))

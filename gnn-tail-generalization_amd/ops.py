@@ -2,13 +2,101 @@
 (include/coldbrew_hip.h).  One torch.autograd.Function per fused stage; tensors must live
 on the MI355X (no CPU fallback — _lib.require_device raises otherwise).
 
-Stage map (reference lines are GNN_model/GCN.py):
-  transform   Z = (X * a) @ W + E            :213,:225,:230-231   (dense, MFMA-bound)
-  aggregate   Y = act(b * (A^T Z) + bias)    :238,:250,:253(+:128) (sparse, HBM-bound)
+Stage map (reference lines are GNN_model/GCN.py unless noted):
+  dropout     Xd = X * keep / (1-p)                  :104,:110,:133  (counter-based RNG, mask never stored)
+  transform   Z  = (Xd * a) @ W + E ; ||E||_F        :213,:225,:230-232  (dense, MFMA-bound)
+  aggregate   Y  = act(b * (A^T Z) + bias)           :238,:250,:253(+:128)  (sparse, HBM-bound)
+  res_mix     X' = (1-alpha) * Y + alpha * R         res_tricks.py:14,23
+  nll_logsoftmax  mean nll(log_softmax(out[mask]))   trainer_node_classification.py:390-391
 """
+import ctypes
+
 import torch
 
 from . import _lib
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# dropout
+# ---------------------------------------------------------------------------------------------
+_seed_override = []
+
+
+def next_seed():
+    """63-bit seed drawn from torch's CPU generator: follows torch.manual_seed, costs no device sync."""
+    if _seed_override:
+        return _seed_override.pop(0)
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def _dropout_raw(x, p, seed, offset=0):
+    lib = _lib.load()
+    x = _c(x)
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.cb_dropout_f32(_lib.ptr(x), _lib.ptr(out), x.numel(), float(p), ctypes.c_uint64(seed), int(offset),
+                                      _lib.stream_ptr()), 'cb_dropout_f32')
+    return out
+
+
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, offset):
+        ctx.p, ctx.seed, ctx.offset = p, seed, offset
+        return _dropout_raw(x, p, seed, offset)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _dropout_raw(g, ctx.p, ctx.seed, ctx.offset), None, None, None
+
+
+def dropout(x, p, training=True, seed=None, offset=0):
+    """F.dropout semantics; the keep-mask is a pure function of (seed, flat element index)."""
+    if not training or p == 0.0:
+        return x
+    _lib.require_device(x)
+    if x.dtype != torch.float32:
+        raise TypeError('dropout expects float32')
+    if p >= 1.0:
+        return x * 0
+    if seed is None:
+        seed = next_seed()
+    return _DropoutFn.apply(x, float(p), int(seed), int(offset))
+
+
+def dropout_keep_mask(shape, p, seed, device, offset=0):
+    """The boolean keep-mask `dropout` uses for (seed, shape) — for parity tests that inject the same
+    mask into the oracle."""
+    ones = torch.ones(shape, dtype=torch.float32, device=device)
+    return _dropout_raw(ones, p, seed, offset) > 0
+
+
+# ---------------------------------------------------------------------------------------------
+# aggregation
+# ---------------------------------------------------------------------------------------------
+def act_bwd(g, act=None, row_scale=None, want_out=True, want_colsum=False):
+    """gm = g * (act > 0); returns (gm * row_scale[:,None] or None, colsum(gm) or None) in one pass."""
+    lib = _lib.load()
+    g = _c(g)
+    rows, d = g.shape
+    if act is not None:
+        act = _c(act)
+    out = torch.empty_like(g) if want_out else None
+    colsum = torch.empty(d, dtype=torch.float32, device=g.device) if want_colsum else None
+    wsb = lib.cb_colsum_workspace_bytes(rows, d) if want_colsum else 0
+    ws = _ws(wsb, g.device) if want_colsum else None
+    with torch.cuda.device(g.device):
+        _lib.check(lib.cb_act_bwd_f32(_lib.ptr(g), _lib.ptr(act), _lib.ptr(row_scale), _lib.ptr(out), rows, d,
+                                      _lib.ptr(colsum), _lib.ptr(ws), wsb, _lib.stream_ptr()), 'cb_act_bwd_f32')
+    return out, colsum
 
 
 class _AggregateFn(torch.autograd.Function):
@@ -27,14 +115,12 @@ class _AggregateFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         out, row_scale = ctx.saved_tensors
-        g = g.contiguous()
-        if ctx.relu:
-            g = g * (out > 0)
-        dbias = g.sum(dim=0) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
-        dh = None
-        if ctx.needs_input_grad[1]:
-            gs = g * row_scale.unsqueeze(1) if row_scale is not None else g
-            dh = ctx.graph.spmm(gs, transpose=True)
+        need_h, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[3]
+        if not (ctx.relu or row_scale is not None or need_b):
+            gs, dbias = _c(g), None
+        else:
+            gs, dbias = act_bwd(g, out if ctx.relu else None, row_scale, want_out=need_h, want_colsum=need_b)
+        dh = ctx.graph.spmm(gs, transpose=True) if need_h else None
         return None, dh, None, dbias, None
 
 
@@ -43,10 +129,112 @@ def aggregate(graph, h, row_scale=None, bias=None, relu=False):
     return _AggregateFn.apply(graph, h, row_scale, bias, bool(relu))
 
 
+# ---------------------------------------------------------------------------------------------
+# structural-embedding regulariser
+# ---------------------------------------------------------------------------------------------
+class _FrobeniusFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        xc = _c(x)
+        out2 = torch.empty(2, dtype=torch.float32, device=x.device)
+        wsb = lib.cb_reduce_workspace_bytes()
+        ws = _ws(wsb, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.cb_frobenius_norm_f32(_lib.ptr(xc), xc.numel(), _lib.ptr(out2), _lib.ptr(ws), wsb,
+                                                 _lib.stream_ptr()), 'cb_frobenius_norm_f32')
+        norm = out2[0]
+        ctx.save_for_backward(x, norm)
+        return norm.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, norm = ctx.saved_tensors
+        return x * (g / norm)          # d||x||/dx = x / ||x||
+
+
+def frobenius_norm(x):
+    _lib.require_device(x)
+    return _FrobeniusFn.apply(x)
+
+
 def transform(feat, norm_out, weight, le=None):
     """Z = (feat * a[:,None]) @ W (+ le) and se_reg = ||le||_F (GCN.py:213,225,230-236)."""
     _lib.require_device(feat, weight)
-    z = torch.matmul(feat * norm_out.unsqueeze(1), weight)
-    if le is not None:
-        return z + le, torch.norm(le)
-    return z, None
+    from . import gemm
+    z = gemm.linear_rowscale(feat, weight, norm_out, le)
+    return z, (frobenius_norm(le) if le is not None else None)
+
+
+# ---------------------------------------------------------------------------------------------
+# residual mixes
+# ---------------------------------------------------------------------------------------------
+def _axpby_raw(a, x, b, y):
+    lib = _lib.load()
+    x, y = _c(x), _c(y)
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.cb_axpby_f32(float(a), _lib.ptr(x), float(b), _lib.ptr(y), _lib.ptr(out), x.numel(),
+                                    _lib.stream_ptr()), 'cb_axpby_f32')
+    return out
+
+
+class _AxpbyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, x, b, y):
+        ctx.a, ctx.b = a, b
+        return _axpby_raw(a, x, b, y)
+
+    @staticmethod
+    def backward(ctx, g):
+        gx = _axpby_raw(ctx.a, g, 0.0, g) if ctx.needs_input_grad[1] else None
+        gy = _axpby_raw(ctx.b, g, 0.0, g) if ctx.needs_input_grad[3] else None
+        return None, gx, None, gy
+
+
+def axpby(a, x, b, y):
+    """a*x + b*y for same-shape float32 device tensors."""
+    _lib.require_device(x, y)
+    if x.shape != y.shape or x.dtype != torch.float32 or y.dtype != torch.float32:
+        raise ValueError('axpby expects same-shape float32 tensors')
+    return _AxpbyFn.apply(float(a), x, float(b), y)
+
+
+# ---------------------------------------------------------------------------------------------
+# loss
+# ---------------------------------------------------------------------------------------------
+class _NllFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, y, mask, count):
+        lib = _lib.load()
+        z = logits if logits.stride(1) == 1 else logits.contiguous()
+        rows, C = z.shape
+        loss = torch.empty(1, dtype=torch.float32, device=z.device)
+        grad = torch.empty((rows, C), dtype=torch.float32, device=z.device) if ctx.needs_input_grad[0] else None
+        wsb = lib.cb_reduce_workspace_bytes()
+        ws = _ws(wsb, z.device)
+        m8 = mask.view(torch.uint8) if mask is not None else None
+        with torch.cuda.device(z.device):
+            _lib.check(lib.cb_nll_logsoftmax_f32(_lib.ptr(z), z.stride(0), _lib.ptr(y), _lib.ptr(m8), rows, C, int(count),
+                                                 _lib.ptr(loss), _lib.ptr(grad), _lib.ptr(ws), wsb, _lib.stream_ptr()),
+                       'cb_nll_logsoftmax_f32')
+        ctx.save_for_backward(grad)
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None
+
+
+def nll_logsoftmax(logits, y, mask=None, count=None):
+    """mean_{r: mask[r]} nll(log_softmax(logits[r]), y[r]) without materialising logits[mask].
+    `count` = number of masked rows (precomputed once per dataset to avoid a per-step host sync)."""
+    _lib.require_device(logits, y, mask)
+    if logits.dtype != torch.float32 or y.dtype != torch.int64:
+        raise TypeError('nll_logsoftmax expects float32 logits and int64 labels')
+    if mask is not None and mask.dtype != torch.bool:
+        raise TypeError('mask must be a bool tensor')
+    if count is None:
+        count = int(mask.sum().item()) if mask is not None else logits.shape[0]
+    return _NllFn.apply(logits, _c(y), _c(mask) if mask is not None else None, count)

@@ -1,11 +1,49 @@
 """Optimisers of the path (trainer_node_classification.py:293-296,310): `--optfun` names map to
-classes with torch.optim's constructor signature and update rule."""
+classes with torch.optim's constructor signature.  Adam runs as one fused HIP kernel per parameter
+tensor (cb_adam_step_f32) with torch.optim.Adam's update rule."""
 import torch
+
+from . import _lib
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError('invalid Adam hyper-parameter')
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        for group in self.param_groups:
+            b1, b2 = group['betas']
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                _lib.require_device(p)
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise TypeError('fused Adam expects contiguous float32 parameters')
+                st = self.state[p]
+                if not st:
+                    st['step'] = 0
+                    st['exp_avg'] = torch.zeros_like(p)
+                    st['exp_avg_sq'] = torch.zeros_like(p)
+                st['step'] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                with torch.cuda.device(p.device):
+                    _lib.check(lib.cb_adam_step_f32(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st['exp_avg']), _lib.ptr(st['exp_avg_sq']),
+                                                    p.numel(), group['lr'], b1, b2, group['eps'], group['weight_decay'],
+                                                    st['step'], _lib.stream_ptr()), 'cb_adam_step_f32')
+        return loss
 
 
 def resolve(name):
     if name == 'torch.optim.Adam':
-        return torch.optim.Adam
+        return Adam
     if name == 'torch.optim.SGD':
         return torch.optim.SGD
     raise ValueError(f'unknown --optfun {name}')

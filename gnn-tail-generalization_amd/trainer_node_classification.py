@@ -12,6 +12,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import ops
 from . import optim as cb_optim
 from .data import load_data
 from .GNN_model.GNN_normalizations import TeacherGNN
@@ -119,9 +120,12 @@ class trainer:
 
     def training_loss(self):
         """Forward + loss of run_trainSet (:386-394): nll(log_softmax(out[train])) + se_reg * sum ||E||."""
-        res = self.teacherGNN.get_3_embs(self.data.x, self.data.edge_index, self.data.train_mask)
-        logits = F.log_softmax(res.emb4classi, 1)
-        loss = self.loss_fn(logits, self.data.y[self.data.train_mask]) * self.args.TeacherGNN.lossa_semantic
+        res = self.teacherGNN.get_3_embs(self.data.x, self.data.edge_index)
+        if getattr(self, '_n_train', None) is None:
+            self._n_train = int(self.data.train_mask.sum().item())      # once: keeps the step free of host syncs
+        # == F.nll_loss(F.log_softmax(out[train_mask], 1), y[train_mask]) (:390-391), fused, no row gather
+        loss = ops.nll_logsoftmax(res.emb4classi_full, self.data.y, self.data.train_mask, self._n_train)
+        loss = loss * self.args.TeacherGNN.lossa_semantic
         if self.teacherGNN.se_reg_all is not None:
             loss = loss + self.args.se_reg * self.teacherGNN.se_reg_all
         return loss

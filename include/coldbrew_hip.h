@@ -93,6 +93,66 @@ int cb_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_
                     const int32_t* hub_rows, const int32_t* hub_chunk_ptr,
                     void* ws, size_t ws_bytes, void* stream);
 
+
+/* ------------------------------------------------------------------------------------
+ * Elementwise / reduction stages around the GEMM + aggregation pairs (HBM-bound).
+ * ---------------------------------------------------------------------------------- */
+
+/* out[i] = x[i] * keep(seed, offset + i) / (1 - p) — `F.dropout(x, p, training=True)` of GCN.py:104,110,133.
+ * keep() is a counter-based Philox4x32-10 draw of (seed, flat index): the backward calls the same
+ * function on the gradient with the same seed instead of storing a mask; `offset` = flat index of x[0]
+ * in the unsharded tensor (0 on one GPU), so row shards draw the mask of the full tensor.
+ * In-place (out == x) is allowed. */
+int cb_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t seed, int64_t offset, void* stream);
+
+/* out = a*x + b*y — ResidualConnection / InitialConnection (res_tricks.py:14,23) and gradient sums. */
+int cb_axpby_f32(float a, const float* x, float b, const float* y, float* out, int64_t n, void* stream);
+
+/* Backward of the aggregation epilogue  Y = act(row_scale * R + bias)  (autograd of GCN.py:250,253 and
+ * F.relu GCN.py:128) in one pass over [rows, d] contiguous matrices:
+ *     gm = g * (act > 0)  (act == NULL: gm = g);  colsum[c] = sum_r gm[r,c]  (= dbias; NULL to skip);
+ *     out[r,c] = gm[r,c] * row_scale[r]  (row_scale NULL: factor 1; out NULL: column sums only).
+ * Column sums are reduced in a fixed order (ws: cb_colsum_workspace_bytes(rows, d)). */
+size_t cb_colsum_workspace_bytes(int64_t rows, int64_t d);
+int cb_act_bwd_f32(const float* g, const float* act, const float* row_scale, float* out, int64_t rows, int64_t d,
+                   float* colsum, void* ws, size_t ws_bytes, void* stream);
+
+/* out2[0] = ||x||_F (`th.norm(self.le)`, GCN.py:232), out2[1] = sum x^2; ws: cb_reduce_workspace_bytes(). */
+size_t cb_reduce_workspace_bytes(void);
+int cb_frobenius_norm_f32(const float* x, int64_t n, float* out2, void* ws, size_t ws_bytes, void* stream);
+
+/* Fused `F.nll_loss(F.log_softmax(logits[mask], 1), y[mask])` (trainer_node_classification.py:390-391)
+ * and its gradient: loss[0] = mean over the `count` rows with mask != 0 (mask NULL: all rows);
+ * grad [rows, C] contiguous (NULL to skip) = (softmax - onehot) / count on masked rows, 0 elsewhere.
+ * mask is one byte per row (torch.bool). */
+int cb_nll_logsoftmax_f32(const float* logits, int64_t ld, const int64_t* y, const uint8_t* mask, int64_t rows, int64_t C,
+                          int64_t count, float* loss, float* grad, void* ws, size_t ws_bytes, void* stream);
+
+/* One fused Adam update of a parameter tensor — `torch.optim.Adam(params, lr, weight_decay)` of
+ * trainer_node_classification.py:310,430 (L2-style weight decay added to the gradient, bias-corrected
+ * moments, step >= 1). */
+int cb_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int64_t step, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Dense contractions on the fp32 matrix cores (v_mfma_f32_32x32x2_f32; exact fp32).
+ * ---------------------------------------------------------------------------------- */
+
+/* C[M,N] = act( rowscale[m] * (A[M,K] @ B[K,N]) + addend[m,n] + bias[n] ) — `feat_src = feat * norm`,
+ * `th.matmul(feat_src, weight)`, `+ self.le` (GCN.py:213,225,231) in one kernel (the row scale commutes
+ * with the product); with bias/relu it is also nn.Linear + F.relu (GCN.py:105-106,138) and, fed with
+ * gradients, the dX GEMMs of their backward.  rowscale/addend/bias may be NULL. */
+int cb_gemm_nn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
+                   int64_t K, const float* rowscale, const float* addend, int64_t ld_add, const float* bias, int relu,
+                   void* stream);
+
+/* C[K1,K2] = sum_m A[m,K1] * rowscale[m] * G[m,K2] — the weight gradients (autograd of GCN.py:225 and
+ * of nn.Linear): a reduction over the node axis, split into row slabs whose partial products are summed
+ * in a fixed order (ws: cb_gemm_tn_workspace_bytes).  rowscale may be NULL. */
+size_t cb_gemm_tn_workspace_bytes(int64_t M, int64_t K1, int64_t K2);
+int cb_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, const float* rowscale, float* C, int64_t M,
+                   int64_t K1, int64_t K2, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,168 @@
+"""GPU parity of the dense / elementwise / optimiser kernels (through the C ABI) against fp64 torch
+references and the oracle's Adam.  fp32 tolerances are written per test."""
+import numpy as np
+import pytest
+import torch
+
+import coldbrew_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _rand(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.mark.parametrize('M,K,N', [(1, 1, 1), (5, 3, 7), (128, 16, 128), (130, 17, 129), (257, 1433, 64), (1000, 500, 256),
+                                   (333, 256, 40), (64, 100, 47), (4096, 256, 256), (300, 64, 7)])
+def test_gemm_nn_epilogues(M, K, N):
+    from gnn_tail_generalization_amd import gemm
+    a, b = _rand(M, K, seed=1), _rand(K, N, seed=2)
+    rs, add, bias = torch.rand(M) + 0.5, _rand(M, N, seed=3), _rand(N, seed=4)
+    ref = a.double() @ b.double()
+    tol = dict(atol=2e-5 * max(1, K ** 0.5), rtol=2e-5)
+    out = gemm.mm_nn(a.to(DEV), b.to(DEV))
+    torch.testing.assert_close(out.cpu().double(), ref, **tol)
+    out = gemm.mm_nn(a.to(DEV), b.to(DEV), rowscale=rs.to(DEV), addend=add.to(DEV), bias=bias.to(DEV), relu=True)
+    ref2 = torch.relu(ref * rs.double().unsqueeze(1) + add.double() + bias.double())
+    torch.testing.assert_close(out.cpu().double(), ref2, **tol)
+
+
+def test_gemm_nn_asymmetric_identity_and_strides():
+    """A = I against an asymmetric B catches a transposed C write; strided (non-16B) operands take the generic path."""
+    from gnn_tail_generalization_amd import gemm
+    n = 160
+    b = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 97) - 13.0
+    out = gemm.mm_nn(torch.eye(n, device=DEV), b.to(DEV))
+    assert torch.equal(out.cpu(), b)
+    big = _rand(200, 301, seed=5).to(DEV)
+    a = big[:, 3:203]                      # ld = 301, misaligned start
+    w = _rand(200, 33, seed=6).to(DEV)
+    torch.testing.assert_close(gemm.mm_nn(a, w).cpu().double(), a.cpu().double() @ w.cpu().double(), atol=3e-4, rtol=2e-5)
+
+
+@pytest.mark.parametrize('M,K1,K2', [(1, 1, 1), (77, 5, 9), (1000, 128, 256), (5000, 256, 256), (3001, 1433, 64), (20000, 40, 256),
+                                     (999, 130, 7)])
+def test_gemm_tn(M, K1, K2):
+    from gnn_tail_generalization_amd import gemm
+    a, g, rs = _rand(M, K1, seed=1), _rand(M, K2, seed=2), torch.rand(M) + 0.5
+    ref = a.double().t() @ (g.double() * rs.double().unsqueeze(1))
+    out = gemm.mm_tn(a.to(DEV), g.to(DEV), rowscale=rs.to(DEV))
+    torch.testing.assert_close(out.cpu().double(), ref, atol=3e-5 * max(1, M ** 0.5), rtol=3e-5)
+    out2 = gemm.mm_tn(a.to(DEV), g.to(DEV), rowscale=rs.to(DEV))
+    assert torch.equal(out, out2)          # fixed reduction order
+
+
+def test_linear_autograd_matches_torch():
+    from gnn_tail_generalization_amd import gemm
+    x, w, b = _rand(300, 50, seed=1), _rand(20, 50, seed=2), _rand(20, seed=3)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = torch.relu(torch.nn.functional.linear(xr, wr, br))
+    go = _rand(300, 20, seed=4)
+    yr.backward(go.double())
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = gemm.linear(xd, wd, bd, relu=True)
+    y.backward(go.to(DEV))
+    for got, ref in [(y, yr), (xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)]:
+        torch.testing.assert_close(got.detach().cpu().double(), ref.detach(), atol=1e-4, rtol=1e-4)
+    rs, e = torch.rand(300) + 0.5, _rand(300, 30, seed=7)
+    w2 = _rand(50, 30, seed=8)
+    xr, w2r, er = (t.double().requires_grad_(True) for t in (x, w2, e))
+    zr = (xr * rs.double().unsqueeze(1)) @ w2r + er
+    g2 = _rand(300, 30, seed=9)
+    zr.backward(g2.double())
+    xd, w2d, ed = (t.to(DEV).requires_grad_(True) for t in (x, w2, e))
+    z = gemm.linear_rowscale(xd, w2d, rs.to(DEV), ed)
+    z.backward(g2.to(DEV))
+    for got, ref in [(z, zr), (xd.grad, xr.grad), (w2d.grad, w2r.grad), (ed.grad, er.grad)]:
+        torch.testing.assert_close(got.detach().cpu().double(), ref.detach(), atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize('n', [1, 3, 4, 1023, 4096 * 37 + 5])
+def test_dropout_properties(n):
+    from gnn_tail_generalization_amd import ops
+    x = (torch.rand(n) + 0.5).to(DEV).requires_grad_(True)
+    p, seed = 0.3, 123456789
+    y = ops.dropout(x, p, True, seed=seed)
+    keep = ops.dropout_keep_mask((n,), p, seed, DEV)
+    torch.testing.assert_close(y.detach(), torch.where(keep, x.detach() / (1 - p), torch.zeros_like(x)), rtol=1e-6, atol=0)
+    assert torch.equal(y, ops.dropout(x, p, True, seed=seed))                 # pure function of (seed, index)
+    if n > 1000:
+        assert abs(float(keep.float().mean()) - (1 - p)) < 0.01
+        assert not torch.equal(keep, ops.dropout_keep_mask((n,), p, seed + 1, DEV))
+    g = torch.rand(n, device=DEV)
+    y.backward(g)
+    torch.testing.assert_close(x.grad, torch.where(keep, g / (1 - p), torch.zeros_like(g)), rtol=1e-6, atol=0)
+    assert ops.dropout(x, p, False) is x and ops.dropout(x, 0.0, True) is x
+    # row shards reproduce the full mask (offset = flat index of the shard's first element)
+    for off in (0, 1, 2, 3, 8):
+        if off < n:
+            part = ops.dropout_keep_mask((n - off,), p, seed, DEV, offset=off)
+            assert torch.equal(part, keep[off:])
+
+
+def test_axpby_act_bwd_frobenius():
+    from gnn_tail_generalization_amd import ops
+    for shape in [(7, 3), (100, 40), (513, 256), (64, 260), (33, 7)]:
+        x, y = _rand(*shape, seed=1).to(DEV).requires_grad_(True), _rand(*shape, seed=2).to(DEV).requires_grad_(True)
+        out = ops.axpby(0.9, x, 0.1, y)
+        torch.testing.assert_close(out, 0.9 * x + 0.1 * y, rtol=1e-6, atol=1e-7)
+        out.backward(torch.ones_like(out))
+        assert torch.allclose(x.grad, torch.full_like(x, 0.9)) and torch.allclose(y.grad, torch.full_like(y, 0.1))
+        g, act, rs = _rand(*shape, seed=3), _rand(*shape, seed=4), torch.rand(shape[0]) + 0.5
+        gs, cs = ops.act_bwd(g.to(DEV), act.to(DEV), rs.to(DEV), want_out=True, want_colsum=True)
+        gm = g.double() * (act > 0)
+        torch.testing.assert_close(gs.cpu().double(), gm * rs.double().unsqueeze(1), rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(cs.cpu().double(), gm.sum(0), rtol=1e-5, atol=1e-4)
+        gs2, cs2 = ops.act_bwd(g.to(DEV), None, None, want_out=False, want_colsum=True)
+        assert gs2 is None
+        torch.testing.assert_close(cs2.cpu().double(), g.double().sum(0), rtol=1e-5, atol=1e-4)
+        le = _rand(*shape, seed=5).to(DEV).requires_grad_(True)
+        nrm = ops.frobenius_norm(le)
+        torch.testing.assert_close(nrm.cpu(), torch.norm(le.detach().cpu()), rtol=1e-6, atol=1e-6)
+        (3.0 * nrm).backward()
+        torch.testing.assert_close(le.grad.cpu(), 3.0 * le.detach().cpu() / torch.norm(le.detach().cpu()), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('rows,C', [(1, 2), (50, 3), (1000, 7), (5000, 40), (777, 47), (300, 128)])
+def test_nll_logsoftmax_fused(rows, C):
+    from gnn_tail_generalization_amd import ops
+    z = (3 * _rand(rows, C, seed=rows)).requires_grad_(True)
+    y = torch.randint(0, C, (rows,), generator=torch.Generator().manual_seed(C))
+    mask = torch.rand(rows, generator=torch.Generator().manual_seed(1)) < 0.4
+    mask[0] = True
+    ref = torch.nn.functional.nll_loss(torch.nn.functional.log_softmax(z.double()[mask], 1), y[mask])
+    ref.backward()
+    zd = z.detach().to(DEV).requires_grad_(True)
+    loss = ops.nll_logsoftmax(zd, y.to(DEV), mask.to(DEV))
+    (2.0 * loss).backward()
+    torch.testing.assert_close(loss.cpu().double(), ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(zd.grad.cpu().double(), 2.0 * z.grad.double(), rtol=1e-4, atol=1e-7)
+    loss_all = ops.nll_logsoftmax(zd.detach(), y.to(DEV))
+    ref_all = torch.nn.functional.nll_loss(torch.nn.functional.log_softmax(z.detach().double(), 1), y)
+    torch.testing.assert_close(loss_all.cpu().double(), ref_all, rtol=1e-5, atol=1e-6)
+
+
+def test_fused_adam_matches_oracle_and_torch():
+    from gnn_tail_generalization_amd.optim import Adam
+    shapes = [(5,), (33, 7), (256, 256), (1001,)]
+    ps = [_rand(*s, seed=i) for i, s in enumerate(shapes)]
+    mine = [p.clone().to(DEV).requires_grad_(True) for p in ps]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    orc_p = {str(i): p.clone() for i, p in enumerate(ps)}
+    opt_m = Adam(mine, lr=0.01, weight_decay=5e-4)
+    opt_r = torch.optim.Adam(ref, lr=0.01, weight_decay=5e-4)
+    state = {}
+    for step in range(1, 6):
+        grads = [_rand(*s, seed=100 * step + i) for i, s in enumerate(shapes)]
+        for p, g in zip(mine, grads):
+            p.grad = g.to(DEV)
+        for p, g in zip(ref, grads):
+            p.grad = g.clone()
+        opt_m.step()
+        opt_r.step()
+        orc.adam_step(orc_p, {str(i): g for i, g in enumerate(grads)}, state, 0.01, 5e-4, step)
+    for i, (m, r) in enumerate(zip(mine, ref)):
+        torch.testing.assert_close(m.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(m.detach().cpu(), orc_p[str(i)], rtol=1e-5, atol=1e-6)

@@ -46,3 +46,34 @@ def test_model_matches_reference_golden(name):
         torch.testing.assert_close(got[k].cpu(), ref, atol=2e-5, rtol=2e-4, msg=lambda m, k=k: f'{k}: {m}')
     for k, v in g['bn_after'].items():
         torch.testing.assert_close(model.state_dict()[k].cpu(), v, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('name', ['case_nr_se111_L3', 'case_r_initialbn_se111_L3_powerlaw', 'case_r_residual_L3'])
+def test_train_mode_with_dropout_matches_oracle(name):
+    """Dropout cannot match torch's RNG stream; parity is defined by injecting the product's own
+    keep-masks (pure functions of seed and index) into the oracle."""
+    import coldbrew_oracle as orc
+    from gnn_tail_generalization_amd import ops
+    from helpers import oracle_cfg
+    g = load_golden(name)
+    cfg = dict(g['cfg'])
+    cfg['dropout'] = 0.4
+    args, model = product_model(cfg, g['sd'], DEV)
+    x, ei = g['x'].to(DEV), g['edge_index'].to(DEV)
+    n, L, H, C, F_ = cfg['N_nodes'], cfg['num_layers'], cfg['dim_hidden'], cfg['num_classes'], cfg['num_feats']
+    residual = orc.has_residual_mlp(oracle_cfg(cfg))
+    if residual:
+        shapes = [(n, F_)] + [(n, H)] * L + [(n, H)]
+    else:
+        shapes = [(n, F_)] + [(n, H)] * (L - 1) + [(n, C)]
+    seeds = [1000 + i for i in range(len(shapes))]
+    ops._seed_override[:] = list(seeds)
+    model.train()
+    out = model(x, ei)
+    assert not ops._seed_override
+    masks = [ops.dropout_keep_mask(s, 0.4, sd, DEV).cpu() for s, sd in zip(shapes, seeds)]
+    ocfg = oracle_cfg(cfg)
+    ocfg.dropout = 0.4
+    csr = orc.build_csr(g['edge_index'], n)
+    ref, _ = orc.teacher_forward(ocfg, g['sd'], g['x'], csr, training=True, dropout_masks=masks)
+    torch.testing.assert_close(out.detach().cpu(), ref, atol=1e-4, rtol=1e-4)

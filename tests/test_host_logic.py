@@ -165,6 +165,8 @@ def test_product_never_imports_oracle():
         for f in files:
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
-                assert 'coldbrew_oracle' not in src and 'ref_import' not in src and 'oracle' not in src.replace('oracle/', ''), f
-    for f in ('main.py',):
-        assert 'oracle' not in open(os.path.join(ROOT, f)).read()
+                assert not _IMPORTS_ORACLE.search(src), f
+    assert not _IMPORTS_ORACLE.search(open(os.path.join(ROOT, 'main.py')).read())
+
+
+_IMPORTS_ORACLE = re.compile(r"^\s*(import|from)\s+\S*(coldbrew_oracle|ref_import|oracle)|sys\.path\S*oracle|'oracle'|\"oracle\"", re.M)
