@@ -67,6 +67,7 @@ class CSRGraph:
         self._plan = self._make_plan(self.rowptr)
         self._plan_t = self._plan if self.symmetric else self._make_plan(self.rowptr_t)
         self._ws = None
+        self.profile = None      # bench.py sets a list: (start_event, end_event, algorithmic_bytes) per aggregation
 
     # -- DGL-like surface (GCN.py:188,200,206,243) --------------------------------------
     def number_of_nodes(self):
@@ -130,12 +131,19 @@ class CSRGraph:
         ws = self._workspace(ws_bytes)
         ld_h = h.stride(0) if h.shape[0] > 1 else d
         ld_o = out.stride(0) if out.shape[0] > 1 else d
+        prof = self.profile
+        if prof is not None:   # HIP events on the stream the kernels are launched on
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         with torch.cuda.device(h.device):
             _lib.check(lib.cb_spmm_csr_f32(_lib.ptr(rowptr), _lib.ptr(col), self.N, self.E, _lib.ptr(h), ld_h, d,
                                            _lib.ptr(row_scale), _lib.ptr(bias), int(bool(relu)), _lib.ptr(out), ld_o,
                                            self.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows),
                                            _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
                        'cb_spmm_csr_f32')
+        if prof is not None:
+            ev1.record()
+            prof.append((ev0, ev1, self.algorithmic_bytes(d, row_scale=row_scale is not None, bias=bias is not None)))
         return out
 
     def algorithmic_bytes(self, d, elem=4, row_scale=True, bias=True):

@@ -85,10 +85,25 @@ class trainer:
         else:
             load_model(self.teacherGNN, join(self.modeldir, 'teacherGNN'))
 
-    def train_teacherGNN(self):
+    def setup_teacherGNN(self):
+        """Model + optimiser construction of train_teacherGNN (:304-310)."""
         self.proj2class = getMLP(self.args.TeacherGNN.neurons_proj2class).to(self.device) if self.args.has_proj2class else None
         self.teacherGNN = TeacherGNN(self.args, self.proj2class).to(self.device)
         self.optimizer = self.optfun(self.teacherGNN.parameters(), lr=self.args.lr, weight_decay=self.weight_decay)
+
+    def graph(self):
+        """The cached device graph (built by the first forward, GCN.py:92-95)."""
+        tc = self.teacherGNN.model.model
+        return tc._graph(self.data.edge_index)
+
+    def global_nodes(self):
+        return int(self.data.x.shape[0])
+
+    def global_edges(self):
+        return int(self.data.edge_index.shape[1])
+
+    def train_teacherGNN(self):
+        self.setup_teacherGNN()
         best_train_loss, best_test_acc = 100, 0.
         results_arr2D = []
         for epoch in range(self.epochs):

@@ -81,6 +81,15 @@ def aggregate_sum(csr, h):
     return out.index_add(0, dst, h.index_select(0, src))
 
 
+_AGGREGATE = [aggregate_sum]
+
+
+def set_aggregate(fn=None):
+    """bench.py's cpu_baseline leg swaps in the C/OpenMP SpMM (oracle/oracle_c.py) for graphs where the
+    index_add message tensor [E, d] would not fit in host memory; None restores the default."""
+    _AGGREGATE[0] = fn or aggregate_sum
+
+
 def aggregate_sum_dense_f64(csr, h):
     """Independent check of aggregate_sum: dense A^T.h in fp64 (small graphs only)."""
     A = np.zeros((csr.N, csr.N), dtype=np.float64)
@@ -103,7 +112,7 @@ def gcnconv_forward(csr, feat, weight, bias=None, le=None, a=None, b=None):
     else:
         h = feat_src
         se_reg = None
-    rst = aggregate_sum(csr, h)                              # :238
+    rst = _AGGREGATE[0](csr, h)                              # :238
     rst = rst * b.reshape(-1, 1)                             # :250
     if bias is not None:
         rst = rst + bias                                     # :253
