@@ -89,13 +89,14 @@ class TricksComb(nn.Module):
         graph = self._graph(edge_index)
         x_list, le_collection, se_reg_all = [], [], None
         new_adjs = self.graph_dropout(edge_index)      # computed and discarded, as in the reference (GCN.py:101,111)
+        row0 = getattr(graph, 'row_offset', 0)     # first global row of this rank's shard (0 on one GPU)
         if self.has_residual_MLP:
-            x = ops.dropout(x, self.embedding_dropout, self.training)
+            x = ops.dropout(x, self.embedding_dropout, self.training, offset=row0 * x.shape[1])
             x = gemm.linear(x, self.layers_MLP[0].weight, self.layers_MLP[0].bias, relu=True)   # Linear + ReLU, GCN.py:105-106
             x_list.append(x)
         norms_run = self.args.type_trick in ('BatchNorm', 'PairNorm', 'NodeNorm', 'MeanNorm', 'GroupNorm', 'CombNorm')
         for i in range(self.num_layers):
-            x = ops.dropout(x, self.dropout, self.training)
+            x = ops.dropout(x, self.dropout, self.training, offset=row0 * x.shape[1])
             _unused_edge_index, _ = new_adjs[i]
             act = self.has_residual_MLP or i < self.num_layers - 1
             # the ReLU of GCN.py:127-128 rides in the aggregation epilogue when nothing sits in between
@@ -113,7 +114,7 @@ class TricksComb(nn.Module):
             x_list.append(x)
             if AcontainsB(self.type_trick, ['Initial', 'Dense', 'Residual']):
                 x = self.layers_res[i](x_list)
-        x = ops.dropout(x, self.args.dropout, self.training)   # on the logits in non-residual mode (GCN.py:133)
+        x = ops.dropout(x, self.args.dropout, self.training, offset=row0 * x.shape[1])   # on the logits in non-residual mode (GCN.py:133)
         if self.has_residual_MLP:
             if AcontainsB(self.type_trick, ['Jumping']):
                 x = self.layers_res[0](x_list)
@@ -170,7 +171,7 @@ class GCNConv(nn.Module):
         if weight is None:
             raise NotImplementedError('GCNConv without a weight is not reachable from TricksComb')
         le = self.le if self.whetherHasSE else None
-        h, se_reg = ops.transform(feat, graph.norm_out, weight, le)                 # GCN.py:213,225,230-236
+        h, se_reg = ops.transform(feat, graph.norm_out, weight, le, graph)          # GCN.py:213,225,230-236
         rst = ops.aggregate(graph, h, row_scale=graph.norm_in, bias=self.bias,      # GCN.py:238,250,253
                             relu=_fused_relu)
         if self._activation is not None:

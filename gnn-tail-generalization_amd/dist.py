@@ -1,0 +1,264 @@
+"""Node-sharded TeacherGNN over the GPUs of one node (one process per GPU, torch.distributed
+`nccl` = RCCL over xGMI).  New relative to the reference, which is single-device
+(SURVEY.md §8e).
+
+Partition: 1-D contiguous row blocks of equal size R = ceil(N / P) (node ids of the synthetic
+graphs are randomly permuted, so equal rows ~ equal edges).  Rank p owns rows
+[p*R, min((p+1)*R, N)) of x / y / masks / activations / structural embeddings and the matching row
+slices of both CSR orientations, with GLOBAL column ids.
+
+Exchange (the only data-path collective): before each aggregation the ranks all-gather their
+[R, d] activation shards into the full [P*R, d] matrix (rows >= N are padding that no column id
+references); the local rows are then reduced by the same SpMM kernel as on one GPU.  The backward
+of the aggregation is the same exchange on the gradient followed by the SpMM on the by-src slice
+(no symmetry assumption).  Everything else is row-local; tiny all-reduces cover the replicated
+weights' gradients, the loss numerator and sum(E^2) of the structural-embedding regulariser.
+
+The exchange and bookkeeping are device-agnostic torch.distributed code (tested on CPU with gloo,
+world_size 2); the compute stays on the HIP path.
+"""
+import contextlib
+import io
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .graph import CSRGraph, ZeroInDegreeError
+
+
+class Partition:
+    """Equal row blocks: rank p owns [lo(p), hi(p))."""
+
+    def __init__(self, n_nodes, world, rank):
+        self.N, self.world, self.rank = int(n_nodes), int(world), int(rank)
+        self.R = (self.N + self.world - 1) // self.world
+
+    def lo(self, p=None):
+        p = self.rank if p is None else p
+        return min(p * self.R, self.N)
+
+    def hi(self, p=None):
+        p = self.rank if p is None else p
+        return min((p + 1) * self.R, self.N)
+
+    @property
+    def n_local(self):
+        return self.hi() - self.lo()
+
+    @property
+    def padded(self):
+        return self.R * self.world
+
+    def slice_rows(self, t):
+        return t[self.lo():self.hi()]
+
+    def owner(self, node_ids):
+        return torch.div(node_ids, self.R, rounding_mode='floor')
+
+
+def gather_rows(x_local, part, group=None, out=None):
+    """All-gather of the row shards: [n_local, d] on each rank -> [P*R, d] (rows >= N are padding)."""
+    d = x_local.shape[1]
+    if out is None:
+        out = torch.empty((part.padded, d), dtype=x_local.dtype, device=x_local.device)
+    if x_local.shape[0] == part.R and x_local.is_contiguous():
+        src = x_local
+    else:   # last rank: pad its shard to R rows
+        src = torch.zeros((part.R, d), dtype=x_local.dtype, device=x_local.device)
+        src[:x_local.shape[0]] = x_local
+    dist.all_gather_into_tensor(out, src, group=group)
+    return out
+
+
+class ShardedGraph:
+    """Row slice [lo, hi) of both CSR orientations with global column ids + local degree norms.
+    Quacks like graph.CSRGraph for GCNConv / ops.aggregate."""
+
+    def __init__(self, full, part, group=None, spmm_fn=None):
+        """full: an object with rowptr/col/rowptr_t/col_t/norm_in/norm_out/N/E (a CSRGraph built from
+        the whole edge_index, or the numpy oracle CSR in the CPU tests)."""
+        self.part, self.group = part, group
+        self.N_global, self.E_global = full.N, full.E
+        self.n_zero_in_degree = getattr(full, 'n_zero_in_degree', 0)
+        self.row_offset = part.lo()
+        lo, hi = part.lo(), part.hi()
+        self.N = hi - lo
+        self._spmm_fn = spmm_fn
+        self.profile = None
+
+        def cut(rowptr, col):
+            rp = torch.as_tensor(rowptr)
+            e0, e1 = int(rp[lo]), int(rp[hi])
+            loc_rp = (rp[lo:hi + 1] - rp[lo]).clone()
+            loc_col = torch.as_tensor(col)[e0:e1].clone()
+            return loc_rp, loc_col
+
+        rp, c = cut(full.rowptr, full.col)
+        rpt, ct = cut(full.rowptr_t, full.col_t)
+        self.E = int(c.numel())
+        self.norm_in = torch.as_tensor(full.norm_in)[lo:hi].clone()
+        self.norm_out = torch.as_tensor(full.norm_out)[lo:hi].clone()
+        if spmm_fn is None:     # HIP path: wrap the slices as rectangular device CSRs
+            self.fwd = CSRGraph.from_csr(rp, c, n_cols=part.padded)
+            self.bwd = CSRGraph.from_csr(rpt, ct, n_cols=part.padded)
+        else:
+            self.fwd, self.bwd = (rp, c), (rpt, ct)
+
+    def check_zero_in_degree(self):
+        if self.n_zero_in_degree:
+            raise ZeroInDegreeError('There are 0-in-degree nodes in the graph')
+
+    def number_of_nodes(self):
+        return self.N_global
+
+    def number_of_edges(self):
+        return self.E_global
+
+    def local_spmm(self, h_full, transpose=False, row_scale=None, bias=None, relu=False):
+        g = self.bwd if transpose else self.fwd
+        if self._spmm_fn is not None:
+            return self._spmm_fn(g[0], g[1], h_full, row_scale, bias, relu)
+        g.profile = self.profile
+        return g.spmm(h_full, row_scale=row_scale, bias=bias, relu=relu)
+
+    def algorithmic_bytes(self, d, **kw):
+        return self.fwd.algorithmic_bytes(d, **kw)
+
+
+class _ShardedAggregateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, graph, h_local, row_scale, bias, relu):
+        h_full = gather_rows(h_local, graph.part, graph.group)
+        out = graph.local_spmm(h_full, False, row_scale, bias, relu)
+        ctx.graph, ctx.relu, ctx.has_bias = graph, relu, bias is not None
+        ctx.save_for_backward(out if relu else None, row_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, row_scale = ctx.saved_tensors
+        graph = ctx.graph
+        need_b = ctx.has_bias and ctx.needs_input_grad[3]
+        gs, dbias = _act_bwd(g, out if ctx.relu else None, row_scale, need_b)
+        dh = None
+        if ctx.needs_input_grad[1]:
+            g_full = gather_rows(gs, graph.part, graph.group)
+            dh = graph.local_spmm(g_full, True)
+        return None, dh, None, dbias, None
+
+
+def _act_bwd(g, act, row_scale, need_b):
+    if g.is_cuda:
+        from .ops import act_bwd
+        return act_bwd(g, act, row_scale, want_out=True, want_colsum=need_b)
+    gm = g * (act > 0) if act is not None else g           # CPU tests of the exchange logic only
+    return (gm * row_scale.unsqueeze(1) if row_scale is not None else gm), (gm.sum(0) if need_b else None)
+
+
+def sharded_aggregate(graph, h_local, row_scale=None, bias=None, relu=False):
+    return _ShardedAggregateFn.apply(graph, h_local, row_scale, bias, bool(relu))
+
+
+def allreduce_grads(params, group=None):
+    """Sum the gradients of the replicated parameters in one flat bucket (weights are a few hundred KB)."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+class _AllReduceSumFn(torch.autograd.Function):
+    """y = sum over ranks of x; backward = all-reduce of the upstream gradients (each rank holds only its
+    share of the loss, and all shares depend on x through y)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        y = x.clone()
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.clone()                      # every rank's loss depends on x through y: sum the upstream gradients
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        return g, None
+
+
+def allreduce_sum(x, group=None):
+    return _AllReduceSumFn.apply(x, group)
+
+
+class ShardedTrainer:
+    """bench.py / multi-GPU driver of the TeacherGNN step.  Mirrors trainer.train_step()."""
+
+    def __init__(self, args, which_run, group=None):
+        from . import optim as cb_optim
+        from .data import synthetic_data
+        from .utils import set_arch_configs
+        self.args, self.group = args, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device = torch.device(f'cuda:{args.cuda_num}')
+        args.device = self.device
+        # every rank generates the same seeded graph, keeps its row block and drops the rest
+        data = synthetic_data(args.dataset, seed=0, device=self.device)
+        self._n, self._e = int(data.x.shape[0]), int(data.edge_index.shape[1])
+        self.part = Partition(self._n, self.world, self.rank)
+        full = CSRGraph(data.edge_index, self._n)
+        self.sgraph = ShardedGraph(full, self.part, group)
+        self.n_train = int(data.train_mask.sum().item())
+        p = self.part
+        self.x = p.slice_rows(data.x).float().contiguous()
+        self.y = p.slice_rows(data.y).contiguous()
+        self.train_mask = p.slice_rows(data.train_mask).contiguous()
+        self.edge_index = data.edge_index[:, :1]     # placeholder: the cached sharded graph is injected below
+        del data, full
+        torch.cuda.empty_cache()
+        self.optfun = cb_optim.resolve(args.optfun)
+        set_arch_configs(args)
+        args.N_nodes_global = self._n
+        args.N_nodes = self.part.n_local             # structural-embedding tables are row-sharded
+
+    def setup_teacherGNN(self):
+        from .GNN_model.GNN_normalizations import TeacherGNN
+        if self.args.type_trick in ('BatchNorm', 'PairNorm', 'MeanNorm', 'GroupNorm', 'CombNorm'):
+            raise NotImplementedError('column-statistic norm tricks need a cross-rank all-reduce; not built for the sharded path')
+        torch.manual_seed(self.args.random_seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            self.teacherGNN = TeacherGNN(self.args, None).to(self.device)
+        self.teacherGNN.model.model.dglgraph = self.sgraph
+        self.replicated = [p for n, p in self.teacherGNN.named_parameters() if not n.endswith('.le') and n != 'embs']
+        self.optimizer = self.optfun(self.teacherGNN.parameters(), lr=self.args.lr, weight_decay=self.args.weight_decay)
+
+    def graph(self):
+        return self.sgraph
+
+    def global_nodes(self):
+        return self._n
+
+    def global_edges(self):
+        return self._e
+
+    def train_step(self):
+        from . import ops
+        m = self.teacherGNN
+        m.train()
+        out = m.get_3_embs(self.x, self.edge_index).emb4classi_full
+        # local numerator / global count; the global loss is the sum over ranks
+        loss = ops.nll_logsoftmax(out, self.y, self.train_mask, self.n_train)
+        if m.se_reg_all is not None:
+            loss = loss + self.args.se_reg * m.se_reg_all / self.world   # se_reg_all is already global; count it once
+        self.optimizer.zero_grad()
+        loss.backward()
+        allreduce_grads(self.replicated, self.group)
+        self.optimizer.step()
+        total = loss.detach().clone()
+        dist.all_reduce(total, group=self.group)
+        return total

@@ -37,6 +37,7 @@ class CSRGraph:
             num_nodes = int(ei.max().item()) + 1 if E else 0
         N = int(num_nodes)
         self.N, self.E, self.device = N, E, dev
+        self.n_cols, self.row_offset = N, 0
         self.hub_threshold = int(hub_threshold)
         self.rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
         self.col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
@@ -68,6 +69,25 @@ class CSRGraph:
         self._plan_t = self._plan if self.symmetric else self._make_plan(self.rowptr_t)
         self._ws = None
         self.profile = None      # bench.py sets a list: (start_event, end_event, algorithmic_bytes) per aggregation
+
+    @classmethod
+    def from_csr(cls, rowptr, col, n_cols, hub_threshold=HUB_THRESHOLD):
+        """Wraps an existing (possibly rectangular: len(rowptr)-1 rows x n_cols columns) device CSR, e.g.
+        the row block a rank owns in the node-sharded path.  Forward orientation only."""
+        _lib.require_device(rowptr, col)
+        g = cls.__new__(cls)
+        g.device = rowptr.device
+        g.N, g.E, g.n_cols = int(rowptr.numel()) - 1, int(col.numel()), int(n_cols)
+        g.hub_threshold = int(hub_threshold)
+        g.rowptr = rowptr.to(torch.int32).contiguous()
+        g.col = col.to(torch.int32).contiguous() if col.numel() else torch.zeros(1, dtype=torch.int32, device=g.device)
+        g.rowptr_t = g.col_t = None
+        g.symmetric, g.n_zero_in_degree, g.max_in_degree = False, 0, -1
+        g._plan = g._make_plan(g.rowptr)
+        g._plan_t = None
+        g._ws, g.profile = None, None
+        g.row_offset = 0
+        return g
 
     # -- DGL-like surface (GCN.py:188,200,206,243) --------------------------------------
     def number_of_nodes(self):
@@ -119,8 +139,10 @@ class CSRGraph:
         _lib.require_device(h, row_scale, bias, out)
         if h.dtype != torch.float32:
             raise TypeError(f'aggregation expects float32 features, got {h.dtype}')
-        if h.dim() != 2 or h.shape[0] != self.N:
-            raise ValueError(f'feature matrix must be [{self.N}, d], got {tuple(h.shape)}')
+        if transpose and self.rowptr_t is None:
+            raise ValueError('this graph holds the forward orientation only')
+        if h.dim() != 2 or h.shape[0] != self.n_cols:
+            raise ValueError(f'feature matrix must be [{self.n_cols}, d], got {tuple(h.shape)}')
         if h.stride(1) != 1 and h.shape[1] > 1:
             h = h.contiguous()
         d = h.shape[1]

@@ -126,6 +126,9 @@ class _AggregateFn(torch.autograd.Function):
 
 def aggregate(graph, h, row_scale=None, bias=None, relu=False):
     _lib.require_device(h)
+    if hasattr(graph, 'part'):      # node-sharded graph: all-gather exchange + local rows (dist.py)
+        from .dist import sharded_aggregate
+        return sharded_aggregate(graph, h, row_scale, bias, relu)
     return _AggregateFn.apply(graph, h, row_scale, bias, bool(relu))
 
 
@@ -158,12 +161,19 @@ def frobenius_norm(x):
     return _FrobeniusFn.apply(x)
 
 
-def transform(feat, norm_out, weight, le=None):
-    """Z = (feat * a[:,None]) @ W (+ le) and se_reg = ||le||_F (GCN.py:213,225,230-236)."""
+def transform(feat, norm_out, weight, le=None, graph=None):
+    """Z = (feat * a[:,None]) @ W (+ le) and se_reg = ||le||_F (GCN.py:213,225,230-236).  With a
+    node-sharded graph `le` holds the local rows and the norm is taken over all ranks."""
     _lib.require_device(feat, weight)
     from . import gemm
     z = gemm.linear_rowscale(feat, weight, norm_out, le)
-    return z, (frobenius_norm(le) if le is not None else None)
+    if le is None:
+        return z, None
+    reg = frobenius_norm(le)
+    if graph is not None and hasattr(graph, 'part'):
+        from .dist import allreduce_sum
+        reg = allreduce_sum(reg * reg, graph.group).sqrt()
+    return z, reg
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,0 +1,128 @@
+"""CPU, world_size 2, gloo: the node-sharded exchange logic of dist.py (partition, row-slice CSR with
+global columns, all-gather exchange, backward exchange, gradient / regulariser all-reduces) against
+the unsharded oracle.  The local SpMM is injected from the oracle's C restatement (the product's HIP
+kernels need a GPU); everything else is the product's dist.py code."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_spmm(rowptr, col, h_full, row_scale, bias, relu):
+    import oracle_c
+    out = oracle_c.spmm(rowptr.numpy().astype(np.int64), col.numpy().astype(np.int32), h_full.detach().numpy(),
+                        None if row_scale is None else row_scale.numpy(), None if bias is None else bias.detach().numpy(), relu)
+    return torch.from_numpy(out)
+
+
+def _worker(rank, world, port, name, q):
+    for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import coldbrew_oracle as orc
+        from gnn_tail_generalization_amd import dist as cbdist
+        torch.set_num_threads(1)
+        g = load_golden(name)
+        n = g['cfg']['N_nodes']
+        csr = orc.build_csr(g['edge_index'], n)
+        a, b = orc.degree_norms(csr)
+        csr.norm_out, csr.norm_in = a, b
+        part = cbdist.Partition(n, world, rank)
+        sg = cbdist.ShardedGraph(csr, part, spmm_fn=_oracle_spmm)
+        assert sg.N == part.n_local and sg.row_offset == part.lo()
+        # the row slices re-assemble the global CSR
+        counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([sg.E]))
+        assert sum(int(c) for c in counts) == csr.E
+        gen = torch.Generator().manual_seed(0)
+        d_in, d_h, C = 6, 8, 3
+        x = torch.randn(n, d_in, generator=gen)
+        w1 = torch.randn(d_in, d_h, generator=gen, requires_grad=True)
+        w2 = torch.randn(d_h, C, generator=gen, requires_grad=True)
+        b1 = torch.randn(d_h, generator=gen, requires_grad=True)
+        le = torch.randn(n, d_h, generator=gen)
+        y = torch.randint(0, C, (n,), generator=gen)
+        mask = torch.rand(n, generator=gen) < 0.5
+        # ---- sharded: local rows only ----
+        xl, yl, ml = part.slice_rows(x), part.slice_rows(y), part.slice_rows(mask)
+        le_l = part.slice_rows(le).clone().requires_grad_(True)
+        h = (xl * sg.norm_out.unsqueeze(1)) @ w1 + le_l
+        h = cbdist.sharded_aggregate(sg, h, sg.norm_in, b1, relu=True)
+        h = (h * sg.norm_out.unsqueeze(1)) @ w2
+        out = cbdist.sharded_aggregate(sg, h, sg.norm_in, None, relu=False)
+        reg_l = torch.norm(le_l)
+        reg = cbdist.allreduce_sum(reg_l * reg_l).sqrt()
+        n_train = int(mask.sum())
+        logp = torch.log_softmax(out, 1)
+        nll_local = -(logp[torch.arange(part.n_local), yl] * ml).sum() / n_train
+        loss = nll_local + 0.5 * reg / world
+        loss.backward()
+        cbdist.allreduce_grads([w1, w2, b1])
+        total = loss.detach().clone()
+        dist.all_reduce(total)
+        # ---- unsharded oracle on every rank ----
+        w1r, w2r, b1r = (t.detach().clone().requires_grad_(True) for t in (w1, w2, b1))
+        ler = le.clone().requires_grad_(True)
+        hr, regr = orc.gcnconv_forward(csr, x, w1r, b1r, ler, a, b)
+        hr = torch.relu(hr)
+        outr, _ = orc.gcnconv_forward(csr, hr, w2r, None, None, a, b)
+        lossr = torch.nn.functional.nll_loss(torch.log_softmax(outr[mask], 1), y[mask]) + 0.5 * regr
+        lossr.backward()
+        torch.testing.assert_close(out.detach(), part.slice_rows(outr.detach()), atol=1e-5, rtol=1e-5)
+        torch.testing.assert_close(total, lossr.detach(), atol=1e-5, rtol=1e-5)
+        for got, ref in [(w1.grad, w1r.grad), (w2.grad, w2r.grad), (b1.grad, b1r.grad), (le_l.grad, part.slice_rows(ler.grad))]:
+            torch.testing.assert_close(got, ref, atol=2e-5, rtol=1e-4)
+        q.put((rank, 'ok'))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, 'FAIL ' + traceback.format_exc()[-1500:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name', ['case_graph_asym_multi', 'case_graph_powerlaw_d7_d64'])
+def test_sharded_exchange_matches_unsharded_oracle(name):
+    import oracle_c
+    oracle_c.load()                      # build the C restatement before forking
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r, msg in res:
+        assert msg == 'ok', f'rank {r}: {msg}'
+
+
+def test_partition_bookkeeping():
+    from gnn_tail_generalization_amd.dist import Partition
+    for n, w in [(10, 3), (8, 2), (7, 8), (1000001, 8)]:
+        parts = [Partition(n, w, r) for r in range(w)]
+        assert parts[0].lo() == 0 and parts[-1].hi() == n
+        assert all(parts[i].hi() == parts[i + 1].lo() for i in range(w - 1))
+        assert sum(p.n_local for p in parts) == n and parts[0].padded >= n
+        ids = torch.arange(n)
+        own = parts[0].owner(ids)
+        for p in parts:
+            assert (own[p.lo():p.hi()] == p.rank).all()

@@ -61,3 +61,38 @@ def test_cli_end_to_end_tiny():
     finally:
         os.chdir(cwd)
     assert len(recs) == 1 and recs[0].shape == (4, 3) and np.isfinite(recs[0]).all()
+
+
+def test_sharded_trainer_world1_matches_plain_trainer():
+    """The node-sharded code path (rectangular row-slice CSR, all-gather exchange, grad all-reduce) on one
+    rank reproduces the plain trainer's losses on the same seeded data."""
+    import contextlib
+    import io
+    import os
+    import torch.distributed as dist
+    from gnn_tail_generalization_amd import ops
+    from gnn_tail_generalization_amd.base_options import BaseOptions
+    from gnn_tail_generalization_amd.dist import ShardedTrainer
+    from gnn_tail_generalization_amd.trainer_node_classification import trainer
+    argv = ['--dataset=S-tiny', '--use_special_split=0', '--want_headtail=0', '--whetherHasSE=111', '--se_reg=0.5',
+            '--num_layers=3', '--manual_assign_GPU=0', '--do_deg_analyze=0']
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        losses = []
+        for cls in (trainer, ShardedTrainer):
+            with contextlib.redirect_stdout(io.StringIO()):
+                args = BaseOptions().get_arguments(argv)
+                args.random_seed = 0
+                torch.manual_seed(0)
+                t = cls(args, 0)
+                torch.manual_seed(0)
+                t.setup_teacherGNN()
+            ops._seed_override[:] = list(range(500, 530))
+            losses.append([float(t.train_step()) for _ in range(4)])
+            ops._seed_override[:] = []
+        np.testing.assert_allclose(losses[0], losses[1], rtol=1e-5)
+    finally:
+        dist.destroy_process_group()
