@@ -151,6 +151,10 @@ def main():
     avg_ms = sum(spmm_ms) / max(len(spmm_ms), 1)
     avg_bytes = sum(spmm_bytes) / max(len(spmm_bytes), 1)
     achieved = avg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    if sharded:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
         return
     traffic = None
@@ -175,7 +179,7 @@ def main():
     }
     if a.cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(a, n_nodes)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

@@ -81,7 +81,8 @@ int cb_spmm_hub_fill(const int32_t* rowptr, int64_t N, int32_t hub_threshold, in
  * row_scale / bias may be NULL (factor 1 / no bias); relu = 0/1.  Called with the by-dst
  * CSR for the forward and with the by-src CSR (no epilogue) for the backward
  * (autograd of gspmm = SpMM on the reverse graph).
- * `ws` holds the hub partial sums: cb_spmm_workspace_bytes(n_chunks, d).
+ * `ws` holds the hub partial sums: cb_spmm_workspace_bytes(n_chunks, d).  With n_hubs == 0 (no plan) every
+ * row is reduced whole by one wavefront — correct for any graph, slow for power-law hubs.
  * Deterministic: every row is reduced in CSR order by one wavefront, hub rows in chunk order.
  * ---------------------------------------------------------------------------------- */
 size_t cb_spmm_workspace_bytes(int64_t n_chunks, int64_t d);
