@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn import init
 
-from .. import gemm, ops
+from .. import gemm, ops, trunk
 from ..graph import CSRGraph, DGLError
 from .drop_tricks import DropoutTrick
 from .norm_tricks import AcontainsB, appendNormLayer, run_norm_if_any
@@ -85,10 +85,14 @@ class TricksComb(nn.Module):
             self.dglgraph = CSRGraph(edge_index)
         return self.dglgraph
 
+    use_fused_trunk = True   # 'Initial' connection without a bare norm runs as one fused autograd node (trunk.py)
+
     def forward(self, x, edge_index, want_les=False):
         graph = self._graph(edge_index)
         x_list, le_collection, se_reg_all = [], [], None
         new_adjs = self.graph_dropout(edge_index)      # computed and discarded, as in the reference (GCN.py:101,111)
+        if self.use_fused_trunk and trunk.eligible(self, x, want_les):
+            return trunk.forward(self, x, graph)
         row0 = getattr(graph, 'row_offset', 0)     # first global row of this rank's shard (0 on one GPU)
         if self.has_residual_MLP:
             x = ops.dropout(x, self.embedding_dropout, self.training, offset=row0 * x.shape[1])

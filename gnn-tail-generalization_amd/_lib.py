@@ -43,6 +43,12 @@ SIGNATURES = {
     'cb_gemm_nn_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int, _P]),
     'cb_gemm_tn_workspace_bytes': (_SZ, [_I64, _I64, _I64]),
     'cb_gemm_tn_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _SZ, _P]),
+    'cb_spmm_csr_fused_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,
+                                             ctypes.c_float, ctypes.c_uint64, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P,
+                                             _P, _SZ, _P]),
+    'cb_trunk_layer_bwd_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, _I64, _I64, ctypes.c_float, ctypes.c_uint64, _I64,
+                                              ctypes.c_float, ctypes.c_float, _P, _P, _SZ, _P]),
+    'cb_trunk_input_bwd_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64, ctypes.c_float, ctypes.c_uint64, _I64, _P, _P, _SZ, _P]),
 }
 
 _lib = None

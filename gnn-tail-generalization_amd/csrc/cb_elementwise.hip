@@ -3,6 +3,7 @@
 // All fp32, 16-byte vector accesses when the data allows it, grid-stride loops capped at
 // 256 CUs x 8 blocks, reductions in a fixed two-stage order (no float atomics -> bit-reproducible).
 #include "cb_common.h"
+#include "cb_philox.h"
 
 namespace cb {
 
@@ -13,33 +14,6 @@ static inline int grid_for(int64_t work_items) {
   int64_t b = (work_items + kBlock - 1) / kBlock;
   if (b < 1) b = 1;
   return (int)(b > kMaxBlocks ? kMaxBlocks : b);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Counter-based RNG: Philox4x32-10 keyed by (seed), counter = element index / 4.  The mask of an
-// element depends only on (seed, flat index), so forward and backward regenerate it instead of
-// storing it (F.dropout of GCN.py:104,110,133 cannot be matched bit-for-bit on any device; parity
-// is defined with injected masks).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
-  uint32_t c2 = 0x243F6A88u, c3 = 0x85A308D3u;
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-__device__ __forceinline__ void keep4(uint64_t seed, int64_t quad, uint32_t thresh, float scale, float (&m)[4]) {
-  uint32_t r[4];
-  philox4x32_10((uint32_t)quad, (uint32_t)((uint64_t)quad >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) m[i] = (r[i] >= thresh) ? scale : 0.f;
 }
 
 // out[i] = x[i] * keep(offset + i) / (1 - p).  `offset` is the flat index of x[0] in the logical
@@ -152,6 +126,81 @@ __global__ void __launch_bounds__(kBlock) k_act_bwd(const float* __restrict__ g,
           for (int k = 0; k < 4; ++k) t[k] += s_red[(j * tx + cx) * 4 + k];
         for (int k = 0; k < 4; ++k)
           if (c + k < d) partial[(int64_t)blockIdx.x * d + c + k] = t[k];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the fused aggregation epilogue of the residual trunk, one pass over [rows, d], d % 256 == 0:
+//   gm = g * keep(seed, row0 + r, c) / (1 - p)            dropout backward (thresh == 0: gm = g)
+//   gx0 = (accumulate ? gx0 : 0) + c_mix * gm             gradient flowing to the mixed-in tensor (X0)
+//   gy  = c_act * gm * relu_bit(r, c)                      mix + ReLU backward (mask bits written by the forward)
+//   colsum(gy) -> dbias partials;  out = gy * row_scale[r] (input of the reverse-graph aggregation)
+// One wavefront per row per iteration, lane l owns columns 4l..4l+3 of each 256-wide tile (same mapping as
+// the forward epilogue, so mask word k is tested at bit l).
+// MODE 0: the layer kernel above.  MODE 1: trunk input stage  gy = (add + gm) * (act > 0); out = gy; colsum(gy).
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ g, const unsigned long long* __restrict__ bits,
+                                                      const float* __restrict__ act, const float* __restrict__ row_scale,
+                                                      float* __restrict__ out, float* __restrict__ gx0, int accumulate,
+                                                      int64_t rows, int d, uint32_t thresh, float keep_scale, uint64_t seed,
+                                                      int64_t row0, float c_act, float c_mix, float* __restrict__ partial) {
+  extern __shared__ float s_red[];  // [4 waves][256 cols] per tile pass
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int tiles = d >> 8;
+  const int64_t rows_per_block = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r_end = min(rows, r_begin + rows_per_block);
+  for (int tile = 0; tile < tiles; ++tile) {
+    const int c = tile * 256 + lane * 4;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t r = r_begin + w; r < r_end; r += kBlock / kWave) {
+      const int64_t off = r * d + c;
+      const float4 gv = *reinterpret_cast<const float4*>(g + off);
+      float gm[4] = {gv.x, gv.y, gv.z, gv.w};
+      if (thresh) {
+        float m[4];
+        keep4(seed, ((row0 + r) * d + c) >> 2, thresh, keep_scale, m);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gm[k] *= m[k];
+      }
+      float gy[4];
+      if (MODE == 0) {
+        if (gx0) {
+          float4 a = accumulate ? *reinterpret_cast<const float4*>(gx0 + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+          a.x += c_mix * gm[0]; a.y += c_mix * gm[1]; a.z += c_mix * gm[2]; a.w += c_mix * gm[3];
+          *reinterpret_cast<float4*>(gx0 + off) = a;
+        }
+        const unsigned long long* bw = bits + (r * tiles + tile) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gy[k] = ((bw[k] >> lane) & 1ull) ? c_act * gm[k] : 0.f;
+      } else {
+        const float4 a = *reinterpret_cast<const float4*>(gx0 + off);
+        const float4 x = *reinterpret_cast<const float4*>(act + off);
+        gy[0] = x.x > 0.f ? a.x + gm[0] : 0.f;
+        gy[1] = x.y > 0.f ? a.y + gm[1] : 0.f;
+        gy[2] = x.z > 0.f ? a.z + gm[2] : 0.f;
+        gy[3] = x.w > 0.f ? a.w + gm[3] : 0.f;
+      }
+      const float sc = row_scale ? row_scale[r] : 1.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s[k] += gy[k];
+      *reinterpret_cast<float4*>(out + off) = make_float4(gy[0] * sc, gy[1] * sc, gy[2] * sc, gy[3] * sc);
+    }
+    if (partial) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s_red[(w * 64 + lane) * 4 + k] = s[k];
+      __syncthreads();
+      if (w == 0) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < kBlock / kWave; ++j)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) t[k] += s_red[(j * 64 + lane) * 4 + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) partial[(int64_t)blockIdx.x * d + c + k] = t[k];
       }
       __syncthreads();
     }
@@ -300,8 +349,7 @@ extern "C" int cb_dropout_f32(const float* x, float* out, int64_t n, float p, ui
   CB_CHECK_ARG(n >= 0 && offset >= 0 && (n == 0 || (x && out)) && p >= 0.f && p < 1.f, CB_E_INVALID,
                "cb_dropout_f32: bad argument (p=%f)", p);
   if (n == 0) return CB_OK;
-  const double t = (double)p * 4294967296.0;
-  const uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  const uint32_t thresh = dropout_threshold(p);
   const int vec_ok = aligned16(x) && aligned16(out);
   hipLaunchKernelGGL(k_dropout, dim3(grid_for((n + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, x, out, n, thresh,
                      1.f / (1.f - p), seed, offset, vec_ok);
@@ -391,4 +439,54 @@ extern "C" int cb_adam_step_f32(float* p, const float* g, float* m, float* v, in
                      eps, weight_decay, (float)bc1, (float)sqrt(bc2), vec_ok);
   CB_LAUNCH_CHECK();
   return CB_OK;
+}
+
+static int launch_trunk_bwd(int mode, const float* g, const uint64_t* bits, const float* act, const float* row_scale, float* out,
+                            float* gx0, int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed, int64_t row0,
+                            float c_act, float c_mix, float* colsum, void* ws, size_t ws_bytes, hipStream_t st) {
+  int64_t nb = (rows + 63) / 64;
+  if (nb > kMaxBlocks) nb = kMaxBlocks;
+  const uint32_t thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
+  const float ks = 1.f / (1.f - drop_p);
+  float* partial = colsum ? (float*)ws : nullptr;
+  if (mode == 0)
+    hipLaunchKernelGGL((k_trunk_bwd<0>), dim3((unsigned)nb), dim3(kBlock), kBlock * 4 * sizeof(float), st, g,
+                       (const unsigned long long*)bits, act, row_scale, out, gx0, accumulate, rows, (int)d, thresh, ks, seed, row0,
+                       c_act, c_mix, partial);
+  else
+    hipLaunchKernelGGL((k_trunk_bwd<1>), dim3((unsigned)nb), dim3(kBlock), kBlock * 4 * sizeof(float), st, g,
+                       (const unsigned long long*)bits, act, row_scale, out, gx0, accumulate, rows, (int)d, thresh, ks, seed, row0,
+                       c_act, c_mix, partial);
+  CB_LAUNCH_CHECK();
+  if (colsum) {
+    hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, (const float*)ws, (int)nb, (int)d, colsum);
+    CB_LAUNCH_CHECK();
+  }
+  return CB_OK;
+}
+
+extern "C" int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits, const float* row_scale, float* out, float* gx0,
+                                      int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed, int64_t row0, float c_act,
+                                      float c_mix, float* colsum, void* ws, size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(rows >= 0 && d > 0 && d % 256 == 0 && d < (1 << 20), CB_E_INVALID, "cb_trunk_layer_bwd_f32: d must be a multiple of 256");
+  if (rows == 0) return CB_OK;
+  CB_CHECK_ARG(g && relu_bits && out && aligned16(g) && aligned16(out) && (!gx0 || aligned16(gx0)), CB_E_INVALID,
+               "cb_trunk_layer_bwd_f32: null or misaligned pointer");
+  CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, CB_E_INVALID, "cb_trunk_layer_bwd_f32: dropout p out of range");
+  CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_colsum_workspace_bytes(rows, d)), CB_E_WORKSPACE, "cb_trunk_layer_bwd_f32: workspace too small");
+  return launch_trunk_bwd(0, g, relu_bits, nullptr, row_scale, out, gx0, accumulate, rows, d, drop_p, seed, row0, c_act, c_mix, colsum,
+                          ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int cb_trunk_input_bwd_f32(const float* g, const float* add, const float* act, float* out, int64_t rows, int64_t d,
+                                      float drop_p, uint64_t seed, int64_t row0, float* colsum, void* ws, size_t ws_bytes,
+                                      void* stream) {
+  CB_CHECK_ARG(rows >= 0 && d > 0 && d % 256 == 0 && d < (1 << 20), CB_E_INVALID, "cb_trunk_input_bwd_f32: d must be a multiple of 256");
+  if (rows == 0) return CB_OK;
+  CB_CHECK_ARG(g && add && act && out && aligned16(g) && aligned16(add) && aligned16(act) && aligned16(out), CB_E_INVALID,
+               "cb_trunk_input_bwd_f32: null or misaligned pointer");
+  CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, CB_E_INVALID, "cb_trunk_input_bwd_f32: dropout p out of range");
+  CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_colsum_workspace_bytes(rows, d)), CB_E_WORKSPACE, "cb_trunk_input_bwd_f32: workspace too small");
+  return launch_trunk_bwd(1, g, nullptr, act, nullptr, out, const_cast<float*>(add), 1, rows, d, drop_p, seed, row0, 0.f, 0.f, colsum, ws,
+                          ws_bytes, (hipStream_t)stream);
 }

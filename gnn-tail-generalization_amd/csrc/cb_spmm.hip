@@ -22,6 +22,7 @@
 //   * streaming data (indices, output rows) uses non-temporal accesses so the 4 MiB L2s and
 //     the 256 MiB Infinity Cache keep the re-used neighbour rows (hub sources).
 #include "cb_common.h"
+#include "cb_philox.h"
 
 namespace cb {
 
@@ -76,6 +77,54 @@ struct Epilogue {
   int relu;
 };
 
+// Extended epilogue of the fused residual trunk (GCN.py:127-133 folded into the aggregation's store):
+//   act    = relu(row_scale * acc + bias)                      -> ReLU mask bits and/or the activation itself
+//   x_next = dropout_{seed}((1-alpha) * act + alpha * mix_src[row])   -> the next stage's input
+// Only for VEC = 4 full tiles (d % 256 == 0): lane l owns columns 4l..4l+3 of its 256-wide tile, the mask
+// word k of a (row, tile) holds the ballot of component k over the 64 lanes.
+struct FusedEpi {
+  const float* mix_src;   // [N, ld_mix] or null (no mix)
+  int64_t ld_mix;
+  float c_act, c_mix;     // (1 - alpha), alpha
+  uint32_t thresh;        // dropout threshold (0 = keep everything)
+  float keep_scale;       // 1 / (1 - p)
+  uint64_t seed;
+  int64_t row0;           // global index of local row 0 (node-sharded runs draw the unsharded mask)
+  unsigned long long* bits;  // [N][d/256][4] or null
+  float* out_act;         // [N, ld_act] or null
+  int64_t ld_act;
+  float* out_next;        // [N, ld_next]
+  int64_t ld_next;
+  int d;
+};
+
+__device__ __forceinline__ void fused_store(const FusedEpi& fe, int64_t row, int c0, const float (&acc)[4], float scale,
+                                            const float (&b)[4], const float (&rmix)[4]) {
+  float a[4], x[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = fmaxf(acc[i] * scale + b[i], 0.f);
+  if (fe.bits) {
+    const int lane = lane_id();
+    unsigned long long mine = 0ull;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned long long m = __ballot(a[k] > 0.f);
+      if (lane == k) mine = m;
+    }
+    if (lane < 4) fe.bits[(row * (fe.d >> 8) + (c0 >> 8)) * 4 + lane] = mine;
+  }
+  if (fe.out_act) store_stream<4>(fe.out_act + row * fe.ld_act + c0, a);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] = fe.mix_src ? fe.c_act * a[i] + fe.c_mix * rmix[i] : a[i];
+  if (fe.thresh) {
+    float m[4];
+    keep4(fe.seed, ((fe.row0 + row) * fe.d + c0) >> 2, fe.thresh, fe.keep_scale, m);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] *= m[i];
+  }
+  store_stream<4>(fe.out_next + row * fe.ld_next + c0, x);
+}
+
 template <int VEC>
 __device__ __forceinline__ void write_row(float* __restrict__ out_row, const float (&acc)[VEC], float scale,
                                           const float (&b)[VEC], int relu) {
@@ -91,11 +140,21 @@ __device__ __forceinline__ void write_row(float* __restrict__ out_row, const flo
 
 // Walks the contiguous edge range of local rows [rlo, rhi) of this wavefront's row block.
 // my_ptr: lane i holds rowptr[r0 + i] (i <= nr).  All control flow is wave-uniform.
-template <int VEC, int U, bool FULL>
-__device__ __forceinline__ void stream_rows(int rlo, int rhi, int my_ptr, float my_scale, int r0, const int* __restrict__ col,
+template <int VEC, int U, bool FULL, bool FUSED>
+__device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr, float my_scale, int r0, const int* __restrict__ col,
                                             const float* __restrict__ h_lane, int64_t ld_h, float* __restrict__ out_lane,
-                                            int64_t ld_out, bool active_in, int relu, const float (&bvec)[VEC]) {
+                                            int64_t ld_out, bool active_in, int relu, const float (&bvec)[VEC], const FusedEpi& fe,
+                                            int c0) {
   const bool active = FULL ? true : active_in;
+  float rmix[4] = {0.f, 0.f, 0.f, 0.f};   // FUSED: mix_src row of local row `cur`, fetched one row ahead
+  if constexpr (FUSED) {
+    if (fe.mix_src) {
+      float t[VEC];
+      gather<VEC>(t, fe.mix_src + (int64_t)(r0 + rlo) * fe.ld_mix + c0);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) rmix[i] = t[i];
+    }
+  }
   const int lane = lane_id();
   const int e_begin = bcast_lane(my_ptr, rlo);
   const int e_end = bcast_lane(my_ptr, rhi);
@@ -105,8 +164,19 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int my_ptr, float 
   zero<VEC>(acc);
 
   auto flush = [&]() {
-    if (active) {
-      const float s = __int_as_float(bcast_lane(__float_as_int(my_scale), cur));  // row scale of local row `cur`
+    const float s = __int_as_float(bcast_lane(__float_as_int(my_scale), cur));  // row scale of local row `cur`
+    if constexpr (FUSED) {
+      float a4[4], b4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a4[i] = acc[i % VEC]; b4[i] = bvec[i % VEC]; }
+      fused_store(fe, (int64_t)(r0 + cur), c0, a4, s, b4, rmix);
+      if (fe.mix_src && cur + 1 < nr) {
+        float t[VEC];
+        gather<VEC>(t, fe.mix_src + (int64_t)(r0 + cur + 1) * fe.ld_mix + c0);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) rmix[i] = t[i];
+      }
+    } else if (active) {
       write_row<VEC>(out_lane + (int64_t)(r0 + cur) * ld_out, acc, s, bvec, relu);
     }
     zero<VEC>(acc);
@@ -149,10 +219,11 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int my_ptr, float 
   while (cur < rhi) flush();  // last row + trailing empty rows
 }
 
-template <int VEC, int RPW, int U, bool FULL>
+template <int VEC, int RPW, int U, bool FULL, bool FUSED>
 __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                    const float* __restrict__ h, int64_t ld_h, float* __restrict__ out,
-                                                   int64_t ld_out, int n_rows, int d, Epilogue ep, int hub_T) {
+                                                   int64_t ld_out, int n_rows, int d, Epilogue ep, int hub_T, FusedEpi fe) {
+  static_assert(!FUSED || (VEC == 4 && FULL), "fused epilogue: d % 256 == 0, float4 lanes");
   static_assert(RPW < kWave, "row block must fit the lanes of one wavefront (+1 end pointer)");
   const int lane = lane_id();
   const int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -178,13 +249,13 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
   float* out_lane = out + c0;
 
   if (hubmask == 0) {
-    stream_rows<VEC, U, FULL>(0, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec);
+    stream_rows<VEC, U, FULL, FUSED>(0, nr, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0);
   } else {
     int r = 0;
     while (r < nr) {  // maximal hub-free runs; hub rows are written by the hub kernels
       unsigned long long m = hubmask >> r;
       int nh = m ? r + (__ffsll((long long)m) - 1) : nr;
-      if (nh > r) stream_rows<VEC, U, FULL>(r, nh, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec);
+      if (nh > r) stream_rows<VEC, U, FULL, FUSED>(r, nh, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0);
       r = nh + 1;
     }
   }
@@ -250,11 +321,11 @@ __global__ void __launch_bounds__(256) k_spmm_hub_chunks(const int* __restrict__
 }
 
 // One wavefront per hub row: partials summed in chunk order, then the epilogue.
-template <int VEC>
+template <int VEC, bool FUSED>
 __global__ void __launch_bounds__(256) k_spmm_hub_finish(int d, int n_hubs, const int* __restrict__ hub_rows,
                                                          const int* __restrict__ hub_chunk_ptr,
                                                          const float* __restrict__ partial, int64_t ld_p,
-                                                         float* __restrict__ out, int64_t ld_out, Epilogue ep) {
+                                                         float* __restrict__ out, int64_t ld_out, Epilogue ep, FusedEpi fe) {
   const int lane = lane_id();
   const int i = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   if (i >= n_hubs) return;
@@ -276,15 +347,29 @@ __global__ void __launch_bounds__(256) k_spmm_hub_finish(int d, int n_hubs, cons
     for (int k = 0; k < VEC; ++k) bvec[k] = ep.bias[c0 + k];
   }
   float s = ep.row_scale ? ep.row_scale[row] : 1.f;
-  write_row<VEC>(out + (int64_t)row * ld_out + c0, acc, s, bvec, ep.relu);
+  if constexpr (FUSED) {
+    float a4[4], b4[4], rmix[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a4[k] = acc[k % VEC]; b4[k] = bvec[k % VEC]; }
+    if (fe.mix_src) {
+      float t[VEC];
+      gather<VEC>(t, fe.mix_src + (int64_t)row * fe.ld_mix + c0);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) rmix[k] = t[k];
+    }
+    fused_store(fe, (int64_t)row, c0, a4, s, b4, rmix);
+  } else {
+    write_row<VEC>(out + (int64_t)row * ld_out + c0, acc, s, bvec, ep.relu);
+  }
 }
 
 static inline int64_t partial_ld(int64_t d) { return (d + 3) / 4 * 4; }
 
-template <int VEC>
+template <int VEC, bool FUSED = false>
 static int launch_spmm(const int32_t* rowptr, const int32_t* col, int64_t N, const float* h, int64_t ld_h, int64_t d,
                        Epilogue ep, float* out, int64_t ld_out, int hub_T, int n_hubs, int n_chunks,
-                       const int32_t* hub_rows, const int32_t* hub_chunk_ptr, float* partial, hipStream_t st) {
+                       const int32_t* hub_rows, const int32_t* hub_chunk_ptr, float* partial, hipStream_t st,
+                       FusedEpi fe = FusedEpi{}) {
   constexpr int RPW = 16;
   constexpr int U = (VEC == 4) ? 8 : 8;
   const int tile = kWave * VEC;
@@ -293,12 +378,16 @@ static int launch_spmm(const int32_t* rowptr, const int32_t* col, int64_t N, con
   {
     int64_t n_waves = (N + RPW - 1) / RPW;
     dim3 grid((unsigned)((n_waves + waves_per_block - 1) / waves_per_block), ny);
-    if (d % tile == 0)
-      hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, true>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h,
-                         out, ld_out, (int)N, (int)d, ep, hub_T);
-    else
-      hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, false>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h,
-                         out, ld_out, (int)N, (int)d, ep, hub_T);
+    if constexpr (FUSED) {
+      hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, true, true>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h,
+                         out, ld_out, (int)N, (int)d, ep, hub_T, fe);
+    } else if (d % tile == 0) {
+      hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, true, false>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h,
+                         out, ld_out, (int)N, (int)d, ep, hub_T, fe);
+    } else {
+      hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, false, false>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h,
+                         out, ld_out, (int)N, (int)d, ep, hub_T, fe);
+    }
     CB_LAUNCH_CHECK();
   }
   if (n_hubs > 0) {
@@ -308,8 +397,8 @@ static int launch_spmm(const int32_t* rowptr, const int32_t* col, int64_t N, con
                        hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, ld_p);
     CB_LAUNCH_CHECK();
     dim3 grid2((unsigned)((n_hubs + waves_per_block - 1) / waves_per_block), ny);
-    hipLaunchKernelGGL((k_spmm_hub_finish<VEC>), grid2, dim3(kWave * waves_per_block), 0, st, (int)d, n_hubs, hub_rows,
-                       hub_chunk_ptr, partial, ld_p, out, ld_out, ep);
+    hipLaunchKernelGGL((k_spmm_hub_finish<VEC, FUSED>), grid2, dim3(kWave * waves_per_block), 0, st, (int)d, n_hubs, hub_rows,
+                       hub_chunk_ptr, partial, ld_p, out, ld_out, ep, fe);
     CB_LAUNCH_CHECK();
   }
   return CB_OK;
@@ -348,4 +437,34 @@ extern "C" int cb_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_
   if (al8 && d >= 128)
     return launch_spmm<2>(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st);
   return launch_spmm<1>(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st);
+}
+
+extern "C" int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h,
+                                     int64_t d, const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix,
+                                     float c_act, float c_mix, float drop_p, uint64_t seed, int64_t row0, uint64_t* relu_bits,
+                                     float* out_act, int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_T,
+                                     int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr,
+                                     void* ws, size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(N >= 0 && E >= 0 && d > 0 && d % 256 == 0, CB_E_INVALID, "cb_spmm_csr_fused_f32: d must be a positive multiple of 256");
+  CB_CHECK_ARG(N < INT32_MAX && E < INT32_MAX && d < (1 << 20), CB_E_RANGE, "cb_spmm_csr_fused_f32: size exceeds the int32 contract");
+  if (N == 0) return CB_OK;
+  CB_CHECK_ARG(rowptr && h && out_next && (E == 0 || col), CB_E_INVALID, "cb_spmm_csr_fused_f32: null pointer");
+  CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, CB_E_INVALID, "cb_spmm_csr_fused_f32: dropout p out of range");
+  const bool al = ((uintptr_t)h % 16 == 0) && ((uintptr_t)out_next % 16 == 0) && ld_h % 4 == 0 && ld_next % 4 == 0 &&
+                  (!mix_src || ((uintptr_t)mix_src % 16 == 0 && ld_mix % 4 == 0)) &&
+                  (!out_act || ((uintptr_t)out_act % 16 == 0 && ld_act % 4 == 0));
+  CB_CHECK_ARG(al && ld_h >= d && ld_next >= d, CB_E_INVALID, "cb_spmm_csr_fused_f32: 16-byte aligned rows required");
+  CB_CHECK_ARG(hub_T > 0 && n_hubs >= 0 && n_chunks >= 0, CB_E_INVALID, "cb_spmm_csr_fused_f32: bad hub plan");
+  CB_CHECK_ARG(n_hubs == 0 || (hub_rows && hub_chunk_ptr && ws && ws_bytes >= cb_spmm_workspace_bytes(n_chunks, d)),
+               CB_E_WORKSPACE, "cb_spmm_csr_fused_f32: hub plan given but workspace missing/too small");
+  if (n_hubs == 0) hub_T = INT32_MAX;
+  Epilogue ep{row_scale, bias, 1};
+  FusedEpi fe{};
+  fe.mix_src = mix_src; fe.ld_mix = ld_mix; fe.c_act = c_act; fe.c_mix = c_mix;
+  fe.thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
+  fe.keep_scale = 1.f / (1.f - drop_p);
+  fe.seed = seed; fe.row0 = row0; fe.bits = (unsigned long long*)relu_bits;
+  fe.out_act = out_act; fe.ld_act = ld_act; fe.out_next = out_next; fe.ld_next = ld_next; fe.d = (int)d;
+  return launch_spmm<4, true>(rowptr, col, N, h, ld_h, d, ep, out_next, ld_next, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr,
+                              (float*)ws, (hipStream_t)stream, fe);
 }

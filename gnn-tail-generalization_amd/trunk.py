@@ -1,0 +1,210 @@
+"""Fused residual trunk of TricksComb.forward for the 'Initial' connection without a bare norm — the
+configuration the reference's best-config table selects for Pubmed / ogbn-arxiv ('InitialBatchNorm',
+base_options.py:416) and the benchmark graphs.  One autograd node for
+
+    X0   = relu(Linear_0(dropout(x)))                                   GCN.py:103-107
+    for l: X  = dropout(X);  Y = GCNConv_l(X);  A = relu(Y);  X = (1-a) A + a X0      GCN.py:109-131
+    out  = Linear_1(dropout(X))                                          GCN.py:133-138
+
+with the hand-written backward.  Per layer the forward is exactly two kernels (MFMA GEMM with
+row-scale/+E epilogue, aggregation with ReLU-mask/mix/dropout epilogue) and the backward four
+(fused elementwise, reverse aggregation, two GEMMs); ReLU masks are kept as bits, dropout masks are
+regenerated, the gradient w.r.t. X0 is accumulated in place.  Same arithmetic and the same sequence
+of dropout seeds as the modular path (ops.py), which stays the general fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib, gemm, ops
+
+
+def eligible(tc, x, want_les):
+    t = tc.type_trick
+    return (tc.has_residual_MLP and 'Initial' in t and 'Residual' not in t and 'Jumping' not in t and not want_les
+            and tc.args.type_trick not in ('BatchNorm', 'PairNorm', 'NodeNorm', 'MeanNorm', 'GroupNorm', 'CombNorm')
+            and tc.dim_hidden % 256 == 0 and x.is_cuda and x.dtype == torch.float32 and len(tc.layers_GCN) == tc.num_layers
+            and len(tc.layers_MLP) == 2)
+
+
+def _graph_parts(graph):
+    """(local forward CSRGraph, local backward CSRGraph or None(=use transpose), partition or None)"""
+    if hasattr(graph, 'part'):
+        return graph.fwd, graph.bwd, graph
+    return graph, None, None
+
+
+def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False):
+    """(bits, out_next[, act]) of cb_spmm_csr_fused_f32 on the (possibly node-sharded) graph."""
+    lib = _lib.load()
+    g, _, sh = _graph_parts(graph)
+    if sh is not None:
+        from .dist import gather_rows
+        z = gather_rows(z, sh.part, sh.group)
+    n, d = g.N, z.shape[1]
+    dev = z.device
+    bits = torch.empty((n, d // 256, 4), dtype=torch.int64, device=dev)
+    out_next = torch.empty((n, d), dtype=torch.float32, device=dev)
+    act = torch.empty((n, d), dtype=torch.float32, device=dev) if want_act else None
+    plan = g._plan
+    wsb = lib.cb_spmm_workspace_bytes(plan.n_chunks, d)
+    ws = g._workspace(wsb)
+    prof = getattr(graph, 'profile', None)
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    with torch.cuda.device(dev):
+        _lib.check(lib.cb_spmm_csr_fused_f32(
+            _lib.ptr(g.rowptr), _lib.ptr(g.col), n, g.E, _lib.ptr(z), z.stride(0), d, _lib.ptr(graph.norm_in), _lib.ptr(bias),
+            _lib.ptr(x0), x0.stride(0) if x0 is not None else 0, float(c_act), float(c_mix), float(p), ctypes.c_uint64(seed),
+            int(getattr(graph, 'row_offset', 0)), _lib.ptr(bits), _lib.ptr(act), d, _lib.ptr(out_next), d, g.hub_threshold,
+            plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), wsb,
+            _lib.stream_ptr()), 'cb_spmm_csr_fused_f32')
+    if prof is not None:
+        ev1.record()
+        # algorithmic bytes of the fused launch: the plain aggregation + the mixed-in row read + the mask bits
+        prof.append((ev0, ev1, g.algorithmic_bytes(d) + n * d * 4 + n * d // 8))
+    return bits, out_next, act
+
+
+def _spmm_t(graph, gr):
+    g, gb, sh = _graph_parts(graph)
+    if sh is not None:
+        from .dist import gather_rows
+        gb.profile = getattr(graph, 'profile', None)
+        return gb.spmm(gather_rows(gr, sh.part, sh.group))
+    return g.spmm(gr, transpose=True)
+
+
+def _layer_bwd(g, bits, row_scale, gx0, accumulate, p, seed, row0, c_act, c_mix, want_colsum):
+    lib = _lib.load()
+    rows, d = g.shape
+    out = torch.empty_like(g)
+    colsum = torch.empty(d, dtype=torch.float32, device=g.device) if want_colsum else None
+    wsb = lib.cb_colsum_workspace_bytes(rows, d) if want_colsum else 0
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=g.device)
+    with torch.cuda.device(g.device):
+        _lib.check(lib.cb_trunk_layer_bwd_f32(_lib.ptr(g), _lib.ptr(bits), _lib.ptr(row_scale), _lib.ptr(out), _lib.ptr(gx0),
+                                              int(accumulate), rows, d, float(p), ctypes.c_uint64(seed), int(row0), float(c_act),
+                                              float(c_mix), _lib.ptr(colsum), _lib.ptr(ws), wsb, _lib.stream_ptr()),
+                   'cb_trunk_layer_bwd_f32')
+    return out, colsum
+
+
+def _input_bwd(g, add, act, p, seed, row0):
+    lib = _lib.load()
+    rows, d = g.shape
+    out = torch.empty_like(g)
+    colsum = torch.empty(d, dtype=torch.float32, device=g.device)
+    wsb = lib.cb_colsum_workspace_bytes(rows, d)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=g.device)
+    with torch.cuda.device(g.device):
+        _lib.check(lib.cb_trunk_input_bwd_f32(_lib.ptr(g), _lib.ptr(add), _lib.ptr(act), _lib.ptr(out), rows, d, float(p),
+                                              ctypes.c_uint64(seed), int(row0), _lib.ptr(colsum), _lib.ptr(ws), wsb,
+                                              _lib.stream_ptr()), 'cb_trunk_input_bwd_f32')
+    return out, colsum
+
+
+class _TrunkFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, graph, cfg, x, w_in, b_in, w_out, b_out, *layer_params):
+        """layer_params = (W_0, bias_0, le_0 | None, W_1, ...).  cfg = (L, alpha, p, seeds)."""
+        L, alpha, p, seeds = cfg
+        row0 = int(getattr(graph, 'row_offset', 0))
+        a = graph.norm_out
+        x = x.contiguous()
+        xd = ops._dropout_raw(x, p, seeds[0], row0 * x.shape[1]) if p > 0 else x
+        x0 = gemm.mm_nn(xd, w_in.t().contiguous(), bias=b_in, relu=True)
+        h = x0.shape[1]
+        cur = ops._dropout_raw(x0, p, seeds[1], row0 * h) if p > 0 else x0
+        saved_in, saved_bits = [cur], []
+        for l in range(L):
+            w, b, le = layer_params[3 * l: 3 * l + 3]
+            z = gemm.mm_nn(cur, w, rowscale=a, addend=le)
+            bits, cur, _ = _fused_spmm(graph, z, b, x0, 1 - alpha, alpha, p, seeds[l + 2] if p > 0 else 0)
+            del z
+            saved_bits.append(bits)
+            saved_in.append(cur)
+        out = gemm.mm_nn(cur, w_out.t().contiguous(), bias=b_out)
+        ctx.graph, ctx.cfg, ctx.row0 = graph, cfg, row0
+        ctx.n_layer_params = len(layer_params)
+        ctx.save_for_backward(xd, x0, w_in, w_out, *saved_in, *saved_bits, *[t for t in layer_params if t is not None])
+        ctx.le_present = [layer_params[3 * l + 2] is not None for l in range(L)]
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        graph, (L, alpha, p, seeds), row0 = ctx.graph, ctx.cfg, ctx.row0
+        sv = list(ctx.saved_tensors)
+        xd, x0, w_in, w_out = sv[:4]
+        saved_in = sv[4: 4 + L + 1]
+        saved_bits = sv[4 + L + 1: 4 + 2 * L + 1]
+        rest = sv[4 + 2 * L + 1:]
+        lp, k = [], 0
+        for l in range(L):
+            w, b = rest[k], rest[k + 1]
+            k += 2
+            le = None
+            if ctx.le_present[l]:
+                le = rest[k]
+                k += 1
+            lp.append((w, b, le))
+        a, bnorm = graph.norm_out, graph.norm_in
+        need = ctx.needs_input_grad       # (graph, cfg, x, w_in, b_in, w_out, b_out, *layer_params)
+        gout = gemm._rowmajor(gout)
+        h = x0.shape[1]
+        # output Linear (GCN.py:138)
+        xl = saved_in[L]
+        d_w_out = gemm.mm_tn(gout, xl) if need[5] else None
+        d_b_out = ops.act_bwd(gout, None, None, want_out=False, want_colsum=True)[1] if need[6] else None
+        g = gemm.mm_nn(gout, w_out)                                  # dL/d(dropped X_L)
+        gx0 = torch.empty_like(x0)
+        grads_layers = [None] * (3 * L)
+        for l in range(L - 1, -1, -1):
+            w, b, le = lp[l]
+            gr, dbias = _layer_bwd(g, saved_bits[l], bnorm, gx0, l != L - 1, p, seeds[l + 2] if p > 0 else 0, row0, 1 - alpha, alpha,
+                                   need[7 + 3 * l + 1])
+            del g
+            gz = _spmm_t(graph, gr)                                 # dL/dZ_l = A (b * dY')
+            del gr
+            if need[7 + 3 * l]:
+                grads_layers[3 * l] = gemm.mm_tn(saved_in[l], gz, rowscale=a)
+            grads_layers[3 * l + 1] = dbias
+            g = gemm.mm_nn(gz, w.t().contiguous(), rowscale=a)       # dL/d(dropped X_l)
+            if le is not None and need[7 + 3 * l + 2]:
+                grads_layers[3 * l + 2] = gz
+            else:
+                del gz
+        # input stage: X0 feeds layer 0 (through its dropout) and every mix
+        gpre, d_b_in = _input_bwd(g, gx0, x0, p, seeds[1] if p > 0 else 0, row0)
+        del g, gx0
+        d_w_in = gemm.mm_tn(gpre, xd) if need[3] else None
+        d_x = None
+        if need[2]:
+            d_x = gemm.mm_nn(gpre, w_in)
+            if p > 0:
+                d_x = ops._dropout_raw(d_x, p, seeds[0], row0 * d_x.shape[1])
+        return (None, None, d_x, d_w_in, d_b_in if need[4] else None, d_w_out, d_b_out, *grads_layers)
+
+
+def forward(tc, x, graph):
+    """TricksComb.forward on the fused trunk; returns (logits, se_reg_all)."""
+    L = tc.num_layers
+    p = float(tc.dropout) if tc.training else 0.0
+    if tc.embedding_dropout != tc.dropout or tc.args.dropout != tc.dropout:
+        raise RuntimeError('fused trunk expects one dropout rate (args.dropout)')
+    seeds = tuple(ops.next_seed() for _ in range(L + 2)) if p > 0 else (0,) * (L + 2)
+    params, se_reg_all = [], None
+    for conv in tc.layers_GCN:
+        le = conv.le if conv.whetherHasSE else None
+        params += [conv.weight, conv.bias, le]
+        if le is not None:
+            reg = ops.frobenius_norm(le)
+            if hasattr(graph, 'part'):
+                from .dist import allreduce_sum
+                reg = allreduce_sum(reg * reg, graph.group).sqrt()
+            se_reg_all = reg if se_reg_all is None else se_reg_all + reg
+    graph.check_zero_in_degree()
+    out = _TrunkFn.apply(graph, (L, float(tc.alpha), p, seeds), x, tc.layers_MLP[0].weight, tc.layers_MLP[0].bias,
+                         tc.layers_MLP[1].weight, tc.layers_MLP[1].bias, *params)
+    return out, se_reg_all

@@ -154,6 +154,35 @@ size_t cb_gemm_tn_workspace_bytes(int64_t M, int64_t K1, int64_t K2);
 int cb_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, const float* rowscale, float* C, int64_t M,
                    int64_t K1, int64_t K2, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Fused residual trunk (type_trick with 'Initial', no bare norm: the default configs of
+ * Pubmed / ogbn-arxiv / the synthetic power-law benchmark).  Folds GCN.py:127-133 of layer l
+ * and GCN.py:110 of layer l+1 into the aggregation's store:
+ *     act      = relu(row_scale[v] * sum_j h[col[j]] + bias)                       (GCN.py:238-253,128)
+ *     out_next = dropout_{seed,p}( c_act * act + c_mix * mix_src[v] )              (res_tricks.py:23, GCN.py:110/133)
+ * relu_bits [N][d/256][4] uint64 receives the ReLU mask (word k, bit l = column 256*tile + 4*l + k), out_act
+ * (nullable) the activation itself.  d must be a multiple of 256; rows 16-byte aligned.  row0 = global index
+ * of local row 0 (dropout mask of the unsharded tensor).  mix_src NULL: no mix; drop_p 0: no dropout.
+ * ---------------------------------------------------------------------------------- */
+int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h, int64_t d,
+                          const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix, float c_act,
+                          float c_mix, float drop_p, uint64_t seed, int64_t row0, uint64_t* relu_bits, float* out_act,
+                          int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs,
+                          int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes,
+                          void* stream);
+
+/* Backward of that epilogue in one pass over contiguous [rows, d]:
+ *     gm = dropout_bwd(g);  gx0 = (accumulate ? gx0 : 0) + c_mix * gm  (gx0 NULL: skipped);
+ *     gy = c_act * gm * relu_bit;  colsum = sum_rows gy (dbias; NULL to skip);  out = gy * row_scale[r]. */
+int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits, const float* row_scale, float* out, float* gx0,
+                           int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed, int64_t row0, float c_act,
+                           float c_mix, float* colsum, void* ws, size_t ws_bytes, void* stream);
+
+/* Backward into the trunk's input stage X0 = relu(Linear(dropout(x))) (GCN.py:104-107,110):
+ *     out = (add + dropout_bwd(g)) * (act > 0);  colsum = sum_rows out  (bias gradient of the input Linear). */
+int cb_trunk_input_bwd_f32(const float* g, const float* add, const float* act, float* out, int64_t rows, int64_t d, float drop_p,
+                           uint64_t seed, int64_t row0, float* colsum, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,3 +77,77 @@ def test_train_mode_with_dropout_matches_oracle(name):
     csr = orc.build_csr(g['edge_index'], n)
     ref, _ = orc.teacher_forward(ocfg, g['sd'], g['x'], csr, training=True, dropout_masks=masks)
     torch.testing.assert_close(out.detach().cpu(), ref, atol=1e-4, rtol=1e-4)
+
+
+def _tiny_trunk_setup(L=3, se='111', n_override=None):
+    import contextlib
+    import io
+    from gnn_tail_generalization_amd.base_options import BaseOptions
+    from gnn_tail_generalization_amd.data import synthetic_data
+    from gnn_tail_generalization_amd.GNN_model import TeacherGNN
+    from gnn_tail_generalization_amd.utils import set_arch_configs
+    with contextlib.redirect_stdout(io.StringIO()):
+        args = BaseOptions().get_arguments(['--dataset=S-pl1M', '--use_special_split=0', f'--num_layers={L}', f'--whetherHasSE={se}',
+                                            '--se_reg=0.5', '--manual_assign_GPU=0'])
+    data = synthetic_data('S-pl1M', seed=2, device=DEV, n_override=n_override or 3000)
+    args.N_nodes = data.x.shape[0]
+    args.dropout = 0.3
+    args.device = torch.device(DEV)
+    set_arch_configs(args)
+    torch.manual_seed(0)
+    model = TeacherGNN(args).to(DEV)
+    return args, model, data
+
+
+@pytest.mark.parametrize('se', ['000', '111'])
+@pytest.mark.parametrize('train', [True, False])
+def test_fused_trunk_equals_modular_path(se, train):
+    """The fused residual trunk (trunk.py) and the modular operator path compute the same logits, loss and
+    gradients from the same parameters and the same dropout seeds (hidden = 256, hub rows present)."""
+    from gnn_tail_generalization_amd import ops
+    from gnn_tail_generalization_amd.GNN_model.GCN import TricksComb
+    args, model, data = _tiny_trunk_setup(se=se)
+    assert model.model.model.type_trick == 'InitialBatchNorm'
+    res = {}
+    for fused in (True, False):
+        TricksComb.use_fused_trunk = fused
+        try:
+            model.train(train)
+            model.zero_grad()
+            ops._seed_override[:] = list(range(900, 910)) if train else []
+            out = model(data.x, data.edge_index)
+            ops._seed_override[:] = []
+            loss = ops.nll_logsoftmax(out, data.y, data.train_mask)
+            if model.se_reg_all is not None:
+                loss = loss + args.se_reg * model.se_reg_all
+            loss.backward()
+            res[fused] = (out.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        finally:
+            TricksComb.use_fused_trunk = True
+    assert model.model.model.dglgraph._plan.n_hubs >= 0
+    torch.testing.assert_close(res[True][0], res[False][0], atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(res[True][1], res[False][1], atol=1e-6, rtol=1e-6)
+    assert set(res[True][2]) == set(res[False][2])
+    for k in res[True][2]:
+        torch.testing.assert_close(res[True][2][k], res[False][2][k], atol=2e-6, rtol=1e-4, msg=lambda m, k=k: f'{k}: {m}')
+
+
+def test_fused_trunk_matches_oracle_with_injected_masks():
+    import coldbrew_oracle as orc
+    from gnn_tail_generalization_amd import ops
+    args, model, data = _tiny_trunk_setup(L=2, se='111', n_override=1500)
+    n, H, F_, C, L = data.x.shape[0], 256, 128, 40, 2
+    shapes = [(n, F_)] + [(n, H)] * L + [(n, H)]
+    seeds = [4000 + i for i in range(len(shapes))]
+    ops._seed_override[:] = list(seeds)
+    model.train()
+    out = model(data.x, data.edge_index)
+    ops._seed_override[:] = []
+    masks = [ops.dropout_keep_mask(s, 0.3, sd, DEV).cpu() for s, sd in zip(shapes, seeds)]
+    cfg = orc.make_cfg(type_trick='InitialBatchNorm', num_layers=L, num_feats=F_, dim_hidden=H, num_classes=C, dropout=0.3,
+                       res_alpha=args.res_alpha, whetherHasSE=(1, 1, 1), se_reg=0.5)
+    csr = orc.build_csr(data.edge_index.cpu(), n)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref, reg = orc.teacher_forward(cfg, sd, data.x.cpu(), csr, training=True, dropout_masks=masks)
+    torch.testing.assert_close(out.detach().cpu(), ref, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(model.se_reg_all.detach().cpu(), reg, atol=1e-3, rtol=1e-5)
