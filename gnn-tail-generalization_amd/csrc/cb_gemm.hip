@@ -10,19 +10,23 @@
 //   TN : C[K1,K2] = sum_m A[m,K1] * (rowscale[m] * G[m,K2])      (reduction over the long node axis,
 //        split over blocks into partial slabs that a second kernel sums in a fixed order)
 //
-// Tiling: 256 threads = 4 wavefronts (2x2), block tile 128x128, K step 16, each wavefront owns a
-// 64x64 sub-tile = 2x2 MFMA 32x32 tiles (64 accumulator VGPRs).  Both operands sit k-major in LDS
-// ([k][128 + 4 pad] floats): a fragment read is 32 consecutive floats per half-wave (conflict-free
-// ds_read_b32), A is transposed on the way in (global row-major [m][k] -> LDS [k][m]).  Global loads
-// of tile t+1 are issued before the MFMAs of tile t and stored to the other LDS buffer after them:
-// one barrier per K step.
+// Tiling: 256 threads = 4 wavefronts arranged WM x WN (2x2 for wide outputs, 4x1 / 1x4 for skinny
+// ones such as the 40-class head), each wavefront owns a 64x64 sub-tile = 2x2 MFMA 32x32 tiles
+// (64 accumulator registers); block tile (64*WM) x (64*WN), K step 16.  Both operands sit k-major in
+// LDS ([k][tile + 4 pad] floats): a fragment read is 32 consecutive floats per half-wave
+// (conflict-free ds_read_b32), the row-major A of NN is transposed on the way in.  Global loads of
+// K-tile t+1 are issued before the MFMAs of tile t and stored to the other LDS buffer after them (one
+// barrier per K step); fragment reads of k-step kk+2 are issued before the MFMAs of k-step kk.
+// Epilogue (NN): the accumulators are transposed through LDS 32 rows at a time so that every lane
+// handles 4 consecutive columns of one row: row scale / addend / bias are applied on float4 values and
+// the tile leaves as coalesced 16-byte stores.
 #include "cb_common.h"
 
 namespace cb {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;  // LDT: padded LDS row (floats)
+constexpr int BK = 16;
 
 struct GemmEpilogue {
   const float* rowscale;  // [M] or null
@@ -32,36 +36,52 @@ struct GemmEpilogue {
   int relu;
 };
 
+template <int WM, int WN>
+struct Tile {
+  static constexpr int BM = 64 * WM, BN = 64 * WN, LDA = BM + 4, LDB = BN + 4;
+  static constexpr int SMEM_FLOATS = 2 * BK * (LDA + LDB);
+  static_assert(WM * WN == 4, "four wavefronts per block");
+  static_assert(32 * LDB <= SMEM_FLOATS, "epilogue staging (32 rows) must fit the operand buffers");
+};
+
+template <int LDA, int LDB>
 __device__ __forceinline__ void mfma_tile_step(const float* __restrict__ As, const float* __restrict__ Bs, int wr, int wc,
                                                int lane, f32x16 (&acc)[2][2]) {
   const int l31 = lane & 31, kh = lane >> 5;
+  const float* ar = As + kh * LDA + wr * 64 + l31;
+  const float* br = Bs + kh * LDB + wc * 64 + l31;
+  float a0 = ar[0], a1 = ar[32], b0 = br[0], b1 = br[32];
 #pragma unroll
   for (int kk = 0; kk < BK; kk += 2) {
-    const float* ar = As + (kk + kh) * LDT + wr * 64 + l31;
-    const float* br = Bs + (kk + kh) * LDT + wc * 64 + l31;
-    const float a0 = ar[0], a1 = ar[32];
-    const float b0 = br[0], b1 = br[32];
+    float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+    if (kk + 2 < BK) {  // next k-step's fragments are in flight while this k-step's MFMAs issue
+      na0 = ar[(kk + 2) * LDA];
+      na1 = ar[(kk + 2) * LDA + 32];
+      nb0 = br[(kk + 2) * LDB];
+      nb1 = br[(kk + 2) * LDB + 32];
+    }
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
   }
 }
 
 // ---- operand staging -----------------------------------------------------------------------
-// "row" operand: global [rows of the tile dimension][k], 16 k per tile row -> needs the transpose into [k][m]
+// "row-major" operand (A of NN): global [tile rows][k], 16 k per K step -> transposed into LDS [k][row].
+// thread t: k quad = t % 4, rows (t / 4) + 64 * j
+template <int BMT>
 struct RowFrag {
-  float v[2][4];
+  float v[BMT / 64][4];
 };
-// thread t: m = t/4 + 64*j (j = 0,1), k quad = t%4
-template <bool ALIGNED>
-__device__ __forceinline__ void load_rowmajor(RowFrag& f, const float* __restrict__ A, int64_t lda, int64_t m0, int64_t M, int k0,
-                                              int K, int t) {
-  const int kq = (t & 3) * 4;
+template <bool ALIGNED, int BMT>
+__device__ __forceinline__ void load_rowmajor(RowFrag<BMT>& f, const float* __restrict__ A, int64_t lda, int64_t m0, int64_t M,
+                                              int k0, int K, int t) {
+  const int k = k0 + (t & 3) * 4;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < BMT / 64; ++j) {
     const int64_t m = m0 + (t >> 2) + 64 * j;
-    const int k = k0 + kq;
     if (ALIGNED && m < M && k + 4 <= K) {
       const float4 x = *reinterpret_cast<const float4*>(A + m * lda + k);
       f.v[j][0] = x.x; f.v[j][1] = x.y; f.v[j][2] = x.z; f.v[j][3] = x.w;
@@ -71,28 +91,31 @@ __device__ __forceinline__ void load_rowmajor(RowFrag& f, const float* __restric
     }
   }
 }
-__device__ __forceinline__ void store_rowmajor_T(const RowFrag& f, float* __restrict__ S, int t) {
+template <int BMT>
+__device__ __forceinline__ void store_rowmajor_T(const RowFrag<BMT>& f, float* __restrict__ S, int t) {
   const int kq = (t & 3) * 4;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < BMT / 64; ++j) {
     const int m = (t >> 2) + 64 * j;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) S[(kq + i) * LDT + m] = f.v[j][i];
+    for (int i = 0; i < 4; ++i) S[(kq + i) * (BMT + 4) + m] = f.v[j][i];
   }
 }
 
-// "k-major" operand: global [k][n] with n contiguous (B of NN; both operands of TN): straight copy
+// "k-major" operand: global [k][n] with n contiguous (B of NN; both operands of TN): straight copy.
+// thread t: n quad = t % (BNT/4), k = t / (BNT/4) + (1024/BNT) * j
+template <int BNT>
 struct KFrag {
-  float4 v[2];
+  float4 v[BNT / 64];
 };
-// thread t: k = t/32 + 8*j, n quad = t%32
-template <bool ALIGNED>
-__device__ __forceinline__ void load_kmajor(KFrag& f, const float* __restrict__ B, int64_t ldb, int64_t k0, int64_t Kdim, int n0,
-                                            int N, int t, const float* __restrict__ kscale) {
-  const int n = n0 + (t & 31) * 4;
+template <bool ALIGNED, int BNT>
+__device__ __forceinline__ void load_kmajor(KFrag<BNT>& f, const float* __restrict__ B, int64_t ldb, int64_t k0, int64_t Kdim,
+                                            int n0, int N, int t, const float* __restrict__ kscale) {
+  constexpr int TPR = BNT / 4, RPP = 256 / TPR;   // threads per row, rows per pass
+  const int n = n0 + (t % TPR) * 4;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int64_t k = k0 + (t >> 5) + 8 * j;
+  for (int j = 0; j < BNT / 64; ++j) {
+    const int64_t k = k0 + t / TPR + RPP * j;
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k < Kdim) {
       if (ALIGNED && n + 4 <= N) {
@@ -111,19 +134,33 @@ __device__ __forceinline__ void load_kmajor(KFrag& f, const float* __restrict__ 
     f.v[j] = x;
   }
 }
-__device__ __forceinline__ void store_kmajor(const KFrag& f, float* __restrict__ S, int t) {
+template <int BNT>
+__device__ __forceinline__ void store_kmajor(const KFrag<BNT>& f, float* __restrict__ S, int t) {
+  constexpr int TPR = BNT / 4, RPP = 256 / TPR;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(S + ((t >> 5) + 8 * j) * LDT + (t & 31) * 4) = f.v[j];
+  for (int j = 0; j < BNT / 64; ++j)
+    *reinterpret_cast<float4*>(S + (t / TPR + RPP * j) * (BNT + 4) + (t % TPR) * 4) = f.v[j];
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 }
 
 // ---- NN ------------------------------------------------------------------------------------
-template <bool ALIGNED>
+template <int WM, int WN, bool ALIGNED>
 __global__ void __launch_bounds__(256) k_gemm_nn(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
                                                  float* __restrict__ C, int64_t ldc, int64_t M, int N, int K, GemmEpilogue ep,
-                                                 int n_row_blocks, int n_col_blocks) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * LDT];
-  auto As = [&](int b) { return smem + b * (BK * LDT); };
-  auto Bs = [&](int b) { return smem + (2 + b) * (BK * LDT); };
+                                                 int n_row_blocks, int n_col_blocks, int c_vec_ok) {
+  using T = Tile<WM, WN>;
+  constexpr int BM = T::BM, BN = T::BN, LDA = T::LDA, LDB = T::LDB;
+  __shared__ __attribute__((aligned(16))) float smem[T::SMEM_FLOATS];
+  auto As = [&](int b) { return smem + b * (BK * LDA); };
+  auto Bs = [&](int b) { return smem + 2 * BK * LDA + b * (BK * LDB); };
   // XCD-aware tile order: the column blocks of one row block get ids congruent mod 8, i.e. the same
   // XCD / L2 under the observed round-robin dispatch, so the A rows are fetched from HBM once.
   const int per_group = 8 * n_col_blocks;
@@ -132,104 +169,132 @@ __global__ void __launch_bounds__(256) k_gemm_nn(const float* __restrict__ A, in
   if (row_blk >= n_row_blocks) return;
   const int64_t m0 = (int64_t)row_blk * BM;
   const int n0 = col_blk * BN;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w / WN, wc = w % WN;
 
   f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
+  zero_acc(acc);
   const int nk = (K + BK - 1) / BK;
-  RowFrag fa;
-  KFrag fb;
-  load_rowmajor<ALIGNED>(fa, A, lda, m0, M, 0, K, t);
-  load_kmajor<ALIGNED>(fb, B, ldb, 0, K, n0, N, t, nullptr);
-  store_rowmajor_T(fa, As(0), t);
-  store_kmajor(fb, Bs(0), t);
+  RowFrag<BM> fa;
+  KFrag<BN> fb;
+  load_rowmajor<ALIGNED, BM>(fa, A, lda, m0, M, 0, K, t);
+  load_kmajor<ALIGNED, BN>(fb, B, ldb, 0, K, n0, N, t, nullptr);
+  store_rowmajor_T<BM>(fa, As(0), t);
+  store_kmajor<BN>(fb, Bs(0), t);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      load_rowmajor<ALIGNED>(fa, A, lda, m0, M, (kt + 1) * BK, K, t);
-      load_kmajor<ALIGNED>(fb, B, ldb, (int64_t)(kt + 1) * BK, K, n0, N, t, nullptr);
+      load_rowmajor<ALIGNED, BM>(fa, A, lda, m0, M, (kt + 1) * BK, K, t);
+      load_kmajor<ALIGNED, BN>(fb, B, ldb, (int64_t)(kt + 1) * BK, K, n0, N, t, nullptr);
     }
-    mfma_tile_step(As(cur), Bs(cur), wr, wc, lane, acc);
+    mfma_tile_step<LDA, LDB>(As(cur), Bs(cur), wr, wc, lane, acc);
     if (kt + 1 < nk) {
-      store_rowmajor_T(fa, As(cur ^ 1), t);
-      store_kmajor(fb, Bs(cur ^ 1), t);
+      store_rowmajor_T<BM>(fa, As(cur ^ 1), t);
+      store_kmajor<BN>(fb, Bs(cur ^ 1), t);
     }
     __syncthreads();
   }
 
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  // ---- epilogue through LDS: 32 rows x BN per pass -------------------------------------------
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  float* Cs = smem;                       // [32][LDB]
   const int l31 = lane & 31, lh = lane >> 5;
+  constexpr int TPR = BN / 4;             // threads per staged row
+  constexpr int NV = 32 * TPR / 256;      // float4 per thread per pass
 #pragma unroll
-  for (int ti = 0; ti < 2; ++ti) {
+  for (int pass = 0; pass < 2 * WM; ++pass) {
+    const int wr_sel = pass >> 1, ti = pass & 1;
+    if (wr == wr_sel) {
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
-      const int n = n0 + wc * 64 + tj * 32 + l31;
-      if (n >= N) continue;
-      const float bv = ep.bias ? ep.bias[n] : 0.f;
+      for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int64_t m = m0 + wr * 64 + ti * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-        if (m >= M) continue;
-        float v = acc[ti][tj][reg];
-        if (ep.rowscale) v *= ep.rowscale[m];
-        if (ep.addend) v += ep.addend[m * ep.ld_add + n];
-        v += bv;
-        if (ep.relu) v = fmaxf(v, 0.f);
-        C[m * ldc + n] = v;
+        for (int reg = 0; reg < 16; ++reg)
+          Cs[((reg & 3) + 8 * (reg >> 2) + 4 * lh) * LDB + wc * 64 + tj * 32 + l31] = acc[ti][tj][reg];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = t + 256 * i;
+      const int row = idx / TPR, c4 = (idx % TPR) * 4;
+      const int64_t m = m0 + wr_sel * 64 + ti * 32 + row;
+      const int n = n0 + c4;
+      if (m < M && n < N) {
+        const float4 v = *reinterpret_cast<const float4*>(Cs + row * LDB + c4);
+        float o[4] = {v.x, v.y, v.z, v.w};
+        const float rs = ep.rowscale ? ep.rowscale[m] : 1.f;
+        const bool full4 = n + 4 <= N;
+        float ad[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ep.addend) {
+          const float* ap = ep.addend + m * ep.ld_add + n;
+          if (full4 && c_vec_ok) {
+            const float4 a4 = *reinterpret_cast<const float4*>(ap);
+            ad[0] = a4.x; ad[1] = a4.y; ad[2] = a4.z; ad[3] = a4.w;
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (n + q < N) ad[q] = ap[q];
+          }
+        }
+        if (ep.bias) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (n + q < N) bv[q] = ep.bias[n + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          o[q] = o[q] * rs + ad[q] + bv[q];
+          if (ep.relu) o[q] = fmaxf(o[q], 0.f);
+        }
+        float* cp = C + m * ldc + n;
+        if (full4 && c_vec_ok) {
+          *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (n + q < N) cp[q] = o[q];
+        }
       }
     }
+    __syncthreads();
   }
 }
 
 // ---- TN ------------------------------------------------------------------------------------
 // partial[split][K1][K2]: block (tile i, tile j, split s) reduces rows [s*rows_per_split, ...)
-template <bool ALIGNED>
+template <int WM, int WN, bool ALIGNED>
 __global__ void __launch_bounds__(256) k_gemm_tn(const float* __restrict__ A, int64_t lda, const float* __restrict__ G, int64_t ldg,
                                                  const float* __restrict__ rowscale, float* __restrict__ partial, int64_t M, int K1,
                                                  int K2, int64_t rows_per_split, int tiles_j) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * LDT];
-  auto As = [&](int b) { return smem + b * (BK * LDT); };
-  auto Bs = [&](int b) { return smem + (2 + b) * (BK * LDT); };
+  using T = Tile<WM, WN>;
+  constexpr int BM = T::BM, BN = T::BN, LDA = T::LDA, LDB = T::LDB;
+  __shared__ __attribute__((aligned(16))) float smem[T::SMEM_FLOATS];
+  auto As = [&](int b) { return smem + b * (BK * LDA); };
+  auto Bs = [&](int b) { return smem + 2 * BK * LDA + b * (BK * LDB); };
   const int tile = blockIdx.x, split = blockIdx.y;
   const int i0 = (tile / tiles_j) * BM, j0 = (tile % tiles_j) * BN;
   const int64_t r_begin = (int64_t)split * rows_per_split;
   const int64_t r_end = min(M, r_begin + rows_per_split);
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w / WN, wc = w % WN;
 
   f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
+  zero_acc(acc);
   const int64_t nk = r_end > r_begin ? (r_end - r_begin + BK - 1) / BK : 0;
-  KFrag fa, fb;
+  KFrag<BM> fa;
+  KFrag<BN> fb;
   if (nk > 0) {
-    load_kmajor<ALIGNED>(fa, A, lda, r_begin, r_end, i0, K1, t, nullptr);
-    load_kmajor<ALIGNED>(fb, G, ldg, r_begin, r_end, j0, K2, t, rowscale);
-    store_kmajor(fa, As(0), t);
-    store_kmajor(fb, Bs(0), t);
+    load_kmajor<ALIGNED, BM>(fa, A, lda, r_begin, r_end, i0, K1, t, nullptr);
+    load_kmajor<ALIGNED, BN>(fb, G, ldg, r_begin, r_end, j0, K2, t, rowscale);
+    store_kmajor<BM>(fa, As(0), t);
+    store_kmajor<BN>(fb, Bs(0), t);
   }
   __syncthreads();
   for (int64_t kt = 0; kt < nk; ++kt) {
     const int cur = (int)(kt & 1);
     if (kt + 1 < nk) {
-      load_kmajor<ALIGNED>(fa, A, lda, r_begin + (kt + 1) * BK, r_end, i0, K1, t, nullptr);
-      load_kmajor<ALIGNED>(fb, G, ldg, r_begin + (kt + 1) * BK, r_end, j0, K2, t, rowscale);
+      load_kmajor<ALIGNED, BM>(fa, A, lda, r_begin + (kt + 1) * BK, r_end, i0, K1, t, nullptr);
+      load_kmajor<ALIGNED, BN>(fb, G, ldg, r_begin + (kt + 1) * BK, r_end, j0, K2, t, rowscale);
     }
-    mfma_tile_step(As(cur), Bs(cur), wr, wc, lane, acc);
+    mfma_tile_step<LDA, LDB>(As(cur), Bs(cur), wr, wc, lane, acc);
     if (kt + 1 < nk) {
-      store_kmajor(fa, As(cur ^ 1), t);
-      store_kmajor(fb, Bs(cur ^ 1), t);
+      store_kmajor<BM>(fa, As(cur ^ 1), t);
+      store_kmajor<BN>(fb, Bs(cur ^ 1), t);
     }
     __syncthreads();
   }
@@ -269,6 +334,53 @@ static inline int tn_splits(int64_t M, int tiles) {
 
 static inline bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
+// tile shape by output width: 2x2 (128x128) by default; for TN 1x4 (64x256) when K1 <= 64, 4x1 (256x64) when K2 <= 64
+static inline void tn_tile(int64_t K1, int64_t K2, int& bm, int& bn) {
+  if (K1 <= 64 && K2 > 64) { bm = 64; bn = 256; }
+  else if (K2 <= 64 && K1 > 64) { bm = 256; bn = 64; }
+  else { bm = 128; bn = 128; }
+}
+
+template <int WM, int WN>
+static int launch_nn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
+                     int64_t K, GemmEpilogue ep, hipStream_t st) {
+  using T = Tile<WM, WN>;
+  const int nrb = (int)((M + T::BM - 1) / T::BM), ncb = (int)((N + T::BN - 1) / T::BN);
+  const int64_t groups = (nrb + 7) / 8;
+  const dim3 grid((unsigned)(groups * 8 * ncb));
+  const bool aligned = al16(A) && al16(B) && lda % 4 == 0 && ldb % 4 == 0;
+  const int c_vec_ok = al16(C) && ldc % 4 == 0 && (!ep.addend || (al16(ep.addend) && ep.ld_add % 4 == 0));
+  if (aligned)
+    hipLaunchKernelGGL((k_gemm_nn<WM, WN, true>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
+  else
+    hipLaunchKernelGGL((k_gemm_nn<WM, WN, false>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
+template <int WM, int WN>
+static int launch_tn(const float* A, int64_t lda, const float* G, int64_t ldg, const float* rowscale, float* C, int64_t M,
+                     int64_t K1, int64_t K2, float* ws, hipStream_t st) {
+  using T = Tile<WM, WN>;
+  const int tiles_i = (int)((K1 + T::BM - 1) / T::BM), tiles_j = (int)((K2 + T::BN - 1) / T::BN);
+  const int nsplit = tn_splits(M, tiles_i * tiles_j);
+  int64_t rows_per_split = (M + nsplit - 1) / nsplit;
+  rows_per_split = (rows_per_split + BK - 1) / BK * BK;
+  const bool aligned = al16(A) && al16(G) && lda % 4 == 0 && ldg % 4 == 0;
+  const dim3 grid((unsigned)(tiles_i * tiles_j), (unsigned)nsplit);
+  if (aligned)
+    hipLaunchKernelGGL((k_gemm_tn<WM, WN, true>), grid, dim3(256), 0, st, A, lda, G, ldg, rowscale, ws, M, (int)K1, (int)K2,
+                       rows_per_split, tiles_j);
+  else
+    hipLaunchKernelGGL((k_gemm_tn<WM, WN, false>), grid, dim3(256), 0, st, A, lda, G, ldg, rowscale, ws, M, (int)K1, (int)K2,
+                       rows_per_split, tiles_j);
+  CB_LAUNCH_CHECK();
+  const int64_t n = K1 * K2;
+  hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsplit, n, C);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
 }  // namespace cb
 
 using namespace cb;
@@ -277,27 +389,21 @@ extern "C" int cb_gemm_nn_f32(const float* A, int64_t lda, const float* B, int64
                               int64_t K, const float* rowscale, const float* addend, int64_t ld_add, const float* bias, int relu,
                               void* stream) {
   CB_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, CB_E_INVALID, "cb_gemm_nn_f32: negative size");
-  CB_CHECK_ARG(N < (1 << 24) && K < (1 << 24) && (M + BM - 1) / BM < (1 << 24), CB_E_RANGE, "cb_gemm_nn_f32: size out of range");
+  CB_CHECK_ARG(N < (1 << 24) && K < (1 << 24) && (M + 63) / 64 < (1 << 24), CB_E_RANGE, "cb_gemm_nn_f32: size out of range");
   if (M == 0 || N == 0) return CB_OK;
   CB_CHECK_ARG(C && (K == 0 || (A && B)) && lda >= K && ldb >= N && ldc >= N && (!addend || ld_add >= N), CB_E_INVALID,
                "cb_gemm_nn_f32: null pointer or leading dimension too small");
   GemmEpilogue ep{rowscale, addend, ld_add, bias, relu};
-  const int nrb = (int)((M + BM - 1) / BM), ncb = (int)((N + BN - 1) / BN);
-  const int64_t groups = (nrb + 7) / 8;
-  const dim3 grid((unsigned)(groups * 8 * ncb));
-  const bool aligned = al16(A) && al16(B) && lda % 4 == 0 && ldb % 4 == 0;
   hipStream_t st = (hipStream_t)stream;
-  if (aligned)
-    hipLaunchKernelGGL((k_gemm_nn<true>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb);
-  else
-    hipLaunchKernelGGL((k_gemm_nn<false>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb);
-  CB_LAUNCH_CHECK();
-  return CB_OK;
+  if (N <= 64) return launch_nn<4, 1>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
+  return launch_nn<2, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
 }
 
 extern "C" size_t cb_gemm_tn_workspace_bytes(int64_t M, int64_t K1, int64_t K2) {
   if (M <= 0 || K1 <= 0 || K2 <= 0) return 0;
-  const int tiles = (int)(((K1 + BM - 1) / BM) * ((K2 + BN - 1) / BN));
+  int bm, bn;
+  tn_tile(K1, K2, bm, bn);
+  const int tiles = (int)(((K1 + bm - 1) / bm) * ((K2 + bn - 1) / bn));
   return (size_t)tn_splits(M, tiles) * (size_t)K1 * (size_t)K2 * sizeof(float);
 }
 
@@ -313,21 +419,9 @@ extern "C" int cb_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64
     return CB_OK;
   }
   CB_CHECK_ARG(ws && ws_bytes >= cb_gemm_tn_workspace_bytes(M, K1, K2), CB_E_WORKSPACE, "cb_gemm_tn_f32: workspace too small");
-  const int tiles_i = (int)((K1 + BM - 1) / BM), tiles_j = (int)((K2 + BN - 1) / BN);
-  const int nsplit = tn_splits(M, tiles_i * tiles_j);
-  int64_t rows_per_split = (M + nsplit - 1) / nsplit;
-  rows_per_split = (rows_per_split + BK - 1) / BK * BK;
-  const bool aligned = al16(A) && al16(G) && lda % 4 == 0 && ldg % 4 == 0;
-  const dim3 grid((unsigned)(tiles_i * tiles_j), (unsigned)nsplit);
-  if (aligned)
-    hipLaunchKernelGGL((k_gemm_tn<true>), grid, dim3(256), 0, st, A, lda, G, ldg, rowscale, (float*)ws, M, (int)K1, (int)K2,
-                       rows_per_split, tiles_j);
-  else
-    hipLaunchKernelGGL((k_gemm_tn<false>), grid, dim3(256), 0, st, A, lda, G, ldg, rowscale, (float*)ws, M, (int)K1, (int)K2,
-                       rows_per_split, tiles_j);
-  CB_LAUNCH_CHECK();
-  const int64_t n = K1 * K2;
-  hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsplit, n, C);
-  CB_LAUNCH_CHECK();
-  return CB_OK;
+  int bm, bn;
+  tn_tile(K1, K2, bm, bn);
+  if (bm == 64) return launch_tn<1, 4>(A, lda, G, ldg, rowscale, C, M, K1, K2, (float*)ws, st);
+  if (bm == 256) return launch_tn<4, 1>(A, lda, G, ldg, rowscale, C, M, K1, K2, (float*)ws, st);
+  return launch_tn<2, 2>(A, lda, G, ldg, rowscale, C, M, K1, K2, (float*)ws, st);
 }
