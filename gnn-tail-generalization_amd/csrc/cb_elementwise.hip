@@ -207,6 +207,26 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
   }
 }
 
+// out[i, :] = src[idx[i], :]  — packs the rows a peer rank asked for (halo exchange of the node-sharded path)
+__global__ void __launch_bounds__(kBlock) k_gather_rows(const float* __restrict__ src, int64_t ld, const int64_t* __restrict__ idx,
+                                                        int64_t n_idx, int d, float* __restrict__ out, int vec_ok) {
+  if (vec_ok) {
+    const int q = d >> 2;
+    const int64_t total = n_idx * q;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t r = i / q;
+      const int c = (int)(i - r * q) * 4;
+      *reinterpret_cast<float4*>(out + r * d + c) = *reinterpret_cast<const float4*>(src + idx[r] * ld + c);
+    }
+  } else {
+    const int64_t total = n_idx * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t r = i / d;
+      out[i] = src[idx[r] * ld + (i - r * d)];
+    }
+  }
+}
+
 __global__ void k_colsum_finish(const float* __restrict__ partial, int nparts, int d, float* __restrict__ out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d) return;
@@ -489,4 +509,16 @@ extern "C" int cb_trunk_input_bwd_f32(const float* g, const float* add, const fl
   CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_colsum_workspace_bytes(rows, d)), CB_E_WORKSPACE, "cb_trunk_input_bwd_f32: workspace too small");
   return launch_trunk_bwd(1, g, nullptr, act, nullptr, out, const_cast<float*>(add), 1, rows, d, drop_p, seed, row0, 0.f, 0.f, colsum, ws,
                           ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int cb_gather_rows_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, float* out,
+                                  void* stream) {
+  CB_CHECK_ARG(n_idx >= 0 && d >= 0 && d < (1 << 24) && ld >= d, CB_E_INVALID, "cb_gather_rows_f32: bad size");
+  if (n_idx == 0 || d == 0) return CB_OK;
+  CB_CHECK_ARG(src && idx && out, CB_E_INVALID, "cb_gather_rows_f32: null pointer");
+  const int vec_ok = aligned16(src) && aligned16(out) && d % 4 == 0 && ld % 4 == 0;
+  const int64_t work = vec_ok ? n_idx * (d / 4) : n_idx * d;
+  hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(work)), dim3(kBlock), 0, (hipStream_t)stream, src, ld, idx, n_idx, (int)d, out, vec_ok);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
 }

@@ -21,6 +21,9 @@
 //     so results are bit-reproducible run to run.
 //   * streaming data (indices, output rows) uses non-temporal accesses so the 4 MiB L2s and
 //     the 256 MiB Infinity Cache keep the re-used neighbour rows (hub sources).
+#include <stdlib.h>
+#include <string.h>
+
 #include "cb_common.h"
 #include "cb_philox.h"
 
@@ -365,13 +368,10 @@ __global__ void __launch_bounds__(256) k_spmm_hub_finish(int d, int n_hubs, cons
 
 static inline int64_t partial_ld(int64_t d) { return (d + 3) / 4 * 4; }
 
-template <int VEC, bool FUSED = false>
-static int launch_spmm(const int32_t* rowptr, const int32_t* col, int64_t N, const float* h, int64_t ld_h, int64_t d,
-                       Epilogue ep, float* out, int64_t ld_out, int hub_T, int n_hubs, int n_chunks,
-                       const int32_t* hub_rows, const int32_t* hub_chunk_ptr, float* partial, hipStream_t st,
-                       FusedEpi fe = FusedEpi{}) {
-  constexpr int RPW = 16;
-  constexpr int U = (VEC == 4) ? 8 : 8;
+template <int VEC, bool FUSED, int RPW, int U>
+static int launch_spmm_cfg(const int32_t* rowptr, const int32_t* col, int64_t N, const float* h, int64_t ld_h, int64_t d,
+                           Epilogue ep, float* out, int64_t ld_out, int hub_T, int n_hubs, int n_chunks,
+                           const int32_t* hub_rows, const int32_t* hub_chunk_ptr, float* partial, hipStream_t st, FusedEpi fe) {
   const int tile = kWave * VEC;
   const int ny = (int)((d + tile - 1) / tile);
   const int waves_per_block = 4;
@@ -393,7 +393,7 @@ static int launch_spmm(const int32_t* rowptr, const int32_t* col, int64_t N, con
   if (n_hubs > 0) {
     const int64_t ld_p = partial_ld(d);
     dim3 grid((unsigned)((n_chunks + waves_per_block - 1) / waves_per_block), ny);
-    hipLaunchKernelGGL((k_spmm_hub_chunks<VEC, U>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h, (int)d,
+    hipLaunchKernelGGL((k_spmm_hub_chunks<VEC, 8>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h, (int)d,
                        hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, ld_p);
     CB_LAUNCH_CHECK();
     dim3 grid2((unsigned)((n_hubs + waves_per_block - 1) / waves_per_block), ny);
@@ -402,6 +402,44 @@ static int launch_spmm(const int32_t* rowptr, const int32_t* col, int64_t N, con
     CB_LAUNCH_CHECK();
   }
   return CB_OK;
+}
+
+// Tuning hook (measurement only): CB_SPMM_VARIANT = "<RPW>x<U>" selects another row-block / unroll shape of the
+// d = 256 kernel; unset = the tuned default.
+static int spmm_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CB_SPMM_VARIANT");
+    v = 0;
+    if (e) {
+      if (!strcmp(e, "8x8")) v = 1;
+      else if (!strcmp(e, "32x8")) v = 2;
+      else if (!strcmp(e, "16x4")) v = 3;
+      else if (!strcmp(e, "16x16")) v = 4;
+      else if (!strcmp(e, "8x4")) v = 5;
+    }
+  }
+  return v;
+}
+
+template <int VEC, bool FUSED = false>
+static int launch_spmm(const int32_t* rowptr, const int32_t* col, int64_t N, const float* h, int64_t ld_h, int64_t d,
+                       Epilogue ep, float* out, int64_t ld_out, int hub_T, int n_hubs, int n_chunks,
+                       const int32_t* hub_rows, const int32_t* hub_chunk_ptr, float* partial, hipStream_t st,
+                       FusedEpi fe = FusedEpi{}) {
+#define CB_SPMM_ARGS rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st, fe
+  if constexpr (VEC == 4 && !FUSED) {
+    switch (spmm_variant()) {
+      case 1: return launch_spmm_cfg<VEC, FUSED, 8, 8>(CB_SPMM_ARGS);
+      case 2: return launch_spmm_cfg<VEC, FUSED, 32, 8>(CB_SPMM_ARGS);
+      case 3: return launch_spmm_cfg<VEC, FUSED, 16, 4>(CB_SPMM_ARGS);
+      case 4: return launch_spmm_cfg<VEC, FUSED, 16, 16>(CB_SPMM_ARGS);
+      case 5: return launch_spmm_cfg<VEC, FUSED, 8, 4>(CB_SPMM_ARGS);
+      default: break;
+    }
+  }
+  return launch_spmm_cfg<VEC, FUSED, 16, 8>(CB_SPMM_ARGS);
+#undef CB_SPMM_ARGS
 }
 
 }  // namespace cb

@@ -39,8 +39,7 @@ def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False):
     lib = _lib.load()
     g, _, sh = _graph_parts(graph)
     if sh is not None:
-        from .dist import gather_rows
-        z = gather_rows(z, sh.part, sh.group)
+        z = sh.exchange(z, False)
     n, d = g.N, z.shape[1]
     dev = z.device
     bits = torch.empty((n, d // 256, 4), dtype=torch.int64, device=dev)
@@ -70,9 +69,8 @@ def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False):
 def _spmm_t(graph, gr):
     g, gb, sh = _graph_parts(graph)
     if sh is not None:
-        from .dist import gather_rows
         gb.profile = getattr(graph, 'profile', None)
-        return gb.spmm(gather_rows(gr, sh.part, sh.group))
+        return gb.spmm(sh.exchange(gr, True))
     return g.spmm(gr, transpose=True)
 
 

@@ -183,6 +183,10 @@ int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits, const floa
 int cb_trunk_input_bwd_f32(const float* g, const float* add, const float* act, float* out, int64_t rows, int64_t d, float drop_p,
                            uint64_t seed, int64_t row0, float* colsum, void* ws, size_t ws_bytes, void* stream);
 
+/* out[i, :] = src[idx[i], :] (contiguous out [n_idx, d]) — packs the rows a peer asked for before the
+ * all-to-all of the node-sharded halo exchange (new; the reference is single-device). */
+int cb_gather_rows_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,7 +30,7 @@ def _oracle_spmm(rowptr, col, h_full, row_scale, bias, relu):
     return torch.from_numpy(out)
 
 
-def _worker(rank, world, port, name, q):
+def _worker(rank, world, port, name, q, exchange='halo'):
     for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -46,7 +46,10 @@ def _worker(rank, world, port, name, q):
         a, b = orc.degree_norms(csr)
         csr.norm_out, csr.norm_in = a, b
         part = cbdist.Partition(n, world, rank)
-        sg = cbdist.ShardedGraph(csr, part, spmm_fn=_oracle_spmm)
+        sg = cbdist.ShardedGraph(csr, part, spmm_fn=_oracle_spmm, exchange=exchange)
+        if exchange == 'halo' and world > 1:
+            assert sg.plan_fwd.n_halo > 0 and sum(sg.plan_fwd.recv_counts) == sg.plan_fwd.n_halo
+            assert sg.plan_fwd.n_halo <= csr.N - part.n_local
         assert sg.N == part.n_local and sg.row_offset == part.lo()
         # the row slices re-assemble the global CSR
         counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
@@ -98,14 +101,15 @@ def _worker(rank, world, port, name, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('name', ['case_graph_asym_multi', 'case_graph_powerlaw_d7_d64'])
-def test_sharded_exchange_matches_unsharded_oracle(name):
+@pytest.mark.parametrize('name,world,exchange', [('case_graph_asym_multi', 2, 'halo'), ('case_graph_powerlaw_d7_d64', 2, 'halo'),
+                                                 ('case_graph_asym_multi', 3, 'halo'), ('case_graph_powerlaw_d7_d64', 2, 'allgather')])
+def test_sharded_exchange_matches_unsharded_oracle(name, world, exchange):
     import oracle_c
     oracle_c.load()                      # build the C restatement before forking
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]

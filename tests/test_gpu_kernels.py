@@ -166,3 +166,12 @@ def test_fused_adam_matches_oracle_and_torch():
     for i, (m, r) in enumerate(zip(mine, ref)):
         torch.testing.assert_close(m.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(m.detach().cpu(), orc_p[str(i)], rtol=1e-5, atol=1e-6)
+
+
+def test_gather_rows_by_index():
+    from gnn_tail_generalization_amd import ops
+    for shape in [(100, 256), (57, 40), (9, 7)]:
+        x = _rand(*shape, seed=1).to(DEV)
+        idx = torch.randint(0, shape[0], (333,), generator=torch.Generator().manual_seed(2)).to(DEV)
+        assert torch.equal(ops.gather_rows_by_index(x, idx), x[idx])
+    assert ops.gather_rows_by_index(x, idx[:0]).shape == (0, 7)
