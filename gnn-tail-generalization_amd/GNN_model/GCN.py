@@ -10,8 +10,6 @@ What changes is below the surface: the graph is a device CSR built once through 
 (graph.CSRGraph instead of dgl.graph from Python lists, GCN.py:92-95), and the
 transform / aggregate stages run as hand-written gfx950 kernels (ops.py).
 """
-import math
-
 import torch as th
 import torch.nn.functional as F
 from torch import nn
@@ -24,59 +22,75 @@ from .norm_tricks import AcontainsB, appendNormLayer, run_norm_if_any
 from .res_tricks import DenseConnection, InitialConnection, ResidualConnection
 
 
+_BARE_NORMS = ('BatchNorm', 'PairNorm', 'NodeNorm', 'MeanNorm', 'GroupNorm', 'CombNorm')
+
+
 class TricksComb(nn.Module):
+    """Layer stack of the teacher: non-residual mode = GCNConv(F,H), (L-2) x GCNConv(H,H), GCNConv(H,C);
+    residual mode (type_trick names Jumping/Initial/Residual/Dense) = Linear(F,H), L x GCNConv(H,H), Linear(H,C)."""
+
+    use_fused_trunk = True   # 'Initial' connection without a bare norm runs as one fused autograd node (trunk.py)
+
     def __init__(self, args):
         super().__init__()
         self.args = args
-        self.dglgraph = None            # name kept: cached graph object (a CSRGraph here)
+        self.dglgraph = None            # name kept: the cached graph object (a CSRGraph here)
         self.alpha = args.res_alpha
         self.embedding_dropout = args.dropout
-        for k, v in vars(args).items():   # the reference mirrors every option onto the module (GCN.py:26-27)
-            setattr(self, k, v)
+        for name, value in vars(args).items():   # every option is mirrored onto the module (reference GCN.py:26-27)
+            setattr(self, name, value)
         self.cached = self.transductive = args.transductive
         if AcontainsB(self.type_trick, ['DropEdge', 'DropNode', 'FastGCN', 'LADIES']):
             self.cached = False
-        # residual-style tricks keep the hidden width constant behind an input/output Linear (GCN.py:34-36)
         self.has_residual_MLP = AcontainsB(self.type_trick, ['Jumping', 'Initial', 'Residual', 'Dense'])
-        se = self.args.TeacherGNN.whetherHasSE
-
-        self.layers_GCN = nn.ModuleList([])
-        self.layers_res = nn.ModuleList([])
-        self.layers_norm = nn.ModuleList([])
-        self.layers_MLP = nn.ModuleList([])
-        self.layers_MLP.append(nn.Linear(self.num_feats, self.dim_hidden))
+        self.layers_GCN, self.layers_res = nn.ModuleList(), nn.ModuleList()
+        self.layers_norm, self.layers_MLP = nn.ModuleList(), nn.ModuleList()
+        # registration order below = the reference's, so equal seeds give bit-identical initial parameters
+        se_first, se_mid, se_last = self.args.TeacherGNN.whetherHasSE
+        H, L = self.dim_hidden, self.num_layers
+        self.layers_MLP.append(nn.Linear(self.num_feats, H))
         if not self.has_residual_MLP:
-            self.layers_GCN.append(GCNConv(self.num_feats, self.dim_hidden, cached=self.cached, args=self.args, whetherHasSE=se[0]))
-        for i in range(self.num_layers):
-            if self.has_residual_MLP or 0 < i < self.num_layers - 1:
-                # hidden -> hidden layers all take the "middle" SE flag (GCN.py:50,52)
-                self.layers_GCN.append(GCNConv(self.dim_hidden, self.dim_hidden, cached=self.cached, args=self.args, whetherHasSE=se[1]))
-            appendNormLayer(self, args, self.dim_hidden if i < self.num_layers - 1 else self.num_classes)
-            if AcontainsB(self.type_trick, ['Residual']):
-                self.layers_res.append(ResidualConnection(alpha=self.alpha))
-            elif AcontainsB(self.type_trick, ['Initial']):
-                self.layers_res.append(InitialConnection(alpha=self.alpha))
-            elif AcontainsB(self.type_trick, ['Dense']):
-                if self.layer_agg in ['concat', 'maxpool']:
-                    self.layers_res.append(DenseConnection((i + 2) * self.dim_hidden, self.dim_hidden, self.layer_agg))
-                elif self.layer_agg == 'attention':
-                    self.layers_res.append(DenseConnection(self.dim_hidden, self.dim_hidden, self.layer_agg))
+            self.layers_GCN.append(self._conv(self.num_feats, H, se_first))
+        for i in range(L):
+            if self.has_residual_MLP or 0 < i < L - 1:   # hidden->hidden layers all take the "middle" SE flag
+                self.layers_GCN.append(self._conv(H, H, se_mid))
+            appendNormLayer(self, args, H if i < L - 1 else self.num_classes)
+            res = self._res_layer(i)
+            if res is not None:
+                self.layers_res.append(res)
         self.graph_dropout = DropoutTrick(args)
         if not self.has_residual_MLP:
-            self.layers_GCN.append(GCNConv(self.dim_hidden, self.num_classes, cached=self.cached, args=self.args, whetherHasSE=se[2]))
+            self.layers_GCN.append(self._conv(H, self.num_classes, se_last))
         if AcontainsB(self.type_trick, ['Jumping']):
-            if self.layer_agg in ['concat', 'maxpool']:
-                self.layers_res.append(DenseConnection((self.num_layers + 1) * self.dim_hidden, self.num_classes, self.layer_agg))
-            elif self.layer_agg == 'attention':
-                self.layers_res.append(DenseConnection(self.dim_hidden, self.num_classes, self.layer_agg))
+            head = self._dense((L + 1) * H, self.num_classes)
+            if head is not None:
+                self.layers_res.append(head)
         else:
-            self.layers_MLP.append(nn.Linear(self.dim_hidden, self.num_classes))
+            self.layers_MLP.append(nn.Linear(H, self.num_classes))
         if AcontainsB(self.type_trick, ['IdentityMapping']):
             self.lamda = args.lamda
-        elif self.type_model == 'SGC':
-            self.lamda = 0.
-        elif self.type_model == 'GCN':
-            self.lamda = 1.
+        elif self.type_model in ('SGC', 'GCN'):
+            self.lamda = 0. if self.type_model == 'SGC' else 1.
+
+    def _conv(self, d_in, d_out, has_se):
+        return GCNConv(d_in, d_out, cached=self.cached, args=self.args, whetherHasSE=has_se)
+
+    def _dense(self, concat_dim, d_out):
+        if self.layer_agg in ('concat', 'maxpool'):
+            return DenseConnection(concat_dim, d_out, self.layer_agg)
+        if self.layer_agg == 'attention':
+            return DenseConnection(self.dim_hidden, d_out, self.layer_agg)
+        return None
+
+    def _res_layer(self, i):
+        """Per-layer skip connection; precedence Residual > Initial > Dense as in the reference (GCN.py:57-67)."""
+        if 'Residual' in self.type_trick:
+            return ResidualConnection(alpha=self.alpha)
+        if 'Initial' in self.type_trick:
+            return InitialConnection(alpha=self.alpha)
+        if 'Dense' in self.type_trick:
+            return self._dense((i + 2) * self.dim_hidden, self.dim_hidden)
+        return None
 
     def _graph(self, edge_index):
         """First call builds the device CSR and caches it forever; later edge_index arguments are
@@ -85,59 +99,65 @@ class TricksComb(nn.Module):
             self.dglgraph = CSRGraph(edge_index)
         return self.dglgraph
 
-    use_fused_trunk = True   # 'Initial' connection without a bare norm runs as one fused autograd node (trunk.py)
-
     def forward(self, x, edge_index, want_les=False):
         graph = self._graph(edge_index)
-        x_list, le_collection, se_reg_all = [], [], None
         new_adjs = self.graph_dropout(edge_index)      # computed and discarded, as in the reference (GCN.py:101,111)
         if self.use_fused_trunk and trunk.eligible(self, x, want_les):
             return trunk.forward(self, x, graph)
+        return self._forward_modular(x, graph, new_adjs, want_les)
+
+    def _forward_modular(self, x, graph, new_adjs, want_les):
+        """General path: one HIP operator per stage, any trick combination."""
+        L, train = self.num_layers, self.training
         row0 = getattr(graph, 'row_offset', 0)     # first global row of this rank's shard (0 on one GPU)
-        if self.has_residual_MLP:
-            x = ops.dropout(x, self.embedding_dropout, self.training, offset=row0 * x.shape[1])
-            x = gemm.linear(x, self.layers_MLP[0].weight, self.layers_MLP[0].bias, relu=True)   # Linear + ReLU, GCN.py:105-106
+        drop = lambda t, p: ops.dropout(t, p, train, offset=row0 * t.shape[1])   # noqa: E731
+        x_list, les, se_reg_all = [], [], None
+        if self.has_residual_MLP:                   # GCN.py:103-107
+            lin = self.layers_MLP[0]
+            x = gemm.linear(drop(x, self.embedding_dropout), lin.weight, lin.bias, relu=True)
             x_list.append(x)
-        norms_run = self.args.type_trick in ('BatchNorm', 'PairNorm', 'NodeNorm', 'MeanNorm', 'GroupNorm', 'CombNorm')
-        for i in range(self.num_layers):
-            x = ops.dropout(x, self.dropout, self.training, offset=row0 * x.shape[1])
+        norms_run = self.args.type_trick in _BARE_NORMS
+        mixes = AcontainsB(self.type_trick, ['Initial', 'Dense', 'Residual'])
+        for i in range(L):                          # GCN.py:109-131
             _unused_edge_index, _ = new_adjs[i]
-            act = self.has_residual_MLP or i < self.num_layers - 1
-            # the ReLU of GCN.py:127-128 rides in the aggregation epilogue when nothing sits in between
-            fuse_relu = act and not norms_run and not want_les
-            x, se_reg = self.layers_GCN[i](graph, x, _fused_relu=fuse_relu)
+            act = self.has_residual_MLP or i < L - 1
+            fuse_relu = act and not norms_run and not want_les   # ReLU rides in the aggregation epilogue
+            x, se_reg = self.layers_GCN[i](graph, drop(x, self.dropout), _fused_relu=fuse_relu)
             if se_reg is not None:
-                # intended semantics of GCN.py:116-120 (sum of per-layer norms); the reference's in-place
-                # `+=` on a tensor autograd saved breaks backward for >= 2 SE layers
+                # intended semantics of GCN.py:116-120 (sum of the per-layer norms); the reference's in-place `+=`
+                # on a tensor autograd saved breaks backward for >= 2 SE layers
                 se_reg_all = se_reg if se_reg_all is None else se_reg_all + se_reg
             x = run_norm_if_any(self, x, i)
             if want_les:
-                le_collection.append(x.clone().detach())
+                les.append(x.clone().detach())
             if act and not fuse_relu:
                 x = F.relu(x)
             x_list.append(x)
-            if AcontainsB(self.type_trick, ['Initial', 'Dense', 'Residual']):
+            if mixes:
                 x = self.layers_res[i](x_list)
-        x = ops.dropout(x, self.args.dropout, self.training, offset=row0 * x.shape[1])   # on the logits in non-residual mode (GCN.py:133)
+        x = drop(x, self.args.dropout)              # on the logits in non-residual mode (GCN.py:133)
         if self.has_residual_MLP:
             if AcontainsB(self.type_trick, ['Jumping']):
-                x = self.layers_res[0](x_list)
+                x = self.layers_res[0](x_list)      # index 0, as the reference writes it (GCN.py:136)
             else:
-                x = gemm.linear(x, self.layers_MLP[-1].weight, self.layers_MLP[-1].bias)
+                lin = self.layers_MLP[-1]
+                x = gemm.linear(x, lin.weight, lin.bias)
         if want_les:
-            return x, se_reg_all, th.cat(le_collection, dim=-1)
+            return x, se_reg_all, th.cat(les, dim=-1)
         return x, se_reg_all
 
     def get_se_dim(self, x, edge_index):
-        return self.forward(x, edge_index, want_les=1)[2].shape[-1]
+        return self.collect_SE(x, edge_index).shape[-1]
 
     def collect_SE(self, x, edge_index):
+        """Per-layer pre-activation outputs concatenated on the feature axis (teacher -> SEMLP hand-off)."""
         return self.forward(x, edge_index, want_les=1)[2]
 
 
 class GCNConv(nn.Module):
-    """Cold Brew's GraphConv: W first, + structural embedding `le`, sum-aggregate, symmetric
-    degree normalisation, + bias; returns (rst, se_reg) (reference GCN.py:152-258)."""
+    """Cold Brew's graph convolution:  Y = D_in^-1/2 . A^T . ( (X . D_out^-1/2) W + E ) + bias,  with the
+    optional structural embedding E (`le`, one row per node) and its Frobenius norm as regulariser.
+    Always multiplies by W before aggregating.  Returns (Y, ||E||_F or None)   (reference GCN.py:152-258)."""
 
     def __init__(self, in_feats, out_feats, norm='both', weight=True, bias=True, activation=None,
                  allow_zero_in_degree=False, cached=None, args=None, whetherHasSE=False):
@@ -145,42 +165,14 @@ class GCNConv(nn.Module):
         self.args = args
         self._in_feats, self._out_feats, self._norm = in_feats, out_feats, norm
         self._allow_zero_in_degree = allow_zero_in_degree
-        if weight:
-            self.weight = nn.Parameter(th.Tensor(in_feats, out_feats))
-        else:
-            self.register_parameter('weight', None)
-        if bias:
-            self.bias = nn.Parameter(th.Tensor(out_feats))
-        else:
-            self.register_parameter('bias', None)
-        self.reset_parameters()
         self._activation = activation
         self.whetherHasSE = whetherHasSE
+        # registration order weight, bias, le and the initialisers match the reference (xavier / zeros / randn)
+        self.weight = nn.Parameter(th.empty(in_feats, out_feats)) if weight else None
+        self.bias = nn.Parameter(th.empty(out_feats)) if bias else None
+        self.reset_parameters()
         if whetherHasSE:
-            self.le = nn.Parameter(th.randn(args.N_nodes, self._out_feats), requires_grad=True)
-
-    def forward(self, graph, feat, weight=None, edge_weight=None, _fused_relu=False):
-        if not self._allow_zero_in_degree:
-            graph.check_zero_in_degree()                       # GCN.py:187-197
-        if edge_weight is not None:
-            raise NotImplementedError('edge_weight (u_mul_e) is never passed by TricksComb (GCN.py:115,199-202)')
-        if self._norm != 'both':
-            raise NotImplementedError("only norm='both' is reachable from TricksComb")
-        if weight is not None:
-            if self.weight is not None:
-                raise DGLError('External weight is provided while at the same time the module has defined its own '
-                               'weight parameter. Please create the module with flag weight=False.')
-        else:
-            weight = self.weight
-        if weight is None:
-            raise NotImplementedError('GCNConv without a weight is not reachable from TricksComb')
-        le = self.le if self.whetherHasSE else None
-        h, se_reg = ops.transform(feat, graph.norm_out, weight, le, graph)          # GCN.py:213,225,230-236
-        rst = ops.aggregate(graph, h, row_scale=graph.norm_in, bias=self.bias,      # GCN.py:238,250,253
-                            relu=_fused_relu)
-        if self._activation is not None:
-            rst = self._activation(rst)
-        return rst, se_reg
+            self.le = nn.Parameter(th.randn(args.N_nodes, out_feats), requires_grad=True)
 
     def reset_parameters(self):
         if self.weight is not None:
@@ -190,6 +182,27 @@ class GCNConv(nn.Module):
 
     def set_allow_zero_in_degree(self, set_value):
         self._allow_zero_in_degree = set_value
+
+    def _pick_weight(self, weight):
+        if weight is not None and self.weight is not None:
+            raise DGLError('External weight is provided while at the same time the module has defined its own '
+                           'weight parameter. Please create the module with flag weight=False.')
+        w = self.weight if weight is None else weight
+        if w is None:
+            raise NotImplementedError('GCNConv without a weight is not reachable from TricksComb')
+        return w
+
+    def forward(self, graph, feat, weight=None, edge_weight=None, _fused_relu=False):
+        if not self._allow_zero_in_degree:
+            graph.check_zero_in_degree()                       # GCN.py:187-197
+        if edge_weight is not None:
+            raise NotImplementedError('edge_weight (u_mul_e) is never passed by TricksComb (GCN.py:115,199-202)')
+        if self._norm != 'both':
+            raise NotImplementedError("only norm='both' is reachable from TricksComb")
+        w = self._pick_weight(weight)
+        h, se_reg = ops.transform(feat, graph.norm_out, w, self.le if self.whetherHasSE else None, graph)   # :213,225,230-236
+        rst = ops.aggregate(graph, h, row_scale=graph.norm_in, bias=self.bias, relu=_fused_relu)            # :238,250,253
+        return (rst if self._activation is None else self._activation(rst)), se_reg
 
     def extra_repr(self):
         return f'in={self._in_feats}, out={self._out_feats}, normalization={self._norm}'

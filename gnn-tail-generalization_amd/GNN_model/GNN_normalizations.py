@@ -1,13 +1,18 @@
-"""TeacherGNN wrapper — drop-in for the reference's GNN_model/GNN_normalizations.py:9-73."""
+"""TeacherGNN wrapper on the HIP path — same surface as the reference's
+GNN_model/GNN_normalizations.py (TeacherGNN :9-65, GNN_norm :67-73): constructor `(args, proj2class)`,
+`forward`, `get_3_embs`, `graph2commonEmb`, attributes `se_reg_all` / `out` / `model.model`.
+"""
 import torch
 from torch import nn
 
 from ..utils import D
 from .GCN import TricksComb
-from .norm_tricks import *  # noqa: F401,F403  (the reference re-exports these names)
+from .norm_tricks import *  # noqa: F401,F403  (names re-exported by the reference module as well)
 
 
 class GNN_norm(nn.Module):
+    """Pass-through holder: `.model` is the TricksComb body (state_dict prefix `model.model.`)."""
+
     def __init__(self, args):
         super().__init__()
         self.model = TricksComb(args)
@@ -17,52 +22,50 @@ class GNN_norm(nn.Module):
 
 
 class TeacherGNN(nn.Module):
-    """Teacher GCN with structural embeddings.  Mutates `args` like the reference does
-    (num_classes := dim_commonEmb, num_feats := dim_learnable_input; :13-22)."""
+    """Teacher GCN with structural embeddings (Cold Brew).
+
+    Side effects on `args` are part of the contract (reference :13-22): `num_classes` becomes the common
+    embedding width (`dim_commonEmb`), and in learnable-input mode `num_feats` becomes
+    `dim_learnable_input` (the originals are kept as `*_bkup`)."""
 
     def __init__(self, args, proj2class=None):
         super().__init__()
-        proj2class = proj2class or nn.Identity()
-        args.num_classes_bkup = args.num_classes
-        args.num_classes = args.dim_commonEmb
         self.args = args
-        if self.args.dim_learnable_input > 0:
-            self.embs = nn.Parameter(torch.randn(args.N_nodes, args.dim_learnable_input) * 0.001, requires_grad=True)
-            self.args.num_feats_bkup = self.args.num_feats
-            self.args.num_feats = self.args.dim_learnable_input
+        args.num_classes_bkup, args.num_classes = args.num_classes, args.dim_commonEmb
+        learn_dim = args.dim_learnable_input
+        if learn_dim > 0:   # featureless mode: trainable node inputs replace x
+            self.embs = nn.Parameter(torch.randn(args.N_nodes, learn_dim) * 0.001, requires_grad=True)
+            args.num_feats_bkup, args.num_feats = args.num_feats, learn_dim
         self.model = GNN_norm(args)
         self.proj2linkp = nn.Identity()
-        self.proj2class = proj2class
+        self.proj2class = proj2class if proj2class else nn.Identity()
         self.dglgraph = None
-        self.se_reg_all = None
-        self.out = None
+        self.se_reg_all, self.out = None, None
 
-    def forward(self, x, edge_index):
+    def _input(self, x):
         if self.args.TeacherGNN.change_to_featureless:
             x = x * 0
-        if self.args.dim_learnable_input > 0:
-            x = self.embs
-        commonEmb, self.se_reg_all = self.model(x, edge_index)
-        self.out = commonEmb
-        return commonEmb
+        return self.embs if self.args.dim_learnable_input > 0 else x
+
+    def forward(self, x, edge_index):
+        self.out, self.se_reg_all = self.model(self._input(x), edge_index)
+        return self.out
 
     def get_3_embs(self, x, edge_index, mask=None, want_heads=True):
-        commonEmb = self.forward(x, edge_index)
-        emb4classi_full = self.proj2class(commonEmb)
-        if want_heads:
-            emb4classi = emb4classi_full[mask] if mask is not None else emb4classi_full
-            emb4linkp = self.proj2linkp(commonEmb)
-        else:
-            emb4linkp = emb4classi = None
         res = D()
-        res.commonEmb, res.emb4classi, res.emb4classi_full, res.emb4linkp = commonEmb, emb4classi, emb4classi_full, emb4linkp
+        res.commonEmb = self.forward(x, edge_index)
+        res.emb4classi_full = self.proj2class(res.commonEmb)
+        res.emb4classi = res.emb4linkp = None
+        if want_heads:
+            res.emb4classi = res.emb4classi_full if mask is None else res.emb4classi_full[mask]
+            res.emb4linkp = self.proj2linkp(res.commonEmb)
         return res
 
     def get_emb4linkp(self, x, edge_index, mask=None):
-        # the reference unpacks the D namespace as a tuple here (:59) and so always raises; it is
-        # unreachable in coldbrew mode.  This returns what that method was meant to return.
+        # the reference unpacks the result namespace as a tuple here (:59) and therefore always raises; the
+        # method is unreachable in coldbrew mode.  This returns what it was meant to return.
         return self.get_3_embs(x, edge_index, want_heads=True).emb4linkp
 
     def graph2commonEmb(self, x, edge_index, train_mask):
-        commonEmb = self.forward(x, edge_index)
-        return commonEmb[train_mask], commonEmb
+        emb = self.forward(x, edge_index)
+        return emb[train_mask], emb

@@ -1,11 +1,12 @@
-"""Skip-connection tricks — same classes and semantics as the reference's
-GNN_model/res_tricks.py:7-55 (ResidualConnection, InitialConnection, DenseConnection)."""
+"""Skip-connection tricks on the HIP path — the classes of the reference's GNN_model/res_tricks.py
+(ResidualConnection :7, InitialConnection :16, DenseConnection :25) with the same constructor
+arguments, parameter names (`layer_transform`, `layer_att`) and arithmetic."""
 import torch
 from torch import nn
 
 
 class _AlphaMix(nn.Module):
-    """(1 - alpha) * Xs[-1] + alpha * Xs[pick]; a single entry passes through."""
+    """(1 - alpha) * Xs[-1] + alpha * Xs[pick]; a single entry passes through unchanged."""
     _pick = -2
 
     def __init__(self, alpha=0.5):
@@ -20,15 +21,34 @@ class _AlphaMix(nn.Module):
         return axpby(1 - self.alpha, Xs[-1], self.alpha, Xs[self._pick])
 
 
-class ResidualConnection(_AlphaMix):     # res_tricks.py:7-14: mixes with the previous layer
+class ResidualConnection(_AlphaMix):
+    """Mixes with the previous layer's activation."""
     _pick = -2
 
 
-class InitialConnection(_AlphaMix):      # res_tricks.py:16-23: mixes with the first entry (input MLP output)
+class InitialConnection(_AlphaMix):
+    """Mixes with the first entry (the output of the input Linear + ReLU)."""
     _pick = 0
 
 
-class DenseConnection(nn.Module):        # res_tricks.py:25-55
+def _concat(mod, Xs):
+    return mod.layer_transform(torch.cat(Xs, dim=-1))
+
+
+def _maxpool(mod, Xs):
+    return torch.stack(Xs, dim=-1).amax(dim=-1)
+
+
+def _attention(mod, Xs):
+    """DAGNN-style retain scores over the k+1 stacked layers (n x (k+1) x c)."""
+    stacked = torch.stack(Xs, dim=1)
+    retain = torch.sigmoid(mod.layer_att(stacked).squeeze()).unsqueeze(1)
+    return torch.matmul(retain, stacked).squeeze()
+
+
+class DenseConnection(nn.Module):
+    _POOL = {'concat': _concat, 'maxpool': _maxpool, 'attention': _attention}
+
     def __init__(self, in_dim, out_dim, aggregation='concat'):
         super().__init__()
         self.in_dim, self.out_dim, self.aggregation = in_dim, out_dim, aggregation
@@ -39,12 +59,6 @@ class DenseConnection(nn.Module):        # res_tricks.py:25-55
 
     def forward(self, Xs: list):
         assert len(Xs) >= 1
-        if self.aggregation == 'concat':
-            return self.layer_transform(torch.cat(Xs, dim=-1))
-        if self.aggregation == 'maxpool':
-            return torch.stack(Xs, dim=-1).max(dim=-1)[0]
-        if self.aggregation == 'attention':          # DAGNN-style retain scores, n x (k+1) x c
-            pps = torch.stack(Xs, dim=1)
-            retain = torch.sigmoid(self.layer_att(pps).squeeze()).unsqueeze(1)
-            return torch.matmul(retain, pps).squeeze()
-        raise Exception('Unknown aggregation')
+        if self.aggregation not in self._POOL:
+            raise Exception('Unknown aggregation')
+        return self._POOL[self.aggregation](self, Xs)
