@@ -92,6 +92,11 @@ def cpu_baseline(a, full_nodes):
 
 def main():
     a = parse()
+    # Libraries (RCCL banner, rocm notices) write to the C stdout and flush it at exit, i.e. AFTER Python's
+    # prints; keep a private copy of fd 1 for the JSON line and route everything else to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -179,7 +184,7 @@ def main():
     }
     if a.cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(a, n_nodes)
-    print(json.dumps(out), flush=True)
+    os.write(json_fd, (json.dumps(out) + '\n').encode())
 
 
 if __name__ == '__main__':

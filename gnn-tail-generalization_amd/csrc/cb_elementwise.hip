@@ -227,12 +227,20 @@ __global__ void __launch_bounds__(kBlock) k_gather_rows(const float* __restrict_
   }
 }
 
-__global__ void k_colsum_finish(const float* __restrict__ partial, int nparts, int d, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= d) return;
+// out[c] = sum_p partial[p][c]: one block per column, strided partial sums per thread then a fixed-order
+// LDS tree — the result does not depend on scheduling.
+__global__ void __launch_bounds__(kBlock) k_colsum_finish(const float* __restrict__ partial, int nparts, int d, float* __restrict__ out) {
+  __shared__ float s_t[kBlock];
+  const int c = blockIdx.x;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * d + c];
-  out[c] = s;
+  for (int p = threadIdx.x; p < nparts; p += kBlock) s += partial[(int64_t)p * d + c];
+  s_t[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s_t[threadIdx.x] += s_t[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = s_t[0];
 }
 
 // sum of squares -> partial[block] (double accumulation across the partials in the finish kernel)
@@ -409,7 +417,7 @@ extern "C" int cb_act_bwd_f32(const float* g, const float* act, const float* row
                      (int)d, colsum ? (float*)ws : nullptr);
   CB_LAUNCH_CHECK();
   if (colsum) {
-    hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, (const float*)ws, (int)nb, (int)d, colsum);
+    hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)d), dim3(kBlock), 0, st, (const float*)ws, (int)nb, (int)d, colsum);
     CB_LAUNCH_CHECK();
   }
   return CB_OK;
@@ -479,7 +487,7 @@ static int launch_trunk_bwd(int mode, const float* g, const uint64_t* bits, cons
                        c_act, c_mix, partial);
   CB_LAUNCH_CHECK();
   if (colsum) {
-    hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, (const float*)ws, (int)nb, (int)d, colsum);
+    hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)d), dim3(kBlock), 0, st, (const float*)ws, (int)nb, (int)d, colsum);
     CB_LAUNCH_CHECK();
   }
   return CB_OK;
