@@ -104,6 +104,9 @@ class TricksComb(nn.Module):
         new_adjs = self.graph_dropout(edge_index)      # computed and discarded, as in the reference (GCN.py:101,111)
         if self.use_fused_trunk and trunk.eligible(self, x, want_les):
             return trunk.forward(self, x, graph)
+        if getattr(self.args, 'agg_dtype', 'f32') != 'f32' and not want_les:
+            raise NotImplementedError("--agg_dtype=bf16 (bf16-stored aggregation rows) is built for the fused 'Initial' trunk "
+                                      '(hidden width a multiple of 256); this configuration runs the fp32 operator path')
         return self._forward_modular(x, graph, new_adjs, want_les)
 
     def _forward_modular(self, x, graph, new_adjs, want_les):

@@ -11,7 +11,8 @@ Documented deviations:
     `--manual_assign_GPU` the device is LOCAL_RANK (one process per GPU) or 0;
   * `--dataset` additionally accepts 'ogbn-products' and the synthetic stand-ins of
     SURVEY.md §8(d) ('S-cora', 'S-pubmed', 'S-arxiv', 'S-products', 'S-pl10M', 'S-tiny');
-  * extra flags `--bench_steps`, `--dtype` are ignored by the reference path.
+  * extra flag `--agg_dtype {f32,bf16}` (build extension, BASELINE config 2): bf16 storage of the rows the
+    aggregation gathers, fp32 accumulation; the reference is fp32-only.
 """
 import argparse
 import os
@@ -132,6 +133,7 @@ def build_parser():
     a('--rexName', type=str, default='res.npy')
     a('--graph_dropout', type=float, default=0.2)
     a('--layerwise_dropout', action='store_true', default=False)
+    a('--agg_dtype', type=str, default='f32', choices=['f32', 'bf16'])   # build extension: storage type of the aggregated rows
     # link-prediction (I2-GTL) flags: accepted for CLI compatibility, unused by this path
     a('--public_data_convert_overlapped_subgraph', type=bool, default=True)
     a('--transfer_setting', type=str, default='i2t', choices=['t2t', 'u2t', 'i2t', 'u', 'i', ''])

@@ -42,4 +42,16 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int bcast_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int bcast_lane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
+// bf16 storage helpers (round-to-nearest-even, as torch's float -> bfloat16 conversion)
+typedef uint16_t bf16_t;
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) {
+  return make_uint2((uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16), (uint32_t)f32_to_bf16(c) | ((uint32_t)f32_to_bf16(d) << 16));
+}
+
 }  // namespace cb

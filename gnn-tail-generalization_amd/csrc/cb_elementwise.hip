@@ -142,10 +142,10 @@ __global__ void __launch_bounds__(kBlock) k_act_bwd(const float* __restrict__ g,
 // One wavefront per row per iteration, lane l owns columns 4l..4l+3 of each 256-wide tile (same mapping as
 // the forward epilogue, so mask word k is tested at bit l).
 // MODE 0: the layer kernel above.  MODE 1: trunk input stage  gy = (add + gm) * (act > 0); out = gy; colsum(gy).
-template <int MODE>
+template <int MODE, bool OUT_BF16>
 __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ g, const unsigned long long* __restrict__ bits,
                                                       const float* __restrict__ act, const float* __restrict__ row_scale,
-                                                      float* __restrict__ out, float* __restrict__ gx0, int accumulate,
+                                                      void* __restrict__ outv, float* __restrict__ gx0, int accumulate,
                                                       int64_t rows, int d, uint32_t thresh, float keep_scale, uint64_t seed,
                                                       int64_t row0, float c_act, float c_mix, float* __restrict__ partial) {
   extern __shared__ float s_red[];  // [4 waves][256 cols] per tile pass
@@ -188,7 +188,10 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
       const float sc = row_scale ? row_scale[r] : 1.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) s[k] += gy[k];
-      *reinterpret_cast<float4*>(out + off) = make_float4(gy[0] * sc, gy[1] * sc, gy[2] * sc, gy[3] * sc);
+      if constexpr (OUT_BF16)
+        *reinterpret_cast<uint2*>((bf16_t*)outv + off) = pack4_bf16(gy[0] * sc, gy[1] * sc, gy[2] * sc, gy[3] * sc);
+      else
+        *reinterpret_cast<float4*>((float*)outv + off) = make_float4(gy[0] * sc, gy[1] * sc, gy[2] * sc, gy[3] * sc);
     }
     if (partial) {
 #pragma unroll
@@ -469,22 +472,21 @@ extern "C" int cb_adam_step_f32(float* p, const float* g, float* m, float* v, in
   return CB_OK;
 }
 
-static int launch_trunk_bwd(int mode, const float* g, const uint64_t* bits, const float* act, const float* row_scale, float* out,
-                            float* gx0, int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed, int64_t row0,
+static int launch_trunk_bwd(int mode, int out_bf16, const float* g, const uint64_t* bits, const float* act, const float* row_scale,
+                            void* out, float* gx0, int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed, int64_t row0,
                             float c_act, float c_mix, float* colsum, void* ws, size_t ws_bytes, hipStream_t st) {
   int64_t nb = (rows + 63) / 64;
   if (nb > kMaxBlocks) nb = kMaxBlocks;
   const uint32_t thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
   const float ks = 1.f / (1.f - drop_p);
   float* partial = colsum ? (float*)ws : nullptr;
-  if (mode == 0)
-    hipLaunchKernelGGL((k_trunk_bwd<0>), dim3((unsigned)nb), dim3(kBlock), kBlock * 4 * sizeof(float), st, g,
-                       (const unsigned long long*)bits, act, row_scale, out, gx0, accumulate, rows, (int)d, thresh, ks, seed, row0,
-                       c_act, c_mix, partial);
-  else
-    hipLaunchKernelGGL((k_trunk_bwd<1>), dim3((unsigned)nb), dim3(kBlock), kBlock * 4 * sizeof(float), st, g,
-                       (const unsigned long long*)bits, act, row_scale, out, gx0, accumulate, rows, (int)d, thresh, ks, seed, row0,
-                       c_act, c_mix, partial);
+#define CB_TB_ARGS g, (const unsigned long long*)bits, act, row_scale, out, gx0, accumulate, rows, (int)d, thresh, ks, seed, row0, c_act, c_mix, partial
+  const dim3 grid((unsigned)nb), blk(kBlock);
+  const size_t sh = kBlock * 4 * sizeof(float);
+  if (mode == 0 && out_bf16) hipLaunchKernelGGL((k_trunk_bwd<0, true>), grid, blk, sh, st, CB_TB_ARGS);
+  else if (mode == 0) hipLaunchKernelGGL((k_trunk_bwd<0, false>), grid, blk, sh, st, CB_TB_ARGS);
+  else hipLaunchKernelGGL((k_trunk_bwd<1, false>), grid, blk, sh, st, CB_TB_ARGS);
+#undef CB_TB_ARGS
   CB_LAUNCH_CHECK();
   if (colsum) {
     hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)d), dim3(kBlock), 0, st, (const float*)ws, (int)nb, (int)d, colsum);
@@ -493,17 +495,17 @@ static int launch_trunk_bwd(int mode, const float* g, const uint64_t* bits, cons
   return CB_OK;
 }
 
-extern "C" int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits, const float* row_scale, float* out, float* gx0,
-                                      int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed, int64_t row0, float c_act,
-                                      float c_mix, float* colsum, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits, const float* row_scale, void* out, int out_bf16,
+                                      float* gx0, int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed, int64_t row0,
+                                      float c_act, float c_mix, float* colsum, void* ws, size_t ws_bytes, void* stream) {
   CB_CHECK_ARG(rows >= 0 && d > 0 && d % 256 == 0 && d < (1 << 20), CB_E_INVALID, "cb_trunk_layer_bwd_f32: d must be a multiple of 256");
   if (rows == 0) return CB_OK;
-  CB_CHECK_ARG(g && relu_bits && out && aligned16(g) && aligned16(out) && (!gx0 || aligned16(gx0)), CB_E_INVALID,
-               "cb_trunk_layer_bwd_f32: null or misaligned pointer");
+  CB_CHECK_ARG(g && relu_bits && out && aligned16(g) && ((uintptr_t)out % (out_bf16 ? 8 : 16) == 0) && (!gx0 || aligned16(gx0)),
+               CB_E_INVALID, "cb_trunk_layer_bwd_f32: null or misaligned pointer");
   CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, CB_E_INVALID, "cb_trunk_layer_bwd_f32: dropout p out of range");
   CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_colsum_workspace_bytes(rows, d)), CB_E_WORKSPACE, "cb_trunk_layer_bwd_f32: workspace too small");
-  return launch_trunk_bwd(0, g, relu_bits, nullptr, row_scale, out, gx0, accumulate, rows, d, drop_p, seed, row0, c_act, c_mix, colsum,
-                          ws, ws_bytes, (hipStream_t)stream);
+  return launch_trunk_bwd(0, out_bf16, g, relu_bits, nullptr, row_scale, out, gx0, accumulate, rows, d, drop_p, seed, row0, c_act, c_mix,
+                          colsum, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int cb_trunk_input_bwd_f32(const float* g, const float* add, const float* act, float* out, int64_t rows, int64_t d,
@@ -515,8 +517,8 @@ extern "C" int cb_trunk_input_bwd_f32(const float* g, const float* add, const fl
                "cb_trunk_input_bwd_f32: null or misaligned pointer");
   CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, CB_E_INVALID, "cb_trunk_input_bwd_f32: dropout p out of range");
   CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_colsum_workspace_bytes(rows, d)), CB_E_WORKSPACE, "cb_trunk_input_bwd_f32: workspace too small");
-  return launch_trunk_bwd(1, g, nullptr, act, nullptr, out, const_cast<float*>(add), 1, rows, d, drop_p, seed, row0, 0.f, 0.f, colsum, ws,
-                          ws_bytes, (hipStream_t)stream);
+  return launch_trunk_bwd(1, 0, g, nullptr, act, nullptr, out, const_cast<float*>(add), 1, rows, d, drop_p, seed, row0, 0.f, 0.f, colsum,
+                          ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int cb_gather_rows_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, float* out,

@@ -152,10 +152,11 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
 }
 
 // ---- NN ------------------------------------------------------------------------------------
-template <int WM, int WN, bool ALIGNED>
+template <int WM, int WN, bool ALIGNED, bool OUT_BF16>
 __global__ void __launch_bounds__(256) k_gemm_nn(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
-                                                 float* __restrict__ C, int64_t ldc, int64_t M, int N, int K, GemmEpilogue ep,
+                                                 void* __restrict__ Cv, int64_t ldc, int64_t M, int N, int K, GemmEpilogue ep,
                                                  int n_row_blocks, int n_col_blocks, int c_vec_ok) {
+  float* C = (float*)Cv;
   using T = Tile<WM, WN>;
   constexpr int BM = T::BM, BN = T::BN, LDA = T::LDA, LDB = T::LDB;
   __shared__ __attribute__((aligned(16))) float smem[T::SMEM_FLOATS];
@@ -243,12 +244,22 @@ __global__ void __launch_bounds__(256) k_gemm_nn(const float* __restrict__ A, in
           o[q] = o[q] * rs + ad[q] + bv[q];
           if (ep.relu) o[q] = fmaxf(o[q], 0.f);
         }
-        float* cp = C + m * ldc + n;
-        if (full4 && c_vec_ok) {
-          *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
-        } else {
+        if constexpr (OUT_BF16) {   // Z stored as bf16 for the aggregation (build extension, fp32 accumulate downstream)
+          bf16_t* cp = (bf16_t*)Cv + m * ldc + n;
+          if (full4 && c_vec_ok) {
+            *reinterpret_cast<uint2*>(cp) = pack4_bf16(o[0], o[1], o[2], o[3]);
+          } else {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) if (n + q < N) cp[q] = o[q];
+            for (int q = 0; q < 4; ++q) if (n + q < N) cp[q] = f32_to_bf16(o[q]);
+          }
+        } else {
+          float* cp = C + m * ldc + n;
+          if (full4 && c_vec_ok) {
+            *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (n + q < N) cp[q] = o[q];
+          }
         }
       }
     }
@@ -341,19 +352,19 @@ static inline void tn_tile(int64_t K1, int64_t K2, int& bm, int& bn) {
   else { bm = 128; bn = 128; }
 }
 
-template <int WM, int WN>
-static int launch_nn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
+template <int WM, int WN, bool OUT_BF16 = false>
+static int launch_nn(const float* A, int64_t lda, const float* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
                      int64_t K, GemmEpilogue ep, hipStream_t st) {
   using T = Tile<WM, WN>;
   const int nrb = (int)((M + T::BM - 1) / T::BM), ncb = (int)((N + T::BN - 1) / T::BN);
   const int64_t groups = (nrb + 7) / 8;
   const dim3 grid((unsigned)(groups * 8 * ncb));
   const bool aligned = al16(A) && al16(B) && lda % 4 == 0 && ldb % 4 == 0;
-  const int c_vec_ok = al16(C) && ldc % 4 == 0 && (!ep.addend || (al16(ep.addend) && ep.ld_add % 4 == 0));
+  const int c_vec_ok = ((uintptr_t)C % (OUT_BF16 ? 8 : 16) == 0) && ldc % 4 == 0 && (!ep.addend || (al16(ep.addend) && ep.ld_add % 4 == 0));
   if (aligned)
-    hipLaunchKernelGGL((k_gemm_nn<WM, WN, true>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
+    hipLaunchKernelGGL((k_gemm_nn<WM, WN, true, OUT_BF16>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
   else
-    hipLaunchKernelGGL((k_gemm_nn<WM, WN, false>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
+    hipLaunchKernelGGL((k_gemm_nn<WM, WN, false, OUT_BF16>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
   CB_LAUNCH_CHECK();
   return CB_OK;
 }
@@ -397,6 +408,20 @@ extern "C" int cb_gemm_nn_f32(const float* A, int64_t lda, const float* B, int64
   hipStream_t st = (hipStream_t)stream;
   if (N <= 64) return launch_nn<4, 1>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
   return launch_nn<2, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
+}
+
+extern "C" int cb_gemm_nn_bf16out_f32(const float* A, int64_t lda, const float* B, int64_t ldb, uint16_t* C, int64_t ldc, int64_t M,
+                                      int64_t N, int64_t K, const float* rowscale, const float* addend, int64_t ld_add,
+                                      const float* bias, int relu, void* stream) {
+  CB_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, CB_E_INVALID, "cb_gemm_nn_bf16out_f32: negative size");
+  CB_CHECK_ARG(N < (1 << 24) && K < (1 << 24) && (M + 63) / 64 < (1 << 24), CB_E_RANGE, "cb_gemm_nn_bf16out_f32: size out of range");
+  if (M == 0 || N == 0) return CB_OK;
+  CB_CHECK_ARG(C && (K == 0 || (A && B)) && lda >= K && ldb >= N && ldc >= N && (!addend || ld_add >= N), CB_E_INVALID,
+               "cb_gemm_nn_bf16out_f32: null pointer or leading dimension too small");
+  GemmEpilogue ep{rowscale, addend, ld_add, bias, relu};
+  hipStream_t st = (hipStream_t)stream;
+  if (N <= 64) return launch_nn<4, 1, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
+  return launch_nn<2, 2, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
 }
 
 extern "C" size_t cb_gemm_tn_workspace_bytes(int64_t M, int64_t K1, int64_t K2) {

@@ -67,6 +67,26 @@ __device__ __forceinline__ void gather(float (&v)[VEC], const float* __restrict_
   }
 }
 
+// Source-row load of the aggregation: fp32 rows, or bf16-stored rows widened to fp32 (accumulation stays fp32)
+template <int VEC, typename HT>
+__device__ __forceinline__ void gather_in(float (&v)[VEC], const HT* __restrict__ p) {
+  if constexpr (sizeof(HT) == 4) {
+    gather<VEC>(v, reinterpret_cast<const float*>(p));
+  } else if constexpr (VEC == 4) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16);
+    v[1] = __uint_as_float(t.x & 0xFFFF0000u);
+    v[2] = __uint_as_float(t.y << 16);
+    v[3] = __uint_as_float(t.y & 0xFFFF0000u);
+  } else if constexpr (VEC == 2) {
+    const uint32_t t = *reinterpret_cast<const uint32_t*>(p);
+    v[0] = __uint_as_float(t << 16);
+    v[1] = __uint_as_float(t & 0xFFFF0000u);
+  } else {
+    v[0] = bf16_to_f32(*reinterpret_cast<const bf16_t*>(p));
+  }
+}
+
 template <int VEC>
 __device__ __forceinline__ void store_stream(float* __restrict__ p, const float (&v)[VEC]) {
   // written once, read by a later kernel: keep it out of the caches
@@ -143,9 +163,9 @@ __device__ __forceinline__ void write_row(float* __restrict__ out_row, const flo
 
 // Walks the contiguous edge range of local rows [rlo, rhi) of this wavefront's row block.
 // my_ptr: lane i holds rowptr[r0 + i] (i <= nr).  All control flow is wave-uniform.
-template <int VEC, int U, bool FULL, bool FUSED>
+template <int VEC, int U, bool FULL, bool FUSED, typename HT>
 __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr, float my_scale, int r0, const int* __restrict__ col,
-                                            const float* __restrict__ h_lane, int64_t ld_h, float* __restrict__ out_lane,
+                                            const HT* __restrict__ h_lane, int64_t ld_h, float* __restrict__ out_lane,
                                             int64_t ld_out, bool active_in, int relu, const float (&bvec)[VEC], const FusedEpi& fe,
                                             int c0) {
   const bool active = FULL ? true : active_in;
@@ -197,7 +217,7 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int c = bcast_lane(my_col, k + u);
-        if (active) gather<VEC>(v[u], h_lane + (int64_t)c * ld_h);
+        if (active) gather_in<VEC, HT>(v[u], h_lane + (int64_t)c * ld_h);
         else zero<VEC>(v[u]);
       }
 #pragma unroll
@@ -211,7 +231,7 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
     for (; k < cnt; ++k) {
       const int c = bcast_lane(my_col, k);
       float v[VEC];
-      if (active) gather<VEC>(v, h_lane + (int64_t)c * ld_h);
+      if (active) gather_in<VEC, HT>(v, h_lane + (int64_t)c * ld_h);
       else zero<VEC>(v);
       const int e = base + k;
       while (e == cur_end) flush();
@@ -222,9 +242,9 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
   while (cur < rhi) flush();  // last row + trailing empty rows
 }
 
-template <int VEC, int RPW, int U, bool FULL, bool FUSED>
+template <int VEC, int RPW, int U, bool FULL, bool FUSED, typename HT>
 __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowptr, const int* __restrict__ col,
-                                                   const float* __restrict__ h, int64_t ld_h, float* __restrict__ out,
+                                                   const HT* __restrict__ h, int64_t ld_h, float* __restrict__ out,
                                                    int64_t ld_out, int n_rows, int d, Epilogue ep, int hub_T, FusedEpi fe) {
   static_assert(!FUSED || (VEC == 4 && FULL), "fused epilogue: d % 256 == 0, float4 lanes");
   static_assert(RPW < kWave, "row block must fit the lanes of one wavefront (+1 end pointer)");
@@ -248,26 +268,26 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
 #pragma unroll
     for (int i = 0; i < VEC; ++i) bvec[i] = ep.bias[c0 + i];
   }
-  const float* h_lane = h + c0;
+  const HT* h_lane = h + c0;
   float* out_lane = out + c0;
 
   if (hubmask == 0) {
-    stream_rows<VEC, U, FULL, FUSED>(0, nr, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0);
+    stream_rows<VEC, U, FULL, FUSED, HT>(0, nr, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0);
   } else {
     int r = 0;
     while (r < nr) {  // maximal hub-free runs; hub rows are written by the hub kernels
       unsigned long long m = hubmask >> r;
       int nh = m ? r + (__ffsll((long long)m) - 1) : nr;
-      if (nh > r) stream_rows<VEC, U, FULL, FUSED>(r, nh, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0);
+      if (nh > r) stream_rows<VEC, U, FULL, FUSED, HT>(r, nh, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0);
       r = nh + 1;
     }
   }
 }
 
 // One wavefront per chunk of T edges of a hub row -> one partial row in `partial`.
-template <int VEC, int U>
+template <int VEC, int U, typename HT>
 __global__ void __launch_bounds__(256) k_spmm_hub_chunks(const int* __restrict__ rowptr, const int* __restrict__ col,
-                                                         const float* __restrict__ h, int64_t ld_h, int d, int hub_T,
+                                                         const HT* __restrict__ h, int64_t ld_h, int d, int hub_T,
                                                          int n_hubs, int n_chunks, const int* __restrict__ hub_rows,
                                                          const int* __restrict__ hub_chunk_ptr, float* __restrict__ partial,
                                                          int64_t ld_p) {
@@ -286,7 +306,7 @@ __global__ void __launch_bounds__(256) k_spmm_hub_chunks(const int* __restrict__
   const int j = chunk - hub_chunk_ptr[lo];
   const int e_begin = rowptr[row] + j * hub_T;
   const int e_end = min(e_begin + hub_T, rowptr[row + 1]);
-  const float* h_lane = h + c0;
+  const HT* h_lane = h + c0;
   float acc[VEC];
   zero<VEC>(acc);
   for (int base = e_begin; base < e_end; base += kWave) {
@@ -299,7 +319,7 @@ __global__ void __launch_bounds__(256) k_spmm_hub_chunks(const int* __restrict__
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int c = bcast_lane(my_col, k + u);
-        if (active) gather<VEC>(v[u], h_lane + (int64_t)c * ld_h);
+        if (active) gather_in<VEC, HT>(v[u], h_lane + (int64_t)c * ld_h);
         else zero<VEC>(v[u]);
       }
 #pragma unroll
@@ -310,7 +330,7 @@ __global__ void __launch_bounds__(256) k_spmm_hub_chunks(const int* __restrict__
     for (; k < cnt; ++k) {
       const int c = bcast_lane(my_col, k);
       float v[VEC];
-      if (active) gather<VEC>(v, h_lane + (int64_t)c * ld_h);
+      if (active) gather_in<VEC, HT>(v, h_lane + (int64_t)c * ld_h);
       else zero<VEC>(v);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] += v[i];
@@ -368,8 +388,8 @@ __global__ void __launch_bounds__(256) k_spmm_hub_finish(int d, int n_hubs, cons
 
 static inline int64_t partial_ld(int64_t d) { return (d + 3) / 4 * 4; }
 
-template <int VEC, bool FUSED, int RPW, int U>
-static int launch_spmm_cfg(const int32_t* rowptr, const int32_t* col, int64_t N, const float* h, int64_t ld_h, int64_t d,
+template <int VEC, bool FUSED, int RPW, int U, typename HT>
+static int launch_spmm_cfg(const int32_t* rowptr, const int32_t* col, int64_t N, const HT* h, int64_t ld_h, int64_t d,
                            Epilogue ep, float* out, int64_t ld_out, int hub_T, int n_hubs, int n_chunks,
                            const int32_t* hub_rows, const int32_t* hub_chunk_ptr, float* partial, hipStream_t st, FusedEpi fe) {
   const int tile = kWave * VEC;
@@ -379,13 +399,13 @@ static int launch_spmm_cfg(const int32_t* rowptr, const int32_t* col, int64_t N,
     int64_t n_waves = (N + RPW - 1) / RPW;
     dim3 grid((unsigned)((n_waves + waves_per_block - 1) / waves_per_block), ny);
     if constexpr (FUSED) {
-      hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, true, true>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h,
+      hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, true, true, HT>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h,
                          out, ld_out, (int)N, (int)d, ep, hub_T, fe);
     } else if (d % tile == 0) {
-      hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, true, false>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h,
+      hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, true, false, HT>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h,
                          out, ld_out, (int)N, (int)d, ep, hub_T, fe);
     } else {
-      hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, false, false>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h,
+      hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, false, false, HT>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h,
                          out, ld_out, (int)N, (int)d, ep, hub_T, fe);
     }
     CB_LAUNCH_CHECK();
@@ -393,7 +413,7 @@ static int launch_spmm_cfg(const int32_t* rowptr, const int32_t* col, int64_t N,
   if (n_hubs > 0) {
     const int64_t ld_p = partial_ld(d);
     dim3 grid((unsigned)((n_chunks + waves_per_block - 1) / waves_per_block), ny);
-    hipLaunchKernelGGL((k_spmm_hub_chunks<VEC, 8>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h, (int)d,
+    hipLaunchKernelGGL((k_spmm_hub_chunks<VEC, 8, HT>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h, (int)d,
                        hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, ld_p);
     CB_LAUNCH_CHECK();
     dim3 grid2((unsigned)((n_hubs + waves_per_block - 1) / waves_per_block), ny);
@@ -422,23 +442,23 @@ static int spmm_variant() {
   return v;
 }
 
-template <int VEC, bool FUSED = false>
-static int launch_spmm(const int32_t* rowptr, const int32_t* col, int64_t N, const float* h, int64_t ld_h, int64_t d,
+template <int VEC, bool FUSED = false, typename HT = float>
+static int launch_spmm(const int32_t* rowptr, const int32_t* col, int64_t N, const HT* h, int64_t ld_h, int64_t d,
                        Epilogue ep, float* out, int64_t ld_out, int hub_T, int n_hubs, int n_chunks,
                        const int32_t* hub_rows, const int32_t* hub_chunk_ptr, float* partial, hipStream_t st,
                        FusedEpi fe = FusedEpi{}) {
 #define CB_SPMM_ARGS rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st, fe
-  if constexpr (VEC == 4 && !FUSED) {
+  if constexpr (VEC == 4 && !FUSED && sizeof(HT) == 4) {
     switch (spmm_variant()) {
-      case 1: return launch_spmm_cfg<VEC, FUSED, 8, 8>(CB_SPMM_ARGS);
-      case 2: return launch_spmm_cfg<VEC, FUSED, 32, 8>(CB_SPMM_ARGS);
-      case 3: return launch_spmm_cfg<VEC, FUSED, 16, 4>(CB_SPMM_ARGS);
-      case 4: return launch_spmm_cfg<VEC, FUSED, 16, 16>(CB_SPMM_ARGS);
-      case 5: return launch_spmm_cfg<VEC, FUSED, 8, 4>(CB_SPMM_ARGS);
+      case 1: return launch_spmm_cfg<VEC, FUSED, 8, 8, HT>(CB_SPMM_ARGS);
+      case 2: return launch_spmm_cfg<VEC, FUSED, 32, 8, HT>(CB_SPMM_ARGS);
+      case 3: return launch_spmm_cfg<VEC, FUSED, 16, 4, HT>(CB_SPMM_ARGS);
+      case 4: return launch_spmm_cfg<VEC, FUSED, 16, 16, HT>(CB_SPMM_ARGS);
+      case 5: return launch_spmm_cfg<VEC, FUSED, 8, 4, HT>(CB_SPMM_ARGS);
       default: break;
     }
   }
-  return launch_spmm_cfg<VEC, FUSED, 16, 8>(CB_SPMM_ARGS);
+  return launch_spmm_cfg<VEC, FUSED, 16, 8, HT>(CB_SPMM_ARGS);
 #undef CB_SPMM_ARGS
 }
 
@@ -477,7 +497,7 @@ extern "C" int cb_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_
   return launch_spmm<1>(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st);
 }
 
-extern "C" int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h,
+static int spmm_fused_impl(int h_bf16, const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const void* h, int64_t ld_h,
                                      int64_t d, const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix,
                                      float c_act, float c_mix, float drop_p, uint64_t seed, int64_t row0, uint64_t* relu_bits,
                                      float* out_act, int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_T,
@@ -488,7 +508,7 @@ extern "C" int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, 
   if (N == 0) return CB_OK;
   CB_CHECK_ARG(rowptr && h && out_next && (E == 0 || col), CB_E_INVALID, "cb_spmm_csr_fused_f32: null pointer");
   CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, CB_E_INVALID, "cb_spmm_csr_fused_f32: dropout p out of range");
-  const bool al = ((uintptr_t)h % 16 == 0) && ((uintptr_t)out_next % 16 == 0) && ld_h % 4 == 0 && ld_next % 4 == 0 &&
+  const bool al = ((uintptr_t)h % (h_bf16 ? 8 : 16) == 0) && ((uintptr_t)out_next % 16 == 0) && ld_h % 4 == 0 && ld_next % 4 == 0 &&
                   (!mix_src || ((uintptr_t)mix_src % 16 == 0 && ld_mix % 4 == 0)) &&
                   (!out_act || ((uintptr_t)out_act % 16 == 0 && ld_act % 4 == 0));
   CB_CHECK_ARG(al && ld_h >= d && ld_next >= d, CB_E_INVALID, "cb_spmm_csr_fused_f32: 16-byte aligned rows required");
@@ -503,6 +523,63 @@ extern "C" int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, 
   fe.keep_scale = 1.f / (1.f - drop_p);
   fe.seed = seed; fe.row0 = row0; fe.bits = (unsigned long long*)relu_bits;
   fe.out_act = out_act; fe.ld_act = ld_act; fe.out_next = out_next; fe.ld_next = ld_next; fe.d = (int)d;
-  return launch_spmm<4, true>(rowptr, col, N, h, ld_h, d, ep, out_next, ld_next, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr,
-                              (float*)ws, (hipStream_t)stream, fe);
+  if (h_bf16)
+    return launch_spmm<4, true, bf16_t>(rowptr, col, N, (const bf16_t*)h, ld_h, d, ep, out_next, ld_next, hub_T, n_hubs, n_chunks,
+                                        hub_rows, hub_chunk_ptr, (float*)ws, (hipStream_t)stream, fe);
+  return launch_spmm<4, true, float>(rowptr, col, N, (const float*)h, ld_h, d, ep, out_next, ld_next, hub_T, n_hubs, n_chunks, hub_rows,
+                                     hub_chunk_ptr, (float*)ws, (hipStream_t)stream, fe);
+}
+
+#define CB_FUSED_PARAMS                                                                                                          \
+  const int32_t *rowptr, const int32_t *col, int64_t N, int64_t E, const void *h, int64_t ld_h, int64_t d, const float *row_scale, \
+      const float *bias, const float *mix_src, int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed, int64_t row0, \
+      uint64_t *relu_bits, float *out_act, int64_t ld_act, float *out_next, int64_t ld_next, int32_t hub_T, int32_t n_hubs,        \
+      int32_t n_chunks, const int32_t *hub_rows, const int32_t *hub_chunk_ptr, void *ws, size_t ws_bytes, void *stream
+#define CB_FUSED_ARGS                                                                                                            \
+  rowptr, col, N, E, h, ld_h, d, row_scale, bias, mix_src, ld_mix, c_act, c_mix, drop_p, seed, row0, relu_bits, out_act, ld_act,  \
+      out_next, ld_next, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, stream
+
+extern "C" int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h,
+                                     int64_t d, const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix,
+                                     float c_act, float c_mix, float drop_p, uint64_t seed, int64_t row0, uint64_t* relu_bits,
+                                     float* out_act, int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_T,
+                                     int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr,
+                                     void* ws, size_t ws_bytes, void* stream) {
+  return spmm_fused_impl(0, CB_FUSED_ARGS);
+}
+
+extern "C" int cb_spmm_csr_fused_bf16_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const uint16_t* h,
+                                          int64_t ld_h, int64_t d, const float* row_scale, const float* bias, const float* mix_src,
+                                          int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed, int64_t row0,
+                                          uint64_t* relu_bits, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
+                                          int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
+                                          const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
+  return spmm_fused_impl(1, CB_FUSED_ARGS);
+}
+
+// bf16-stored source rows, fp32 accumulation and output (build extension: BASELINE config 2)
+extern "C" int cb_spmm_csr_bf16_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const uint16_t* h, int64_t ld_h,
+                                    int64_t d, const float* row_scale, const float* bias, int relu, float* out, int64_t ld_out,
+                                    int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
+                                    const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(N >= 0 && E >= 0 && d >= 0, CB_E_INVALID, "cb_spmm_csr_bf16_f32: negative size");
+  CB_CHECK_ARG(N < INT32_MAX && E < INT32_MAX && d < (1 << 20), CB_E_RANGE, "cb_spmm_csr_bf16_f32: size exceeds the int32 contract");
+  if (N == 0 || d == 0) return CB_OK;
+  CB_CHECK_ARG(rowptr && h && out && (E == 0 || col), CB_E_INVALID, "cb_spmm_csr_bf16_f32: null pointer");
+  CB_CHECK_ARG(ld_h >= d && ld_out >= d, CB_E_INVALID, "cb_spmm_csr_bf16_f32: leading dimension smaller than d");
+  CB_CHECK_ARG(hub_T > 0 && n_hubs >= 0 && n_chunks >= 0, CB_E_INVALID, "cb_spmm_csr_bf16_f32: bad hub plan");
+  CB_CHECK_ARG(n_hubs == 0 || (hub_rows && hub_chunk_ptr && ws && ws_bytes >= cb_spmm_workspace_bytes(n_chunks, d)),
+               CB_E_WORKSPACE, "cb_spmm_csr_bf16_f32: hub plan given but workspace missing/too small");
+  Epilogue ep{row_scale, bias, relu};
+  hipStream_t st = (hipStream_t)stream;
+  if (n_hubs == 0) hub_T = INT32_MAX;
+  const bf16_t* hb = (const bf16_t*)h;
+  const bool al8 = ((uintptr_t)h % 8 == 0) && ((uintptr_t)out % 16 == 0) && (ld_h % 4 == 0) && (ld_out % 4 == 0) && (d % 4 == 0);
+  const bool al4 = ((uintptr_t)h % 4 == 0) && ((uintptr_t)out % 8 == 0) && (ld_h % 2 == 0) && (ld_out % 2 == 0) && (d % 2 == 0);
+  float* partial = (float*)ws;
+  if (al8 && d >= 256)
+    return launch_spmm<4, false, bf16_t>(rowptr, col, N, hb, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st);
+  if (al4 && d >= 128)
+    return launch_spmm<2, false, bf16_t>(rowptr, col, N, hb, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st);
+  return launch_spmm<1, false, bf16_t>(rowptr, col, N, hb, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st);
 }

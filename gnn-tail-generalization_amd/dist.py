@@ -109,9 +109,12 @@ class HaloPlan:
 
 
 def _pack_rows(x, idx):
-    if x.is_cuda:
+    if x.is_cuda and x.dtype == torch.float32:
         from .ops import gather_rows_by_index
         return gather_rows_by_index(x, idx)
+    if x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] % 2 == 0 and x.is_contiguous():
+        from .ops import gather_rows_by_index      # bf16 rows move as packed 32-bit words
+        return gather_rows_by_index(x.view(torch.float32), idx).view(torch.bfloat16)
     return x.index_select(0, idx)
 
 

@@ -21,8 +21,9 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
 
 
-def mm_nn(a, b, rowscale=None, addend=None, bias=None, relu=False):
-    """act(rowscale[:,None] * (a @ b) + addend + bias) in one kernel; a [M,K], b [K,N] float32 on device."""
+def mm_nn(a, b, rowscale=None, addend=None, bias=None, relu=False, out_bf16=False):
+    """act(rowscale[:,None] * (a @ b) + addend + bias) in one kernel; a [M,K], b [K,N] float32 on device.
+    out_bf16: store the result as bfloat16 (round-to-nearest-even) — the bf16 aggregation variant."""
     lib = _lib.load()
     _lib.require_device(a, b, rowscale, addend, bias)
     a, b = _rowmajor(a), _rowmajor(b)
@@ -34,11 +35,12 @@ def mm_nn(a, b, rowscale=None, addend=None, bias=None, relu=False):
         raise TypeError('mm_nn expects float32')
     if addend is not None:
         addend = _rowmajor(addend)
-    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    out = torch.empty((M, N), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=a.device)
+    fn = lib.cb_gemm_nn_bf16out_f32 if out_bf16 else lib.cb_gemm_nn_f32
     with torch.cuda.device(a.device):
-        _lib.check(lib.cb_gemm_nn_f32(_lib.ptr(a), _ld(a), _lib.ptr(b), _ld(b), _lib.ptr(out), N, M, N, K, _lib.ptr(rowscale),
-                                      _lib.ptr(addend), _ld(addend) if addend is not None else 0, _lib.ptr(bias),
-                                      int(bool(relu)), _lib.stream_ptr()), 'cb_gemm_nn_f32')
+        _lib.check(fn(_lib.ptr(a), _ld(a), _lib.ptr(b), _ld(b), _lib.ptr(out), N, M, N, K, _lib.ptr(rowscale),
+                      _lib.ptr(addend), _ld(addend) if addend is not None else 0, _lib.ptr(bias),
+                      int(bool(relu)), _lib.stream_ptr()), 'cb_gemm_nn')
     return out
 
 

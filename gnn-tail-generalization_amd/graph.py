@@ -137,8 +137,9 @@ class CSRGraph:
         """out[v] = act(row_scale[v] * sum_{u in row v} h[u] + bias); by-dst CSR unless transpose."""
         lib = _lib.load()
         _lib.require_device(h, row_scale, bias, out)
-        if h.dtype != torch.float32:
-            raise TypeError(f'aggregation expects float32 features, got {h.dtype}')
+        if h.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError(f'aggregation expects float32 (or bf16-stored) features, got {h.dtype}')
+        bf16 = h.dtype == torch.bfloat16
         if transpose and self.rowptr_t is None:
             raise ValueError('this graph holds the forward orientation only')
         if h.dim() != 2 or h.shape[0] != self.n_cols:
@@ -157,20 +158,23 @@ class CSRGraph:
         if prof is not None:   # HIP events on the stream the kernels are launched on
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
+        fn = lib.cb_spmm_csr_bf16_f32 if bf16 else lib.cb_spmm_csr_f32
         with torch.cuda.device(h.device):
-            _lib.check(lib.cb_spmm_csr_f32(_lib.ptr(rowptr), _lib.ptr(col), self.N, self.E, _lib.ptr(h), ld_h, d,
-                                           _lib.ptr(row_scale), _lib.ptr(bias), int(bool(relu)), _lib.ptr(out), ld_o,
-                                           self.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows),
-                                           _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
-                       'cb_spmm_csr_f32')
+            _lib.check(fn(_lib.ptr(rowptr), _lib.ptr(col), self.N, self.E, _lib.ptr(h), ld_h, d,
+                          _lib.ptr(row_scale), _lib.ptr(bias), int(bool(relu)), _lib.ptr(out), ld_o,
+                          self.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows),
+                          _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
+                       'cb_spmm_csr')
         if prof is not None:
             ev1.record()
-            prof.append((ev0, ev1, self.algorithmic_bytes(d, row_scale=row_scale is not None, bias=bias is not None)))
+            prof.append((ev0, ev1, self.algorithmic_bytes(d, row_scale=row_scale is not None, bias=bias is not None,
+                                                          src_elem=2 if bf16 else 4)))
         return out
 
-    def algorithmic_bytes(self, d, elem=4, row_scale=True, bias=True):
-        """E*(d*s+4) + N*(d*s+4) [+4N row scale] [+d*s bias]."""
-        b = self.E * (d * elem + 4) + self.N * (d * elem + 4)
+    def algorithmic_bytes(self, d, elem=4, row_scale=True, bias=True, src_elem=None):
+        """E*(d*s+4) + N*(d*s+4) [+4N row scale] [+d*s bias]; src_elem = bytes per gathered element
+        when the source rows are stored narrower than the output (bf16 variant)."""
+        b = self.E * (d * (src_elem or elem) + 4) + self.N * (d * elem + 4)
         if row_scale:
             b += 4 * self.N
         if bias:

@@ -52,8 +52,10 @@ def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False):
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
+    bf16 = z.dtype == torch.bfloat16
+    fn = lib.cb_spmm_csr_fused_bf16_f32 if bf16 else lib.cb_spmm_csr_fused_f32
     with torch.cuda.device(dev):
-        _lib.check(lib.cb_spmm_csr_fused_f32(
+        _lib.check(fn(
             _lib.ptr(g.rowptr), _lib.ptr(g.col), n, g.E, _lib.ptr(z), z.stride(0), d, _lib.ptr(graph.norm_in), _lib.ptr(bias),
             _lib.ptr(x0), x0.stride(0) if x0 is not None else 0, float(c_act), float(c_mix), float(p), ctypes.c_uint64(seed),
             int(getattr(graph, 'row_offset', 0)), _lib.ptr(bits), _lib.ptr(act), d, _lib.ptr(out_next), d, g.hub_threshold,
@@ -62,7 +64,7 @@ def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False):
     if prof is not None:
         ev1.record()
         # algorithmic bytes of the fused launch: the plain aggregation + the mixed-in row read + the mask bits
-        prof.append((ev0, ev1, g.algorithmic_bytes(d) + n * d * 4 + n * d // 8))
+        prof.append((ev0, ev1, g.algorithmic_bytes(d, src_elem=2 if bf16 else 4) + n * d * 4 + n * d // 8))
     return bits, out_next, act
 
 
@@ -74,16 +76,16 @@ def _spmm_t(graph, gr):
     return g.spmm(gr, transpose=True)
 
 
-def _layer_bwd(g, bits, row_scale, gx0, accumulate, p, seed, row0, c_act, c_mix, want_colsum):
+def _layer_bwd(g, bits, row_scale, gx0, accumulate, p, seed, row0, c_act, c_mix, want_colsum, out_bf16=False):
     lib = _lib.load()
     rows, d = g.shape
-    out = torch.empty_like(g)
+    out = torch.empty(g.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=g.device)
     colsum = torch.empty(d, dtype=torch.float32, device=g.device) if want_colsum else None
     wsb = lib.cb_colsum_workspace_bytes(rows, d) if want_colsum else 0
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=g.device)
     with torch.cuda.device(g.device):
-        _lib.check(lib.cb_trunk_layer_bwd_f32(_lib.ptr(g), _lib.ptr(bits), _lib.ptr(row_scale), _lib.ptr(out), _lib.ptr(gx0),
-                                              int(accumulate), rows, d, float(p), ctypes.c_uint64(seed), int(row0), float(c_act),
+        _lib.check(lib.cb_trunk_layer_bwd_f32(_lib.ptr(g), _lib.ptr(bits), _lib.ptr(row_scale), _lib.ptr(out), int(out_bf16),
+                                              _lib.ptr(gx0), int(accumulate), rows, d, float(p), ctypes.c_uint64(seed), int(row0), float(c_act),
                                               float(c_mix), _lib.ptr(colsum), _lib.ptr(ws), wsb, _lib.stream_ptr()),
                    'cb_trunk_layer_bwd_f32')
     return out, colsum
@@ -106,8 +108,8 @@ def _input_bwd(g, add, act, p, seed, row0):
 class _TrunkFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph, cfg, x, w_in, b_in, w_out, b_out, *layer_params):
-        """layer_params = (W_0, bias_0, le_0 | None, W_1, ...).  cfg = (L, alpha, p, seeds)."""
-        L, alpha, p, seeds = cfg
+        """layer_params = (W_0, bias_0, le_0 | None, W_1, ...).  cfg = (L, alpha, p, seeds, agg_bf16)."""
+        L, alpha, p, seeds, agg_bf16 = cfg
         row0 = int(getattr(graph, 'row_offset', 0))
         a = graph.norm_out
         x = x.contiguous()
@@ -118,7 +120,7 @@ class _TrunkFn(torch.autograd.Function):
         saved_in, saved_bits = [cur], []
         for l in range(L):
             w, b, le = layer_params[3 * l: 3 * l + 3]
-            z = gemm.mm_nn(cur, w, rowscale=a, addend=le)
+            z = gemm.mm_nn(cur, w, rowscale=a, addend=le, out_bf16=agg_bf16)
             bits, cur, _ = _fused_spmm(graph, z, b, x0, 1 - alpha, alpha, p, seeds[l + 2] if p > 0 else 0)
             del z
             saved_bits.append(bits)
@@ -132,7 +134,7 @@ class _TrunkFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        graph, (L, alpha, p, seeds), row0 = ctx.graph, ctx.cfg, ctx.row0
+        graph, (L, alpha, p, seeds, agg_bf16), row0 = ctx.graph, ctx.cfg, ctx.row0
         sv = list(ctx.saved_tensors)
         xd, x0, w_in, w_out = sv[:4]
         saved_in = sv[4: 4 + L + 1]
@@ -161,7 +163,7 @@ class _TrunkFn(torch.autograd.Function):
         for l in range(L - 1, -1, -1):
             w, b, le = lp[l]
             gr, dbias = _layer_bwd(g, saved_bits[l], bnorm, gx0, l != L - 1, p, seeds[l + 2] if p > 0 else 0, row0, 1 - alpha, alpha,
-                                   need[7 + 3 * l + 1])
+                                   need[7 + 3 * l + 1], out_bf16=agg_bf16)
             del g
             gz = _spmm_t(graph, gr)                                 # dL/dZ_l = A (b * dY')
             del gr
@@ -203,6 +205,7 @@ def forward(tc, x, graph):
                 reg = allreduce_sum(reg * reg, graph.group).sqrt()
             se_reg_all = reg if se_reg_all is None else se_reg_all + reg
     graph.check_zero_in_degree()
-    out = _TrunkFn.apply(graph, (L, float(tc.alpha), p, seeds), x, tc.layers_MLP[0].weight, tc.layers_MLP[0].bias,
+    agg_bf16 = getattr(tc.args, 'agg_dtype', 'f32') == 'bf16'
+    out = _TrunkFn.apply(graph, (L, float(tc.alpha), p, seeds, agg_bf16), x, tc.layers_MLP[0].weight, tc.layers_MLP[0].bias,
                          tc.layers_MLP[1].weight, tc.layers_MLP[1].bias, *params)
     return out, se_reg_all

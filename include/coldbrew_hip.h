@@ -174,14 +174,36 @@ int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, int64_t N, 
 /* Backward of that epilogue in one pass over contiguous [rows, d]:
  *     gm = dropout_bwd(g);  gx0 = (accumulate ? gx0 : 0) + c_mix * gm  (gx0 NULL: skipped);
  *     gy = c_act * gm * relu_bit;  colsum = sum_rows gy (dbias; NULL to skip);  out = gy * row_scale[r]. */
-int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits, const float* row_scale, float* out, float* gx0,
+int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits, const float* row_scale, void* out, int out_bf16, float* gx0,
                            int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed, int64_t row0, float c_act,
                            float c_mix, float* colsum, void* ws, size_t ws_bytes, void* stream);
+/* (out_bf16 != 0: `out` is a bf16 [rows, d] matrix — gradient rows stored in bf16 for the bf16 aggregation variant.) */
 
 /* Backward into the trunk's input stage X0 = relu(Linear(dropout(x))) (GCN.py:104-107,110):
  *     out = (add + dropout_bwd(g)) * (act > 0);  colsum = sum_rows out  (bias gradient of the input Linear). */
 int cb_trunk_input_bwd_f32(const float* g, const float* add, const float* act, float* out, int64_t rows, int64_t d, float drop_p,
                            uint64_t seed, int64_t row0, float* colsum, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * bf16-storage variant of the aggregation (build extension = BASELINE config 2; the reference is fp32-only):
+ * the rows that are gathered (Z in the forward, b*dY' in the backward) are stored as bf16 (round-to-nearest-
+ * even), accumulation, outputs and everything else stay fp32.  Halves the dominant gather traffic.
+ * Same semantics and arguments as cb_gemm_nn_f32 / cb_spmm_csr_f32 / cb_spmm_csr_fused_f32 otherwise
+ * (ld in elements of the respective type; bf16 rows must be 8-byte aligned for the vector paths).
+ * ---------------------------------------------------------------------------------- */
+int cb_gemm_nn_bf16out_f32(const float* A, int64_t lda, const float* B, int64_t ldb, uint16_t* C, int64_t ldc, int64_t M, int64_t N,
+                           int64_t K, const float* rowscale, const float* addend, int64_t ld_add, const float* bias, int relu,
+                           void* stream);
+int cb_spmm_csr_bf16_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const uint16_t* h, int64_t ld_h, int64_t d,
+                         const float* row_scale, const float* bias, int relu, float* out, int64_t ld_out, int32_t hub_threshold,
+                         int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,
+                         size_t ws_bytes, void* stream);
+int cb_spmm_csr_fused_bf16_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const uint16_t* h, int64_t ld_h,
+                               int64_t d, const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix,
+                               float c_act, float c_mix, float drop_p, uint64_t seed, int64_t row0, uint64_t* relu_bits,
+                               float* out_act, int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_threshold,
+                               int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,
+                               size_t ws_bytes, void* stream);
 
 /* out[i, :] = src[idx[i], :] (contiguous out [n_idx, d]) — packs the rows a peer asked for before the
  * all-to-all of the node-sharded halo exchange (new; the reference is single-device). */

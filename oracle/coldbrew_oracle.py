@@ -100,7 +100,21 @@ def aggregate_sum_dense_f64(csr, h):
 # --------------------------------------------------------------------------------------
 # GCNConv (GNN_model/GCN.py:184-258)
 # --------------------------------------------------------------------------------------
-def gcnconv_forward(csr, feat, weight, bias=None, le=None, a=None, b=None):
+class _QuantGradBf16(torch.autograd.Function):
+    """Identity whose backward rounds the gradient to bf16 (storage of b*dY' in the bf16 aggregation variant)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def gcnconv_forward(csr, feat, weight, bias=None, le=None, a=None, b=None, quant_bf16=False):
+    """quant_bf16 (build extension, not in the reference): the rows the aggregation gathers — Z in the forward,
+    the scaled gradient in the backward — are rounded to bf16 (RNE), everything else stays fp32."""
     check_no_zero_in_degree(csr)
     if a is None or b is None:
         a, b = degree_norms(csr, feat.dtype)
@@ -112,7 +126,11 @@ def gcnconv_forward(csr, feat, weight, bias=None, le=None, a=None, b=None):
     else:
         h = feat_src
         se_reg = None
+    if quant_bf16:
+        h = h + (h.detach().to(torch.bfloat16).to(h.dtype) - h.detach())    # value rounded, gradient passes straight through
     rst = _AGGREGATE[0](csr, h)                              # :238
+    if quant_bf16:
+        rst = _QuantGradBf16.apply(rst)
     rst = rst * b.reshape(-1, 1)                             # :250
     if bias is not None:
         rst = rst + bias                                     # :253
@@ -240,7 +258,7 @@ def res_mix(cfg, p, xs, i):
 def make_cfg(**kw):
     d = dict(type_trick='NoResNoNorm', num_layers=2, num_feats=None, dim_hidden=64, num_classes=None,
              dropout=0.0, res_alpha=0.1, layer_agg='concat', whetherHasSE=(0, 0, 0), node_norm_type='n',
-             num_groups=None, skip_weight=None, se_reg=0.0, change_to_featureless=0, dim_learnable_input=0)
+             num_groups=None, skip_weight=None, se_reg=0.0, change_to_featureless=0, dim_learnable_input=0, quant_bf16=False)
     d.update(kw)
     return SimpleNamespace(**d)
 
@@ -288,7 +306,7 @@ def trickscomb_forward(cfg, p, x, csr, training=False, dropout_masks=None, want_
     for i in range(cfg.num_layers):                          # GCN.py:109-131
         x = drop(x, cfg.dropout)
         x, se_reg = gcnconv_forward(csr, x, p[f'layers_GCN.{i}.weight'], p[f'layers_GCN.{i}.bias'],
-                                    p.get(f'layers_GCN.{i}.le'), a, b)
+                                    p.get(f'layers_GCN.{i}.le'), a, b, getattr(cfg, 'quant_bf16', False))
         if se_reg is not None:
             se_reg_all = se_reg if se_reg_all is None else se_reg_all + se_reg
         x = run_norm(cfg, p, x, i, training, buffers_out)

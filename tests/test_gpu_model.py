@@ -151,3 +151,50 @@ def test_fused_trunk_matches_oracle_with_injected_masks():
     ref, reg = orc.teacher_forward(cfg, sd, data.x.cpu(), csr, training=True, dropout_masks=masks)
     torch.testing.assert_close(out.detach().cpu(), ref, atol=1e-4, rtol=1e-4)
     torch.testing.assert_close(model.se_reg_all.detach().cpu(), reg, atol=1e-3, rtol=1e-5)
+
+
+def test_bf16_aggregation_variant_config2():
+    """BASELINE config 2 (Pubmed-shaped, whetherHasSE=111, 2 layers, hidden 256) with --agg_dtype=bf16.
+    Parity targets (stated here, separate from the 1e-4 fp32 target): against the oracle that rounds the
+    gathered rows to bf16 at the same two points: logits 2e-3 abs, loss 1e-4 rel, weight gradients 2e-2 of
+    their max; against the pure fp32 oracle: logits 5e-2 abs."""
+    import contextlib
+    import io
+    import coldbrew_oracle as orc
+    from gnn_tail_generalization_amd import ops
+    from gnn_tail_generalization_amd.base_options import BaseOptions
+    from gnn_tail_generalization_amd.data import synthetic_data
+    from gnn_tail_generalization_amd.GNN_model import TeacherGNN
+    from gnn_tail_generalization_amd.utils import set_arch_configs
+    with contextlib.redirect_stdout(io.StringIO()):
+        args = BaseOptions().get_arguments(['--dataset=S-pubmed', '--whetherHasSE=111', '--num_layers=2', '--se_reg=0.5',
+                                            '--agg_dtype=bf16', '--manual_assign_GPU=0'])
+    data = synthetic_data('S-pubmed', seed=0, device=DEV, n_override=4000)
+    args.N_nodes, args.dropout, args.device = data.x.shape[0], 0.0, torch.device(DEV)
+    set_arch_configs(args)
+    torch.manual_seed(1)
+    model = TeacherGNN(args).to(DEV)
+    assert model.model.model.type_trick == 'InitialBatchNorm' and model.model.model.dim_hidden == 256
+    model.train()
+    out = model(data.x, data.edge_index)
+    loss = ops.nll_logsoftmax(out, data.y, data.train_mask) + args.se_reg * model.se_reg_all
+    loss.backward()
+    n = data.x.shape[0]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    csr = orc.build_csr(data.edge_index.cpu(), n)
+    ref = {}
+    for quant in (True, False):
+        cfg = orc.make_cfg(type_trick='InitialBatchNorm', num_layers=2, num_feats=500, dim_hidden=256, num_classes=3,
+                           res_alpha=args.res_alpha, whetherHasSE=(1, 1, 1), se_reg=0.5, quant_bf16=quant)
+        sdr = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+        o, reg = orc.teacher_forward(cfg, sdr, data.x.cpu(), csr, training=True)
+        l = orc.training_loss(cfg, o, reg, data.y.cpu(), data.train_mask.cpu())
+        l.backward()
+        ref[quant] = (o.detach(), l.detach(), {k: v.grad for k, v in sdr.items() if v.grad is not None})
+    torch.testing.assert_close(out.detach().cpu(), ref[True][0], atol=2e-3, rtol=0)
+    torch.testing.assert_close(loss.detach().cpu(), ref[True][1], atol=0, rtol=1e-4)
+    torch.testing.assert_close(out.detach().cpu(), ref[False][0], atol=5e-2, rtol=0)
+    for k, p in model.named_parameters():
+        if p.grad is not None and k.endswith('weight'):
+            r = ref[True][2][k]
+            assert float((p.grad.cpu() - r).abs().max()) <= 2e-2 * float(r.abs().max()) + 1e-7, k
