@@ -39,6 +39,7 @@ def parse():
     ap.add_argument('--dataset', default='S-pl10M', help='synthetic workload (S-pl10M = BASELINE headline config)')
     ap.add_argument('--cpu-baseline', type=int, default=1)
     ap.add_argument('--cpu-sample-nodes', type=int, default=200000)
+    ap.add_argument('--agg-dtype', default='f32', choices=['f32', 'bf16'], help='bf16 = build-extension storage of the gathered rows')
     return ap.parse_args()
 
 
@@ -115,7 +116,7 @@ def main():
         print(f'[bench] --gpus {a.gpus} but WORLD_SIZE={world}: using WORLD_SIZE', file=sys.stderr)
 
     from gnn_tail_generalization_amd import trainer_node_classification as tnc
-    args = make_args(a.dataset, [f'--manual_assign_GPU={local_rank}'])
+    args = make_args(a.dataset, [f'--manual_assign_GPU={local_rank}', f'--agg_dtype={a.agg_dtype}'])
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()):
         if sharded:
@@ -170,7 +171,8 @@ def main():
     out = {
         'metric': 'teachergnn_fullgraph_train_steps_per_sec', 'value': a.steps / dt, 'unit': 'steps/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
-        'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32' if a.agg_dtype == 'f32' else 'f32 (bf16-stored aggregation rows)',
+        'data': 'synthetic',
         'aggregated_edges_per_sec': n_edges * 2 * L * a.steps / dt,
         'final_loss': float(loss),
         'config': {'workload': f'{a.dataset}: N={n_nodes} nodes, E={n_edges} edge_index columns (Chung-Lu power law gamma=2.3, '
@@ -178,7 +180,7 @@ def main():
                                f'C={args.num_classes} L={L}, type_trick={args.type_trick} (residual mode), whetherHasSE=000, '
                                f'dropout={args.dropout}, Adam lr={args.lr}; step = fwd+loss+bwd+Adam, 2L={2 * L} aggregations',
                    'parallelism': 'single GPU' if not sharded else f'node-sharded x{world} (RCCL all-gather exchange)'},
-        'roofline': {'bound': 'hbm', 'kernel': 'k_spmm_rows (+hub kernels) d=256 f32', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+        'roofline': {'bound': 'hbm', 'kernel': f'k_spmm_rows (+hub kernels) d=256 {a.agg_dtype} source rows, f32 accumulate', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                      'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                      'launches_timed': len(spmm_ms), 'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': avg_bytes},
     }
