@@ -20,13 +20,15 @@
 // Epilogue (NN): the accumulators are transposed through LDS 32 rows at a time so that every lane
 // handles 4 consecutive columns of one row: row scale / addend / bias are applied on float4 values and
 // the tile leaves as coalesced 16-byte stores.
+#include <stdlib.h>
+
 #include "cb_common.h"
 
 namespace cb {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
+constexpr int BK = 16;   // default K step (BKT template parameter; 32 selectable for measurement)
 
 struct GemmEpilogue {
   const float* rowscale;  // [M] or null
@@ -36,15 +38,15 @@ struct GemmEpilogue {
   int relu;
 };
 
-template <int WM, int WN>
+template <int WM, int WN, int BKT = BK>
 struct Tile {
   static constexpr int BM = 64 * WM, BN = 64 * WN, LDA = BM + 4, LDB = BN + 4;
-  static constexpr int SMEM_FLOATS = 2 * BK * (LDA + LDB);
+  static constexpr int SMEM_FLOATS = 2 * BKT * (LDA + LDB);
   static_assert(WM * WN == 4, "four wavefronts per block");
   static_assert(32 * LDB <= SMEM_FLOATS, "epilogue staging (32 rows) must fit the operand buffers");
 };
 
-template <int LDA, int LDB>
+template <int LDA, int LDB, int BKT>
 __device__ __forceinline__ void mfma_tile_step(const float* __restrict__ As, const float* __restrict__ Bs, int wr, int wc,
                                                int lane, f32x16 (&acc)[2][2]) {
   const int l31 = lane & 31, kh = lane >> 5;
@@ -52,9 +54,9 @@ __device__ __forceinline__ void mfma_tile_step(const float* __restrict__ As, con
   const float* br = Bs + kh * LDB + wc * 64 + l31;
   float a0 = ar[0], a1 = ar[32], b0 = br[0], b1 = br[32];
 #pragma unroll
-  for (int kk = 0; kk < BK; kk += 2) {
+  for (int kk = 0; kk < BKT; kk += 2) {
     float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-    if (kk + 2 < BK) {  // next k-step's fragments are in flight while this k-step's MFMAs issue
+    if (kk + 2 < BKT) {  // next k-step's fragments are in flight while this k-step's MFMAs issue
       na0 = ar[(kk + 2) * LDA];
       na1 = ar[(kk + 2) * LDA + 32];
       nb0 = br[(kk + 2) * LDB];
@@ -71,17 +73,18 @@ __device__ __forceinline__ void mfma_tile_step(const float* __restrict__ As, con
 // ---- operand staging -----------------------------------------------------------------------
 // "row-major" operand (A of NN): global [tile rows][k], 16 k per K step -> transposed into LDS [k][row].
 // thread t: k quad = t % 4, rows (t / 4) + 64 * j
-template <int BMT>
+template <int BMT, int BKT>
 struct RowFrag {
-  float v[BMT / 64][4];
+  float v[BMT * BKT / 1024][4];
 };
-template <bool ALIGNED, int BMT>
-__device__ __forceinline__ void load_rowmajor(RowFrag<BMT>& f, const float* __restrict__ A, int64_t lda, int64_t m0, int64_t M,
+template <bool ALIGNED, int BMT, int BKT>
+__device__ __forceinline__ void load_rowmajor(RowFrag<BMT, BKT>& f, const float* __restrict__ A, int64_t lda, int64_t m0, int64_t M,
                                               int k0, int K, int t) {
-  const int k = k0 + (t & 3) * 4;
+  constexpr int TPR = BKT / 4, RPP = 256 / TPR;   // threads per row (one float4 each), rows per pass
+  const int k = k0 + (t % TPR) * 4;
 #pragma unroll
-  for (int j = 0; j < BMT / 64; ++j) {
-    const int64_t m = m0 + (t >> 2) + 64 * j;
+  for (int j = 0; j < BMT / RPP; ++j) {
+    const int64_t m = m0 + t / TPR + RPP * j;
     if (ALIGNED && m < M && k + 4 <= K) {
       const float4 x = *reinterpret_cast<const float4*>(A + m * lda + k);
       f.v[j][0] = x.x; f.v[j][1] = x.y; f.v[j][2] = x.z; f.v[j][3] = x.w;
@@ -91,12 +94,13 @@ __device__ __forceinline__ void load_rowmajor(RowFrag<BMT>& f, const float* __re
     }
   }
 }
-template <int BMT>
-__device__ __forceinline__ void store_rowmajor_T(const RowFrag<BMT>& f, float* __restrict__ S, int t) {
-  const int kq = (t & 3) * 4;
+template <int BMT, int BKT>
+__device__ __forceinline__ void store_rowmajor_T(const RowFrag<BMT, BKT>& f, float* __restrict__ S, int t) {
+  constexpr int TPR = BKT / 4, RPP = 256 / TPR;
+  const int kq = (t % TPR) * 4;
 #pragma unroll
-  for (int j = 0; j < BMT / 64; ++j) {
-    const int m = (t >> 2) + 64 * j;
+  for (int j = 0; j < BMT / RPP; ++j) {
+    const int m = t / TPR + RPP * j;
 #pragma unroll
     for (int i = 0; i < 4; ++i) S[(kq + i) * (BMT + 4) + m] = f.v[j][i];
   }
@@ -104,17 +108,17 @@ __device__ __forceinline__ void store_rowmajor_T(const RowFrag<BMT>& f, float* _
 
 // "k-major" operand: global [k][n] with n contiguous (B of NN; both operands of TN): straight copy.
 // thread t: n quad = t % (BNT/4), k = t / (BNT/4) + (1024/BNT) * j
-template <int BNT>
+template <int BNT, int BKT>
 struct KFrag {
-  float4 v[BNT / 64];
+  float4 v[BNT * BKT / 1024];
 };
-template <bool ALIGNED, int BNT>
-__device__ __forceinline__ void load_kmajor(KFrag<BNT>& f, const float* __restrict__ B, int64_t ldb, int64_t k0, int64_t Kdim,
+template <bool ALIGNED, int BNT, int BKT>
+__device__ __forceinline__ void load_kmajor(KFrag<BNT, BKT>& f, const float* __restrict__ B, int64_t ldb, int64_t k0, int64_t Kdim,
                                             int n0, int N, int t, const float* __restrict__ kscale) {
   constexpr int TPR = BNT / 4, RPP = 256 / TPR;   // threads per row, rows per pass
   const int n = n0 + (t % TPR) * 4;
 #pragma unroll
-  for (int j = 0; j < BNT / 64; ++j) {
+  for (int j = 0; j < BKT / RPP; ++j) {
     const int64_t k = k0 + t / TPR + RPP * j;
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k < Kdim) {
@@ -134,11 +138,11 @@ __device__ __forceinline__ void load_kmajor(KFrag<BNT>& f, const float* __restri
     f.v[j] = x;
   }
 }
-template <int BNT>
-__device__ __forceinline__ void store_kmajor(const KFrag<BNT>& f, float* __restrict__ S, int t) {
+template <int BNT, int BKT>
+__device__ __forceinline__ void store_kmajor(const KFrag<BNT, BKT>& f, float* __restrict__ S, int t) {
   constexpr int TPR = BNT / 4, RPP = 256 / TPR;
 #pragma unroll
-  for (int j = 0; j < BNT / 64; ++j)
+  for (int j = 0; j < BKT / RPP; ++j)
     *reinterpret_cast<float4*>(S + (t / TPR + RPP * j) * (BNT + 4) + (t % TPR) * 4) = f.v[j];
 }
 
@@ -152,16 +156,16 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
 }
 
 // ---- NN ------------------------------------------------------------------------------------
-template <int WM, int WN, bool ALIGNED, bool OUT_BF16>
+template <int WM, int WN, bool ALIGNED, bool OUT_BF16, int BKT = BK>
 __global__ void __launch_bounds__(256) k_gemm_nn(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
                                                  void* __restrict__ Cv, int64_t ldc, int64_t M, int N, int K, GemmEpilogue ep,
                                                  int n_row_blocks, int n_col_blocks, int c_vec_ok) {
   float* C = (float*)Cv;
-  using T = Tile<WM, WN>;
+  using T = Tile<WM, WN, BKT>;
   constexpr int BM = T::BM, BN = T::BN, LDA = T::LDA, LDB = T::LDB;
   __shared__ __attribute__((aligned(16))) float smem[T::SMEM_FLOATS];
-  auto As = [&](int b) { return smem + b * (BK * LDA); };
-  auto Bs = [&](int b) { return smem + 2 * BK * LDA + b * (BK * LDB); };
+  auto As = [&](int b) { return smem + b * (BKT * LDA); };
+  auto Bs = [&](int b) { return smem + 2 * BKT * LDA + b * (BKT * LDB); };
   // XCD-aware tile order: the column blocks of one row block get ids congruent mod 8, i.e. the same
   // XCD / L2 under the observed round-robin dispatch, so the A rows are fetched from HBM once.
   const int per_group = 8 * n_col_blocks;
@@ -174,24 +178,24 @@ __global__ void __launch_bounds__(256) k_gemm_nn(const float* __restrict__ A, in
 
   f32x16 acc[2][2];
   zero_acc(acc);
-  const int nk = (K + BK - 1) / BK;
-  RowFrag<BM> fa;
-  KFrag<BN> fb;
-  load_rowmajor<ALIGNED, BM>(fa, A, lda, m0, M, 0, K, t);
-  load_kmajor<ALIGNED, BN>(fb, B, ldb, 0, K, n0, N, t, nullptr);
-  store_rowmajor_T<BM>(fa, As(0), t);
-  store_kmajor<BN>(fb, Bs(0), t);
+  const int nk = (K + BKT - 1) / BKT;
+  RowFrag<BM, BKT> fa;
+  KFrag<BN, BKT> fb;
+  load_rowmajor<ALIGNED, BM, BKT>(fa, A, lda, m0, M, 0, K, t);
+  load_kmajor<ALIGNED, BN, BKT>(fb, B, ldb, 0, K, n0, N, t, nullptr);
+  store_rowmajor_T<BM, BKT>(fa, As(0), t);
+  store_kmajor<BN, BKT>(fb, Bs(0), t);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      load_rowmajor<ALIGNED, BM>(fa, A, lda, m0, M, (kt + 1) * BK, K, t);
-      load_kmajor<ALIGNED, BN>(fb, B, ldb, (int64_t)(kt + 1) * BK, K, n0, N, t, nullptr);
+      load_rowmajor<ALIGNED, BM, BKT>(fa, A, lda, m0, M, (kt + 1) * BKT, K, t);
+      load_kmajor<ALIGNED, BN, BKT>(fb, B, ldb, (int64_t)(kt + 1) * BKT, K, n0, N, t, nullptr);
     }
-    mfma_tile_step<LDA, LDB>(As(cur), Bs(cur), wr, wc, lane, acc);
+    mfma_tile_step<LDA, LDB, BKT>(As(cur), Bs(cur), wr, wc, lane, acc);
     if (kt + 1 < nk) {
-      store_rowmajor_T<BM>(fa, As(cur ^ 1), t);
-      store_kmajor<BN>(fb, Bs(cur ^ 1), t);
+      store_rowmajor_T<BM, BKT>(fa, As(cur ^ 1), t);
+      store_kmajor<BN, BKT>(fb, Bs(cur ^ 1), t);
     }
     __syncthreads();
   }
@@ -287,25 +291,25 @@ __global__ void __launch_bounds__(256) k_gemm_tn(const float* __restrict__ A, in
   f32x16 acc[2][2];
   zero_acc(acc);
   const int64_t nk = r_end > r_begin ? (r_end - r_begin + BK - 1) / BK : 0;
-  KFrag<BM> fa;
-  KFrag<BN> fb;
+  KFrag<BM, BK> fa;
+  KFrag<BN, BK> fb;
   if (nk > 0) {
-    load_kmajor<ALIGNED, BM>(fa, A, lda, r_begin, r_end, i0, K1, t, nullptr);
-    load_kmajor<ALIGNED, BN>(fb, G, ldg, r_begin, r_end, j0, K2, t, rowscale);
-    store_kmajor<BM>(fa, As(0), t);
-    store_kmajor<BN>(fb, Bs(0), t);
+    load_kmajor<ALIGNED, BM, BK>(fa, A, lda, r_begin, r_end, i0, K1, t, nullptr);
+    load_kmajor<ALIGNED, BN, BK>(fb, G, ldg, r_begin, r_end, j0, K2, t, rowscale);
+    store_kmajor<BM, BK>(fa, As(0), t);
+    store_kmajor<BN, BK>(fb, Bs(0), t);
   }
   __syncthreads();
   for (int64_t kt = 0; kt < nk; ++kt) {
     const int cur = (int)(kt & 1);
     if (kt + 1 < nk) {
-      load_kmajor<ALIGNED, BM>(fa, A, lda, r_begin + (kt + 1) * BK, r_end, i0, K1, t, nullptr);
-      load_kmajor<ALIGNED, BN>(fb, G, ldg, r_begin + (kt + 1) * BK, r_end, j0, K2, t, rowscale);
+      load_kmajor<ALIGNED, BM, BK>(fa, A, lda, r_begin + (kt + 1) * BK, r_end, i0, K1, t, nullptr);
+      load_kmajor<ALIGNED, BN, BK>(fb, G, ldg, r_begin + (kt + 1) * BK, r_end, j0, K2, t, rowscale);
     }
-    mfma_tile_step<LDA, LDB>(As(cur), Bs(cur), wr, wc, lane, acc);
+    mfma_tile_step<LDA, LDB, BK>(As(cur), Bs(cur), wr, wc, lane, acc);
     if (kt + 1 < nk) {
-      store_kmajor<BM>(fa, As(cur ^ 1), t);
-      store_kmajor<BN>(fb, Bs(cur ^ 1), t);
+      store_kmajor<BM, BK>(fa, As(cur ^ 1), t);
+      store_kmajor<BN, BK>(fb, Bs(cur ^ 1), t);
     }
     __syncthreads();
   }
@@ -361,7 +365,10 @@ static int launch_nn(const float* A, int64_t lda, const float* B, int64_t ldb, v
   const dim3 grid((unsigned)(groups * 8 * ncb));
   const bool aligned = al16(A) && al16(B) && lda % 4 == 0 && ldb % 4 == 0;
   const int c_vec_ok = ((uintptr_t)C % (OUT_BF16 ? 8 : 16) == 0) && ldc % 4 == 0 && (!ep.addend || (al16(ep.addend) && ep.ld_add % 4 == 0));
-  if (aligned)
+  static const int bk32 = getenv("CB_GEMM_BK32") != nullptr;   // measurement hook: K step 32 instead of 16
+  if (aligned && bk32 && WM == 2)
+    hipLaunchKernelGGL((k_gemm_nn<WM, WN, true, OUT_BF16, 32>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
+  else if (aligned)
     hipLaunchKernelGGL((k_gemm_nn<WM, WN, true, OUT_BF16>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
   else
     hipLaunchKernelGGL((k_gemm_nn<WM, WN, false, OUT_BF16>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
