@@ -24,15 +24,24 @@ class comb_norm(nn.Module):                      # norm_tricks.py:9-17
         return x
 
 
-class pair_norm(nn.Module):                      # norm_tricks.py:20-30
-    def forward(self, x):
-        x = x - x.mean(dim=0)
-        return x / (1e-6 + x.pow(2).sum(dim=1).mean()).sqrt()
+def _bn(layer, x):
+    """nn.BatchNorm1d layers stay torch modules (parameter / buffer names), their arithmetic runs on the HIP reductions."""
+    if x.is_cuda and x.dtype == torch.float32:
+        from ..norms_hip import batch_norm
+        return batch_norm(layer, x)
+    return layer(x)
 
 
-class mean_norm(nn.Module):                      # norm_tricks.py:33-41
+class pair_norm(nn.Module):                      # norm_tricks.py:20-30: centre columns, divide by the rms row norm
     def forward(self, x):
-        return x - x.mean(dim=0)
+        from ..norms_hip import pair_norm as fn
+        return fn(x)
+
+
+class mean_norm(nn.Module):                      # norm_tricks.py:33-41: centre columns
+    def forward(self, x):
+        from ..norms_hip import mean_norm as fn
+        return fn(x)
 
 
 class node_norm(nn.Module):                      # norm_tricks.py:44-92
@@ -42,22 +51,18 @@ class node_norm(nn.Module):                      # norm_tricks.py:44-92
         self.node_norm_type = node_norm_type
         self.power = 1 / power_root
 
-    def _std(self, x):
-        return (torch.var(x, unbiased=self.unbiased, dim=1, keepdim=True) + self.eps).sqrt()
-
     def forward(self, x):
+        if self.unbiased or self.node_norm_type not in ('n', 'v', 'm', 'srv', 'pr'):
+            return x if self.node_norm_type not in ('n', 'v', 'm', 'srv', 'pr') else self._torch(x)
+        from ..norms_hip import node_norm as fn
+        return fn(x, self.node_norm_type, self.eps, self.power)
+
+    def _torch(self, x):   # unbiased=True is never selected by the reference's options; kept for the ctor contract
+        std = (torch.var(x, unbiased=self.unbiased, dim=1, keepdim=True) + self.eps).sqrt()
+        mean = torch.mean(x, dim=1, keepdim=True)
         t = self.node_norm_type
-        if t == 'n':
-            return (x - torch.mean(x, dim=1, keepdim=True)) / self._std(x)
-        if t == 'v':
-            return x / self._std(x)
-        if t == 'm':
-            return x - torch.mean(x, dim=1, keepdim=True)
-        if t == 'srv':
-            return x / torch.sqrt(self._std(x))
-        if t == 'pr':
-            return x / torch.pow(self._std(x), self.power)
-        return x
+        return {'n': (x - mean) / std, 'v': x / std, 'm': x - mean, 'srv': x / torch.sqrt(std),
+                'pr': x / torch.pow(std, self.power)}[t]
 
     def extra_repr(self):
         return f'node_norm_type={self.node_norm_type}'
@@ -73,11 +78,12 @@ class group_norm(nn.Module):                     # norm_tricks.py:95-120
 
     def forward(self, x):
         if self.num_groups == 1:
-            x_temp = self.bn(x)
+            x_temp = _bn(self.bn, x)
         else:
-            score = F.softmax(self.group_func(x), dim=1)                         # [N, G]
+            from ..gemm import linear
+            score = F.softmax(linear(x, self.group_func.weight, self.group_func.bias), dim=1)   # [N, G] gates (MFMA GEMM)
             x_temp = (score.unsqueeze(2) * x.unsqueeze(1)).reshape(x.shape[0], -1)  # G scaled copies, concatenated
-            x_temp = self.bn(x_temp).view(-1, self.num_groups, self.dim_hidden).sum(dim=1)
+            x_temp = _bn(self.bn, x_temp).view(-1, self.num_groups, self.dim_hidden).sum(dim=1)
         return x + x_temp * self.skip_weight
 
 
@@ -104,7 +110,8 @@ def appendNormLayer(net, args, dim_to_norm=None):   # norm_tricks.py:130-143 (su
 
 def run_norm_if_any(net, x, ilayer):             # norm_tricks.py:146-150 (exact match)
     if net.args.type_trick in BARE_NORM_NAMES:
-        return net.layers_norm[ilayer](x)
+        layer = net.layers_norm[ilayer]
+        return _bn(layer, x) if isinstance(layer, nn.BatchNorm1d) else layer(x)
     return x
 
 

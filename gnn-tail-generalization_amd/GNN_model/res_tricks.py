@@ -32,7 +32,8 @@ class InitialConnection(_AlphaMix):
 
 
 def _concat(mod, Xs):
-    return mod.layer_transform(torch.cat(Xs, dim=-1))
+    from ..gemm import linear
+    return linear(torch.cat(Xs, dim=-1), mod.layer_transform.weight, mod.layer_transform.bias)   # Linear on the MFMA GEMM
 
 
 def _maxpool(mod, Xs):
@@ -41,8 +42,11 @@ def _maxpool(mod, Xs):
 
 def _attention(mod, Xs):
     """DAGNN-style retain scores over the k+1 stacked layers (n x (k+1) x c)."""
+    from ..gemm import linear
     stacked = torch.stack(Xs, dim=1)
-    retain = torch.sigmoid(mod.layer_att(stacked).squeeze()).unsqueeze(1)
+    n, k1, c = stacked.shape
+    logits = linear(stacked.reshape(n * k1, c), mod.layer_att.weight, mod.layer_att.bias).reshape(n, k1, 1)
+    retain = torch.sigmoid(logits.squeeze()).unsqueeze(1)
     return torch.matmul(retain, stacked).squeeze()
 
 

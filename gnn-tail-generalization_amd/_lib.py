@@ -54,6 +54,12 @@ SIGNATURES = {
     'cb_spmm_csr_fused_bf16_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,
                                                   ctypes.c_float, ctypes.c_uint64, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P,
                                                   _P, _P, _SZ, _P]),
+    'cb_node_norm_fwd_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I64, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P]),
+    'cb_node_norm_bwd_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64, ctypes.c_float, ctypes.c_float, _P]),
+    'cb_colstats_workspace_bytes': (_SZ, [_I64, _I64]),
+    'cb_colstats_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _SZ, _P]),
+    'cb_col_affine_f32': (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_float, _P, _I64, _I64, _P]),
+    'cb_col_bwd_combine_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _P, _I64, _I64, _P]),
     'cb_gather_rows_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _P, _P]),
     'cb_trunk_input_bwd_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64, ctypes.c_float, ctypes.c_uint64, _I64, _P, _P, _SZ, _P]),
 }

@@ -532,3 +532,172 @@ extern "C" int cb_gather_rows_f32(const float* src, int64_t ld, const int64_t* i
   CB_LAUNCH_CHECK();
   return CB_OK;
 }
+
+// =============================================================================================
+// Normalisation tricks (GNN_model/norm_tricks.py) as fused reductions.
+// =============================================================================================
+namespace cb {
+
+// ---- row-wise: node_norm (norm_tricks.py:53-84) ---------------------------------------------
+// y = (x - c*mu) * std^-q with mu, std = sqrt(var_biased + eps) over the features of one row:
+//   'n': c=1,q=1   'v': c=0,q=1   'm': c=1,q=0   'srv'/'pr'(power_root 2): c=0,q=1/2
+// One wavefront per row; the row stays in registers for d <= 64*NR (d <= 1024), otherwise it is re-read.
+// stats[r] = {mu, std} is kept for the backward:
+//   dx = s*(g - c*mean(g)) - q * std^(-q-2) / d * (x - mu) * sum_k g_k (x_k - c*mu)
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+__global__ void __launch_bounds__(kBlock) k_node_norm_fwd(const float* __restrict__ x, float* __restrict__ y, float2* __restrict__ stats,
+                                                          int64_t rows, int d, float c, float q, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave0; r < rows; r += nw) {
+    const float* xr = x + r * d;
+    float s = 0.f;
+    for (int j = lane; j < d; j += 64) s += xr[j];
+    const float mu = wave_sum(s) / d;
+    float v = 0.f;
+    for (int j = lane; j < d; j += 64) { const float t = xr[j] - mu; v += t * t; }
+    const float sd = sqrtf(wave_sum(v) / d + eps);
+    const float sc = (q == 0.f) ? 1.f : (q == 1.f ? 1.f / sd : 1.f / sqrtf(sd));
+    float* yr = y + r * d;
+    for (int j = lane; j < d; j += 64) yr[j] = (xr[j] - c * mu) * sc;
+    if (lane == 0 && stats) stats[r] = make_float2(mu, sd);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_node_norm_bwd(const float* __restrict__ x, const float* __restrict__ g,
+                                                          const float2* __restrict__ stats, float* __restrict__ dx, int64_t rows,
+                                                          int d, float c, float q) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave0; r < rows; r += nw) {
+    const float* xr = x + r * d;
+    const float* gr = g + r * d;
+    const float2 st = stats[r];
+    const float mu = st.x, sd = st.y;
+    float sg = 0.f, sgx = 0.f;
+    for (int j = lane; j < d; j += 64) { const float gv = gr[j]; sg += gv; sgx += gv * (xr[j] - c * mu); }
+    sg = wave_sum(sg);
+    sgx = wave_sum(sgx);
+    const float sc = (q == 0.f) ? 1.f : (q == 1.f ? 1.f / sd : 1.f / sqrtf(sd));
+    const float k2 = (q == 0.f) ? 0.f : q * sc / (sd * sd) / d * sgx;   // q * std^(-q-2) / d * sum g (x - c mu)
+    const float gbar = c * sg / d;
+    float* dr = dx + r * d;
+    for (int j = lane; j < d; j += 64) dr[j] = sc * (gr[j] - gbar) - k2 * (xr[j] - mu);
+  }
+}
+
+// ---- column statistics: colsum(x) and colsum(x^2) in one pass (two-stage, fixed order) -------------
+__global__ void __launch_bounds__(kBlock) k_colstats(const float* __restrict__ x, const float* __restrict__ w, int64_t rows, int d,
+                                                     float* __restrict__ p_sum, float* __restrict__ p_sq) {
+  // thread owns one column per pass; block owns a row slab.  w (optional) multiplies x element-wise (for sum(g*xhat)).
+  const int64_t rows_per_block = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float s = 0.f, s2 = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+      const float v = x[r * d + c];
+      const float u = w ? v * w[r * d + c] : v * v;
+      s += v;
+      s2 += u;
+    }
+    p_sum[(int64_t)blockIdx.x * d + c] = s;
+    p_sq[(int64_t)blockIdx.x * d + c] = s2;
+  }
+}
+
+// y[r,c] = (x[r,c] - shift[c]) * scale[c] + bias[c]   (mean_norm / pair_norm / BatchNorm1d apply; any of the vectors may be null)
+__global__ void __launch_bounds__(kBlock) k_col_affine(const float* __restrict__ x, const float* __restrict__ shift,
+                                                       const float* __restrict__ scale, const float* __restrict__ bias,
+                                                       float gscale, float* __restrict__ y, int64_t n, int d) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % d);
+    float v = x[i];
+    if (shift) v -= shift[c];
+    if (scale) v *= scale[c];
+    v *= gscale;
+    if (bias) v += bias[c];
+    y[i] = v;
+  }
+}
+
+// dx[r,c] = a[c] * g[r,c] + b[c] * xh[r,c] + e[c]   (backward combine of the column norms; xh may be null)
+__global__ void __launch_bounds__(kBlock) k_col_bwd_combine(const float* __restrict__ g, const float* __restrict__ xh,
+                                                            const float* __restrict__ a, const float* __restrict__ b,
+                                                            const float* __restrict__ e, float ga, float gb, float* __restrict__ dx,
+                                                            int64_t n, int d) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % d);
+    float v = (a ? a[c] : 1.f) * ga * g[i];
+    if (xh) v += (b ? b[c] : 1.f) * gb * xh[i];
+    if (e) v += e[c];
+    dx[i] = v;
+  }
+}
+
+}  // namespace cb
+
+extern "C" int cb_node_norm_fwd_f32(const float* x, float* y, float* stats2, int64_t rows, int64_t d, float c, float q, float eps,
+                                    void* stream) {
+  CB_CHECK_ARG(rows >= 0 && d > 0 && d < (1 << 24) && (rows == 0 || (x && y)), CB_E_INVALID, "cb_node_norm_fwd_f32: bad argument");
+  if (rows == 0) return CB_OK;
+  hipLaunchKernelGGL(k_node_norm_fwd, dim3(grid_for(rows * 64)), dim3(kBlock), 0, (hipStream_t)stream, x, y, (float2*)stats2, rows,
+                     (int)d, c, q, eps);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
+extern "C" int cb_node_norm_bwd_f32(const float* x, const float* g, const float* stats2, float* dx, int64_t rows, int64_t d, float c,
+                                    float q, void* stream) {
+  CB_CHECK_ARG(rows >= 0 && d > 0 && d < (1 << 24) && (rows == 0 || (x && g && stats2 && dx)), CB_E_INVALID,
+               "cb_node_norm_bwd_f32: bad argument");
+  if (rows == 0) return CB_OK;
+  hipLaunchKernelGGL(k_node_norm_bwd, dim3(grid_for(rows * 64)), dim3(kBlock), 0, (hipStream_t)stream, x, g, (const float2*)stats2, dx,
+                     rows, (int)d, c, q);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
+extern "C" size_t cb_colstats_workspace_bytes(int64_t rows, int64_t d) { return 2 * cb_colsum_workspace_bytes(rows, d); }
+
+extern "C" int cb_colstats_f32(const float* x, const float* w, int64_t rows, int64_t d, float* colsum, float* colsum2, void* ws,
+                               size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(rows >= 0 && d > 0 && d < (1 << 20) && colsum && colsum2 && (rows == 0 || x), CB_E_INVALID, "cb_colstats_f32: bad argument");
+  CB_CHECK_ARG(ws && ws_bytes >= cb_colstats_workspace_bytes(rows > 0 ? rows : 1, d), CB_E_WORKSPACE, "cb_colstats_f32: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t nb = (rows + 63) / 64;
+  if (nb > kMaxBlocks) nb = kMaxBlocks;
+  if (nb < 1) nb = 1;
+  float* p1 = (float*)ws;
+  float* p2 = p1 + (size_t)nb * d;
+  hipLaunchKernelGGL(k_colstats, dim3((unsigned)nb), dim3(kBlock), 0, st, x, w, rows, (int)d, p1, p2);
+  CB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)d), dim3(kBlock), 0, st, (const float*)p1, (int)nb, (int)d, colsum);
+  CB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)d), dim3(kBlock), 0, st, (const float*)p2, (int)nb, (int)d, colsum2);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
+extern "C" int cb_col_affine_f32(const float* x, const float* shift, const float* scale, const float* bias, float gscale, float* y,
+                                 int64_t rows, int64_t d, void* stream) {
+  CB_CHECK_ARG(rows >= 0 && d > 0 && (rows == 0 || (x && y)), CB_E_INVALID, "cb_col_affine_f32: bad argument");
+  if (rows == 0) return CB_OK;
+  hipLaunchKernelGGL(k_col_affine, dim3(grid_for(rows * d)), dim3(kBlock), 0, (hipStream_t)stream, x, shift, scale, bias, gscale, y,
+                     rows * d, (int)d);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
+extern "C" int cb_col_bwd_combine_f32(const float* g, const float* xh, const float* a, const float* b, const float* e, float ga,
+                                      float gb, float* dx, int64_t rows, int64_t d, void* stream) {
+  CB_CHECK_ARG(rows >= 0 && d > 0 && (rows == 0 || (g && dx)), CB_E_INVALID, "cb_col_bwd_combine_f32: bad argument");
+  if (rows == 0) return CB_OK;
+  hipLaunchKernelGGL(k_col_bwd_combine, dim3(grid_for(rows * d)), dim3(kBlock), 0, (hipStream_t)stream, g, xh, a, b, e, ga, gb, dx,
+                     rows * d, (int)d);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}

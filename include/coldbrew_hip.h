@@ -205,6 +205,28 @@ int cb_spmm_csr_fused_bf16_f32(const int32_t* rowptr, const int32_t* col, int64_
                                int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,
                                size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Normalisation tricks (GNN_model/norm_tricks.py) as fused reductions; all matrices contiguous [rows, d].
+ * ---------------------------------------------------------------------------------- */
+/* node_norm (norm_tricks.py:53-84): y = (x - c*mu_r) * std_r^-q, mu/std over the features of row r
+ * (std = sqrt(biased var + eps)); 'n': c=1,q=1; 'v': c=0,q=1; 'm': c=1,q=0; 'srv'/'pr': c=0,q=0.5.
+ * stats2 [rows][2] = (mu, std) is written by the forward (may be NULL) and read by the backward. */
+int cb_node_norm_fwd_f32(const float* x, float* y, float* stats2, int64_t rows, int64_t d, float c, float q, float eps, void* stream);
+int cb_node_norm_bwd_f32(const float* x, const float* g, const float* stats2, float* dx, int64_t rows, int64_t d, float c, float q,
+                         void* stream);
+/* Column statistics in one pass: colsum[c] = sum_r x[r,c]; colsum2[c] = sum_r x[r,c]^2 (w == NULL) or
+ * sum_r x[r,c]*w[r,c] — the reductions behind mean_norm / pair_norm / BatchNorm1d (norm_tricks.py:25-41,106,132)
+ * and their backward; fixed-order two-stage reduce (ws: cb_colstats_workspace_bytes). */
+size_t cb_colstats_workspace_bytes(int64_t rows, int64_t d);
+int cb_colstats_f32(const float* x, const float* w, int64_t rows, int64_t d, float* colsum, float* colsum2, void* ws, size_t ws_bytes,
+                    void* stream);
+/* y[r,c] = ((x[r,c] - shift[c]) * scale[c]) * gscale + bias[c]  (vectors may be NULL). */
+int cb_col_affine_f32(const float* x, const float* shift, const float* scale, const float* bias, float gscale, float* y, int64_t rows,
+                      int64_t d, void* stream);
+/* dx[r,c] = a[c]*ga*g[r,c] + b[c]*gb*xh[r,c] + e[c]  (xh, a, b, e may be NULL: a,b default 1) — the backward of the column norms. */
+int cb_col_bwd_combine_f32(const float* g, const float* xh, const float* a, const float* b, const float* e, float ga, float gb,
+                           float* dx, int64_t rows, int64_t d, void* stream);
+
 /* out[i, :] = src[idx[i], :] (contiguous out [n_idx, d]) — packs the rows a peer asked for before the
  * all-to-all of the node-sharded halo exchange (new; the reference is single-device). */
 int cb_gather_rows_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, float* out, void* stream);
