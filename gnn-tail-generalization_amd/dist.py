@@ -150,6 +150,10 @@ class ShardedGraph:
         if exchange == 'halo':
             self.plan_fwd = HaloPlan(c, part, group)
             same = (rpt.shape == rp.shape and ct.shape == c.shape and bool(torch.equal(rpt, rp)) and bool(torch.equal(ct, c)))
+            if part.world > 1:      # one global decision, or the ranks would disagree on which collectives follow
+                flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=rp.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                same = bool(flag.item())
             self.plan_bwd = self.plan_fwd if same else HaloPlan(ct, part, group)
             c, ct = self.plan_fwd.col, self.plan_bwd.col
             ncols_f, ncols_b = self.N + self.plan_fwd.n_halo, self.N + self.plan_bwd.n_halo
