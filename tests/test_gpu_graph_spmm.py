@@ -126,3 +126,34 @@ def test_spmm_linearity_large():
     deg = G.spmm(ones)[:, 0]
     assert torch.equal(deg.to(torch.int64), G.in_degrees())
     assert G._plan.n_hubs > 0
+
+
+def test_full_size_properties_s_pl10m():
+    """BASELINE full size (10^7 nodes, 10^8 edge_index columns, d = 256): size-independent properties of the
+    ingest + aggregation that need no dense oracle."""
+    from gnn_tail_generalization_amd.data import synthetic_data
+    data = synthetic_data('S-pl10M', seed=0, device=DEV)
+    n, E = data.x.shape[0], data.edge_index.shape[1]
+    assert (n, E) == (10_000_000, 100_000_000)
+    G = _graph(data.edge_index, n)
+    ei = data.edge_index
+    # CSR == edge multiset: row lengths are the in-degrees, the (row, col) pairs re-sorted equal the sorted edge keys
+    assert torch.equal(G.in_degrees(), torch.bincount(ei[1], minlength=n))
+    rows = torch.repeat_interleave(torch.arange(n, device=DEV), G.in_degrees())
+    key_csr = rows * n + G.col.to(torch.int64)
+    assert bool((key_csr[1:] >= key_csr[:-1]).all())                          # sorted by (dst, src)
+    assert torch.equal(key_csr, torch.sort(ei[1] * n + ei[0])[0])             # same multiset, bit-exact
+    del rows, key_csr
+    assert G.symmetric and G.n_zero_in_degree == 0 and G._plan.n_hubs > 0
+    # aggregation of ones = in-degree (exact in fp32: max degree < 2^24), through main + hub kernels
+    deg = G.spmm(torch.ones(n, 256, device=DEV))
+    assert torch.equal(deg[:, 0].to(torch.int64), G.in_degrees()) and torch.equal(deg[:, 255], deg[:, 0])
+    del deg
+    # column-sum identity: sum_v out[v] = sum_u outdeg(u) * h[u]   (checksum of checksums, fp64)
+    h = torch.rand(n, 256, device=DEV)
+    out = G.spmm(h)
+    lhs = out.sum(dim=0, dtype=torch.float64)
+    rhs = (h.double() * G.out_degrees().double().unsqueeze(1)).sum(dim=0)
+    torch.testing.assert_close(lhs, rhs, rtol=1e-6, atol=0)
+    # run-to-run bit reproducibility (no atomics)
+    assert torch.equal(out, G.spmm(h))
