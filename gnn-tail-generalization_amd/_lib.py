@@ -31,7 +31,7 @@ SIGNATURES = {
     'cb_spmm_workspace_bytes': (_SZ, [_I64, _I64]),
     'cb_spmm_csr_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_int, _P, _I64,
                                        _I32, _I32, _I32, _P, _P, _P, _SZ, _P]),
-    'cb_dropout_f32': (ctypes.c_int, [_P, _P, _I64, ctypes.c_float, ctypes.c_uint64, _I64, _P]),
+    'cb_dropout_f32': (ctypes.c_int, [_P, _P, _I64, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P]),
     'cb_axpby_f32': (ctypes.c_int, [ctypes.c_float, _P, ctypes.c_float, _P, _P, _I64, _P]),
     'cb_colsum_workspace_bytes': (_SZ, [_I64, _I64]),
     'cb_act_bwd_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _SZ, _P]),
@@ -39,20 +39,20 @@ SIGNATURES = {
     'cb_frobenius_norm_f32': (ctypes.c_int, [_P, _I64, _P, _P, _SZ, _P]),
     'cb_nll_logsoftmax_f32': (ctypes.c_int, [_P, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _P, _SZ, _P]),
     'cb_adam_step_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
-                                        ctypes.c_float, ctypes.c_float, _I64, _P]),
+                                        ctypes.c_float, ctypes.c_float, _I64, _P, _P]),
     'cb_gemm_nn_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int, _P]),
     'cb_gemm_tn_workspace_bytes': (_SZ, [_I64, _I64, _I64]),
     'cb_gemm_tn_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _SZ, _P]),
     'cb_spmm_csr_fused_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,
-                                             ctypes.c_float, ctypes.c_uint64, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P,
+                                             ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P,
                                              _P, _SZ, _P]),
     'cb_trunk_layer_bwd_f32': (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, _P, ctypes.c_int, _I64, _I64, ctypes.c_float, ctypes.c_uint64,
-                                              _I64, ctypes.c_float, ctypes.c_float, _P, _P, _SZ, _P]),
+                                              _P, _I64, ctypes.c_float, ctypes.c_float, _P, _P, _SZ, _P]),
     'cb_gemm_nn_bf16out_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int, _P]),
     'cb_spmm_csr_bf16_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_int, _P, _I64,
                                             _I32, _I32, _I32, _P, _P, _P, _SZ, _P]),
     'cb_spmm_csr_fused_bf16_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,
-                                                  ctypes.c_float, ctypes.c_uint64, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P,
+                                                  ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P,
                                                   _P, _P, _SZ, _P]),
     'cb_node_norm_fwd_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I64, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P]),
     'cb_node_norm_bwd_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64, ctypes.c_float, ctypes.c_float, _P]),
@@ -61,7 +61,7 @@ SIGNATURES = {
     'cb_col_affine_f32': (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_float, _P, _I64, _I64, _P]),
     'cb_col_bwd_combine_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _P, _I64, _I64, _P]),
     'cb_gather_rows_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _P, _P]),
-    'cb_trunk_input_bwd_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64, ctypes.c_float, ctypes.c_uint64, _I64, _P, _P, _SZ, _P]),
+    'cb_trunk_input_bwd_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _P, _SZ, _P]),
 }
 
 _lib = None

@@ -19,7 +19,9 @@ static inline int grid_for(int64_t work_items) {
 // out[i] = x[i] * keep(offset + i) / (1 - p).  `offset` is the flat index of x[0] in the logical
 // (unsharded) tensor, so a row shard draws the same mask as the full tensor would.
 __global__ void __launch_bounds__(kBlock) k_dropout(const float* __restrict__ x, float* __restrict__ out, int64_t n,
-                                                    uint32_t thresh, float scale, uint64_t seed, int64_t offset, int vec_ok) {
+                                                    uint32_t thresh, float scale, uint64_t seed, const uint64_t* __restrict__ seed_dev,
+                                                    int64_t offset, int vec_ok) {
+  if (seed_dev) seed += *seed_dev;   // hipGraph mode: the per-step part of the seed lives in device memory
   const int64_t nq = (n + 3) / 4;
   const int sub = (int)(offset & 3);
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
@@ -147,8 +149,10 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
                                                       const float* __restrict__ act, const float* __restrict__ row_scale,
                                                       void* __restrict__ outv, float* __restrict__ gx0, int accumulate,
                                                       int64_t rows, int d, uint32_t thresh, float keep_scale, uint64_t seed,
-                                                      int64_t row0, float c_act, float c_mix, float* __restrict__ partial) {
+                                                      const uint64_t* __restrict__ seed_dev, int64_t row0, float c_act, float c_mix,
+                                                      float* __restrict__ partial) {
   extern __shared__ float s_red[];  // [4 waves][256 cols] per tile pass
+  if (seed_dev) seed += *seed_dev;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int tiles = d >> 8;
   const int64_t rows_per_block = (rows + gridDim.x - 1) / gridDim.x;
@@ -331,8 +335,13 @@ __global__ void k_loss_finish(const float* __restrict__ partial, int nparts, flo
 // torch.optim.Adam semantics (trainer_node_classification.py:310): g += wd*p; m,v EMA; bias-corrected step
 __global__ void __launch_bounds__(kBlock) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                  float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-                                                 float wd, float bc1, float bc2_sqrt, int vec_ok) {
+                                                 float wd, float bc1, float bc2_sqrt, const int64_t* __restrict__ step_dev, int vec_ok) {
   const int64_t nq = (n + 3) / 4;
+  if (step_dev) {   // hipGraph mode: the step count lives in device memory, bias corrections are derived here
+    const double t = (double)*step_dev;
+    bc1 = (float)(1.0 - pow((double)b1, t));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+  }
   const float step = lr / bc1;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = q * 4;
@@ -376,14 +385,15 @@ static inline int aligned16(const void* a) { return ((uintptr_t)a % 16) == 0; }
 
 using namespace cb;
 
-extern "C" int cb_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t seed, int64_t offset, void* stream) {
+extern "C" int cb_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, int64_t offset,
+                              void* stream) {
   CB_CHECK_ARG(n >= 0 && offset >= 0 && (n == 0 || (x && out)) && p >= 0.f && p < 1.f, CB_E_INVALID,
                "cb_dropout_f32: bad argument (p=%f)", p);
   if (n == 0) return CB_OK;
   const uint32_t thresh = dropout_threshold(p);
   const int vec_ok = aligned16(x) && aligned16(out);
   hipLaunchKernelGGL(k_dropout, dim3(grid_for((n + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, x, out, n, thresh,
-                     1.f / (1.f - p), seed, offset, vec_ok);
+                     1.f / (1.f - p), seed, seed_dev, offset, vec_ok);
   CB_LAUNCH_CHECK();
   return CB_OK;
 }
@@ -460,27 +470,29 @@ extern "C" int cb_nll_logsoftmax_f32(const float* logits, int64_t ld, const int6
 }
 
 extern "C" int cb_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                                float eps, float weight_decay, int64_t step, void* stream) {
-  CB_CHECK_ARG(n >= 0 && step >= 1 && (n == 0 || (p && g && m && v)), CB_E_INVALID, "cb_adam_step_f32: bad argument");
+                                float eps, float weight_decay, int64_t step, const int64_t* step_dev, void* stream) {
+  CB_CHECK_ARG(n >= 0 && (step >= 1 || step_dev) && (n == 0 || (p && g && m && v)), CB_E_INVALID, "cb_adam_step_f32: bad argument");
+  if (step < 1) step = 1;
   if (n == 0) return CB_OK;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const int vec_ok = aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v);
   hipLaunchKernelGGL(k_adam, dim3(grid_for((n + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
-                     eps, weight_decay, (float)bc1, (float)sqrt(bc2), vec_ok);
+                     eps, weight_decay, (float)bc1, (float)sqrt(bc2), step_dev, vec_ok);
   CB_LAUNCH_CHECK();
   return CB_OK;
 }
 
 static int launch_trunk_bwd(int mode, int out_bf16, const float* g, const uint64_t* bits, const float* act, const float* row_scale,
-                            void* out, float* gx0, int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed, int64_t row0,
-                            float c_act, float c_mix, float* colsum, void* ws, size_t ws_bytes, hipStream_t st) {
+                            void* out, float* gx0, int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed,
+                            const uint64_t* seed_dev, int64_t row0, float c_act, float c_mix, float* colsum, void* ws, size_t ws_bytes,
+                            hipStream_t st) {
   int64_t nb = (rows + 63) / 64;
   if (nb > kMaxBlocks) nb = kMaxBlocks;
   const uint32_t thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
   const float ks = 1.f / (1.f - drop_p);
   float* partial = colsum ? (float*)ws : nullptr;
-#define CB_TB_ARGS g, (const unsigned long long*)bits, act, row_scale, out, gx0, accumulate, rows, (int)d, thresh, ks, seed, row0, c_act, c_mix, partial
+#define CB_TB_ARGS g, (const unsigned long long*)bits, act, row_scale, out, gx0, accumulate, rows, (int)d, thresh, ks, seed, seed_dev, row0, c_act, c_mix, partial
   const dim3 grid((unsigned)nb), blk(kBlock);
   const size_t sh = kBlock * 4 * sizeof(float);
   if (mode == 0 && out_bf16) hipLaunchKernelGGL((k_trunk_bwd<0, true>), grid, blk, sh, st, CB_TB_ARGS);
@@ -496,28 +508,29 @@ static int launch_trunk_bwd(int mode, int out_bf16, const float* g, const uint64
 }
 
 extern "C" int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits, const float* row_scale, void* out, int out_bf16,
-                                      float* gx0, int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed, int64_t row0,
-                                      float c_act, float c_mix, float* colsum, void* ws, size_t ws_bytes, void* stream) {
+                                      float* gx0, int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed,
+                                      const uint64_t* seed_dev, int64_t row0, float c_act, float c_mix, float* colsum, void* ws,
+                                      size_t ws_bytes, void* stream) {
   CB_CHECK_ARG(rows >= 0 && d > 0 && d % 256 == 0 && d < (1 << 20), CB_E_INVALID, "cb_trunk_layer_bwd_f32: d must be a multiple of 256");
   if (rows == 0) return CB_OK;
   CB_CHECK_ARG(g && relu_bits && out && aligned16(g) && ((uintptr_t)out % (out_bf16 ? 8 : 16) == 0) && (!gx0 || aligned16(gx0)),
                CB_E_INVALID, "cb_trunk_layer_bwd_f32: null or misaligned pointer");
   CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, CB_E_INVALID, "cb_trunk_layer_bwd_f32: dropout p out of range");
   CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_colsum_workspace_bytes(rows, d)), CB_E_WORKSPACE, "cb_trunk_layer_bwd_f32: workspace too small");
-  return launch_trunk_bwd(0, out_bf16, g, relu_bits, nullptr, row_scale, out, gx0, accumulate, rows, d, drop_p, seed, row0, c_act, c_mix,
+  return launch_trunk_bwd(0, out_bf16, g, relu_bits, nullptr, row_scale, out, gx0, accumulate, rows, d, drop_p, seed, seed_dev, row0, c_act, c_mix,
                           colsum, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int cb_trunk_input_bwd_f32(const float* g, const float* add, const float* act, float* out, int64_t rows, int64_t d,
-                                      float drop_p, uint64_t seed, int64_t row0, float* colsum, void* ws, size_t ws_bytes,
-                                      void* stream) {
+                                      float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws,
+                                      size_t ws_bytes, void* stream) {
   CB_CHECK_ARG(rows >= 0 && d > 0 && d % 256 == 0 && d < (1 << 20), CB_E_INVALID, "cb_trunk_input_bwd_f32: d must be a multiple of 256");
   if (rows == 0) return CB_OK;
   CB_CHECK_ARG(g && add && act && out && aligned16(g) && aligned16(add) && aligned16(act) && aligned16(out), CB_E_INVALID,
                "cb_trunk_input_bwd_f32: null or misaligned pointer");
   CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, CB_E_INVALID, "cb_trunk_input_bwd_f32: dropout p out of range");
   CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_colsum_workspace_bytes(rows, d)), CB_E_WORKSPACE, "cb_trunk_input_bwd_f32: workspace too small");
-  return launch_trunk_bwd(1, 0, g, nullptr, act, nullptr, out, const_cast<float*>(add), 1, rows, d, drop_p, seed, row0, 0.f, 0.f, colsum,
+  return launch_trunk_bwd(1, 0, g, nullptr, act, nullptr, out, const_cast<float*>(add), 1, rows, d, drop_p, seed, seed_dev, row0, 0.f, 0.f, colsum,
                           ws, ws_bytes, (hipStream_t)stream);
 }
 

@@ -112,6 +112,7 @@ struct FusedEpi {
   uint32_t thresh;        // dropout threshold (0 = keep everything)
   float keep_scale;       // 1 / (1 - p)
   uint64_t seed;
+  const uint64_t* seed_dev;  // hipGraph mode: per-step seed part in device memory (added to `seed`), or null
   int64_t row0;           // global index of local row 0 (node-sharded runs draw the unsharded mask)
   unsigned long long* bits;  // [N][d/256][4] or null
   float* out_act;         // [N, ld_act] or null
@@ -141,7 +142,7 @@ __device__ __forceinline__ void fused_store(const FusedEpi& fe, int64_t row, int
   for (int i = 0; i < 4; ++i) x[i] = fe.mix_src ? fe.c_act * a[i] + fe.c_mix * rmix[i] : a[i];
   if (fe.thresh) {
     float m[4];
-    keep4(fe.seed, ((fe.row0 + row) * fe.d + c0) >> 2, fe.thresh, fe.keep_scale, m);
+    keep4(fe.seed_dev ? fe.seed + *fe.seed_dev : fe.seed, ((fe.row0 + row) * fe.d + c0) >> 2, fe.thresh, fe.keep_scale, m);
 #pragma unroll
     for (int i = 0; i < 4; ++i) x[i] *= m[i];
   }
@@ -499,7 +500,7 @@ extern "C" int cb_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_
 
 static int spmm_fused_impl(int h_bf16, const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const void* h, int64_t ld_h,
                                      int64_t d, const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix,
-                                     float c_act, float c_mix, float drop_p, uint64_t seed, int64_t row0, uint64_t* relu_bits,
+                                     float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits,
                                      float* out_act, int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_T,
                                      int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr,
                                      void* ws, size_t ws_bytes, void* stream) {
@@ -521,7 +522,7 @@ static int spmm_fused_impl(int h_bf16, const int32_t* rowptr, const int32_t* col
   fe.mix_src = mix_src; fe.ld_mix = ld_mix; fe.c_act = c_act; fe.c_mix = c_mix;
   fe.thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
   fe.keep_scale = 1.f / (1.f - drop_p);
-  fe.seed = seed; fe.row0 = row0; fe.bits = (unsigned long long*)relu_bits;
+  fe.seed = seed; fe.seed_dev = seed_dev; fe.row0 = row0; fe.bits = (unsigned long long*)relu_bits;
   fe.out_act = out_act; fe.ld_act = ld_act; fe.out_next = out_next; fe.ld_next = ld_next; fe.d = (int)d;
   if (h_bf16)
     return launch_spmm<4, true, bf16_t>(rowptr, col, N, (const bf16_t*)h, ld_h, d, ep, out_next, ld_next, hub_T, n_hubs, n_chunks,
@@ -532,26 +533,27 @@ static int spmm_fused_impl(int h_bf16, const int32_t* rowptr, const int32_t* col
 
 #define CB_FUSED_PARAMS                                                                                                          \
   const int32_t *rowptr, const int32_t *col, int64_t N, int64_t E, const void *h, int64_t ld_h, int64_t d, const float *row_scale, \
-      const float *bias, const float *mix_src, int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed, int64_t row0, \
+      const float *bias, const float *mix_src, int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed,               \
+      const uint64_t *seed_dev, int64_t row0,                                                                                      \
       uint64_t *relu_bits, float *out_act, int64_t ld_act, float *out_next, int64_t ld_next, int32_t hub_T, int32_t n_hubs,        \
       int32_t n_chunks, const int32_t *hub_rows, const int32_t *hub_chunk_ptr, void *ws, size_t ws_bytes, void *stream
 #define CB_FUSED_ARGS                                                                                                            \
-  rowptr, col, N, E, h, ld_h, d, row_scale, bias, mix_src, ld_mix, c_act, c_mix, drop_p, seed, row0, relu_bits, out_act, ld_act,  \
+  rowptr, col, N, E, h, ld_h, d, row_scale, bias, mix_src, ld_mix, c_act, c_mix, drop_p, seed, seed_dev, row0, relu_bits, out_act, ld_act,  \
       out_next, ld_next, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, stream
 
 extern "C" int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h,
                                      int64_t d, const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix,
-                                     float c_act, float c_mix, float drop_p, uint64_t seed, int64_t row0, uint64_t* relu_bits,
-                                     float* out_act, int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_T,
-                                     int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr,
-                                     void* ws, size_t ws_bytes, void* stream) {
+                                     float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0,
+                                     uint64_t* relu_bits, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
+                                     int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
+                                     const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
   return spmm_fused_impl(0, CB_FUSED_ARGS);
 }
 
 extern "C" int cb_spmm_csr_fused_bf16_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const uint16_t* h,
                                           int64_t ld_h, int64_t d, const float* row_scale, const float* bias, const float* mix_src,
-                                          int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed, int64_t row0,
-                                          uint64_t* relu_bits, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
+                                          int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed,
+                                          const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
                                           int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
                                           const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
   return spmm_fused_impl(1, CB_FUSED_ARGS);

@@ -28,6 +28,7 @@ def _c(t):
 # dropout
 # ---------------------------------------------------------------------------------------------
 _seed_override = []
+_graph_seed = None      # hipGraph mode: int64 device tensor [1]; kernels add its value to the per-site host seed
 
 
 def next_seed():
@@ -37,13 +38,24 @@ def next_seed():
     return int(torch.randint(0, 2 ** 62, (1,)).item())
 
 
+def set_graph_seed(t):
+    """Install (or clear with None) the device-resident per-step seed word used while a training step is
+    captured / replayed as a hipGraph: the captured kernels keep their per-site host seeds and add *t."""
+    global _graph_seed
+    _graph_seed = t
+
+
+def seed_dev_ptr():
+    return _lib.ptr(_graph_seed) if _graph_seed is not None else None
+
+
 def _dropout_raw(x, p, seed, offset=0):
     lib = _lib.load()
     x = _c(x)
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
-        _lib.check(lib.cb_dropout_f32(_lib.ptr(x), _lib.ptr(out), x.numel(), float(p), ctypes.c_uint64(seed), int(offset),
-                                      _lib.stream_ptr()), 'cb_dropout_f32')
+        _lib.check(lib.cb_dropout_f32(_lib.ptr(x), _lib.ptr(out), x.numel(), float(p), ctypes.c_uint64(seed), seed_dev_ptr(),
+                                      int(offset), _lib.stream_ptr()), 'cb_dropout_f32')
     return out
 
 

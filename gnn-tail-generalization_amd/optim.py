@@ -11,6 +11,16 @@ class Adam(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError('invalid Adam hyper-parameter')
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._step_dev = None      # hipGraph mode: int64 device tensor holding the step count
+
+    def make_capturable(self, device):
+        """Moves the step count to device memory so that step() can be captured in a hipGraph: the kernels read
+        the count (and derive the bias corrections) at replay time.  All parameters must share one step count."""
+        steps = {self.state[p]['step'] for g in self.param_groups for p in g['params'] if self.state.get(p)}
+        if len(steps) > 1:
+            raise RuntimeError('capturable Adam needs one common step count')
+        self._step_dev = torch.tensor([steps.pop() if steps else 0], dtype=torch.int64, device=device)
+        return self._step_dev
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -19,6 +29,8 @@ class Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
+        if self._step_dev is not None:
+            self._step_dev.add_(1)         # captured: every replay advances the device-resident count
         for group in self.param_groups:
             b1, b2 = group['betas']
             for p in group['params']:
@@ -37,7 +49,7 @@ class Adam(torch.optim.Optimizer):
                 with torch.cuda.device(p.device):
                     _lib.check(lib.cb_adam_step_f32(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st['exp_avg']), _lib.ptr(st['exp_avg_sq']),
                                                     p.numel(), group['lr'], b1, b2, group['eps'], group['weight_decay'],
-                                                    st['step'], _lib.stream_ptr()), 'cb_adam_step_f32')
+                                                    st['step'], _lib.ptr(self._step_dev), _lib.stream_ptr()), 'cb_adam_step_f32')
         return loss
 
 

@@ -58,7 +58,7 @@ def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False):
         _lib.check(fn(
             _lib.ptr(g.rowptr), _lib.ptr(g.col), n, g.E, _lib.ptr(z), z.stride(0), d, _lib.ptr(graph.norm_in), _lib.ptr(bias),
             _lib.ptr(x0), x0.stride(0) if x0 is not None else 0, float(c_act), float(c_mix), float(p), ctypes.c_uint64(seed),
-            int(getattr(graph, 'row_offset', 0)), _lib.ptr(bits), _lib.ptr(act), d, _lib.ptr(out_next), d, g.hub_threshold,
+            ops.seed_dev_ptr(), int(getattr(graph, 'row_offset', 0)), _lib.ptr(bits), _lib.ptr(act), d, _lib.ptr(out_next), d, g.hub_threshold,
             plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), wsb,
             _lib.stream_ptr()), 'cb_spmm_csr_fused_f32')
     if prof is not None:
@@ -85,8 +85,8 @@ def _layer_bwd(g, bits, row_scale, gx0, accumulate, p, seed, row0, c_act, c_mix,
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=g.device)
     with torch.cuda.device(g.device):
         _lib.check(lib.cb_trunk_layer_bwd_f32(_lib.ptr(g), _lib.ptr(bits), _lib.ptr(row_scale), _lib.ptr(out), int(out_bf16),
-                                              _lib.ptr(gx0), int(accumulate), rows, d, float(p), ctypes.c_uint64(seed), int(row0), float(c_act),
-                                              float(c_mix), _lib.ptr(colsum), _lib.ptr(ws), wsb, _lib.stream_ptr()),
+                                              _lib.ptr(gx0), int(accumulate), rows, d, float(p), ctypes.c_uint64(seed), ops.seed_dev_ptr(),
+                                              int(row0), float(c_act), float(c_mix), _lib.ptr(colsum), _lib.ptr(ws), wsb, _lib.stream_ptr()),
                    'cb_trunk_layer_bwd_f32')
     return out, colsum
 
@@ -100,7 +100,7 @@ def _input_bwd(g, add, act, p, seed, row0):
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=g.device)
     with torch.cuda.device(g.device):
         _lib.check(lib.cb_trunk_input_bwd_f32(_lib.ptr(g), _lib.ptr(add), _lib.ptr(act), _lib.ptr(out), rows, d, float(p),
-                                              ctypes.c_uint64(seed), int(row0), _lib.ptr(colsum), _lib.ptr(ws), wsb,
+                                              ctypes.c_uint64(seed), ops.seed_dev_ptr(), int(row0), _lib.ptr(colsum), _lib.ptr(ws), wsb,
                                               _lib.stream_ptr()), 'cb_trunk_input_bwd_f32')
     return out, colsum
 

@@ -104,7 +104,10 @@ int cb_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_
  * function on the gradient with the same seed instead of storing a mask; `offset` = flat index of x[0]
  * in the unsharded tensor (0 on one GPU), so row shards draw the mask of the full tensor.
  * In-place (out == x) is allowed. */
-int cb_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t seed, int64_t offset, void* stream);
+int cb_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, int64_t offset,
+                   void* stream);
+/* seed_dev (all dropout-bearing entry points; may be NULL): a device word added to `seed` at kernel time, so a step
+ * captured in a hipGraph draws fresh masks on every replay (the host advances *seed_dev inside the graph). */
 
 /* out = a*x + b*y — ResidualConnection / InitialConnection (res_tricks.py:14,23) and gradient sums. */
 int cb_axpby_f32(float a, const float* x, float b, const float* y, float* out, int64_t n, void* stream);
@@ -133,7 +136,8 @@ int cb_nll_logsoftmax_f32(const float* logits, int64_t ld, const int64_t* y, con
  * trainer_node_classification.py:310,430 (L2-style weight decay added to the gradient, bias-corrected
  * moments, step >= 1). */
 int cb_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                     float weight_decay, int64_t step, void* stream);
+                     float weight_decay, int64_t step, const int64_t* step_dev, void* stream);
+/* step_dev (may be NULL): the step count read from device memory instead of `step` (hipGraph replay). */
 
 /* ------------------------------------------------------------------------------------
  * Dense contractions on the fp32 matrix cores (v_mfma_f32_32x32x2_f32; exact fp32).
@@ -166,8 +170,8 @@ int cb_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, con
  * ---------------------------------------------------------------------------------- */
 int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h, int64_t d,
                           const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix, float c_act,
-                          float c_mix, float drop_p, uint64_t seed, int64_t row0, uint64_t* relu_bits, float* out_act,
-                          int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs,
+                          float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits,
+                          float* out_act, int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs,
                           int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes,
                           void* stream);
 
@@ -175,14 +179,15 @@ int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, int64_t N, 
  *     gm = dropout_bwd(g);  gx0 = (accumulate ? gx0 : 0) + c_mix * gm  (gx0 NULL: skipped);
  *     gy = c_act * gm * relu_bit;  colsum = sum_rows gy (dbias; NULL to skip);  out = gy * row_scale[r]. */
 int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits, const float* row_scale, void* out, int out_bf16, float* gx0,
-                           int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed, int64_t row0, float c_act,
-                           float c_mix, float* colsum, void* ws, size_t ws_bytes, void* stream);
+                           int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed, const uint64_t* seed_dev,
+                           int64_t row0, float c_act, float c_mix, float* colsum, void* ws, size_t ws_bytes, void* stream);
 /* (out_bf16 != 0: `out` is a bf16 [rows, d] matrix — gradient rows stored in bf16 for the bf16 aggregation variant.) */
 
 /* Backward into the trunk's input stage X0 = relu(Linear(dropout(x))) (GCN.py:104-107,110):
  *     out = (add + dropout_bwd(g)) * (act > 0);  colsum = sum_rows out  (bias gradient of the input Linear). */
 int cb_trunk_input_bwd_f32(const float* g, const float* add, const float* act, float* out, int64_t rows, int64_t d, float drop_p,
-                           uint64_t seed, int64_t row0, float* colsum, void* ws, size_t ws_bytes, void* stream);
+                           uint64_t seed, const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------
  * bf16-storage variant of the aggregation (build extension = BASELINE config 2; the reference is fp32-only):
@@ -200,10 +205,10 @@ int cb_spmm_csr_bf16_f32(const int32_t* rowptr, const int32_t* col, int64_t N, i
                          size_t ws_bytes, void* stream);
 int cb_spmm_csr_fused_bf16_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const uint16_t* h, int64_t ld_h,
                                int64_t d, const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix,
-                               float c_act, float c_mix, float drop_p, uint64_t seed, int64_t row0, uint64_t* relu_bits,
-                               float* out_act, int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_threshold,
-                               int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,
-                               size_t ws_bytes, void* stream);
+                               float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0,
+                               uint64_t* relu_bits, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
+                               int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
+                               const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Normalisation tricks (GNN_model/norm_tricks.py) as fused reductions; all matrices contiguous [rows, d].
