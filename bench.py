@@ -39,6 +39,7 @@ def parse():
     ap.add_argument('--dataset', default='S-pl10M', help='synthetic workload (S-pl10M = BASELINE headline config)')
     ap.add_argument('--cpu-baseline', type=int, default=1)
     ap.add_argument('--cpu-sample-nodes', type=int, default=200000)
+    ap.add_argument('--hip-graph', type=int, default=0, help='replay the step as one hipGraph (pays off on launch-bound small graphs)')
     ap.add_argument('--agg-dtype', default='f32', choices=['f32', 'bf16'], help='bf16 = build-extension storage of the gathered rows')
     return ap.parse_args()
 
@@ -139,13 +140,27 @@ def main():
     for _ in range(a.warmup):
         t.train_step()
     sync()
-    graph_obj.profile = []
+    use_graph = bool(a.hip_graph) and not sharded
+    if use_graph:
+        # kernel events cannot be recorded inside a captured graph: time the aggregation in an eager pass of the
+        # same K steps first, then capture and time the replays
+        graph_obj.profile = []
+        for _ in range(a.steps):
+            t.train_step()
+        sync()
+        prof, graph_obj.profile = graph_obj.profile, None
+        t.enable_hip_graph(warmup=1)
+        t.train_step()
+        sync()
+    else:
+        graph_obj.profile = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = t.train_step()
     sync()
     dt = time.perf_counter() - t0
-    prof, graph_obj.profile = graph_obj.profile, None
+    if not use_graph:
+        prof, graph_obj.profile = graph_obj.profile, None
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -179,6 +194,7 @@ def main():
                                f'symmetric + self-loops, ids permuted, seed 0), F={args.num_feats} H={args.dim_hidden} '
                                f'C={args.num_classes} L={L}, type_trick={args.type_trick} (residual mode), whetherHasSE=000, '
                                f'dropout={args.dropout}, Adam lr={args.lr}; step = fwd+loss+bwd+Adam, 2L={2 * L} aggregations',
+                   'launch': 'one hipGraph replay per step' if use_graph else 'eager launches',
                    'parallelism': 'single GPU' if not sharded else f'node-sharded x{world} (RCCL all-gather exchange)'},
         'roofline': {'bound': 'hbm', 'kernel': f'k_spmm_rows (+hub kernels) d=256 {a.agg_dtype} source rows, f32 accumulate', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                      'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,

@@ -157,6 +157,12 @@ class trainer:
             self._n_train = int(self.data.train_mask.sum().item())
         self._seed_dev = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(self.device)
         ops.set_graph_seed(self._seed_dev)
+        # the model keeps its last outputs (`out`, `se_reg_all`: reference attributes) and with them the previous autograd
+        # graph, whose gradient accumulators are bound to the stream of the earlier eager steps; capture must not depend on
+        # that (legacy) stream, so drop them and let the warm-up below recreate everything on the capture stream
+        self.teacherGNN.out = self.teacherGNN.se_reg_all = None
+        self.optimizer.zero_grad(set_to_none=True)
+        torch.cuda.synchronize(self.device)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -170,8 +176,9 @@ class trainer:
         if hasattr(self.optimizer, 'make_capturable'):
             self.optimizer.make_capturable(self.device)
         self.optimizer.zero_grad(set_to_none=True)
+        self.teacherGNN.out = self.teacherGNN.se_reg_all = None
         self._hip_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._hip_graph):
+        with torch.cuda.graph(self._hip_graph, stream=side):
             self._seed_dev.add_(0x5DEECE66D)
             loss = self.training_loss()
             loss.backward()
