@@ -38,35 +38,42 @@ struct GemmEpilogue {
   int relu;
 };
 
-template <int WM, int WN, int BKT = BK>
+template <int WM, int WN, int BKT = BK, int WTN = 2>
 struct Tile {
-  static constexpr int BM = 64 * WM, BN = 64 * WN, LDA = BM + 4, LDB = BN + 4;
+  static constexpr int BM = 64 * WM, BN = 32 * WTN * WN, LDA = BM + 4, LDB = BN + 4;   // wave tile = 64 x (32*WTN)
   static constexpr int SMEM_FLOATS = 2 * BKT * (LDA + LDB);
   static_assert(WM * WN == 4, "four wavefronts per block");
   static_assert(32 * LDB <= SMEM_FLOATS, "epilogue staging (32 rows) must fit the operand buffers");
 };
 
-template <int LDA, int LDB, int BKT>
+template <int LDA, int LDB, int BKT, int WTN>
 __device__ __forceinline__ void mfma_tile_step(const float* __restrict__ As, const float* __restrict__ Bs, int wr, int wc,
-                                               int lane, f32x16 (&acc)[2][2]) {
+                                               int lane, f32x16 (&acc)[2][WTN]) {
   const int l31 = lane & 31, kh = lane >> 5;
   const float* ar = As + kh * LDA + wr * 64 + l31;
-  const float* br = Bs + kh * LDB + wc * 64 + l31;
-  float a0 = ar[0], a1 = ar[32], b0 = br[0], b1 = br[32];
+  const float* br = Bs + kh * LDB + wc * (32 * WTN) + l31;
+  float a[2], b[WTN];
+  a[0] = ar[0]; a[1] = ar[32];
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) b[j] = br[32 * j];
 #pragma unroll
   for (int kk = 0; kk < BKT; kk += 2) {
-    float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+    float na[2] = {0.f, 0.f}, nb[WTN];
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) nb[j] = 0.f;
     if (kk + 2 < BKT) {  // next k-step's fragments are in flight while this k-step's MFMAs issue
-      na0 = ar[(kk + 2) * LDA];
-      na1 = ar[(kk + 2) * LDA + 32];
-      nb0 = br[(kk + 2) * LDB];
-      nb1 = br[(kk + 2) * LDB + 32];
+      na[0] = ar[(kk + 2) * LDA];
+      na[1] = ar[(kk + 2) * LDA + 32];
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) nb[j] = br[(kk + 2) * LDB + 32 * j];
     }
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    a[0] = na[0]; a[1] = na[1];
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) b[j] = nb[j];
   }
 }
 
@@ -146,22 +153,23 @@ __device__ __forceinline__ void store_kmajor(const KFrag<BNT, BKT>& f, float* __
     *reinterpret_cast<float4*>(S + (t / TPR + RPP * j) * (BNT + 4) + (t % TPR) * 4) = f.v[j];
 }
 
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
+template <int WTN>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][WTN]) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < WTN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 }
 
 // ---- NN ------------------------------------------------------------------------------------
-template <int WM, int WN, bool ALIGNED, bool OUT_BF16, int BKT = BK>
+template <int WM, int WN, bool ALIGNED, bool OUT_BF16, int BKT = BK, int WTN = 2>
 __global__ void __launch_bounds__(256) k_gemm_nn(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
                                                  void* __restrict__ Cv, int64_t ldc, int64_t M, int N, int K, GemmEpilogue ep,
                                                  int n_row_blocks, int n_col_blocks, int c_vec_ok) {
   float* C = (float*)Cv;
-  using T = Tile<WM, WN, BKT>;
+  using T = Tile<WM, WN, BKT, WTN>;
   constexpr int BM = T::BM, BN = T::BN, LDA = T::LDA, LDB = T::LDB;
   __shared__ __attribute__((aligned(16))) float smem[T::SMEM_FLOATS];
   auto As = [&](int b) { return smem + b * (BKT * LDA); };
@@ -176,8 +184,8 @@ __global__ void __launch_bounds__(256) k_gemm_nn(const float* __restrict__ A, in
   const int n0 = col_blk * BN;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w / WN, wc = w % WN;
 
-  f32x16 acc[2][2];
-  zero_acc(acc);
+  f32x16 acc[2][WTN];
+  zero_acc<WTN>(acc);
   const int nk = (K + BKT - 1) / BKT;
   RowFrag<BM, BKT> fa;
   KFrag<BN, BKT> fb;
@@ -192,7 +200,7 @@ __global__ void __launch_bounds__(256) k_gemm_nn(const float* __restrict__ A, in
       load_rowmajor<ALIGNED, BM, BKT>(fa, A, lda, m0, M, (kt + 1) * BKT, K, t);
       load_kmajor<ALIGNED, BN, BKT>(fb, B, ldb, (int64_t)(kt + 1) * BKT, K, n0, N, t, nullptr);
     }
-    mfma_tile_step<LDA, LDB, BKT>(As(cur), Bs(cur), wr, wc, lane, acc);
+    mfma_tile_step<LDA, LDB, BKT, WTN>(As(cur), Bs(cur), wr, wc, lane, acc);
     if (kt + 1 < nk) {
       store_rowmajor_T<BM, BKT>(fa, As(cur ^ 1), t);
       store_kmajor<BN, BKT>(fb, Bs(cur ^ 1), t);
@@ -211,10 +219,10 @@ __global__ void __launch_bounds__(256) k_gemm_nn(const float* __restrict__ A, in
     const int wr_sel = pass >> 1, ti = pass & 1;
     if (wr == wr_sel) {
 #pragma unroll
-      for (int tj = 0; tj < 2; ++tj)
+      for (int tj = 0; tj < WTN; ++tj)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
-          Cs[((reg & 3) + 8 * (reg >> 2) + 4 * lh) * LDB + wc * 64 + tj * 32 + l31] = acc[ti][tj][reg];
+          Cs[((reg & 3) + 8 * (reg >> 2) + 4 * lh) * LDB + wc * (32 * WTN) + tj * 32 + l31] = acc[ti][tj][reg];
     }
     __syncthreads();
 #pragma unroll
@@ -289,7 +297,7 @@ __global__ void __launch_bounds__(256) k_gemm_tn(const float* __restrict__ A, in
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w / WN, wc = w % WN;
 
   f32x16 acc[2][2];
-  zero_acc(acc);
+  zero_acc<2>(acc);
   const int64_t nk = r_end > r_begin ? (r_end - r_begin + BK - 1) / BK : 0;
   KFrag<BM, BK> fa;
   KFrag<BN, BK> fb;
@@ -306,7 +314,7 @@ __global__ void __launch_bounds__(256) k_gemm_tn(const float* __restrict__ A, in
       load_kmajor<ALIGNED, BM, BK>(fa, A, lda, r_begin + (kt + 1) * BK, r_end, i0, K1, t, nullptr);
       load_kmajor<ALIGNED, BN, BK>(fb, G, ldg, r_begin + (kt + 1) * BK, r_end, j0, K2, t, rowscale);
     }
-    mfma_tile_step<LDA, LDB, BK>(As(cur), Bs(cur), wr, wc, lane, acc);
+    mfma_tile_step<LDA, LDB, BK, 2>(As(cur), Bs(cur), wr, wc, lane, acc);
     if (kt + 1 < nk) {
       store_kmajor<BM, BK>(fa, As(cur ^ 1), t);
       store_kmajor<BN, BK>(fb, Bs(cur ^ 1), t);
@@ -356,22 +364,22 @@ static inline void tn_tile(int64_t K1, int64_t K2, int& bm, int& bn) {
   else { bm = 128; bn = 128; }
 }
 
-template <int WM, int WN, bool OUT_BF16 = false>
+template <int WM, int WN, bool OUT_BF16 = false, int WTN = 2>
 static int launch_nn(const float* A, int64_t lda, const float* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
                      int64_t K, GemmEpilogue ep, hipStream_t st) {
-  using T = Tile<WM, WN>;
+  using T = Tile<WM, WN, BK, WTN>;
   const int nrb = (int)((M + T::BM - 1) / T::BM), ncb = (int)((N + T::BN - 1) / T::BN);
   const int64_t groups = (nrb + 7) / 8;
   const dim3 grid((unsigned)(groups * 8 * ncb));
   const bool aligned = al16(A) && al16(B) && lda % 4 == 0 && ldb % 4 == 0;
   const int c_vec_ok = ((uintptr_t)C % (OUT_BF16 ? 8 : 16) == 0) && ldc % 4 == 0 && (!ep.addend || (al16(ep.addend) && ep.ld_add % 4 == 0));
   static const int bk32 = getenv("CB_GEMM_BK32") != nullptr;   // measurement hook: K step 32 instead of 16
-  if (aligned && bk32 && WM == 2)
-    hipLaunchKernelGGL((k_gemm_nn<WM, WN, true, OUT_BF16, 32>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
+  if (aligned && bk32 && WM == 2 && WTN == 2)
+    hipLaunchKernelGGL((k_gemm_nn<WM, WN, true, OUT_BF16, 32, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
   else if (aligned)
-    hipLaunchKernelGGL((k_gemm_nn<WM, WN, true, OUT_BF16>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
+    hipLaunchKernelGGL((k_gemm_nn<WM, WN, true, OUT_BF16, BK, WTN>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
   else
-    hipLaunchKernelGGL((k_gemm_nn<WM, WN, false, OUT_BF16>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
+    hipLaunchKernelGGL((k_gemm_nn<WM, WN, false, OUT_BF16, BK, WTN>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
   CB_LAUNCH_CHECK();
   return CB_OK;
 }
@@ -414,6 +422,8 @@ extern "C" int cb_gemm_nn_f32(const float* A, int64_t lda, const float* B, int64
   GemmEpilogue ep{rowscale, addend, ld_add, bias, relu};
   hipStream_t st = (hipStream_t)stream;
   if (N <= 64) return launch_nn<4, 1>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
+  static const int wide = getenv("CB_GEMM_WIDE") != nullptr;   // measurement hook: 128x256 block tile (wave tile 64x128)
+  if (wide && N > 128) return launch_nn<2, 2, false, 4>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
   return launch_nn<2, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
 }
 
