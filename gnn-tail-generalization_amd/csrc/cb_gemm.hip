@@ -394,11 +394,14 @@ static int launch_tn(const float* A, int64_t lda, const float* G, int64_t ldg, c
   rows_per_split = (rows_per_split + BK - 1) / BK * BK;
   const bool aligned = al16(A) && al16(G) && lda % 4 == 0 && ldg % 4 == 0;
   const dim3 grid((unsigned)(tiles_i * tiles_j), (unsigned)nsplit);
+  // Measurement hook: extra (unused) dynamic LDS caps the blocks per CU, leaving registers for a concurrently running
+  // HBM-bound kernel on another stream (see tools/overlap_probe.py).
+  static const int pad_lds = getenv("CB_GEMM_TN_PADLDS") ? atoi(getenv("CB_GEMM_TN_PADLDS")) : 0;
   if (aligned)
-    hipLaunchKernelGGL((k_gemm_tn<WM, WN, true>), grid, dim3(256), 0, st, A, lda, G, ldg, rowscale, ws, M, (int)K1, (int)K2,
+    hipLaunchKernelGGL((k_gemm_tn<WM, WN, true>), grid, dim3(256), pad_lds, st, A, lda, G, ldg, rowscale, ws, M, (int)K1, (int)K2,
                        rows_per_split, tiles_j);
   else
-    hipLaunchKernelGGL((k_gemm_tn<WM, WN, false>), grid, dim3(256), 0, st, A, lda, G, ldg, rowscale, ws, M, (int)K1, (int)K2,
+    hipLaunchKernelGGL((k_gemm_tn<WM, WN, false>), grid, dim3(256), pad_lds, st, A, lda, G, ldg, rowscale, ws, M, (int)K1, (int)K2,
                        rows_per_split, tiles_j);
   CB_LAUNCH_CHECK();
   const int64_t n = K1 * K2;
