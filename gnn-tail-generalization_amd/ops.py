@@ -274,3 +274,19 @@ def gather_rows_by_index(x, idx):
         _lib.check(lib.cb_gather_rows_f32(_lib.ptr(x), x.stride(0) if x.shape[0] > 1 else x.shape[1], _lib.ptr(idx), idx.numel(),
                                           x.shape[1], _lib.ptr(out), _lib.stream_ptr()), 'cb_gather_rows_f32')
     return out
+
+
+def label_propagation(graph, y0, deg_inv_sqrt, alpha, num_propagations):
+    """result <- clamp(alpha * D^-1/2 A D^-1/2 result + (1 - alpha) * y0, 0, 1), `num_propagations` times, starting from
+    y0 (Label_propagation_model/outcome_correlation.py:128-156 with post_step = clamp(0,1), alpha_term=True).
+    Every product with the adjacency is the aggregation kernel on the cached CSR (symmetric graph)."""
+    _lib.require_device(y0, deg_inv_sqrt)
+    y0 = _c(y0.float())
+    dis = _c(deg_inv_sqrt.float())
+    a_dis = _c(dis * float(alpha))
+    result = y0.clone()
+    for _ in range(int(num_propagations)):
+        h, _ = act_bwd(result, None, dis, want_out=True, want_colsum=False)          # D^-1/2 result
+        prop = graph.spmm(h, row_scale=a_dis)                                        # alpha * D^-1/2 A (.)
+        result = _axpby_raw(1.0, prop, 1.0 - float(alpha), y0).clamp_(0, 1)
+    return result

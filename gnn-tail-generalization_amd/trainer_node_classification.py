@@ -41,8 +41,33 @@ class trainer:
             save_graph_analyze(self.args.N_nodes, self.data, self.args.use_special_split)
         if self.args.train_which in ['TeacherGNN']:
             return self.train_teacherGNN()
+        if self.args.train_which in ['LP']:
+            return self.run_pureLP()
         raise NotImplementedError(f'--train_which={self.args.train_which}: only the TeacherGNN path is built '
-                                  '(student / label-propagation trainers are out of scope, SURVEY.md §8f)')
+                                  'and the pure label-propagation baseline (--train_which=LP) are built; the student MLP '
+                                  'trainers are out of scope (SURVEY.md §8f)')
+
+    def run_pureLP(self):
+        """Pure label propagation (reference trainer :33-63): 50 steps of result <- clamp(0.5 * D^-1/2 A D^-1/2 result
+        + 0.5 * y0, 0, 1) from the one-hot training labels, on the same aggregation kernel as the teacher."""
+        from .graph import CSRGraph
+        from .utils import to_undirected
+        self.args.lpStep_alpha, self.args.lpStep_num_propagations = 0.5, 50
+        n = int(self.data.x.shape[0])
+        self.data.edge_index = to_undirected(self.data.edge_index, n)        # process_adj rewrites data.edge_index too
+        graph = CSRGraph(self.data.edge_index, n)
+        deg_inv_sqrt = graph.in_degrees().to(torch.float32).pow(-0.5)
+        deg_inv_sqrt[deg_inv_sqrt == float('inf')] = 0
+        labels, train = self.data.y, self.data.train_mask
+        c = int(labels.max().item()) + 1
+        y0 = torch.zeros((n, c), device=self.device)
+        y0[train] = F.one_hot(labels[train], c).float()
+        out = ops.label_propagation(graph, y0, deg_inv_sqrt, self.args.lpStep_alpha, self.args.lpStep_num_propagations)
+        self.lp_out = out
+        acc_train = np.round(evaluate(out, labels, train) * 100, 2)
+        acc_test = np.round(evaluate(out, labels, ~train) * 100, 2)
+        print('train,test acc = ', acc_train, acc_test)
+        return np.array([[acc_train, acc_test]])
 
     def __init__(self, args, which_run):
         self.bag = {}

@@ -400,3 +400,33 @@ def train_steps(cfg, sd, x, csr, y, train_mask, steps, lr, weight_decay, dropout
             adam_step({k: sd[k] for k in used}, {k: g for k, g in zip(used, grads)}, state, lr, weight_decay, s + 1)
         losses.append(float(loss.detach()))
     return losses
+
+
+# --------------------------------------------------------------------------------------
+# Pure label propagation: trainer_node_classification.run_pureLP :33-63 over
+# Label_propagation_model/outcome_correlation.py — process_adj :39-49, gen_normalized_adjs :51-55 (DAD),
+# label_propagation :147-156, general_outcome_correlation :128-145.
+# The sparse algebra of the reference is torch_sparse==0.6.10 (absent): PARITY UNPINNED at that boundary,
+# pinned against the reference functions run over the SparseTensor stand-in (tests/golden/lp_fixture.pt).
+# --------------------------------------------------------------------------------------
+def to_undirected(edge_index, num_nodes):
+    """PyG to_undirected: union with the transpose, duplicates removed, sorted by (row, col) (:41)."""
+    ei = edge_index.to(torch.int64)
+    key = torch.unique(torch.cat([ei[0] * num_nodes + ei[1], ei[1] * num_nodes + ei[0]]))
+    return torch.stack([key // num_nodes, key % num_nodes])
+
+
+def label_propagation(edge_index, y, train_mask, num_classes, alpha=0.5, num_propagations=50):
+    n = y.shape[0]
+    ei = to_undirected(edge_index, n)
+    csr = build_csr(ei, n)
+    deg = torch.from_numpy(csr.in_deg).to(torch.float32)           # adj.sum(dim=1) (:46)
+    dis = deg.pow(-0.5)
+    dis[dis == float('inf')] = 0                                  # :47-48
+    y0 = torch.zeros((n, num_classes))
+    y0[train_mask] = F.one_hot(y[train_mask], num_classes).float()  # :151-153
+    result = y0.clone()
+    for _ in range(num_propagations):                               # :137-143 with alpha_term, post_step = clamp(0, 1)
+        prop = aggregate_sum(csr, result * dis.unsqueeze(1)) * dis.unsqueeze(1)    # DAD @ result
+        result = torch.clamp(alpha * prop + (1 - alpha) * y0, 0, 1)
+    return result, dis

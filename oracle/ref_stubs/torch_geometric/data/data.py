@@ -5,6 +5,10 @@ class Data:
         for k, v in kw.items():
             setattr(self, k, v)
 
+    @property
+    def num_nodes(self):
+        return self.x.shape[0]
+
     def to(self, device):
         import torch
         for k, v in list(vars(self).items()):

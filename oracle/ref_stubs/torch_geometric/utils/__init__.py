@@ -34,4 +34,11 @@ def subgraph(subset, edge_index, edge_attr=None, relabel_nodes=False, num_nodes=
     return edge_index[:, keep], (None if edge_attr is None else edge_attr[keep])
 
 
-to_undirected = to_networkx = negative_sampling = _absent
+def to_undirected(edge_index, num_nodes=None):
+    """Published PyG semantics: union with the transpose, duplicates removed, sorted by (row, col)."""
+    n = int(edge_index.max()) + 1 if num_nodes is None else num_nodes
+    key = torch.unique(torch.cat([edge_index[0] * n + edge_index[1], edge_index[1] * n + edge_index[0]]))
+    return torch.stack([key // n, key % n])
+
+
+to_networkx = negative_sampling = _absent

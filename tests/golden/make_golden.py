@@ -310,6 +310,35 @@ def utils_fixture(ns):
     return out
 
 
+def lp_fixture(ns):
+    """§8f row 4 — pure label propagation (trainer_node_classification.run_pureLP :33-63): the reference's own
+    process_adj / gen_normalized_adjs / general_outcome_correlation (outcome_correlation.py:39-55,128-156) driven
+    exactly as label_propagation does (:147-156), with device='cpu' passed explicitly (its default 'cuda' cannot
+    run in this container)."""
+    with ref_import.in_scratch():
+        from Label_propagation_model import outcome_correlation as oc
+    import torch.nn.functional as F
+    Data = sys.modules['torch_geometric.data.data'].Data
+    ei, n = make_graph('powerlaw', 180, 21)
+    g = torch.Generator().manual_seed(21)
+    c = 6
+    y = torch.randint(0, c, (n,), generator=g)
+    train_mask = torch.rand(n, generator=g) < 0.4
+    data = Data(x=torch.zeros(n, 2), y=y, edge_index=ei.clone(), train_mask=train_mask)
+    adj, d_isqrt = oc.process_adj(data)
+    dad, _, _ = oc.gen_normalized_adjs(adj, d_isqrt)
+    y0 = torch.zeros((n, c))
+    idx = oc.get_labels_from_name(['train'], {'train': train_mask})
+    y0[idx] = F.one_hot(y[idx], c).float().squeeze(1)
+    out = oc.general_outcome_correlation(dad, y0, 0.5, 50, post_step=lambda t: torch.clamp(t, 0, 1), alpha_term=True,
+                                         device='cpu', display=False)
+    acc_train = ns.trainer.evaluate(out, y, train_mask)
+    acc_test = ns.trainer.evaluate(out, y, ~train_mask)
+    return dict(edge_index=ei, edge_index_undirected=data.edge_index.clone(), y=y, train_mask=train_mask, deg_inv_sqrt=d_isqrt,
+                out=out, acc=torch.tensor([np.round(acc_train * 100, 2), np.round(acc_test * 100, 2)], dtype=torch.float64),
+                alpha=0.5, num_propagations=50, num_classes=c)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='')
@@ -317,7 +346,7 @@ def main():
     ns = ref_import.load_reference()
     torch.set_num_threads(1)
     for c in CASES:
-        if a.only and (a.only in ('utils', 'options', 'trainer') or a.only not in c['name']):
+        if a.only and (a.only in ('utils', 'options', 'trainer', 'lp') or a.only not in c['name']):
             continue
         out = run_case(ns, c)
         torch.save(out, os.path.join(HERE, f'case_{c["name"]}.pt'))
@@ -332,6 +361,9 @@ def main():
     if not a.only or 'utils' in a.only:
         torch.save(utils_fixture(ns), os.path.join(HERE, 'utils_fixture.pt'))
         print('wrote utils_fixture.pt')
+    if not a.only or 'lp' in a.only:
+        torch.save(lp_fixture(ns), os.path.join(HERE, 'lp_fixture.pt'))
+        print('wrote lp_fixture.pt')
     if not a.only or 'options' in a.only:
         import json
         with open(os.path.join(HERE, 'options.json'), 'w') as f:

@@ -137,3 +137,24 @@ def test_hip_graph_step_matches_eager():
         assert np.isfinite(losses).all() and len(set(round(v, 6) for v in losses)) == 4
     finally:
         ops.set_graph_seed(None)
+
+
+def test_label_propagation_matches_reference_fixture():
+    """§8f row 4: --train_which=LP on the HIP aggregation reproduces the reference's outcome_correlation output."""
+    import contextlib
+    import io
+    from gnn_tail_generalization_amd.base_options import BaseOptions
+    from gnn_tail_generalization_amd.data import Data
+    from gnn_tail_generalization_amd.trainer_node_classification import trainer
+    g = load_golden('lp_fixture')
+    with contextlib.redirect_stdout(io.StringIO()):
+        args = BaseOptions().get_arguments(['--dataset=S-tiny', '--train_which=LP', '--manual_assign_GPU=0'])
+    n = g['y'].shape[0]
+    t = trainer.__new__(trainer)
+    t.args, t.device = args, torch.device(DEV)
+    t.data = Data(x=torch.zeros(n, 2), y=g['y'], edge_index=g['edge_index'], train_mask=g['train_mask']).to(DEV)
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = t.run_pureLP()
+    assert torch.equal(t.data.edge_index.cpu(), g['edge_index_undirected'])
+    torch.testing.assert_close(t.lp_out.cpu(), g['out'], atol=1e-5, rtol=1e-5)
+    assert res.shape == (1, 2) and res[0].tolist() == g['acc'].tolist()

@@ -92,3 +92,14 @@ def test_oracle_training_trajectory(name):
     out, _ = orc.teacher_forward(cfg, {k: v.detach() for k, v in sd.items()}, g['x'], csr, training=False)
     assert orc.evaluate(out, g['y'], g['train_mask']) == pytest.approx(float(g['trajectory'][-1, 1]))
     assert orc.evaluate(out, g['y'], ~g['train_mask']) == pytest.approx(float(g['trajectory'][-1, 2]))
+
+
+def test_oracle_label_propagation_matches_reference():
+    """§8f row 4: pure label propagation against the reference's outcome_correlation functions."""
+    g = load_golden('lp_fixture')
+    assert torch.equal(orc.to_undirected(g['edge_index'], g['y'].shape[0]), g['edge_index_undirected'])
+    out, dis = orc.label_propagation(g['edge_index'], g['y'], g['train_mask'], g['num_classes'], g['alpha'], g['num_propagations'])
+    torch.testing.assert_close(dis, g['deg_inv_sqrt'], atol=0, rtol=1e-6)
+    torch.testing.assert_close(out, g['out'], atol=1e-5, rtol=1e-5)
+    acc = [np.round(orc.evaluate(out, g['y'], m) * 100, 2) for m in (g['train_mask'], ~g['train_mask'])]
+    assert acc == g['acc'].tolist()
