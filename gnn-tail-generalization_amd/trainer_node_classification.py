@@ -127,11 +127,38 @@ class trainer:
     def global_edges(self):
         return int(self.data.edge_index.shape[1])
 
+    # -- resumable checkpoint (the reference saves weights only and never reads --resume) -------
+    def checkpoint_path(self):
+        return join(self.modeldir, 'teacherGNN-ckpt')
+
+    def save_checkpoint(self, epoch, results):
+        """Weights + fused-Adam moments/step + RNG state + per-epoch records: enough to continue bit-for-bit."""
+        torch.save({'model': self.teacherGNN.state_dict(), 'optimizer': self.optimizer.state_dict(), 'epoch': epoch,
+                    'results': results, 'torch_rng': torch.get_rng_state(), 'numpy_rng': np.random.get_state()},
+                   self.checkpoint_path())
+
+    def load_checkpoint(self):
+        path = self.checkpoint_path()
+        if not os.path.exists(path):
+            return -1, []
+        ck = torch.load(path, map_location=self.device, weights_only=False)
+        self.teacherGNN.load_state_dict(ck['model'])
+        self.optimizer.load_state_dict(ck['optimizer'])
+        torch.set_rng_state(ck['torch_rng'].cpu())
+        np.random.set_state(ck['numpy_rng'])
+        print(f'---››››  RESUME from {path} after epoch {ck["epoch"]}')
+        return ck['epoch'], ck['results']
+
     def train_teacherGNN(self):
         self.setup_teacherGNN()
         best_train_loss, best_test_acc = 100, 0.
         results_arr2D = []
-        for epoch in range(self.epochs):
+        first_epoch = 0
+        if getattr(self.args, 'resume', False):
+            last, results_arr2D = self.load_checkpoint()
+            first_epoch = last + 1
+        ckpt_every = int(getattr(self.args, 'ckpt_every', 0) or 0)
+        for epoch in range(first_epoch, self.epochs):
             self.epoch = epoch
             acc_train, acc_val, acc_test, loss_train, loss_val, linkp_train, linkp_test = self.train_net()
             if 'SEMLP' in self.args.train_which and acc_test > best_test_acc:
@@ -142,6 +169,9 @@ class trainer:
                 results_arr2D[-1].extend(self.bag['head_tail_iso'])
             if epoch % 20 == 0:
                 print(f'Ep{epoch:03d}, acc @ train/test: {acc_train * 100:.1f}, {acc_test * 100:.1f} ')
+            if ckpt_every and (epoch + 1) % ckpt_every == 0:
+                self.save_checkpoint(epoch, results_arr2D)
+        self.save_checkpoint(self.epochs - 1, results_arr2D)
         print('train_loss: {:.4f},  test_acc:{:.4f}'.format(best_train_loss, best_test_acc))
         save_model(self.teacherGNN, join(self.modeldir, 'teacherGNN'))
         results_arr2D = np.array(results_arr2D).T

@@ -158,3 +158,26 @@ def test_label_propagation_matches_reference_fixture():
     assert torch.equal(t.data.edge_index.cpu(), g['edge_index_undirected'])
     torch.testing.assert_close(t.lp_out.cpu(), g['out'], atol=1e-5, rtol=1e-5)
     assert res.shape == (1, 2) and res[0].tolist() == g['acc'].tolist()
+
+
+def test_resume_from_checkpoint_continues_bit_for_bit():
+    """§8f row 3: weights + fused-Adam state + RNG are checkpointed; 3 epochs, resume, 2 more == 5 straight epochs."""
+    import os
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import main as cli
+    common = ['--dataset=S-tiny', '--whetherHasSE=111', '--se_reg=0.5', '--want_headtail=0', '--use_special_split=0',
+              '--do_deg_analyze=0', '--manual_assign_GPU=0']
+    cwd = os.getcwd()
+    try:
+        os.chdir(tempfile.mkdtemp())
+        straight = cli.main(common + ['--epochs=5'])[0]
+        os.chdir(tempfile.mkdtemp())
+        cli.main(common + ['--epochs=3'])
+        resumed = cli.main(common + ['--epochs=5', '--resume'])[0]
+    finally:
+        os.chdir(cwd)
+    assert straight.shape == resumed.shape == (1, 5)
+    np.testing.assert_array_equal(straight, resumed)
