@@ -34,6 +34,39 @@ from . import _lib
 from .graph import CSRGraph, ZeroInDegreeError
 
 
+def _staged(t, group):
+    """gloo cannot move device tensors for every collective: stage through the host in that case (used to exercise the
+    whole sharded HIP path with several processes on ONE GPU; the production backend is nccl = RCCL, no staging)."""
+    return t.is_cuda and dist.get_backend(group) == 'gloo'
+
+
+def _all_reduce(t, op=dist.ReduceOp.SUM, group=None):
+    if _staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def _all_to_all_single(out, inp, out_splits=None, in_splits=None, group=None):
+    if _staged(inp, group) or _staged(out, group):
+        ho, hi = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
+        dist.all_to_all_single(ho, hi, out_splits, in_splits, group=group)
+        out.copy_(ho)
+    else:
+        dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
+
+
+def _all_gather_into_tensor(out, inp, group=None):
+    if _staged(inp, group):
+        ho, hi = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
+        dist.all_gather_into_tensor(ho, hi, group=group)
+        out.copy_(ho)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
 class Partition:
     """Equal row blocks: rank p owns [lo(p), hi(p))."""
 
@@ -74,7 +107,7 @@ def gather_rows(x_local, part, group=None, out=None):
     else:   # last rank: pad its shard to R rows
         src = torch.zeros((part.R, d), dtype=x_local.dtype, device=x_local.device)
         src[:x_local.shape[0]] = x_local
-    dist.all_gather_into_tensor(out, src, group=group)
+    _all_gather_into_tensor(out, src, group=group)
     return out
 
 
@@ -95,14 +128,14 @@ class HaloPlan:
         recv_counts = torch.bincount(torch.div(uniq, R, rounding_mode='floor'), minlength=P)[:P]
         send_counts = torch.empty_like(recv_counts)
         if P > 1:
-            dist.all_to_all_single(send_counts, recv_counts, group=group)    # how many rows each peer wants from me
+            _all_to_all_single(send_counts, recv_counts, group=group)    # how many rows each peer wants from me
         else:
             send_counts.copy_(recv_counts)
         self.recv_counts = [int(v) for v in recv_counts.tolist()]
         self.send_counts = [int(v) for v in send_counts.tolist()]
         wanted = torch.empty(sum(self.send_counts), dtype=torch.int64, device=dev)
         if P > 1:
-            dist.all_to_all_single(wanted, uniq, self.send_counts, self.recv_counts, group=group)
+            _all_to_all_single(wanted, uniq, self.send_counts, self.recv_counts, group=group)
         self.send_idx = (wanted - lo).contiguous()                         # my local rows, in per-destination order
         if self.send_idx.numel() and (int(self.send_idx.min()) < 0 or int(self.send_idx.max()) >= self.n_local):
             raise RuntimeError('halo plan: a peer requested a row this rank does not own')
@@ -152,7 +185,7 @@ class ShardedGraph:
             same = (rpt.shape == rp.shape and ct.shape == c.shape and bool(torch.equal(rpt, rp)) and bool(torch.equal(ct, c)))
             if part.world > 1:      # one global decision, or the ranks would disagree on which collectives follow
                 flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=rp.device)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                _all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
                 same = bool(flag.item())
             self.plan_bwd = self.plan_fwd if same else HaloPlan(ct, part, group)
             c, ct = self.plan_fwd.col, self.plan_bwd.col
@@ -179,7 +212,7 @@ class ShardedGraph:
         ext = torch.empty((plan.n_local + plan.n_halo, d), dtype=x_local.dtype, device=x_local.device)
         ext[:plan.n_local] = x_local
         send = _pack_rows(x_local, plan.send_idx)
-        dist.all_to_all_single(ext[plan.n_local:], send, plan.recv_counts, plan.send_counts, group=self.group)
+        _all_to_all_single(ext[plan.n_local:], send, plan.recv_counts, plan.send_counts, group=self.group)
         return ext
 
     def check_zero_in_degree(self):
@@ -243,7 +276,7 @@ def allreduce_grads(params, group=None):
     if not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     off = 0
     for g in grads:
         n = g.numel()
@@ -259,13 +292,13 @@ class _AllReduceSumFn(torch.autograd.Function):
     def forward(ctx, x, group):
         ctx.group = group
         y = x.clone()
-        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce(y, op=dist.ReduceOp.SUM, group=group)
         return y
 
     @staticmethod
     def backward(ctx, g):
         g = g.clone()                      # every rank's loss depends on x through y: sum the upstream gradients
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        _all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
         return g, None
 
 
@@ -291,8 +324,8 @@ class ShardedTrainer:
         chk = torch.stack([data.edge_index.sum(), (data.edge_index[0] * 31 + data.edge_index[1]).sum(),
                            data.train_mask.sum().to(torch.int64)]).to(torch.float64)
         lo_, hi_ = chk.clone(), chk.clone()
-        dist.all_reduce(lo_, op=dist.ReduceOp.MIN, group=group)
-        dist.all_reduce(hi_, op=dist.ReduceOp.MAX, group=group)
+        _all_reduce(lo_, op=dist.ReduceOp.MIN, group=group)
+        _all_reduce(hi_, op=dist.ReduceOp.MAX, group=group)
         if not torch.equal(lo_, hi_):
             raise RuntimeError('ranks generated different graphs (seeded generator mismatch)')
         self.part = Partition(self._n, self.world, self.rank)
@@ -323,6 +356,16 @@ class ShardedTrainer:
         self.replicated = [p for n, p in self.teacherGNN.named_parameters() if not n.endswith('.le') and n != 'embs']
         self.optimizer = self.optfun(self.teacherGNN.parameters(), lr=self.args.lr, weight_decay=self.args.weight_decay)
 
+    def load_full_state_dict(self, sd_full):
+        """Loads a single-GPU (unsharded) TeacherGNN state_dict: replicated tensors as they are, the per-node tables
+        (structural embeddings `le`, learnable inputs `embs`) cut to this rank's row block."""
+        lo, hi = self.part.lo(), self.part.hi()
+        sd = {}
+        for k, v in sd_full.items():
+            per_node = (k.endswith('.le') or k == 'embs') and v.dim() == 2 and v.shape[0] == self._n
+            sd[k] = v[lo:hi].clone() if per_node else v
+        self.teacherGNN.load_state_dict(sd)
+
     def graph(self):
         return self.sgraph
 
@@ -346,5 +389,5 @@ class ShardedTrainer:
         allreduce_grads(self.replicated, self.group)
         self.optimizer.step()
         total = loss.detach().clone()
-        dist.all_reduce(total, group=self.group)
+        _all_reduce(total, group=self.group)
         return total

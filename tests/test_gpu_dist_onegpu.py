@@ -1,0 +1,105 @@
+"""GPU: the complete node-sharded HIP path (halo plans on the device, rectangular row-slice CSRs, fused trunk with
+global dropout indices, sharded structural embeddings, gradient / regulariser all-reduces) run by TWO processes that
+share the single GPU of the test box, against the single-process trainer.  Collectives go through gloo with host
+staging (dist._staged) because RCCL refuses two ranks on one device; everything else is the production code."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGV = ['--dataset=S-pubmed', '--use_special_split=0', '--want_headtail=0', '--whetherHasSE=111', '--se_reg=0.5',
+        '--num_layers=2', '--manual_assign_GPU=0', '--do_deg_analyze=0']
+SEEDS = list(range(7000, 7040))
+STEPS = 3
+
+
+def _full_state(args_cls):
+    import contextlib
+    import io
+    from gnn_tail_generalization_amd.base_options import BaseOptions
+    from gnn_tail_generalization_amd.GNN_model import TeacherGNN
+    from gnn_tail_generalization_amd.utils import set_arch_configs
+    with contextlib.redirect_stdout(io.StringIO()):
+        a = BaseOptions().get_arguments(ARGV)
+    set_arch_configs(a)
+    torch.manual_seed(0)
+    return {k: v.detach().clone() for k, v in TeacherGNN(a).state_dict().items()}
+
+
+def _worker(rank, world, port, exchange, q):
+    sys.path.insert(0, ROOT)
+    import contextlib
+    import io
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), COLDBREW_EXCHANGE=exchange)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from gnn_tail_generalization_amd import ops
+        from gnn_tail_generalization_amd.base_options import BaseOptions
+        from gnn_tail_generalization_amd.dist import ShardedTrainer
+        torch.cuda.set_device(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            args = BaseOptions().get_arguments(ARGV)
+            t = ShardedTrainer(args, 0)
+            t.setup_teacherGNN()
+        t.load_full_state_dict({k: v.cuda() for k, v in _full_state(None).items()})
+        assert t.sgraph.exchange_kind == exchange and t.teacherGNN.model.model.layers_GCN[0].le.shape[0] == t.part.n_local
+        ops._seed_override[:] = list(SEEDS)
+        losses = [float(t.train_step()) for _ in range(STEPS)]
+        w = t.teacherGNN.model.model.layers_GCN[1].weight.detach().cpu()
+        le = t.teacherGNN.model.model.layers_GCN[0].le.detach().cpu()
+        q.put((rank, 'ok', losses, w, le, t.part.lo(), t.part.hi()))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, 'FAIL ' + traceback.format_exc()[-2500:], None, None, None, 0, 0))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize('exchange', ['halo', 'allgather'])
+def test_two_ranks_on_one_gpu_match_single_process(exchange):
+    import contextlib
+    import io
+    sys.path.insert(0, ROOT)
+    from gnn_tail_generalization_amd import ops
+    from gnn_tail_generalization_amd.base_options import BaseOptions
+    from gnn_tail_generalization_amd.trainer_node_classification import trainer
+    # single-process reference on the same data, parameters and dropout seeds
+    with contextlib.redirect_stdout(io.StringIO()):
+        args = BaseOptions().get_arguments(ARGV)
+        ref = trainer(args, 0)
+        ref.setup_teacherGNN()
+    ref.teacherGNN.load_state_dict({k: v.cuda() for k, v in _full_state(None).items()})
+    ops._seed_override[:] = list(SEEDS)
+    want = [float(ref.train_step()) for _ in range(STEPS)]
+    ops._seed_override[:] = []
+    w_ref = ref.teacherGNN.model.model.layers_GCN[1].weight.detach().cpu()
+    le_ref = ref.teacherGNN.model.model.layers_GCN[0].le.detach().cpu()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, exchange, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, msg, losses, w, le, lo, hi in res:
+        assert msg == 'ok', f'rank {rank}: {msg}'
+        np.testing.assert_allclose(losses, want, rtol=2e-5)
+        torch.testing.assert_close(w, w_ref, atol=1e-5, rtol=1e-4)
+        torch.testing.assert_close(le, le_ref[lo:hi], atol=1e-5, rtol=1e-4)
