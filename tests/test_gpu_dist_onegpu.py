@@ -54,7 +54,7 @@ def _worker(rank, world, port, exchange, q):
         losses = [float(t.train_step()) for _ in range(STEPS)]
         w = t.teacherGNN.model.model.layers_GCN[1].weight.detach().cpu()
         le = t.teacherGNN.model.model.layers_GCN[0].le.detach().cpu()
-        q.put((rank, 'ok', losses, w, le, t.part.lo(), t.part.hi()))
+        q.put((rank, 'ok', losses, w.numpy(), le.numpy(), t.part.lo(), t.part.hi()))   # by value: the child may exit first
     except Exception:  # noqa: BLE001
         import traceback
         q.put((rank, 'FAIL ' + traceback.format_exc()[-2500:], None, None, None, 0, 0))
@@ -101,5 +101,5 @@ def test_two_ranks_on_one_gpu_match_single_process(exchange):
     for rank, msg, losses, w, le, lo, hi in res:
         assert msg == 'ok', f'rank {rank}: {msg}'
         np.testing.assert_allclose(losses, want, rtol=2e-5)
-        torch.testing.assert_close(w, w_ref, atol=1e-5, rtol=1e-4)
-        torch.testing.assert_close(le, le_ref[lo:hi], atol=1e-5, rtol=1e-4)
+        torch.testing.assert_close(torch.from_numpy(w), w_ref, atol=1e-5, rtol=1e-4)
+        torch.testing.assert_close(torch.from_numpy(le), le_ref[lo:hi], atol=1e-5, rtol=1e-4)
