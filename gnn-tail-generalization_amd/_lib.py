@@ -60,6 +60,8 @@ SIGNATURES = {
     'cb_colstats_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _SZ, _P]),
     'cb_col_affine_f32': (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_float, _P, _I64, _I64, _P]),
     'cb_col_bwd_combine_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _P, _I64, _I64, _P]),
+    'cb_topk_replace_workspace_bytes': (_SZ, [_I64, _I64, _I64]),
+    'cb_topk_replace_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I64, _I64, _I32, _P, _P, _P, _P, _SZ, _P]),
     'cb_gather_rows_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _P, _P]),
     'cb_trunk_input_bwd_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _P, _SZ, _P]),
 }

@@ -1,0 +1,145 @@
+// Shared fp32-MFMA GEMM building blocks (tile geometry, LDS operand staging, the MFMA inner step) used by
+// cb_gemm.hip (NN / TN contractions) and cb_topk.hip (scores + running top-K).  See cb_gemm.hip for the design notes.
+#pragma once
+#include "cb_common.h"
+
+namespace cb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;   // default K step (BKT template parameter; 32 selectable for measurement)
+
+struct GemmEpilogue {
+  const float* rowscale;  // [M] or null
+  const float* addend;    // [M, ld_add] or null
+  int64_t ld_add;
+  const float* bias;      // [N] or null
+  int relu;
+};
+
+template <int WM, int WN, int BKT = BK, int WTN = 2>
+struct Tile {
+  static constexpr int BM = 64 * WM, BN = 32 * WTN * WN, LDA = BM + 4, LDB = BN + 4;   // wave tile = 64 x (32*WTN)
+  static constexpr int SMEM_FLOATS = 2 * BKT * (LDA + LDB);
+  static_assert(WM * WN == 4, "four wavefronts per block");
+  static_assert(32 * LDB <= SMEM_FLOATS, "epilogue staging (32 rows) must fit the operand buffers");
+};
+
+template <int LDA, int LDB, int BKT, int WTN>
+__device__ __forceinline__ void mfma_tile_step(const float* __restrict__ As, const float* __restrict__ Bs, int wr, int wc,
+                                               int lane, f32x16 (&acc)[2][WTN]) {
+  const int l31 = lane & 31, kh = lane >> 5;
+  const float* ar = As + kh * LDA + wr * 64 + l31;
+  const float* br = Bs + kh * LDB + wc * (32 * WTN) + l31;
+  float a[2], b[WTN];
+  a[0] = ar[0]; a[1] = ar[32];
+#pragma unroll
+  for (int j = 0; j < WTN; ++j) b[j] = br[32 * j];
+#pragma unroll
+  for (int kk = 0; kk < BKT; kk += 2) {
+    float na[2] = {0.f, 0.f}, nb[WTN];
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) nb[j] = 0.f;
+    if (kk + 2 < BKT) {  // next k-step's fragments are in flight while this k-step's MFMAs issue
+      na[0] = ar[(kk + 2) * LDA];
+      na[1] = ar[(kk + 2) * LDA + 32];
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) nb[j] = br[(kk + 2) * LDB + 32 * j];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    a[0] = na[0]; a[1] = na[1];
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) b[j] = nb[j];
+  }
+}
+
+// ---- operand staging -----------------------------------------------------------------------
+// "row-major" operand (A of NN): global [tile rows][k], 16 k per K step -> transposed into LDS [k][row].
+// thread t: k quad = t % 4, rows (t / 4) + 64 * j
+template <int BMT, int BKT>
+struct RowFrag {
+  float v[BMT * BKT / 1024][4];
+};
+template <bool ALIGNED, int BMT, int BKT>
+__device__ __forceinline__ void load_rowmajor(RowFrag<BMT, BKT>& f, const float* __restrict__ A, int64_t lda, int64_t m0, int64_t M,
+                                              int k0, int K, int t) {
+  constexpr int TPR = BKT / 4, RPP = 256 / TPR;   // threads per row (one float4 each), rows per pass
+  const int k = k0 + (t % TPR) * 4;
+#pragma unroll
+  for (int j = 0; j < BMT / RPP; ++j) {
+    const int64_t m = m0 + t / TPR + RPP * j;
+    if (ALIGNED && m < M && k + 4 <= K) {
+      const float4 x = *reinterpret_cast<const float4*>(A + m * lda + k);
+      f.v[j][0] = x.x; f.v[j][1] = x.y; f.v[j][2] = x.z; f.v[j][3] = x.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f.v[j][i] = (m < M && k + i < K) ? A[m * lda + k + i] : 0.f;
+    }
+  }
+}
+template <int BMT, int BKT>
+__device__ __forceinline__ void store_rowmajor_T(const RowFrag<BMT, BKT>& f, float* __restrict__ S, int t) {
+  constexpr int TPR = BKT / 4, RPP = 256 / TPR;
+  const int kq = (t % TPR) * 4;
+#pragma unroll
+  for (int j = 0; j < BMT / RPP; ++j) {
+    const int m = t / TPR + RPP * j;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) S[(kq + i) * (BMT + 4) + m] = f.v[j][i];
+  }
+}
+
+// "k-major" operand: global [k][n] with n contiguous (B of NN; both operands of TN): straight copy.
+// thread t: n quad = t % (BNT/4), k = t / (BNT/4) + (1024/BNT) * j
+template <int BNT, int BKT>
+struct KFrag {
+  float4 v[BNT * BKT / 1024];
+};
+template <bool ALIGNED, int BNT, int BKT>
+__device__ __forceinline__ void load_kmajor(KFrag<BNT, BKT>& f, const float* __restrict__ B, int64_t ldb, int64_t k0, int64_t Kdim,
+                                            int n0, int N, int t, const float* __restrict__ kscale) {
+  constexpr int TPR = BNT / 4, RPP = 256 / TPR;   // threads per row, rows per pass
+  const int n = n0 + (t % TPR) * 4;
+#pragma unroll
+  for (int j = 0; j < BKT / RPP; ++j) {
+    const int64_t k = k0 + t / TPR + RPP * j;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < Kdim) {
+      if (ALIGNED && n + 4 <= N) {
+        x = *reinterpret_cast<const float4*>(B + k * ldb + n);
+      } else {
+        if (n + 0 < N) x.x = B[k * ldb + n + 0];
+        if (n + 1 < N) x.y = B[k * ldb + n + 1];
+        if (n + 2 < N) x.z = B[k * ldb + n + 2];
+        if (n + 3 < N) x.w = B[k * ldb + n + 3];
+      }
+      if (kscale) {
+        const float s = kscale[k];
+        x.x *= s; x.y *= s; x.z *= s; x.w *= s;
+      }
+    }
+    f.v[j] = x;
+  }
+}
+template <int BNT, int BKT>
+__device__ __forceinline__ void store_kmajor(const KFrag<BNT, BKT>& f, float* __restrict__ S, int t) {
+  constexpr int TPR = BNT / 4, RPP = 256 / TPR;
+#pragma unroll
+  for (int j = 0; j < BKT / RPP; ++j)
+    *reinterpret_cast<float4*>(S + (t / TPR + RPP * j) * (BNT + 4) + (t % TPR) * 4) = f.v[j];
+}
+
+template <int WTN>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][WTN]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+}
+
+}  // namespace cb

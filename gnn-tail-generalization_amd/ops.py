@@ -290,3 +290,30 @@ def label_propagation(graph, y0, deg_inv_sqrt, alpha, num_propagations):
         prop = graph.spmm(h, row_scale=a_dis)                                        # alpha * D^-1/2 A (.)
         result = _axpby_raw(1.0, prop, 1.0 - float(alpha), y0).clamp_(0, 1)
     return result
+
+
+def se_topk_replace(le_guess, teacher_se, k, return_selection=False):
+    """`SEMLP.replacement` (MLP_model/__init__.py:143-156) for all rows of `le_guess` at once: softmax-weighted mix of the K
+    teacher structural embeddings with the largest inner product.  No gradient (the reference detaches both sides)."""
+    lib = _lib.load()
+    _lib.require_device(le_guess, teacher_se)
+    q = le_guess.detach().float()
+    t = teacher_se.detach().float()
+    if q.stride(1) != 1:
+        q = q.contiguous()
+    if t.stride(1) != 1:
+        t = t.contiguous()
+    B, D = q.shape
+    N = t.shape[0]
+    if t.shape[1] != D:
+        raise ValueError(f'embedding widths differ: {tuple(q.shape)} vs {tuple(t.shape)}')
+    out = torch.empty((B, D), dtype=torch.float32, device=q.device)
+    idx = torch.empty((B, k), dtype=torch.int32, device=q.device) if return_selection else None
+    wgt = torch.empty((B, k), dtype=torch.float32, device=q.device) if return_selection else None
+    wsb = lib.cb_topk_replace_workspace_bytes(B, N, k)
+    ws = _ws(wsb, q.device)
+    with torch.cuda.device(q.device):
+        _lib.check(lib.cb_topk_replace_f32(_lib.ptr(q), q.stride(0) if B > 1 else D, _lib.ptr(t), t.stride(0) if N > 1 else D, B, N, D,
+                                           int(k), _lib.ptr(out), _lib.ptr(idx), _lib.ptr(wgt), _lib.ptr(ws), wsb, _lib.stream_ptr()),
+                   'cb_topk_replace_f32')
+    return (out, idx, wgt) if return_selection else out

@@ -232,6 +232,19 @@ int cb_col_affine_f32(const float* x, const float* shift, const float* scale, co
 int cb_col_bwd_combine_f32(const float* g, const float* xh, const float* a, const float* b, const float* e, float ga, float gb,
                            float* dx, int64_t rows, int64_t d, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Teacher -> student hand-off: `SEMLP.replacement` (MLP_model/__init__.py:143-156), a per-node
+ * Python loop of [1,N] matmuls + argsort in the reference.  For every query row q_i [D]:
+ *     s_j = <q_i, t_j> over the N teacher rows;  sel = the K largest (ties: larger index);
+ *     out_i = sum_k softmax(s_sel)_k * t_sel_k          (contiguous out [B, D])
+ * One fp32-MFMA sweep with a running top-K in LDS (the B x N score matrix is never written) + a merge kernel.
+ * out_idx [B,K] / out_w [B,K] (nullable) receive the selection and the softmax weights in ascending score order
+ * (the order of `sortidx[-K:]`).  1 <= K <= 8.  ws: cb_topk_replace_workspace_bytes(B, N, K).
+ * ---------------------------------------------------------------------------------- */
+size_t cb_topk_replace_workspace_bytes(int64_t B, int64_t N, int64_t K);
+int cb_topk_replace_f32(const float* q, int64_t ldq, const float* t, int64_t ldt, int64_t B, int64_t N, int64_t D, int32_t K,
+                        float* out, int32_t* out_idx, float* out_w, void* ws, size_t ws_bytes, void* stream);
+
 /* out[i, :] = src[idx[i], :] (contiguous out [n_idx, d]) — packs the rows a peer asked for before the
  * all-to-all of the node-sharded halo exchange (new; the reference is single-device). */
 int cb_gather_rows_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, float* out, void* stream);

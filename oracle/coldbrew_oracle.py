@@ -430,3 +430,21 @@ def label_propagation(edge_index, y, train_mask, num_classes, alpha=0.5, num_pro
         prop = aggregate_sum(csr, result * dis.unsqueeze(1)) * dis.unsqueeze(1)    # DAD @ result
         result = torch.clamp(alpha * prop + (1 - alpha) * y0, 0, 1)
     return result, dis
+
+
+# --------------------------------------------------------------------------------------
+# Teacher -> student hand-off: SEMLP.replacement, MLP_model/__init__.py:143-156
+# --------------------------------------------------------------------------------------
+def semlp_replacement(le_guess, teacher_se, k):
+    """Per query: scores against all teacher rows (:150), the K largest by ascending argsort()[-K:] (:151-152), softmax over
+    them (:153), weighted sum of the selected teacher rows (:154).  Returns (out [B,D], select [B,K] ascending, weights)."""
+    outs, sels, wts = [], [], []
+    t_T = teacher_se.transpose(0, 1)
+    for i in range(le_guess.shape[0]):
+        attn = torch.matmul(le_guess[[i]], t_T)
+        select = attn.argsort()[0][-k:]
+        w = F.softmax(attn[:, select], dim=1)
+        outs.append(torch.matmul(w, teacher_se[select]))
+        sels.append(select)
+        wts.append(w[0])
+    return torch.cat(outs, dim=0), torch.stack(sels), torch.stack(wts)

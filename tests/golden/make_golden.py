@@ -339,6 +339,22 @@ def lp_fixture(ns):
                 alpha=0.5, num_propagations=50, num_classes=c)
 
 
+def semlp_fixture(ns):
+    """§8f row 2 — the unmodified SEMLP.replacement (MLP_model/__init__.py:143-156) on seeded embeddings."""
+    with ref_import.in_scratch():
+        import MLP_model
+    out = {}
+    for name, (b, n, d, k) in {'small': (40, 150, 24, 2), 'wide': (33, 300, 71, 3)}.items():
+        g = torch.Generator().manual_seed(b + n)
+        obj = MLP_model.SEMLP.__new__(MLP_model.SEMLP)
+        torch.nn.Module.__init__(obj)
+        obj.teacherSE = torch.randn(n, d, generator=g)
+        obj.topK_2_replace = k
+        q = torch.randn(b, d, generator=g)
+        out[name] = dict(q=q, teacher=obj.teacherSE.clone(), k=k, out=obj.replacement(q).clone())
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='')
@@ -346,7 +362,7 @@ def main():
     ns = ref_import.load_reference()
     torch.set_num_threads(1)
     for c in CASES:
-        if a.only and (a.only in ('utils', 'options', 'trainer', 'lp') or a.only not in c['name']):
+        if a.only and (a.only in ('utils', 'options', 'trainer', 'lp', 'semlp') or a.only not in c['name']):
             continue
         out = run_case(ns, c)
         torch.save(out, os.path.join(HERE, f'case_{c["name"]}.pt'))
@@ -361,6 +377,9 @@ def main():
     if not a.only or 'utils' in a.only:
         torch.save(utils_fixture(ns), os.path.join(HERE, 'utils_fixture.pt'))
         print('wrote utils_fixture.pt')
+    if not a.only or 'semlp' in a.only:
+        torch.save(semlp_fixture(ns), os.path.join(HERE, 'semlp_fixture.pt'))
+        print('wrote semlp_fixture.pt')
     if not a.only or 'lp' in a.only:
         torch.save(lp_fixture(ns), os.path.join(HERE, 'lp_fixture.pt'))
         print('wrote lp_fixture.pt')

@@ -202,3 +202,22 @@ def test_bf16_storage_kernels():
             want = orc.aggregate_sum_dense_f64(csr, h16.double())
             got = G.spmm(h16.to(DEV))
             torch.testing.assert_close(got.cpu().double(), want, atol=1e-4, rtol=1e-5)
+
+
+def test_se_topk_replace_matches_reference_and_oracle():
+    """§8f row 2: fused scores + running top-K + softmax-combine (cb_topk_replace_f32) vs the reference fixture and,
+    on larger ragged shapes, vs the oracle's per-node restatement."""
+    from gnn_tail_generalization_amd import ops
+    from conftest import load_golden
+    fx = load_golden('semlp_fixture')
+    for name, g in fx.items():
+        out = ops.se_topk_replace(g['q'].to(DEV), g['teacher'].to(DEV), g['k'])
+        torch.testing.assert_close(out.cpu(), g['out'], atol=2e-5, rtol=2e-5, msg=lambda m, name=name: f'{name}: {m}')
+    for b, n, d, k, seed in [(1, 5, 3, 1, 0), (130, 1000, 71, 2, 1), (257, 3333, 256, 3, 2), (64, 129, 768, 8, 3), (500, 128, 16, 4, 4)]:
+        gen = torch.Generator().manual_seed(seed)
+        q, t = torch.randn(b, d, generator=gen), torch.randn(n, d, generator=gen)
+        want, sel, w = orc.semlp_replacement(q, t, k)
+        out, idx, wgt = ops.se_topk_replace(q.to(DEV), t.to(DEV), k, return_selection=True)
+        assert torch.equal(idx.cpu().to(torch.int64), sel), (b, n, d, k)
+        torch.testing.assert_close(wgt.cpu(), w, atol=1e-5, rtol=1e-4)
+        torch.testing.assert_close(out.cpu(), want, atol=1e-4, rtol=1e-4)

@@ -103,3 +103,12 @@ def test_oracle_label_propagation_matches_reference():
     torch.testing.assert_close(out, g['out'], atol=1e-5, rtol=1e-5)
     acc = [np.round(orc.evaluate(out, g['y'], m) * 100, 2) for m in (g['train_mask'], ~g['train_mask'])]
     assert acc == g['acc'].tolist()
+
+
+def test_oracle_semlp_replacement_matches_reference():
+    """§8f row 2: the SEMLP top-K "virtual neighbour" lookup against the unmodified reference method."""
+    fx = load_golden('semlp_fixture')
+    for name, g in fx.items():
+        out, sel, w = orc.semlp_replacement(g['q'], g['teacher'], g['k'])
+        torch.testing.assert_close(out, g['out'], atol=1e-6, rtol=1e-6, msg=lambda m, name=name: f'{name}: {m}')
+        assert sel.shape == (g['q'].shape[0], g['k'])
