@@ -24,6 +24,7 @@
 
 #include "cb_common.h"
 #include "cb_gemm_core.h"
+#include "cb_gemm_limb.h"
 
 namespace cb {
 
@@ -32,7 +33,6 @@ template <int WM, int WN, bool ALIGNED, bool OUT_BF16, int BKT = BK, int WTN = 2
 __global__ void __launch_bounds__(256) k_gemm_nn(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
                                                  void* __restrict__ Cv, int64_t ldc, int64_t M, int N, int K, GemmEpilogue ep,
                                                  int n_row_blocks, int n_col_blocks, int c_vec_ok) {
-  float* C = (float*)Cv;
   using T = Tile<WM, WN, BKT, WTN>;
   constexpr int BM = T::BM, BN = T::BN, LDA = T::LDA, LDB = T::LDB;
   __shared__ __attribute__((aligned(16))) float smem[T::SMEM_FLOATS];
@@ -72,75 +72,7 @@ __global__ void __launch_bounds__(256) k_gemm_nn(const float* __restrict__ A, in
     __syncthreads();
   }
 
-  // ---- epilogue through LDS: 32 rows x BN per pass -------------------------------------------
-  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-  float* Cs = smem;                       // [32][LDB]
-  const int l31 = lane & 31, lh = lane >> 5;
-  constexpr int TPR = BN / 4;             // threads per staged row
-  constexpr int NV = 32 * TPR / 256;      // float4 per thread per pass
-#pragma unroll
-  for (int pass = 0; pass < 2 * WM; ++pass) {
-    const int wr_sel = pass >> 1, ti = pass & 1;
-    if (wr == wr_sel) {
-#pragma unroll
-      for (int tj = 0; tj < WTN; ++tj)
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-          Cs[((reg & 3) + 8 * (reg >> 2) + 4 * lh) * LDB + wc * (32 * WTN) + tj * 32 + l31] = acc[ti][tj][reg];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = t + 256 * i;
-      const int row = idx / TPR, c4 = (idx % TPR) * 4;
-      const int64_t m = m0 + wr_sel * 64 + ti * 32 + row;
-      const int n = n0 + c4;
-      if (m < M && n < N) {
-        const float4 v = *reinterpret_cast<const float4*>(Cs + row * LDB + c4);
-        float o[4] = {v.x, v.y, v.z, v.w};
-        const float rs = ep.rowscale ? ep.rowscale[m] : 1.f;
-        const bool full4 = n + 4 <= N;
-        float ad[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (ep.addend) {
-          const float* ap = ep.addend + m * ep.ld_add + n;
-          if (full4 && c_vec_ok) {
-            const float4 a4 = *reinterpret_cast<const float4*>(ap);
-            ad[0] = a4.x; ad[1] = a4.y; ad[2] = a4.z; ad[3] = a4.w;
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (n + q < N) ad[q] = ap[q];
-          }
-        }
-        if (ep.bias) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) if (n + q < N) bv[q] = ep.bias[n + q];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          o[q] = o[q] * rs + ad[q] + bv[q];
-          if (ep.relu) o[q] = fmaxf(o[q], 0.f);
-        }
-        if constexpr (OUT_BF16) {   // Z stored as bf16 for the aggregation (build extension, fp32 accumulate downstream)
-          bf16_t* cp = (bf16_t*)Cv + m * ldc + n;
-          if (full4 && c_vec_ok) {
-            *reinterpret_cast<uint2*>(cp) = pack4_bf16(o[0], o[1], o[2], o[3]);
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (n + q < N) cp[q] = f32_to_bf16(o[q]);
-          }
-        } else {
-          float* cp = C + m * ldc + n;
-          if (full4 && c_vec_ok) {
-            *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (n + q < N) cp[q] = o[q];
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
+  nn_epilogue<WM, WN, WTN, OUT_BF16>(acc, smem, Cv, ldc, m0, n0, M, N, ep, c_vec_ok, t);
 }
 
 // ---- TN ------------------------------------------------------------------------------------
@@ -221,6 +153,13 @@ static inline int tn_splits(int64_t M, int tiles) {
 
 static inline bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
+// CB_GEMM_PLAIN_F32=1 keeps every contraction on the fp32-input MFMA (v_mfma_f32_32x32x2_f32) instead of the
+// three-limb bf16 path of cb_gemm_limb.hip
+static inline bool use_limb3() {
+  static const bool on = getenv("CB_GEMM_PLAIN_F32") == nullptr;
+  return on;
+}
+
 // tile shape by output width: 2x2 (128x128) by default; for TN 1x4 (64x256) when K1 <= 64, 4x1 (256x64) when K2 <= 64
 static inline void tn_tile(int64_t K1, int64_t K2, int& bm, int& bn) {
   if (K1 <= 64 && K2 > 64) { bm = 64; bn = 256; }
@@ -255,9 +194,17 @@ static int launch_tn(const float* A, int64_t lda, const float* G, int64_t ldg, c
   const int tiles_i = (int)((K1 + T::BM - 1) / T::BM), tiles_j = (int)((K2 + T::BN - 1) / T::BN);
   const int nsplit = tn_splits(M, tiles_i * tiles_j);
   int64_t rows_per_split = (M + nsplit - 1) / nsplit;
-  rows_per_split = (rows_per_split + BK - 1) / BK * BK;
+  rows_per_split = (rows_per_split + 31) / 32 * 32;   // whole K steps of either kernel family
   const bool aligned = al16(A) && al16(G) && lda % 4 == 0 && ldg % 4 == 0;
   const dim3 grid((unsigned)(tiles_i * tiles_j), (unsigned)nsplit);
+  if (use_limb3() && limb3_tn_eligible(A, lda, G, ldg, K1, K2)) {
+    const int rc = launch_tn_limb3(A, lda, G, ldg, rowscale, ws, M, K1, K2, T::BM, nsplit, rows_per_split, st);
+    if (rc != CB_OK) return rc;
+    const int64_t n = K1 * K2;
+    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsplit, n, C);
+    CB_LAUNCH_CHECK();
+    return CB_OK;
+  }
   // Measurement hook: extra (unused) dynamic LDS caps the blocks per CU, leaving registers for a concurrently running
   // HBM-bound kernel on another stream (see tools/overlap_probe.py).
   static const int pad_lds = getenv("CB_GEMM_TN_PADLDS") ? atoi(getenv("CB_GEMM_TN_PADLDS")) : 0;
@@ -288,6 +235,7 @@ extern "C" int cb_gemm_nn_f32(const float* A, int64_t lda, const float* B, int64
                "cb_gemm_nn_f32: null pointer or leading dimension too small");
   GemmEpilogue ep{rowscale, addend, ld_add, bias, relu};
   hipStream_t st = (hipStream_t)stream;
+  if (use_limb3() && limb3_nn_eligible(A, lda, B, ldb, N, K)) return launch_nn_limb3(A, lda, B, ldb, C, ldc, M, N, K, ep, false, st);
   if (N <= 64) return launch_nn<4, 1>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
   static const int wide = getenv("CB_GEMM_WIDE") != nullptr;   // measurement hook: 128x256 block tile (wave tile 64x128)
   if (wide && N > 128) return launch_nn<2, 2, false, 4>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
@@ -304,6 +252,7 @@ extern "C" int cb_gemm_nn_bf16out_f32(const float* A, int64_t lda, const float* 
                "cb_gemm_nn_bf16out_f32: null pointer or leading dimension too small");
   GemmEpilogue ep{rowscale, addend, ld_add, bias, relu};
   hipStream_t st = (hipStream_t)stream;
+  if (use_limb3() && limb3_nn_eligible(A, lda, B, ldb, N, K)) return launch_nn_limb3(A, lda, B, ldb, C, ldc, M, N, K, ep, true, st);
   if (N <= 64) return launch_nn<4, 1, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
   return launch_nn<2, 2, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
 }

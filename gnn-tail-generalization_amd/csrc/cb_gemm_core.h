@@ -142,4 +142,83 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][WTN]) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 }
 
+// ---- NN epilogue through LDS: 32 rows x BN per pass -------------------------------------------
+// C/D layout of the 32x32 MFMA (any input dtype): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+// The accumulators are transposed through LDS so that every lane handles 4 consecutive columns of one row: row scale /
+// addend / bias / relu are applied on float4 values and the tile leaves as coalesced 16-byte stores (8-byte for bf16 output).
+// `Cs` must hold 32 x (BN + 4) floats and must no longer be read as operand storage by any wavefront of the block.
+template <int WM, int WN, int WTN, bool OUT_BF16>
+__device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __restrict__ Cs, void* __restrict__ Cv, int64_t ldc,
+                                            int64_t m0, int n0, int64_t M, int N, const GemmEpilogue& ep, int c_vec_ok, int t) {
+  constexpr int BN = 32 * WTN * WN, LDB = BN + 4;
+  float* C = (float*)Cv;
+  const int lane = t & 63, w = t >> 6, wr = w / WN, wc = w % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  constexpr int TPR = BN / 4;             // threads per staged row
+  constexpr int NV = 32 * TPR / 256;      // float4 per thread per pass
+#pragma unroll
+  for (int pass = 0; pass < 2 * WM; ++pass) {
+    const int wr_sel = pass >> 1, ti = pass & 1;
+    if (wr == wr_sel) {
+#pragma unroll
+      for (int tj = 0; tj < WTN; ++tj)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          Cs[((reg & 3) + 8 * (reg >> 2) + 4 * lh) * LDB + wc * (32 * WTN) + tj * 32 + l31] = acc[ti][tj][reg];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = t + 256 * i;
+      const int row = idx / TPR, c4 = (idx % TPR) * 4;
+      const int64_t m = m0 + wr_sel * 64 + ti * 32 + row;
+      const int n = n0 + c4;
+      if (m < M && n < N) {
+        const float4 v = *reinterpret_cast<const float4*>(Cs + row * LDB + c4);
+        float o[4] = {v.x, v.y, v.z, v.w};
+        const float rs = ep.rowscale ? ep.rowscale[m] : 1.f;
+        const bool full4 = n + 4 <= N;
+        float ad[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ep.addend) {
+          const float* ap = ep.addend + m * ep.ld_add + n;
+          if (full4 && c_vec_ok) {
+            const float4 a4 = *reinterpret_cast<const float4*>(ap);
+            ad[0] = a4.x; ad[1] = a4.y; ad[2] = a4.z; ad[3] = a4.w;
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (n + q < N) ad[q] = ap[q];
+          }
+        }
+        if (ep.bias) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (n + q < N) bv[q] = ep.bias[n + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          o[q] = o[q] * rs + ad[q] + bv[q];
+          if (ep.relu) o[q] = fmaxf(o[q], 0.f);
+        }
+        if constexpr (OUT_BF16) {   // Z stored as bf16 for the aggregation (build extension, fp32 accumulate downstream)
+          bf16_t* cp = (bf16_t*)Cv + m * ldc + n;
+          if (full4 && c_vec_ok) {
+            *reinterpret_cast<uint2*>(cp) = pack4_bf16(o[0], o[1], o[2], o[3]);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (n + q < N) cp[q] = f32_to_bf16(o[q]);
+          }
+        } else {
+          float* cp = C + m * ldc + n;
+          if (full4 && c_vec_ok) {
+            *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (n + q < N) cp[q] = o[q];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace cb
