@@ -1,0 +1,158 @@
+"""Builds measurement-only variants of libcoldbrew_hip.so (tools/probes/_bin/lib_<name>.so) in which one cost of the
+three-limb GEMM is removed (results become wrong on purpose), to see what the kernels are sensitive to.
+  nosplit : the limb split is replaced by a plain repack (VALU work of the split removed)
+  mfma3   : only three of the six limb products are issued
+  nostore : the NN epilogue's global stores are skipped
+usage: python tools/probes/limb_variants.py build | python tools/probes/limb_variants.py run <name|base> [M]"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+CSRC = os.path.join(ROOT, 'gnn-tail-generalization_amd', 'csrc')
+BIN = os.path.join(ROOT, 'tools', 'probes', '_bin')
+
+VARIANTS = {
+    'nosplit': [('cb_gemm_limb.hip', '''  hi = __float_as_uint(a) & 0xffff0000u;
+  const float r1 = a - __uint_as_float(hi);
+  mid = __float_as_uint(r1) & 0xffff0000u;
+  lo = __float_as_uint(r1 - __uint_as_float(mid));''', '''  hi = __float_as_uint(a);
+  mid = hi;
+  lo = hi;''')],
+    'mfma3': [('cb_gemm_limb.hip', '''    CB_MFMA4(a_mid, b_mid, 6 * S_ + 2)                                                                                       \\
+    CB_MFMA4(a_mid, b_hi, 6 * S_ + 3)                                                                                        \\
+    CB_MFMA4(a_hi, b_mid, 6 * S_ + 4)                                                                                        \\
+    CB_MFMA4(a_hi, b_hi, 6 * S_ + 5)                                                                                         \\''', '''    CB_MFMA4(a_mid, b_mid, 6 * S_ + 2)                                                                                       \\
+    pf.template group<6 * S_ + 3>(); pf.template group<6 * S_ + 4>(); pf.template group<6 * S_ + 5>(); \\''')],
+    'timing': [('cb_gemm_limb.hip', '''  for (int64_t kt = 0; kt < nk; ++kt) {
+    const int64_t row = r_begin + kt * KS;
+    oa.stage(fa, As, r_end - row, t);
+    ob.stage(fb, Bs, r_end - row, t);
+    __syncthreads();
+    const int64_t nrow = row + KS;
+    const Prefetch<OA, OB> pf{oa, ob, fa, fb, a_col + nrow * lda, g_col + nrow * ldg, SCALED ? rowscale + nrow : nullptr, lda, ldg,
+                              r_end - nrow, t};
+    limb_tile_step<OA, OB>(As, Bs, aaddr, baddr, acc, pf);
+    __syncthreads();
+  }''', '''  uint64_t ts[4][6];
+#define STAMP(I) if (rec) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ts[kt - 8][I] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+  for (int64_t kt = 0; kt < nk; ++kt) {
+    const bool rec = kt >= 8 && kt < 12;
+    const int64_t row = r_begin + kt * KS;
+    STAMP(0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(1)
+    oa.stage(fa, As, r_end - row, t);
+    ob.stage(fb, Bs, r_end - row, t);
+    STAMP(2)
+    __syncthreads();
+    STAMP(3)
+    const int64_t nrow = row + KS;
+    const Prefetch<OA, OB> pf{oa, ob, fa, fb, a_col + nrow * lda, g_col + nrow * ldg, SCALED ? rowscale + nrow : nullptr, lda, ldg,
+                              r_end - nrow, t};
+    limb_tile_step<OA, OB>(As, Bs, aaddr, baddr, acc, pf);
+    STAMP(4)
+    __syncthreads();
+    STAMP(5)
+  }
+  const bool probe = (split == 165 && tile == 0 && w == 1);'''),
+        ('cb_gemm_limb.hip', '''        if (m < K1) P[(int64_t)m * K2 + n] = acc[ti][tj][reg];
+      }
+    }
+}''', '''        if (m < K1) P[(int64_t)m * K2 + n] = acc[ti][tj][reg];
+      }
+    }
+  __syncthreads();
+  if (probe && lane == 0) {
+    for (int a = 0; a < 4; ++a)
+      for (int c = 0; c < 6; ++c) P[a * 6 + c] = (float)(ts[a][c] - ts[0][0]);
+  }
+}''')],
+    'nostore': [('cb_gemm_core.h', '''      if (m < M && n < N) {
+        const float4 v = *reinterpret_cast<const float4*>(Cs + row * LDB + c4);''', '''      if (m < M && n < N && ep.relu == 77) {
+        const float4 v = *reinterpret_cast<const float4*>(Cs + row * LDB + c4);''')],
+}
+
+
+def build():
+    os.makedirs(BIN, exist_ok=True)
+    objs = [os.path.join(CSRC, '..', '_build', f) for f in os.listdir(os.path.join(CSRC, '..', '_build'))
+            if f.endswith('.o') and f not in ('cb_gemm_limb.o', 'cb_gemm.o')]
+    for name, edits in VARIANTS.items():
+        tmp = os.path.join(BIN, 'src_' + name)
+        os.makedirs(tmp, exist_ok=True)
+        for f in os.listdir(CSRC):
+            if f.endswith(('.h', '.hip')):
+                s = open(os.path.join(CSRC, f)).read()
+                for ef, old, new in edits:
+                    if ef == f:
+                        assert old in s, (name, f)
+                        s = s.replace(old, new)
+                open(os.path.join(tmp, f), 'w').write(s)
+        outs = []
+        for f in ('cb_gemm_limb.hip', 'cb_gemm.hip'):
+            o = os.path.join(tmp, f[:-4] + '.o')
+            subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'),
+                                   '-I' + os.path.join(ROOT, 'gnn-tail-generalization_amd', 'csrc'), '-c', os.path.join(tmp, f), '-o', o])
+            outs.append(o)
+        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', os.path.join(BIN, f'lib_{name}.so')] + objs + outs)
+        print('built', name)
+
+
+def run(name, M):
+    sys.path.insert(0, ROOT)
+    import torch
+    from gnn_tail_generalization_amd import _lib, gemm
+    if name != 'base':
+        _lib.LIB_PATH = os.path.join(BIN, f'lib_{name}.so')
+    dev = 'cuda:0'
+    a = torch.rand(M, 256, device=dev) - 0.5
+    b = torch.rand(256, 256, device=dev) - 0.5
+    g = torch.rand(M, 256, device=dev) - 0.5
+    rs = torch.rand(M, device=dev)
+
+    def timeit(fn, iters=5):
+        fn()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+        ev[0].record()
+        for i in range(iters):
+            fn()
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        return min(ev[i].elapsed_time(ev[i + 1]) for i in range(iters))
+    print(f'{name:8s} NN {timeit(lambda: gemm.mm_nn(a, b, rowscale=rs)):7.3f} ms   TN {timeit(lambda: gemm.mm_tn(a, g, rowscale=rs)):7.3f} ms', flush=True)
+
+
+def timing(M):
+    """prints the s_memtime stamps of one wavefront over four consecutive K steps of k_gemm_tn_l3 (variant 'timing')"""
+    sys.path.insert(0, ROOT)
+    import torch
+    from gnn_tail_generalization_amd import _lib
+    _lib.LIB_PATH = os.path.join(BIN, 'lib_timing.so')
+    lib = _lib.load()
+    dev = 'cuda:0'
+    a = torch.rand(M, 256, device=dev) - 0.5
+    g = torch.rand(M, 256, device=dev) - 0.5
+    rs = torch.rand(M, device=dev)
+    out = torch.empty(256, 256, device=dev)
+    wsb = lib.cb_gemm_tn_workspace_bytes(M, 256, 256)
+    ws = torch.zeros(wsb // 4, dtype=torch.float32, device=dev)
+    for _ in range(2):
+        _lib.check(lib.cb_gemm_tn_f32(_lib.ptr(a), 256, _lib.ptr(g), 256, _lib.ptr(rs), _lib.ptr(out), M, 256, 256, _lib.ptr(ws), wsb,
+                                      _lib.stream_ptr()), 'tn')
+    torch.cuda.synchronize()
+    t = ws[165 * 65536: 165 * 65536 + 24].cpu().view(4, 6)
+    print('nsplit', wsb // 4 // 65536)
+    print('stamps (cycles from K-step 8 start): top, loads landed, staged, barrier1, mfma(+loads issued) done, barrier2')
+    for r in t.tolist():
+        print('  '.join(f'{int(x):7d}' for x in r), '  | vmwait %d  stage %d  bar1 %d  mfma %d  bar2 %d' % (r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4]))
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'timing':
+        timing(int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000)
+    elif sys.argv[1] == 'build':
+        build()
+    else:
+        run(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 10_000_000)
