@@ -15,19 +15,23 @@
 // Bound: at K = N = 256 and M = 10^7 the six-pass MFMA time (~3.6 ms at 2.1 GHz) is next to the HBM time of streaming
 // A in and C out once (20.5 GB, ~3.2 ms), so the kernel sits on the ridge; the fp32-MFMA kernel is 10 ms on the same shape.
 //
-// Tiling: 256 threads = 4 wavefronts WM x WN, wave tile 64 x 64 = 2x2 MFMA tiles, K step 32 (= two MFMA k-steps, 48 MFMAs
+// Tiling: 256 threads = 4 wavefronts WM x WN, wave tile 64 x 64 = 2x2 MFMA tiles, K step 16 (= one MFMA k-step, 24 MFMAs
 // per wavefront between barriers).  Every operand is fetched with coalesced float4 loads in its natural row-major
 // orientation, split into limbs in registers and written as three bf16 planes into LDS, again in its natural orientation:
-//   * "row" operand (A of NN, k contiguous in memory): plane [tile row][32 k], 64 B per row; a fragment (8 consecutive k
-//     of one row) is one ds_read_b128; the four 16-byte slots of a row are XOR-swizzled with (row >> 2) & 3;
-//   * "col" operand (B of NN, both operands of TN: k runs down the rows): plane [32 k][tile cols]; a fragment (8
+//   * "row" operand (A of NN, k contiguous in memory): plane [tile row][16 k], 32 B per row; a fragment (8 consecutive k
+//     of one row) is one ds_read_b128; the two 16-byte slots of a row are swapped when (row >> 3) & 1;
+//   * "col" operand (B of NN, both operands of TN: k runs down the rows): plane [16 k][tile cols]; a fragment (8
 //     consecutive k of one column) is gathered by two ds_read_b64_tr_b16 — the gfx950 LDS transpose read hands lane L of
 //     each 16-lane group column L of a 4 x 16 block whose rows the group's lanes address — so no transposition ever
 //     happens in registers or in the global access pattern; the 64-byte (32-column) chunks of a row are XOR-swizzled
 //     with k & 3 so that the four rows of one transpose read sit on disjoint banks.
-// One LDS stage (48 KB for 128 x 128 tiles, three blocks per CU); the next K step's global loads are in flight in registers
-// during the MFMAs.  Addressing inside the K loop: a wave-uniform base pointer (scalar registers) per K step plus lane
-// offsets that never change.
+// Software pipeline inside every wavefront (two LDS stages of 24 KB for 128 x 128 tiles, three blocks per CU, one barrier
+// per K step): while the MFMAs of K step k read stage k & 1, the same instruction stream splits the registers that hold
+// step k+1 and writes them to the other stage, and re-fills those registers with the global loads of step k+2 — one
+// slice of that work after every group of four MFMAs.  The matrix core, the vector ALU (the split), the LDS and the
+// memory pipeline are therefore all busy at any instant instead of taking turns (thread blocks that share a CU fall
+// into lock step, so phases that use only one of these units are not hidden by the neighbours).
+// Addressing inside the K loop: a wave-uniform base pointer (scalar registers) per K step plus lane offsets that never change.
 #include <stdlib.h>
 
 #include <utility>
@@ -62,103 +66,99 @@ __device__ __forceinline__ void split4(const float (&v)[4], uint2 (&pl)[3]) {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-constexpr int KS = 32;   // K step per barrier pair
+constexpr int KS = 16;   // K step
 
-// ---- "row" operand: global [rows][k] (k contiguous) -> LDS planes [R rows][32 k] -------------------
-// Loads are split into NV pieces (one float4 per lane each) so that the K loop can issue them between MFMA groups; a piece
-// only moves raw data into registers, masking of out-of-range elements happens when the registers are staged.
+// ---- "row" operand: global [rows][k] (k contiguous) -> LDS planes [R rows][16 k] -------------------
+// The K step's data moves in NV pieces (one float4 per lane each): load() only brings raw data into registers, stage()
+// masks out-of-range elements, splits and writes the three planes.
 template <int R>
 struct RowOperand {
-  static constexpr int PLANE = R * 64, BYTES = 3 * PLANE, NV = R / 32;   // float4 per thread per K step
-  uint32_t voff;      // element offset of this lane's first float4 from (tile row 0, k0): row (t/8), k quad (t%8)
-  uint32_t woff;      // LDS byte offset of its 8-byte store in plane 0 (swizzled), j-th store: + j * 32 * 64
-  uint32_t rmask;     // bit j: tile row t/8 + 32 j lies inside the matrix
+  static constexpr int PLANE = R * 32, BYTES = 3 * PLANE, NV = R / 64;   // float4 per thread per K step
+  static_assert(NV >= 1, "tile rows");
+  uint32_t voff;      // element offset of this lane's first float4 from (tile row 0, k0): row t/4, k quad t%4
+  uint32_t woff;      // LDS byte offset of its 8-byte store in plane 0; j-th store: + j * 64 * 32
+  uint32_t rmask;     // bit j: tile row t/4 + 64 j lies inside the matrix
   __device__ __forceinline__ void init(int64_t ld, int64_t rows_left, int t) {
-    const int row = t >> 3, kq = t & 7;
+    const int row = t >> 2, kq = t & 3;
     voff = (uint32_t)(row * ld + kq * 4);
-    woff = row * 64 + (((kq >> 1) ^ ((row >> 2) & 3)) << 4) + ((kq & 1) << 3);
+    woff = row * 32 + (((kq >> 1) ^ ((row >> 3) & 1)) << 4) + ((kq & 1) << 3);
     rmask = 0;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) rmask |= (row + 32 * j < rows_left) ? (1u << j) : 0u;
+    for (int j = 0; j < NV; ++j) rmask |= (row + 64 * j < rows_left) ? (1u << j) : 0u;
   }
-  // base = &A[tile row 0][k0] (uniform); k_left = K - k0 (FULL => k_left >= 32); K % 4 == 0
-  template <bool FULL, int J>
-  __device__ __forceinline__ void piece(float4 (&f)[NV], const float* __restrict__ base, int64_t ld, int64_t k_left, const float*,
-                                        int t) const {
-    const bool in = ((rmask >> J) & 1) && (FULL || (t & 7) * 4 < k_left);
-    f[J] = *reinterpret_cast<const float4*>((base + (int64_t)(32 * J) * ld) + (in ? voff : 0u));
+  // base = &A[tile row 0][k0] (uniform); k_left = K - k0 > 0; K % 4 == 0
+  template <int J>
+  __device__ __forceinline__ void load(float4 (&f)[NV], const float* __restrict__ base, int64_t ld, int64_t k_left, const float*,
+                                       int t) const {
+    const bool in = ((rmask >> J) & 1) && (t & 3) * 4 < k_left;
+    f[J] = *reinterpret_cast<const float4*>((base + (int64_t)(64 * J) * ld) + (in ? voff : 0u));
   }
+  template <int J>
   __device__ __forceinline__ void stage(const float4 (&f)[NV], char* __restrict__ S, int64_t k_left, int t) const {
-    const bool kin = (t & 7) * 4 < k_left;
+    const bool live = ((rmask >> J) & 1) && (t & 3) * 4 < k_left;
+    const float v[4] = {live ? f[J].x : 0.f, live ? f[J].y : 0.f, live ? f[J].z : 0.f, live ? f[J].w : 0.f};
+    uint2 pl[3];
+    split4(v, pl);
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const bool live = ((rmask >> j) & 1) && kin;
-      const float v[4] = {live ? f[j].x : 0.f, live ? f[j].y : 0.f, live ? f[j].z : 0.f, live ? f[j].w : 0.f};
-      uint2 pl[3];
-      split4(v, pl);
-#pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(S + p * PLANE + woff + j * (32 * 64)) = pl[p];
-    }
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(S + p * PLANE + woff + J * (64 * 32)) = pl[p];
   }
-  // fragment address (plane 0, k-substep 0) of tile rows r0 + (lane & 31); substep 1 = address ^ 32
+  // fragment address (plane 0) of tile rows r0 + (lane & 31), r0 % 32 == 0
   static __device__ __forceinline__ uint32_t frag_addr(int r0, int lane) {
     const int row = r0 + (lane & 31);
-    return row * 64 + (((lane >> 5) ^ ((row >> 2) & 3)) << 4);
+    return row * 32 + (((lane >> 5) ^ ((row >> 3) & 1)) << 4);
   }
-  static __device__ __forceinline__ bf16x8 frag(const char* __restrict__ S, uint32_t addr, int plane, int s) {
-    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(S + plane * PLANE + (addr ^ (s << 5))));
+  static __device__ __forceinline__ bf16x8 frag(const char* __restrict__ S, uint32_t addr, int plane) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(S + plane * PLANE + addr));
   }
 };
 
-// ---- "col" operand: global [k][cols] (cols contiguous) -> LDS planes [32 k][C cols] ------------------
+// ---- "col" operand: global [k][cols] (cols contiguous) -> LDS planes [16 k][C cols] ------------------
 template <int C, bool SCALED>
 struct ColOperand {
-  static constexpr int ROWB = C * 2, PLANE = 32 * ROWB, BYTES = 3 * PLANE;
-  static constexpr int TPR = C / 4, KPP = 256 / TPR, NV = 32 / KPP;   // threads per k row, k rows per pass, float4 per thread
+  static constexpr int ROWB = C * 2, PLANE = 16 * ROWB, BYTES = 3 * PLANE;
+  static constexpr int TPR = C / 4, KPP = 256 / TPR, NV = 16 / KPP;   // threads per k row, k rows per pass, float4 per thread
   static constexpr int NC = C / 32;                                    // 64-byte chunks per row
   static_assert(NC == 2 || NC == 4 || NC == 8, "tile widths 64 / 128 / 256");
   static __device__ __forceinline__ int swz(int k) { return NC == 2 ? ((k >> 1) & 1) : (k & 3); }
   uint32_t voff;      // element offset of this lane's first float4 from (step row 0, tile col 0): k = t / TPR, quad t % TPR
   uint32_t woff;      // LDS byte offset of its 8-byte store in plane 0; j-th store: + j * KPP * ROWB  (KPP % 4 == 0)
   bool cok;           // its 4 columns lie inside the matrix (N % 4 == 0)
-  float sc[SCALED ? NV : 1];   // raw per-row scales of the fetched step
+  static constexpr bool HAS_SC = SCALED;
+  float sc[SCALED ? NV : 1];   // raw per-row scales of the loaded step
   __device__ __forceinline__ void init(int64_t ld, int cols_left, int t) {
     const int k = t / TPR, nq = t % TPR;
     cok = nq * 4 < cols_left;
     voff = (uint32_t)(k * ld + (cok ? nq * 4 : 0));
     woff = k * ROWB + ((((nq >> 3) ^ swz(k)) & (NC - 1)) << 6) + ((nq & 7) << 3);
   }
-  // base = &B[step row 0][tile col 0] (uniform); k_left = operand rows from there (FULL => >= 32); kscale = their scales
-  template <bool FULL, int J>
-  __device__ __forceinline__ void piece(float4 (&f)[NV], const float* __restrict__ base, int64_t ld, int64_t k_left,
-                                        const float* __restrict__ kscale, int t) {
+  // base = &B[step row 0][tile col 0] (uniform); k_left = operand rows from there > 0; kscale = their scales
+  template <int J>
+  __device__ __forceinline__ void load(float4 (&f)[NV], const float* __restrict__ base, int64_t ld, int64_t k_left,
+                                       const float* __restrict__ kscale, int t) {
     const int k = t / TPR;
-    const bool kin = FULL || k + KPP * J < k_left;
+    const bool kin = k + KPP * J < k_left;
     f[J] = *reinterpret_cast<const float4*>((base + (int64_t)(KPP * J) * ld) + (kin ? voff : 0u));
     if constexpr (SCALED) sc[J] = (kscale + KPP * J)[kin ? k : 0];
   }
+  template <int J>
   __device__ __forceinline__ void stage(const float4 (&f)[NV], char* __restrict__ S, int64_t k_left, int t) const {
-    const int k = t / TPR;
+    const bool live = cok && t / TPR + KPP * J < k_left;
+    const float m = SCALED ? sc[J] : 1.f;
+    const float v[4] = {live ? f[J].x * m : 0.f, live ? f[J].y * m : 0.f, live ? f[J].z * m : 0.f, live ? f[J].w * m : 0.f};
+    uint2 pl[3];
+    split4(v, pl);
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const bool live = cok && k + KPP * j < k_left;
-      const float m = SCALED ? sc[j] : 1.f;
-      const float v[4] = {live ? f[j].x * m : 0.f, live ? f[j].y * m : 0.f, live ? f[j].z * m : 0.f, live ? f[j].w * m : 0.f};
-      uint2 pl[3];
-      split4(v, pl);
-#pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(S + p * PLANE + woff + j * (KPP * ROWB)) = pl[p];
-    }
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(S + p * PLANE + woff + J * (KPP * ROWB)) = pl[p];
   }
-  // address (plane 0, k-substep 0, first transpose read) of the fragment of tile columns c0 .. c0+31 (c0 % 32 == 0):
+  // address (plane 0, first transpose read) of the fragment of tile columns c0 .. c0+31 (c0 % 32 == 0):
   // lane L of a 16-lane group addresses row (L >> 2), column quad (L & 3) of the group's 4 x 16 block
   static __device__ __forceinline__ uint32_t frag_addr(int c0, int lane) {
     const int L = lane & 15, k = 8 * (lane >> 5) + (L >> 2);
     return k * ROWB + ((((c0 >> 5) ^ swz(k)) & (NC - 1)) << 6) + (((lane >> 4) & 1) << 5) + ((L & 3) << 3);
   }
-  // k rows 16 s + 8 (lane >> 5) + {0..3} and {4..7}
-  static __device__ __forceinline__ bf16x8 frag(const char* __restrict__ S, uint32_t addr, int plane, int s) {
-    const char* q = S + plane * PLANE + addr + s * (16 * ROWB);
+  // k rows 8 (lane >> 5) + {0..3} and {4..7}
+  static __device__ __forceinline__ bf16x8 frag(const char* __restrict__ S, uint32_t addr, int plane) {
+    const char* q = S + plane * PLANE + addr;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q + 4 * ROWB));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -167,79 +167,78 @@ struct ColOperand {
   }
 };
 
-// The next K step's global loads, cut into NV_A + NV_B pieces that limb_tile_step issues between its MFMA groups: a
-// wavefront that issued them in one burst would sit in the memory pipeline's queue instead of feeding the matrix core.
+// The producer side of the software pipeline: registers fa / fb hold K step s+1 on entry to the MFMAs of step s; piece p
+// stages its float4 into the LDS stage `dst` (if step s+1 exists) and re-fills it with step s+2 (if that exists).
 template <class OPA, class OPB>
-struct Prefetch {
+struct Producer {
   OPA& oa;
   OPB& ob;
   float4 (&fa)[OPA::NV];
   float4 (&fb)[OPB::NV];
-  const float* abase;
+  char* dstA;                  // LDS stage that receives step s+1
+  char* dstB;
+  const float* abase;          // operand bases of step s+2
   const float* bbase;
   const float* bscale;
-  int64_t lda, ldb, k_left;   // k_left <= 0: nothing to fetch
+  int64_t lda, ldb;
+  int64_t left1, left2;        // operand rows / k left from the staged / the loaded step on (left1 <= 0: stage zeros; left2 > 0)
   int t;
+  bool do_stage = true;        // compile-time constant at every use (prologue only)
   static constexpr int P = OPA::NV + OPB::NV;
+  // branch-free on purpose: the K loop body must stay one basic block so that the compiler's vmcnt bookkeeping can let
+  // older loads be consumed while younger ones are still in flight (a step that does not exist stages zeros into a stage
+  // nobody reads / re-loads a clamped, valid address)
   template <int PIECE>
-  __device__ __forceinline__ void one() const {
-    if (k_left <= 0) return;
+  __device__ __forceinline__ void one() {
     if constexpr (PIECE < OPA::NV) {
-      if (k_left >= KS) oa.template piece<true, PIECE>(fa, abase, lda, k_left, nullptr, t);
-      else oa.template piece<false, PIECE>(fa, abase, lda, k_left, nullptr, t);
+      if (do_stage) oa.template stage<PIECE>(fa, dstA, left1, t);
+      oa.template load<PIECE>(fa, abase, lda, left2, nullptr, t);
     } else {
       constexpr int J = PIECE - OPA::NV;
-      if (k_left >= KS) ob.template piece<true, J>(fb, bbase, ldb, k_left, bscale, t);
-      else ob.template piece<false, J>(fb, bbase, ldb, k_left, bscale, t);
+      if (do_stage) ob.template stage<J>(fb, dstB, left1, t);
+      ob.template load<J>(fb, bbase, ldb, left2, bscale, t);
     }
   }
   template <int G, int NG, int... Is>
-  __device__ __forceinline__ void group_impl(std::integer_sequence<int, Is...>) const {
+  __device__ __forceinline__ void group_impl(std::integer_sequence<int, Is...>) {
     ((Is * NG / P == G ? one<Is>() : void()), ...);
   }
-  // pieces scheduled with MFMA group G of NG
+  // pieces scheduled after MFMA group G of NG
   template <int G, int NG>
-  __device__ __forceinline__ void group() const { group_impl<G, NG>(std::make_integer_sequence<int, P>{}); }
-  __device__ __forceinline__ void all() const { group<0, 1>(); }
+  __device__ __forceinline__ void group() { group_impl<G, NG>(std::make_integer_sequence<int, P>{}); }
 };
 
-// ---- one K step (32 = two MFMA k-steps) of a 64x64 wave tile -------------------------------------
-// OPA / OPB: RowOperand or ColOperand; aaddr[i] / baddr[j]: fragment addresses of the wave's two 32-row / 32-column blocks.
-// Limb products in increasing magnitude; planes are read just before their first use so that at most eight fragments
-// are live; consecutive MFMAs go to different accumulators; one slice of the next K step's global loads per MFMA group.
-template <int WTN, class OPA, class OPB, class PF>
+// ---- one K step (16) of a 64 x (32 WTN) wave tile ---------------------------------------------------
+// OPA / OPB: RowOperand or ColOperand; aaddr[i] / baddr[j]: fragment addresses of the wave's 32-row / 32-column blocks.
+// Limb products in increasing magnitude; planes are read just before their first use; consecutive MFMAs go to different
+// accumulators; one slice of the producer's work after every group of four MFMAs.
+template <int WTN, class OPA, class OPB, class PR>
 __device__ __forceinline__ void limb_tile_step(const char* __restrict__ As, const char* __restrict__ Bs, const uint32_t (&aaddr)[2],
-                                               const uint32_t (&baddr)[WTN], f32x16 (&acc)[2][WTN], const PF& pf) {
-  constexpr int NH = WTN / 2, NG = 12 * NH;   // column halves of the wave tile; MFMA groups (of four) per K step
+                                               const uint32_t (&baddr)[WTN], f32x16 (&acc)[2][WTN], PR& pr) {
+  constexpr int NH = WTN / 2, NG = 6 * NH;   // column halves of the wave tile; MFMA groups (of four) per K step
 #define CB_MFMA4(A_, B_, H_, G_)                                                                             \
-  pf.template group<G_, NG>();                                                                               \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
-      acc[i][2 * H_ + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[i], B_[j], acc[i][2 * H_ + j], 0, 0, 0);
-#define CB_HALF(S_, H_)                                                                                                      \
+      acc[i][2 * H_ + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[i], B_[j], acc[i][2 * H_ + j], 0, 0, 0); \
+  pr.template group<G_, NG>();
+#define CB_HALF(H_)                                                                                                          \
   {                                                                                                                          \
     bf16x8 b_hi[2], b_mid[2], b_lo[2];                                                                                       \
-    if (H_ == 0) { _Pragma("unroll") for (int i = 0; i < 2; ++i) a_lo[i] = OPA::frag(As, aaddr[i], 2, S_); }                 \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) b_hi[j] = OPB::frag(Bs, baddr[2 * H_ + j], 0, S_);                         \
-    if (H_ == 0) { _Pragma("unroll") for (int i = 0; i < 2; ++i) a_hi[i] = OPA::frag(As, aaddr[i], 0, S_); }                 \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) b_lo[j] = OPB::frag(Bs, baddr[2 * H_ + j], 2, S_);                         \
-    CB_MFMA4(a_lo, b_hi, H_, (S_ * NH + H_) * 6 + 0)                                                                             \
-    if (H_ == 0) { _Pragma("unroll") for (int i = 0; i < 2; ++i) a_mid[i] = OPA::frag(As, aaddr[i], 1, S_); }                \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) b_mid[j] = OPB::frag(Bs, baddr[2 * H_ + j], 1, S_);                        \
-    CB_MFMA4(a_hi, b_lo, H_, (S_ * NH + H_) * 6 + 1)                                                                             \
-    CB_MFMA4(a_mid, b_mid, H_, (S_ * NH + H_) * 6 + 2)                                                                           \
-    CB_MFMA4(a_mid, b_hi, H_, (S_ * NH + H_) * 6 + 3)                                                                            \
-    CB_MFMA4(a_hi, b_mid, H_, (S_ * NH + H_) * 6 + 4)                                                                            \
-    CB_MFMA4(a_hi, b_hi, H_, (S_ * NH + H_) * 6 + 5)                                                                             \
+    if (H_ == 0) { _Pragma("unroll") for (int i = 0; i < 2; ++i) a_lo[i] = OPA::frag(As, aaddr[i], 2); }                     \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) b_hi[j] = OPB::frag(Bs, baddr[2 * H_ + j], 0);                             \
+    if (H_ == 0) { _Pragma("unroll") for (int i = 0; i < 2; ++i) a_hi[i] = OPA::frag(As, aaddr[i], 0); }                     \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) b_lo[j] = OPB::frag(Bs, baddr[2 * H_ + j], 2);                             \
+    if (H_ == 0) { _Pragma("unroll") for (int i = 0; i < 2; ++i) a_mid[i] = OPA::frag(As, aaddr[i], 1); }                    \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) b_mid[j] = OPB::frag(Bs, baddr[2 * H_ + j], 1);                            \
+    CB_MFMA4(a_lo, b_hi, H_, H_ * 6 + 0)                                                                                     \
+    CB_MFMA4(a_hi, b_lo, H_, H_ * 6 + 1)                                                                                     \
+    CB_MFMA4(a_mid, b_mid, H_, H_ * 6 + 2)                                                                                   \
+    CB_MFMA4(a_mid, b_hi, H_, H_ * 6 + 3)                                                                                    \
+    CB_MFMA4(a_hi, b_mid, H_, H_ * 6 + 4)                                                                                    \
+    CB_MFMA4(a_hi, b_hi, H_, H_ * 6 + 5)                                                                                     \
   }
-#define CB_STEP(S_)                         \
-  {                                         \
-    bf16x8 a_hi[2], a_mid[2], a_lo[2];      \
-    CB_HALF(S_, 0)                          \
-    if constexpr (NH > 1) CB_HALF(S_, 1)    \
-  }
-  CB_STEP(0)
-  CB_STEP(1)
-#undef CB_STEP
+  bf16x8 a_hi[2], a_mid[2], a_lo[2];
+  CB_HALF(0)
+  if constexpr (NH > 1) CB_HALF(1)
 #undef CB_HALF
 #undef CB_MFMA4
 }
@@ -255,29 +254,79 @@ __device__ __forceinline__ void zero_acc_n(f32x16 (&acc)[2][WTN]) {
 }
 
 // wave tile 64 x (32 * WTN); block tile (64 * WM) x (32 * WTN * WN)
-template <int WM, int WN, int WTN = 2>
+template <int WM, int WN, int WTN = 2, int PD = 2>
 struct LTile {
   static constexpr int BM = 64 * WM, BN = 32 * WTN * WN;
-  static constexpr int MINW = (WM == 2 && WTN == 2 ? 3 : 2);   // blocks per CU that the LDS stage allows
+  static constexpr int MINW = (WM == 2 && WTN == 2 && PD < 3 ? 3 : 2);   // wavefronts per SIMD the registers must allow
   static_assert(WM * WN == 4, "four wavefronts per block");
 };
 
+// The K loop shared by NN and TN.  a0 / b0: operand bases of K step 0 (uniform); astep / bstep: their advance per K step
+// in elements; total = length of the reduction axis covered by this block.  PD = register prefetch depth: while the MFMAs
+// of step s run, step s+1 is staged from registers and step s+1+PD is requested from memory, i.e. PD K steps of loads are
+// in flight per wavefront (the ring of register slots is indexed at compile time, hence the PD-fold unrolled loop; the
+// step count is rounded up to a multiple of PD — the surplus steps multiply staged zeros).
+template <int WTN, int PD, class OA, class OB>
+__device__ __forceinline__ void limb_k_loop(OA& oa, OB& ob, char* __restrict__ smem, const float* __restrict__ a0, int64_t astep,
+                                            int64_t lda, const float* __restrict__ b0, int64_t bstep, int64_t ldb,
+                                            const float* __restrict__ bscale0, int64_t total, const uint32_t (&aaddr)[2],
+                                            const uint32_t (&baddr)[WTN], f32x16 (&acc)[2][WTN], int t) {
+  constexpr int STAGE = OA::BYTES + OB::BYTES;
+  float4 fa[PD][OA::NV], fb[PD][OB::NV];
+  float scs[PD][OB::NV];   // per-slot copies of the col operand's raw scales (ob.sc is the working copy)
+  if (total <= 0) return;
+  const int64_t nk = (total + KS - 1) / KS;
+  auto clampi = [&](int64_t step) { return step < nk ? step : nk - 1; };   // loads of steps past the end re-read the last one
+  {  // prologue: step 0 -> LDS stage 0; steps 1..PD -> register slots 1 % PD .. PD % PD
+    Producer<OA, OB> p0{oa, ob, fa[0], fb[0], smem, smem + OA::BYTES, a0, b0, bscale0, lda, ldb, 0, total, t, false};
+    p0.template group<0, 1>();                        // load step 0
+    p0.left1 = total; p0.do_stage = true;
+    p0.template group<0, 1>();                        // stage it (and load it once more: keeps one() branch-free)
+#pragma unroll
+    for (int d = 1; d <= PD; ++d) {
+      const int64_t st = clampi(d);
+      Producer<OA, OB> pd{oa, ob, fa[d % PD], fb[d % PD], smem, smem, a0 + st * astep, b0 + st * bstep,
+                          bscale0 ? bscale0 + st * KS : nullptr, lda, ldb, 0, total - st * KS, t, false};
+      pd.template group<0, 1>();
+#pragma unroll
+      for (int j = 0; j < OB::NV; ++j) scs[d % PD][j] = ob.sc[OB::HAS_SC ? j : 0];
+    }
+  }
+  __syncthreads();
+  for (int64_t kt0 = 0; kt0 < nk; kt0 += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      const int64_t kt = kt0 + u;
+      char* cur = smem + (kt & 1) * STAGE;
+      char* nxt = smem + ((kt + 1) & 1) * STAGE;
+      const int slot = (u + 1) % PD;   // holds step kt + 1; re-filled with step kt + 1 + PD
+#pragma unroll
+      for (int j = 0; j < OB::NV; ++j) if (OB::HAS_SC) ob.sc[j] = scs[slot][j];
+      const int64_t st = clampi(kt + 1 + PD);
+      Producer<OA, OB> pr{oa, ob, fa[slot], fb[slot], nxt, nxt + OA::BYTES, a0 + st * astep, b0 + st * bstep,
+                          bscale0 ? bscale0 + st * KS : nullptr, lda, ldb, total - (kt + 1) * KS, total - st * KS, t};
+      limb_tile_step<WTN, OA, OB>(cur, cur + OA::BYTES, aaddr, baddr, acc, pr);
+#pragma unroll
+      for (int j = 0; j < OB::NV; ++j) if (OB::HAS_SC) scs[slot][j] = ob.sc[j];
+      __syncthreads();
+    }
+  }
+}
+
 // ---- NN ------------------------------------------------------------------------------------
-template <int WM, int WN, bool OUT_BF16, int WTN = 2>
-__global__ void __launch_bounds__(256, (LTile<WM, WN, WTN>::MINW)) k_gemm_nn_l3(const float* __restrict__ A, int64_t lda,
-                                                                            const float* __restrict__ B, int64_t ldb,
-                                                                            void* __restrict__ Cv, int64_t ldc, int64_t M, int N, int K,
-                                                                            GemmEpilogue ep, int n_row_blocks, int n_col_blocks,
-                                                                            int c_vec_ok) {
+template <int WM, int WN, bool OUT_BF16, int WTN = 2, int PD = 2>
+__global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_nn_l3(const float* __restrict__ A, int64_t lda,
+                                                                                 const float* __restrict__ B, int64_t ldb,
+                                                                                 void* __restrict__ Cv, int64_t ldc, int64_t M, int N,
+                                                                                 int K, GemmEpilogue ep, int n_row_blocks,
+                                                                                 int n_col_blocks, int c_vec_ok) {
   using T = LTile<WM, WN, WTN>;
   using OA = RowOperand<T::BM>;
   using OB = ColOperand<T::BN, false>;
   constexpr int BM = T::BM, BN = T::BN;
-  constexpr int SMEM = OA::BYTES + OB::BYTES;
+  constexpr int SMEM = 2 * (OA::BYTES + OB::BYTES);
   static_assert(32 * (BN + 4) * 4 <= SMEM, "epilogue staging must fit");
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
-  char* As = smem;
-  char* Bs = smem + OA::BYTES;
   const int per_group = 8 * n_col_blocks;   // XCD-aware order, see k_gemm_nn
   const int grp = blockIdx.x / per_group, r = blockIdx.x % per_group;
   const int row_blk = grp * 8 + (r & 7), col_blk = r >> 3;
@@ -296,42 +345,25 @@ __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN>::MINW)) k_gemm_nn_l3(
   uint32_t baddr[WTN];
 #pragma unroll
   for (int j = 0; j < WTN; ++j) baddr[j] = OB::frag_addr(wc * (32 * WTN) + 32 * j, lane);
-  const float* a_tile = A + m0 * lda;
-  const float* b_tile = B + n0;
-  float4 fa[OA::NV], fb[OB::NV];
-  const int nk = (K + KS - 1) / KS;
-  Prefetch<OA, OB>{oa, ob, fa, fb, a_tile, b_tile, nullptr, lda, ldb, (int64_t)K, t}.all();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int k0 = kt * KS;
-    oa.stage(fa, As, K - k0, t);
-    ob.stage(fb, Bs, K - k0, t);
-    __syncthreads();
-    // next K step's operands travel while this one's MFMAs run
-    const Prefetch<OA, OB> pf{oa, ob, fa, fb, a_tile + (k0 + KS), b_tile + (int64_t)(k0 + KS) * ldb, nullptr, lda, ldb,
-                              (int64_t)K - (k0 + KS), t};
-    limb_tile_step<WTN, OA, OB>(As, Bs, aaddr, baddr, acc, pf);
-    __syncthreads();
-  }
+  limb_k_loop<WTN, PD, OA, OB>(oa, ob, smem, A + m0 * lda, KS, lda, B + n0, (int64_t)KS * ldb, ldb, nullptr, K, aaddr, baddr, acc, t);
   nn_epilogue<WM, WN, WTN, OUT_BF16>(acc, reinterpret_cast<float*>(smem), Cv, ldc, m0, n0, M, N, ep, c_vec_ok, t);
 }
 
 // ---- TN ------------------------------------------------------------------------------------
 // 1-D grid, XCD-aware: the tiles of one row split get block ids congruent mod 8 (same XCD / L2), so each operand
 // panel is fetched from HBM once although tiles_i (tiles_j) tiles consume it.
-template <int WM, int WN, bool SCALED, int WTN = 2>
-__global__ void __launch_bounds__(256, (LTile<WM, WN, WTN>::MINW)) k_gemm_tn_l3(const float* __restrict__ A, int64_t lda,
-                                                                            const float* __restrict__ G, int64_t ldg,
-                                                                            const float* __restrict__ rowscale,
-                                                                            float* __restrict__ partial, int64_t M, int K1, int K2,
-                                                                            int64_t rows_per_split, int tiles_j, int n_tiles,
-                                                                            int nsplit) {
+template <int WM, int WN, bool SCALED, int WTN = 2, int PD = 2>
+__global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_tn_l3(const float* __restrict__ A, int64_t lda,
+                                                                                 const float* __restrict__ G, int64_t ldg,
+                                                                                 const float* __restrict__ rowscale,
+                                                                                 float* __restrict__ partial, int64_t M, int K1, int K2,
+                                                                                 int64_t rows_per_split, int tiles_j, int n_tiles,
+                                                                                 int nsplit) {
   using T = LTile<WM, WN, WTN>;
   using OA = ColOperand<T::BM, false>;
   using OB = ColOperand<T::BN, SCALED>;
   constexpr int BM = T::BM, BN = T::BN;
-  __shared__ __attribute__((aligned(16))) char smem[OA::BYTES + OB::BYTES];
-  char* As = smem;
-  char* Bs = smem + OA::BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[2 * (OA::BYTES + OB::BYTES)];
   const int b = blockIdx.x;
   const int tile = (b >> 3) % n_tiles, split = (b & 7) + 8 * (b / (8 * n_tiles));
   if (split >= nsplit) return;
@@ -350,23 +382,8 @@ __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN>::MINW)) k_gemm_tn_l3(
   uint32_t baddr[WTN];
 #pragma unroll
   for (int j = 0; j < WTN; ++j) baddr[j] = OB::frag_addr(wc * (32 * WTN) + 32 * j, lane);
-  float4 fa[OA::NV], fb[OB::NV];
-  const int64_t nk = r_end > r_begin ? (r_end - r_begin + KS - 1) / KS : 0;
-  const float* a_col = A + i0;
-  const float* g_col = G + j0;
-  Prefetch<OA, OB>{oa, ob, fa, fb, a_col + r_begin * lda, g_col + r_begin * ldg, SCALED ? rowscale + r_begin : nullptr, lda, ldg,
-                   r_end - r_begin, t}.all();
-  for (int64_t kt = 0; kt < nk; ++kt) {
-    const int64_t row = r_begin + kt * KS;
-    oa.stage(fa, As, r_end - row, t);
-    ob.stage(fb, Bs, r_end - row, t);
-    __syncthreads();
-    const int64_t nrow = row + KS;
-    const Prefetch<OA, OB> pf{oa, ob, fa, fb, a_col + nrow * lda, g_col + nrow * ldg, SCALED ? rowscale + nrow : nullptr, lda, ldg,
-                              r_end - nrow, t};
-    limb_tile_step<WTN, OA, OB>(As, Bs, aaddr, baddr, acc, pf);
-    __syncthreads();
-  }
+  limb_k_loop<WTN, PD, OA, OB>(oa, ob, smem, A + r_begin * lda + i0, (int64_t)KS * lda, lda, G + r_begin * ldg + j0, (int64_t)KS * ldg, ldg,
+                           SCALED ? rowscale + r_begin : nullptr, r_end - r_begin, aaddr, baddr, acc, t);
   const int l31 = lane & 31, lh = lane >> 5;
   float* P = partial + (int64_t)split * K1 * K2;
 #pragma unroll
@@ -385,6 +402,11 @@ __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN>::MINW)) k_gemm_tn_l3(
 
 static inline bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
+static inline int limb_pd() {
+  static const int pd = getenv("CB_LIMB_PD") ? atoi(getenv("CB_LIMB_PD")) : 1;   // measurement hook: register prefetch depth
+  return pd;
+}
+
 template <int WM, int WN, bool OUT_BF16, int WTN = 2>
 static int launch_nn_l3_t(const float* A, int64_t lda, const float* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
                           int64_t K, GemmEpilogue ep, hipStream_t st) {
@@ -392,8 +414,16 @@ static int launch_nn_l3_t(const float* A, int64_t lda, const float* B, int64_t l
   const int nrb = (int)((M + T::BM - 1) / T::BM), ncb = (int)((N + T::BN - 1) / T::BN);
   const int64_t groups = (nrb + 7) / 8;
   const int c_vec_ok = ((uintptr_t)C % (OUT_BF16 ? 8 : 16) == 0) && ldc % 4 == 0 && (!ep.addend || (al16(ep.addend) && ep.ld_add % 4 == 0));
-  hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, OUT_BF16, WTN>), dim3((unsigned)(groups * 8 * ncb)), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M,
-                     (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
+  const dim3 grid((unsigned)(groups * 8 * ncb));
+  if (limb_pd() == 1)
+    hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, OUT_BF16, WTN, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb,
+                       ncb, c_vec_ok);
+  else if (limb_pd() == 3)
+    hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, OUT_BF16, WTN, 3>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb,
+                       ncb, c_vec_ok);
+  else
+    hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, OUT_BF16, WTN, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb,
+                       ncb, c_vec_ok);
   CB_LAUNCH_CHECK();
   return CB_OK;
 }
@@ -423,12 +453,13 @@ static void launch_tn_l3_t(const float* A, int64_t lda, const float* G, int64_t 
   using T = LTile<WM, WN, WTN>;
   const int ti = (int)((K1 + T::BM - 1) / T::BM), tj = (int)((K2 + T::BN - 1) / T::BN);
   const dim3 grid((unsigned)(((nsplit + 7) / 8) * 8 * ti * tj));
-  if (rowscale)
-    hipLaunchKernelGGL((k_gemm_tn_l3<WM, WN, true, WTN>), grid, dim3(256), 0, st, A, lda, G, ldg, rowscale, partial, M, (int)K1, (int)K2,
-                       rows_per_split, tj, ti * tj, nsplit);
-  else
-    hipLaunchKernelGGL((k_gemm_tn_l3<WM, WN, false, WTN>), grid, dim3(256), 0, st, A, lda, G, ldg, rowscale, partial, M, (int)K1, (int)K2,
-                       rows_per_split, tj, ti * tj, nsplit);
+#define CB_TN_LAUNCH(SC_, PD_)                                                                                                   \
+  hipLaunchKernelGGL((k_gemm_tn_l3<WM, WN, SC_, WTN, PD_>), grid, dim3(256), 0, st, A, lda, G, ldg, rowscale, partial, M, (int)K1, \
+                     (int)K2, rows_per_split, tj, ti * tj, nsplit)
+  const int pd = limb_pd();
+  if (rowscale) { if (pd == 1) CB_TN_LAUNCH(true, 1); else if (pd == 3) CB_TN_LAUNCH(true, 3); else CB_TN_LAUNCH(true, 2); }
+  else { if (pd == 1) CB_TN_LAUNCH(false, 1); else if (pd == 3) CB_TN_LAUNCH(false, 3); else CB_TN_LAUNCH(false, 2); }
+#undef CB_TN_LAUNCH
 }
 
 bool limb3_tn_eligible(const float* A, int64_t lda, const float* G, int64_t ldg, int64_t K1, int64_t K2) {

@@ -19,43 +19,36 @@ VARIANTS = {
   lo = __float_as_uint(r1 - __uint_as_float(mid));''', '''  hi = __float_as_uint(a);
   mid = hi;
   lo = hi;''')],
-    'mfma3': [('cb_gemm_limb.hip', '''    CB_MFMA4(a_mid, b_mid, 6 * S_ + 2)                                                                                       \\
-    CB_MFMA4(a_mid, b_hi, 6 * S_ + 3)                                                                                        \\
-    CB_MFMA4(a_hi, b_mid, 6 * S_ + 4)                                                                                        \\
-    CB_MFMA4(a_hi, b_hi, 6 * S_ + 5)                                                                                         \\''', '''    CB_MFMA4(a_mid, b_mid, 6 * S_ + 2)                                                                                       \\
-    pf.template group<6 * S_ + 3>(); pf.template group<6 * S_ + 4>(); pf.template group<6 * S_ + 5>(); \\''')],
-    'timing': [('cb_gemm_limb.hip', '''  for (int64_t kt = 0; kt < nk; ++kt) {
-    const int64_t row = r_begin + kt * KS;
-    oa.stage(fa, As, r_end - row, t);
-    ob.stage(fb, Bs, r_end - row, t);
-    __syncthreads();
-    const int64_t nrow = row + KS;
-    const Prefetch<OA, OB> pf{oa, ob, fa, fb, a_col + nrow * lda, g_col + nrow * ldg, SCALED ? rowscale + nrow : nullptr, lda, ldg,
-                              r_end - nrow, t};
-    limb_tile_step<OA, OB>(As, Bs, aaddr, baddr, acc, pf);
-    __syncthreads();
-  }''', '''  uint64_t ts[4][6];
-#define STAMP(I) if (rec) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ts[kt - 8][I] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-  for (int64_t kt = 0; kt < nk; ++kt) {
-    const bool rec = kt >= 8 && kt < 12;
-    const int64_t row = r_begin + kt * KS;
-    STAMP(0)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP(1)
-    oa.stage(fa, As, r_end - row, t);
-    ob.stage(fb, Bs, r_end - row, t);
-    STAMP(2)
-    __syncthreads();
-    STAMP(3)
-    const int64_t nrow = row + KS;
-    const Prefetch<OA, OB> pf{oa, ob, fa, fb, a_col + nrow * lda, g_col + nrow * ldg, SCALED ? rowscale + nrow : nullptr, lda, ldg,
-                              r_end - nrow, t};
-    limb_tile_step<OA, OB>(As, Bs, aaddr, baddr, acc, pf);
-    STAMP(4)
-    __syncthreads();
-    STAMP(5)
+    'mfma3': [('cb_gemm_limb.hip', '''    CB_MFMA4(a_mid, b_mid, H_, H_ * 6 + 2)                                                                                   \\
+    CB_MFMA4(a_mid, b_hi, H_, H_ * 6 + 3)                                                                                    \\
+    CB_MFMA4(a_hi, b_mid, H_, H_ * 6 + 4)                                                                                    \\
+    CB_MFMA4(a_hi, b_hi, H_, H_ * 6 + 5)                                                                                     \\''', '''    CB_MFMA4(a_mid, b_mid, H_, H_ * 6 + 2)                                                                                   \\
+    pr.template group<H_ * 6 + 3, NG>(); pr.template group<H_ * 6 + 4, NG>(); pr.template group<H_ * 6 + 5, NG>(); \\''')],
+    'timing': [('cb_gemm_limb.hip', '''        limb_tile_step<WTN, OA, OB>(cur, cur + OA::BYTES, aaddr, baddr, acc, pr);''', '''        if (kt >= 16 && kt < 24) { __builtin_amdgcn_sched_barrier(0); g_ts[kt - 16][0] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+        limb_tile_step<WTN, OA, OB>(cur, cur + OA::BYTES, aaddr, baddr, acc, pr);
+        if (kt >= 16 && kt < 24) { __builtin_amdgcn_sched_barrier(0); g_ts[kt - 16][1] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }'''),
+        ('cb_gemm_limb.hip', '''  float4 fa[PD][OA::NV], fb[PD][OB::NV];''', '''  float4 fa[PD][OA::NV], fb[PD][OB::NV];
+  uint64_t g_ts[8][2];'''),
+        ('cb_gemm_limb.hip', '''      __syncthreads();
+    }
   }
-  const bool probe = (split == 165 && tile == 0 && w == 1);'''),
+}
+''', '''      __syncthreads();
+    }
+  }
+  if ((t & 63) == 0 && (t >> 6) == 1) {
+    float* dbg = (float*)(smem);
+    for (int a = 0; a < 8; ++a) { dbg[2 * a] = (float)(g_ts[a][0] - g_ts[0][0]); dbg[2 * a + 1] = (float)(g_ts[a][1] - g_ts[0][0]); }
+  }
+  __syncthreads();
+}
+'''),
+        ('cb_gemm_limb.hip', '''  const int l31 = lane & 31, lh = lane >> 5;
+  float* P = partial + (int64_t)split * K1 * K2;''', '''  const int l31 = lane & 31, lh = lane >> 5;
+  float* P = partial + (int64_t)split * K1 * K2;
+  float dbgv = 0.f;
+  if (split == 165 && tile == 0 && t < 16) dbgv = ((float*)smem)[t];
+  __syncthreads();'''),
         ('cb_gemm_limb.hip', '''        if (m < K1) P[(int64_t)m * K2 + n] = acc[ti][tj][reg];
       }
     }
@@ -63,10 +56,7 @@ VARIANTS = {
       }
     }
   __syncthreads();
-  if (probe && lane == 0) {
-    for (int a = 0; a < 4; ++a)
-      for (int c = 0; c < 6; ++c) P[a * 6 + c] = (float)(ts[a][c] - ts[0][0]);
-  }
+  if (split == 165 && tile == 0 && t < 16) P[t] = dbgv;
 }''')],
     'nostore': [('cb_gemm_core.h', '''      if (m < M && n < N) {
         const float4 v = *reinterpret_cast<const float4*>(Cs + row * LDB + c4);''', '''      if (m < M && n < N && ep.relu == 77) {
@@ -142,8 +132,13 @@ def timing(M):
         _lib.check(lib.cb_gemm_tn_f32(_lib.ptr(a), 256, _lib.ptr(g), 256, _lib.ptr(rs), _lib.ptr(out), M, 256, 256, _lib.ptr(ws), wsb,
                                       _lib.stream_ptr()), 'tn')
     torch.cuda.synchronize()
-    t = ws[165 * 65536: 165 * 65536 + 24].cpu().view(4, 6)
+    t = ws[165 * 65536: 165 * 65536 + 16].cpu().view(8, 2)
     print('nsplit', wsb // 4 // 65536)
+    prev_end = None
+    for r in t.tolist():
+        print(f'step start {int(r[0]):7d}  mfma+producer {int(r[1] - r[0]):6d}  barrier+loop {"" if prev_end is None else int(r[0] - prev_end)}')
+        prev_end = r[1]
+    return
     print('stamps (cycles from K-step 8 start): top, loads landed, staged, barrier1, mfma(+loads issued) done, barrier2')
     for r in t.tolist():
         print('  '.join(f'{int(x):7d}' for x in r), '  | vmwait %d  stage %d  bar1 %d  mfma %d  bar2 %d' % (r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4]))
