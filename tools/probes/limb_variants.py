@@ -24,40 +24,30 @@ VARIANTS = {
     CB_MFMA4(a_hi, b_mid, H_, H_ * 6 + 4)                                                                                    \\
     CB_MFMA4(a_hi, b_hi, H_, H_ * 6 + 5)                                                                                     \\''', '''    CB_MFMA4(a_mid, b_mid, H_, H_ * 6 + 2)                                                                                   \\
     pr.template group<H_ * 6 + 3, NG>(); pr.template group<H_ * 6 + 4, NG>(); pr.template group<H_ * 6 + 5, NG>(); \\''')],
-    'timing': [('cb_gemm_limb.hip', '''        limb_tile_step<WTN, OA, OB>(cur, cur + OA::BYTES, aaddr, baddr, acc, pr);''', '''        if (kt >= 16 && kt < 24) { __builtin_amdgcn_sched_barrier(0); g_ts[kt - 16][0] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-        limb_tile_step<WTN, OA, OB>(cur, cur + OA::BYTES, aaddr, baddr, acc, pr);
-        if (kt >= 16 && kt < 24) { __builtin_amdgcn_sched_barrier(0); g_ts[kt - 16][1] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }'''),
-        ('cb_gemm_limb.hip', '''  float4 fa[PD][OA::NV], fb[PD][OB::NV];''', '''  float4 fa[PD][OA::NV], fb[PD][OB::NV];
-  uint64_t g_ts[8][2];'''),
-        ('cb_gemm_limb.hip', '''      __syncthreads();
-    }
-  }
-}
-''', '''      __syncthreads();
-    }
-  }
-  if ((t & 63) == 0 && (t >> 6) == 1) {
-    float* dbg = (float*)(smem);
-    for (int a = 0; a < 8; ++a) { dbg[2 * a] = (float)(g_ts[a][0] - g_ts[0][0]); dbg[2 * a + 1] = (float)(g_ts[a][1] - g_ts[0][0]); }
-  }
-  __syncthreads();
-}
-'''),
-        ('cb_gemm_limb.hip', '''  const int l31 = lane & 31, lh = lane >> 5;
-  float* P = partial + (int64_t)split * K1 * K2;''', '''  const int l31 = lane & 31, lh = lane >> 5;
-  float* P = partial + (int64_t)split * K1 * K2;
-  float dbgv = 0.f;
-  if (split == 165 && tile == 0 && t < 16) dbgv = ((float*)smem)[t];
-  __syncthreads();'''),
-        ('cb_gemm_limb.hip', '''        if (m < K1) P[(int64_t)m * K2 + n] = acc[ti][tj][reg];
-      }
-    }
-}''', '''        if (m < K1) P[(int64_t)m * K2 + n] = acc[ti][tj][reg];
-      }
-    }
-  __syncthreads();
-  if (split == 165 && tile == 0 && t < 16) P[t] = dbgv;
-}''')],
+    'noload': [('cb_gemm_limb.hip', '''      oa.template load<PIECE>(fa, abase, lda, left2, nullptr, t);''', '''      if (left2 == -12345) oa.template load<PIECE>(fa, abase, lda, left2, nullptr, t);'''),
+               ('cb_gemm_limb.hip', '''      ob.template load<J>(fb, bbase, ldb, left2, bscale, t);''', '''      if (left2 == -12345) ob.template load<J>(fb, bbase, ldb, left2, bscale, t);''')],
+    'l2load': [('cb_gemm_limb.hip', '''      Producer<OA, OB> pr{oa, ob, fa[slot], fb[slot], nxt, nxt + OA::BYTES, a0 + st * astep, b0 + st * bstep,''', '''      Producer<OA, OB> pr{oa, ob, fa[slot], fb[slot], nxt, nxt + OA::BYTES, a0 + (st & 1) * astep, b0 + (st & 1) * bstep,''')],
+    'l2blk': [('cb_gemm_limb.hip', '''  limb_k_loop<WTN, PD, OA, OB>(oa, ob, smem, A + m0 * lda, KS, lda, B + n0,''', '''  limb_k_loop<WTN, PD, OA, OB>(oa, ob, smem, A + (m0 & 0xfffff) * lda, KS, lda, B + n0,'''),
+              ('cb_gemm_limb.hip', '''  limb_k_loop<WTN, PD, OA, OB>(oa, ob, smem, A + r_begin * lda + i0, (int64_t)KS * lda, lda, G + r_begin * ldg + j0, (int64_t)KS * ldg, ldg,''', '''  limb_k_loop<WTN, PD, OA, OB>(oa, ob, smem, A + (r_begin & 0xfffff) * lda + i0, (int64_t)KS * lda, lda, G + (r_begin & 0xfffff) * ldg + j0, (int64_t)KS * ldg, ldg,''')],
+    'rawstage': [('cb_gemm_limb.hip', '''    const bool live = ((rmask >> J) & 1) && (t & 3) * 4 < k_left;
+    const float v[4] = {live ? f[J].x : 0.f, live ? f[J].y : 0.f, live ? f[J].z : 0.f, live ? f[J].w : 0.f};
+    uint2 pl[3];
+    split4(v, pl);''', '''    uint2 pl[3];
+    pl[0] = make_uint2(__float_as_uint(f[J].x), __float_as_uint(f[J].y)); pl[1] = make_uint2(__float_as_uint(f[J].z), __float_as_uint(f[J].w)); pl[2] = pl[0];'''),
+                 ('cb_gemm_limb.hip', '''    const bool live = cok && t / TPR + KPP * J < k_left;
+    const float m = SCALED ? sc[J] : 1.f;
+    const float v[4] = {live ? f[J].x * m : 0.f, live ? f[J].y * m : 0.f, live ? f[J].z * m : 0.f, live ? f[J].w * m : 0.f};
+    uint2 pl[3];
+    split4(v, pl);''', '''    uint2 pl[3];
+    pl[0] = make_uint2(__float_as_uint(f[J].x), __float_as_uint(f[J].y)); pl[1] = make_uint2(__float_as_uint(f[J].z), __float_as_uint(f[J].w)); pl[2] = pl[0];''')],
+    'nostage': [('cb_gemm_limb.hip', '''      if (do_stage) oa.template stage<PIECE>(fa, dstA, left1, t);''', '''      if (do_stage && left1 == -12345) oa.template stage<PIECE>(fa, dstA, left1, t);'''),
+                ('cb_gemm_limb.hip', '''      if (do_stage) ob.template stage<J>(fb, dstB, left1, t);''', '''      if (do_stage && left1 == -12345) ob.template stage<J>(fb, dstB, left1, t);''')],
+    'nobarrier': [('cb_gemm_limb.hip', '''      for (int j = 0; j < OB::NV; ++j) if (OB::HAS_SC) scs[slot][j] = ob.sc[j];
+      __syncthreads();''', '''      for (int j = 0; j < OB::NV; ++j) if (OB::HAS_SC) scs[slot][j] = ob.sc[j];''')],
+    'nofrag': [('cb_gemm_limb.hip', '''    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(S + plane * PLANE + addr));''', '''    uint4 z = make_uint4(addr, plane, addr, plane); return __builtin_bit_cast(bf16x8, z);'''),
+               ('cb_gemm_limb.hip', '''    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q + 4 * ROWB));''', '''    const s16x4 lo = {(short)addr, (short)plane, 1, 2};
+    const s16x4 hi = {(short)plane, (short)addr, 3, 4}; (void)q;''')],
     'nostore': [('cb_gemm_core.h', '''      if (m < M && n < N) {
         const float4 v = *reinterpret_cast<const float4*>(Cs + row * LDB + c4);''', '''      if (m < M && n < N && ep.relu == 77) {
         const float4 v = *reinterpret_cast<const float4*>(Cs + row * LDB + c4);''')],
