@@ -195,6 +195,8 @@ def main():
                                f'C={args.num_classes} L={L}, type_trick={args.type_trick} (residual mode), whetherHasSE=000, '
                                f'dropout={args.dropout}, Adam lr={args.lr}; step = fwd+loss+bwd+Adam, 2L={2 * L} aggregations',
                    'launch': 'one hipGraph replay per step' if use_graph else 'eager launches',
+                   'gemm': ('fp32-input MFMA' if os.environ.get('CB_GEMM_PLAIN_F32') else
+                            'fp32 operands as three exact bf16 limbs, 6 bf16 MFMA products, fp32 accumulate (error <= fp32 GEMM)'),
                    'parallelism': 'single GPU' if not sharded else f'node-sharded x{world} (RCCL all-gather exchange)'},
         'roofline': {'bound': 'hbm', 'kernel': f'k_spmm_rows (+hub kernels) d=256 {a.agg_dtype} source rows, f32 accumulate', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                      'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
