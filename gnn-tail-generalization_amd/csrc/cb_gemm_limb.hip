@@ -75,23 +75,26 @@ template <int R>
 struct RowOperand {
   static constexpr int PLANE = R * 32, BYTES = 3 * PLANE, NV = R / 64;   // float4 per thread per K step
   static_assert(NV >= 1, "tile rows");
-  uint32_t voff;      // element offset of this lane's first float4 from (tile row 0, k0): row t/4, k quad t%4
+  uint32_t voff[NV];  // element offset of this lane's j-th float4 from (tile row 0, k0): row t/4 + 64 j, k quad t%4;
+                      // 0 when that row is outside the matrix, so a masked lane never addresses beyond the operand
   uint32_t woff;      // LDS byte offset of its 8-byte store in plane 0; j-th store: + j * 64 * 32
   uint32_t rmask;     // bit j: tile row t/4 + 64 j lies inside the matrix
   __device__ __forceinline__ void init(int64_t ld, int64_t rows_left, int t) {
     const int row = t >> 2, kq = t & 3;
-    voff = (uint32_t)(row * ld + kq * 4);
     woff = row * 32 + (((kq >> 1) ^ ((row >> 3) & 1)) << 4) + ((kq & 1) << 3);
     rmask = 0;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) rmask |= (row + 64 * j < rows_left) ? (1u << j) : 0u;
+    for (int j = 0; j < NV; ++j) {
+      const bool in = row + 64 * j < rows_left;
+      rmask |= in ? (1u << j) : 0u;
+      voff[j] = in ? (uint32_t)((row + 64 * j) * ld + kq * 4) : 0u;
+    }
   }
   // base = &A[tile row 0][k0] (uniform); k_left = K - k0 > 0; K % 4 == 0
   template <int J>
   __device__ __forceinline__ void load(float4 (&f)[NV], const float* __restrict__ base, int64_t ld, int64_t k_left, const float*,
                                        int t) const {
-    const bool in = ((rmask >> J) & 1) && (t & 3) * 4 < k_left;
-    f[J] = *reinterpret_cast<const float4*>((base + (int64_t)(64 * J) * ld) + (in ? voff : 0u));
+    f[J] = *reinterpret_cast<const float4*>(base + ((t & 3) * 4 < k_left ? voff[J] : 0u));
   }
   template <int J>
   __device__ __forceinline__ void stage(const float4 (&f)[NV], char* __restrict__ S, int64_t k_left, int t) const {
@@ -120,7 +123,7 @@ struct ColOperand {
   static constexpr int NC = C / 32;                                    // 64-byte chunks per row
   static_assert(NC == 2 || NC == 4 || NC == 8, "tile widths 64 / 128 / 256");
   static __device__ __forceinline__ int swz(int k) { return NC == 2 ? ((k >> 1) & 1) : (k & 3); }
-  uint32_t voff;      // element offset of this lane's first float4 from (step row 0, tile col 0): k = t / TPR, quad t % TPR
+  uint32_t voff[NV];  // element offset of this lane's j-th float4 from (step row 0, tile col 0): k = t / TPR + KPP j, quad t % TPR
   uint32_t woff;      // LDS byte offset of its 8-byte store in plane 0; j-th store: + j * KPP * ROWB  (KPP % 4 == 0)
   bool cok;           // its 4 columns lie inside the matrix (N % 4 == 0)
   static constexpr bool HAS_SC = SCALED;
@@ -128,17 +131,19 @@ struct ColOperand {
   __device__ __forceinline__ void init(int64_t ld, int cols_left, int t) {
     const int k = t / TPR, nq = t % TPR;
     cok = nq * 4 < cols_left;
-    voff = (uint32_t)(k * ld + (cok ? nq * 4 : 0));
+#pragma unroll
+    for (int j = 0; j < NV; ++j) voff[j] = (uint32_t)((k + KPP * j) * ld + (cok ? nq * 4 : 0));
     woff = k * ROWB + ((((nq >> 3) ^ swz(k)) & (NC - 1)) << 6) + ((nq & 7) << 3);
   }
-  // base = &B[step row 0][tile col 0] (uniform); k_left = operand rows from there > 0; kscale = their scales
+  // base = &B[step row 0][tile col 0] (uniform); k_left = operand rows from there > 0; kscale = their scales.
+  // Lanes whose k row is past the end address row 0 of the step instead.
   template <int J>
   __device__ __forceinline__ void load(float4 (&f)[NV], const float* __restrict__ base, int64_t ld, int64_t k_left,
                                        const float* __restrict__ kscale, int t) {
-    const int k = t / TPR;
-    const bool kin = k + KPP * J < k_left;
-    f[J] = *reinterpret_cast<const float4*>((base + (int64_t)(KPP * J) * ld) + (kin ? voff : 0u));
-    if constexpr (SCALED) sc[J] = (kscale + KPP * J)[kin ? k : 0];
+    const int k = t / TPR + KPP * J;
+    const bool kin = k < k_left;
+    f[J] = *reinterpret_cast<const float4*>(base + (kin ? voff[J] : 0u));
+    if constexpr (SCALED) sc[J] = kscale[kin ? k : 0];
   }
   template <int J>
   __device__ __forceinline__ void stage(const float4 (&f)[NV], char* __restrict__ S, int64_t k_left, int t) const {
