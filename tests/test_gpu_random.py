@@ -78,3 +78,45 @@ def test_random_fused_epilogue_matches_composition(seed):
     tile, lane, k = cols // 256, (cols % 256) // 4, cols % 4
     got_mask = ((b[:, tile, k] >> lane.astype(np.uint64)) & np.uint64(1)).astype(bool)
     assert np.array_equal(got_mask, (ref_act > 0).cpu().numpy())
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_random_gemm_shapes_strides_and_epilogues(seed):
+    """Dense contractions on random ragged shapes: every size around the tile / K-step boundaries, operands that are
+    column slices of wider buffers (leading dimension > width, pointer offsets), shapes that qualify for the three-limb
+    path (multiples of 4, 16-byte aligned) and shapes that fall back to the fp32-input MFMA path, with the fused epilogue
+    terms switched on at random.  Reference: fp64 on the host."""
+    from gnn_tail_generalization_amd import gemm
+    rng = np.random.default_rng(500 + seed)
+    M = int(rng.choice([1, 3, 63, 64, 65, 127, 128, 129, 255, 257, 640, 1031]))
+    K = int(rng.choice([4, 8, 12, 16, 20, 36, 64, 100, 128, 260, 7, 33]))
+    N = int(rng.choice([4, 8, 40, 60, 64, 68, 128, 132, 256, 260, 300, 5, 130]))
+    pad_a, pad_b = int(rng.choice([0, 4, 8, 3])), int(rng.choice([0, 4, 12, 1]))
+    off_a, off_b = int(rng.choice([0, 4, 1])), int(rng.choice([0, 4]))
+    abuf = torch.from_numpy(rng.standard_normal((M, K + pad_a + off_a)).astype(np.float32)).to(DEV)
+    bbuf = torch.from_numpy(rng.standard_normal((K, N + pad_b + off_b)).astype(np.float32)).to(DEV)
+    a, b = abuf[:, off_a:off_a + K], bbuf[:, off_b:off_b + N]
+    rs = torch.from_numpy(rng.random(M).astype(np.float32) + 0.5).to(DEV) if rng.random() < 0.6 else None
+    add = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).to(DEV) if rng.random() < 0.5 else None
+    bias = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(DEV) if rng.random() < 0.5 else None
+    relu = bool(rng.random() < 0.5)
+    got = gemm.mm_nn(a, b, rowscale=rs, addend=add, bias=bias, relu=relu).cpu().double()
+    ref = a.cpu().double() @ b.cpu().double()
+    if rs is not None:
+        ref = ref * rs.cpu().double().unsqueeze(1)
+    if add is not None:
+        ref = ref + add.cpu().double()
+    if bias is not None:
+        ref = ref + bias.cpu().double()
+    if relu:
+        ref = torch.relu(ref)
+    scale = (a.cpu().double().abs() @ b.cpu().double().abs()).max().item() + 10.0
+    assert (got - ref).abs().max().item() <= 3e-6 * scale, (M, K, N, pad_a, off_a, pad_b, off_b)
+    # weight-gradient form on the same operands: a^T @ (rs * g)
+    gbuf = torch.from_numpy(rng.standard_normal((M, N + pad_b + off_b)).astype(np.float32)).to(DEV)
+    g = gbuf[:, off_b:off_b + N]
+    got_t = gemm.mm_tn(a, g, rowscale=rs).cpu().double()
+    gs = g.cpu().double() * (rs.cpu().double().unsqueeze(1) if rs is not None else 1.0)
+    ref_t = a.cpu().double().t() @ gs
+    scale_t = (a.cpu().double().abs().t() @ gs.abs()).max().item() + 10.0
+    assert (got_t - ref_t).abs().max().item() <= 3e-6 * scale_t, (M, K, N)
