@@ -4,13 +4,18 @@
 //     sel   = the K largest s_j                                (:151-152, K = --SEMLP_topK_2_replace)
 //     out_i = sum_k softmax(s_sel)_k * T_sel_k                 (:153-154)
 // Here: one MFMA GEMM sweep that never materialises the B x N score matrix.  Each block owns 128 queries and a slab of
-// teacher rows; per 128x128 score tile (exact fp32 MFMA, same core as cb_gemm.hip, both operands row-major -> transposed
-// into LDS) the epilogue folds the tile into a running top-K per query held in LDS; a second kernel merges the slabs'
-// lists, applies the softmax and combines the K selected teacher rows.
-// Bound: MFMA (2*B*N*D flop).  Ordering of ties: larger score first, then larger index (what an ascending stable argsort
+// teacher rows; per 128x128 score tile the epilogue folds the tile into a running top-K per query held in LDS; a second
+// kernel merges the slabs' lists, applies the softmax and combines the K selected teacher rows.  The scores come from the
+// three-limb bf16-MFMA core of cb_gemm_limb.hip (fp32 operands split exactly, error at the level of an fp32 GEMM; both
+// operands are k-contiguous "row" operands) when the operands allow float4 access, else from the fp32-input MFMA core of
+// cb_gemm.hip (operands transposed into LDS).
+// Bound: MFMA (2*B*N*D flop, x6 bf16 passes on the limb path).  Ordering of ties: larger score first, then larger index (what an ascending stable argsort
 // followed by [-K:] selects).
+#include <stdlib.h>
+
 #include "cb_common.h"
 #include "cb_gemm_core.h"
+#include "cb_limb_core.h"
 
 namespace cb {
 
@@ -37,6 +42,52 @@ __device__ __forceinline__ void push(Cand (&best)[K_], int K, float v, int i) {
   }
   best[p].v = v;
   best[p].i = i;
+}
+
+// fold one 128x128 score tile (accumulators of the four wavefronts) into the running top-K lists, 32 query rows per pass
+__device__ __forceinline__ void fold_tile(f32x16 (&acc)[2][2], float* __restrict__ Cs, Cand (&s_cand)[32][8][KMAX],
+                                          Cand (&s_run)[128][KMAX], int n0, int N, int K, int t) {
+  constexpr int LDB = 128 + 4;
+  const int lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int wr_sel = pass >> 1, ti = pass & 1;
+    if (wr == wr_sel) {
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          Cs[((reg & 3) + 8 * (reg >> 2) + 4 * lh) * LDB + wc * 64 + tj * 32 + l31] = acc[ti][tj][reg];
+    }
+    __syncthreads();
+    {
+      const int row = t >> 3, seg = t & 7;
+      Cand best[KMAX];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) { best[k].v = -INFINITY; best[k].i = -1; }
+      for (int c = 0; c < 16; ++c) {
+        const int col = seg * 16 + c, n = n0 + col;
+        if (n < N) push<KMAX>(best, K, Cs[row * LDB + col], n);
+      }
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) s_cand[row][seg][k] = best[k];
+    }
+    __syncthreads();
+    if ((t & 7) == 0) {
+      const int row = t >> 3, grow = wr_sel * 64 + ti * 32 + row;
+      Cand best[KMAX];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) best[k] = s_run[grow][k];
+      for (int seg = 0; seg < 8; ++seg)
+        for (int k = 0; k < K; ++k) {
+          const Cand c = s_cand[row][seg][k];
+          if (c.i >= 0) push<KMAX>(best, K, c.v, c.i);
+        }
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) s_run[grow][k] = best[k];
+    }
+    __syncthreads();
+  }
 }
 
 __global__ void __launch_bounds__(256) k_topk_scores(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ T, int64_t ldt,
@@ -93,47 +144,47 @@ __global__ void __launch_bounds__(256) k_topk_scores(const float* __restrict__ Q
       }
       __syncthreads();
     }
-    // fold the 128x128 score tile into the running lists, 32 query rows per pass
-    float* Cs = smem;  // [32][LDB]
-    const int l31 = lane & 31, lh = lane >> 5;
-    for (int pass = 0; pass < 4; ++pass) {
-      const int wr_sel = pass >> 1, ti = pass & 1;
-      if (wr == wr_sel) {
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-          for (int reg = 0; reg < 16; ++reg)
-            Cs[((reg & 3) + 8 * (reg >> 2) + 4 * lh) * LDB + wc * 64 + tj * 32 + l31] = acc[ti][tj][reg];
-      }
-      __syncthreads();
-      {
-        const int row = t >> 3, seg = t & 7;
-        Cand best[KMAX];
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) { best[k].v = -INFINITY; best[k].i = -1; }
-        for (int c = 0; c < 16; ++c) {
-          const int col = seg * 16 + c, n = n0 + col;
-          if (n < N) push<KMAX>(best, K, Cs[row * LDB + col], n);
-        }
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) s_cand[row][seg][k] = best[k];
-      }
-      __syncthreads();
-      if ((t & 7) == 0) {
-        const int row = t >> 3, grow = wr_sel * 64 + ti * 32 + row;
-        Cand best[KMAX];
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) best[k] = s_run[grow][k];
-        for (int seg = 0; seg < 8; ++seg)
-          for (int k = 0; k < K; ++k) {
-            const Cand c = s_cand[row][seg][k];
-            if (c.i >= 0) push<KMAX>(best, K, c.v, c.i);
-          }
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) s_run[grow][k] = best[k];
-      }
-      __syncthreads();
-    }
+    fold_tile(acc, smem, s_cand, s_run, n0, N, K, t);
+  }
+  for (int i = t; i < BM * K; i += 256) {
+    const int row = i / K, k = i % K;
+    const int64_t m = m0 + row;
+    if (m < B) partial[((int64_t)split * B + m) * K + k] = s_run[row][k];
+  }
+}
+
+// Same sweep on the three-limb core: Q rows and T rows are both k-contiguous "row" operands.
+__global__ void __launch_bounds__(256, 2) k_topk_scores_l3(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ T,
+                                                           int64_t ldt, int64_t B, int N, int D, int K, int tiles_per_split,
+                                                           int n_col_tiles, Cand* __restrict__ partial) {
+  using OA = RowOperand<128>;
+  using OB = RowOperand<128>;
+  constexpr int BM = 128, BN = 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * (OA::BYTES + OB::BYTES)];
+  static_assert(32 * (BN + 4) * 4 <= 2 * (OA::BYTES + OB::BYTES), "fold staging must fit");
+  __shared__ Cand s_cand[32][8][KMAX];
+  __shared__ Cand s_run[BM][KMAX];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int split = blockIdx.y;
+  for (int i = t; i < BM * KMAX; i += 256) {
+    s_run[i / KMAX][i % KMAX].v = -INFINITY;
+    s_run[i / KMAX][i % KMAX].i = -1;
+  }
+  __syncthreads();
+  OA oa;
+  oa.init(ldq, B - m0, t);
+  const uint32_t aaddr[2] = {OA::frag_addr(wr * 64, lane), OA::frag_addr(wr * 64 + 32, lane)};
+  const uint32_t baddr[2] = {OB::frag_addr(wc * 64, lane), OB::frag_addr(wc * 64 + 32, lane)};
+  const int ct_begin = split * tiles_per_split, ct_end = min(n_col_tiles, ct_begin + tiles_per_split);
+  for (int ct = ct_begin; ct < ct_end; ++ct) {
+    const int n0 = ct * BN;
+    OB ob;
+    ob.init(ldt, N - n0, t);
+    f32x16 acc[2][2];
+    zero_acc_n<2>(acc);
+    limb_k_loop<2, 1, OA, OB>(oa, ob, smem, Q + m0 * ldq, KS, ldq, T + (int64_t)n0 * ldt, KS, ldt, nullptr, D, aaddr, baddr, acc, t);
+    fold_tile(acc, reinterpret_cast<float*>(smem), s_cand, s_run, n0, N, K, t);
   }
   for (int i = t; i < BM * K; i += 256) {
     const int row = i / K, k = i % K;
@@ -224,8 +275,13 @@ extern "C" int cb_topk_replace_f32(const float* q, int64_t ldq, const float* t, 
   topk_geometry(B, N, rb, ctl, ns, tps);
   hipStream_t st = (hipStream_t)stream;
   const int aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)t % 16 == 0) && ldq % 4 == 0 && ldt % 4 == 0;
-  hipLaunchKernelGGL(k_topk_scores, dim3((unsigned)rb, (unsigned)ns), dim3(256), 0, st, q, ldq, t, ldt, B, (int)N, (int)D, (int)K, tps,
-                     ctl, (Cand*)ws, aligned);
+  static const bool plain = getenv("CB_GEMM_PLAIN_F32") != nullptr;
+  if (aligned && !plain && D % 4 == 0 && ldq < (1 << 22) && ldt < (1 << 22))
+    hipLaunchKernelGGL(k_topk_scores_l3, dim3((unsigned)rb, (unsigned)ns), dim3(256), 0, st, q, ldq, t, ldt, B, (int)N, (int)D, (int)K,
+                       tps, ctl, (Cand*)ws);
+  else
+    hipLaunchKernelGGL(k_topk_scores, dim3((unsigned)rb, (unsigned)ns), dim3(256), 0, st, q, ldq, t, ldt, B, (int)N, (int)D, (int)K,
+                       tps, ctl, (Cand*)ws, aligned);
   CB_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_topk_finish, dim3((unsigned)((B * 64 + 255) / 256)), dim3(256), 0, st, (const Cand*)ws, ns, B, (int)K, t, ldt,
                      (int)D, out, out_idx, out_w);
