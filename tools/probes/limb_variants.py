@@ -57,20 +57,19 @@ VARIANTS = {
 def build():
     os.makedirs(BIN, exist_ok=True)
     objs = [os.path.join(CSRC, '..', '_build', f) for f in os.listdir(os.path.join(CSRC, '..', '_build'))
-            if f.endswith('.o') and f not in ('cb_gemm_limb.o', 'cb_gemm.o')]
+            if f.endswith('.o') and f not in ('cb_gemm_limb.o', 'cb_gemm.o', 'cb_topk.o')]
     for name, edits in VARIANTS.items():
         tmp = os.path.join(BIN, 'src_' + name)
         os.makedirs(tmp, exist_ok=True)
-        for f in os.listdir(CSRC):
-            if f.endswith(('.h', '.hip')):
-                s = open(os.path.join(CSRC, f)).read()
-                for ef, old, new in edits:
-                    if ef == f:
-                        assert old in s, (name, f)
-                        s = s.replace(old, new)
-                open(os.path.join(tmp, f), 'w').write(s)
+        srcs = {f: open(os.path.join(CSRC, f)).read() for f in os.listdir(CSRC) if f.endswith(('.h', '.hip'))}
+        for _, old, new in edits:          # the pattern may live in the kernel file or in the shared core header
+            hits = [f for f, txt in srcs.items() if old in txt]
+            assert len(hits) == 1, (name, old[:60], hits)
+            srcs[hits[0]] = srcs[hits[0]].replace(old, new)
+        for f, txt in srcs.items():
+            open(os.path.join(tmp, f), 'w').write(txt)
         outs = []
-        for f in ('cb_gemm_limb.hip', 'cb_gemm.hip'):
+        for f in ('cb_gemm_limb.hip', 'cb_gemm.hip', 'cb_topk.hip'):
             o = os.path.join(tmp, f[:-4] + '.o')
             subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'),
                                    '-I' + os.path.join(ROOT, 'gnn-tail-generalization_amd', 'csrc'), '-c', os.path.join(tmp, f), '-o', o])
@@ -104,40 +103,8 @@ def run(name, M):
     print(f'{name:8s} NN {timeit(lambda: gemm.mm_nn(a, b, rowscale=rs)):7.3f} ms   TN {timeit(lambda: gemm.mm_tn(a, g, rowscale=rs)):7.3f} ms', flush=True)
 
 
-def timing(M):
-    """prints the s_memtime stamps of one wavefront over four consecutive K steps of k_gemm_tn_l3 (variant 'timing')"""
-    sys.path.insert(0, ROOT)
-    import torch
-    from gnn_tail_generalization_amd import _lib
-    _lib.LIB_PATH = os.path.join(BIN, 'lib_timing.so')
-    lib = _lib.load()
-    dev = 'cuda:0'
-    a = torch.rand(M, 256, device=dev) - 0.5
-    g = torch.rand(M, 256, device=dev) - 0.5
-    rs = torch.rand(M, device=dev)
-    out = torch.empty(256, 256, device=dev)
-    wsb = lib.cb_gemm_tn_workspace_bytes(M, 256, 256)
-    ws = torch.zeros(wsb // 4, dtype=torch.float32, device=dev)
-    for _ in range(2):
-        _lib.check(lib.cb_gemm_tn_f32(_lib.ptr(a), 256, _lib.ptr(g), 256, _lib.ptr(rs), _lib.ptr(out), M, 256, 256, _lib.ptr(ws), wsb,
-                                      _lib.stream_ptr()), 'tn')
-    torch.cuda.synchronize()
-    t = ws[165 * 65536: 165 * 65536 + 16].cpu().view(8, 2)
-    print('nsplit', wsb // 4 // 65536)
-    prev_end = None
-    for r in t.tolist():
-        print(f'step start {int(r[0]):7d}  mfma+producer {int(r[1] - r[0]):6d}  barrier+loop {"" if prev_end is None else int(r[0] - prev_end)}')
-        prev_end = r[1]
-    return
-    print('stamps (cycles from K-step 8 start): top, loads landed, staged, barrier1, mfma(+loads issued) done, barrier2')
-    for r in t.tolist():
-        print('  '.join(f'{int(x):7d}' for x in r), '  | vmwait %d  stage %d  bar1 %d  mfma %d  bar2 %d' % (r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4]))
-
-
 if __name__ == '__main__':
-    if sys.argv[1] == 'timing':
-        timing(int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000)
-    elif sys.argv[1] == 'build':
+    if sys.argv[1] == 'build':
         build()
     else:
         run(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 10_000_000)
