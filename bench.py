@@ -167,11 +167,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_step = dt / a.steps * 1e3
-    spmm_ms = [e0.elapsed_time(e1) for e0, e1, _ in prof]
-    spmm_bytes = [b for _, _, b in prof]
+    spmm_ms = [e0.elapsed_time(e1) for e0, e1, _, _ in prof]
+    spmm_bytes = [b for _, _, b, _ in prof]                  # E(ds+4) + N(ds+4) [+4N] [+ds] per launch
+    extra_bytes = [x for _, _, _, x in prof]                 # fused forward store: mixed-in X0 row + ReLU mask bits
     avg_ms = sum(spmm_ms) / max(len(spmm_ms), 1)
     avg_bytes = sum(spmm_bytes) / max(len(spmm_bytes), 1)
+    avg_extra = sum(extra_bytes) / max(len(extra_bytes), 1)
     achieved = avg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    achieved_incl = (avg_bytes + avg_extra) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     if sharded:
         import torch.distributed as dist
         dist.barrier()
@@ -200,7 +203,8 @@ def main():
                    'parallelism': 'single GPU' if not sharded else f'node-sharded x{world} (RCCL all-gather exchange)'},
         'roofline': {'bound': 'hbm', 'kernel': f'k_spmm_rows (+hub kernels) d=256 {a.agg_dtype} source rows, f32 accumulate', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                      'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                     'launches_timed': len(spmm_ms), 'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': avg_bytes},
+                     'launches_timed': len(spmm_ms), 'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': avg_bytes,
+                     'fused_epilogue_bytes_per_launch': avg_extra, 'achieved_incl_fused_epilogue': achieved_incl},
     }
     if a.cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(a, n_nodes)

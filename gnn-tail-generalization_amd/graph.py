@@ -68,7 +68,7 @@ class CSRGraph:
         self._plan = self._make_plan(self.rowptr)
         self._plan_t = self._plan if self.symmetric else self._make_plan(self.rowptr_t)
         self._ws = None
-        self.profile = None      # bench.py sets a list: (start_event, end_event, algorithmic_bytes) per aggregation
+        self.profile = None      # bench.py sets a list: (start_event, end_event, SURVEY §8(d) bytes, extra epilogue bytes) per aggregation
 
     @classmethod
     def from_csr(cls, rowptr, col, n_cols, hub_threshold=HUB_THRESHOLD):
@@ -168,7 +168,7 @@ class CSRGraph:
         if prof is not None:
             ev1.record()
             prof.append((ev0, ev1, self.algorithmic_bytes(d, row_scale=row_scale is not None, bias=bias is not None,
-                                                          src_elem=2 if bf16 else 4)))
+                                                          src_elem=2 if bf16 else 4), 0))
         return out
 
     def algorithmic_bytes(self, d, elem=4, row_scale=True, bias=True, src_elem=None):

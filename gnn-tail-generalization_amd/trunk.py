@@ -63,8 +63,8 @@ def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False):
             _lib.stream_ptr()), 'cb_spmm_csr_fused_f32')
     if prof is not None:
         ev1.record()
-        # algorithmic bytes of the fused launch: the plain aggregation + the mixed-in row read + the mask bits
-        prof.append((ev0, ev1, g.algorithmic_bytes(d, src_elem=2 if bf16 else 4) + n * d * 4 + n * d // 8))
+        # SURVEY §8(d) bytes of the aggregation; the fused store's own streams (mixed-in row read + mask bits) are kept apart
+        prof.append((ev0, ev1, g.algorithmic_bytes(d, src_elem=2 if bf16 else 4), n * d * 4 + n * d // 8))
     return bits, out_next, act
 
 
