@@ -67,6 +67,14 @@ __device__ __forceinline__ void gather(float (&v)[VEC], const float* __restrict_
   }
 }
 
+// Row that is read exactly once (the mixed-in X0 row of the fused store): keep it out of L2 / Infinity Cache, which hold the
+// re-used hub source rows
+template <int VEC>
+__device__ __forceinline__ void gather_stream(float (&v)[VEC], const float* __restrict__ p) {
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) v[i] = __builtin_nontemporal_load(p + i);
+}
+
 // Source-row load of the aggregation: fp32 rows, or bf16-stored rows widened to fp32 (accumulation stays fp32)
 template <int VEC, typename HT>
 __device__ __forceinline__ void gather_in(float (&v)[VEC], const HT* __restrict__ p) {
@@ -174,7 +182,7 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
   if constexpr (FUSED) {
     if (fe.mix_src) {
       float t[VEC];
-      gather<VEC>(t, fe.mix_src + (int64_t)(r0 + rlo) * fe.ld_mix + c0);
+      gather_stream<VEC>(t, fe.mix_src + (int64_t)(r0 + rlo) * fe.ld_mix + c0);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) rmix[i] = t[i];
     }
@@ -196,7 +204,7 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
       fused_store(fe, (int64_t)(r0 + cur), c0, a4, s, b4, rmix);
       if (fe.mix_src && cur + 1 < nr) {
         float t[VEC];
-        gather<VEC>(t, fe.mix_src + (int64_t)(r0 + cur + 1) * fe.ld_mix + c0);
+        gather_stream<VEC>(t, fe.mix_src + (int64_t)(r0 + cur + 1) * fe.ld_mix + c0);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) rmix[i] = t[i];
       }
@@ -377,7 +385,7 @@ __global__ void __launch_bounds__(256) k_spmm_hub_finish(int d, int n_hubs, cons
     for (int k = 0; k < 4; ++k) { a4[k] = acc[k % VEC]; b4[k] = bvec[k % VEC]; }
     if (fe.mix_src) {
       float t[VEC];
-      gather<VEC>(t, fe.mix_src + (int64_t)row * fe.ld_mix + c0);
+      gather_stream<VEC>(t, fe.mix_src + (int64_t)row * fe.ld_mix + c0);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) rmix[k] = t[k];
     }
