@@ -163,8 +163,9 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (int64_t r = r_begin + w; r < r_end; r += kBlock / kWave) {
       const int64_t off = r * d + c;
-      const float4 gv = *reinterpret_cast<const float4*>(g + off);
-      float gm[4] = {gv.x, gv.y, gv.z, gv.w};
+      // g is read once (streaming)
+      float gm[4] = {__builtin_nontemporal_load(g + off), __builtin_nontemporal_load(g + off + 1), __builtin_nontemporal_load(g + off + 2),
+                     __builtin_nontemporal_load(g + off + 3)};
       if (thresh) {
         float m[4];
         keep4(seed, ((row0 + r) * d + c) >> 2, thresh, keep_scale, m);
