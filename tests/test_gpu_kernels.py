@@ -265,3 +265,34 @@ def test_gemm_three_limb_split_is_exact_on_special_values():
     at = a.t().contiguous()[:, :40].contiguous()
     out_t = gemm.mm_tn(eye.to(DEV), at.to(DEV)).cpu()       # I^T @ A^T
     assert torch.equal(out_t[big.t()[:, :40]], at[big.t()[:, :40]]) and (out_t - at).abs().max().item() <= 2.0 ** -126
+
+
+def test_gemm_full_size_properties():
+    """BASELINE full size (10^7 rows, 256 x 256 weights): size-independent properties of the dense contractions.
+    NN with the identity returns the operand bit for bit (the three-limb split is exact and every other limb product is an
+    exact zero), on every row block incl. the ragged last one; TN against a one-hot row selector returns the selected rows;
+    TN of ones gives exact column sums of small integers; both are deterministic across launches."""
+    from gnn_tail_generalization_amd import gemm
+    M, D = 10_000_003, 256
+    g = torch.Generator(device=DEV).manual_seed(11)
+    a = torch.randn(M, D, device=DEV, generator=g)
+    eye = torch.eye(D, device=DEV)
+    out = gemm.mm_nn(a, eye)
+    assert torch.equal(out, a)
+    del out
+    # TN: sel^T @ a with sel[r_j, j] = 1 picks rows r_j of a exactly
+    rows = torch.tensor([0, 1, 127, 128, 5_000_000, M - 2, M - 1, 777_777], device=DEV)
+    sel = torch.zeros(M, 8, device=DEV)
+    sel[rows, torch.arange(8, device=DEV)] = 1.0
+    picked = gemm.mm_tn(sel, a)
+    assert torch.equal(picked, a[rows])
+    # exact integer column sums (all partial sums < 2^24) and launch-to-launch determinism
+    ints = torch.randint(0, 2, (M, D), device=DEV, generator=g).float()
+    ones = torch.ones(M, 4, device=DEV)
+    s1 = gemm.mm_tn(ones, ints)
+    assert torch.equal(s1[0].double(), ints.sum(0, dtype=torch.float64)) and torch.equal(s1[0], s1[3])
+    w = torch.randn(D, D, device=DEV, generator=g)
+    z1, z2 = gemm.mm_nn(a, w), gemm.mm_nn(a, w)
+    assert torch.equal(z1, z2)
+    d1, d2 = gemm.mm_tn(a, z1), gemm.mm_tn(a, z1)
+    assert torch.equal(d1, d2)
