@@ -140,7 +140,14 @@ int cb_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
 /* step_dev (may be NULL): the step count read from device memory instead of `step` (hipGraph replay). */
 
 /* ------------------------------------------------------------------------------------
- * Dense contractions on the fp32 matrix cores (v_mfma_f32_32x32x2_f32; exact fp32).
+ * Dense fp32 contractions on the matrix cores.  Default: every fp32 operand is decomposed exactly into three
+ * bf16 limbs and the six leading limb products run as v_mfma_f32_32x32x16_bf16 with fp32 accumulation (error
+ * at the level of an fp32 GEMM, csrc/cb_gemm_limb.hip).  Operands that are not 16-byte aligned, or whose leading
+ * dimensions / K / N are not multiples of 4, and every call when CB_GEMM_PLAIN_F32=1 is set in the environment,
+ * use the fp32-input MFMA (v_mfma_f32_32x32x2_f32) instead.
+ * Differences from an IEEE fp32 GEMM on the limb path: an infinite operand yields NaN (inf - inf in the split)
+ * where fp32 would yield +-inf; limbs that fall below the smallest normal fp32 (|x| < ~2^-110) are flushed
+ * (absolute error < 2^-126).
  * ---------------------------------------------------------------------------------- */
 
 /* C[M,N] = act( rowscale[m] * (A[M,K] @ B[K,N]) + addend[m,n] + bias[n] ) — `feat_src = feat * norm`,
