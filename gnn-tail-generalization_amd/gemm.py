@@ -1,4 +1,5 @@
-"""Dense stages of the path on the hand-written fp32 MFMA kernels (csrc/cb_gemm.hip) with their
+"""Dense stages of the path on the hand-written MFMA kernels (csrc/cb_gemm_limb.hip: fp32 operands as three exact bf16
+limbs on the bf16 matrix cores, fp32 accumulate; csrc/cb_gemm.hip: fp32-input MFMA fallback) with their
 autograd.  Raw entry points: mm_nn / mm_tn; autograd stages: linear_rowscale (GCNConv transform,
 GNN_model/GCN.py:213,225,231) and linear (nn.Linear + optional ReLU, GCN.py:105-106,138)."""
 import torch
