@@ -170,3 +170,34 @@ def test_product_never_imports_oracle():
 
 
 _IMPORTS_ORACLE = re.compile(r"^\s*(import|from)\s+\S*(coldbrew_oracle|ref_import|oracle)|sys\.path\S*oracle|'oracle'|\"oracle\"", re.M)
+
+
+def test_three_limb_split_arithmetic_numpy():
+    """The arithmetic the default GEMM path relies on (csrc/cb_limb_core.h `split3`), restated in numpy: the truncating split
+    a = hi + mid + lo is exact with every limb a bf16 (low 16 bits of the fp32 pattern zero), and the six limb products the
+    kernels issue reproduce a*b to within 2^-20 |a*b| in the worst case (|mid| < 2^-7 |a|, |lo| < 2^-14 |a|, so the dropped
+    mid*lo + lo*mid + lo*lo < 2^-20 |a*b|) and to about 2^-24 |a*b| on average — inside the K * 2^-24 bound of an fp32 dot product."""
+    rng = np.random.default_rng(0)
+    a = np.concatenate([rng.standard_normal(20000).astype(np.float32) * np.exp(rng.uniform(-20, 20, 20000)).astype(np.float32),
+                        np.array([0.0, -0.0, 1.0, -1.0, 3.1415927, 16777215.0, 1.0000001, 3.4e37, 1e-30], dtype=np.float32)])
+
+    def split(x):
+        hi = (x.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+        r1 = x - hi                                     # exact: the low 16 significand bits
+        mid = (r1.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+        r2 = r1 - mid                                   # exact
+        lo = (r2.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)   # what the pack keeps of the last limb
+        return hi, mid, lo, r2
+
+    hi, mid, lo, r2 = split(a)
+    assert np.array_equal(lo, r2)                       # nothing is lost in the last limb: <= 8 significant bits remain
+    assert np.array_equal((hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64)).astype(np.float32), a)
+    assert np.array_equal(hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64), a.astype(np.float64))
+    b = np.roll(a, 7)
+    bh, bm, bl, _ = split(b)
+    f = lambda x: x.astype(np.float64)
+    six = f(hi) * f(bh) + f(hi) * f(bm) + f(mid) * f(bh) + f(hi) * f(bl) + f(lo) * f(bh) + f(mid) * f(bm)
+    exact = f(a) * f(b)
+    ok = np.isfinite(exact) & (np.abs(exact) > 1e-30) & (np.abs(exact) < 1e30)
+    rel = np.abs(six - exact)[ok] / np.abs(exact)[ok]
+    assert rel.max() <= 2.0 ** -20 and rel.mean() <= 2.0 ** -23.5
