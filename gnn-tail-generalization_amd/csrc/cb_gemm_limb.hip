@@ -1,12 +1,12 @@
 // fp32 contractions on the bf16 matrix cores by exact operand decomposition ("three-limb" GEMM).
 //
 // gfx950 runs v_mfma_f32_32x32x16_bf16 at 16x the rate of the fp32-input MFMA (2.5 PF/s vs 157 TF/s dense).  An fp32
-// value has a 24-bit significand = three 8-bit fields, and a bf16 holds exactly one such field with the full fp32 exponent
-// range, so   a = a_hi + a_mid + a_lo   with three bf16 limbs is an EXACT identity (truncating split, every residual
-// subtraction exact).  Then
+// value has a 24-bit significand and a bf16 keeps 8 significant bits with the full fp32 exponent range, so taking three
+// times the round-to-nearest bf16 of what is left gives   a = a_hi + a_mid + a_lo   EXACTLY (every residual subtraction is
+// exact; the last residual fits 8 bits), with |a_mid| <= 2^-8 |a| and |a_lo| <= 2^-17 |a|.  Then
 //     a*b = hi*hi + (hi*mid + mid*hi) + (hi*lo + lo*hi + mid*mid) + [mid*lo + lo*mid + lo*lo]
-// With |mid| < 2^-7 |a| and |lo| < 2^-14 |a| the bracket is below 2^-20 |a*b| in the worst case and about 2^-24.5 |a*b| on
-// average (tests/test_host_logic.py restates this in numpy) — inside the K * 2^-24 error bound of any fp32 dot product.
+// and the bracket is below 2^-24 |a*b| — half an ulp of the fp32 product, without bias (tests/test_host_logic.py restates
+// the split in numpy: worst case 2^-24.3, mean 2^-28 of |a*b|).
 // The kernels here issue the six leading limb products as bf16 MFMAs that accumulate in fp32 (each bf16 x bf16 product is
 // exact in the fp32 accumulator datapath), i.e. 6/16 of the fp32-MFMA time.  Measured against fp64 the result is at least as
 // accurate as an fp32 GEMM (this repository's fp32-MFMA kernel and hipBLASLt) on every shape and value distribution tried

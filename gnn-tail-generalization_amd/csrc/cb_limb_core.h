@@ -11,23 +11,30 @@ namespace cb {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// a == hi + mid + lo exactly; each limb is an fp32 bit pattern whose low 16 bits are zero (= a bf16 in the high half)
-__device__ __forceinline__ void split3(float a, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-  hi = __float_as_uint(a) & 0xffff0000u;
-  const float r1 = a - __uint_as_float(hi);
-  mid = __float_as_uint(r1) & 0xffff0000u;
-  lo = __float_as_uint(r1 - __uint_as_float(mid));   // <= 8 significant bits left: the pack below keeps all of them
+// a == hi + mid + lo exactly, each limb a bf16 obtained by round-to-nearest-even (v_cvt_pk_bf16_f32) of what is left:
+// |a - hi| <= 2^-9 |a|, |a - hi - mid| <= 2^-17 |a|, and the last residual has at most 8 significant bits, so its conversion
+// is exact.  Works on pairs because the hardware converts and packs two values per instruction.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float x0, float x1) {   // {bf16(x0), bf16(x1)} in one dword
+  const f32x2 v = {x0, x1};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
-// two limbs (high halves of x0, x1) -> one dword {bf16(x0), bf16(x1)}
-__device__ __forceinline__ uint32_t pack_hi16(uint32_t x0, uint32_t x1) { return __builtin_amdgcn_perm(x1, x0, 0x07060302u); }
+__device__ __forceinline__ void split3x2(float a0, float a1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  hi = cvt_pk_bf16(a0, a1);
+  const float r0 = a0 - __uint_as_float(hi << 16), r1 = a1 - __uint_as_float(hi & 0xffff0000u);       // exact
+  mid = cvt_pk_bf16(r0, r1);
+  const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);     // exact
+  lo = cvt_pk_bf16(s0, s1);                                                                            // exact
+}
 
 __device__ __forceinline__ void split4(const float (&v)[4], uint2 (&pl)[3]) {
-  uint32_t h[4], m[4], l[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) split3(v[i], h[i], m[i], l[i]);
-  pl[0] = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
-  pl[1] = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
-  pl[2] = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+  uint32_t h[2], m[2], l[2];
+  split3x2(v[0], v[1], h[0], m[0], l[0]);
+  split3x2(v[2], v[3], h[1], m[1], l[1]);
+  pl[0] = make_uint2(h[0], h[1]);
+  pl[1] = make_uint2(m[0], m[1]);
+  pl[2] = make_uint2(l[0], l[1]);
 }
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));

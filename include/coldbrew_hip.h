@@ -145,9 +145,9 @@ int cb_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
  * at the level of an fp32 GEMM, csrc/cb_gemm_limb.hip).  Operands that are not 16-byte aligned, or whose leading
  * dimensions / K / N are not multiples of 4, and every call when CB_GEMM_PLAIN_F32=1 is set in the environment,
  * use the fp32-input MFMA (v_mfma_f32_32x32x2_f32) instead.
- * Differences from an IEEE fp32 GEMM on the limb path: an infinite operand yields NaN (inf - inf in the split)
- * where fp32 would yield +-inf; limbs that fall below the smallest normal fp32 (|x| < ~2^-110) are flushed
- * (absolute error < 2^-126).
+ * Differences from an IEEE fp32 GEMM on the limb path: an infinite operand, or one above the largest bf16
+ * (|x| > 3.39e38), yields NaN (inf - inf in the split) where fp32 would yield +-inf / a finite value; limbs that
+ * fall below the smallest normal fp32 (|x| < ~2^-110) are flushed (absolute error < 2^-126).
  * ---------------------------------------------------------------------------------- */
 
 /* C[M,N] = act( rowscale[m] * (A[M,K] @ B[K,N]) + addend[m,n] + bias[n] ) — `feat_src = feat * norm`,
