@@ -13,10 +13,11 @@ CSRC = os.path.join(ROOT, 'gnn-tail-generalization_amd', 'csrc')
 BIN = os.path.join(ROOT, 'tools', 'probes', '_bin')
 
 VARIANTS = {
-    'nosplit': [('cb_gemm_limb.hip', '''  hi = __float_as_uint(a) & 0xffff0000u;
-  const float r1 = a - __uint_as_float(hi);
-  mid = __float_as_uint(r1) & 0xffff0000u;
-  lo = __float_as_uint(r1 - __uint_as_float(mid));''', '''  hi = __float_as_uint(a);
+    'nosplit': [('cb_limb_core.h', '''  hi = cvt_pk_bf16(a0, a1);
+  const float r0 = a0 - __uint_as_float(hi << 16), r1 = a1 - __uint_as_float(hi & 0xffff0000u);       // exact
+  mid = cvt_pk_bf16(r0, r1);
+  const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);     // exact
+  lo = cvt_pk_bf16(s0, s1);                                                                            // exact''', '''  hi = cvt_pk_bf16(a0, a1);
   mid = hi;
   lo = hi;''')],
     'mfma3': [('cb_gemm_limb.hip', '''    CB_MFMA4(a_mid, b_mid, H_, H_ * 6 + 2)                                                                                   \\
