@@ -68,7 +68,7 @@ struct RowOperand {
   }
   // base = &A[tile row 0][k0] (uniform); k_left = K - k0 > 0; K % 4 == 0
   template <int J>
-  __device__ __forceinline__ void load(float4 (&f)[NV], const float* __restrict__ base, int64_t ld, int64_t k_left, const float*,
+  __device__ __forceinline__ void load(float4 (&f)[NV], const float* __restrict__ base, int64_t /*ld*/, int64_t k_left, const float*,
                                        int t) const {
     f[J] = *reinterpret_cast<const float4*>(base + ((t & 3) * 4 < k_left ? voff[J] : 0u));
   }
@@ -114,7 +114,7 @@ struct ColOperand {
   // base = &B[step row 0][tile col 0] (uniform); k_left = operand rows from there > 0; kscale = their scales.
   // Lanes whose k row is past the end address row 0 of the step instead.
   template <int J>
-  __device__ __forceinline__ void load(float4 (&f)[NV], const float* __restrict__ base, int64_t ld, int64_t k_left,
+  __device__ __forceinline__ void load(float4 (&f)[NV], const float* __restrict__ base, int64_t /*ld*/, int64_t k_left,
                                        const float* __restrict__ kscale, int t) {
     const int k = t / TPR + KPP * J;
     const bool kin = k < k_left;
