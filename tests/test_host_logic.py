@@ -206,3 +206,17 @@ def test_three_limb_split_arithmetic_numpy():
     ok = np.isfinite(exact) & (np.abs(exact) > 1e-30) & (np.abs(exact) < 1e30)
     rel = np.abs(six - exact)[ok] / np.abs(exact)[ok]
     assert rel.max() <= 2.0 ** -24 and rel.mean() <= 2.0 ** -27
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/coldbrew_hip.h is the drop-in boundary: it must compile as C99 (extern "C" guards, no C++ / torch types)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('gcc not available')
+    src = tmp_path / 'h.c'
+    src.write_text('#include "coldbrew_hip.h"\nint main(void) { return cb_version() < 0; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include')
+    r = subprocess.run([gcc, '-std=c99', '-Wall', '-Wextra', '-Werror', '-fsyntax-only', '-I' + inc, str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
