@@ -1,0 +1,279 @@
+"""GPU: the kernels the headline bench actually times, at the sizes it runs them (S-pl10M: 10^7 nodes, 10^8
+edge_index columns, d = 256), compared against compositions of the separately oracle-tested operators; plus the
+BASELINE configurations at their FULL node counts against the oracle (configs 2 and 3) and the ogbn-products
+shape (config 4) through size-independent properties at full size and against the oracle on a sub-sample.
+
+Why compositions: the dense fp64 oracle cannot reach 10^7 rows, but every piece of the fused kernels
+(plain aggregation, ReLU, mix, Philox keep-mask, act_bwd) is pinned to the oracle at small sizes elsewhere
+(test_gpu_graph_spmm.py, test_gpu_kernels.py, test_gpu_random.py); what can only break at full size is the
+indexing — mask-bit word index (row*(d>>8)+(c0>>8))*4+lane, Philox counter (row0+row)*d+c0 beyond 2^31,
+X0-row prefetch, gx0 read-modify-write — and that is exactly what a composition compares element by element.
+"""
+import contextlib
+import io
+
+import pytest
+import torch
+
+import coldbrew_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def pl10m_graph():
+    from gnn_tail_generalization_amd.data import synthetic_data
+    from gnn_tail_generalization_amd.graph import CSRGraph
+    data = synthetic_data('S-pl10M', seed=0, device=DEV)
+    n = data.x.shape[0]
+    assert (n, data.edge_index.shape[1]) == (10_000_000, 100_000_000)
+    G = CSRGraph(data.edge_index, n)
+    del data
+    torch.cuda.empty_cache()
+    yield G
+    del G
+    torch.cuda.empty_cache()
+
+
+def _unpack_bits(bits, rows, d):
+    """bool [len(rows), d] from the forward's mask words: word k of (row, tile), bit l <-> column 256*tile + 4*l + k."""
+    b = bits[rows]                                     # [r, d/256, 4] int64
+    cols = torch.arange(d, device=bits.device)
+    tile, lane, k = cols // 256, (cols % 256) // 4, cols % 4
+    return ((b[:, tile, k] >> lane) & 1).bool()
+
+
+def _max_abs_diff_inplace(a, b):
+    """max |a - b| without a third [N, d] temporary (a is overwritten)."""
+    a.sub_(b).abs_()
+    return float(a.max())
+
+
+def test_fused_aggregation_store_full_size(pl10m_graph):
+    """cb_spmm_csr_fused_f32 at N = 10^7, d = 256, dropout on == plain aggregation + relu + mix + keep-mask."""
+    from gnn_tail_generalization_amd import ops, trunk
+    G = pl10m_graph
+    n, d, p, seed, alpha = G.N, 256, 0.1, 0x5EED1234, 0.1
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    z = torch.randn(n, d, device=DEV, generator=gen)
+    x0 = torch.randn(n, d, device=DEV, generator=gen)
+    bias = torch.randn(d, device=DEV, generator=gen)
+    bits, nxt, act = trunk._fused_spmm(G, z, bias, x0, 1 - alpha, alpha, p, seed, want_act=True)
+    ref_act = G.spmm(z, row_scale=G.norm_in, bias=bias, relu=True)
+    del z
+    # the activation leaves both kernels through the same arithmetic: bit-identical
+    assert torch.equal(act, ref_act)
+    del act
+    # mask bits on every row class: first / last wave blocks, hub rows, a random 200k sample
+    rows = torch.cat([torch.arange(0, 64, device=DEV), torch.arange(n - 64, n, device=DEV),
+                      G._plan.hub_rows[:4096].to(torch.int64), torch.randint(0, n, (200_000,), device=DEV, generator=gen)])
+    assert torch.equal(_unpack_bits(bits, rows, d), ref_act[rows] > 0)
+    # popcount over ALL rows equals the number of positive activations
+    pos_ref = int((ref_act > 0).sum())
+    tbl = torch.tensor([bin(i).count('1') for i in range(256)], dtype=torch.int64, device=DEV)
+    assert int(tbl[bits.view(-1).view(torch.uint8).to(torch.int64)].sum()) == pos_ref     # byte-wise popcount
+    # x_next = dropout((1-a) act + a x0): same formula, same keep-mask (pure function of seed and flat index)
+    keep = ops.dropout_keep_mask((n, d), p, seed, DEV)
+    ref_act.mul_(1 - alpha).add_(x0, alpha=alpha)
+    ref_act.div_(1 - p)
+    ref_act.mul_(keep)
+    del keep
+    assert _max_abs_diff_inplace(ref_act, nxt) <= 1e-5
+
+
+def test_trunk_backward_kernels_full_size(pl10m_graph):
+    """cb_trunk_layer_bwd_f32 / cb_trunk_input_bwd_f32 at N = 10^7, d = 256 == dropout-mask * g -> gx0 accumulate ->
+    ops.act_bwd composition; checks the in-place X0-gradient accumulation and the bias column sums."""
+    from gnn_tail_generalization_amd import ops, trunk
+    G = pl10m_graph
+    n, d, p, seed, alpha = G.N, 256, 0.1, 0xABCDEF01, 0.1
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    g = torch.randn(n, d, device=DEV, generator=gen)
+    act = torch.randn(n, d, device=DEV, generator=gen)              # stands for the forward activation: sign = ReLU mask
+    # forward-style mask words from `act` through the same packing the forward uses
+    bits = torch.zeros((n, 1, 4), dtype=torch.int64, device=DEV)
+    pos = act > 0
+    for kk in range(4):
+        sel = pos[:, kk::4].to(torch.int64)                          # columns 4l + kk, l = 0..63
+        w = (sel << torch.arange(64, device=DEV, dtype=torch.int64)).sum(dim=1)   # bit 63 wraps to the sign bit, as wanted
+        bits[:, 0, kk] = w
+        del sel, w
+    gx0_prev = torch.randn(n, d, device=DEV, generator=gen)
+    gx0 = gx0_prev.clone()
+    out, colsum = trunk._layer_bwd(g, bits, G.norm_in, gx0, True, p, seed, 0, 1 - alpha, alpha, True)
+    keep = ops.dropout_keep_mask((n, d), p, seed, DEV)
+    gm = (g / (1 - p)) * keep
+    del keep
+    # gx0 = gx0_prev + alpha * gm
+    gx0_prev.add_(gm, alpha=alpha)
+    assert _max_abs_diff_inplace(gx0_prev, gx0) <= 1e-5
+    del gx0_prev
+    gm.mul_(1 - alpha)
+    ref_out, ref_colsum = ops.act_bwd(gm, act, G.norm_in, want_out=True, want_colsum=True)
+    del gm
+    torch.testing.assert_close(colsum, ref_colsum, atol=2e-2, rtol=1e-4)      # 10^7-term fp32 column sums, different partial order
+    assert _max_abs_diff_inplace(ref_out, out) <= 1e-5
+    del ref_out, out
+    # input stage: gy = (add + dropout_bwd(g)) * (act > 0)
+    add = gx0
+    out2, colsum2 = trunk._input_bwd(g, add, act, p, seed + 1, 0)
+    keep = ops.dropout_keep_mask((n, d), p, seed + 1, DEV)
+    ref = (g / (1 - p)) * keep
+    del keep
+    ref.add_(add)
+    ref.mul_(pos)
+    torch.testing.assert_close(colsum2, ref.sum(dim=0), atol=5e-2, rtol=1e-4)
+    assert _max_abs_diff_inplace(ref, out2) <= 1e-5
+
+
+def _teacher(argv, dataset, n_override=None, dropout=0.0, seed=0):
+    from gnn_tail_generalization_amd.base_options import BaseOptions
+    from gnn_tail_generalization_amd.data import synthetic_data
+    from gnn_tail_generalization_amd.GNN_model import TeacherGNN
+    from gnn_tail_generalization_amd.utils import set_arch_configs
+    with contextlib.redirect_stdout(io.StringIO()):
+        args = BaseOptions().get_arguments([f'--dataset={dataset}', '--manual_assign_GPU=0'] + argv)
+    data = synthetic_data(dataset, seed=0, device=DEV, n_override=n_override)
+    args.N_nodes, args.dropout, args.device = data.x.shape[0], dropout, torch.device(DEV)
+    set_arch_configs(args)
+    torch.manual_seed(seed)
+    model = TeacherGNN(args).to(DEV)
+    return args, model, data
+
+
+def test_fused_step_equals_modular_step_s_pl1m():
+    """One full training step (dropout on) of the fused trunk vs the modular operator path on S-pl1M (10^6 nodes,
+    10^7 edge_index columns): logits, loss and every weight gradient agree."""
+    from gnn_tail_generalization_amd import ops
+    from gnn_tail_generalization_amd.GNN_model.GCN import TricksComb
+    args, model, data = _teacher(['--num_layers=3', '--use_special_split=0', '--whetherHasSE=000'], 'S-pl1M', dropout=0.1)
+    assert model.model.model.type_trick == 'InitialBatchNorm' and data.x.shape[0] == 1_000_000
+    res = {}
+    for fused in (True, False):
+        TricksComb.use_fused_trunk = fused
+        try:
+            model.train()
+            model.zero_grad()
+            ops._seed_override[:] = list(range(7000, 7010))
+            out = model(data.x, data.edge_index)
+            ops._seed_override[:] = []
+            loss = ops.nll_logsoftmax(out, data.y, data.train_mask)
+            loss.backward()
+            res[fused] = (out.detach().clone(), loss.detach().clone(),
+                          {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        finally:
+            TricksComb.use_fused_trunk = True
+    torch.testing.assert_close(res[True][0], res[False][0], atol=5e-5, rtol=1e-5)
+    torch.testing.assert_close(res[True][1], res[False][1], atol=1e-6, rtol=1e-6)
+    assert set(res[True][2]) == set(res[False][2])
+    for k in res[True][2]:
+        a, b = res[True][2][k], res[False][2][k]
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-9, k
+
+
+def _oracle_cfg(args):
+    return orc.make_cfg(type_trick=args.type_trick, num_layers=args.num_layers, num_feats=args.num_feats, dim_hidden=args.dim_hidden,
+                        num_classes=args.num_classes, res_alpha=args.res_alpha, whetherHasSE=tuple(args.TeacherGNN.whetherHasSE),
+                        se_reg=args.se_reg, node_norm_type=args.node_norm_type)
+
+
+def _product_vs_oracle(args, model, data, grad_rel=5e-4):
+    import oracle_c
+    from gnn_tail_generalization_amd import ops
+    model.train()
+    out = model(data.x, data.edge_index)
+    loss = nll = ops.nll_logsoftmax(out, data.y, data.train_mask)
+    if model.se_reg_all is not None:
+        loss = nll + args.se_reg * model.se_reg_all
+    loss.backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    csr = orc.build_csr(data.edge_index.cpu(), data.x.shape[0])
+    cfg = _oracle_cfg(args)
+    orc.set_aggregate(oracle_c.aggregate_sum)       # the C restatement of the aggregation (checked against numpy in test_oracle_c.py)
+    try:
+        o, reg = orc.teacher_forward(cfg, sd, data.x.cpu(), csr, training=True)
+        nll_o = orc.training_loss(cfg, o, None, data.y.cpu(), data.train_mask.cpu())
+        l = nll_o if reg is None else nll_o + cfg.se_reg * reg
+        l.backward()
+    finally:
+        orc.set_aggregate(None)
+    torch.testing.assert_close(out.detach().cpu(), o.detach(), atol=1e-4, rtol=1e-4)        # north_star: logits within 1e-4
+    torch.testing.assert_close(nll.detach().cpu(), nll_o.detach(), atol=1e-5, rtol=1e-5)
+    if reg is not None:
+        # The regulariser sum_l ||E_l||_F is compared against fp64, not against torch's CPU fp32 `th.norm` that the oracle
+        # (and the reference, GCN.py:232) call: on a 19 717 x 256 table that CPU kernel is 1.3e-4 low (float accumulation;
+        # measured here against fp64), which is summation error of the baseline, not semantics.  The classification part of
+        # the loss is compared on its own above.
+        reg64 = sum(torch.linalg.vector_norm(v.detach().double()) for k, v in sd.items() if k.endswith('.le'))
+        torch.testing.assert_close(model.se_reg_all.detach().cpu().double(), reg64, atol=0, rtol=2e-6)
+        torch.testing.assert_close(reg.detach().double(), reg64, atol=0, rtol=5e-4)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            torch.testing.assert_close(p.grad.cpu(), sd[k].grad, atol=2e-5, rtol=grad_rel, msg=lambda m, k=k: f'{k}: {m}')
+
+
+def test_config2_pubmed_shape_full_size_vs_oracle():
+    """BASELINE config 2 at its full node count (19 717 nodes, whetherHasSE=111, 2 layers, hidden 256), fp32."""
+    args, model, data = _teacher(['--whetherHasSE=111', '--num_layers=2', '--se_reg=0.5'], 'S-pubmed')
+    assert data.x.shape == (19717, 500) and model.model.model.type_trick == 'InitialBatchNorm'
+    _product_vs_oracle(args, model, data)
+
+
+def test_config3_arxiv_shape_full_size_vs_oracle():
+    """BASELINE config 3 at its full node count (169 343 nodes, 2 315 598 edge_index columns, 3 layers, hidden 256)."""
+    args, model, data = _teacher(['--num_layers=3', '--use_special_split=0'], 'S-arxiv')
+    assert data.x.shape == (169343, 128) and data.edge_index.shape[1] == 2 * 1157799
+    _product_vs_oracle(args, model, data)
+
+
+def test_config4_products_shape_subsample_vs_oracle():
+    """BASELINE config 4 (ogbn-products shape: F=100, H=256, C=47, 3 layers) on a 60 000-node instance of the same
+    synthetic family against the oracle."""
+    args, model, data = _teacher(['--num_layers=3', '--use_special_split=0'], 'S-products', n_override=60_000)
+    assert (args.num_feats, args.dim_hidden, args.num_classes) == (100, 256, 47)
+    _product_vs_oracle(args, model, data)
+
+
+def test_config4_products_shape_full_size_properties():
+    """BASELINE config 4 at full size (2 449 029 nodes, 123 718 280 edge_index columns): ingest == edge multiset
+    (bit-exact), aggregation checksums, and one full training step whose fused path equals the modular one."""
+    from gnn_tail_generalization_amd import ops
+    from gnn_tail_generalization_amd.GNN_model.GCN import TricksComb
+    args, model, data = _teacher(['--num_layers=3', '--use_special_split=0'], 'S-products', dropout=0.1)
+    n, E = data.x.shape[0], data.edge_index.shape[1]
+    assert (n, E) == (2_449_029, 123_718_280)
+    res = {}
+    for fused in (True, False):
+        TricksComb.use_fused_trunk = fused
+        try:
+            model.train()
+            model.zero_grad()
+            ops._seed_override[:] = list(range(8000, 8010))
+            out = model(data.x, data.edge_index)
+            ops._seed_override[:] = []
+            loss = ops.nll_logsoftmax(out, data.y, data.train_mask)
+            loss.backward()
+            res[fused] = (out.detach().clone(), loss.detach().clone(),
+                          {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        finally:
+            TricksComb.use_fused_trunk = True
+    torch.testing.assert_close(res[True][0], res[False][0], atol=1e-4, rtol=1e-5)
+    torch.testing.assert_close(res[True][1], res[False][1], atol=1e-6, rtol=1e-6)
+    for k in res[True][2]:
+        a, b = res[True][2][k], res[False][2][k]
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-9, k
+    G = model.model.model.dglgraph
+    ei = data.edge_index
+    assert torch.equal(G.in_degrees(), torch.bincount(ei[1], minlength=n))
+    rows = torch.repeat_interleave(torch.arange(n, device=DEV), G.in_degrees())
+    key_csr = rows * n + G.col.to(torch.int64)
+    assert torch.equal(key_csr, torch.sort(ei[1] * n + ei[0])[0])             # same multiset, bit-exact
+    del rows, key_csr
+    assert G.symmetric and G.n_zero_in_degree == 0
+    h = torch.rand(n, 256, device=DEV)
+    agg = G.spmm(h)
+    lhs = agg.sum(dim=0, dtype=torch.float64)
+    rhs = (h.double() * G.out_degrees().double().unsqueeze(1)).sum(dim=0)
+    torch.testing.assert_close(lhs, rhs, rtol=1e-6, atol=0)
+    assert torch.equal(agg, G.spmm(h))
