@@ -24,6 +24,7 @@ import sys
 import time
 
 import torch
+import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -39,6 +40,10 @@ def parse():
     ap.add_argument('--dataset', default='S-pl10M', help='synthetic workload (S-pl10M = BASELINE headline config)')
     ap.add_argument('--cpu-baseline', type=int, default=1)
     ap.add_argument('--cpu-sample-nodes', type=int, default=200000)
+    ap.add_argument('--cpu-baseline-mode', default='auto', choices=['auto', 'full', 'sample'],
+                    help='full = one measured full-size oracle step on the host cores; sample = sub-sampled + scaled (fallback)')
+    ap.add_argument('--cpu-budget-s', type=float, default=20.0, help='keep timing full-size CPU steps until this many seconds (max 3 steps)')
+    ap.add_argument('--ref-epochs', type=int, default=2, help='epochs of the reference epoch (2 train fwd + 1 bwd + 1 eval fwd) to time; 0 = skip')
     ap.add_argument('--hip-graph', type=int, default=0, help='replay the step as one hipGraph (pays off on launch-bound small graphs)')
     ap.add_argument('--agg-dtype', default='f32', choices=['f32', 'bf16'], help='bf16 = build-extension storage of the gathered rows')
     return ap.parse_args()
@@ -52,18 +57,42 @@ def make_args(dataset, extra=()):
         return BaseOptions().get_arguments(argv)
 
 
-def cpu_baseline(a, full_nodes):
-    """Oracle training step (fwd + loss + bwd + Adam) on a node-subsampled instance of the same
-    synthetic family, all host cores (torch intra-op + OpenMP aggregation)."""
+def _host_info():
+    model = ''
+    with contextlib.suppress(Exception):
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    avail = 0
+    with contextlib.suppress(Exception):
+        for line in open('/proc/meminfo'):
+            if line.startswith('MemAvailable'):
+                avail = int(line.split()[1]) * 1024
+    return model, avail
+
+
+def _oracle_modules():
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import coldbrew_oracle as orc
     import oracle_c
+    return orc, oracle_c
+
+
+def _cpu_threads():
+    n = os.cpu_count() or 1
+    return max(1, min(n // 2 if n >= 16 else n, 128))      # one thread per physical core (SMT siblings only add contention)
+
+
+def cpu_baseline_sample(a, args, full_nodes):
+    """Fallback: oracle training step on a node-subsampled instance of the same synthetic family, scaled linearly."""
+    orc, oracle_c = _oracle_modules()
     from gnn_tail_generalization_amd.data import synthetic_data
-    cores = min(os.cpu_count() or 1, 32)   # more threads only add barrier/NUMA cost on these small per-op sizes
+    cores = min(_cpu_threads(), 32)   # more threads only add barrier/NUMA cost on these small per-op sizes
     torch.set_num_threads(cores)
+    oracle_c.set_num_threads(cores)
     n = min(a.cpu_sample_nodes, full_nodes)
     data = synthetic_data(a.dataset, seed=0, device='cpu', n_override=n if n < full_nodes else None)
-    args = make_args(a.dataset)
     cfg = orc.make_cfg(type_trick=args.type_trick, num_layers=args.num_layers, num_feats=args.num_feats, dim_hidden=args.dim_hidden,
                        num_classes=args.num_classes, dropout=0.0, res_alpha=args.res_alpha, se_reg=args.se_reg)
     torch.manual_seed(0)
@@ -86,10 +115,104 @@ def cpu_baseline(a, full_nodes):
     finally:
         orc.set_aggregate(None)
     scale = n / full_nodes
-    return {'value': (1.0 / dt) * scale, 'unit': 'steps/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{a.dataset} family sub-sampled to N={n} nodes / E={csr.E} edges ({k} timed steps, {dt:.3f} s/step); '
+    return {'value': (1.0 / dt) * scale, 'unit': 'steps/s', 'cores': cores, 'kind': 'port', 'measured': False,
+            'sample': f'EXTRAPOLATED: {a.dataset} family sub-sampled to N={n} nodes / E={csr.E} edges ({k} timed steps, {dt:.3f} s/step); '
                       f'value = sample steps/s x {scale:.4g} (linear in nodes) to the full {full_nodes}-node workload; '
                       'dropout masks omitted (p=0) on the CPU leg'}
+
+
+def cpu_baseline_full(a, args, trainer, sd0, graph_obj, budget_s):
+    """MEASURED: the oracle's training step (torch CPU ops + the C/OpenMP aggregation of oracle/coldbrew_oracle.c) on the
+    SAME full-size inputs, initial weights and dropout rate as the GPU leg (keep-masks drawn by the product's Philox
+    generator and injected, as in the parity tests).  One thread per physical core."""
+    from types import SimpleNamespace
+    import numpy as np
+    orc, oracle_c = _oracle_modules()
+    from gnn_tail_generalization_amd import ops
+    cores = _cpu_threads()
+    torch.set_num_threads(cores)
+    oracle_c.set_num_threads(cores)
+    d = trainer.data
+    n, E = int(d.x.shape[0]), int(d.edge_index.shape[1])
+    t_setup = time.time()
+    x, y, mask = d.x.cpu(), d.y.cpu(), d.train_mask.cpu()
+    src, dst = d.edge_index[0].cpu().numpy(), d.edge_index[1].cpu().numpy()
+    rowptr, col = oracle_c.csr_from_coo(dst, src, n)                 # by-dst CSR (GCN.py:93-94)
+    if graph_obj.symmetric:
+        rowptr_t, col_t = rowptr, col
+    else:
+        rowptr_t, col_t = oracle_c.csr_from_coo(src, dst, n)
+    deg_in, deg_out = np.diff(rowptr), np.diff(rowptr_t)
+    csr = SimpleNamespace(N=n, E=E, rowptr=rowptr, col=col, rowptr_t=rowptr_t, col_t=col_t, in_deg=deg_in, out_deg=deg_out,
+                          src=src, dst=dst)
+    p = float(args.dropout)
+    cfg = orc.make_cfg(type_trick=args.type_trick, num_layers=args.num_layers, num_feats=args.num_feats, dim_hidden=args.dim_hidden,
+                       num_classes=args.num_classes, dropout=p, res_alpha=args.res_alpha, se_reg=args.se_reg)
+    masks = None
+    if p > 0:
+        L, H = args.num_layers, args.dim_hidden
+        shapes = [(n, args.num_feats)] + [(n, H)] * L + [(n, H)]
+        masks = [ops.dropout_keep_mask(s, p, 1234 + i, d.x.device).cpu() for i, s in enumerate(shapes)]
+    sd = {k: v.clone() for k, v in sd0.items()}
+    t_setup = time.time() - t_setup
+    orc.set_aggregate(oracle_c.aggregate_sum)
+    try:
+        t0 = time.time()
+        k = 0
+        while k < 1 or (time.time() - t0 < budget_s and k < 3):
+            orc.train_steps(cfg, sd, x, csr, y, mask, 1, lr=args.lr, weight_decay=args.weight_decay,
+                            dropout_masks_per_step=[masks] if masks is not None else None)
+            k += 1
+        dt = (time.time() - t0) / k
+    finally:
+        orc.set_aggregate(None)
+    model, _ = _host_info()
+    return {'value': 1.0 / dt, 'unit': 'steps/s', 'cores': cores, 'kind': 'port', 'measured': True, 'cpu_model': model,
+            'host_logical_cpus': os.cpu_count(), 'torch_threads': torch.get_num_threads(), 'omp_threads': cores,
+            'sample': f'MEASURED at full size: {k} timed step(s) of the whole {a.dataset} workload (N={n}, E={E}, '
+                      f'{dt:.2f} s/step; no extrapolation), same inputs, initial weights and dropout p={p} (injected keep-masks) '
+                      f'as the GPU leg; host set-up (copies, CSR build, masks) {t_setup:.1f} s not timed'}
+
+
+def cpu_baseline(a, args, trainer, sd0, graph_obj, full_nodes):
+    """`cpu_baseline` object of the bench line.  full = one real full-size step (needs host RAM for ~45 activation-sized
+    tensors); sample = the sub-sampled, linearly scaled fallback (labelled EXTRAPOLATED)."""
+    mode = a.cpu_baseline_mode
+    if mode == 'auto':
+        _, avail = _host_info()
+        need = 45 * full_nodes * max(args.dim_hidden, args.num_feats) * 4 * 1.5
+        mode = 'full' if (avail >= need and (os.cpu_count() or 1) >= 32) else 'sample'
+    if mode == 'full':
+        return cpu_baseline_full(a, args, trainer, sd0, graph_obj, a.cpu_budget_s)
+    return cpu_baseline_sample(a, args, full_nodes)
+
+
+def reference_epoch_rate(t, args, epochs, sync):
+    """Epochs/s of the reference's own epoch (train_net: run_trainSet with the metrics-only second train-mode forward of
+    want_headtail=1, trainer_node_classification.py:397-413, + run_testSet's eval forward, :453-495) = 2 train forwards +
+    1 backward + Adam + 1 eval forward + the accuracy reductions with their host syncs."""
+    from gnn_tail_generalization_amd.utils import save_graph_analyze
+    t0 = time.perf_counter()
+    with contextlib.redirect_stdout(io.StringIO()):
+        save_graph_analyze(t.global_nodes(), t.data, 0, verbose=False)       # head / tail node sets (utils.py:680-729)
+    torch.cuda.synchronize()
+    analyze_s = time.perf_counter() - t0
+    for name in ('large_deg_idx', 'small_deg_idx'):
+        setattr(t.data, name, torch.as_tensor(getattr(t.data, name), device=t.device))
+    old = args.want_headtail
+    args.want_headtail = 1
+    try:
+        t.train_net()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(epochs):
+            t.train_net()
+        sync()
+        dt = time.perf_counter() - t0
+    finally:
+        args.want_headtail = old
+    return {'epochs_per_sec_reference_epoch': epochs / dt, 'reference_epoch_ms': dt / epochs * 1e3,
+            'head_tail_split_s': analyze_s}
 
 
 def main():
@@ -108,7 +231,6 @@ def main():
     dev = torch.device(f'cuda:{local_rank}')
     sharded = world > 1 or os.environ.get('COLDBREW_FORCE_SHARDED') == '1'   # the latter: exercise the sharded code on 1 GPU
     if sharded:
-        import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
@@ -129,11 +251,12 @@ def main():
     graph_obj = t.graph()
     n_nodes, n_edges = t.global_nodes(), t.global_edges()
     L = args.num_layers
+    sd0 = {k: v.detach().cpu().clone() for k, v in t.teacherGNN.state_dict().items()} if not sharded else None
+    torch.cuda.reset_peak_memory_stats(dev)
 
     def sync():
         torch.cuda.synchronize()
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -162,11 +285,15 @@ def main():
     if not use_graph:
         prof, graph_obj.profile = graph_obj.profile, None
     if world > 1:
-        import torch.distributed as dist
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_step = dt / a.steps * 1e3
+    peak_mem = torch.cuda.max_memory_allocated(dev)
+    if world > 1:
+        pm = torch.tensor([peak_mem], device=dev, dtype=torch.float64)
+        dist.all_reduce(pm, op=dist.ReduceOp.MAX)
+        peak_mem = float(pm.item())
     spmm_ms = [e0.elapsed_time(e1) for e0, e1, _, _ in prof]
     spmm_bytes = [b for _, _, b, _ in prof]                  # E(ds+4) + N(ds+4) [+4N] [+ds] per launch
     extra_bytes = [x for _, _, _, x in prof]                 # fused forward store: mixed-in X0 row + ReLU mask bits
@@ -175,17 +302,26 @@ def main():
     avg_extra = sum(extra_bytes) / max(len(extra_bytes), 1)
     achieved = avg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     achieved_incl = (avg_bytes + avg_extra) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    ref_epoch = None
+    if a.ref_epochs > 0 and not sharded and not use_graph:
+        ref_epoch = reference_epoch_rate(t, args, a.ref_epochs, sync)
     if sharded:
-        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
     if rank != 0:
         return
-    traffic = None
+    # HBM-side bytes of the aggregation from the PMC counters: not collected by this process (counters need a rocprofv3
+    # run); the committed profile's figure is carried under its own name, `traffic` stays null unless measured in-run
+    traffic_profile = None
     pmc = os.path.join(ROOT, 'profiles', 'spmm_pmc_traffic.json')
     if os.path.isfile(pmc):
         with contextlib.suppress(Exception):
-            traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+            traffic_profile = json.load(open(pmc)).get('hbm_bytes_per_launch')
+    if sharded:
+        par = (f'node-sharded x{world}, 1-D row partition ({t.part.kind}), RCCL {t.sgraph.exchange_kind} exchange'
+               f'{" overlapped with the interior-column aggregation" if t.sgraph.overlap else ""}; roofline figures are per rank (rank 0 shard)')
+    else:
+        par = 'single GPU'
     out = {
         'metric': 'teachergnn_fullgraph_train_steps_per_sec', 'value': a.steps / dt, 'unit': 'steps/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
@@ -200,14 +336,17 @@ def main():
                    'launch': 'one hipGraph replay per step' if use_graph else 'eager launches',
                    'gemm': ('fp32-input MFMA' if os.environ.get('CB_GEMM_PLAIN_F32') else
                             'fp32 operands as three exact bf16 limbs, 6 bf16 MFMA products, fp32 accumulate (error <= fp32 GEMM)'),
-                   'parallelism': 'single GPU' if not sharded else f'node-sharded x{world} (RCCL all-gather exchange)'},
+                   'parallelism': par},
         'roofline': {'bound': 'hbm', 'kernel': f'k_spmm_rows (+hub kernels) d=256 {a.agg_dtype} source rows, f32 accumulate', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                     'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                     'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'traffic_from_profile': traffic_profile,
                      'launches_timed': len(spmm_ms), 'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': avg_bytes,
                      'fused_epilogue_bytes_per_launch': avg_extra, 'achieved_incl_fused_epilogue': achieved_incl},
     }
-    if a.cpu_baseline and world == 1:
-        out['cpu_baseline'] = cpu_baseline(a, n_nodes)
+    out['peak_mem_gb'] = peak_mem / 2 ** 30
+    if ref_epoch is not None:
+        out.update(ref_epoch)
+    if a.cpu_baseline and world == 1 and not sharded:
+        out['cpu_baseline'] = cpu_baseline(a, args, t, sd0, graph_obj, n_nodes)
     os.write(json_fd, (json.dumps(out) + '\n').encode())
 
 

@@ -26,6 +26,7 @@
 
 #include "cb_common.h"
 #include "cb_philox.h"
+#include "cb_spmm_small.h"
 
 namespace cb {
 
@@ -499,6 +500,10 @@ extern "C" int cb_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_
   const bool al16 = ((uintptr_t)h % 16 == 0) && ((uintptr_t)out % 16 == 0) && (ld_h % 4 == 0) && (ld_out % 4 == 0) && (d % 4 == 0);
   const bool al8 = ((uintptr_t)h % 8 == 0) && ((uintptr_t)out % 8 == 0) && (ld_h % 2 == 0) && (ld_out % 2 == 0) && (d % 2 == 0);
   float* partial = (float*)ws;
+  static const bool small_off = getenv("CB_SPMM_NO_SMALL") != nullptr;   // measurement hook: one wavefront per gathered row at every width
+  if (!small_off && spmm_small_eligible(d, al16))
+    return launch_spmm_small(rowptr, col, N, h, ld_h, d, row_scale, bias, relu, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows,
+                             hub_chunk_ptr, partial, partial_ld(d), al16, st);
   if (al16 && d >= 256)
     return launch_spmm<4>(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st);
   if (al8 && d >= 128)

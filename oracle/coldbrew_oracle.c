@@ -13,6 +13,18 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* thread count of the aggregation (bench.py reports it as `cores`); 0 = OpenMP default */
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 
 /* rows = major key, in-row order = ascending minor key (stable two-pass counting sort) */
 int orc_csr_from_coo(const int64_t* major, const int64_t* minor, int64_t E, int64_t N, int64_t* rowptr, int32_t* col) {

@@ -25,8 +25,14 @@ def load(build=True):
         lib.orc_deg_norm.argtypes = [P, I64, P]
         lib.orc_spmm_csr.restype = None
         lib.orc_spmm_csr.argtypes = [P, P, I64, P, I64, P, P, ctypes.c_int, P]
+        lib.orc_set_num_threads.restype = None
+        lib.orc_set_num_threads.argtypes = [ctypes.c_int]
         _lib = lib
     return _lib
+
+
+def set_num_threads(n):
+    load().orc_set_num_threads(int(n))
 
 
 def _p(a):
