@@ -107,6 +107,10 @@ struct Epilogue {
   const float* row_scale;  // [N] or null
   const float* bias;       // [d] or null
   int relu;
+  // ACC kernels only: partial sums [N, ld_init] the reduction starts from (the interior-column pass of the node-sharded
+  // path, dist.py: out = act(row_scale * (acc_init + sum over THIS CSR's columns) + bias))
+  const float* acc_init;
+  int64_t ld_init;
 };
 
 // Extended epilogue of the fused residual trunk (GCN.py:127-133 folded into the aggregation's store):
@@ -173,12 +177,17 @@ __device__ __forceinline__ void write_row(float* __restrict__ out_row, const flo
 
 // Walks the contiguous edge range of local rows [rlo, rhi) of this wavefront's row block.
 // my_ptr: lane i holds rowptr[r0 + i] (i <= nr).  All control flow is wave-uniform.
-template <int VEC, int U, bool FULL, bool FUSED, typename HT>
+template <int VEC, int U, bool FULL, bool FUSED, bool ACC, typename HT>
 __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr, float my_scale, int r0, const int* __restrict__ col,
                                             const HT* __restrict__ h_lane, int64_t ld_h, float* __restrict__ out_lane,
                                             int64_t ld_out, bool active_in, int relu, const float (&bvec)[VEC], const FusedEpi& fe,
-                                            int c0) {
+                                            int c0, const float* __restrict__ init_lane, int64_t ld_init) {
   const bool active = FULL ? true : active_in;
+  float ainit[VEC];                          // ACC: partial sums of local row `cur`, fetched one row ahead (read once: streaming)
+  zero<VEC>(ainit);
+  if constexpr (ACC) {
+    if (active) gather_stream<VEC>(ainit, init_lane + (int64_t)(r0 + rlo) * ld_init);
+  }
   float rmix[4] = {0.f, 0.f, 0.f, 0.f};   // FUSED: mix_src row of local row `cur`, fetched one row ahead
   if constexpr (FUSED) {
     if (fe.mix_src) {
@@ -198,6 +207,11 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
 
   auto flush = [&]() {
     const float s = __int_as_float(bcast_lane(__float_as_int(my_scale), cur));  // row scale of local row `cur`
+    if constexpr (ACC) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += ainit[i];
+      if (active && cur + 1 < rhi) gather_stream<VEC>(ainit, init_lane + (int64_t)(r0 + cur + 1) * ld_init);
+    }
     if constexpr (FUSED) {
       float a4[4], b4[4];
 #pragma unroll
@@ -252,7 +266,7 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
   while (cur < rhi) flush();  // last row + trailing empty rows
 }
 
-template <int VEC, int RPW, int U, bool FULL, bool FUSED, typename HT>
+template <int VEC, int RPW, int U, bool FULL, bool FUSED, typename HT, bool ACC = false>
 __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                    const HT* __restrict__ h, int64_t ld_h, float* __restrict__ out,
                                                    int64_t ld_out, int n_rows, int d, Epilogue ep, int hub_T, FusedEpi fe) {
@@ -280,15 +294,19 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
   }
   const HT* h_lane = h + c0;
   float* out_lane = out + c0;
+  const float* init_lane = ACC ? ep.acc_init + c0 : nullptr;
 
   if (hubmask == 0) {
-    stream_rows<VEC, U, FULL, FUSED, HT>(0, nr, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0);
+    stream_rows<VEC, U, FULL, FUSED, ACC, HT>(0, nr, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0,
+                                              init_lane, ep.ld_init);
   } else {
     int r = 0;
     while (r < nr) {  // maximal hub-free runs; hub rows are written by the hub kernels
       unsigned long long m = hubmask >> r;
       int nh = m ? r + (__ffsll((long long)m) - 1) : nr;
-      if (nh > r) stream_rows<VEC, U, FULL, FUSED, HT>(r, nh, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0);
+      if (nh > r)
+        stream_rows<VEC, U, FULL, FUSED, ACC, HT>(r, nh, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe,
+                                                  c0, init_lane, ep.ld_init);
       r = nh + 1;
     }
   }
@@ -373,6 +391,12 @@ __global__ void __launch_bounds__(256) k_spmm_hub_finish(int d, int n_hubs, cons
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] += v[k];
   }
+  if (ep.acc_init) {   // node-sharded path: partial sums of the interior-column pass
+    float v[VEC];
+    gather<VEC>(v, ep.acc_init + (int64_t)row * ep.ld_init + c0);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] += v[k];
+  }
   float bvec[VEC];
   zero<VEC>(bvec);
   if (ep.bias) {
@@ -408,16 +432,18 @@ static int launch_spmm_cfg(const int32_t* rowptr, const int32_t* col, int64_t N,
   {
     int64_t n_waves = (N + RPW - 1) / RPW;
     dim3 grid((unsigned)((n_waves + waves_per_block - 1) / waves_per_block), ny);
+#define CB_ROWS_LAUNCH(FULL_, FUSED_, ACC_)                                                                                         \
+  hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, FULL_, FUSED_, HT, ACC_>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h, \
+                     out, ld_out, (int)N, (int)d, ep, hub_T, fe)
+    const bool acc = ep.acc_init != nullptr;
     if constexpr (FUSED) {
-      hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, true, true, HT>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h,
-                         out, ld_out, (int)N, (int)d, ep, hub_T, fe);
+      if (acc) CB_ROWS_LAUNCH(true, true, true); else CB_ROWS_LAUNCH(true, true, false);
     } else if (d % tile == 0) {
-      hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, true, false, HT>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h,
-                         out, ld_out, (int)N, (int)d, ep, hub_T, fe);
+      if (acc) CB_ROWS_LAUNCH(true, false, true); else CB_ROWS_LAUNCH(true, false, false);
     } else {
-      hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, false, false, HT>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h,
-                         out, ld_out, (int)N, (int)d, ep, hub_T, fe);
+      if (acc) CB_ROWS_LAUNCH(false, false, true); else CB_ROWS_LAUNCH(false, false, false);
     }
+#undef CB_ROWS_LAUNCH
     CB_LAUNCH_CHECK();
   }
   if (n_hubs > 0) {
@@ -481,27 +507,29 @@ extern "C" size_t cb_spmm_workspace_bytes(int64_t n_chunks, int64_t d) {
   return (size_t)n_chunks * (size_t)partial_ld(d) * sizeof(float);
 }
 
-extern "C" int cb_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h,
-                               int64_t d, const float* row_scale, const float* bias, int relu, float* out, int64_t ld_out,
-                               int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
-                               const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
-  CB_CHECK_ARG(N >= 0 && E >= 0 && d >= 0, CB_E_INVALID, "cb_spmm_csr_f32: negative size");
-  CB_CHECK_ARG(N < INT32_MAX && E < INT32_MAX && d < (1 << 20), CB_E_RANGE, "cb_spmm_csr_f32: size exceeds the int32 contract");
+static int spmm_plain_impl(const char* who, const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h,
+                           int64_t d, const float* row_scale, const float* bias, int relu, const float* acc_init, int64_t ld_init,
+                           float* out, int64_t ld_out, int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
+                           const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(N >= 0 && E >= 0 && d >= 0, CB_E_INVALID, "%s: negative size", who);
+  CB_CHECK_ARG(N < INT32_MAX && E < INT32_MAX && d < (1 << 20), CB_E_RANGE, "%s: size exceeds the int32 contract", who);
   if (N == 0 || d == 0) return CB_OK;
-  CB_CHECK_ARG(rowptr && h && out && (E == 0 || col), CB_E_INVALID, "cb_spmm_csr_f32: null pointer");
-  CB_CHECK_ARG(ld_h >= d && ld_out >= d, CB_E_INVALID, "cb_spmm_csr_f32: leading dimension smaller than d");
-  CB_CHECK_ARG(hub_T > 0 && n_hubs >= 0 && n_chunks >= 0, CB_E_INVALID, "cb_spmm_csr_f32: bad hub plan");
+  CB_CHECK_ARG(rowptr && h && out && (E == 0 || col), CB_E_INVALID, "%s: null pointer", who);
+  CB_CHECK_ARG(ld_h >= d && ld_out >= d && (!acc_init || ld_init >= d), CB_E_INVALID, "%s: leading dimension smaller than d", who);
+  CB_CHECK_ARG(hub_T > 0 && n_hubs >= 0 && n_chunks >= 0, CB_E_INVALID, "%s: bad hub plan", who);
   CB_CHECK_ARG(n_hubs == 0 || (hub_rows && hub_chunk_ptr && ws && ws_bytes >= cb_spmm_workspace_bytes(n_chunks, d)),
-               CB_E_WORKSPACE, "cb_spmm_csr_f32: hub plan given but workspace missing/too small (%zu < %zu)", ws_bytes,
+               CB_E_WORKSPACE, "%s: hub plan given but workspace missing/too small (%zu < %zu)", who, ws_bytes,
                cb_spmm_workspace_bytes(n_chunks, d));
-  Epilogue ep{row_scale, bias, relu};
+  Epilogue ep{row_scale, bias, relu, acc_init, ld_init};
   hipStream_t st = (hipStream_t)stream;
   if (n_hubs == 0) hub_T = INT32_MAX;  // no plan given (or no hub rows): every row is reduced whole by one wavefront
-  const bool al16 = ((uintptr_t)h % 16 == 0) && ((uintptr_t)out % 16 == 0) && (ld_h % 4 == 0) && (ld_out % 4 == 0) && (d % 4 == 0);
-  const bool al8 = ((uintptr_t)h % 8 == 0) && ((uintptr_t)out % 8 == 0) && (ld_h % 2 == 0) && (ld_out % 2 == 0) && (d % 2 == 0);
+  const bool ini16 = !acc_init || (((uintptr_t)acc_init % 16 == 0) && ld_init % 4 == 0);
+  const bool ini8 = !acc_init || (((uintptr_t)acc_init % 8 == 0) && ld_init % 2 == 0);
+  const bool al16 = ((uintptr_t)h % 16 == 0) && ((uintptr_t)out % 16 == 0) && (ld_h % 4 == 0) && (ld_out % 4 == 0) && (d % 4 == 0) && ini16;
+  const bool al8 = ((uintptr_t)h % 8 == 0) && ((uintptr_t)out % 8 == 0) && (ld_h % 2 == 0) && (ld_out % 2 == 0) && (d % 2 == 0) && ini8;
   float* partial = (float*)ws;
   static const bool small_off = getenv("CB_SPMM_NO_SMALL") != nullptr;   // measurement hook: one wavefront per gathered row at every width
-  if (!small_off && spmm_small_eligible(d, al16))
+  if (!small_off && !acc_init && spmm_small_eligible(d, al16))
     return launch_spmm_small(rowptr, col, N, h, ld_h, d, row_scale, bias, relu, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows,
                              hub_chunk_ptr, partial, partial_ld(d), al16, st);
   if (al16 && d >= 256)
@@ -511,7 +539,26 @@ extern "C" int cb_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_
   return launch_spmm<1>(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st);
 }
 
-static int spmm_fused_impl(int h_bf16, const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const void* h, int64_t ld_h,
+extern "C" int cb_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h,
+                               int64_t d, const float* row_scale, const float* bias, int relu, float* out, int64_t ld_out,
+                               int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
+                               const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
+  return spmm_plain_impl("cb_spmm_csr_f32", rowptr, col, N, E, h, ld_h, d, row_scale, bias, relu, nullptr, 0, out, ld_out, hub_T, n_hubs,
+                         n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, stream);
+}
+
+// out = act(row_scale * (acc_init + sum over this CSR's columns) + bias): the second (halo-column) pass of the node-sharded
+// aggregation; acc_init holds the raw sums of the interior-column pass (dist.py).  acc_init may alias out.
+extern "C" int cb_spmm_csr_acc_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h,
+                                   int64_t d, const float* row_scale, const float* bias, int relu, const float* acc_init,
+                                   int64_t ld_init, float* out, int64_t ld_out, int32_t hub_T, int32_t n_hubs, int32_t n_chunks,
+                                   const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(acc_init != nullptr || N == 0 || d == 0, CB_E_INVALID, "cb_spmm_csr_acc_f32: acc_init is null");
+  return spmm_plain_impl("cb_spmm_csr_acc_f32", rowptr, col, N, E, h, ld_h, d, row_scale, bias, relu, acc_init, ld_init, out, ld_out, hub_T,
+                         n_hubs, n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, stream);
+}
+
+static int spmm_fused_impl(int h_bf16, const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const void* h, int64_t ld_h,
                                      int64_t d, const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix,
                                      float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits,
                                      float* out_act, int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_T,
@@ -526,11 +573,13 @@ static int spmm_fused_impl(int h_bf16, const int32_t* rowptr, const int32_t* col
                   (!mix_src || ((uintptr_t)mix_src % 16 == 0 && ld_mix % 4 == 0)) &&
                   (!out_act || ((uintptr_t)out_act % 16 == 0 && ld_act % 4 == 0));
   CB_CHECK_ARG(al && ld_h >= d && ld_next >= d, CB_E_INVALID, "cb_spmm_csr_fused_f32: 16-byte aligned rows required");
+  CB_CHECK_ARG(!acc_init || ((uintptr_t)acc_init % 16 == 0 && ld_init % 4 == 0 && ld_init >= d), CB_E_INVALID,
+               "cb_spmm_csr_fused_acc_f32: acc_init must be 16-byte aligned rows of at least d floats");
   CB_CHECK_ARG(hub_T > 0 && n_hubs >= 0 && n_chunks >= 0, CB_E_INVALID, "cb_spmm_csr_fused_f32: bad hub plan");
   CB_CHECK_ARG(n_hubs == 0 || (hub_rows && hub_chunk_ptr && ws && ws_bytes >= cb_spmm_workspace_bytes(n_chunks, d)),
                CB_E_WORKSPACE, "cb_spmm_csr_fused_f32: hub plan given but workspace missing/too small");
   if (n_hubs == 0) hub_T = INT32_MAX;
-  Epilogue ep{row_scale, bias, 1};
+  Epilogue ep{row_scale, bias, 1, acc_init, ld_init};
   FusedEpi fe{};
   fe.mix_src = mix_src; fe.ld_mix = ld_mix; fe.c_act = c_act; fe.c_mix = c_mix;
   fe.thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
@@ -560,7 +609,18 @@ extern "C" int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, 
                                      uint64_t* relu_bits, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
                                      int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
                                      const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
-  return spmm_fused_impl(0, CB_FUSED_ARGS);
+  return spmm_fused_impl(0, nullptr, 0, CB_FUSED_ARGS);
+}
+
+// Fused store of the residual trunk on top of the interior-column partial sums (second pass of the node-sharded aggregation)
+extern "C" int cb_spmm_csr_fused_acc_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int64_t N,
+                                         int64_t E, const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias,
+                                         const float* mix_src, int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed,
+                                         const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, float* out_act, int64_t ld_act,
+                                         float* out_next, int64_t ld_next, int32_t hub_T, int32_t n_hubs, int32_t n_chunks,
+                                         const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(acc_init != nullptr || N == 0, CB_E_INVALID, "cb_spmm_csr_fused_acc_f32: acc_init is null");
+  return spmm_fused_impl(0, acc_init, ld_init, CB_FUSED_ARGS);
 }
 
 extern "C" int cb_spmm_csr_fused_bf16_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const uint16_t* h,
@@ -569,7 +629,7 @@ extern "C" int cb_spmm_csr_fused_bf16_f32(const int32_t* rowptr, const int32_t* 
                                           const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
                                           int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
                                           const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
-  return spmm_fused_impl(1, CB_FUSED_ARGS);
+  return spmm_fused_impl(1, nullptr, 0, CB_FUSED_ARGS);
 }
 
 // bf16-stored source rows, fp32 accumulation and output (build extension: BASELINE config 2)
@@ -585,7 +645,7 @@ extern "C" int cb_spmm_csr_bf16_f32(const int32_t* rowptr, const int32_t* col, i
   CB_CHECK_ARG(hub_T > 0 && n_hubs >= 0 && n_chunks >= 0, CB_E_INVALID, "cb_spmm_csr_bf16_f32: bad hub plan");
   CB_CHECK_ARG(n_hubs == 0 || (hub_rows && hub_chunk_ptr && ws && ws_bytes >= cb_spmm_workspace_bytes(n_chunks, d)),
                CB_E_WORKSPACE, "cb_spmm_csr_bf16_f32: hub plan given but workspace missing/too small");
-  Epilogue ep{row_scale, bias, relu};
+  Epilogue ep{row_scale, bias, relu, nullptr, 0};
   hipStream_t st = (hipStream_t)stream;
   if (n_hubs == 0) hub_T = INT32_MAX;
   const bf16_t* hb = (const bf16_t*)h;

@@ -1,42 +1,53 @@
 """Node-sharded TeacherGNN over the GPUs of one node (one process per GPU, torch.distributed
-`nccl` = RCCL over xGMI).  New relative to the reference, which is single-device
-(SURVEY.md §8e).
+`nccl` = RCCL over xGMI).  New relative to the reference, which is single-device.
 
-Partition: 1-D contiguous row blocks of equal size R = ceil(N / P) (node ids of the synthetic
-graphs are randomly permuted, so equal rows ~ equal edges).  Rank p owns rows
-[p*R, min((p+1)*R, N)) of x / y / masks / activations / structural embeddings and the matching row
-slices of both CSR orientations, with GLOBAL column ids.
+Partition: 1-D contiguous row blocks.  'edges' (default): boundaries from the prefix sum of
+in-degree + NODE_WEIGHT per node, so every rank gets the same share of the step's work (the aggregation
+is per edge, the dense stages per node; NODE_WEIGHT = their cost ratio measured on one MI355X).  'rows':
+equal row counts.  Rank p owns rows [lo(p), hi(p)) of x / y / masks / activations / structural embeddings.
 
-Exchange (the only data-path collective), two interchangeable forms:
-  * 'halo' (default): each rank receives only the remote rows its edges reference.  Per orientation
-    a HaloPlan is built once — unique remote column ids grouped by owner, the owners are told which
-    of their rows to send (one all-to-all of counts + one of ids), local column ids are remapped to
-    [0, n_local) and remote ones to n_local + position in the receive buffer.  Per aggregation: pack
-    (row gather) -> all_to_all_single with uneven splits (RCCL grouped send/recv over the xGMI peer
-    links) -> the local rows are reduced by the same SpMM kernel on [local rows | halo rows].  On the
-    10M-node power-law graph a rank needs 0.41 N remote rows at P = 8 instead of the 0.875 N an
-    all-gather delivers.
-  * 'allgather': all-gather of the [R, d] shards into the full [P*R, d] matrix (simple baseline).
-The backward of the aggregation is the same exchange on the gradient followed by the SpMM on the
-by-src slice (its own plan; no symmetry assumption).  Everything else is row-local; tiny all-reduces cover the replicated
-weights' gradients, the loss numerator and sum(E^2) of the structural-embedding regulariser.
+Ingest: every rank keeps only the edges whose destination (forward CSR) resp. source (reverse CSR) it owns
+and builds its row block from those — no rank ever builds the whole graph's CSR.
 
-The exchange and bookkeeping are device-agnostic torch.distributed code (tested on CPU with gloo,
-world_size 2); the compute stays on the HIP path.
+Exchange (the only data-path collective) before each aggregation, 'halo' form (default): a rank receives
+exactly the remote rows its edges reference.  Per orientation a HaloPlan is built once — unique remote
+column ids grouped by owner, owners learn which rows to send through one all-to-all of counts and one of
+ids.  The row block is split by column owner into an INTERIOR CSR (columns = local rows) and a HALO CSR
+(columns = slots of the receive buffer), and the aggregation runs as
+
+    pack rows for the peers -> all_to_all_single(async)      [RCCL stream, xGMI]
+    interior pass: raw sums over local columns                [compute stream, overlaps the exchange]
+    wait -> halo pass: starts from the interior sums, applies the epilogue once (cb_spmm_csr_acc_f32)
+
+COLDBREW_OVERLAP=0 keeps the single-pass form (one CSR over [local rows | halo rows] after a blocking
+exchange); COLDBREW_EXCHANGE=allgather the all-gather baseline (equal-row partition only).
+The backward of the aggregation is the same exchange on the gradient followed by the reverse-orientation
+passes (own plan; aliasing the forward one when the edge multiset is symmetric on every rank).  Everything
+else is row-local; small all-reduces cover the replicated weights' gradients, the loss numerator, sum(E^2)
+of the structural-embedding regulariser and the column statistics of the norm tricks (norms_hip.py).
+
+The bookkeeping here is device-agnostic torch / torch.distributed code; every pass over node data goes
+through a compute object (HipCompute: the C-ABI kernels).  The CPU tests (gloo, world_size 2-3) plug
+their own oracle-backed compute object in (tests/dist_cpu_compute.py) — there is no CPU arithmetic in
+this module.
 """
 import contextlib
 import io
+import os
 
 import torch
 import torch.distributed as dist
 
 from . import _lib
-from .graph import CSRGraph, ZeroInDegreeError
+
+NODE_WEIGHT = 12      # one node's dense work (GEMMs, elementwise) ~ 12 edges' aggregation work per step (S-pl10M profile)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# collectives (gloo cannot move device tensors for every collective: staged through the host in that case —
+# used to run the whole sharded HIP path with several processes on ONE GPU; production = nccl, no staging)
+# ---------------------------------------------------------------------------------------------------------
 def _staged(t, group):
-    """gloo cannot move device tensors for every collective: stage through the host in that case (used to exercise the
-    whole sharded HIP path with several processes on ONE GPU; the production backend is nccl = RCCL, no staging)."""
     return t.is_cuda and dist.get_backend(group) == 'gloo'
 
 
@@ -49,13 +60,20 @@ def _all_reduce(t, op=dist.ReduceOp.SUM, group=None):
         dist.all_reduce(t, op=op, group=group)
 
 
-def _all_to_all_single(out, inp, out_splits=None, in_splits=None, group=None):
+class _Done:
+    def wait(self):
+        return True
+
+
+def _all_to_all_single(out, inp, out_splits=None, in_splits=None, group=None, async_op=False):
+    """Returns a work handle when async_op (already finished for the staged / gloo-CPU forms)."""
     if _staged(inp, group) or _staged(out, group):
         ho, hi = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
         dist.all_to_all_single(ho, hi, out_splits, in_splits, group=group)
         out.copy_(ho)
-    else:
-        dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
+        return _Done()
+    w = dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=async_op)
+    return w if async_op else _Done()
 
 
 def _all_gather_into_tensor(out, inp, group=None):
@@ -67,20 +85,52 @@ def _all_gather_into_tensor(out, inp, group=None):
         dist.all_gather_into_tensor(out, inp, group=group)
 
 
-class Partition:
-    """Equal row blocks: rank p owns [lo(p), hi(p))."""
+def _broadcast(t, src=0, group=None):
+    if _staged(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
 
-    def __init__(self, n_nodes, world, rank):
-        self.N, self.world, self.rank = int(n_nodes), int(world), int(rank)
-        self.R = (self.N + self.world - 1) // self.world
+
+# ---------------------------------------------------------------------------------------------------------
+# partition
+# ---------------------------------------------------------------------------------------------------------
+class Partition:
+    """Contiguous row blocks: rank p owns [lo(p), hi(p)).  bounds = P+1 ascending ints (default: equal rows)."""
+
+    def __init__(self, n_nodes, world, rank, bounds=None, kind='rows'):
+        self.N, self.world, self.rank, self.kind = int(n_nodes), int(world), int(rank), kind
+        if bounds is None:
+            r = (self.N + self.world - 1) // self.world
+            bounds = [min(p * r, self.N) for p in range(self.world + 1)]
+        self.bounds = [int(b) for b in bounds]
+        if len(self.bounds) != self.world + 1 or self.bounds[0] != 0 or self.bounds[-1] != self.N \
+                or any(self.bounds[i] > self.bounds[i + 1] for i in range(self.world)):
+            raise ValueError(f'bad partition bounds {self.bounds} for N={self.N}, world={self.world}')
+        self.R = max(self.bounds[p + 1] - self.bounds[p] for p in range(self.world))     # largest block (all-gather slot size)
+        self._bt = {}
+
+    @classmethod
+    def balanced(cls, in_degree, world, rank, node_weight=NODE_WEIGHT):
+        """Boundaries at equal shares of sum_v (in_degree[v] + node_weight): SURVEY.md §8e 'balance on edges-per-rank
+        (prefix sum over in-degree), not nodes'.  Deterministic in the degree vector, so all ranks agree."""
+        n = int(in_degree.numel())
+        cost = torch.cumsum(in_degree.to(torch.int64) + int(node_weight), 0)
+        total = int(cost[-1]) if n else 0
+        targets = torch.tensor([(total * p) // world for p in range(1, world)], dtype=torch.int64, device=cost.device)
+        cuts = torch.searchsorted(cost, targets, right=False).tolist() if world > 1 and n else []
+        bounds = [0] + [min(int(c) + 1, n) for c in cuts] + [n]
+        for i in range(1, len(bounds)):
+            bounds[i] = max(bounds[i], bounds[i - 1])
+        return cls(n, world, rank, bounds, kind='edges')
 
     def lo(self, p=None):
-        p = self.rank if p is None else p
-        return min(p * self.R, self.N)
+        return self.bounds[self.rank if p is None else p]
 
     def hi(self, p=None):
-        p = self.rank if p is None else p
-        return min((p + 1) * self.R, self.N)
+        return self.bounds[(self.rank if p is None else p) + 1]
 
     @property
     def n_local(self):
@@ -94,38 +144,50 @@ class Partition:
         return t[self.lo():self.hi()]
 
     def owner(self, node_ids):
-        return torch.div(node_ids, self.R, rounding_mode='floor')
+        key = node_ids.device
+        if key not in self._bt:
+            self._bt[key] = torch.tensor(self.bounds[1:], dtype=torch.int64, device=key)
+        return torch.bucketize(node_ids.to(torch.int64), self._bt[key], right=True)
 
 
-def gather_rows(x_local, part, group=None, out=None):
-    """All-gather of the row shards: [n_local, d] on each rank -> [P*R, d] (rows >= N are padding)."""
-    d = x_local.shape[1]
-    if out is None:
-        out = torch.empty((part.padded, d), dtype=x_local.dtype, device=x_local.device)
-    if x_local.shape[0] == part.R and x_local.is_contiguous():
-        src = x_local
-    else:   # last rank: pad its shard to R rows
-        src = torch.zeros((part.R, d), dtype=x_local.dtype, device=x_local.device)
-        src[:x_local.shape[0]] = x_local
-    _all_gather_into_tensor(out, src, group=group)
-    return out
+# ---------------------------------------------------------------------------------------------------------
+# compute object: every pass over node data (the product has exactly one implementation)
+# ---------------------------------------------------------------------------------------------------------
+class HipCompute:
+    """The C-ABI kernels of libcoldbrew_hip.so behind the few operations the sharded path needs."""
+
+    def csr(self, rows, cols, n_rows, n_cols):
+        """Local row block from (row, col) pairs: CSR with ascending columns inside a row (graph.CSRGraph.from_pairs)."""
+        from .graph import CSRGraph
+        return CSRGraph.from_pairs(rows, cols, n_rows, n_cols)
+
+    def spmm(self, g, h, row_scale=None, bias=None, relu=False, acc_init=None, profile=None):
+        g.profile = profile
+        return g.spmm(h, row_scale=row_scale, bias=bias, relu=relu, acc_init=acc_init)
+
+    def pack_rows(self, x, idx):
+        from .ops import gather_rows_by_index
+        if x.dtype == torch.bfloat16 and x.shape[1] % 2 == 0 and x.is_contiguous():     # bf16 rows move as packed 32-bit words
+            return gather_rows_by_index(x.view(torch.float32), idx).view(torch.bfloat16)
+        return gather_rows_by_index(x, idx)
+
+    def act_bwd(self, g, act, row_scale, need_b):
+        from .ops import act_bwd
+        return act_bwd(g, act, row_scale, want_out=True, want_colsum=need_b)
+
+    def deg_norm(self, deg):
+        return deg.to(torch.float32).clamp_(min=1).pow_(-0.5)        # [n_local] vector (GCN.py:206-208,243-245)
 
 
 class HaloPlan:
     """Who sends which rows to whom for one CSR orientation (built once per graph)."""
 
-    def __init__(self, col_global, part, group=None):
-        lo, hi, P, R = part.lo(), part.hi(), part.world, part.R
-        col = col_global.to(torch.int64)
-        dev = col.device
-        self.n_local = hi - lo
-        remote = (col < lo) | (col >= hi)
-        uniq, inv = torch.unique(col[remote], return_inverse=True)      # ascending ids = grouped by owner
-        self.n_halo = int(uniq.numel())
-        new_col = col - lo
-        new_col[remote] = self.n_local + inv
-        self.col = new_col.to(torch.int32)
-        recv_counts = torch.bincount(torch.div(uniq, R, rounding_mode='floor'), minlength=P)[:P]
+    def __init__(self, uniq_remote, part, group=None):
+        """uniq_remote: ascending unique remote column ids this rank's edges reference (= grouped by owner)."""
+        P = part.world
+        dev = uniq_remote.device
+        self.n_local, self.n_halo = part.n_local, int(uniq_remote.numel())
+        recv_counts = torch.bincount(part.owner(uniq_remote), minlength=P)[:P]
         send_counts = torch.empty_like(recv_counts)
         if P > 1:
             _all_to_all_single(send_counts, recv_counts, group=group)    # how many rows each peer wants from me
@@ -135,87 +197,85 @@ class HaloPlan:
         self.send_counts = [int(v) for v in send_counts.tolist()]
         wanted = torch.empty(sum(self.send_counts), dtype=torch.int64, device=dev)
         if P > 1:
-            _all_to_all_single(wanted, uniq, self.send_counts, self.recv_counts, group=group)
-        self.send_idx = (wanted - lo).contiguous()                         # my local rows, in per-destination order
+            _all_to_all_single(wanted, uniq_remote, self.send_counts, self.recv_counts, group=group)
+        self.send_idx = (wanted - part.lo()).contiguous()                  # my local rows, in per-destination order
         if self.send_idx.numel() and (int(self.send_idx.min()) < 0 or int(self.send_idx.max()) >= self.n_local):
             raise RuntimeError('halo plan: a peer requested a row this rank does not own')
 
 
-def _pack_rows(x, idx):
-    if x.is_cuda and x.dtype == torch.float32:
-        from .ops import gather_rows_by_index
-        return gather_rows_by_index(x, idx)
-    if x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] % 2 == 0 and x.is_contiguous():
-        from .ops import gather_rows_by_index      # bf16 rows move as packed 32-bit words
-        return gather_rows_by_index(x.view(torch.float32), idx).view(torch.bfloat16)
-    return x.index_select(0, idx)
+class _Orientation:
+    """One CSR orientation of a rank's row block: the CSR(s) the local passes read and the plan that feeds them."""
+    __slots__ = ('whole', 'interior', 'halo', 'plan', 'E', 'rowptr_key', 'col_key')
 
 
 class ShardedGraph:
-    """Row slice [lo, hi) of both CSR orientations + local degree norms + the exchange plans.
-    Quacks like graph.CSRGraph for GCNConv / ops.aggregate."""
+    """Row block [lo, hi) of both CSR orientations + local degree norms + the exchange plans.
+    Quacks like graph.CSRGraph for GCNConv / ops.aggregate / the fused trunk."""
 
-    def __init__(self, full, part, group=None, spmm_fn=None, exchange='halo'):
-        """full: an object with rowptr/col/rowptr_t/col_t/norm_in/norm_out/N/E (a CSRGraph built from
-        the whole edge_index, or the numpy oracle CSR in the CPU tests)."""
+    def __init__(self, edge_index, n_nodes, part, group=None, exchange='halo', overlap=True, compute=None):
         self.part, self.group = part, group
         self.exchange_kind = exchange
-        self.N_global, self.E_global = full.N, full.E
-        self.n_zero_in_degree = getattr(full, 'n_zero_in_degree', 0)
+        self.compute = compute if compute is not None else HipCompute()
+        self.N_global, self.E_global = int(n_nodes), int(edge_index.shape[1])
         self.row_offset = part.lo()
         lo, hi = part.lo(), part.hi()
         self.N = hi - lo
-        self._spmm_fn = spmm_fn
         self.profile = None
-
-        def cut(rowptr, col):
-            rp = torch.as_tensor(rowptr)
-            e0, e1 = int(rp[lo]), int(rp[hi])
-            loc_rp = (rp[lo:hi + 1] - rp[lo]).clone()
-            loc_col = torch.as_tensor(col)[e0:e1].clone()
-            return loc_rp, loc_col
-
-        rp, c = cut(full.rowptr, full.col)
-        rpt, ct = cut(full.rowptr_t, full.col_t)
-        self.E = int(c.numel())
-        self.norm_in = torch.as_tensor(full.norm_in)[lo:hi].clone()
-        self.norm_out = torch.as_tensor(full.norm_out)[lo:hi].clone()
-        if exchange == 'halo':
-            self.plan_fwd = HaloPlan(c, part, group)
-            same = (rpt.shape == rp.shape and ct.shape == c.shape and bool(torch.equal(rpt, rp)) and bool(torch.equal(ct, c)))
-            if part.world > 1:      # one global decision, or the ranks would disagree on which collectives follow
-                flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=rp.device)
-                _all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-                same = bool(flag.item())
-            self.plan_bwd = self.plan_fwd if same else HaloPlan(ct, part, group)
-            c, ct = self.plan_fwd.col, self.plan_bwd.col
-            ncols_f, ncols_b = self.N + self.plan_fwd.n_halo, self.N + self.plan_bwd.n_halo
-        elif exchange == 'allgather':
-            self.plan_fwd = self.plan_bwd = None
-            ncols_f = ncols_b = part.padded
-        else:
+        if exchange not in ('halo', 'allgather'):
             raise ValueError(f'unknown exchange {exchange!r}')
-        if spmm_fn is None:     # HIP path: wrap the slices as rectangular device CSRs
-            self.fwd = CSRGraph.from_csr(rp, c, n_cols=ncols_f)
-            self.bwd = CSRGraph.from_csr(rpt, ct, n_cols=ncols_b)
+        if exchange == 'allgather' and part.kind != 'rows':
+            raise ValueError("the all-gather baseline needs the equal-row partition (COLDBREW_PARTITION=rows)")
+        self.overlap = bool(overlap) and exchange == 'halo' and part.world > 1
+        src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
+        bad = int(((src < 0) | (src >= n_nodes) | (dst < 0) | (dst >= n_nodes)).sum()) if src.numel() else 0
+        if bad:
+            raise ValueError(f'edge_index has {bad} edges with an endpoint outside [0, {n_nodes})')
+        mf = (dst >= lo) & (dst < hi)                   # forward block: rows = destinations I own, columns = sources (GCN.py:238)
+        mb = (src >= lo) & (src < hi)                   # reverse block: rows = sources I own, columns = destinations
+        rf, cf = dst[mf] - lo, src[mf]
+        rb, cb = src[mb] - lo, dst[mb]
+        del mf, mb
+        self.E = int(rf.numel())
+        in_deg = torch.bincount(rf, minlength=self.N)[:self.N]
+        out_deg = torch.bincount(rb, minlength=self.N)[:self.N]
+        self.norm_in = self.compute.deg_norm(in_deg)
+        self.norm_out = self.compute.deg_norm(out_deg)
+        nz = torch.tensor([int((in_deg == 0).sum())], dtype=torch.int64, device=src.device)
+        # one global decision each, or the ranks would disagree on which collectives follow
+        same = bool(rf.numel() == rb.numel() and torch.equal(torch.sort(rf * n_nodes + cf)[0], torch.sort(rb * n_nodes + cb)[0]))
+        flag = torch.tensor([1 if same else 0], dtype=torch.int64, device=src.device)
+        if part.world > 1:
+            _all_reduce(nz, group=group)
+            _all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        self.n_zero_in_degree = int(nz.item())
+        self.symmetric = bool(flag.item())
+        self.f = self._orient(rf, cf)
+        self.b = self.f if self.symmetric else self._orient(rb, cb)
+
+    # -- build one orientation ---------------------------------------------------------------------------
+    def _orient(self, rows, cols):
+        part, lo, hi = self.part, self.part.lo(), self.part.hi()
+        o = _Orientation()
+        o.E = int(rows.numel())
+        o.whole = o.interior = o.halo = o.plan = None
+        if self.exchange_kind == 'allgather':       # columns index the gathered [P*R, d] matrix (equal blocks: identity)
+            o.whole = self.compute.csr(rows, cols, self.N, part.padded)
+            return o
+        remote = (cols < lo) | (cols >= hi)
+        uniq, inv = torch.unique(cols[remote], return_inverse=True)       # ascending ids = grouped by owner
+        o.plan = HaloPlan(uniq, part, self.group)
+        if self.overlap:
+            o.interior = self.compute.csr(rows[~remote], cols[~remote] - lo, self.N, self.N)
+            o.halo = self.compute.csr(rows[remote], inv, self.N, max(o.plan.n_halo, 1))
         else:
-            self.fwd, self.bwd = (rp, c), (rpt, ct)
+            new_col = cols - lo
+            new_col[remote] = self.N + inv
+            o.whole = self.compute.csr(rows, new_col, self.N, self.N + o.plan.n_halo)
+        return o
 
-    def exchange(self, x_local, transpose=False):
-        """[n_local, d] -> the matrix the local SpMM reads: [n_local + n_halo, d] (halo) or [P*R, d] (allgather)."""
-        if self.exchange_kind == 'allgather':
-            return gather_rows(x_local, self.part, self.group)
-        plan = self.plan_bwd if transpose else self.plan_fwd
-        if self.part.world == 1:
-            return x_local
-        d = x_local.shape[1]
-        ext = torch.empty((plan.n_local + plan.n_halo, d), dtype=x_local.dtype, device=x_local.device)
-        ext[:plan.n_local] = x_local
-        send = _pack_rows(x_local, plan.send_idx)
-        _all_to_all_single(ext[plan.n_local:], send, plan.recv_counts, plan.send_counts, group=self.group)
-        return ext
-
+    # -- CSRGraph-like surface ---------------------------------------------------------------------------
     def check_zero_in_degree(self):
+        from .graph import ZeroInDegreeError
         if self.n_zero_in_degree:
             raise ZeroInDegreeError('There are 0-in-degree nodes in the graph')
 
@@ -225,22 +285,71 @@ class ShardedGraph:
     def number_of_edges(self):
         return self.E_global
 
-    def local_spmm(self, h_full, transpose=False, row_scale=None, bias=None, relu=False):
-        g = self.bwd if transpose else self.fwd
-        if self._spmm_fn is not None:
-            return self._spmm_fn(g[0], g[1], h_full, row_scale, bias, relu)
-        g.profile = self.profile
-        return g.spmm(h_full, row_scale=row_scale, bias=bias, relu=relu)
+    def algorithmic_bytes(self, d, elem=4, row_scale=True, bias=True, src_elem=None):
+        """SURVEY.md §8(d) bytes of THIS RANK's share of one aggregation (local edges, local rows)."""
+        b = self.f.E * (d * (src_elem or elem) + 4) + self.N * (d * elem + 4)
+        return b + (4 * self.N if row_scale else 0) + (d * elem if bias else 0)
 
-    def algorithmic_bytes(self, d, **kw):
-        return self.fwd.algorithmic_bytes(d, **kw)
+    # -- exchange + aggregation --------------------------------------------------------------------------
+    def exchange(self, x_local, transpose=False):
+        """Blocking form: [n_local, d] -> the matrix the single-pass CSR reads ([local | halo] or the gathered [P*R, d])."""
+        o = self.b if transpose else self.f
+        if self.exchange_kind == 'allgather':
+            return gather_rows(x_local, self.part, self.group)
+        if self.part.world == 1:
+            return x_local
+        plan = o.plan
+        ext = torch.empty((plan.n_local + plan.n_halo, x_local.shape[1]), dtype=x_local.dtype, device=x_local.device)
+        ext[:plan.n_local] = x_local
+        send = self.compute.pack_rows(x_local, plan.send_idx)
+        _all_to_all_single(ext[plan.n_local:], send, plan.recv_counts, plan.send_counts, group=self.group)
+        return ext
+
+    def start_halo(self, x_local, transpose=False):
+        """Overlapped form, first half: pack + asynchronous all-to-all.  Returns (receive buffer, work handle, send buffer)."""
+        plan = (self.b if transpose else self.f).plan
+        send = self.compute.pack_rows(x_local, plan.send_idx)
+        recv = torch.empty((max(plan.n_halo, 1), x_local.shape[1]), dtype=x_local.dtype, device=x_local.device)
+        work = _all_to_all_single(recv[:plan.n_halo], send, plan.recv_counts, plan.send_counts, group=self.group, async_op=True)
+        return recv, work, send
+
+    def aggregate(self, h_local, transpose=False, row_scale=None, bias=None, relu=False):
+        """act(row_scale * (A_block . h) + bias) for this rank's rows; h_local = this rank's rows of h."""
+        o = self.b if transpose else self.f
+        c = self.compute
+        if not self.overlap or h_local.dtype != torch.float32:
+            return c.spmm(o.whole if o.whole is not None else self._whole(o), self.exchange(h_local, transpose), row_scale, bias, relu,
+                          profile=self.profile)
+        recv, work, send = self.start_halo(h_local, transpose)
+        part = c.spmm(o.interior, h_local, profile=self.profile)             # raw sums over the local columns, overlaps the exchange
+        work.wait()
+        out = c.spmm(o.halo, recv, row_scale, bias, relu, acc_init=part, profile=self.profile)
+        del send
+        return out
+
+    def _whole(self, o):
+        raise RuntimeError('single-pass aggregation requested on a graph built for the overlapped two-pass form '
+                           '(bf16-stored rows need COLDBREW_OVERLAP=0)')
+
+
+def gather_rows(x_local, part, group=None, out=None):
+    """All-gather of the row shards: [n_local, d] on each rank -> [P*R, d] (rows beyond a block's end are padding)."""
+    d = x_local.shape[1]
+    if out is None:
+        out = torch.empty((part.padded, d), dtype=x_local.dtype, device=x_local.device)
+    if x_local.shape[0] == part.R and x_local.is_contiguous():
+        src = x_local
+    else:   # short block: pad to R rows
+        src = torch.zeros((part.R, d), dtype=x_local.dtype, device=x_local.device)
+        src[:x_local.shape[0]] = x_local
+    _all_gather_into_tensor(out, src, group=group)
+    return out
 
 
 class _ShardedAggregateFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph, h_local, row_scale, bias, relu):
-        h_full = graph.exchange(h_local, False)
-        out = graph.local_spmm(h_full, False, row_scale, bias, relu)
+        out = graph.aggregate(h_local, False, row_scale, bias, relu)
         ctx.graph, ctx.relu, ctx.has_bias = graph, relu, bias is not None
         ctx.save_for_backward(out if relu else None, row_scale)
         return out
@@ -250,20 +359,9 @@ class _ShardedAggregateFn(torch.autograd.Function):
         out, row_scale = ctx.saved_tensors
         graph = ctx.graph
         need_b = ctx.has_bias and ctx.needs_input_grad[3]
-        gs, dbias = _act_bwd(g, out if ctx.relu else None, row_scale, need_b)
-        dh = None
-        if ctx.needs_input_grad[1]:
-            g_full = graph.exchange(gs, True)
-            dh = graph.local_spmm(g_full, True)
+        gs, dbias = graph.compute.act_bwd(g, out if ctx.relu else None, row_scale, need_b)
+        dh = graph.aggregate(gs, True) if ctx.needs_input_grad[1] else None
         return None, dh, None, dbias, None
-
-
-def _act_bwd(g, act, row_scale, need_b):
-    if g.is_cuda:
-        from .ops import act_bwd
-        return act_bwd(g, act, row_scale, want_out=True, want_colsum=need_b)
-    gm = g * (act > 0) if act is not None else g           # CPU tests of the exchange logic only
-    return (gm * row_scale.unsqueeze(1) if row_scale is not None else gm), (gm.sum(0) if need_b else None)
 
 
 def sharded_aggregate(graph, h_local, row_scale=None, bias=None, relu=False):
@@ -297,13 +395,34 @@ class _AllReduceSumFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        g = g.clone()                      # every rank's loss depends on x through y: sum the upstream gradients
+        g = g.clone()
         _all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
         return g, None
 
 
 def allreduce_sum(x, group=None):
     return _AllReduceSumFn.apply(x, group)
+
+
+def sync_initial_state(model, part, group=None, seed=0):
+    """Makes a freshly constructed sharded model consistent across ranks: the per-node tables (`le`, `embs`)
+    have part.n_local rows, so ranks with different block sizes consume different amounts of the CPU RNG stream before the
+    replicated layers are drawn.  (1) every replicated parameter and buffer is broadcast from rank 0; (2) the per-node
+    tables are re-drawn from a generator keyed by (seed, first global row), so ranks do not hold identical shards."""
+    per_node = [(n, p) for n, p in model.named_parameters() if n.endswith('.le') or n == 'embs']
+    names = {n for n, _ in per_node}
+    with torch.no_grad():
+        for n, t in list(model.named_parameters()) + list(model.named_buffers()):
+            if n in names or t.numel() == 0:
+                continue
+            if part.world > 1:
+                _broadcast(t.data, 0, group)
+        for i, (n, p) in enumerate(per_node):
+            gen = torch.Generator().manual_seed((int(seed) * 1000003 + part.lo()) * 64 + i)
+            fresh = torch.randn(p.shape, generator=gen)
+            if n == 'embs':
+                fresh = fresh * 0.001                      # GNN_normalizations.py:18-22
+            p.data.copy_(fresh.to(p.device))
 
 
 class ShardedTrainer:
@@ -328,17 +447,22 @@ class ShardedTrainer:
         _all_reduce(hi_, op=dist.ReduceOp.MAX, group=group)
         if not torch.equal(lo_, hi_):
             raise RuntimeError('ranks generated different graphs (seeded generator mismatch)')
-        self.part = Partition(self._n, self.world, self.rank)
-        full = CSRGraph(data.edge_index, self._n)
-        import os
-        self.sgraph = ShardedGraph(full, self.part, group, exchange=os.environ.get('COLDBREW_EXCHANGE', 'halo'))
+        exchange = os.environ.get('COLDBREW_EXCHANGE', 'halo')
+        kind = os.environ.get('COLDBREW_PARTITION', 'rows' if exchange == 'allgather' else 'edges')
+        if kind == 'edges':
+            self.part = Partition.balanced(torch.bincount(data.edge_index[1], minlength=self._n), self.world, self.rank)
+        else:
+            self.part = Partition(self._n, self.world, self.rank)
+        self.sgraph = ShardedGraph(data.edge_index, self._n, self.part, group, exchange=exchange,
+                                   overlap=os.environ.get('COLDBREW_OVERLAP', '1') != '0'
+                                   and getattr(args, 'agg_dtype', 'f32') == 'f32')
         self.n_train = int(data.train_mask.sum().item())
         p = self.part
         self.x = p.slice_rows(data.x).float().contiguous()
         self.y = p.slice_rows(data.y).contiguous()
         self.train_mask = p.slice_rows(data.train_mask).contiguous()
         self.edge_index = data.edge_index[:, :1]     # placeholder: the cached sharded graph is injected below
-        del data, full
+        del data
         torch.cuda.empty_cache()
         self.optfun = cb_optim.resolve(args.optfun)
         set_arch_configs(args)
@@ -347,11 +471,10 @@ class ShardedTrainer:
 
     def setup_teacherGNN(self):
         from .GNN_model.GNN_normalizations import TeacherGNN
-        if self.args.type_trick in ('BatchNorm', 'PairNorm', 'MeanNorm', 'GroupNorm', 'CombNorm'):
-            raise NotImplementedError('column-statistic norm tricks need a cross-rank all-reduce; not built for the sharded path')
         torch.manual_seed(self.args.random_seed)
         with contextlib.redirect_stdout(io.StringIO()):
             self.teacherGNN = TeacherGNN(self.args, None).to(self.device)
+        sync_initial_state(self.teacherGNN, self.part, self.group, self.args.random_seed)
         self.teacherGNN.model.model.dglgraph = self.sgraph
         self.replicated = [p for n, p in self.teacherGNN.named_parameters() if not n.endswith('.le') and n != 'embs']
         self.optimizer = self.optfun(self.teacherGNN.parameters(), lr=self.args.lr, weight_decay=self.args.weight_decay)
@@ -376,16 +499,17 @@ class ShardedTrainer:
         return self._e
 
     def train_step(self):
-        from . import ops
+        from . import norms_hip, ops
         m = self.teacherGNN
         m.train()
-        out = m.get_3_embs(self.x, self.edge_index).emb4classi_full
-        # local numerator / global count; the global loss is the sum over ranks
-        loss = ops.nll_logsoftmax(out, self.y, self.train_mask, self.n_train)
-        if m.se_reg_all is not None:
-            loss = loss + self.args.se_reg * m.se_reg_all / self.world   # se_reg_all is already global; count it once
-        self.optimizer.zero_grad()
-        loss.backward()
+        with norms_hip.row_sharding(self.group, self._n):      # column statistics of the norm tricks span all ranks
+            out = m.get_3_embs(self.x, self.edge_index).emb4classi_full
+            # local numerator / global count; the global loss is the sum over ranks
+            loss = ops.nll_logsoftmax(out, self.y, self.train_mask, self.n_train)
+            if m.se_reg_all is not None:
+                loss = loss + self.args.se_reg * m.se_reg_all / self.world   # se_reg_all is already global; count it once
+            self.optimizer.zero_grad()
+            loss.backward()
         allreduce_grads(self.replicated, self.group)
         self.optimizer.step()
         total = loss.detach().clone()

@@ -89,6 +89,31 @@ class CSRGraph:
         g.row_offset = 0
         return g
 
+    @classmethod
+    def from_pairs(cls, rows, cols, n_rows, n_cols, hub_threshold=HUB_THRESHOLD):
+        """Rectangular device CSR (n_rows x n_cols, ascending columns inside a row) from (row, col) pairs through the same
+        C-ABI ingest as the square graph — the row block a rank owns in the node-sharded path (dist.py)."""
+        lib = _lib.load()
+        _lib.require_device(rows, cols)
+        dev = rows.device
+        rows, cols = rows.to(torch.int64).contiguous(), cols.to(torch.int64).contiguous()
+        E, n = int(rows.numel()), max(int(n_rows), int(n_cols), 1)
+        rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        rowptr_t = torch.empty(n + 1, dtype=torch.int32, device=dev)      # the ingest builds both orientations; the transposed
+        col_t = torch.empty(max(E, 1), dtype=torch.int32, device=dev)     # one of a row block is not used
+        flags = torch.empty(4, dtype=torch.int32, device=dev)
+        wsb = lib.cb_csr_workspace_bytes(E, n)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.cb_csr_from_coo_i64(_lib.ptr(cols), _lib.ptr(rows), E, n, _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(rowptr_t),
+                                               _lib.ptr(col_t), _lib.ptr(flags), _lib.ptr(ws), wsb, _lib.stream_ptr()), 'cb_csr_from_coo_i64')
+            n_bad = flags.tolist()[1]
+        if n_bad or (E and (int(rows.max()) >= n_rows or int(cols.max()) >= n_cols)):
+            raise ValueError('from_pairs: a (row, col) pair lies outside the n_rows x n_cols block')
+        del rowptr_t, col_t, ws
+        return cls.from_csr(rowptr[:int(n_rows) + 1].clone(), col[:E].clone(), n_cols, hub_threshold)
+
     # -- DGL-like surface (GCN.py:188,200,206,243) --------------------------------------
     def number_of_nodes(self):
         return self.N
@@ -133,10 +158,11 @@ class CSRGraph:
         return self._ws
 
     # -- the aggregation ----------------------------------------------------------------
-    def spmm(self, h, transpose=False, row_scale=None, bias=None, relu=False, out=None):
-        """out[v] = act(row_scale[v] * sum_{u in row v} h[u] + bias); by-dst CSR unless transpose."""
+    def spmm(self, h, transpose=False, row_scale=None, bias=None, relu=False, out=None, acc_init=None):
+        """out[v] = act(row_scale[v] * (acc_init[v] + sum_{u in row v} h[u]) + bias); by-dst CSR unless transpose.
+        acc_init (optional, fp32 [N, d]): partial sums of an earlier pass over other columns (node-sharded path)."""
         lib = _lib.load()
-        _lib.require_device(h, row_scale, bias, out)
+        _lib.require_device(h, row_scale, bias, out, acc_init)
         if h.dtype not in (torch.float32, torch.bfloat16):
             raise TypeError(f'aggregation expects float32 (or bf16-stored) features, got {h.dtype}')
         bf16 = h.dtype == torch.bfloat16
@@ -160,11 +186,21 @@ class CSRGraph:
             ev0.record()
         fn = lib.cb_spmm_csr_bf16_f32 if bf16 else lib.cb_spmm_csr_f32
         with torch.cuda.device(h.device):
-            _lib.check(fn(_lib.ptr(rowptr), _lib.ptr(col), self.N, self.E, _lib.ptr(h), ld_h, d,
-                          _lib.ptr(row_scale), _lib.ptr(bias), int(bool(relu)), _lib.ptr(out), ld_o,
-                          self.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows),
-                          _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
-                       'cb_spmm_csr')
+            if acc_init is not None:
+                if bf16 or acc_init.dtype != torch.float32 or acc_init.shape != (self.N, d) or acc_init.stride(1) != 1:
+                    raise ValueError('acc_init must be a float32 [N, d] matrix with contiguous rows (fp32 source rows only)')
+                _lib.check(lib.cb_spmm_csr_acc_f32(_lib.ptr(rowptr), _lib.ptr(col), self.N, self.E, _lib.ptr(h), ld_h, d,
+                                                   _lib.ptr(row_scale), _lib.ptr(bias), int(bool(relu)), _lib.ptr(acc_init),
+                                                   acc_init.stride(0) if self.N > 1 else d, _lib.ptr(out), ld_o,
+                                                   self.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows),
+                                                   _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
+                           'cb_spmm_csr_acc_f32')
+            else:
+                _lib.check(fn(_lib.ptr(rowptr), _lib.ptr(col), self.N, self.E, _lib.ptr(h), ld_h, d,
+                              _lib.ptr(row_scale), _lib.ptr(bias), int(bool(relu)), _lib.ptr(out), ld_o,
+                              self.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows),
+                              _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
+                           'cb_spmm_csr')
         if prof is not None:
             ev1.record()
             prof.append((ev0, ev1, self.algorithmic_bytes(d, row_scale=row_scale is not None, bias=bias is not None,

@@ -165,7 +165,8 @@ class _FrobeniusFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, norm = ctx.saved_tensors
-        return x * (g / norm)          # d||x||/dx = x / ||x||
+        # d||x||/dx = x / ||x||; 0 at x = 0 (the subgradient torch.norm's backward picks), not NaN
+        return x * torch.where(norm > 0, g / norm, torch.zeros_like(norm))
 
 
 def frobenius_norm(x):

@@ -27,19 +27,24 @@ def eligible(tc, x, want_les):
             and len(tc.layers_MLP) == 2)
 
 
-def _graph_parts(graph):
-    """(local forward CSRGraph, local backward CSRGraph or None(=use transpose), partition or None)"""
-    if hasattr(graph, 'part'):
-        return graph.fwd, graph.bwd, graph
-    return graph, None, None
-
-
 def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False):
-    """(bits, out_next[, act]) of cb_spmm_csr_fused_f32 on the (possibly node-sharded) graph."""
+    """(bits, out_next[, act]) of cb_spmm_csr_fused_f32 on the (possibly node-sharded) graph.  Node-sharded + overlapped:
+    the interior-column pass (plain kernel, raw sums) runs while the halo rows travel, the fused store then starts from
+    those sums (cb_spmm_csr_fused_acc_f32) on the halo-column CSR."""
     lib = _lib.load()
-    g, _, sh = _graph_parts(graph)
-    if sh is not None:
-        z = sh.exchange(z, False)
+    sh = graph if hasattr(graph, 'part') else None
+    acc = None
+    if sh is None:
+        g = graph
+    elif sh.overlap and z.dtype == torch.float32:
+        recv, work, send = sh.start_halo(z, False)
+        sh.f.interior.profile = getattr(graph, 'profile', None)
+        acc = sh.f.interior.spmm(z)
+        work.wait()
+        g, z = sh.f.halo, recv
+        del send
+    else:
+        g, z = sh.f.whole, sh.exchange(z, False)
     n, d = g.N, z.shape[1]
     dev = z.device
     bits = torch.empty((n, d // 256, 4), dtype=torch.int64, device=dev)
@@ -53,14 +58,16 @@ def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     bf16 = z.dtype == torch.bfloat16
-    fn = lib.cb_spmm_csr_fused_bf16_f32 if bf16 else lib.cb_spmm_csr_fused_f32
-    with torch.cuda.device(dev):
-        _lib.check(fn(
-            _lib.ptr(g.rowptr), _lib.ptr(g.col), n, g.E, _lib.ptr(z), z.stride(0), d, _lib.ptr(graph.norm_in), _lib.ptr(bias),
+    args = (_lib.ptr(g.rowptr), _lib.ptr(g.col), n, g.E, _lib.ptr(z), z.stride(0), d, _lib.ptr(graph.norm_in), _lib.ptr(bias),
             _lib.ptr(x0), x0.stride(0) if x0 is not None else 0, float(c_act), float(c_mix), float(p), ctypes.c_uint64(seed),
             ops.seed_dev_ptr(), int(getattr(graph, 'row_offset', 0)), _lib.ptr(bits), _lib.ptr(act), d, _lib.ptr(out_next), d, g.hub_threshold,
-            plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), wsb,
-            _lib.stream_ptr()), 'cb_spmm_csr_fused_f32')
+            plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), wsb, _lib.stream_ptr())
+    with torch.cuda.device(dev):
+        if acc is not None:
+            _lib.check(lib.cb_spmm_csr_fused_acc_f32(_lib.ptr(acc), d, *args), 'cb_spmm_csr_fused_acc_f32')
+        else:
+            fn = lib.cb_spmm_csr_fused_bf16_f32 if bf16 else lib.cb_spmm_csr_fused_f32
+            _lib.check(fn(*args), 'cb_spmm_csr_fused_f32')
     if prof is not None:
         ev1.record()
         # SURVEY §8(d) bytes of the aggregation; the fused store's own streams (mixed-in row read + mask bits) are kept apart
@@ -69,11 +76,9 @@ def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False):
 
 
 def _spmm_t(graph, gr):
-    g, gb, sh = _graph_parts(graph)
-    if sh is not None:
-        gb.profile = getattr(graph, 'profile', None)
-        return gb.spmm(sh.exchange(gr, True))
-    return g.spmm(gr, transpose=True)
+    if hasattr(graph, 'part'):
+        return graph.aggregate(gr, True)
+    return graph.spmm(gr, transpose=True)
 
 
 def _layer_bwd(g, bits, row_scale, gx0, accumulate, p, seed, row0, c_act, c_mix, want_colsum, out_bf16=False):

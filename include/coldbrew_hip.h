@@ -252,6 +252,25 @@ size_t cb_topk_replace_workspace_bytes(int64_t B, int64_t N, int64_t K);
 int cb_topk_replace_f32(const float* q, int64_t ldq, const float* t, int64_t ldt, int64_t B, int64_t N, int64_t D, int32_t K,
                         float* out, int32_t* out_idx, float* out_w, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Node-sharded aggregation in two passes (new; the reference is single-device).  A rank's row block of
+ * the CSR is split by column owner: the interior-column pass (plain cb_spmm_csr_f32, no epilogue) runs while the halo
+ * rows travel over xGMI; the halo-column pass starts from those raw sums and applies the epilogue once:
+ *     out[v, :] = act( row_scale[v] * (acc_init[v, :] + sum_{j in row v of THIS csr} h[col[j], :]) + bias[:] )
+ * Same arguments as cb_spmm_csr_f32 / cb_spmm_csr_fused_f32 plus acc_init [N, ld_init] (fp32, read once; the plain
+ * variant allows acc_init == out).  Replaces the same reference lines as those two (GCN.py:198,238-253,127-133).
+ * ---------------------------------------------------------------------------------- */
+int cb_spmm_csr_acc_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h, int64_t d,
+                        const float* row_scale, const float* bias, int relu, const float* acc_init, int64_t ld_init, float* out,
+                        int64_t ld_out, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
+                        const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream);
+int cb_spmm_csr_fused_acc_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E,
+                              const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias,
+                              const float* mix_src, int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed,
+                              const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, float* out_act, int64_t ld_act,
+                              float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
+                              const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream);
+
 /* out[i, :] = src[idx[i], :] (contiguous out [n_idx, d]) — packs the rows a peer asked for before the
  * all-to-all of the node-sharded halo exchange (new; the reference is single-device). */
 int cb_gather_rows_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, float* out, void* stream);

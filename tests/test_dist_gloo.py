@@ -1,7 +1,8 @@
-"""CPU, world_size 2, gloo: the node-sharded exchange logic of dist.py (partition, row-slice CSR with
-global columns, all-gather exchange, backward exchange, gradient / regulariser all-reduces) against
-the unsharded oracle.  The local SpMM is injected from the oracle's C restatement (the product's HIP
-kernels need a GPU); everything else is the product's dist.py code."""
+"""CPU, world_size 2-3, gloo: the node-sharded logic of dist.py (edge-balanced / equal-row partition, per-rank ingest of the
+row blocks, halo plans, interior/halo two-pass aggregation with the asynchronous exchange, all-gather baseline, backward
+exchange, gradient / regulariser all-reduces, cross-rank column statistics of the norm tricks, rank-consistent initial
+state) against the unsharded oracle.  The passes over node data are served by tests/dist_cpu_compute.py (oracle arithmetic;
+the product's HIP kernels need a GPU); everything else is the product's code."""
 import os
 import socket
 import sys
@@ -23,35 +24,43 @@ def _free_port():
     return p
 
 
-def _oracle_spmm(rowptr, col, h_full, row_scale, bias, relu):
-    import oracle_c
-    out = oracle_c.spmm(rowptr.numpy().astype(np.int64), col.numpy().astype(np.int32), h_full.detach().numpy(),
-                        None if row_scale is None else row_scale.numpy(), None if bias is None else bias.detach().numpy(), relu)
-    return torch.from_numpy(out)
-
-
-def _worker(rank, world, port, name, q, exchange='halo'):
+def _setup(rank, world, port):
     for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+
+
+def _worker(rank, world, port, name, q, exchange, overlap, kind):
+    _setup(rank, world, port)
     try:
         import coldbrew_oracle as orc
+        from dist_cpu_compute import OracleCompute
         from gnn_tail_generalization_amd import dist as cbdist
-        torch.set_num_threads(1)
         g = load_golden(name)
         n = g['cfg']['N_nodes']
-        csr = orc.build_csr(g['edge_index'], n)
+        ei = g['edge_index']
+        csr = orc.build_csr(ei, n)
         a, b = orc.degree_norms(csr)
-        csr.norm_out, csr.norm_in = a, b
-        part = cbdist.Partition(n, world, rank)
-        sg = cbdist.ShardedGraph(csr, part, spmm_fn=_oracle_spmm, exchange=exchange)
+        if kind == 'edges':
+            part = cbdist.Partition.balanced(torch.from_numpy(csr.in_deg), world, rank, node_weight=2)
+        else:
+            part = cbdist.Partition(n, world, rank)
+        sg = cbdist.ShardedGraph(ei, n, part, exchange=exchange, overlap=overlap, compute=OracleCompute())
+        assert sg.overlap == (overlap and exchange == 'halo' and world > 1)
         if exchange == 'halo' and world > 1:
-            assert sg.plan_fwd.n_halo > 0 and sum(sg.plan_fwd.recv_counts) == sg.plan_fwd.n_halo
-            assert sg.plan_fwd.n_halo <= csr.N - part.n_local
+            assert sg.f.plan.n_halo > 0 and sum(sg.f.plan.recv_counts) == sg.f.plan.n_halo
+            assert sg.f.plan.n_halo <= csr.N - part.n_local
+            if sg.overlap:
+                assert sg.f.interior.E + sg.f.halo.E == sg.E and sg.f.whole is None
         assert sg.N == part.n_local and sg.row_offset == part.lo()
-        # the row slices re-assemble the global CSR
+        sym = np.array_equal(csr.rowptr, csr.rowptr_t) and np.array_equal(csr.col, csr.col_t)
+        assert sg.symmetric == sym and (sg.b is sg.f) == sym
+        torch.testing.assert_close(sg.norm_in, part.slice_rows(b))
+        torch.testing.assert_close(sg.norm_out, part.slice_rows(a))
+        # the row blocks re-assemble the global edge set
         counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
         dist.all_gather(counts, torch.tensor([sg.E]))
         assert sum(int(c) for c in counts) == csr.E
@@ -94,22 +103,20 @@ def _worker(rank, world, port, name, q, exchange='halo'):
         for got, ref in [(w1.grad, w1r.grad), (w2.grad, w2r.grad), (b1.grad, b1r.grad), (le_l.grad, part.slice_rows(ler.grad))]:
             torch.testing.assert_close(got, ref, atol=2e-5, rtol=1e-4)
         q.put((rank, 'ok'))
-    except Exception as e:  # noqa: BLE001
+    except Exception:  # noqa: BLE001
         import traceback
         q.put((rank, 'FAIL ' + traceback.format_exc()[-1500:]))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('name,world,exchange', [('case_graph_asym_multi', 2, 'halo'), ('case_graph_powerlaw_d7_d64', 2, 'halo'),
-                                                 ('case_graph_asym_multi', 3, 'halo'), ('case_graph_powerlaw_d7_d64', 2, 'allgather')])
-def test_sharded_exchange_matches_unsharded_oracle(name, world, exchange):
+def _run(target, world, *args):
     import oracle_c
     oracle_c.load()                      # build the C restatement before forking
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q, exchange)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port) + args[:1] + (q,) + args[1:]) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
@@ -117,6 +124,17 @@ def test_sharded_exchange_matches_unsharded_oracle(name, world, exchange):
         p.join(timeout=60)
     for r, msg in res:
         assert msg == 'ok', f'rank {r}: {msg}'
+
+
+@pytest.mark.parametrize('name,world,exchange,overlap,kind', [
+    ('case_graph_asym_multi', 2, 'halo', True, 'edges'),          # directed multigraph: own reverse plan
+    ('case_graph_powerlaw_d7_d64', 2, 'halo', True, 'edges'),     # symmetric: the reverse orientation aliases the forward one
+    ('case_graph_asym_multi', 3, 'halo', True, 'rows'),
+    ('case_graph_powerlaw_d7_d64', 3, 'halo', False, 'edges'),    # single-pass form ([local | halo] matrix, blocking exchange)
+    ('case_graph_powerlaw_d7_d64', 2, 'allgather', False, 'rows'),
+])
+def test_sharded_exchange_matches_unsharded_oracle(name, world, exchange, overlap, kind):
+    _run(_worker, world, name, exchange, overlap, kind)
 
 
 def test_partition_bookkeeping():
@@ -130,3 +148,137 @@ def test_partition_bookkeeping():
         own = parts[0].owner(ids)
         for p in parts:
             assert (own[p.lo():p.hi()] == p.rank).all()
+
+
+def test_edge_balanced_partition():
+    """Boundaries from the prefix sum over in-degree (+ a per-node weight): on a power-law degree vector every rank's share of
+    sum(deg + w) is within one row's cost of the mean, while equal-row blocks are far off; owners are consistent."""
+    from gnn_tail_generalization_amd.dist import Partition
+    gen = torch.Generator().manual_seed(0)
+    deg = (torch.rand(200000, generator=gen) ** -0.8).to(torch.int64)          # heavy tail, ids NOT permuted:
+    deg, _ = torch.sort(deg, descending=True)                                  # hubs first (what real ogbn ids can look like)
+    for world in (2, 4, 8):
+        parts = [Partition.balanced(deg, world, r, node_weight=12) for r in range(world)]
+        assert parts[0].lo() == 0 and parts[-1].hi() == deg.numel() and parts[0].kind == 'edges'
+        assert all(parts[i].hi() == parts[i + 1].lo() for i in range(world - 1))
+        cost = deg + 12
+        shares = torch.tensor([int(cost[p.lo():p.hi()].sum()) for p in parts], dtype=torch.float64)
+        mean = float(cost.sum()) / world
+        assert float((shares - mean).abs().max()) <= float(cost.max()) + 1
+        eq = torch.tensor([int(cost[Partition(deg.numel(), world, r).lo():Partition(deg.numel(), world, r).hi()].sum())
+                           for r in range(world)], dtype=torch.float64)
+        assert float(eq.max()) > 1.15 * mean                                  # the equal-row partition is badly unbalanced here
+        own = parts[0].owner(torch.arange(deg.numel()))
+        for p in parts:
+            assert (own[p.lo():p.hi()] == p.rank).all()
+    empty = Partition.balanced(torch.zeros(3, dtype=torch.int64), 8, 0)        # more ranks than rows: empty blocks are legal
+    assert empty.bounds[-1] == 3 and sum(empty.hi(p) - empty.lo(p) for p in range(8)) == 3
+
+
+def _norm_worker(rank, world, port, _unused, q):
+    _setup(rank, world, port)
+    try:
+        import coldbrew_oracle as orc
+        from dist_cpu_compute import OraclePrims
+        from gnn_tail_generalization_amd import norms_hip
+        from gnn_tail_generalization_amd.dist import Partition, allreduce_grads
+        norms_hip.PRIMS = OraclePrims()
+        n, d = 101, 12
+        gen = torch.Generator().manual_seed(3)
+        x = torch.randn(n, d, generator=gen) * 2 + 0.5
+        gout = torch.randn(n, d, generator=gen)
+        part = Partition(n, world, rank, bounds=[0, 17, n] if world == 2 else None)      # uneven blocks
+        bn = torch.nn.BatchNorm1d(d)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(d, generator=gen) + 0.5)
+            bn.bias.copy_(torch.randn(d, generator=gen))
+        bn_ref = torch.nn.BatchNorm1d(d)
+        bn_ref.load_state_dict(bn.state_dict())
+        for kind in ('batch', 'pair', 'mean'):
+            xl = part.slice_rows(x).clone().requires_grad_(True)
+            xr = x.clone().requires_grad_(True)
+            with norms_hip.row_sharding(None, n):
+                if kind == 'batch':
+                    bn.train()
+                    yl = norms_hip.batch_norm(bn, xl)
+                elif kind == 'pair':
+                    yl = norms_hip.pair_norm(xl)
+                else:
+                    yl = norms_hip.mean_norm(xl)
+                (yl * part.slice_rows(gout)).sum().backward()
+            if kind == 'batch':
+                allreduce_grads([bn.weight, bn.bias])
+                bn_ref.train()
+                yr = bn_ref(xr)
+            elif kind == 'pair':
+                yr = orc.pair_norm(xr)
+            else:
+                yr = orc.mean_norm(xr)
+            (yr * gout).sum().backward()
+            torch.testing.assert_close(yl.detach(), part.slice_rows(yr.detach()), atol=2e-5, rtol=1e-5, msg=lambda m: f'{kind}: {m}')
+            torch.testing.assert_close(xl.grad, part.slice_rows(xr.grad), atol=2e-5, rtol=1e-4, msg=lambda m: f'{kind} dx: {m}')
+            if kind == 'batch':
+                torch.testing.assert_close(bn.weight.grad, bn_ref.weight.grad, atol=2e-5, rtol=1e-4)
+                torch.testing.assert_close(bn.bias.grad, bn_ref.bias.grad, atol=2e-5, rtol=1e-4)
+                torch.testing.assert_close(bn.running_mean, bn_ref.running_mean, atol=1e-6, rtol=1e-5)
+                torch.testing.assert_close(bn.running_var, bn_ref.running_var, atol=1e-6, rtol=1e-5)
+        q.put((rank, 'ok'))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, 'FAIL ' + traceback.format_exc()[-1500:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_column_statistic_norms_span_all_ranks(world):
+    """BatchNorm1d / PairNorm / MeanNorm (norm_tricks.py:20-41,132) on row shards == the unsharded norm: outputs, input gradients,
+    affine-parameter gradients (after the replicated-gradient all-reduce) and running statistics."""
+    _run(_norm_worker, world, None)
+
+
+def _init_worker(rank, world, port, _unused, q):
+    _setup(rank, world, port)
+    try:
+        import contextlib
+        import io
+        from gnn_tail_generalization_amd.base_options import BaseOptions
+        from gnn_tail_generalization_amd.dist import Partition, sync_initial_state
+        from gnn_tail_generalization_amd.GNN_model import TeacherGNN
+        from gnn_tail_generalization_amd.utils import set_arch_configs
+        n = 1000                                                    # 1000 % 3 != 0: the last block is shorter
+        part = Partition(n, world, rank)
+        with contextlib.redirect_stdout(io.StringIO()):
+            args = BaseOptions().get_arguments(['--dataset=S-pubmed', '--whetherHasSE=111', '--num_layers=2', '--dim_learnable_input=16',
+                                                '--manual_assign_GPU=0'])
+        set_arch_configs(args)
+        args.N_nodes = part.n_local
+        torch.manual_seed(args.random_seed)
+        model = TeacherGNN(args)                                    # parameters only; no compute on CPU
+        before = torch.cat([p.detach().reshape(-1) for k, p in model.named_parameters() if not k.endswith('.le') and k != 'embs'])
+        sync_initial_state(model, part, None, args.random_seed)
+        rep = torch.cat([p.detach().reshape(-1) for k, p in model.named_parameters() if not k.endswith('.le') and k != 'embs'])
+        got = [torch.zeros_like(rep) for _ in range(world)]
+        dist.all_gather(got, rep)
+        assert all(torch.equal(got[0], t) for t in got), 'replicated weights differ across ranks after sync_initial_state'
+        pre = [torch.zeros_like(before) for _ in range(world)]
+        dist.all_gather(pre, before)
+        differs = not all(torch.equal(pre[0], t) for t in pre)      # the hazard the sync removes (block sizes 334 / 334 / 332)
+        le = model.model.model.layers_GCN[0].le.detach()
+        assert le.shape[0] == part.n_local and model.embs.shape[0] == part.n_local
+        head = [torch.zeros(4, le.shape[1]) for _ in range(world)]
+        dist.all_gather(head, le[:4].contiguous())
+        assert not torch.equal(head[0], head[1]), 'per-node tables must not repeat across ranks'
+        assert float(model.embs.detach().abs().max()) < 0.01        # GNN_normalizations.py:18-22 scale kept
+        q.put((rank, 'ok' if (differs or world == 1) else 'FAIL the unsynchronised init was already consistent: test lost its teeth'))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, 'FAIL ' + traceback.format_exc()[-1500:]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fresh_sharded_init_is_consistent_across_ranks():
+    """with whetherHasSE != 000 and N % world != 0 the ranks draw different amounts of RNG for their
+    per-node tables, so the replicated weights drawn afterwards differ — sync_initial_state must make them identical."""
+    _run(_init_worker, 3, None)

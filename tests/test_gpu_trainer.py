@@ -81,7 +81,7 @@ def test_sharded_trainer_world1_matches_plain_trainer():
     if not dist.is_initialized():
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))
     try:
-        losses = []
+        losses, sd0 = [], None
         for cls in (trainer, ShardedTrainer):
             with contextlib.redirect_stdout(io.StringIO()):
                 args = BaseOptions().get_arguments(argv)
@@ -90,6 +90,10 @@ def test_sharded_trainer_world1_matches_plain_trainer():
                 t = cls(args, 0)
                 torch.manual_seed(0)
                 t.setup_teacherGNN()
+            if sd0 is None:
+                sd0 = {k: v.detach().clone() for k, v in t.teacherGNN.state_dict().items()}
+            else:       # a fresh sharded model re-draws its per-node tables per rank (dist.sync_initial_state): start from the same state
+                t.load_full_state_dict(sd0)
             ops._seed_override[:] = list(range(500, 530))
             losses.append([float(t.train_step()) for _ in range(4)])
             ops._seed_override[:] = []
