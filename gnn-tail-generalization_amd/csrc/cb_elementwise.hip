@@ -278,9 +278,10 @@ __global__ void __launch_bounds__(kBlock) k_sumsq(const float* __restrict__ x, i
 
 // out[0] = sqrt(sum partial) (Frobenius norm, th.norm(self.le) GCN.py:232); out[1] = sum
 __global__ void k_norm_finish(const float* __restrict__ partial, int nparts, float* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double t = 0.0;
-    for (int p = 0; p < nparts; ++p) t += (double)partial[p];
+  double t = 0.0;
+  for (int p = threadIdx.x; p < nparts; p += kWave) t += (double)partial[p];
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+  if (threadIdx.x == 0) {
     out[0] = (float)sqrt(t);
     out[1] = (float)t;
   }
@@ -325,12 +326,17 @@ __global__ void __launch_bounds__(kBlock) k_nll_fused(const float* __restrict__ 
   }
 }
 
+// one wavefront: lane l sums partials l, l+64, ... in double, then a fixed-order butterfly (deterministic)
+__device__ __forceinline__ double wave_sum_partials(const float* __restrict__ partial, int nparts) {
+  double t = 0.0;
+  for (int p = threadIdx.x; p < nparts; p += kWave) t += (double)partial[p];
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+  return t;
+}
+
 __global__ void k_loss_finish(const float* __restrict__ partial, int nparts, float inv_count, float* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double t = 0.0;
-    for (int p = 0; p < nparts; ++p) t += (double)partial[p];
-    out[0] = (float)(t * (double)inv_count);
-  }
+  const double t = wave_sum_partials(partial, nparts);
+  if (threadIdx.x == 0) out[0] = (float)(t * (double)inv_count);
 }
 
 // torch.optim.Adam semantics (trainer_node_classification.py:310): g += wd*p; m,v EMA; bias-corrected step
@@ -363,6 +369,69 @@ __global__ void __launch_bounds__(kBlock) k_adam(float* __restrict__ p, const fl
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+      const float gg = gv[k] + wd * pv[k];
+      mv[k] = b1 * mv[k] + (1.f - b1) * gg;
+      vv[k] = b2 * vv[k] + (1.f - b2) * gg * gg;
+      const float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
+      pv[k] = pv[k] - step * (mv[k] / denom);
+    }
+    if (full) {
+      *reinterpret_cast<float4*>(p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      *reinterpret_cast<float4*>(m + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+      *reinterpret_cast<float4*>(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (i + k < n) { p[i + k] = pv[k]; m[i + k] = mv[k]; v[i + k] = vv[k]; }
+    }
+  }
+}
+
+// All parameter tensors of the model in ONE launch: blockIdx.y selects the tensor, blockIdx.x strides over its elements.
+// The table travels by value in the kernel arguments (no device-side table to keep alive, capturable in a hipGraph).
+constexpr int kAdamMax = 24;
+struct AdamTable {
+  float* p[kAdamMax];
+  const float* g[kAdamMax];
+  float* m[kAdamMax];
+  float* v[kAdamMax];
+  int64_t n[kAdamMax];
+};
+
+__global__ void __launch_bounds__(kBlock) k_adam_multi(AdamTable t, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                       float bc2_sqrt, const int64_t* __restrict__ step_dev) {
+  const int ti = blockIdx.y;
+  float* __restrict__ p = t.p[ti];
+  const float* __restrict__ g = t.g[ti];
+  float* __restrict__ m = t.m[ti];
+  float* __restrict__ v = t.v[ti];
+  const int64_t n = t.n[ti];
+  if (step_dev) {
+    const double s = (double)*step_dev;
+    bc1 = (float)(1.0 - pow((double)b1, s));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, s));
+  }
+  const float step = lr / bc1;
+  const bool vec_ok = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) == 0;
+  const int64_t nq = (n + 3) / 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = q * 4;
+    float pv[4], gv[4], mv[4], vv[4];
+    const bool full = vec_ok && i + 4 <= n;
+    if (full) {
+      const float4 a = *reinterpret_cast<const float4*>(p + i), b = *reinterpret_cast<const float4*>(g + i);
+      const float4 c = *reinterpret_cast<const float4*>(m + i), d = *reinterpret_cast<const float4*>(v + i);
+      pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w;
+      gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
+      mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w;
+      vv[0] = d.x; vv[1] = d.y; vv[2] = d.z; vv[3] = d.w;
+    } else {
+      for (int k = 0; k < 4; ++k) {
+        const bool in = i + k < n;
+        pv[k] = in ? p[i + k] : 0.f; gv[k] = in ? g[i + k] : 0.f; mv[k] = in ? m[i + k] : 0.f; vv[k] = in ? v[i + k] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {      // same arithmetic as k_adam
       const float gg = gv[k] + wd * pv[k];
       mv[k] = b1 * mv[k] + (1.f - b1) * gg;
       vv[k] = b2 * vv[k] + (1.f - b2) * gg * gg;
@@ -481,6 +550,32 @@ extern "C" int cb_adam_step_f32(float* p, const float* g, float* m, float* v, in
   hipLaunchKernelGGL(k_adam, dim3(grid_for((n + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
                      eps, weight_decay, (float)bc1, (float)sqrt(bc2), step_dev, vec_ok);
   CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
+extern "C" int cb_adam_multi_f32(int32_t n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                                 const int64_t* numel, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                                 const int64_t* step_dev, void* stream) {
+  CB_CHECK_ARG(n_tensors >= 0 && (step >= 1 || step_dev) && (n_tensors == 0 || (p && g && m && v && numel)), CB_E_INVALID,
+               "cb_adam_multi_f32: bad argument");
+  if (step < 1) step = 1;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  for (int base = 0; base < n_tensors; base += kAdamMax) {
+    AdamTable t{};
+    const int cnt = n_tensors - base < kAdamMax ? n_tensors - base : kAdamMax;
+    int64_t nmax = 0;
+    for (int i = 0; i < cnt; ++i) {
+      CB_CHECK_ARG(numel[base + i] >= 0 && (numel[base + i] == 0 || (p[base + i] && g[base + i] && m[base + i] && v[base + i])), CB_E_INVALID,
+                   "cb_adam_multi_f32: null tensor %d", base + i);
+      t.p[i] = p[base + i]; t.g[i] = g[base + i]; t.m[i] = m[base + i]; t.v[i] = v[base + i]; t.n[i] = numel[base + i];
+      if (t.n[i] > nmax) nmax = t.n[i];
+    }
+    if (nmax == 0) continue;
+    hipLaunchKernelGGL(k_adam_multi, dim3((unsigned)grid_for((nmax + 3) / 4), (unsigned)cnt), dim3(kBlock), 0, (hipStream_t)stream, t, lr,
+                       beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), step_dev);
+    CB_LAUNCH_CHECK();
+  }
   return CB_OK;
 }
 

@@ -76,6 +76,19 @@ __device__ __forceinline__ void gather_stream(float (&v)[VEC], const float* __re
   for (int i = 0; i < VEC; ++i) v[i] = __builtin_nontemporal_load(p + i);
 }
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// fp32 x4 source row chunk with the streaming (nt) cache policy: one global_load_dwordx4 ... nt
+__device__ __forceinline__ void gather_nt4(float (&v)[4], const float* __restrict__ p) {
+  const f32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+  v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+
+// Gather policy of the source-row loads (GP): 0 = default cache policy for every row; 1 = every row streaming (nt);
+// 2 = the CSR's column ids carry a "hot source" flag in bit 31 (set at graph build for the most-referenced source rows):
+// hot rows default policy, all others streaming, so that the rows that ARE re-used keep L2 / Infinity Cache to themselves.
+constexpr int kColMask = 0x7fffffff;
+
 // Source-row load of the aggregation: fp32 rows, or bf16-stored rows widened to fp32 (accumulation stays fp32)
 template <int VEC, typename HT>
 __device__ __forceinline__ void gather_in(float (&v)[VEC], const HT* __restrict__ p) {
@@ -111,6 +124,7 @@ struct Epilogue {
   // path, dist.py: out = act(row_scale * (acc_init + sum over THIS CSR's columns) + bias))
   const float* acc_init;
   int64_t ld_init;
+  int col_flags;           // 1: bit 31 of every column id marks a hot source row (gather policy 2, see gather_pol)
 };
 
 // Extended epilogue of the fused residual trunk (GCN.py:127-133 folded into the aggregation's store):
@@ -177,7 +191,21 @@ __device__ __forceinline__ void write_row(float* __restrict__ out_row, const flo
 
 // Walks the contiguous edge range of local rows [rlo, rhi) of this wavefront's row block.
 // my_ptr: lane i holds rowptr[r0 + i] (i <= nr).  All control flow is wave-uniform.
-template <int VEC, int U, bool FULL, bool FUSED, bool ACC, typename HT>
+// wave-uniform `craw` = column id as stored (GP == 2: bit 31 = hot flag)
+template <int VEC, typename HT, int GP>
+__device__ __forceinline__ void gather_pol(float (&v)[VEC], const HT* __restrict__ h_lane, int64_t ld_h, int craw) {
+  if constexpr (GP == 0 || VEC != 4 || sizeof(HT) != 4) {
+    gather_in<VEC, HT>(v, h_lane + (int64_t)craw * ld_h);
+  } else if constexpr (GP == 1) {
+    gather_nt4(v, reinterpret_cast<const float*>(h_lane) + (int64_t)craw * ld_h);
+  } else {
+    const float* p = reinterpret_cast<const float*>(h_lane) + (int64_t)(craw & kColMask) * ld_h;
+    if (craw < 0) gather_in<VEC, HT>(v, reinterpret_cast<const HT*>(p));
+    else gather_nt4(v, p);
+  }
+}
+
+template <int VEC, int U, bool FULL, bool FUSED, bool ACC, typename HT, int GP = 0>
 __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr, float my_scale, int r0, const int* __restrict__ col,
                                             const HT* __restrict__ h_lane, int64_t ld_h, float* __restrict__ out_lane,
                                             int64_t ld_out, bool active_in, int relu, const float (&bvec)[VEC], const FusedEpi& fe,
@@ -241,7 +269,7 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int c = bcast_lane(my_col, k + u);
-        if (active) gather_in<VEC, HT>(v[u], h_lane + (int64_t)c * ld_h);
+        if (active) gather_pol<VEC, HT, GP>(v[u], h_lane, ld_h, c);
         else zero<VEC>(v[u]);
       }
 #pragma unroll
@@ -255,7 +283,7 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
     for (; k < cnt; ++k) {
       const int c = bcast_lane(my_col, k);
       float v[VEC];
-      if (active) gather_in<VEC, HT>(v, h_lane + (int64_t)c * ld_h);
+      if (active) gather_pol<VEC, HT, GP>(v, h_lane, ld_h, c);
       else zero<VEC>(v);
       const int e = base + k;
       while (e == cur_end) flush();
@@ -266,7 +294,7 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
   while (cur < rhi) flush();  // last row + trailing empty rows
 }
 
-template <int VEC, int RPW, int U, bool FULL, bool FUSED, typename HT, bool ACC = false>
+template <int VEC, int RPW, int U, bool FULL, bool FUSED, typename HT, bool ACC = false, int GP = 0>
 __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                    const HT* __restrict__ h, int64_t ld_h, float* __restrict__ out,
                                                    int64_t ld_out, int n_rows, int d, Epilogue ep, int hub_T, FusedEpi fe) {
@@ -297,7 +325,7 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
   const float* init_lane = ACC ? ep.acc_init + c0 : nullptr;
 
   if (hubmask == 0) {
-    stream_rows<VEC, U, FULL, FUSED, ACC, HT>(0, nr, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0,
+    stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP>(0, nr, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0,
                                               init_lane, ep.ld_init);
   } else {
     int r = 0;
@@ -305,7 +333,7 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
       unsigned long long m = hubmask >> r;
       int nh = m ? r + (__ffsll((long long)m) - 1) : nr;
       if (nh > r)
-        stream_rows<VEC, U, FULL, FUSED, ACC, HT>(r, nh, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe,
+        stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP>(r, nh, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe,
                                                   c0, init_lane, ep.ld_init);
       r = nh + 1;
     }
@@ -313,7 +341,7 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
 }
 
 // One wavefront per chunk of T edges of a hub row -> one partial row in `partial`.
-template <int VEC, int U, typename HT>
+template <int VEC, int U, typename HT, int GP = 0>
 __global__ void __launch_bounds__(256) k_spmm_hub_chunks(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                          const HT* __restrict__ h, int64_t ld_h, int d, int hub_T,
                                                          int n_hubs, int n_chunks, const int* __restrict__ hub_rows,
@@ -347,7 +375,7 @@ __global__ void __launch_bounds__(256) k_spmm_hub_chunks(const int* __restrict__
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int c = bcast_lane(my_col, k + u);
-        if (active) gather_in<VEC, HT>(v[u], h_lane + (int64_t)c * ld_h);
+        if (active) gather_pol<VEC, HT, GP>(v[u], h_lane, ld_h, c);
         else zero<VEC>(v[u]);
       }
 #pragma unroll
@@ -358,7 +386,7 @@ __global__ void __launch_bounds__(256) k_spmm_hub_chunks(const int* __restrict__
     for (; k < cnt; ++k) {
       const int c = bcast_lane(my_col, k);
       float v[VEC];
-      if (active) gather_in<VEC, HT>(v, h_lane + (int64_t)c * ld_h);
+      if (active) gather_pol<VEC, HT, GP>(v, h_lane, ld_h, c);
       else zero<VEC>(v);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] += v[i];
@@ -422,6 +450,13 @@ __global__ void __launch_bounds__(256) k_spmm_hub_finish(int d, int n_hubs, cons
 
 static inline int64_t partial_ld(int64_t d) { return (d + 3) / 4 * 4; }
 
+// Gather policy of a launch: 2 when the caller hands over flagged column ids (col_flags), else 0; the measurement hook
+// CB_SPMM_GATHER=1 turns plain-id launches into all-streaming ones (measured slower: profiles/r02_spmm_gather_policy.md).
+static int gather_policy(int col_flags) {
+  static const int env = getenv("CB_SPMM_GATHER") ? atoi(getenv("CB_SPMM_GATHER")) : 0;
+  return col_flags ? 2 : (env == 1 ? 1 : 0);
+}
+
 template <int VEC, bool FUSED, int RPW, int U, typename HT>
 static int launch_spmm_cfg(const int32_t* rowptr, const int32_t* col, int64_t N, const HT* h, int64_t ld_h, int64_t d,
                            Epilogue ep, float* out, int64_t ld_out, int hub_T, int n_hubs, int n_chunks,
@@ -432,25 +467,40 @@ static int launch_spmm_cfg(const int32_t* rowptr, const int32_t* col, int64_t N,
   {
     int64_t n_waves = (N + RPW - 1) / RPW;
     dim3 grid((unsigned)((n_waves + waves_per_block - 1) / waves_per_block), ny);
-#define CB_ROWS_LAUNCH(FULL_, FUSED_, ACC_)                                                                                         \
-  hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, FULL_, FUSED_, HT, ACC_>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h, \
-                     out, ld_out, (int)N, (int)d, ep, hub_T, fe)
+#define CB_ROWS_LAUNCH_GP(FULL_, FUSED_, ACC_, GP_)                                                                                 \
+  hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, FULL_, FUSED_, HT, ACC_, GP_>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, \
+                     ld_h, out, ld_out, (int)N, (int)d, ep, hub_T, fe)
+#define CB_ROWS_LAUNCH(FULL_, FUSED_, ACC_) CB_ROWS_LAUNCH_GP(FULL_, FUSED_, ACC_, 0)
     const bool acc = ep.acc_init != nullptr;
+    constexpr bool kGP = VEC == 4 && sizeof(HT) == 4 && RPW == 16 && U == 8;   // gather-policy variants: fp32 d % 256 == 0 kernels only
+    const int gp = kGP && !acc && d % tile == 0 ? gather_policy(ep.col_flags) : 0;
+    CB_CHECK_ARG(!ep.col_flags || gp == 2, CB_E_INVALID, "flagged column ids are only understood by the fp32 d %% 256 == 0 kernels");
     if constexpr (FUSED) {
-      if (acc) CB_ROWS_LAUNCH(true, true, true); else CB_ROWS_LAUNCH(true, true, false);
+      if (acc) CB_ROWS_LAUNCH(true, true, true);
+      else if constexpr (kGP) { if (gp == 1) CB_ROWS_LAUNCH_GP(true, true, false, 1); else if (gp == 2) CB_ROWS_LAUNCH_GP(true, true, false, 2); else CB_ROWS_LAUNCH(true, true, false); }
+      else CB_ROWS_LAUNCH(true, true, false);
     } else if (d % tile == 0) {
-      if (acc) CB_ROWS_LAUNCH(true, false, true); else CB_ROWS_LAUNCH(true, false, false);
+      if (acc) CB_ROWS_LAUNCH(true, false, true);
+      else if constexpr (kGP) { if (gp == 1) CB_ROWS_LAUNCH_GP(true, false, false, 1); else if (gp == 2) CB_ROWS_LAUNCH_GP(true, false, false, 2); else CB_ROWS_LAUNCH(true, false, false); }
+      else CB_ROWS_LAUNCH(true, false, false);
     } else {
       if (acc) CB_ROWS_LAUNCH(false, false, true); else CB_ROWS_LAUNCH(false, false, false);
     }
 #undef CB_ROWS_LAUNCH
+#undef CB_ROWS_LAUNCH_GP
     CB_LAUNCH_CHECK();
   }
   if (n_hubs > 0) {
     const int64_t ld_p = partial_ld(d);
     dim3 grid((unsigned)((n_chunks + waves_per_block - 1) / waves_per_block), ny);
-    hipLaunchKernelGGL((k_spmm_hub_chunks<VEC, 8, HT>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h, (int)d,
-                       hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, ld_p);
+    constexpr bool kGPh = VEC == 4 && sizeof(HT) == 4 && RPW == 16 && U == 8;
+    const int gph = kGPh && d % tile == 0 ? gather_policy(ep.col_flags) : 0;
+#define CB_HUB_LAUNCH(GP_)                                                                                                       \
+  hipLaunchKernelGGL((k_spmm_hub_chunks<VEC, 8, HT, GP_>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h, (int)d, \
+                     hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, ld_p)
+    if constexpr (kGPh) { if (gph == 1) CB_HUB_LAUNCH(1); else if (gph == 2) CB_HUB_LAUNCH(2); else CB_HUB_LAUNCH(0); }
+    else CB_HUB_LAUNCH(0);
+#undef CB_HUB_LAUNCH
     CB_LAUNCH_CHECK();
     dim3 grid2((unsigned)((n_hubs + waves_per_block - 1) / waves_per_block), ny);
     hipLaunchKernelGGL((k_spmm_hub_finish<VEC, FUSED>), grid2, dim3(kWave * waves_per_block), 0, st, (int)d, n_hubs, hub_rows,
@@ -507,7 +557,7 @@ extern "C" size_t cb_spmm_workspace_bytes(int64_t n_chunks, int64_t d) {
   return (size_t)n_chunks * (size_t)partial_ld(d) * sizeof(float);
 }
 
-static int spmm_plain_impl(const char* who, const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h,
+static int spmm_plain_impl(const char* who, const int32_t* rowptr, const int32_t* col, int col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h,
                            int64_t d, const float* row_scale, const float* bias, int relu, const float* acc_init, int64_t ld_init,
                            float* out, int64_t ld_out, int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
                            const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
@@ -520,7 +570,8 @@ static int spmm_plain_impl(const char* who, const int32_t* rowptr, const int32_t
   CB_CHECK_ARG(n_hubs == 0 || (hub_rows && hub_chunk_ptr && ws && ws_bytes >= cb_spmm_workspace_bytes(n_chunks, d)),
                CB_E_WORKSPACE, "%s: hub plan given but workspace missing/too small (%zu < %zu)", who, ws_bytes,
                cb_spmm_workspace_bytes(n_chunks, d));
-  Epilogue ep{row_scale, bias, relu, acc_init, ld_init};
+  Epilogue ep{row_scale, bias, relu, acc_init, ld_init, col_flags};
+  CB_CHECK_ARG(!col_flags || (!acc_init && d % 256 == 0), CB_E_INVALID, "%s: flagged column ids need d %% 256 == 0 and no acc_init", who);
   hipStream_t st = (hipStream_t)stream;
   if (n_hubs == 0) hub_T = INT32_MAX;  // no plan given (or no hub rows): every row is reduced whole by one wavefront
   const bool ini16 = !acc_init || (((uintptr_t)acc_init % 16 == 0) && ld_init % 4 == 0);
@@ -529,6 +580,7 @@ static int spmm_plain_impl(const char* who, const int32_t* rowptr, const int32_t
   const bool al8 = ((uintptr_t)h % 8 == 0) && ((uintptr_t)out % 8 == 0) && (ld_h % 2 == 0) && (ld_out % 2 == 0) && (d % 2 == 0) && ini8;
   float* partial = (float*)ws;
   static const bool small_off = getenv("CB_SPMM_NO_SMALL") != nullptr;   // measurement hook: one wavefront per gathered row at every width
+  CB_CHECK_ARG(!col_flags || al16, CB_E_INVALID, "%s: flagged column ids need 16-byte aligned rows", who);
   if (!small_off && !acc_init && spmm_small_eligible(d, al16))
     return launch_spmm_small(rowptr, col, N, h, ld_h, d, row_scale, bias, relu, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows,
                              hub_chunk_ptr, partial, partial_ld(d), al16, st);
@@ -539,11 +591,11 @@ static int spmm_plain_impl(const char* who, const int32_t* rowptr, const int32_t
   return launch_spmm<1>(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st);
 }
 
-extern "C" int cb_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h,
-                               int64_t d, const float* row_scale, const float* bias, int relu, float* out, int64_t ld_out,
+extern "C" int cb_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h,
+                               int64_t ld_h, int64_t d, const float* row_scale, const float* bias, int relu, float* out, int64_t ld_out,
                                int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
                                const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
-  return spmm_plain_impl("cb_spmm_csr_f32", rowptr, col, N, E, h, ld_h, d, row_scale, bias, relu, nullptr, 0, out, ld_out, hub_T, n_hubs,
+  return spmm_plain_impl("cb_spmm_csr_f32", rowptr, col, col_flags, N, E, h, ld_h, d, row_scale, bias, relu, nullptr, 0, out, ld_out, hub_T, n_hubs,
                          n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, stream);
 }
 
@@ -554,11 +606,11 @@ extern "C" int cb_spmm_csr_acc_f32(const int32_t* rowptr, const int32_t* col, in
                                    int64_t ld_init, float* out, int64_t ld_out, int32_t hub_T, int32_t n_hubs, int32_t n_chunks,
                                    const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
   CB_CHECK_ARG(acc_init != nullptr || N == 0 || d == 0, CB_E_INVALID, "cb_spmm_csr_acc_f32: acc_init is null");
-  return spmm_plain_impl("cb_spmm_csr_acc_f32", rowptr, col, N, E, h, ld_h, d, row_scale, bias, relu, acc_init, ld_init, out, ld_out, hub_T,
+  return spmm_plain_impl("cb_spmm_csr_acc_f32", rowptr, col, 0, N, E, h, ld_h, d, row_scale, bias, relu, acc_init, ld_init, out, ld_out, hub_T,
                          n_hubs, n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, stream);
 }
 
-static int spmm_fused_impl(int h_bf16, const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const void* h, int64_t ld_h,
+static int spmm_fused_impl(int h_bf16, const float* acc_init, int64_t ld_init, int col_flags, const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const void* h, int64_t ld_h,
                                      int64_t d, const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix,
                                      float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits,
                                      float* out_act, int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_T,
@@ -579,7 +631,8 @@ static int spmm_fused_impl(int h_bf16, const float* acc_init, int64_t ld_init, c
   CB_CHECK_ARG(n_hubs == 0 || (hub_rows && hub_chunk_ptr && ws && ws_bytes >= cb_spmm_workspace_bytes(n_chunks, d)),
                CB_E_WORKSPACE, "cb_spmm_csr_fused_f32: hub plan given but workspace missing/too small");
   if (n_hubs == 0) hub_T = INT32_MAX;
-  Epilogue ep{row_scale, bias, 1, acc_init, ld_init};
+  Epilogue ep{row_scale, bias, 1, acc_init, ld_init, col_flags};
+  CB_CHECK_ARG(!col_flags || (!acc_init && !h_bf16), CB_E_INVALID, "cb_spmm_csr_fused_f32: flagged column ids: fp32 rows, no acc_init");
   FusedEpi fe{};
   fe.mix_src = mix_src; fe.ld_mix = ld_mix; fe.c_act = c_act; fe.c_mix = c_mix;
   fe.thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
@@ -603,13 +656,13 @@ static int spmm_fused_impl(int h_bf16, const float* acc_init, int64_t ld_init, c
   rowptr, col, N, E, h, ld_h, d, row_scale, bias, mix_src, ld_mix, c_act, c_mix, drop_p, seed, seed_dev, row0, relu_bits, out_act, ld_act,  \
       out_next, ld_next, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, stream
 
-extern "C" int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h,
-                                     int64_t d, const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix,
+extern "C" int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h,
+                                     int64_t ld_h, int64_t d, const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix,
                                      float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0,
                                      uint64_t* relu_bits, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
                                      int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
                                      const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
-  return spmm_fused_impl(0, nullptr, 0, CB_FUSED_ARGS);
+  return spmm_fused_impl(0, nullptr, 0, col_flags, CB_FUSED_ARGS);
 }
 
 // Fused store of the residual trunk on top of the interior-column partial sums (second pass of the node-sharded aggregation)
@@ -620,7 +673,7 @@ extern "C" int cb_spmm_csr_fused_acc_f32(const float* acc_init, int64_t ld_init,
                                          float* out_next, int64_t ld_next, int32_t hub_T, int32_t n_hubs, int32_t n_chunks,
                                          const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
   CB_CHECK_ARG(acc_init != nullptr || N == 0, CB_E_INVALID, "cb_spmm_csr_fused_acc_f32: acc_init is null");
-  return spmm_fused_impl(0, acc_init, ld_init, CB_FUSED_ARGS);
+  return spmm_fused_impl(0, acc_init, ld_init, 0, CB_FUSED_ARGS);
 }
 
 extern "C" int cb_spmm_csr_fused_bf16_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const uint16_t* h,
@@ -629,7 +682,7 @@ extern "C" int cb_spmm_csr_fused_bf16_f32(const int32_t* rowptr, const int32_t* 
                                           const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
                                           int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
                                           const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
-  return spmm_fused_impl(1, nullptr, 0, CB_FUSED_ARGS);
+  return spmm_fused_impl(1, nullptr, 0, 0, CB_FUSED_ARGS);
 }
 
 // bf16-stored source rows, fp32 accumulation and output (build extension: BASELINE config 2)
@@ -645,7 +698,7 @@ extern "C" int cb_spmm_csr_bf16_f32(const int32_t* rowptr, const int32_t* col, i
   CB_CHECK_ARG(hub_T > 0 && n_hubs >= 0 && n_chunks >= 0, CB_E_INVALID, "cb_spmm_csr_bf16_f32: bad hub plan");
   CB_CHECK_ARG(n_hubs == 0 || (hub_rows && hub_chunk_ptr && ws && ws_bytes >= cb_spmm_workspace_bytes(n_chunks, d)),
                CB_E_WORKSPACE, "cb_spmm_csr_bf16_f32: hub plan given but workspace missing/too small");
-  Epilogue ep{row_scale, bias, relu, nullptr, 0};
+  Epilogue ep{row_scale, bias, relu, nullptr, 0, 0};
   hipStream_t st = (hipStream_t)stream;
   if (n_hubs == 0) hub_T = INT32_MAX;
   const bf16_t* hb = (const bf16_t*)h;

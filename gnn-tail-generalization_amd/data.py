@@ -135,7 +135,7 @@ def synthetic_data(name, seed=0, device='cpu', n_override=None):
 
 
 def load_file(path, device):
-    blob = torch.load(path, map_location='cpu', weights_only=False)
+    blob = torch.load(path, map_location='cpu', weights_only=True)     # a dict of tensors: no pickled code is executed
     d = Data(**{k: v for k, v in blob.items()})
     return d.to(device)
 

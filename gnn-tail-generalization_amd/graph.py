@@ -11,6 +11,7 @@ import torch
 from . import _lib
 
 HUB_THRESHOLD = 256
+HOT_ROWS = 262144          # 256 MiB of 1 KiB (d = 256 fp32) rows = the Infinity Cache; measured optimum on S-pl10M
 
 
 class ZeroInDegreeError(RuntimeError):
@@ -68,7 +69,29 @@ class CSRGraph:
         self._plan = self._make_plan(self.rowptr)
         self._plan_t = self._plan if self.symmetric else self._make_plan(self.rowptr_t)
         self._ws = None
+        self._hot_cols()
         self.profile = None      # bench.py sets a list: (start_event, end_event, SURVEY §8(d) bytes, extra epilogue bytes) per aggregation
+
+    def _hot_cols(self):
+        """Kernel-side column arrays with the hot-source flag in bit 31 (include/coldbrew_hip.h, cb_spmm_csr_f32 col_flags):
+        the HOT_ROWS most-referenced source rows of each orientation (referenced at least twice) keep the default cache
+        policy, every other gather streams.  self.col / self.col_t stay the plain ids (the bit-exact CSR contract).
+        CB_SPMM_GATHER=0 (measurement hook) switches the flags off, CB_SPMM_HOT_ROWS overrides the count."""
+        import os
+        self.col_k = self.col_t_k = None
+        if os.environ.get('CB_SPMM_GATHER', '2') != '2' or self.E == 0 or self.N < 2 * HOT_ROWS:
+            return      # small graphs: the whole feature matrix is cache resident anyway
+        k = min(int(os.environ.get('CB_SPMM_HOT_ROWS', HOT_ROWS)), self.N)
+
+        def flag(col):
+            refs = torch.bincount(col[:self.E].long(), minlength=self.n_cols)          # how often each source row is gathered per launch
+            thr = torch.clamp(torch.topk(refs, k).values[-1], min=2)
+            hot = (refs >= thr)[col.long()]
+            return torch.where(hot, col | (-2 ** 31), col).to(torch.int32)
+
+        self.col_k = flag(self.col)
+        if self.rowptr_t is not None:
+            self.col_t_k = self.col_k if self.symmetric else flag(self.col_t)
 
     @classmethod
     def from_csr(cls, rowptr, col, n_cols, hub_threshold=HUB_THRESHOLD):
@@ -87,6 +110,7 @@ class CSRGraph:
         g._plan_t = None
         g._ws, g.profile = None, None
         g.row_offset = 0
+        g.col_k = g.col_t_k = None
         return g
 
     @classmethod
@@ -176,6 +200,11 @@ class CSRGraph:
         if out is None:
             out = torch.empty((self.N, d), dtype=torch.float32, device=h.device)
         rowptr, col, plan = (self.rowptr_t, self.col_t, self._plan_t) if transpose else (self.rowptr, self.col, self._plan)
+        col_k = self.col_t_k if transpose else self.col_k
+        flags = int(col_k is not None and not bf16 and acc_init is None and d % 256 == 0 and h.data_ptr() % 16 == 0
+                    and out.data_ptr() % 16 == 0 and h.stride(0) % 4 == 0 and out.stride(0) % 4 == 0)
+        if flags:
+            col = col_k
         ws_bytes = lib.cb_spmm_workspace_bytes(plan.n_chunks, d)
         ws = self._workspace(ws_bytes)
         ld_h = h.stride(0) if h.shape[0] > 1 else d
@@ -196,7 +225,7 @@ class CSRGraph:
                                                    _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
                            'cb_spmm_csr_acc_f32')
             else:
-                _lib.check(fn(_lib.ptr(rowptr), _lib.ptr(col), self.N, self.E, _lib.ptr(h), ld_h, d,
+                _lib.check(fn(_lib.ptr(rowptr), _lib.ptr(col), *([flags] if not bf16 else []), self.N, self.E, _lib.ptr(h), ld_h, d,
                               _lib.ptr(row_scale), _lib.ptr(bias), int(bool(relu)), _lib.ptr(out), ld_o,
                               self.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows),
                               _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),

@@ -1,6 +1,6 @@
 """Optimisers of the path (trainer_node_classification.py:293-296,310): `--optfun` names map to
-classes with torch.optim's constructor signature.  Adam runs as one fused HIP kernel per parameter
-tensor (cb_adam_step_f32) with torch.optim.Adam's update rule."""
+classes with torch.optim's constructor signature.  Adam runs as ONE fused HIP launch for all parameter
+tensors of a group (cb_adam_multi_f32) with torch.optim.Adam's update rule."""
 import torch
 
 from . import _lib
@@ -22,6 +22,15 @@ class Adam(torch.optim.Optimizer):
         self._step_dev = torch.tensor([steps.pop() if steps else 0], dtype=torch.int64, device=device)
         return self._step_dev
 
+    def state_dict(self):
+        """hipGraph replays advance the device-resident step count only: bring the per-tensor Python counts up to date first."""
+        if self._step_dev is not None:
+            n = int(self._step_dev.item())
+            for st in self.state.values():
+                if st:
+                    st['step'] = n
+        return super().state_dict()
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -31,8 +40,10 @@ class Adam(torch.optim.Optimizer):
         lib = _lib.load()
         if self._step_dev is not None:
             self._step_dev.add_(1)         # captured: every replay advances the device-resident count
+        import ctypes
         for group in self.param_groups:
             b1, b2 = group['betas']
+            ps, gs, ms, vs, ns, keep, step = [], [], [], [], [], [], None
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -46,10 +57,27 @@ class Adam(torch.optim.Optimizer):
                     st['exp_avg_sq'] = torch.zeros_like(p)
                 st['step'] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                with torch.cuda.device(p.device):
-                    _lib.check(lib.cb_adam_step_f32(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st['exp_avg']), _lib.ptr(st['exp_avg_sq']),
-                                                    p.numel(), group['lr'], b1, b2, group['eps'], group['weight_decay'],
-                                                    st['step'], _lib.ptr(self._step_dev), _lib.stream_ptr()), 'cb_adam_step_f32')
+                if step is None:
+                    step = st['step']
+                if st['step'] != step or p.device != group['params'][0].device:
+                    # tensors that joined later (own bias correction) or live elsewhere: one launch of their own
+                    with torch.cuda.device(p.device):
+                        _lib.check(lib.cb_adam_step_f32(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st['exp_avg']), _lib.ptr(st['exp_avg_sq']),
+                                                        p.numel(), group['lr'], b1, b2, group['eps'], group['weight_decay'],
+                                                        st['step'], _lib.ptr(self._step_dev), _lib.stream_ptr()), 'cb_adam_step_f32')
+                    continue
+                ps.append(p.data_ptr()); gs.append(g.data_ptr()); ms.append(st['exp_avg'].data_ptr())
+                vs.append(st['exp_avg_sq'].data_ptr()); ns.append(p.numel())
+                keep.append(g)                               # contiguous copies stay alive until the launch below
+            if ps:
+                n = len(ps)
+                arr = lambda vals, ty: (ty * n)(*vals)       # noqa: E731
+                with torch.cuda.device(group['params'][0].device):
+                    _lib.check(lib.cb_adam_multi_f32(n, arr(ps, ctypes.c_void_p), arr(gs, ctypes.c_void_p), arr(ms, ctypes.c_void_p),
+                                                     arr(vs, ctypes.c_void_p), arr(ns, ctypes.c_int64), group['lr'], b1, b2, group['eps'],
+                                                     group['weight_decay'], step, _lib.ptr(self._step_dev), _lib.stream_ptr()),
+                               'cb_adam_multi_f32')
+                del keep
         return loss
 
 

@@ -6,6 +6,7 @@ Same class/method names, same per-epoch record layout and return shapes; the for
 runs on the HIP path.  The student / label-propagation modes (SEMLP, StudentBaseMLP, GraphMLP,
 LP) are outside this path and raise NotImplementedError.
 """
+import contextlib
 import os
 
 import numpy as np
@@ -131,23 +132,33 @@ class trainer:
     def checkpoint_path(self):
         return join(self.modeldir, 'teacherGNN-ckpt')
 
-    def save_checkpoint(self, epoch, results):
-        """Weights + fused-Adam moments/step + RNG state + per-epoch records: enough to continue bit-for-bit."""
-        torch.save({'model': self.teacherGNN.state_dict(), 'optimizer': self.optimizer.state_dict(), 'epoch': epoch,
-                    'results': results, 'torch_rng': torch.get_rng_state(), 'numpy_rng': np.random.get_state()},
+    def save_checkpoint(self, epoch, results, best_test_acc=0.):
+        """Weights + fused-Adam moments/step + RNG states (CPU, numpy, every device generator) + per-epoch records + the best test
+        accuracy: enough to continue bit-for-bit.  Tensors and plain containers only, so that the file loads with
+        weights_only=True (no pickled code is executed when a checkpoint is read)."""
+        np_state = np.random.get_state()
+        torch.save({'model': self.teacherGNN.state_dict(), 'optimizer': self.optimizer.state_dict(), 'epoch': int(epoch),
+                    'results': [[float(v) for v in row] for row in results], 'best_test_acc': float(best_test_acc),
+                    'torch_rng': torch.get_rng_state(), 'cuda_rng': list(torch.cuda.get_rng_state_all()),
+                    'numpy_rng': {'kind': str(np_state[0]), 'keys': torch.from_numpy(np_state[1].astype(np.int64)),
+                                  'pos': int(np_state[2]), 'has_gauss': int(np_state[3]), 'cached_gaussian': float(np_state[4])}},
                    self.checkpoint_path())
 
     def load_checkpoint(self):
         path = self.checkpoint_path()
         if not os.path.exists(path):
-            return -1, []
-        ck = torch.load(path, map_location=self.device, weights_only=False)
+            return -1, [], 0.
+        ck = torch.load(path, map_location='cpu', weights_only=True)
         self.teacherGNN.load_state_dict(ck['model'])
         self.optimizer.load_state_dict(ck['optimizer'])
-        torch.set_rng_state(ck['torch_rng'].cpu())
-        np.random.set_state(ck['numpy_rng'])
+        torch.set_rng_state(ck['torch_rng'])
+        if ck.get('cuda_rng'):
+            with contextlib.suppress(Exception):
+                torch.cuda.set_rng_state_all([t for t in ck['cuda_rng']])
+        r = ck['numpy_rng']
+        np.random.set_state((r['kind'], r['keys'].numpy().astype(np.uint32), r['pos'], r['has_gauss'], r['cached_gaussian']))
         print(f'---››››  RESUME from {path} after epoch {ck["epoch"]}')
-        return ck['epoch'], ck['results']
+        return ck['epoch'], ck['results'], ck.get('best_test_acc', 0.)
 
     def train_teacherGNN(self):
         self.setup_teacherGNN()
@@ -155,7 +166,7 @@ class trainer:
         results_arr2D = []
         first_epoch = 0
         if getattr(self.args, 'resume', False):
-            last, results_arr2D = self.load_checkpoint()
+            last, results_arr2D, best_test_acc = self.load_checkpoint()
             first_epoch = last + 1
         ckpt_every = int(getattr(self.args, 'ckpt_every', 0) or 0)
         for epoch in range(first_epoch, self.epochs):
@@ -170,8 +181,8 @@ class trainer:
             if epoch % 20 == 0:
                 print(f'Ep{epoch:03d}, acc @ train/test: {acc_train * 100:.1f}, {acc_test * 100:.1f} ')
             if ckpt_every and (epoch + 1) % ckpt_every == 0:
-                self.save_checkpoint(epoch, results_arr2D)
-        self.save_checkpoint(self.epochs - 1, results_arr2D)
+                self.save_checkpoint(epoch, results_arr2D, best_test_acc)
+        self.save_checkpoint(self.epochs - 1, results_arr2D, best_test_acc)
         print('train_loss: {:.4f},  test_acc:{:.4f}'.format(best_train_loss, best_test_acc))
         save_model(self.teacherGNN, join(self.modeldir, 'teacherGNN'))
         results_arr2D = np.array(results_arr2D).T

@@ -96,9 +96,39 @@ def set_arch_configs(args):
         args.lr = float(_lr)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Graph analysis in front of the path.  Device tensors run on the hand-written HIP kernels of
+# csrc/cb_ingest.hip (histogram / order-preserving compaction / sort-unique, through the C ABI); host tensors (the small
+# fixtures of the CPU tests, host-side data preparation) use the equivalent tensor formulation below.  Both produce exactly
+# what the reference's per-edge Python loops produce (tests/golden/utils_fixture.pt).
+# ---------------------------------------------------------------------------------------------------------
+def _dev_ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _symmetrize_device(edge_index, n):
+    from . import _lib
+    lib = _lib.load()
+    src, dst = edge_index[0].to(torch.int64).contiguous(), edge_index[1].to(torch.int64).contiguous()
+    E, dev = int(src.numel()), src.device
+    out = torch.empty((2, max(2 * E, 1)), dtype=torch.int64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    wsb = lib.cb_symmetrize_workspace_bytes(E, n)
+    ws = _dev_ws(wsb, dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.cb_symmetrize_i64(_lib.ptr(src), _lib.ptr(dst), E, n, _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(cnt), _lib.ptr(bad),
+                                         _lib.ptr(ws), wsb, _lib.stream_ptr()), 'cb_symmetrize_i64')
+        if int(bad.item()):
+            raise ValueError(f'edge_index has {int(bad.item())} edges with an endpoint outside [0, {n})')
+        return out[:, :int(cnt.item())].clone()
+
+
 def ensure_symmetric(edge_index):
     """Union with the transpose, coalesced, sorted by (row, col) (utils.py:667-674)."""
     n = int(edge_index.max()) + 1
+    if edge_index.is_cuda:
+        return _symmetrize_device(edge_index, n)
     key = edge_index[0].to(torch.int64) * n + edge_index[1].to(torch.int64)
     key_t = edge_index[1].to(torch.int64) * n + edge_index[0].to(torch.int64)
     key = torch.unique(torch.cat([key, key_t]))
@@ -119,6 +149,8 @@ def to_undirected(edge_index, num_nodes=None):
     """PyG to_undirected semantics used by load_ogbn (trainer_node_classification.py:574): both
     directions, duplicates removed, sorted by (row, col)."""
     n = int(edge_index.max()) + 1 if num_nodes is None else num_nodes
+    if edge_index.is_cuda:
+        return _symmetrize_device(edge_index, n)
     key = torch.cat([edge_index[0] * n + edge_index[1], edge_index[1] * n + edge_index[0]])
     key = torch.unique(key)
     return torch.stack([key // n, key % n])
@@ -158,19 +190,98 @@ def get_partial_sorted_idx(arr, mode='top25'):
     return idx
 
 
+def _degrees_device(N_nodes, edge_index):
+    """(out-degree, in-degree) int32 [N] on the device: cb_id_count_i64 over edge_index[0] / edge_index[1]."""
+    from . import _lib
+    lib = _lib.load()
+    dev = edge_index.device
+    out = []
+    with torch.cuda.device(dev):
+        for r in (0, 1):
+            ids = edge_index[r].to(torch.int64).contiguous()
+            cnt = torch.empty(N_nodes, dtype=torch.int32, device=dev)
+            bad = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(lib.cb_id_count_i64(_lib.ptr(ids), int(ids.numel()), N_nodes, _lib.ptr(cnt), _lib.ptr(bad), _lib.stream_ptr()),
+                       'cb_id_count_i64')
+            out.append(cnt)
+    return out[0], out[1]
+
+
 def graph_analyze(N_nodes, edge_index):
-    """Out-/in-degree per node (utils.py:300-334), as two bincounts instead of a per-edge dict loop."""
+    """Out-/in-degree per node (utils.py:300-334) — two histograms instead of a per-edge dict loop."""
+    if edge_index.is_cuda:
+        d0, d1 = _degrees_device(N_nodes, edge_index)
+        return tonp(d0).astype(np.int64), tonp(d1).astype(np.int64)
     ei = edge_index.to(torch.int64)
     degs_ori = torch.bincount(ei[0], minlength=N_nodes)[:N_nodes]
     degs_dst = torch.bincount(ei[1], minlength=N_nodes)[:N_nodes]
     return tonp(degs_ori), tonp(degs_dst)
 
 
+def _median_of_range(hist, lo, hi):
+    """np.median of the multiset {v : lo <= v <= hi} described by the value histogram (mean of the two middle order statistics)."""
+    lo, hi = max(int(lo), 0), min(int(hi), len(hist) - 1)
+    if hi < lo:
+        return float('nan')
+    c = np.cumsum(hist[lo:hi + 1])
+    n = int(c[-1]) if len(c) else 0
+    if n == 0:
+        return float('nan')
+    v1 = lo + int(np.searchsorted(c, (n - 1) // 2, side='right'))
+    v2 = lo + int(np.searchsorted(c, n // 2, side='right'))
+    return 0.5 * (v1 + v2)
+
+
+def partial_sorted_select_device(vals, mode='top25'):
+    """get_partial_sorted_idx (utils.py:910-941) for a non-negative int32 device vector: (ascending index tensor, bool mask).
+    Every subset whose median the reference takes is {v <= t} ('top') or {v >= t} ('bottom'), so all medians are read off ONE
+    value histogram (cb_value_hist_i32); the final np.where is one order-preserving compaction (cb_select_range_i32)."""
+    from . import _lib
+    lib = _lib.load()
+    dev, n = vals.device, int(vals.numel())
+    vals = vals.to(torch.int32).contiguous()
+    top = 'top' in mode
+    suffix = mode[3:] if top else mode[6:]
+    with torch.cuda.device(dev):
+        vmax = int(vals.max().item()) if n else 0
+        hist_d = torch.empty(vmax + 1, dtype=torch.int32, device=dev)
+        bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(lib.cb_value_hist_i32(_lib.ptr(vals), n, vmax + 1, _lib.ptr(hist_d), _lib.ptr(bad), _lib.stream_ptr()), 'cb_value_hist_i32')
+        hist = hist_d.cpu().numpy().astype(np.int64)
+        if int(bad.item()):
+            raise ValueError('partial_sorted_select_device expects non-negative values')
+        lo, hi = 0, vmax
+        for _ in range(1 + _DEPTH.get(suffix, 0)):
+            med = _median_of_range(hist, lo, hi)
+            if med != med:                                   # empty subset: the reference's np.where(arr <= nan) selects nothing
+                lo, hi = 1, 0
+                break
+            if top:
+                hi = int(np.floor(med))                      # arr <= med
+            else:
+                lo = int(np.ceil(med))                       # arr >= med
+        idx = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+        mask = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        wsb = lib.cb_compact_workspace_bytes(n)
+        ws = _dev_ws(wsb, dev)
+        _lib.check(lib.cb_select_range_i32(_lib.ptr(vals), n, lo, hi, _lib.ptr(idx), _lib.ptr(mask), _lib.ptr(cnt), _lib.ptr(ws), wsb,
+                                           _lib.stream_ptr()), 'cb_select_range_i32')
+        return idx[:int(cnt.item())].clone(), mask[:n].bool()
+
+
 def save_graph_analyze(N_nodes, data, use_special_split, verbose=True):
     """Head/tail/isolated node sets (utils.py:680-729)."""
     data.N_nodes = N_nodes
-    degs_ori, degs_dst = graph_analyze(N_nodes, data.edge_index)
     dev = data.x.device
+    on_device = data.edge_index.is_cuda
+    if on_device and not use_special_split:
+        # large-graph branch (ogbn / synthetic power-law): everything stays on the device
+        _, deg_dst = _degrees_device(N_nodes, data.edge_index)
+        data.small_deg_idx, data.small_deg_mask = partial_sorted_select_device(deg_dst, 'top3')
+        data.large_deg_idx, data.large_deg_mask = partial_sorted_select_device(deg_dst, 'bottom3')
+        return
+    degs_ori, degs_dst = graph_analyze(N_nodes, data.edge_index)
 
     def mask_of(idx):
         m = torch.zeros(N_nodes, dtype=torch.bool, device=dev)
@@ -183,6 +294,8 @@ def save_graph_analyze(N_nodes, data, use_special_split, verbose=True):
         data.small_deg_mask = mask_of(data.small_deg_idx)
         data.large_deg_mask = mask_of(data.large_deg_idx)
     else:
+        # Planetoid-sized graphs: the tie order of the reference's np.argsort (utils.py:704) is part of the result, so the
+        # N-sized index arithmetic stays on numpy; the per-edge work (degrees above, crafting below) runs on the device
         _idx = get_partial_sorted_idx(degs_dst, 'top6')
         _idx = _idx[np.array(degs_dst)[_idx].argsort()]
         data.zero_deg_idx = _idx[:len(_idx) // 2]
@@ -201,10 +314,28 @@ def craft_isolation_v2(data, verbose=True):
     (utils.py:731-752)."""
     ei = data.edge_index
     z = data.zero_deg_mask
-    drop = (ei[0] != ei[1]) & (z[ei[0]] | z[ei[1]])
-    crafted = ei[:, ~drop]
+    if ei.is_cuda:
+        from . import _lib
+        lib = _lib.load()
+        src, dst = ei[0].to(torch.int64).contiguous(), ei[1].to(torch.int64).contiguous()
+        E, dev = int(src.numel()), ei.device
+        flag = z.to(device=dev, dtype=torch.uint8).contiguous()
+        out = torch.empty((2, max(E, 1)), dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        wsb = lib.cb_compact_workspace_bytes(E)
+        ws = _dev_ws(wsb, dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.cb_craft_isolation_i64(_lib.ptr(src), _lib.ptr(dst), E, _lib.ptr(flag), int(flag.numel()), _lib.ptr(out[0]),
+                                                  _lib.ptr(out[1]), _lib.ptr(cnt), _lib.ptr(ws), wsb, _lib.stream_ptr()),
+                       'cb_craft_isolation_i64')
+            crafted = out[:, :int(cnt.item())].clone()
+        n_drop = E - crafted.shape[1]
+    else:
+        drop = (ei[0] != ei[1]) & (z[ei[0]] | z[ei[1]])
+        crafted = ei[:, ~drop]
+        n_drop = int(drop.sum())
     if verbose:
-        print(f'removed < {int(drop.sum())} > edge; shape change: {ei.shape} ›› {crafted.shape}')
+        print(f'removed < {n_drop} > edge; shape change: {ei.shape} ›› {crafted.shape}')
     data.edge_index_bkup = ei
     data.edge_index = crafted
 

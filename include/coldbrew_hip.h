@@ -84,9 +84,14 @@ int cb_spmm_hub_fill(const int32_t* rowptr, int64_t N, int32_t hub_threshold, in
  * `ws` holds the hub partial sums: cb_spmm_workspace_bytes(n_chunks, d).  With n_hubs == 0 (no plan) every
  * row is reduced whole by one wavefront — correct for any graph, slow for power-law hubs.
  * Deterministic: every row is reduced in CSR order by one wavefront, hub rows in chunk order.
+ * col_flags = 0: `col` holds plain column ids.  col_flags = 1 (fp32 rows, d % 256 == 0, 16-byte aligned only): bit 31 of every
+ * id marks a HOT source row (one of the most-referenced rows, chosen at graph build so that together they fit the 256 MiB
+ * Infinity Cache); hot rows are gathered with the default cache policy, all others with the streaming (nt) policy, which
+ * keeps the re-used rows resident instead of letting 1e8 single-use 1 KiB rows evict them (-11 % per launch on the
+ * 10M-node power-law graph, profiles/r02_spmm_gather_policy.md).  Results do not depend on the flags.
  * ---------------------------------------------------------------------------------- */
 size_t cb_spmm_workspace_bytes(int64_t n_chunks, int64_t d);
-int cb_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E,
+int cb_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E,
                     const float* h, int64_t ld_h, int64_t d,
                     const float* row_scale, const float* bias, int relu,
                     float* out, int64_t ld_out,
@@ -137,6 +142,11 @@ int cb_nll_logsoftmax_f32(const float* logits, int64_t ld, const int64_t* y, con
  * moments, step >= 1). */
 int cb_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int64_t step, const int64_t* step_dev, void* stream);
+/* The same update for n_tensors parameter tensors in ONE launch (host arrays of device pointers; the table travels in the
+ * kernel arguments, 24 tensors per launch).  Identical arithmetic to cb_adam_step_f32. */
+int cb_adam_multi_f32(int32_t n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* numel,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, const int64_t* step_dev,
+                      void* stream);
 /* step_dev (may be NULL): the step count read from device memory instead of `step` (hipGraph replay). */
 
 /* ------------------------------------------------------------------------------------
@@ -175,7 +185,8 @@ int cb_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, con
  * (nullable) the activation itself.  d must be a multiple of 256; rows 16-byte aligned.  row0 = global index
  * of local row 0 (dropout mask of the unsharded tensor).  mix_src NULL: no mix; drop_p 0: no dropout.
  * ---------------------------------------------------------------------------------- */
-int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h, int64_t d,
+int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h,
+                          int64_t d,
                           const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix, float c_act,
                           float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits,
                           float* out_act, int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs,
@@ -270,6 +281,33 @@ int cb_spmm_csr_fused_acc_f32(const float* acc_init, int64_t ld_init, const int3
                               const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, float* out_act, int64_t ld_act,
                               float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
                               const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Device-side graph analysis in front of the path (per-edge Python dict / list loops in the reference).
+ * Integer work, bit-exact, order-preserving (outputs list elements in input order, as np.where and the reference's append
+ * loops do).  ws for the compactions: cb_compact_workspace_bytes(n elements scanned).
+ * ---------------------------------------------------------------------------------- */
+/* counts[v] = #{e : ids[e] == v}, v in [0, N)  — graph_analyze (utils.py:300-334): out-degree from edge_index[0], in-degree
+ * from edge_index[1].  *n_bad = ids outside [0, N) (not counted). */
+int cb_id_count_i64(const int64_t* ids, int64_t E, int64_t N, int32_t* counts, int32_t* n_bad, void* stream);
+/* hist[b] = #{i : vals[i] == b}, b in [0, n_bins)  — the degree-value histogram from which every repeated median of
+ * get_partial_sorted_idx (utils.py:910-941) is read. */
+int cb_value_hist_i32(const int32_t* vals, int64_t N, int32_t n_bins, int32_t* hist, int32_t* n_bad, void* stream);
+size_t cb_compact_workspace_bytes(int64_t n);
+/* out_idx[0 .. *count) = ascending indices i with lo <= vals[i] <= hi; out_mask[i] = 1 for them, 0 otherwise (either output
+ * may be NULL)  — np.where(arr <= median) / (arr >= median) of get_partial_sorted_idx and the *_deg_mask vectors of
+ * save_graph_analyze (utils.py:694-717). */
+int cb_select_range_i32(const int32_t* vals, int64_t N, int32_t lo, int32_t hi, int64_t* out_idx, uint8_t* out_mask, int64_t* count,
+                        void* ws, size_t ws_bytes, void* stream);
+/* craft_isolation_v2 (utils.py:731-752): keeps edge e, in order, unless src[e] != dst[e] and (node_flag[src[e]] or
+ * node_flag[dst[e]]).  out_src / out_dst need room for E entries; *count = edges kept. */
+int cb_craft_isolation_i64(const int64_t* src, const int64_t* dst, int64_t E, const uint8_t* node_flag, int64_t N, int64_t* out_src,
+                           int64_t* out_dst, int64_t* count, void* ws, size_t ws_bytes, void* stream);
+/* ensure_symmetric (utils.py:667-674) / to_undirected as load_ogbn uses it (trainer_node_classification.py:574): the edge set
+ * united with its transpose, duplicates removed, sorted by (row, col).  out_row / out_col need room for 2E entries. */
+size_t cb_symmetrize_workspace_bytes(int64_t E, int64_t N);
+int cb_symmetrize_i64(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int64_t* out_row, int64_t* out_col, int64_t* count,
+                      int32_t* n_bad, void* ws, size_t ws_bytes, void* stream);
 
 /* out[i, :] = src[idx[i], :] (contiguous out [n_idx, d]) — packs the rows a peer asked for before the
  * all-to-all of the node-sharded halo exchange (new; the reference is single-device). */
