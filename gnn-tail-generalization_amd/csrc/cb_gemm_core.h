@@ -2,6 +2,7 @@
 // cb_gemm.hip (NN / TN contractions) and cb_topk.hip (scores + running top-K).  See cb_gemm.hip for the design notes.
 #pragma once
 #include "cb_common.h"
+#include "cb_philox.h"
 
 namespace cb {
 
@@ -15,6 +16,15 @@ struct GemmEpilogue {
   int64_t ld_add;
   const float* bias;      // [N] or null
   int relu;
+  // DUAL kernels only: second output C2 = dropout(C) (F.dropout of the value just stored, GCN.py:110 after :105-107); the
+  // keep-mask is the one cb_dropout_f32 draws for (seed, flat index (row0 + m) * N + n) — N % 4 == 0
+  float* out2;
+  int64_t ld_out2;
+  uint32_t thresh;
+  float keep_scale;
+  uint64_t seed;
+  const uint64_t* seed_dev;
+  int64_t row0;
 };
 
 template <int WM, int WN, int BKT = BK, int WTN = 2>
@@ -147,7 +157,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][WTN]) {
 // The accumulators are transposed through LDS so that every lane handles 4 consecutive columns of one row: row scale /
 // addend / bias / relu are applied on float4 values and the tile leaves as coalesced 16-byte stores (8-byte for bf16 output).
 // `Cs` must hold 32 x (BN + 4) floats and must no longer be read as operand storage by any wavefront of the block.
-template <int WM, int WN, int WTN, bool OUT_BF16>
+template <int WM, int WN, int WTN, bool OUT_BF16, bool DUAL = false>
 __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __restrict__ Cs, void* __restrict__ Cv, int64_t ldc,
                                             int64_t m0, int n0, int64_t M, int N, const GemmEpilogue& ep, int c_vec_ok, int t) {
   constexpr int BN = 32 * WTN * WN, LDB = BN + 4;
@@ -213,6 +223,11 @@ __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __rest
           } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (n + q < N) cp[q] = o[q];
+          }
+          if constexpr (DUAL) {   // launch contract: N % 4 == 0, 16-byte aligned out2 rows
+            float mk[4];
+            keep4(ep.seed_dev ? ep.seed + *ep.seed_dev : ep.seed, ((ep.row0 + m) * N + n) >> 2, ep.thresh, ep.keep_scale, mk);
+            *reinterpret_cast<float4*>(ep.out2 + m * ep.ld_out2 + n) = make_float4(o[0] * mk[0], o[1] * mk[1], o[2] * mk[2], o[3] * mk[3]);
           }
         }
       }

@@ -54,7 +54,7 @@ struct LTile {
 };
 
 // ---- NN ------------------------------------------------------------------------------------
-template <int WM, int WN, bool OUT_BF16, int WTN = 2, int PD = 2>
+template <int WM, int WN, bool OUT_BF16, int WTN = 2, int PD = 2, bool DUAL = false>
 __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_nn_l3(const float* __restrict__ A, int64_t lda,
                                                                                  const float* __restrict__ B, int64_t ldb,
                                                                                  void* __restrict__ Cv, int64_t ldc, int64_t M, int N,
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_nn
 #pragma unroll
   for (int j = 0; j < WTN; ++j) baddr[j] = OB::frag_addr(wc * (32 * WTN) + 32 * j, lane);
   limb_k_loop<WTN, PD, OA, OB>(oa, ob, smem, A + m0 * lda, KS, lda, B + n0, (int64_t)KS * ldb, ldb, nullptr, K, aaddr, baddr, acc, t);
-  nn_epilogue<WM, WN, WTN, OUT_BF16>(acc, reinterpret_cast<float*>(smem), Cv, ldc, m0, n0, M, N, ep, c_vec_ok, t);
+  nn_epilogue<WM, WN, WTN, OUT_BF16, DUAL>(acc, reinterpret_cast<float*>(smem), Cv, ldc, m0, n0, M, N, ep, c_vec_ok, t);
 }
 
 // ---- TN ------------------------------------------------------------------------------------
@@ -155,6 +155,14 @@ static int launch_nn_l3_t(const float* A, int64_t lda, const float* B, int64_t l
   const int64_t groups = (nrb + 7) / 8;
   const int c_vec_ok = ((uintptr_t)C % (OUT_BF16 ? 8 : 16) == 0) && ldc % 4 == 0 && (!ep.addend || (al16(ep.addend) && ep.ld_add % 4 == 0));
   const dim3 grid((unsigned)(groups * 8 * ncb));
+  if constexpr (!OUT_BF16 && WM == 2 && WTN == 4) {
+    if (ep.out2) {    // dual-output epilogue (second, dropped copy): the wide-tile fp32 kernel only, see limb3_nn_dual_eligible
+      hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, false, WTN, 1, true>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb,
+                         ncb, c_vec_ok);
+      CB_LAUNCH_CHECK();
+      return CB_OK;
+    }
+  }
   if (limb_pd() == 1)
     hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, OUT_BF16, WTN, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb,
                        ncb, c_vec_ok);
@@ -171,6 +179,14 @@ static int launch_nn_l3_t(const float* A, int64_t lda, const float* B, int64_t l
 // float4 access to both operands, lane offsets in 32 bits
 bool limb3_nn_eligible(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t N, int64_t K) {
   return al16(A) && al16(B) && lda % 4 == 0 && ldb % 4 == 0 && K % 4 == 0 && N % 4 == 0 && K > 0 && lda < (1 << 22) && ldb < (1 << 22);
+}
+
+// the dual-output epilogue exists for the wide (128 x 256) fp32 tile with vector stores on both outputs
+bool limb3_nn_dual_eligible(const float* A, int64_t lda, const float* B, int64_t ldb, const float* C, int64_t ldc, const float* C2, int64_t ldc2,
+                            int64_t N, int64_t K, const GemmEpilogue& ep) {
+  static const int wide = getenv("CB_LIMB_WIDE") ? atoi(getenv("CB_LIMB_WIDE")) : 1;
+  return wide && N > 128 && limb3_nn_eligible(A, lda, B, ldb, N, K) && al16(C) && al16(C2) && ldc % 4 == 0 && ldc2 % 4 == 0 &&
+         (!ep.addend || (al16(ep.addend) && ep.ld_add % 4 == 0));
 }
 
 int launch_nn_limb3(const float* A, int64_t lda, const float* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,

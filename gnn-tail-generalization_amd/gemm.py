@@ -45,6 +45,27 @@ def mm_nn(a, b, rowscale=None, addend=None, bias=None, relu=False, out_bf16=Fals
     return out
 
 
+def mm_nn_drop2(a, b, p, seed, row0=0, bias=None, relu=False):
+    """(y, dropout_p(y)) with y = act(a @ b + bias), both written by one GEMM epilogue (cb_gemm_nn_drop2_f32); the dropped copy
+    uses the keep-mask ops._dropout_raw(y, p, seed, row0 * N) would draw."""
+    import ctypes
+    from . import ops
+    lib = _lib.load()
+    _lib.require_device(a, b, bias)
+    a, b = _rowmajor(a), _rowmajor(b)
+    M, K = a.shape
+    K2, N = b.shape
+    if K != K2 or a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise ValueError(f'mm_nn_drop2: bad operands {tuple(a.shape)} @ {tuple(b.shape)}')
+    y = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    yd = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.cb_gemm_nn_drop2_f32(_lib.ptr(a), _ld(a), _lib.ptr(b), _ld(b), _lib.ptr(y), N, _lib.ptr(yd), N, M, N, K, None, None, 0,
+                                            _lib.ptr(bias), int(bool(relu)), float(p), ctypes.c_uint64(seed), ops.seed_dev_ptr(), int(row0),
+                                            _lib.stream_ptr()), 'cb_gemm_nn_drop2_f32')
+    return y, yd
+
+
 def mm_tn(a, g, rowscale=None):
     """a^T @ (rowscale[:,None] * g): a [M,K1], g [M,K2] -> [K1,K2]; deterministic split reduction over M."""
     lib = _lib.load()

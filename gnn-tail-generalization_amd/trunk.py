@@ -112,6 +112,27 @@ def _input_bwd(g, add, act, p, seed, row0):
     return out, colsum
 
 
+def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0):
+    """cb_trunk_input_bwd_multi_f32: (dropout_bwd(g) + c_mix * sum_l dropout_bwd_l(g_mix[l])) * (act > 0) and its column sums."""
+    lib = _lib.load()
+    rows, d = g.shape
+    out = torch.empty_like(g)
+    colsum = torch.empty(d, dtype=torch.float32, device=g.device)
+    wsb = lib.cb_colsum_workspace_bytes(rows, d)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=g.device)
+    n = len(g_mix)
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in g_mix])
+    seeds = (ctypes.c_uint64 * max(n, 1))(*[int(s) for s in seeds_mix])
+    with torch.cuda.device(g.device):
+        _lib.check(lib.cb_trunk_input_bwd_multi_f32(_lib.ptr(g), ctypes.c_uint64(seed), n, ptrs, seeds, float(c_mix), _lib.ptr(act), _lib.ptr(out),
+                                                    rows, d, float(p), ops.seed_dev_ptr(), int(row0), _lib.ptr(colsum), _lib.ptr(ws), wsb,
+                                                    _lib.stream_ptr()), 'cb_trunk_input_bwd_multi_f32')
+    return out, colsum
+
+
+MIX_MAX = 7      # mixed-in gradients one cb_trunk_input_bwd_multi_f32 launch gathers (deeper trunks accumulate layer by layer)
+
+
 class _TrunkFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph, cfg, x, w_in, b_in, w_out, b_out, *layer_params):
@@ -121,9 +142,11 @@ class _TrunkFn(torch.autograd.Function):
         a = graph.norm_out
         x = x.contiguous()
         xd = ops._dropout_raw(x, p, seeds[0], row0 * x.shape[1]) if p > 0 else x
-        x0 = gemm.mm_nn(xd, w_in.t().contiguous(), bias=b_in, relu=True)
+        if p > 0:    # X0 and its dropped copy leave the same GEMM epilogue (X0 is not re-read by a dropout pass)
+            x0, cur = gemm.mm_nn_drop2(xd, w_in.t().contiguous(), p, seeds[1], row0, bias=b_in, relu=True)
+        else:
+            x0 = cur = gemm.mm_nn(xd, w_in.t().contiguous(), bias=b_in, relu=True)
         h = x0.shape[1]
-        cur = ops._dropout_raw(x0, p, seeds[1], row0 * h) if p > 0 else x0
         saved_in, saved_bits = [cur], []
         for l in range(L):
             w, b, le = layer_params[3 * l: 3 * l + 3]
@@ -165,12 +188,19 @@ class _TrunkFn(torch.autograd.Function):
         d_w_out = gemm.mm_tn(gout, xl) if need[5] else None
         d_b_out = ops.act_bwd(gout, None, None, want_out=False, want_colsum=True)[1] if need[6] else None
         g = gemm.mm_nn(gout, w_out)                                  # dL/d(dropped X_L)
-        gx0 = torch.empty_like(x0)
+        # the gradient reaching X0 through the L mixes: gathered in one pass by the input stage (the per-layer gradients stay
+        # alive until then) when L <= MIX_MAX, else accumulated in place layer by layer
+        gather = L <= MIX_MAX
+        gx0 = None if gather else torch.empty_like(x0)
+        g_mix, seeds_mix = [], []
         grads_layers = [None] * (3 * L)
         for l in range(L - 1, -1, -1):
             w, b, le = lp[l]
             gr, dbias = _layer_bwd(g, saved_bits[l], bnorm, gx0, l != L - 1, p, seeds[l + 2] if p > 0 else 0, row0, 1 - alpha, alpha,
                                    need[7 + 3 * l + 1], out_bf16=agg_bf16)
+            if gather:
+                g_mix.append(g)
+                seeds_mix.append(seeds[l + 2] if p > 0 else 0)
             del g
             gz = _spmm_t(graph, gr)                                 # dL/dZ_l = A (b * dY')
             del gr
@@ -183,8 +213,11 @@ class _TrunkFn(torch.autograd.Function):
             else:
                 del gz
         # input stage: X0 feeds layer 0 (through its dropout) and every mix
-        gpre, d_b_in = _input_bwd(g, gx0, x0, p, seeds[1] if p > 0 else 0, row0)
-        del g, gx0
+        if gather:
+            gpre, d_b_in = _input_bwd_multi(g, seeds[1] if p > 0 else 0, g_mix, seeds_mix, alpha, x0, p, row0)
+        else:
+            gpre, d_b_in = _input_bwd(g, gx0, x0, p, seeds[1] if p > 0 else 0, row0)
+        del g, gx0, g_mix
         d_w_in = gemm.mm_tn(gpre, xd) if need[3] else None
         d_x = None
         if need[2]:

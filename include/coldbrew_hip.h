@@ -167,6 +167,13 @@ int cb_adam_multi_f32(int32_t n_tensors, float* const* p, const float* const* g,
 int cb_gemm_nn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
                    int64_t K, const float* rowscale, const float* addend, int64_t ld_add, const float* bias, int relu,
                    void* stream);
+/* The same contraction with a second output C2 = dropout_p(C) written by the same epilogue (the value is in registers
+ * anyway): `X = relu(Linear_0(x)); X_dropped = F.dropout(X)` of the residual trunk (GCN.py:105-107,110) without re-reading
+ * X.  C2's keep-mask equals the one cb_dropout_f32 draws for (seed, seed_dev, offset = row0 * N).  Falls back to
+ * cb_gemm_nn_f32 + cb_dropout_f32 (contiguous outputs) when the fused epilogue does not cover the shape. */
+int cb_gemm_nn_drop2_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, float* C2, int64_t ldc2,
+                         int64_t M, int64_t N, int64_t K, const float* rowscale, const float* addend, int64_t ld_add, const float* bias,
+                         int relu, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, void* stream);
 
 /* C[K1,K2] = sum_m A[m,K1] * rowscale[m] * G[m,K2] — the weight gradients (autograd of GCN.py:225 and
  * of nn.Linear): a reduction over the node axis, split into row slabs whose partial products are summed
@@ -206,6 +213,14 @@ int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits, const floa
 int cb_trunk_input_bwd_f32(const float* g, const float* add, const float* act, float* out, int64_t rows, int64_t d, float drop_p,
                            uint64_t seed, const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes,
                            void* stream);
+
+/* The same input stage with the X0 gradient gathered in one pass (no [rows, d] accumulator is read-modify-written per layer):
+ *     out = ( dropout_bwd_seed(g) + c_mix * sum_{l < n_mix} dropout_bwd_seeds_mix[l](g_mix[l]) ) * (act > 0)
+ * g_mix[l] = gradient w.r.t. the output of layer l's fused store (host array of n_mix <= 7 device pointers); used with
+ * cb_trunk_layer_bwd_f32(gx0 = NULL).  Autograd of GCN.py:104-110 + res_tricks.py:23 for every layer at once. */
+int cb_trunk_input_bwd_multi_f32(const float* g, uint64_t seed, int32_t n_mix, const float* const* g_mix, const uint64_t* seeds_mix,
+                                 float c_mix, const float* act, float* out, int64_t rows, int64_t d, float drop_p,
+                                 const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * bf16-storage variant of the aggregation (build extension = BASELINE config 2; the reference is fp32-only):

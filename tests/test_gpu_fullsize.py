@@ -125,6 +125,19 @@ def test_trunk_backward_kernels_full_size(pl10m_graph):
     ref.mul_(pos)
     torch.testing.assert_close(colsum2, ref.sum(dim=0), atol=5e-2, rtol=1e-4)
     assert _max_abs_diff_inplace(ref, out2) <= 1e-5
+    del ref, out2, add, gx0
+    # one-pass gather of the X0 gradient (cb_trunk_input_bwd_multi_f32): (D0 g + alpha * (D1 g1 + D2 g2)) * (act > 0)
+    g1 = torch.randn(n, d, device=DEV, generator=gen)
+    g2 = torch.randn(n, d, device=DEV, generator=gen)
+    out3, colsum3 = trunk._input_bwd_multi(g, seed + 1, [g1, g2], [seed + 2, seed + 3], alpha, act, p, 0)
+    ref = torch.zeros_like(g)
+    for t, sd, c in ((g, seed + 1, 1.0), (g1, seed + 2, alpha), (g2, seed + 3, alpha)):
+        keep = ops.dropout_keep_mask((n, d), p, sd, DEV)
+        ref.add_(t * keep, alpha=c / (1 - p))
+        del keep
+    ref.mul_(pos)
+    torch.testing.assert_close(colsum3, ref.sum(dim=0), atol=5e-2, rtol=1e-4)
+    assert _max_abs_diff_inplace(ref, out3) <= 1e-5
 
 
 def _teacher(argv, dataset, n_override=None, dropout=0.0, seed=0):
