@@ -42,9 +42,10 @@ SIGNATURES = {
                                         ctypes.c_float, ctypes.c_float, _I64, _P, _P]),
     'cb_adam_multi_f32': (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                          ctypes.c_float, _I64, _P, _P]),
-    'cb_gemm_nn_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int, _P]),
+    'cb_gemm_nn_workspace_bytes': (_SZ, [_I64, _I64]),
+    'cb_gemm_nn_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int, _P, _SZ, _P]),
     'cb_gemm_nn_drop2_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int,
-                                            ctypes.c_float, ctypes.c_uint64, _P, _I64, _P]),
+                                            ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _SZ, _P]),
     'cb_gemm_tn_workspace_bytes': (_SZ, [_I64, _I64, _I64]),
     'cb_gemm_tn_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _SZ, _P]),
     'cb_spmm_csr_fused_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,
@@ -52,7 +53,7 @@ SIGNATURES = {
                                              _P, _SZ, _P]),
     'cb_trunk_layer_bwd_f32': (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, _P, ctypes.c_int, _I64, _I64, ctypes.c_float, ctypes.c_uint64,
                                               _P, _I64, ctypes.c_float, ctypes.c_float, _P, _P, _SZ, _P]),
-    'cb_gemm_nn_bf16out_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int, _P]),
+    'cb_gemm_nn_bf16out_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int, _P, _SZ, _P]),
     'cb_spmm_csr_bf16_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_int, _P, _I64,
                                             _I32, _I32, _I32, _P, _P, _P, _SZ, _P]),
     'cb_spmm_csr_fused_bf16_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,

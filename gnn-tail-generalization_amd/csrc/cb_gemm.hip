@@ -225,9 +225,14 @@ static int launch_tn(const float* A, int64_t lda, const float* G, int64_t ldg, c
 
 using namespace cb;
 
+extern "C" size_t cb_gemm_nn_workspace_bytes(int64_t N, int64_t K) {
+  if (N <= 0 || K <= 0) return 0;
+  return limb3_nn_workspace_bytes(N, K);
+}
+
 extern "C" int cb_gemm_nn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
                               int64_t K, const float* rowscale, const float* addend, int64_t ld_add, const float* bias, int relu,
-                              void* stream) {
+                              void* ws, size_t ws_bytes, void* stream) {
   CB_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, CB_E_INVALID, "cb_gemm_nn_f32: negative size");
   CB_CHECK_ARG(N < (1 << 24) && K < (1 << 24) && (M + 63) / 64 < (1 << 24), CB_E_RANGE, "cb_gemm_nn_f32: size out of range");
   if (M == 0 || N == 0) return CB_OK;
@@ -235,7 +240,7 @@ extern "C" int cb_gemm_nn_f32(const float* A, int64_t lda, const float* B, int64
                "cb_gemm_nn_f32: null pointer or leading dimension too small");
   GemmEpilogue ep{rowscale, addend, ld_add, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0};
   hipStream_t st = (hipStream_t)stream;
-  if (use_limb3() && limb3_nn_eligible(A, lda, B, ldb, N, K)) return launch_nn_limb3(A, lda, B, ldb, C, ldc, M, N, K, ep, false, st);
+  if (use_limb3() && limb3_nn_eligible(A, lda, B, ldb, N, K)) return launch_nn_limb3(A, lda, B, ldb, C, ldc, M, N, K, ep, false, st, ws, ws_bytes);
   if (N <= 64) return launch_nn<4, 1>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
   static const int wide = getenv("CB_GEMM_WIDE") != nullptr;   // measurement hook: 128x256 block tile (wave tile 64x128)
   if (wide && N > 128) return launch_nn<2, 2, false, 4>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
@@ -249,7 +254,7 @@ extern "C" int cb_gemm_nn_f32(const float* A, int64_t lda, const float* B, int64
 extern "C" int cb_gemm_nn_drop2_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, float* C2, int64_t ldc2,
                                     int64_t M, int64_t N, int64_t K, const float* rowscale, const float* addend, int64_t ld_add,
                                     const float* bias, int relu, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0,
-                                    void* stream) {
+                                    void* ws, size_t ws_bytes, void* stream) {
   CB_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && drop_p >= 0.f && drop_p < 1.f && row0 >= 0, CB_E_INVALID, "cb_gemm_nn_drop2_f32: bad size or p");
   CB_CHECK_ARG(N < (1 << 24) && K < (1 << 24) && (M + 63) / 64 < (1 << 24), CB_E_RANGE, "cb_gemm_nn_drop2_f32: size out of range");
   if (M == 0 || N == 0) return CB_OK;
@@ -260,9 +265,9 @@ extern "C" int cb_gemm_nn_drop2_f32(const float* A, int64_t lda, const float* B,
   if (use_limb3() && drop_p > 0.f && limb3_nn_dual_eligible(A, lda, B, ldb, C, ldc, C2, ldc2, N, K, ep)) {
     ep.out2 = C2; ep.ld_out2 = ldc2; ep.thresh = dropout_threshold(drop_p); ep.keep_scale = 1.f / (1.f - drop_p);
     ep.seed = seed; ep.seed_dev = seed_dev; ep.row0 = row0;
-    return launch_nn_limb3(A, lda, B, ldb, C, ldc, M, N, K, ep, false, st);
+    return launch_nn_limb3(A, lda, B, ldb, C, ldc, M, N, K, ep, false, st, ws, ws_bytes);
   }
-  int rc = cb_gemm_nn_f32(A, lda, B, ldb, C, ldc, M, N, K, rowscale, addend, ld_add, bias, relu, stream);
+  int rc = cb_gemm_nn_f32(A, lda, B, ldb, C, ldc, M, N, K, rowscale, addend, ld_add, bias, relu, ws, ws_bytes, stream);
   if (rc != CB_OK) return rc;
   CB_CHECK_ARG(ldc == N && ldc2 == N, CB_E_INVALID, "cb_gemm_nn_drop2_f32: the two-kernel form needs contiguous outputs");
   return cb_dropout_f32(C, C2, M * N, drop_p, seed, seed_dev, row0 * N, stream);
@@ -270,7 +275,7 @@ extern "C" int cb_gemm_nn_drop2_f32(const float* A, int64_t lda, const float* B,
 
 extern "C" int cb_gemm_nn_bf16out_f32(const float* A, int64_t lda, const float* B, int64_t ldb, uint16_t* C, int64_t ldc, int64_t M,
                                       int64_t N, int64_t K, const float* rowscale, const float* addend, int64_t ld_add,
-                                      const float* bias, int relu, void* stream) {
+                                      const float* bias, int relu, void* ws, size_t ws_bytes, void* stream) {
   CB_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, CB_E_INVALID, "cb_gemm_nn_bf16out_f32: negative size");
   CB_CHECK_ARG(N < (1 << 24) && K < (1 << 24) && (M + 63) / 64 < (1 << 24), CB_E_RANGE, "cb_gemm_nn_bf16out_f32: size out of range");
   if (M == 0 || N == 0) return CB_OK;
@@ -278,7 +283,7 @@ extern "C" int cb_gemm_nn_bf16out_f32(const float* A, int64_t lda, const float* 
                "cb_gemm_nn_bf16out_f32: null pointer or leading dimension too small");
   GemmEpilogue ep{rowscale, addend, ld_add, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0};
   hipStream_t st = (hipStream_t)stream;
-  if (use_limb3() && limb3_nn_eligible(A, lda, B, ldb, N, K)) return launch_nn_limb3(A, lda, B, ldb, C, ldc, M, N, K, ep, true, st);
+  if (use_limb3() && limb3_nn_eligible(A, lda, B, ldb, N, K)) return launch_nn_limb3(A, lda, B, ldb, C, ldc, M, N, K, ep, true, st, ws, ws_bytes);
   if (N <= 64) return launch_nn<4, 1, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
   return launch_nn<2, 2, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
 }

@@ -36,6 +36,7 @@
 // Addressing inside the K loop: a wave-uniform base pointer (scalar registers) per K step plus lane offsets that never change.
 #include <stdlib.h>
 
+#include <type_traits>
 #include <utility>
 
 #include "cb_common.h"
@@ -54,7 +55,7 @@ struct LTile {
 };
 
 // ---- NN ------------------------------------------------------------------------------------
-template <int WM, int WN, bool OUT_BF16, int WTN = 2, int PD = 2, bool DUAL = false>
+template <int WM, int WN, bool OUT_BF16, int WTN = 2, int PD = 2, bool DUAL = false, bool BPRE = false>
 __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_nn_l3(const float* __restrict__ A, int64_t lda,
                                                                                  const float* __restrict__ B, int64_t ldb,
                                                                                  void* __restrict__ Cv, int64_t ldc, int64_t M, int N,
@@ -62,7 +63,7 @@ __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_nn
                                                                                  int n_col_blocks, int c_vec_ok) {
   using T = LTile<WM, WN, WTN>;
   using OA = RowOperand<T::BM>;
-  using OB = ColOperand<T::BN, false>;
+  using OB = std::conditional_t<BPRE, ColOperandPre<T::BN>, ColOperand<T::BN, false>>;   // BPRE: B = image of k_presplit_cols
   constexpr int BM = T::BM, BN = T::BN;
   constexpr int SMEM = 2 * (OA::BYTES + OB::BYTES);
   static_assert(32 * (BN + 4) * 4 <= SMEM, "epilogue staging must fit");
@@ -85,7 +86,13 @@ __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_nn
   uint32_t baddr[WTN];
 #pragma unroll
   for (int j = 0; j < WTN; ++j) baddr[j] = OB::frag_addr(wc * (32 * WTN) + 32 * j, lane);
-  limb_k_loop<WTN, PD, OA, OB>(oa, ob, smem, A + m0 * lda, KS, lda, B + n0, (int64_t)KS * ldb, ldb, nullptr, K, aaddr, baddr, acc, t);
+  if constexpr (BPRE) {
+    const int64_t nks = (K + KS - 1) / KS;
+    limb_k_loop<WTN, PD, OA, OB>(oa, ob, smem, A + m0 * lda, KS, lda, B + (int64_t)col_blk * nks * OB::STEP_FLOATS, OB::STEP_FLOATS, ldb, nullptr,
+                                 K, aaddr, baddr, acc, t);
+  } else {
+    limb_k_loop<WTN, PD, OA, OB>(oa, ob, smem, A + m0 * lda, KS, lda, B + n0, (int64_t)KS * ldb, ldb, nullptr, K, aaddr, baddr, acc, t);
+  }
   nn_epilogue<WM, WN, WTN, OUT_BF16, DUAL>(acc, reinterpret_cast<float*>(smem), Cv, ldc, m0, n0, M, N, ep, c_vec_ok, t);
 }
 
@@ -147,14 +154,48 @@ static inline int limb_pd() {
   return pd;
 }
 
+// Weight operand split once per launch + LDS-DMA staging (ColOperandPre): measured NEUTRAL (8.23 vs 8.08 ms on 10M x 256 x 256,
+// profiles/r02_gemm_presplit.md) although it removes 36 % of the kernel's VALU instructions — the K loop is bound by the six MFMA
+// passes at the power-limited clock, not by instruction issue — so it stays off unless CB_LIMB_PRESPLIT=1 (and a workspace) is given.
+static inline bool presplit_on() {
+  static const bool on = getenv("CB_LIMB_PRESPLIT") != nullptr && atoi(getenv("CB_LIMB_PRESPLIT")) != 0;
+  return on;
+}
+
+// bytes of the pre-split image of a [K, N] column operand for block width BN
+static inline size_t presplit_bytes(int64_t K, int64_t N, int BN) {
+  return (size_t)((N + BN - 1) / BN) * (size_t)((K + KS - 1) / KS) * (size_t)(3 * 16 * BN * 2);
+}
+
 template <int WM, int WN, bool OUT_BF16, int WTN = 2>
 static int launch_nn_l3_t(const float* A, int64_t lda, const float* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
-                          int64_t K, GemmEpilogue ep, hipStream_t st) {
+                          int64_t K, GemmEpilogue ep, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
   using T = LTile<WM, WN, WTN>;
   const int nrb = (int)((M + T::BM - 1) / T::BM), ncb = (int)((N + T::BN - 1) / T::BN);
   const int64_t groups = (nrb + 7) / 8;
   const int c_vec_ok = ((uintptr_t)C % (OUT_BF16 ? 8 : 16) == 0) && ldc % 4 == 0 && (!ep.addend || (al16(ep.addend) && ep.ld_add % 4 == 0));
   const dim3 grid((unsigned)(groups * 8 * ncb));
+  if constexpr (T::BN >= 128) {
+    // weight operand split once per launch instead of once per block per K step (rows >> the 128-row tile make that worthwhile)
+    if (presplit_on() && ws && ws_bytes >= presplit_bytes(K, N, T::BN) && M >= 8 * T::BM && limb_pd() == 1) {
+      const int nks = (int)((K + KS - 1) / KS);
+      hipLaunchKernelGGL((k_presplit_cols<T::BN>), dim3((unsigned)nks, (unsigned)ncb), dim3(256), 0, st, B, ldb, (int)K, (int)N, nks, (char*)ws);
+      CB_LAUNCH_CHECK();
+      const float* img = reinterpret_cast<const float*>(ws);
+      if constexpr (!OUT_BF16 && WM == 2 && WTN == 4) {
+        if (ep.out2) {
+          hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, false, WTN, 1, true, true>), grid, dim3(256), 0, st, A, lda, img, ldb, C, ldc, M, (int)N, (int)K,
+                             ep, nrb, ncb, c_vec_ok);
+          CB_LAUNCH_CHECK();
+          return CB_OK;
+        }
+      }
+      hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, OUT_BF16, WTN, 1, false, true>), grid, dim3(256), 0, st, A, lda, img, ldb, C, ldc, M, (int)N, (int)K,
+                         ep, nrb, ncb, c_vec_ok);
+      CB_LAUNCH_CHECK();
+      return CB_OK;
+    }
+  }
   if constexpr (!OUT_BF16 && WM == 2 && WTN == 4) {
     if (ep.out2) {    // dual-output epilogue (second, dropped copy): the wide-tile fp32 kernel only, see limb3_nn_dual_eligible
       hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, false, WTN, 1, true>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb,
@@ -189,18 +230,24 @@ bool limb3_nn_dual_eligible(const float* A, int64_t lda, const float* B, int64_t
          (!ep.addend || (al16(ep.addend) && ep.ld_add % 4 == 0));
 }
 
+size_t limb3_nn_workspace_bytes(int64_t N, int64_t K) {
+  if (N <= 64) return 0;
+  const size_t a = presplit_bytes(K, N, 128), b = presplit_bytes(K, N, 256);
+  return (a > b ? a : b) + 256;
+}
+
 int launch_nn_limb3(const float* A, int64_t lda, const float* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                    const GemmEpilogue& ep, bool out_bf16, hipStream_t st) {
+                    const GemmEpilogue& ep, bool out_bf16, hipStream_t st, void* ws, size_t ws_bytes) {
   if (N <= 64) {
     return out_bf16 ? launch_nn_l3_t<4, 1, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, st)
                     : launch_nn_l3_t<4, 1, false>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
   }
   static const int wide = getenv("CB_LIMB_WIDE") ? atoi(getenv("CB_LIMB_WIDE")) : 1;   // 128 x 256 block tile (wave tile 64 x 128); 0: 128 x 128
   if (wide && N > 128)
-    return out_bf16 ? launch_nn_l3_t<2, 2, true, 4>(A, lda, B, ldb, C, ldc, M, N, K, ep, st)
-                    : launch_nn_l3_t<2, 2, false, 4>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
-  return out_bf16 ? launch_nn_l3_t<2, 2, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, st)
-                  : launch_nn_l3_t<2, 2, false>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
+    return out_bf16 ? launch_nn_l3_t<2, 2, true, 4>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes)
+                    : launch_nn_l3_t<2, 2, false, 4>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes);
+  return out_bf16 ? launch_nn_l3_t<2, 2, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes)
+                  : launch_nn_l3_t<2, 2, false>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes);
 }
 
 template <int WM, int WN, int WTN = 2>

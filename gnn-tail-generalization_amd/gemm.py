@@ -22,6 +22,16 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
 
 
+def _b_workspace(lib, N, K, M, device):
+    """Room for the right operand split once per launch (cb_gemm_nn_workspace_bytes).  Measured neutral (profiles/r02_gemm_presplit.md),
+    so only handed over when CB_LIMB_PRESPLIT=1 asks for it."""
+    import os
+    if os.environ.get('CB_LIMB_PRESPLIT', '0') in ('', '0') or M < 1024 or K * N > (1 << 22):
+        return None, 0
+    wsb = lib.cb_gemm_nn_workspace_bytes(N, K)
+    return (torch.empty(wsb, dtype=torch.uint8, device=device), wsb) if wsb else (None, 0)
+
+
 def mm_nn(a, b, rowscale=None, addend=None, bias=None, relu=False, out_bf16=False):
     """act(rowscale[:,None] * (a @ b) + addend + bias) in one kernel; a [M,K], b [K,N] float32 on device.
     out_bf16: store the result as bfloat16 (round-to-nearest-even) — the bf16 aggregation variant."""
@@ -38,10 +48,11 @@ def mm_nn(a, b, rowscale=None, addend=None, bias=None, relu=False, out_bf16=Fals
         addend = _rowmajor(addend)
     out = torch.empty((M, N), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=a.device)
     fn = lib.cb_gemm_nn_bf16out_f32 if out_bf16 else lib.cb_gemm_nn_f32
+    ws, wsb = _b_workspace(lib, N, K, M, a.device)
     with torch.cuda.device(a.device):
         _lib.check(fn(_lib.ptr(a), _ld(a), _lib.ptr(b), _ld(b), _lib.ptr(out), N, M, N, K, _lib.ptr(rowscale),
                       _lib.ptr(addend), _ld(addend) if addend is not None else 0, _lib.ptr(bias),
-                      int(bool(relu)), _lib.stream_ptr()), 'cb_gemm_nn')
+                      int(bool(relu)), _lib.ptr(ws), wsb, _lib.stream_ptr()), 'cb_gemm_nn')
     return out
 
 
@@ -59,10 +70,11 @@ def mm_nn_drop2(a, b, p, seed, row0=0, bias=None, relu=False):
         raise ValueError(f'mm_nn_drop2: bad operands {tuple(a.shape)} @ {tuple(b.shape)}')
     y = torch.empty((M, N), dtype=torch.float32, device=a.device)
     yd = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    ws, wsb = _b_workspace(lib, N, K, M, a.device)
     with torch.cuda.device(a.device):
         _lib.check(lib.cb_gemm_nn_drop2_f32(_lib.ptr(a), _ld(a), _lib.ptr(b), _ld(b), _lib.ptr(y), N, _lib.ptr(yd), N, M, N, K, None, None, 0,
                                             _lib.ptr(bias), int(bool(relu)), float(p), ctypes.c_uint64(seed), ops.seed_dev_ptr(), int(row0),
-                                            _lib.stream_ptr()), 'cb_gemm_nn_drop2_f32')
+                                            _lib.ptr(ws), wsb, _lib.stream_ptr()), 'cb_gemm_nn_drop2_f32')
     return y, yd
 
 

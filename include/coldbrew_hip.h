@@ -163,17 +163,21 @@ int cb_adam_multi_f32(int32_t n_tensors, float* const* p, const float* const* g,
 /* C[M,N] = act( rowscale[m] * (A[M,K] @ B[K,N]) + addend[m,n] + bias[n] ) — `feat_src = feat * norm`,
  * `th.matmul(feat_src, weight)`, `+ self.le` (GCN.py:213,225,231) in one kernel (the row scale commutes
  * with the product); with bias/relu it is also nn.Linear + F.relu (GCN.py:105-106,138) and, fed with
- * gradients, the dX GEMMs of their backward.  rowscale/addend/bias may be NULL. */
+ * gradients, the dX GEMMs of their backward.  rowscale/addend/bias may be NULL.
+ * ws (optional, cb_gemm_nn_workspace_bytes(N, K) = 6 * K * N bytes + padding): room for B split ONCE per launch into its three
+ * bf16 planes, pre-arranged as the kernel's LDS image — B is the small weight matrix, so this replaces the per-block,
+ * per-K-step split of the same values by a straight 16-byte copy.  ws == NULL: every block splits its own copy. */
+size_t cb_gemm_nn_workspace_bytes(int64_t N, int64_t K);
 int cb_gemm_nn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
                    int64_t K, const float* rowscale, const float* addend, int64_t ld_add, const float* bias, int relu,
-                   void* stream);
+                   void* ws, size_t ws_bytes, void* stream);
 /* The same contraction with a second output C2 = dropout_p(C) written by the same epilogue (the value is in registers
  * anyway): `X = relu(Linear_0(x)); X_dropped = F.dropout(X)` of the residual trunk (GCN.py:105-107,110) without re-reading
  * X.  C2's keep-mask equals the one cb_dropout_f32 draws for (seed, seed_dev, offset = row0 * N).  Falls back to
  * cb_gemm_nn_f32 + cb_dropout_f32 (contiguous outputs) when the fused epilogue does not cover the shape. */
 int cb_gemm_nn_drop2_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, float* C2, int64_t ldc2,
                          int64_t M, int64_t N, int64_t K, const float* rowscale, const float* addend, int64_t ld_add, const float* bias,
-                         int relu, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, void* stream);
+                         int relu, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, void* ws, size_t ws_bytes, void* stream);
 
 /* C[K1,K2] = sum_m A[m,K1] * rowscale[m] * G[m,K2] — the weight gradients (autograd of GCN.py:225 and
  * of nn.Linear): a reduction over the node axis, split into row slabs whose partial products are summed
@@ -231,7 +235,7 @@ int cb_trunk_input_bwd_multi_f32(const float* g, uint64_t seed, int32_t n_mix, c
  * ---------------------------------------------------------------------------------- */
 int cb_gemm_nn_bf16out_f32(const float* A, int64_t lda, const float* B, int64_t ldb, uint16_t* C, int64_t ldc, int64_t M, int64_t N,
                            int64_t K, const float* rowscale, const float* addend, int64_t ld_add, const float* bias, int relu,
-                           void* stream);
+                           void* ws, size_t ws_bytes, void* stream);
 int cb_spmm_csr_bf16_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const uint16_t* h, int64_t ld_h, int64_t d,
                          const float* row_scale, const float* bias, int relu, float* out, int64_t ld_out, int32_t hub_threshold,
                          int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,

@@ -296,3 +296,35 @@ def test_gemm_full_size_properties():
     assert torch.equal(z1, z2)
     d1, d2 = gemm.mm_tn(a, z1), gemm.mm_tn(a, z1)
     assert torch.equal(d1, d2)
+
+
+def test_gemm_presplit_lds_dma_variant_matches_fp64():
+    """CB_LIMB_PRESPLIT=1: the weight operand split once per launch (k_presplit_cols) and staged by LDS-DMA
+    (global_load_lds_dwordx4) — off by default (measured neutral), kept correct: same fp32-level error as the default path,
+    ragged K / N / M, with and without the epilogue terms, incl. the dual-output (dropout copy) epilogue."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from gnn_tail_generalization_amd import gemm, ops
+torch.manual_seed(0)
+dev = 'cuda:0'
+for M, K, N in [(4096, 256, 256), (5000, 128, 256), (3001, 40, 256), (2500, 100, 132), (70000, 256, 260)]:
+    a = torch.randn(M, K, device=dev); b = torch.randn(K, N, device=dev)
+    rs = torch.rand(M, device=dev) + 0.5; add = torch.randn(M, N, device=dev); bias = torch.randn(N, device=dev)
+    got = gemm.mm_nn(a, b, rowscale=rs, addend=add, bias=bias, relu=True).double().cpu()
+    ref = torch.relu((a.double().cpu() @ b.double().cpu()) * rs.double().cpu().unsqueeze(1) + add.double().cpu() + bias.double().cpu())
+    scale = float((a.double().abs().cpu() @ b.double().abs().cpu()).max()) + 10
+    err = float((got - ref).abs().max())
+    assert err <= 3e-6 * scale, (M, K, N, err, scale)
+y, yd = gemm.mm_nn_drop2(torch.randn(9000, 128, device=dev), torch.randn(128, 256, device=dev), 0.3, 4242, row0=17, bias=None, relu=True)
+keep = ops.dropout_keep_mask((9000, 256), 0.3, 4242, dev, offset=17 * 256)
+torch.testing.assert_close(yd, torch.where(keep, y / 0.7, torch.zeros_like(y)), atol=1e-6, rtol=1e-6)
+print('PRESPLIT_OK')
+''' % root
+    env = dict(os.environ, CB_LIMB_PRESPLIT='1')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert 'PRESPLIT_OK' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
