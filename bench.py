@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--cpu-baseline-mode', default='auto', choices=['auto', 'full', 'sample'],
                     help='full = one measured full-size oracle step on the host cores; sample = sub-sampled + scaled (fallback)')
     ap.add_argument('--cpu-budget-s', type=float, default=20.0, help='keep timing full-size CPU steps until this many seconds (max 3 steps)')
+    ap.add_argument('--pmc-traffic', type=int, default=1, help='collect roofline.traffic with two rocprofv3 --pmc passes of the aggregation (N=1 only)')
     ap.add_argument('--ref-epochs', type=int, default=2, help='epochs of the reference epoch (2 train fwd + 1 bwd + 1 eval fwd) to time; 0 = skip')
     ap.add_argument('--hip-graph', type=int, default=0, help='replay the step as one hipGraph (pays off on launch-bound small graphs)')
     ap.add_argument('--agg-dtype', default='f32', choices=['f32', 'bf16'], help='bf16 = build-extension storage of the gathered rows')
@@ -185,6 +186,55 @@ def cpu_baseline(a, args, trainer, sd0, graph_obj, full_nodes):
     if mode == 'full':
         return cpu_baseline_full(a, args, trainer, sd0, graph_obj, a.cpu_budget_s)
     return cpu_baseline_sample(a, args, full_nodes)
+
+
+def pmc_traffic(dataset):
+    """HBM-side bytes of one aggregation launch from the PMC counters, collected by THIS run: two separate `rocprofv3 --pmc` passes
+    (FETCH_SIZE, WRITE_SIZE; kernel trace only) over tools/bench_spmm.py on the same graph, corrected as MI355X_MICROARCH.md's
+    HBM section prescribes (KB units; FETCH_SIZE doubled on gfx950 for 16 B/lane reads).  Returns (bytes, note) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which('rocprofv3') is None:
+        return None, 'rocprofv3 not on PATH'
+    if 'rocprof' in os.environ.get('LD_PRELOAD', '') or os.environ.get('ROCP_TOOL_LIBRARIES'):
+        return None, 'this process is itself being profiled: nested counter collection skipped'
+    tool = os.path.join(ROOT, 'tools', 'bench_spmm.py')
+    n_arg = [] if dataset == 'S-pl10M' else None
+    if n_arg is None:
+        return None, 'PMC pass only wired for the S-pl10M workload'
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix='cb_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    try:
+        for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = os.path.join(tmp, ctr)
+            subprocess.run(['rocprofv3', '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d', out, '--', sys.executable, tool,
+                            '--iters', '3'], cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            files = glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True)
+            if not files:
+                return None, f'no counter file for {ctr}'
+            acc, disp = {}, {}
+            for r in csv.DictReader(open(files[0])):
+                name = r['Kernel_Name']
+                key = next((k for k in ('k_spmm_rows', 'k_spmm_hub_chunks', 'k_spmm_hub_finish') if k in name), None)
+                if key is None or r['Counter_Name'] != ctr:
+                    continue
+                acc[key] = acc.get(key, 0.0) + float(r['Counter_Value'])
+                disp.setdefault(key, set()).add(r['Dispatch_Id'])
+            if 'k_spmm_rows' not in acc:
+                return None, f'{ctr}: aggregation kernel not found in the counter file'
+            vals[ctr] = sum(acc[k] / len(disp[k]) for k in acc)          # KB per aggregation launch (one dispatch of each kernel)
+        return (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0, (
+            'measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over tools/bench_spmm.py '
+            '--iters 3 on the same graph; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over k_spmm_rows + hub kernels, per launch; '
+            'L2 memory-side requests (Infinity-Cache hits included)')
+    except Exception as e:  # noqa: BLE001
+        return None, f'PMC pass failed: {type(e).__name__}: {e}'[:300]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def reference_epoch_rate(t, args, epochs, sync):
@@ -347,6 +397,12 @@ def main():
         out.update(ref_epoch)
     if a.cpu_baseline and world == 1 and not sharded:
         out['cpu_baseline'] = cpu_baseline(a, args, t, sd0, graph_obj, n_nodes)
+    if a.pmc_traffic and world == 1 and not sharded:
+        del t, graph_obj                     # the PMC passes build their own copy of the graph in a child process
+        torch.cuda.empty_cache()
+        traffic, note = pmc_traffic(a.dataset)
+        out['roofline']['traffic'] = traffic
+        out['roofline']['traffic_note'] = note
     os.write(json_fd, (json.dumps(out) + '\n').encode())
 
 
