@@ -313,19 +313,30 @@ class ShardedGraph:
         work = _all_to_all_single(recv[:plan.n_halo], send, plan.recv_counts, plan.send_counts, group=self.group, async_op=True)
         return recv, work, send
 
-    def aggregate(self, h_local, transpose=False, row_scale=None, bias=None, relu=False):
-        """act(row_scale * (A_block . h) + bias) for this rank's rows; h_local = this rank's rows of h."""
+    def aggregate_start(self, h_local, transpose=False):
+        """First half of aggregate(): starts the exchange (overlapped form) and returns a handle for aggregate_finish().  Work
+        issued between the two calls (e.g. the previous layer's weight-gradient GEMM in the trunk backward) runs under the exchange."""
+        if not self.overlap or h_local.dtype != torch.float32:
+            return (h_local, None, None, None)
+        recv, work, send = self.start_halo(h_local, transpose)
+        return (h_local, recv, work, send)
+
+    def aggregate_finish(self, handle, transpose=False, row_scale=None, bias=None, relu=False):
+        h_local, recv, work, send = handle
         o = self.b if transpose else self.f
         c = self.compute
-        if not self.overlap or h_local.dtype != torch.float32:
+        if work is None:
             return c.spmm(o.whole if o.whole is not None else self._whole(o), self.exchange(h_local, transpose), row_scale, bias, relu,
                           profile=self.profile)
-        recv, work, send = self.start_halo(h_local, transpose)
         part = c.spmm(o.interior, h_local, profile=self.profile)             # raw sums over the local columns, overlaps the exchange
         work.wait()
         out = c.spmm(o.halo, recv, row_scale, bias, relu, acc_init=part, profile=self.profile)
         del send
         return out
+
+    def aggregate(self, h_local, transpose=False, row_scale=None, bias=None, relu=False):
+        """act(row_scale * (A_block . h) + bias) for this rank's rows; h_local = this rank's rows of h."""
+        return self.aggregate_finish(self.aggregate_start(h_local, transpose), transpose, row_scale, bias, relu)
 
     def _whole(self, o):
         raise RuntimeError('single-pass aggregation requested on a graph built for the overlapped two-pass form '

@@ -194,6 +194,8 @@ class _TrunkFn(torch.autograd.Function):
         gx0 = None if gather else torch.empty_like(x0)
         g_mix, seeds_mix = [], []
         grads_layers = [None] * (3 * L)
+        sharded = hasattr(graph, 'part')
+        deferred = None        # (layer, X_l, dZ_l): weight gradient of the layer above, computed under this layer's halo exchange
         for l in range(L - 1, -1, -1):
             w, b, le = lp[l]
             gr, dbias = _layer_bwd(g, saved_bits[l], bnorm, gx0, l != L - 1, p, seeds[l + 2] if p > 0 else 0, row0, 1 - alpha, alpha,
@@ -202,16 +204,26 @@ class _TrunkFn(torch.autograd.Function):
                 g_mix.append(g)
                 seeds_mix.append(seeds[l + 2] if p > 0 else 0)
             del g
-            gz = _spmm_t(graph, gr)                                 # dL/dZ_l = A (b * dY')
+            handle = graph.aggregate_start(gr, True) if sharded else None       # node-sharded: the exchange is in flight from here
+            if deferred is not None:
+                grads_layers[3 * deferred[0]] = gemm.mm_tn(deferred[1], deferred[2], rowscale=a)
+                deferred = None
+            gz = graph.aggregate_finish(handle, True) if sharded else _spmm_t(graph, gr)     # dL/dZ_l = A (b * dY')
             del gr
             if need[7 + 3 * l]:
-                grads_layers[3 * l] = gemm.mm_tn(saved_in[l], gz, rowscale=a)
+                if sharded:
+                    deferred = (l, saved_in[l], gz)
+                else:
+                    grads_layers[3 * l] = gemm.mm_tn(saved_in[l], gz, rowscale=a)
             grads_layers[3 * l + 1] = dbias
             g = gemm.mm_nn(gz, w.t().contiguous(), rowscale=a)       # dL/d(dropped X_l)
             if le is not None and need[7 + 3 * l + 2]:
                 grads_layers[3 * l + 2] = gz
             else:
                 del gz
+        if deferred is not None:
+            grads_layers[3 * deferred[0]] = gemm.mm_tn(deferred[1], deferred[2], rowscale=a)
+            deferred = None
         # input stage: X0 feeds layer 0 (through its dropout) and every mix
         if gather:
             gpre, d_b_in = _input_bwd_multi(g, seeds[1] if p > 0 else 0, g_mix, seeds_mix, alpha, x0, p, row0)
