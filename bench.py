@@ -237,6 +237,13 @@ def pmc_traffic(dataset):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def graph_desc(dataset):
+    from gnn_tail_generalization_amd.data import ALIASES, SYNTHETIC
+    _, _, _, _, loops, gamma = SYNTHETIC[ALIASES.get(dataset, dataset)]
+    return (f'Chung-Lu power law gamma={gamma}, symmetric' + (' + self-loops' if loops else ', no self-loops, every degree >= 1')
+            + ', ids permuted, seed 0')
+
+
 def reference_epoch_rate(t, args, epochs, sync):
     """Epochs/s of the reference's own epoch (train_net: run_trainSet with the metrics-only second train-mode forward of
     want_headtail=1, trainer_node_classification.py:397-413, + run_testSet's eval forward, :453-495) = 2 train forwards +
@@ -379,8 +386,8 @@ def main():
         'data': 'synthetic',
         'aggregated_edges_per_sec': n_edges * 2 * L * a.steps / dt,
         'final_loss': float(loss),
-        'config': {'workload': f'{a.dataset}: N={n_nodes} nodes, E={n_edges} edge_index columns (Chung-Lu power law gamma=2.3, '
-                               f'symmetric + self-loops, ids permuted, seed 0), F={args.num_feats} H={args.dim_hidden} '
+        'config': {'workload': f'{a.dataset}: N={n_nodes} nodes, E={n_edges} edge_index columns ({graph_desc(a.dataset)}), '
+                               f'F={args.num_feats} H={args.dim_hidden} '
                                f'C={args.num_classes} L={L}, type_trick={args.type_trick} (residual mode), whetherHasSE=000, '
                                f'dropout={args.dropout}, Adam lr={args.lr}; step = fwd+loss+bwd+Adam, 2L={2 * L} aggregations',
                    'launch': 'one hipGraph replay per step' if use_graph else 'eager launches',

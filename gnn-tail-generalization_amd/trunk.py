@@ -24,7 +24,9 @@ def eligible(tc, x, want_les):
     return (tc.has_residual_MLP and 'Initial' in t and 'Residual' not in t and 'Jumping' not in t and not want_les
             and tc.args.type_trick not in ('BatchNorm', 'PairNorm', 'NodeNorm', 'MeanNorm', 'GroupNorm', 'CombNorm')
             and tc.dim_hidden % 256 == 0 and x.is_cuda and x.dtype == torch.float32 and len(tc.layers_GCN) == tc.num_layers
-            and len(tc.layers_MLP) == 2)
+            and len(tc.layers_MLP) == 2
+            # one dropout rate everywhere (else the modular path, which takes the rates one by one)
+            and tc.embedding_dropout == tc.dropout and tc.args.dropout == tc.dropout)
 
 
 def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False):
@@ -243,8 +245,6 @@ def forward(tc, x, graph):
     """TricksComb.forward on the fused trunk; returns (logits, se_reg_all)."""
     L = tc.num_layers
     p = float(tc.dropout) if tc.training else 0.0
-    if tc.embedding_dropout != tc.dropout or tc.args.dropout != tc.dropout:
-        raise RuntimeError('fused trunk expects one dropout rate (args.dropout)')
     seeds = tuple(ops.next_seed() for _ in range(L + 2)) if p > 0 else (0,) * (L + 2)
     params, se_reg_all = [], None
     for conv in tc.layers_GCN:
@@ -256,7 +256,8 @@ def forward(tc, x, graph):
                 from .dist import allreduce_sum
                 reg = allreduce_sum(reg * reg, graph.group).sqrt()
             se_reg_all = reg if se_reg_all is None else se_reg_all + reg
-    graph.check_zero_in_degree()
+    if not all(c._allow_zero_in_degree for c in tc.layers_GCN):      # GCN.py:187-197; set_allow_zero_in_degree(True) lifts it
+        graph.check_zero_in_degree()
     agg_bf16 = getattr(tc.args, 'agg_dtype', 'f32') == 'bf16'
     out = _TrunkFn.apply(graph, (L, float(tc.alpha), p, seeds, agg_bf16), x, tc.layers_MLP[0].weight, tc.layers_MLP[0].bias,
                          tc.layers_MLP[1].weight, tc.layers_MLP[1].bias, *params)
