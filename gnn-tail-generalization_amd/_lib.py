@@ -46,6 +46,9 @@ SIGNATURES = {
     'cb_gemm_nn_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int, _P, _SZ, _P]),
     'cb_gemm_nn_drop2_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int,
                                             ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _SZ, _P]),
+    'cb_gemm_nn_trunkbwd_workspace_bytes': (_SZ, [_I64, _I64]),
+    'cb_gemm_nn_trunkbwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, ctypes.c_float, ctypes.c_float,
+                                               ctypes.c_uint64, _P, _I64, _P, _P, _P, _SZ, _P]),
     'cb_gemm_tn_workspace_bytes': (_SZ, [_I64, _I64, _I64]),
     'cb_gemm_tn_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _SZ, _P]),
     'cb_spmm_csr_fused_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,

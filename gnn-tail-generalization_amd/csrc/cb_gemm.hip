@@ -238,7 +238,7 @@ extern "C" int cb_gemm_nn_f32(const float* A, int64_t lda, const float* B, int64
   if (M == 0 || N == 0) return CB_OK;
   CB_CHECK_ARG(C && (K == 0 || (A && B)) && lda >= K && ldb >= N && ldc >= N && (!addend || ld_add >= N), CB_E_INVALID,
                "cb_gemm_nn_f32: null pointer or leading dimension too small");
-  GemmEpilogue ep{rowscale, addend, ld_add, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0};
+  GemmEpilogue ep{rowscale, addend, ld_add, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, nullptr, 0.f, nullptr, nullptr};
   hipStream_t st = (hipStream_t)stream;
   if (use_limb3() && limb3_nn_eligible(A, lda, B, ldb, N, K)) return launch_nn_limb3(A, lda, B, ldb, C, ldc, M, N, K, ep, false, st, ws, ws_bytes);
   if (N <= 64) return launch_nn<4, 1>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
@@ -260,7 +260,7 @@ extern "C" int cb_gemm_nn_drop2_f32(const float* A, int64_t lda, const float* B,
   if (M == 0 || N == 0) return CB_OK;
   CB_CHECK_ARG(C && C2 && (K == 0 || (A && B)) && lda >= K && ldb >= N && ldc >= N && ldc2 >= N && (!addend || ld_add >= N), CB_E_INVALID,
                "cb_gemm_nn_drop2_f32: null pointer or leading dimension too small");
-  GemmEpilogue ep{rowscale, addend, ld_add, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0};
+  GemmEpilogue ep{rowscale, addend, ld_add, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, nullptr, 0.f, nullptr, nullptr};
   hipStream_t st = (hipStream_t)stream;
   if (use_limb3() && drop_p > 0.f && limb3_nn_dual_eligible(A, lda, B, ldb, C, ldc, C2, ldc2, N, K, ep)) {
     ep.out2 = C2; ep.ld_out2 = ldc2; ep.thresh = dropout_threshold(drop_p); ep.keep_scale = 1.f / (1.f - drop_p);
@@ -273,6 +273,64 @@ extern "C" int cb_gemm_nn_drop2_f32(const float* A, int64_t lda, const float* B,
   return cb_dropout_f32(C, C2, M * N, drop_p, seed, seed_dev, row0 * N, stream);
 }
 
+// one block per column: strided partial sums per thread, fixed-order LDS tree (the result does not depend on scheduling)
+__global__ void __launch_bounds__(256) k_col_finish(const float* __restrict__ partial, int64_t nparts, int d, float* __restrict__ out) {
+  __shared__ float s_t[256];
+  const int c = blockIdx.x;
+  float s = 0.f;
+  for (int64_t p = threadIdx.x; p < nparts; p += 256) s += partial[p * d + c];
+  s_t[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s_t[threadIdx.x] += s_t[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = s_t[0];
+}
+
+extern "C" size_t cb_gemm_nn_trunkbwd_workspace_bytes(int64_t M, int64_t N) {
+  if (M <= 0 || N <= 0) return 0;
+  const size_t a = (size_t)((M + 127) / 128) * (size_t)N * sizeof(float);      // one partial row of column sums per 128-row block
+  const size_t b = cb_colsum_workspace_bytes(M, N);                            // two-kernel fallback
+  return (a > b ? a : b) + 256;
+}
+
+// G = rowscale * (A @ B)   (dL/dx_l = a * (dL/dZ_l @ W_l^T), the dX GEMM of a GCNConv, or dL/dX_L = dL/dlogits @ W_out) AND, from the
+// same epilogue, the backward of the fused aggregation store of the layer below (cb_trunk_layer_bwd_f32 with gx0 = NULL):
+//   GR = c_act * dropout_bwd(G) * relu_bits * row_scale2,   colsum = column sums of the same without row_scale2.
+// G is not re-read by a pass of its own.  Shapes the fused epilogue does not cover run the two kernels one after the other.
+extern "C" int cb_gemm_nn_trunkbwd_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* G, int64_t ldg, float* GR, int64_t ldgr,
+                                       int64_t M, int64_t N, int64_t K, const float* rowscale, const uint64_t* relu_bits, float c_act,
+                                       float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, const float* row_scale2,
+                                       float* colsum, void* ws, size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(M >= 0 && N > 0 && K >= 0 && N % 256 == 0 && drop_p >= 0.f && drop_p < 1.f && row0 >= 0, CB_E_INVALID,
+               "cb_gemm_nn_trunkbwd_f32: bad size (N must be a multiple of 256) or p");
+  CB_CHECK_ARG(N < (1 << 20) && K < (1 << 24) && (M + 63) / 64 < (1 << 24), CB_E_RANGE, "cb_gemm_nn_trunkbwd_f32: size out of range");
+  if (M == 0) return CB_OK;
+  CB_CHECK_ARG(G && GR && relu_bits && (K == 0 || (A && B)) && lda >= K && ldb >= N && ldg >= N && ldgr >= N, CB_E_INVALID,
+               "cb_gemm_nn_trunkbwd_f32: null pointer or leading dimension too small");
+  CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_gemm_nn_trunkbwd_workspace_bytes(M, N)), CB_E_WORKSPACE, "cb_gemm_nn_trunkbwd_f32: workspace too small");
+  GemmEpilogue ep{rowscale, nullptr, 0, nullptr, 0, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, nullptr, 0.f, nullptr, nullptr};
+  hipStream_t st = (hipStream_t)stream;
+  if (use_limb3() && limb3_nn_dual_eligible(A, lda, B, ldb, G, ldg, GR, ldgr, N, K, ep)) {
+    ep.out2 = GR; ep.ld_out2 = ldgr; ep.thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u; ep.keep_scale = 1.f / (1.f - drop_p);
+    ep.seed = seed; ep.seed_dev = seed_dev; ep.row0 = row0;
+    ep.bits = (const unsigned long long*)relu_bits; ep.c_act = c_act; ep.rowscale2 = row_scale2; ep.colsum_partial = colsum ? (float*)ws : nullptr;
+    const int rc = launch_nn_limb3(A, lda, B, ldb, G, ldg, M, N, K, ep, false, st);
+    if (rc != CB_OK) return rc;
+    if (colsum) {
+      hipLaunchKernelGGL(k_col_finish, dim3((unsigned)N), dim3(256), 0, st, (const float*)ws, (M + 127) / 128, (int)N, colsum);
+      CB_LAUNCH_CHECK();
+    }
+    return CB_OK;
+  }
+  int rc = cb_gemm_nn_f32(A, lda, B, ldb, G, ldg, M, N, K, rowscale, nullptr, 0, nullptr, 0, nullptr, 0, stream);
+  if (rc != CB_OK) return rc;
+  CB_CHECK_ARG(ldg == N && ldgr == N, CB_E_INVALID, "cb_gemm_nn_trunkbwd_f32: the two-kernel form needs contiguous outputs");
+  return cb_trunk_layer_bwd_f32(G, relu_bits, row_scale2, GR, 0, nullptr, 0, M, N, drop_p, seed, seed_dev, row0, c_act, 0.f, colsum, ws, ws_bytes,
+                                stream);
+}
+
 extern "C" int cb_gemm_nn_bf16out_f32(const float* A, int64_t lda, const float* B, int64_t ldb, uint16_t* C, int64_t ldc, int64_t M,
                                       int64_t N, int64_t K, const float* rowscale, const float* addend, int64_t ld_add,
                                       const float* bias, int relu, void* ws, size_t ws_bytes, void* stream) {
@@ -281,7 +339,7 @@ extern "C" int cb_gemm_nn_bf16out_f32(const float* A, int64_t lda, const float* 
   if (M == 0 || N == 0) return CB_OK;
   CB_CHECK_ARG(C && (K == 0 || (A && B)) && lda >= K && ldb >= N && ldc >= N && (!addend || ld_add >= N), CB_E_INVALID,
                "cb_gemm_nn_bf16out_f32: null pointer or leading dimension too small");
-  GemmEpilogue ep{rowscale, addend, ld_add, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0};
+  GemmEpilogue ep{rowscale, addend, ld_add, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, nullptr, 0.f, nullptr, nullptr};
   hipStream_t st = (hipStream_t)stream;
   if (use_limb3() && limb3_nn_eligible(A, lda, B, ldb, N, K)) return launch_nn_limb3(A, lda, B, ldb, C, ldc, M, N, K, ep, true, st, ws, ws_bytes);
   if (N <= 64) return launch_nn<4, 1, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);

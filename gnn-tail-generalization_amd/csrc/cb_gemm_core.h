@@ -16,7 +16,7 @@ struct GemmEpilogue {
   int64_t ld_add;
   const float* bias;      // [N] or null
   int relu;
-  // DUAL kernels only: second output C2 = dropout(C) (F.dropout of the value just stored, GCN.py:110 after :105-107); the
+  // EPI == 1 kernels only: second output C2 = dropout(C) (F.dropout of the value just stored, GCN.py:110 after :105-107); the
   // keep-mask is the one cb_dropout_f32 draws for (seed, flat index (row0 + m) * N + n) — N % 4 == 0
   float* out2;
   int64_t ld_out2;
@@ -25,6 +25,13 @@ struct GemmEpilogue {
   uint64_t seed;
   const uint64_t* seed_dev;
   int64_t row0;
+  // EPI == 2 kernels only (backward of the residual trunk): the value just computed is dL/dx_l; the backward of the fused
+  // aggregation store of layer l-1 (dropout, mix, ReLU: what k_trunk_bwd<0> does in a pass of its own) is applied on the way out:
+  //   out2 = c_act * keep(seed, m, n) * o * relu_bit_{l-1}(m, n) * rowscale2[m],   colsum_partial[row block][n] += (the same without rowscale2)
+  const unsigned long long* bits;   // [M][N / 256][4] mask words of the forward store (N % 256 == 0)
+  float c_act;
+  const float* rowscale2;           // [M]
+  float* colsum_partial;            // [row blocks][N] or null
 };
 
 template <int WM, int WN, int BKT = BK, int WTN = 2>
@@ -157,7 +164,8 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][WTN]) {
 // The accumulators are transposed through LDS so that every lane handles 4 consecutive columns of one row: row scale /
 // addend / bias / relu are applied on float4 values and the tile leaves as coalesced 16-byte stores (8-byte for bf16 output).
 // `Cs` must hold 32 x (BN + 4) floats and must no longer be read as operand storage by any wavefront of the block.
-template <int WM, int WN, int WTN, bool OUT_BF16, bool DUAL = false>
+// EPI: 0 = plain; 1 = second output out2 = dropout(C); 2 = second output = trunk layer backward of C (see GemmEpilogue)
+template <int WM, int WN, int WTN, bool OUT_BF16, int EPI = 0>
 __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __restrict__ Cs, void* __restrict__ Cv, int64_t ldc,
                                             int64_t m0, int n0, int64_t M, int N, const GemmEpilogue& ep, int c_vec_ok, int t) {
   constexpr int BN = 32 * WTN * WN, LDB = BN + 4;
@@ -166,6 +174,8 @@ __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __rest
   const int l31 = lane & 31, lh = lane >> 5;
   constexpr int TPR = BN / 4;             // threads per staged row
   constexpr int NV = 32 * TPR / 256;      // float4 per thread per pass
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};     // EPI == 2: column sums of this thread's 4 columns (the same 4 in every pass: 256 % TPR == 0)
+  static_assert(EPI != 2 || 256 % TPR == 0, "fixed column quad per thread");
 #pragma unroll
   for (int pass = 0; pass < 2 * WM; ++pass) {
     const int wr_sel = pass >> 1, ti = pass & 1;
@@ -224,15 +234,54 @@ __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __rest
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (n + q < N) cp[q] = o[q];
           }
-          if constexpr (DUAL) {   // launch contract: N % 4 == 0, 16-byte aligned out2 rows
+          if constexpr (EPI == 1) {   // launch contract: N % 4 == 0, 16-byte aligned out2 rows
             float mk[4];
             keep4(ep.seed_dev ? ep.seed + *ep.seed_dev : ep.seed, ((ep.row0 + m) * N + n) >> 2, ep.thresh, ep.keep_scale, mk);
             *reinterpret_cast<float4*>(ep.out2 + m * ep.ld_out2 + n) = make_float4(o[0] * mk[0], o[1] * mk[1], o[2] * mk[2], o[3] * mk[3]);
+          }
+          if constexpr (EPI == 2) {   // launch contract: N % 256 == 0, 16-byte aligned out2 rows
+            float gm[4] = {o[0], o[1], o[2], o[3]};
+            if (ep.thresh) {
+              float mk[4];
+              keep4(ep.seed_dev ? ep.seed + *ep.seed_dev : ep.seed, ((ep.row0 + m) * N + n) >> 2, ep.thresh, ep.keep_scale, mk);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) gm[q] *= mk[q];
+            }
+            const unsigned long long* bw = ep.bits + (m * (N >> 8) + (n >> 8)) * 4;   // word q, bit L <-> column 256 * tile + 4 L + q
+            const int L = (n & 255) >> 2;
+            const float sc2 = ep.rowscale2 ? ep.rowscale2[m] : 1.f;
+            float gy[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              gy[q] = ((bw[q] >> L) & 1ull) ? ep.c_act * gm[q] : 0.f;
+              cs[q] += gy[q];
+            }
+            *reinterpret_cast<float4*>(ep.out2 + m * ep.ld_out2 + n) = make_float4(gy[0] * sc2, gy[1] * sc2, gy[2] * sc2, gy[3] * sc2);
           }
         }
       }
     }
     __syncthreads();
+  }
+  if constexpr (EPI == 2) {
+    // column sums of the block's rows: the 256 / TPR threads that own the same column quad are added in a fixed order, then one
+    // partial row per row block (summed over the row blocks by a finish kernel: no float atomics, bit-reproducible)
+    if (ep.colsum_partial) {
+      constexpr int RPP = 256 / TPR;
+      const int cq = t % TPR, rr = t / TPR;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Cs[(rr * TPR + cq) * 4 + q] = cs[q];
+      __syncthreads();
+      if (rr == 0 && n0 + cq * 4 < N) {
+        float tot[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < RPP; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) tot[q] += Cs[(j * TPR + cq) * 4 + q];
+        float* pp = ep.colsum_partial + (m0 / (64 * WM)) * (int64_t)N + n0 + cq * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pp[q] = tot[q];
+      }
+    }
   }
 }
 

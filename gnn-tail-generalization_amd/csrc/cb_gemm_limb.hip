@@ -55,7 +55,7 @@ struct LTile {
 };
 
 // ---- NN ------------------------------------------------------------------------------------
-template <int WM, int WN, bool OUT_BF16, int WTN = 2, int PD = 2, bool DUAL = false, bool BPRE = false>
+template <int WM, int WN, bool OUT_BF16, int WTN = 2, int PD = 2, int EPI = 0, bool BPRE = false>
 __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_nn_l3(const float* __restrict__ A, int64_t lda,
                                                                                  const float* __restrict__ B, int64_t ldb,
                                                                                  void* __restrict__ Cv, int64_t ldc, int64_t M, int N,
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_nn
   } else {
     limb_k_loop<WTN, PD, OA, OB>(oa, ob, smem, A + m0 * lda, KS, lda, B + n0, (int64_t)KS * ldb, ldb, nullptr, K, aaddr, baddr, acc, t);
   }
-  nn_epilogue<WM, WN, WTN, OUT_BF16, DUAL>(acc, reinterpret_cast<float*>(smem), Cv, ldc, m0, n0, M, N, ep, c_vec_ok, t);
+  nn_epilogue<WM, WN, WTN, OUT_BF16, EPI>(acc, reinterpret_cast<float*>(smem), Cv, ldc, m0, n0, M, N, ep, c_vec_ok, t);
 }
 
 // ---- TN ------------------------------------------------------------------------------------
@@ -177,29 +177,33 @@ static int launch_nn_l3_t(const float* A, int64_t lda, const float* B, int64_t l
   const dim3 grid((unsigned)(groups * 8 * ncb));
   if constexpr (T::BN >= 128) {
     // weight operand split once per launch instead of once per block per K step (rows >> the 128-row tile make that worthwhile)
-    if (presplit_on() && ws && ws_bytes >= presplit_bytes(K, N, T::BN) && M >= 8 * T::BM && limb_pd() == 1) {
+    if (presplit_on() && !ep.bits && ws && ws_bytes >= presplit_bytes(K, N, T::BN) && M >= 8 * T::BM && limb_pd() == 1) {
       const int nks = (int)((K + KS - 1) / KS);
       hipLaunchKernelGGL((k_presplit_cols<T::BN>), dim3((unsigned)nks, (unsigned)ncb), dim3(256), 0, st, B, ldb, (int)K, (int)N, nks, (char*)ws);
       CB_LAUNCH_CHECK();
       const float* img = reinterpret_cast<const float*>(ws);
       if constexpr (!OUT_BF16 && WM == 2 && WTN == 4) {
         if (ep.out2) {
-          hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, false, WTN, 1, true, true>), grid, dim3(256), 0, st, A, lda, img, ldb, C, ldc, M, (int)N, (int)K,
+          hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, false, WTN, 1, 1, true>), grid, dim3(256), 0, st, A, lda, img, ldb, C, ldc, M, (int)N, (int)K,
                              ep, nrb, ncb, c_vec_ok);
           CB_LAUNCH_CHECK();
           return CB_OK;
         }
       }
-      hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, OUT_BF16, WTN, 1, false, true>), grid, dim3(256), 0, st, A, lda, img, ldb, C, ldc, M, (int)N, (int)K,
+      hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, OUT_BF16, WTN, 1, 0, true>), grid, dim3(256), 0, st, A, lda, img, ldb, C, ldc, M, (int)N, (int)K,
                          ep, nrb, ncb, c_vec_ok);
       CB_LAUNCH_CHECK();
       return CB_OK;
     }
   }
   if constexpr (!OUT_BF16 && WM == 2 && WTN == 4) {
-    if (ep.out2) {    // dual-output epilogue (second, dropped copy): the wide-tile fp32 kernel only, see limb3_nn_dual_eligible
-      hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, false, WTN, 1, true>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb,
-                         ncb, c_vec_ok);
+    if (ep.out2) {    // dual-output epilogues (dropped copy / trunk layer backward): the wide-tile fp32 kernel only, see limb3_nn_dual_eligible
+      if (ep.bits)
+        hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, false, WTN, 1, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb,
+                           ncb, c_vec_ok);
+      else
+        hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, false, WTN, 1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb,
+                           ncb, c_vec_ok);
       CB_LAUNCH_CHECK();
       return CB_OK;
     }

@@ -78,6 +78,31 @@ def mm_nn_drop2(a, b, p, seed, row0=0, bias=None, relu=False):
     return y, yd
 
 
+def mm_nn_trunkbwd(a, b, rowscale, bits, c_act, p, seed, row0, row_scale2, want_colsum):
+    """(G, GR, colsum): G = rowscale * (a @ b) and, from the same epilogue, GR = c_act * dropout_bwd(G) * relu_bits * row_scale2 with
+    the column sums of the unscaled GR (cb_gemm_nn_trunkbwd_f32) — the dX GEMM + the layer-below's trunk backward in one kernel."""
+    import ctypes
+    from . import ops
+    lib = _lib.load()
+    _lib.require_device(a, b, rowscale, bits, row_scale2)
+    a, b = _rowmajor(a), _rowmajor(b)
+    M, K = a.shape
+    K2, N = b.shape
+    if K != K2 or a.dtype != torch.float32 or b.dtype != torch.float32 or N % 256:
+        raise ValueError(f'mm_nn_trunkbwd: bad operands {tuple(a.shape)} @ {tuple(b.shape)}')
+    g = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    gr = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    colsum = torch.empty(N, dtype=torch.float32, device=a.device) if want_colsum else None
+    wsb = lib.cb_gemm_nn_trunkbwd_workspace_bytes(M, N) if want_colsum else 0
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.cb_gemm_nn_trunkbwd_f32(_lib.ptr(a), _ld(a), _lib.ptr(b), _ld(b), _lib.ptr(g), N, _lib.ptr(gr), N, M, N, K,
+                                               _lib.ptr(rowscale), _lib.ptr(bits), float(c_act), float(p), ctypes.c_uint64(seed),
+                                               ops.seed_dev_ptr(), int(row0), _lib.ptr(row_scale2), _lib.ptr(colsum), _lib.ptr(ws), wsb,
+                                               _lib.stream_ptr()), 'cb_gemm_nn_trunkbwd_f32')
+    return g, gr, colsum
+
+
 def mm_tn(a, g, rowscale=None):
     """a^T @ (rowscale[:,None] * g): a [M,K1], g [M,K2] -> [K1,K2]; deterministic split reduction over M."""
     lib = _lib.load()

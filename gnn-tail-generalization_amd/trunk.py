@@ -132,6 +132,8 @@ def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0):
     return out, colsum
 
 
+import os
+FUSE_BWD_EPILOGUE = os.environ.get('CB_TRUNK_FUSE_BWD', '1') != '0'     # measurement switch: 0 runs cb_trunk_layer_bwd_f32 as a pass of its own
 MIX_MAX = 7      # mixed-in gradients one cb_trunk_input_bwd_multi_f32 launch gathers (deeper trunks accumulate layer by layer)
 
 
@@ -189,19 +191,31 @@ class _TrunkFn(torch.autograd.Function):
         xl = saved_in[L]
         d_w_out = gemm.mm_tn(gout, xl) if need[5] else None
         d_b_out = ops.act_bwd(gout, None, None, want_out=False, want_colsum=True)[1] if need[6] else None
-        g = gemm.mm_nn(gout, w_out)                                  # dL/d(dropped X_L)
         # the gradient reaching X0 through the L mixes: gathered in one pass by the input stage (the per-layer gradients stay
         # alive until then) when L <= MIX_MAX, else accumulated in place layer by layer
         gather = L <= MIX_MAX
+        # gather mode, fp32 rows: the layer-below's trunk backward (dropout, mix, ReLU, row scale, bias column sums) leaves the
+        # epilogue of the GEMM that produces dL/dx (cb_gemm_nn_trunkbwd_f32) instead of re-reading it in a pass of its own
+        fuse = gather and not agg_bf16 and FUSE_BWD_EPILOGUE
         gx0 = None if gather else torch.empty_like(x0)
         g_mix, seeds_mix = [], []
         grads_layers = [None] * (3 * L)
         sharded = hasattr(graph, 'part')
+
+        def dx_gemm(src, wt, rowscale, below):
+            """dL/dx of the stage above layer `below` (+ that layer's trunk backward when fused): (g, gr, dbias)."""
+            sd = seeds[below + 2] if p > 0 else 0
+            if fuse:
+                return gemm.mm_nn_trunkbwd(src, wt, rowscale, saved_bits[below], 1 - alpha, p, sd, row0, bnorm, need[7 + 3 * below + 1])
+            g_ = gemm.mm_nn(src, wt, rowscale=rowscale)
+            gr_, db_ = _layer_bwd(g_, saved_bits[below], bnorm, gx0, below != L - 1, p, sd, row0, 1 - alpha, alpha,
+                                  need[7 + 3 * below + 1], out_bf16=agg_bf16)
+            return g_, gr_, db_
+
+        g, gr, dbias = dx_gemm(gout, w_out, None, L - 1)               # dL/d(dropped X_L) and the backward of layer L-1's store
         deferred = None        # (layer, X_l, dZ_l): weight gradient of the layer above, computed under this layer's halo exchange
         for l in range(L - 1, -1, -1):
             w, b, le = lp[l]
-            gr, dbias = _layer_bwd(g, saved_bits[l], bnorm, gx0, l != L - 1, p, seeds[l + 2] if p > 0 else 0, row0, 1 - alpha, alpha,
-                                   need[7 + 3 * l + 1], out_bf16=agg_bf16)
             if gather:
                 g_mix.append(g)
                 seeds_mix.append(seeds[l + 2] if p > 0 else 0)
@@ -218,7 +232,10 @@ class _TrunkFn(torch.autograd.Function):
                 else:
                     grads_layers[3 * l] = gemm.mm_tn(saved_in[l], gz, rowscale=a)
             grads_layers[3 * l + 1] = dbias
-            g = gemm.mm_nn(gz, w.t().contiguous(), rowscale=a)       # dL/d(dropped X_l)
+            if l > 0:
+                g, gr, dbias = dx_gemm(gz, w.t().contiguous(), a, l - 1)      # dL/d(dropped X_l) and the backward of layer l-1's store
+            else:
+                g = gemm.mm_nn(gz, w.t().contiguous(), rowscale=a)            # dL/d(dropped X_0): consumed by the input stage
             if le is not None and need[7 + 3 * l + 2]:
                 grads_layers[3 * l + 2] = gz
             else:

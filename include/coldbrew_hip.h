@@ -178,6 +178,19 @@ int cb_gemm_nn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, flo
 int cb_gemm_nn_drop2_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, float* C2, int64_t ldc2,
                          int64_t M, int64_t N, int64_t K, const float* rowscale, const float* addend, int64_t ld_add, const float* bias,
                          int relu, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, void* ws, size_t ws_bytes, void* stream);
+/* The dX GEMM of a GCNConv (or of the output Linear) with the backward of the fused aggregation store of the layer below
+ * applied by the same epilogue (what cb_trunk_layer_bwd_f32 with gx0 = NULL does in a pass of its own):
+ *     G  = rowscale * (A @ B)                                   dL/dx_l   (kept: the input stage gathers it later)
+ *     GR = c_act * dropout_bwd_seed(G) * relu_bits * row_scale2  input of the reverse aggregation of layer l-1
+ *     colsum[n] = sum_m (the same without row_scale2)            bias gradient of layer l-1 (may be NULL)
+ * Autograd of th.matmul GCN.py:225 / nn.Linear :138 followed by autograd of F.dropout :110,133, InitialConnection
+ * res_tricks.py:23 and F.relu :128.  N % 256 == 0.  ws: cb_gemm_nn_trunkbwd_workspace_bytes(M, N) (column-sum partials).
+ * Falls back to cb_gemm_nn_f32 + cb_trunk_layer_bwd_f32 when the fused epilogue does not cover the shape. */
+size_t cb_gemm_nn_trunkbwd_workspace_bytes(int64_t M, int64_t N);
+int cb_gemm_nn_trunkbwd_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* G, int64_t ldg, float* GR, int64_t ldgr,
+                            int64_t M, int64_t N, int64_t K, const float* rowscale, const uint64_t* relu_bits, float c_act, float drop_p,
+                            uint64_t seed, const uint64_t* seed_dev, int64_t row0, const float* row_scale2, float* colsum, void* ws,
+                            size_t ws_bytes, void* stream);
 
 /* C[K1,K2] = sum_m A[m,K1] * rowscale[m] * G[m,K2] — the weight gradients (autograd of GCN.py:225 and
  * of nn.Linear): a reduction over the node axis, split into row slabs whose partial products are summed
