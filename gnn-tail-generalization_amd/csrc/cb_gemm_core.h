@@ -32,6 +32,7 @@ struct GemmEpilogue {
   float c_act;
   const float* rowscale2;           // [M]
   float* colsum_partial;            // [row blocks][N] or null
+  int nt_store;                     // fp32 C leaves with the streaming (nt) policy
 };
 
 template <int WM, int WN, int BKT = BK, int WTN = 2>
@@ -164,6 +165,16 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][WTN]) {
 // The accumulators are transposed through LDS so that every lane handles 4 consecutive columns of one row: row scale /
 // addend / bias / relu are applied on float4 values and the tile leaves as coalesced 16-byte stores (8-byte for bf16 output).
 // `Cs` must hold 32 x (BN + 4) floats and must no longer be read as operand storage by any wavefront of the block.
+__device__ __forceinline__ void store4(float* __restrict__ p, float a, float b, float c, float d, int nt) {
+  if (nt) {
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    const f4_t v4 = {a, b, c, d};
+    __builtin_nontemporal_store(v4, reinterpret_cast<f4_t*>(p));
+  } else {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+  }
+}
+
 // EPI: 0 = plain; 1 = second output out2 = dropout(C); 2 = second output = trunk layer backward of C (see GemmEpilogue)
 template <int WM, int WN, int WTN, bool OUT_BF16, int EPI = 0>
 __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __restrict__ Cs, void* __restrict__ Cv, int64_t ldc,
@@ -174,6 +185,14 @@ __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __rest
   const int l31 = lane & 31, lh = lane >> 5;
   constexpr int TPR = BN / 4;             // threads per staged row
   constexpr int NV = 32 * TPR / 256;      // float4 per thread per pass
+  // a thread owns the same 4 columns in every pass whenever 256 % TPR == 0 (all tiles here): its bias values are loaded once
+  constexpr bool FIXED_COLS = 256 % TPR == 0;
+  float bfix[4] = {0.f, 0.f, 0.f, 0.f};
+  if (FIXED_COLS && ep.bias) {
+    const int n = n0 + (t % TPR) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (n + q < N) bfix[q] = ep.bias[n + q];
+  }
   float cs[4] = {0.f, 0.f, 0.f, 0.f};     // EPI == 2: column sums of this thread's 4 columns (the same 4 in every pass: 256 % TPR == 0)
   static_assert(EPI != 2 || 256 % TPR == 0, "fixed column quad per thread");
 #pragma unroll
@@ -209,7 +228,10 @@ __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __rest
             for (int q = 0; q < 4; ++q) if (n + q < N) ad[q] = ap[q];
           }
         }
-        if (ep.bias) {
+        if (FIXED_COLS) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bv[q] = bfix[q];
+        } else if (ep.bias) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) if (n + q < N) bv[q] = ep.bias[n + q];
         }
@@ -229,7 +251,7 @@ __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __rest
         } else {
           float* cp = C + m * ldc + n;
           if (full4 && c_vec_ok) {
-            *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
+            store4(cp, o[0], o[1], o[2], o[3], ep.nt_store);
           } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (n + q < N) cp[q] = o[q];
@@ -237,7 +259,7 @@ __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __rest
           if constexpr (EPI == 1) {   // launch contract: N % 4 == 0, 16-byte aligned out2 rows
             float mk[4];
             keep4(ep.seed_dev ? ep.seed + *ep.seed_dev : ep.seed, ((ep.row0 + m) * N + n) >> 2, ep.thresh, ep.keep_scale, mk);
-            *reinterpret_cast<float4*>(ep.out2 + m * ep.ld_out2 + n) = make_float4(o[0] * mk[0], o[1] * mk[1], o[2] * mk[2], o[3] * mk[3]);
+            store4(ep.out2 + m * ep.ld_out2 + n, o[0] * mk[0], o[1] * mk[1], o[2] * mk[2], o[3] * mk[3], ep.nt_store);
           }
           if constexpr (EPI == 2) {   // launch contract: N % 256 == 0, 16-byte aligned out2 rows
             float gm[4] = {o[0], o[1], o[2], o[3]};
@@ -256,7 +278,7 @@ __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __rest
               gy[q] = ((bw[q] >> L) & 1ull) ? ep.c_act * gm[q] : 0.f;
               cs[q] += gy[q];
             }
-            *reinterpret_cast<float4*>(ep.out2 + m * ep.ld_out2 + n) = make_float4(gy[0] * sc2, gy[1] * sc2, gy[2] * sc2, gy[3] * sc2);
+            store4(ep.out2 + m * ep.ld_out2 + n, gy[0] * sc2, gy[1] * sc2, gy[2] * sc2, gy[3] * sc2, ep.nt_store);
           }
         }
       }

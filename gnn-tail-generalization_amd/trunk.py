@@ -133,7 +133,10 @@ def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0):
 
 
 import os
-FUSE_BWD_EPILOGUE = os.environ.get('CB_TRUNK_FUSE_BWD', '1') != '0'     # measurement switch: 0 runs cb_trunk_layer_bwd_f32 as a pass of its own
+# cb_gemm_nn_trunkbwd_f32 (the layer-below's trunk backward in the dX GEMM's epilogue) measured 2-3 ms per step SLOWER than the
+# GEMM + cb_trunk_layer_bwd_f32 as a pass of its own (215.1-216.3 vs 212.4-214.1 ms on S-pl10M): the extra 10 GB leave through the
+# GEMM's store phase, its least efficient part.  Off unless CB_TRUNK_FUSE_BWD=1; both forms are tested.
+FUSE_BWD_EPILOGUE = os.environ.get('CB_TRUNK_FUSE_BWD', '0') == '1'
 MIX_MAX = 7      # mixed-in gradients one cb_trunk_input_bwd_multi_f32 launch gathers (deeper trunks accumulate layer by layer)
 
 
@@ -194,8 +197,7 @@ class _TrunkFn(torch.autograd.Function):
         # the gradient reaching X0 through the L mixes: gathered in one pass by the input stage (the per-layer gradients stay
         # alive until then) when L <= MIX_MAX, else accumulated in place layer by layer
         gather = L <= MIX_MAX
-        # gather mode, fp32 rows: the layer-below's trunk backward (dropout, mix, ReLU, row scale, bias column sums) leaves the
-        # epilogue of the GEMM that produces dL/dx (cb_gemm_nn_trunkbwd_f32) instead of re-reading it in a pass of its own
+        # opt-in (CB_TRUNK_FUSE_BWD=1): the layer-below's trunk backward leaves the epilogue of the GEMM that produces dL/dx
         fuse = gather and not agg_bf16 and FUSE_BWD_EPILOGUE
         gx0 = None if gather else torch.empty_like(x0)
         g_mix, seeds_mix = [], []
