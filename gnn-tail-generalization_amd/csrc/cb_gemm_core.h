@@ -176,10 +176,13 @@ __device__ __forceinline__ void store4(float* __restrict__ p, float a, float b, 
 }
 
 // EPI: 0 = plain; 1 = second output out2 = dropout(C); 2 = second output = trunk layer backward of C (see GemmEpilogue)
-template <int WM, int WN, int WTN, bool OUT_BF16, int EPI = 0>
+// CS_FLOATS = floats available at Cs: when all WM wave rows fit (32 * WM staged rows), every wavefront stages in every pass
+// (2 passes with 2 barriers each instead of 2 * WM passes in which only one wave row writes).
+template <int WM, int WN, int WTN, bool OUT_BF16, int EPI = 0, int CS_FLOATS = 0>
 __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __restrict__ Cs, void* __restrict__ Cv, int64_t ldc,
                                             int64_t m0, int n0, int64_t M, int N, const GemmEpilogue& ep, int c_vec_ok, int t) {
   constexpr int BN = 32 * WTN * WN, LDB = BN + 4;
+  constexpr int G = (32 * WM * LDB <= CS_FLOATS) ? WM : 1;     // wave rows staged per pass
   float* C = (float*)Cv;
   const int lane = t & 63, w = t >> 6, wr = w / WN, wc = w % WN;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -196,21 +199,21 @@ __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __rest
   float cs[4] = {0.f, 0.f, 0.f, 0.f};     // EPI == 2: column sums of this thread's 4 columns (the same 4 in every pass: 256 % TPR == 0)
   static_assert(EPI != 2 || 256 % TPR == 0, "fixed column quad per thread");
 #pragma unroll
-  for (int pass = 0; pass < 2 * WM; ++pass) {
-    const int wr_sel = pass >> 1, ti = pass & 1;
-    if (wr == wr_sel) {
+  for (int pass = 0; pass < 2 * (WM / G); ++pass) {
+    const int grp = pass >> 1, ti = pass & 1;
+    if (wr / G == grp) {
 #pragma unroll
       for (int tj = 0; tj < WTN; ++tj)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
-          Cs[((reg & 3) + 8 * (reg >> 2) + 4 * lh) * LDB + wc * (32 * WTN) + tj * 32 + l31] = acc[ti][tj][reg];
+          Cs[((wr % G) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh) * LDB + wc * (32 * WTN) + tj * 32 + l31] = acc[ti][tj][reg];
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
+    for (int i = 0; i < G * NV; ++i) {
       const int idx = t + 256 * i;
       const int row = idx / TPR, c4 = (idx % TPR) * 4;
-      const int64_t m = m0 + wr_sel * 64 + ti * 32 + row;
+      const int64_t m = m0 + (grp * G + row / 32) * 64 + ti * 32 + (row % 32);
       const int n = n0 + c4;
       if (m < M && n < N) {
         const float4 v = *reinterpret_cast<const float4*>(Cs + row * LDB + c4);
