@@ -71,9 +71,9 @@ SIGNATURES = {
     'cb_topk_replace_workspace_bytes': (_SZ, [_I64, _I64, _I64]),
     'cb_topk_replace_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I64, _I64, _I32, _P, _P, _P, _P, _SZ, _P]),
     'cb_gather_rows_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _P, _P]),
-    'cb_spmm_csr_acc_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_int, _P, _I64, _P, _I64,
+    'cb_spmm_csr_acc_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_int, _P, _I64, _P, _I64,
                                            _I32, _I32, _I32, _P, _P, _P, _SZ, _P]),
-    'cb_spmm_csr_fused_acc_f32': (ctypes.c_int, [_P, _I64, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float,
+    'cb_spmm_csr_fused_acc_f32': (ctypes.c_int, [_P, _I64, _P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float,
                                                  ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _P, _I64, _P, _I64, _I32,
                                                  _I32, _I32, _P, _P, _P, _SZ, _P]),
     'cb_trunk_input_bwd_multi_f32': (ctypes.c_int, [_P, ctypes.c_uint64, _I32, _P, _P, ctypes.c_float, _P, _P, _I64, _I64, ctypes.c_float,

@@ -473,14 +473,14 @@ static int launch_spmm_cfg(const int32_t* rowptr, const int32_t* col, int64_t N,
 #define CB_ROWS_LAUNCH(FULL_, FUSED_, ACC_) CB_ROWS_LAUNCH_GP(FULL_, FUSED_, ACC_, 0)
     const bool acc = ep.acc_init != nullptr;
     constexpr bool kGP = VEC == 4 && sizeof(HT) == 4 && RPW == 16 && U == 8;   // gather-policy variants: fp32 d % 256 == 0 kernels only
-    const int gp = kGP && !acc && d % tile == 0 ? gather_policy(ep.col_flags) : 0;
+    const int gp = kGP && d % tile == 0 ? (acc ? (ep.col_flags ? 2 : 0) : gather_policy(ep.col_flags)) : 0;
     CB_CHECK_ARG(!ep.col_flags || gp == 2, CB_E_INVALID, "flagged column ids are only understood by the fp32 d %% 256 == 0 kernels");
     if constexpr (FUSED) {
-      if (acc) CB_ROWS_LAUNCH(true, true, true);
+      if (acc) { if constexpr (kGP) { if (gp == 2) CB_ROWS_LAUNCH_GP(true, true, true, 2); else CB_ROWS_LAUNCH(true, true, true); } else CB_ROWS_LAUNCH(true, true, true); }
       else if constexpr (kGP) { if (gp == 1) CB_ROWS_LAUNCH_GP(true, true, false, 1); else if (gp == 2) CB_ROWS_LAUNCH_GP(true, true, false, 2); else CB_ROWS_LAUNCH(true, true, false); }
       else CB_ROWS_LAUNCH(true, true, false);
     } else if (d % tile == 0) {
-      if (acc) CB_ROWS_LAUNCH(true, false, true);
+      if (acc) { if constexpr (kGP) { if (gp == 2) CB_ROWS_LAUNCH_GP(true, false, true, 2); else CB_ROWS_LAUNCH(true, false, true); } else CB_ROWS_LAUNCH(true, false, true); }
       else if constexpr (kGP) { if (gp == 1) CB_ROWS_LAUNCH_GP(true, false, false, 1); else if (gp == 2) CB_ROWS_LAUNCH_GP(true, false, false, 2); else CB_ROWS_LAUNCH(true, false, false); }
       else CB_ROWS_LAUNCH(true, false, false);
     } else {
@@ -571,7 +571,7 @@ static int spmm_plain_impl(const char* who, const int32_t* rowptr, const int32_t
                CB_E_WORKSPACE, "%s: hub plan given but workspace missing/too small (%zu < %zu)", who, ws_bytes,
                cb_spmm_workspace_bytes(n_chunks, d));
   Epilogue ep{row_scale, bias, relu, acc_init, ld_init, col_flags};
-  CB_CHECK_ARG(!col_flags || (!acc_init && d % 256 == 0), CB_E_INVALID, "%s: flagged column ids need d %% 256 == 0 and no acc_init", who);
+  CB_CHECK_ARG(!col_flags || d % 256 == 0, CB_E_INVALID, "%s: flagged column ids need d %% 256 == 0", who);
   hipStream_t st = (hipStream_t)stream;
   if (n_hubs == 0) hub_T = INT32_MAX;  // no plan given (or no hub rows): every row is reduced whole by one wavefront
   const bool ini16 = !acc_init || (((uintptr_t)acc_init % 16 == 0) && ld_init % 4 == 0);
@@ -601,12 +601,12 @@ extern "C" int cb_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, int32_
 
 // out = act(row_scale * (acc_init + sum over this CSR's columns) + bias): the second (halo-column) pass of the node-sharded
 // aggregation; acc_init holds the raw sums of the interior-column pass (dist.py).  acc_init may alias out.
-extern "C" int cb_spmm_csr_acc_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h,
+extern "C" int cb_spmm_csr_acc_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h,
                                    int64_t d, const float* row_scale, const float* bias, int relu, const float* acc_init,
                                    int64_t ld_init, float* out, int64_t ld_out, int32_t hub_T, int32_t n_hubs, int32_t n_chunks,
                                    const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
   CB_CHECK_ARG(acc_init != nullptr || N == 0 || d == 0, CB_E_INVALID, "cb_spmm_csr_acc_f32: acc_init is null");
-  return spmm_plain_impl("cb_spmm_csr_acc_f32", rowptr, col, 0, N, E, h, ld_h, d, row_scale, bias, relu, acc_init, ld_init, out, ld_out, hub_T,
+  return spmm_plain_impl("cb_spmm_csr_acc_f32", rowptr, col, col_flags, N, E, h, ld_h, d, row_scale, bias, relu, acc_init, ld_init, out, ld_out, hub_T,
                          n_hubs, n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, stream);
 }
 
@@ -632,7 +632,7 @@ static int spmm_fused_impl(int h_bf16, const float* acc_init, int64_t ld_init, i
                CB_E_WORKSPACE, "cb_spmm_csr_fused_f32: hub plan given but workspace missing/too small");
   if (n_hubs == 0) hub_T = INT32_MAX;
   Epilogue ep{row_scale, bias, 1, acc_init, ld_init, col_flags};
-  CB_CHECK_ARG(!col_flags || (!acc_init && !h_bf16), CB_E_INVALID, "cb_spmm_csr_fused_f32: flagged column ids: fp32 rows, no acc_init");
+  CB_CHECK_ARG(!col_flags || !h_bf16, CB_E_INVALID, "cb_spmm_csr_fused_f32: flagged column ids: fp32 rows only");
   FusedEpi fe{};
   fe.mix_src = mix_src; fe.ld_mix = ld_mix; fe.c_act = c_act; fe.c_mix = c_mix;
   fe.thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
@@ -666,14 +666,14 @@ extern "C" int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, 
 }
 
 // Fused store of the residual trunk on top of the interior-column partial sums (second pass of the node-sharded aggregation)
-extern "C" int cb_spmm_csr_fused_acc_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int64_t N,
-                                         int64_t E, const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias,
+extern "C" int cb_spmm_csr_fused_acc_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int32_t col_flags,
+                                         int64_t N, int64_t E, const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias,
                                          const float* mix_src, int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed,
                                          const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, float* out_act, int64_t ld_act,
                                          float* out_next, int64_t ld_next, int32_t hub_T, int32_t n_hubs, int32_t n_chunks,
                                          const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
   CB_CHECK_ARG(acc_init != nullptr || N == 0, CB_E_INVALID, "cb_spmm_csr_fused_acc_f32: acc_init is null");
-  return spmm_fused_impl(0, acc_init, ld_init, 0, CB_FUSED_ARGS);
+  return spmm_fused_impl(0, acc_init, ld_init, col_flags, CB_FUSED_ARGS);
 }
 
 extern "C" int cb_spmm_csr_fused_bf16_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const uint16_t* h,

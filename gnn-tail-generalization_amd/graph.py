@@ -79,9 +79,9 @@ class CSRGraph:
         CB_SPMM_GATHER=0 (measurement hook) switches the flags off, CB_SPMM_HOT_ROWS overrides the count."""
         import os
         self.col_k = self.col_t_k = None
-        if os.environ.get('CB_SPMM_GATHER', '2') != '2' or self.E == 0 or self.N < 2 * HOT_ROWS:
+        if os.environ.get('CB_SPMM_GATHER', '2') != '2' or self.E == 0 or self.n_cols < 2 * HOT_ROWS:
             return      # small graphs: the whole feature matrix is cache resident anyway
-        k = min(int(os.environ.get('CB_SPMM_HOT_ROWS', HOT_ROWS)), self.N)
+        k = min(int(os.environ.get('CB_SPMM_HOT_ROWS', HOT_ROWS)), self.n_cols)
 
         def flag(col):
             refs = torch.bincount(col[:self.E].long(), minlength=self.n_cols)          # how often each source row is gathered per launch
@@ -110,7 +110,8 @@ class CSRGraph:
         g._plan_t = None
         g._ws, g.profile = None, None
         g.row_offset = 0
-        g.col_k = g.col_t_k = None
+        g.n_cols = int(n_cols)
+        g._hot_cols()                  # row blocks of the node-sharded path gather from [local | halo] matrices far beyond the caches too
         return g
 
     @classmethod
@@ -201,7 +202,7 @@ class CSRGraph:
             out = torch.empty((self.N, d), dtype=torch.float32, device=h.device)
         rowptr, col, plan = (self.rowptr_t, self.col_t, self._plan_t) if transpose else (self.rowptr, self.col, self._plan)
         col_k = self.col_t_k if transpose else self.col_k
-        flags = int(col_k is not None and not bf16 and acc_init is None and d % 256 == 0 and h.data_ptr() % 16 == 0
+        flags = int(col_k is not None and not bf16 and d % 256 == 0 and h.data_ptr() % 16 == 0
                     and out.data_ptr() % 16 == 0 and h.stride(0) % 4 == 0 and out.stride(0) % 4 == 0)
         if flags:
             col = col_k
@@ -218,7 +219,7 @@ class CSRGraph:
             if acc_init is not None:
                 if bf16 or acc_init.dtype != torch.float32 or acc_init.shape != (self.N, d) or acc_init.stride(1) != 1:
                     raise ValueError('acc_init must be a float32 [N, d] matrix with contiguous rows (fp32 source rows only)')
-                _lib.check(lib.cb_spmm_csr_acc_f32(_lib.ptr(rowptr), _lib.ptr(col), self.N, self.E, _lib.ptr(h), ld_h, d,
+                _lib.check(lib.cb_spmm_csr_acc_f32(_lib.ptr(rowptr), _lib.ptr(col), flags, self.N, self.E, _lib.ptr(h), ld_h, d,
                                                    _lib.ptr(row_scale), _lib.ptr(bias), int(bool(relu)), _lib.ptr(acc_init),
                                                    acc_init.stride(0) if self.N > 1 else d, _lib.ptr(out), ld_o,
                                                    self.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows),

@@ -303,11 +303,12 @@ int cb_topk_replace_f32(const float* q, int64_t ldq, const float* t, int64_t ldt
  * Same arguments as cb_spmm_csr_f32 / cb_spmm_csr_fused_f32 plus acc_init [N, ld_init] (fp32, read once; the plain
  * variant allows acc_init == out).  Replaces the same reference lines as those two (GCN.py:198,238-253,127-133).
  * ---------------------------------------------------------------------------------- */
-int cb_spmm_csr_acc_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h, int64_t d,
+int cb_spmm_csr_acc_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h, int64_t d,
                         const float* row_scale, const float* bias, int relu, const float* acc_init, int64_t ld_init, float* out,
                         int64_t ld_out, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
                         const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream);
-int cb_spmm_csr_fused_acc_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E,
+int cb_spmm_csr_fused_acc_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N,
+                              int64_t E,
                               const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias,
                               const float* mix_src, int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed,
                               const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, float* out_act, int64_t ld_act,
