@@ -28,13 +28,13 @@ __global__ void __launch_bounds__(kBlock) k_dropout(const float* __restrict__ x,
     float m[4];
     const int64_t gq = (offset >> 2) + q;
     keep4(seed, gq, thresh, scale, m);
-    if (sub) {  // local quad straddles two global quads
-      float m2[4], t[4];
+    if (sub) {  // local quad straddles two global quads (compile-time shifts: no dynamically indexed register arrays)
+      float m2[4];
       keep4(seed, gq + 1, thresh, scale, m2);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) t[k] = (k + sub < 4) ? m[(k + sub) & 3] : m2[(k + sub) & 3];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) m[k] = t[k];
+      const float e[8] = {m[0], m[1], m[2], m[3], m2[0], m2[1], m2[2], m2[3]};
+      if (sub == 1) { m[0] = e[1]; m[1] = e[2]; m[2] = e[3]; m[3] = e[4]; }
+      else if (sub == 2) { m[0] = e[2]; m[1] = e[3]; m[2] = e[4]; m[3] = e[5]; }
+      else { m[0] = e[3]; m[1] = e[4]; m[2] = e[5]; m[3] = e[6]; }
     }
     const int64_t i = q * 4;
     if (vec_ok && i + 4 <= n) {

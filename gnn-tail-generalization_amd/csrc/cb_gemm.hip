@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) k_gemm_nn(const float* __restrict__ A, in
     __syncthreads();
   }
 
-  nn_epilogue<WM, WN, WTN, OUT_BF16, 0, T::SMEM_FLOATS>(acc, smem, Cv, ldc, m0, n0, M, N, ep, c_vec_ok, t);
+  nn_epilogue<WM, WN, WTN, OUT_BF16>(acc, smem, Cv, ldc, m0, n0, M, N, ep, c_vec_ok, t);
 }
 
 // ---- TN ------------------------------------------------------------------------------------
