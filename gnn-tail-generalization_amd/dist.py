@@ -437,7 +437,8 @@ def sync_initial_state(model, part, group=None, seed=0):
 
 
 class ShardedTrainer:
-    """bench.py / multi-GPU driver of the TeacherGNN step.  Mirrors trainer.train_step()."""
+    """Multi-GPU driver of the TeacherGNN path: bench.py (train_step) and `torchrun ... main.py` (main -> train_teacherGNN: the
+    reference's epoch loop with accuracy counts all-reduced).  Mirrors trainer.train_step / run_testSet / train_teacherGNN."""
 
     def __init__(self, args, which_run, group=None):
         from . import optim as cb_optim
@@ -472,6 +473,9 @@ class ShardedTrainer:
         self.x = p.slice_rows(data.x).float().contiguous()
         self.y = p.slice_rows(data.y).contiguous()
         self.train_mask = p.slice_rows(data.train_mask).contiguous()
+        test_mask = data.test_mask if getattr(data, 'test_mask', None) is not None else ~data.train_mask
+        self.test_mask = p.slice_rows(test_mask).contiguous()
+        self.n_test = int(test_mask.sum().item())
         self.edge_index = data.edge_index[:, :1]     # placeholder: the cached sharded graph is injected below
         del data
         torch.cuda.empty_cache()
@@ -526,3 +530,36 @@ class ShardedTrainer:
         total = loss.detach().clone()
         _all_reduce(total, group=self.group)
         return total
+
+    # -- the reference's epoch on row shards (trainer_node_classification.py:303-369,453-495,672-681) ----------------------
+    def run_testSet(self):
+        """Eval forward + argmax accuracy on the train / test masks: per-rank hit counts, all-reduced."""
+        from . import norms_hip
+        m = self.teacherGNN
+        m.eval()
+        with torch.no_grad(), norms_hip.row_sharding(self.group, self._n):
+            out = m.get_3_embs(self.x, self.edge_index).emb4classi_full
+        hit = out.argmax(dim=1) == self.y
+        cnt = torch.stack([(hit & self.train_mask).sum(), (hit & self.test_mask).sum()]).to(torch.float64)
+        _all_reduce(cnt, group=self.group)
+        acc_train, acc_test = (cnt / torch.tensor([max(self.n_train, 1), max(self.n_test, 1)], dtype=torch.float64, device=cnt.device)).tolist()
+        return acc_train, float('nan'), acc_test, float('nan')
+
+    def train_teacherGNN(self):
+        """Epoch loop with the record layout of trainer.train_teacherGNN (want_headtail = 0): returns [[acc_test * 100 per epoch]].
+        Every rank returns the same array."""
+        import numpy as np
+        self.setup_teacherGNN()
+        rows = []
+        for epoch in range(self.args.epochs):
+            loss = float(self.train_step())
+            acc_train, _, acc_test, _ = self.run_testSet()
+            rows.append([np.log(loss), acc_train * 100, acc_test * 100, 0, 0])
+            if epoch % 20 == 0 and self.rank == 0:
+                print(f'Ep{epoch:03d}, acc @ train/test: {acc_train * 100:.1f}, {acc_test * 100:.1f} ')
+        return np.array(rows).T[[2]]
+
+    def main(self):
+        if self.args.train_which != 'TeacherGNN' or self.args.want_headtail:
+            raise NotImplementedError('the node-sharded trainer runs --train_which=TeacherGNN with --want_headtail=0')
+        return self.train_teacherGNN()

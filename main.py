@@ -22,6 +22,18 @@ def main(argv=None):
     else:
         raise NotImplementedError(f"--exp_mode={args.exp_mode}: only 'coldbrew' (node classification, TeacherGNN) is built; "
                                   'the I2_GTL link-prediction trainer is out of scope (SURVEY.md §2 #13-14)')
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        # launched by torchrun (one process per GPU): the node-sharded trainer over RCCL (new; the reference is single-device)
+        import torch.distributed as dist
+        from gnn_tail_generalization_amd.dist import ShardedTrainer
+        local_rank = int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)   # (modulo: several gloo ranks on one GPU in the tests)
+        args.cuda_num = local_rank
+        torch.cuda.set_device(local_rank)
+        if not dist.is_initialized():
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            dist.init_process_group(os.environ.get('COLDBREW_DIST_BACKEND', 'nccl'))
+        trainer = ShardedTrainer
     if args.prog:
         tensorRex(None, args.prog, args.rexName)
     full_recs_3D = []

@@ -58,13 +58,14 @@ def _worker(rank, world, port, exchange, overlap, partition, argv, q):
         assert (not conv0.whetherHasSE) or conv0.le.shape[0] == t.part.n_local
         ops._seed_override[:] = list(SEEDS)
         losses = [float(t.train_step()) for _ in range(STEPS)]
+        accs = t.run_testSet()
         w = t.teacherGNN.model.model.layers_GCN[1].weight.detach().cpu()
         le = conv0.le.detach().cpu() if conv0.whetherHasSE else torch.zeros(1)
         bn = t.teacherGNN.state_dict().get('model.model.layers_norm.0.running_var', torch.zeros(1)).cpu()
-        q.put((rank, 'ok', losses, w.numpy(), le.numpy(), t.part.lo(), t.part.hi(), bn.numpy()))   # by value: the child may exit first
+        q.put((rank, 'ok', losses, w.numpy(), le.numpy(), t.part.lo(), t.part.hi(), bn.numpy(), (accs[0], accs[2])))   # by value: the child may exit first
     except Exception:  # noqa: BLE001
         import traceback
-        q.put((rank, 'FAIL ' + traceback.format_exc()[-2500:], None, None, None, 0, 0, None))
+        q.put((rank, 'FAIL ' + traceback.format_exc()[-2500:], None, None, None, 0, 0, None, None))
     finally:
         dist.destroy_process_group()
 
@@ -96,6 +97,8 @@ def test_two_ranks_on_one_gpu_match_single_process(exchange, overlap, partition,
     ops._seed_override[:] = list(SEEDS)
     want = [float(ref.train_step()) for _ in range(STEPS)]
     ops._seed_override[:] = []
+    acc_ref = ref.run_testSet()
+    n_nodes = ref.data.x.shape[0]
     conv0 = ref.teacherGNN.model.model.layers_GCN[0]
     w_ref = ref.teacherGNN.model.model.layers_GCN[1].weight.detach().cpu()
     le_ref = conv0.le.detach().cpu() if conv0.whetherHasSE else None
@@ -109,8 +112,10 @@ def test_two_ranks_on_one_gpu_match_single_process(exchange, overlap, partition,
     res = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=120)
-    for rank, msg, losses, w, le, lo, hi, bn in res:
+    for rank, msg, losses, w, le, lo, hi, bn, accs in res:
         assert msg == 'ok', f'rank {rank}: {msg}'
+        # accuracy = all-reduced hit counts / global mask sizes (eval forward on the shards); an argmax tie may flip a node or two
+        assert abs(accs[0] - acc_ref[0]) <= 3.0 / n_nodes * 10 and abs(accs[1] - acc_ref[2]) <= 3.0 / n_nodes * 10, (accs, acc_ref)
         np.testing.assert_allclose(losses, want, rtol=2e-5)
         torch.testing.assert_close(torch.from_numpy(w), w_ref, atol=1e-5, rtol=1e-4)
         if le_ref is not None:
