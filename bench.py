@@ -284,6 +284,7 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (torch.cuda.is_available() is False); the HIP path has no CPU fallback')
+    local_rank %= torch.cuda.device_count()            # >1 rank per GPU only in the gloo dry run of the N>1 code path
     torch.cuda.set_device(local_rank)
     dev = torch.device(f'cuda:{local_rank}')
     sharded = world > 1 or os.environ.get('COLDBREW_FORCE_SHARDED') == '1'   # the latter: exercise the sharded code on 1 GPU
@@ -291,7 +292,11 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get('COLDBREW_DIST_BACKEND', 'nccl')      # 'gloo': dry run of this file's N>1 path on a 1-GPU box
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if a.gpus != world and rank == 0:
         print(f'[bench] --gpus {a.gpus} but WORLD_SIZE={world}: using WORLD_SIZE', file=sys.stderr)
 
@@ -343,13 +348,13 @@ def main():
         prof, graph_obj.profile = graph_obj.profile, None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        cbdist._all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_step = dt / a.steps * 1e3
     peak_mem = torch.cuda.max_memory_allocated(dev)
     if world > 1:
         pm = torch.tensor([peak_mem], device=dev, dtype=torch.float64)
-        dist.all_reduce(pm, op=dist.ReduceOp.MAX)
+        cbdist._all_reduce(pm, op=dist.ReduceOp.MAX)
         peak_mem = float(pm.item())
     spmm_ms = [e0.elapsed_time(e1) for e0, e1, _, _ in prof]
     spmm_bytes = [b for _, _, b, _ in prof]                  # E(ds+4) + N(ds+4) [+4N] [+ds] per launch
