@@ -43,6 +43,7 @@ SIGNATURES = {
     'cb_adam_multi_f32': (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                          ctypes.c_float, _I64, _P, _P]),
     'cb_gemm_nn_workspace_bytes': (_SZ, [_I64, _I64]),
+    'cb_gemm_nn_splitk_workspace_bytes': (_SZ, [_I64, _I64, _I64]),
     'cb_gemm_nn_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int, _P, _SZ, _P]),
     'cb_gemm_nn_drop2_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int,
                                             ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _SZ, _P]),

@@ -32,8 +32,15 @@ namespace cb {
 template <int WM, int WN, bool ALIGNED, bool OUT_BF16, int BKT = BK, int WTN = 2>
 __global__ void __launch_bounds__(256) k_gemm_nn(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
                                                  void* __restrict__ Cv, int64_t ldc, int64_t M, int N, int K, GemmEpilogue ep,
-                                                 int n_row_blocks, int n_col_blocks, int c_vec_ok) {
+                                                 int n_row_blocks, int n_col_blocks, int c_vec_ok, int k_chunk) {
   using T = Tile<WM, WN, BKT, WTN>;
+  if (k_chunk) {   // split-K launch: block row blockIdx.y contracts k in [y * k_chunk, ...) into its own partial plane [M, ldc]
+    const int k0 = blockIdx.y * k_chunk;
+    A += k0;
+    B += (int64_t)k0 * ldb;
+    Cv = reinterpret_cast<float*>(Cv) + (int64_t)blockIdx.y * M * ldc;
+    K = min(k_chunk, K - k0);
+  }
   constexpr int BM = T::BM, BN = T::BN, LDA = T::LDA, LDB = T::LDB;
   __shared__ __attribute__((aligned(16))) float smem[T::SMEM_FLOATS];
   auto As = [&](int b) { return smem + b * (BKT * LDA); };
@@ -136,15 +143,23 @@ __global__ void __launch_bounds__(256) k_gemm_tn(const float* __restrict__ A, in
 __global__ void k_sum_partials(const float* __restrict__ partial, int nsplit, int64_t n, float* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float s = 0.f;
-  for (int p = 0; p < nsplit; ++p) s += partial[(int64_t)p * n + i];
-  out[i] = s;
+  // eight independent running sums (eight loads in flight per lane: with one, 154 slabs of a Pubmed-sized weight gradient took
+  // 37 us), combined in a fixed order
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int p = 0;
+  for (; p + 8 <= nsplit; p += 8)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] += partial[(int64_t)(p + j) * n + i];
+  for (; p < nsplit; ++p) s[0] += partial[(int64_t)p * n + i];
+  out[i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
 static inline int tn_splits(int64_t M, int tiles) {
-  // enough blocks for ~4 per CU, each with at least 64 K-steps of work
+  // enough blocks for ~4 per CU, each with at least 8 K-steps of work: a K step of a lone block costs ~1.7 us of load latency,
+  // so the Cora / Pubmed-sized reductions (M = 2 708 / 19 717 rows) want many short slabs (64 K-steps per slab left them
+  // at 3 / 20 blocks on 256 CUs: 90-190 us per weight gradient instead of ~30)
   int64_t want = (256 * 4 + tiles - 1) / tiles;
-  int64_t max_by_work = (M + BK * 64 - 1) / (BK * 64);
+  int64_t max_by_work = (M + BK * 8 - 1) / (BK * 8);
   int64_t s = want < max_by_work ? want : max_by_work;
   if (s < 1) s = 1;
   if (s > 1024) s = 1024;
@@ -174,22 +189,72 @@ static inline void tn_tile(int64_t K1, int64_t K2, int& bm, int& bn) {
   else { bm = 128; bn = 128; }
 }
 
+// Split-K of the fallback NN kernel: few output tiles and a long contraction (x @ W_0 of a Cora / Citeseer-sized graph:
+// 2 708 x 1 433 x 64 = 11 blocks looping 90 K steps, 220 us) — the K range is cut into `splits` chunks of whole K steps, every
+// chunk's raw product goes to its own plane of the workspace and k_splitk_finish sums the planes in a fixed order and applies
+// the epilogue once.  0 = do not split.
+static inline int nn_splitk(int64_t M, int64_t N, int64_t K, int bm, int bn, int* k_chunk) {
+  const int64_t blocks = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  if (blocks * 2 > 256 || K < 512) return 0;
+  int64_t s = 256 / blocks;
+  const int64_t by_work = K / (BK * 8);
+  if (s > by_work) s = by_work;
+  if (s > 64) s = 64;
+  if (s < 2) return 0;
+  const int64_t kc = ((K + s - 1) / s + BK - 1) / BK * BK;
+  *k_chunk = (int)kc;
+  return (int)((K + kc - 1) / kc);
+}
+
+__global__ void k_splitk_finish(const float* __restrict__ partial, int nsplit, int64_t M, int N, float* __restrict__ C, int64_t ldc,
+                                GemmEpilogue ep) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  const int64_t m = i / N;
+  const int n = (int)(i - m * N);
+  float s = 0.f;
+#pragma unroll 4
+  for (int p = 0; p < nsplit; ++p) s += partial[(int64_t)p * M * N + i];
+  if (ep.rowscale) s *= ep.rowscale[m];
+  if (ep.addend) s += ep.addend[m * ep.ld_add + n];
+  if (ep.bias) s += ep.bias[n];
+  if (ep.relu) s = fmaxf(s, 0.f);
+  C[m * ldc + n] = s;
+}
+
 template <int WM, int WN, bool OUT_BF16 = false, int WTN = 2>
 static int launch_nn(const float* A, int64_t lda, const float* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
-                     int64_t K, GemmEpilogue ep, hipStream_t st) {
+                     int64_t K, GemmEpilogue ep, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
   using T = Tile<WM, WN, BK, WTN>;
   const int nrb = (int)((M + T::BM - 1) / T::BM), ncb = (int)((N + T::BN - 1) / T::BN);
   const int64_t groups = (nrb + 7) / 8;
   const dim3 grid((unsigned)(groups * 8 * ncb));
   const bool aligned = al16(A) && al16(B) && lda % 4 == 0 && ldb % 4 == 0;
   const int c_vec_ok = ((uintptr_t)C % (OUT_BF16 ? 8 : 16) == 0) && ldc % 4 == 0 && (!ep.addend || (al16(ep.addend) && ep.ld_add % 4 == 0));
+  if constexpr (!OUT_BF16) {
+    int k_chunk = 0;
+    const int splits = nn_splitk(M, N, K, T::BM, T::BN, &k_chunk);
+    if (splits && ws && ws_bytes >= (size_t)splits * M * N * sizeof(float)) {
+      const GemmEpilogue raw{};
+      const dim3 grid2(grid.x, (unsigned)splits);
+      const int pv = ((uintptr_t)ws % 16 == 0) && N % 4 == 0;
+      if (aligned)
+        hipLaunchKernelGGL((k_gemm_nn<WM, WN, true, false, BK, WTN>), grid2, dim3(256), 0, st, A, lda, B, ldb, ws, N, M, (int)N, (int)K, raw, nrb, ncb, pv, k_chunk);
+      else
+        hipLaunchKernelGGL((k_gemm_nn<WM, WN, false, false, BK, WTN>), grid2, dim3(256), 0, st, A, lda, B, ldb, ws, N, M, (int)N, (int)K, raw, nrb, ncb, pv, k_chunk);
+      CB_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_splitk_finish, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, st, (const float*)ws, splits, M, (int)N, (float*)C, ldc, ep);
+      CB_LAUNCH_CHECK();
+      return CB_OK;
+    }
+  }
   static const int bk32 = getenv("CB_GEMM_BK32") != nullptr;   // measurement hook: K step 32 instead of 16
   if (aligned && bk32 && WM == 2 && WTN == 2)
-    hipLaunchKernelGGL((k_gemm_nn<WM, WN, true, OUT_BF16, 32, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
+    hipLaunchKernelGGL((k_gemm_nn<WM, WN, true, OUT_BF16, 32, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok, 0);
   else if (aligned)
-    hipLaunchKernelGGL((k_gemm_nn<WM, WN, true, OUT_BF16, BK, WTN>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
+    hipLaunchKernelGGL((k_gemm_nn<WM, WN, true, OUT_BF16, BK, WTN>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok, 0);
   else
-    hipLaunchKernelGGL((k_gemm_nn<WM, WN, false, OUT_BF16, BK, WTN>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
+    hipLaunchKernelGGL((k_gemm_nn<WM, WN, false, OUT_BF16, BK, WTN>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok, 0);
   CB_LAUNCH_CHECK();
   return CB_OK;
 }
@@ -237,6 +302,13 @@ extern "C" size_t cb_gemm_nn_workspace_bytes(int64_t N, int64_t K) {
   return limb3_nn_workspace_bytes(N, K);
 }
 
+extern "C" size_t cb_gemm_nn_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  int k_chunk = 0;
+  const int splits = N <= 64 ? nn_splitk(M, N, K, 256, 64, &k_chunk) : nn_splitk(M, N, K, 128, 128, &k_chunk);
+  return (size_t)splits * (size_t)M * (size_t)N * sizeof(float);
+}
+
 extern "C" int cb_gemm_nn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
                               int64_t K, const float* rowscale, const float* addend, int64_t ld_add, const float* bias, int relu,
                               void* ws, size_t ws_bytes, void* stream) {
@@ -248,10 +320,10 @@ extern "C" int cb_gemm_nn_f32(const float* A, int64_t lda, const float* B, int64
   GemmEpilogue ep{rowscale, addend, ld_add, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, nullptr, 0.f, nullptr, nullptr, gemm_nt_store(M, N)};
   hipStream_t st = (hipStream_t)stream;
   if (use_limb3() && limb3_nn_eligible(A, lda, B, ldb, N, K)) return launch_nn_limb3(A, lda, B, ldb, C, ldc, M, N, K, ep, false, st, ws, ws_bytes);
-  if (N <= 64) return launch_nn<4, 1>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
+  if (N <= 64) return launch_nn<4, 1>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes);
   static const int wide = getenv("CB_GEMM_WIDE") != nullptr;   // measurement hook: 128x256 block tile (wave tile 64x128)
   if (wide && N > 128) return launch_nn<2, 2, false, 4>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
-  return launch_nn<2, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
+  return launch_nn<2, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes);
 }
 
 // C = act(rowscale * (A @ B) + addend + bias) and C2 = dropout_p(C) from ONE pass: the input Linear + ReLU of the residual
@@ -269,7 +341,7 @@ extern "C" int cb_gemm_nn_drop2_f32(const float* A, int64_t lda, const float* B,
                "cb_gemm_nn_drop2_f32: null pointer or leading dimension too small");
   GemmEpilogue ep{rowscale, addend, ld_add, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, nullptr, 0.f, nullptr, nullptr, gemm_nt_store(M, N)};
   hipStream_t st = (hipStream_t)stream;
-  if (use_limb3() && drop_p > 0.f && limb3_nn_dual_eligible(A, lda, B, ldb, C, ldc, C2, ldc2, N, K, ep)) {
+  if (use_limb3() && drop_p > 0.f && limb3_nn_dual_eligible(A, lda, B, ldb, C, ldc, C2, ldc2, M, N, K, ep)) {
     ep.out2 = C2; ep.ld_out2 = ldc2; ep.thresh = dropout_threshold(drop_p); ep.keep_scale = 1.f / (1.f - drop_p);
     ep.seed = seed; ep.seed_dev = seed_dev; ep.row0 = row0;
     return launch_nn_limb3(A, lda, B, ldb, C, ldc, M, N, K, ep, false, st, ws, ws_bytes);
@@ -319,7 +391,7 @@ extern "C" int cb_gemm_nn_trunkbwd_f32(const float* A, int64_t lda, const float*
   CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_gemm_nn_trunkbwd_workspace_bytes(M, N)), CB_E_WORKSPACE, "cb_gemm_nn_trunkbwd_f32: workspace too small");
   GemmEpilogue ep{rowscale, nullptr, 0, nullptr, 0, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, nullptr, 0.f, nullptr, nullptr, gemm_nt_store(M, N)};
   hipStream_t st = (hipStream_t)stream;
-  if (use_limb3() && limb3_nn_dual_eligible(A, lda, B, ldb, G, ldg, GR, ldgr, N, K, ep)) {
+  if (use_limb3() && limb3_nn_dual_eligible(A, lda, B, ldb, G, ldg, GR, ldgr, M, N, K, ep)) {
     ep.out2 = GR; ep.ld_out2 = ldgr; ep.thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u; ep.keep_scale = 1.f / (1.f - drop_p);
     ep.seed = seed; ep.seed_dev = seed_dev; ep.row0 = row0;
     ep.bits = (const unsigned long long*)relu_bits; ep.c_act = c_act; ep.rowscale2 = row_scale2; ep.colsum_partial = colsum ? (float*)ws : nullptr;

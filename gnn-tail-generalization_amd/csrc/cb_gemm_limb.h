@@ -12,7 +12,7 @@ size_t limb3_nn_workspace_bytes(int64_t N, int64_t K);
 int launch_nn_limb3(const float* A, int64_t lda, const float* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                     const GemmEpilogue& ep, bool out_bf16, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0);
 bool limb3_nn_dual_eligible(const float* A, int64_t lda, const float* B, int64_t ldb, const float* C, int64_t ldc, const float* C2, int64_t ldc2,
-                            int64_t N, int64_t K, const GemmEpilogue& ep);
+                            int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep);
 bool limb3_tn_eligible(const float* A, int64_t lda, const float* G, int64_t ldg, int64_t K1, int64_t K2);
 // partial slabs [nsplit][K1][K2] exactly as k_gemm_tn writes them; bm = tile rows chosen by tn_tile()
 int launch_tn_limb3(const float* A, int64_t lda, const float* G, int64_t ldg, const float* rowscale, float* partial, int64_t M,

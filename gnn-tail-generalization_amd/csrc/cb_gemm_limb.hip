@@ -230,9 +230,10 @@ bool limb3_nn_eligible(const float* A, int64_t lda, const float* B, int64_t ldb,
 
 // the dual-output epilogue exists for the wide (128 x 256) fp32 tile with vector stores on both outputs
 bool limb3_nn_dual_eligible(const float* A, int64_t lda, const float* B, int64_t ldb, const float* C, int64_t ldc, const float* C2, int64_t ldc2,
-                            int64_t N, int64_t K, const GemmEpilogue& ep) {
+                            int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep) {
   static const int wide = getenv("CB_LIMB_WIDE") ? atoi(getenv("CB_LIMB_WIDE")) : 1;
-  return wide && N > 128 && limb3_nn_eligible(A, lda, B, ldb, N, K) && al16(C) && al16(C2) && ldc % 4 == 0 && ldc2 % 4 == 0 &&
+  // below one wide tile per CU the 128 x 128 tile + a separate elementwise pass is faster (see launch_nn_limb3)
+  return wide && N > 128 && ((M + 127) / 128) * ((N + 255) / 256) >= 256 && limb3_nn_eligible(A, lda, B, ldb, N, K) && al16(C) && al16(C2) && ldc % 4 == 0 && ldc2 % 4 == 0 &&
          (!ep.addend || (al16(ep.addend) && ep.ld_add % 4 == 0));
 }
 
@@ -249,7 +250,10 @@ int launch_nn_limb3(const float* A, int64_t lda, const float* B, int64_t ldb, vo
                     : launch_nn_l3_t<4, 1, false>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
   }
   static const int wide = getenv("CB_LIMB_WIDE") ? atoi(getenv("CB_LIMB_WIDE")) : 1;   // 128 x 256 block tile (wave tile 64 x 128); 0: 128 x 128
-  if (wide && N > 128)
+  // fewer than one wide tile per CU (a Pubmed-sized M = 19 717: 155 tiles): the 128 x 128 tile doubles the blocks in flight (-6 % on
+  // the S-pubmed step); the dual-output epilogues exist for the wide tile only
+  const bool fills = ((M + 127) / 128) * ((N + 255) / 256) >= 256 || ep.out2;
+  if (wide && N > 128 && fills)
     return out_bf16 ? launch_nn_l3_t<2, 2, true, 4>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes)
                     : launch_nn_l3_t<2, 2, false, 4>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes);
   return out_bf16 ? launch_nn_l3_t<2, 2, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes)
@@ -281,7 +285,7 @@ int launch_tn_limb3(const float* A, int64_t lda, const float* G, int64_t ldg, co
   else if (bm == 256) launch_tn_l3_t<4, 1>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st);
   else {
     static const int wide = getenv("CB_LIMB_WIDE") ? atoi(getenv("CB_LIMB_WIDE")) : 1;
-    if (wide && K2 > 128) launch_tn_l3_t<2, 2, 4>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st);
+    if (wide && K2 > 128 && ((K1 + 127) / 128) * ((K2 + 255) / 256) * nsplit >= 256) launch_tn_l3_t<2, 2, 4>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st);
     else launch_tn_l3_t<2, 2>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st);
   }
   CB_LAUNCH_CHECK();

@@ -23,12 +23,15 @@ def _ld(t):
 
 
 def _b_workspace(lib, N, K, M, device):
-    """Room for the right operand split once per launch (cb_gemm_nn_workspace_bytes).  Measured neutral (profiles/r02_gemm_presplit.md),
-    so only handed over when CB_LIMB_PRESPLIT=1 asks for it."""
+    """Workspace of an NN launch: split-K partial planes for small-M / long-K shapes (cb_gemm_nn_splitk_workspace_bytes), or — only
+    when CB_LIMB_PRESPLIT=1 asks for it, measured neutral (profiles/r02_gemm_presplit.md) — room for the right operand split once
+    per launch (cb_gemm_nn_workspace_bytes)."""
     import os
     if os.environ.get('CB_LIMB_PRESPLIT', '0') in ('', '0') or M < 1024 or K * N > (1 << 22):
-        return None, 0
-    wsb = lib.cb_gemm_nn_workspace_bytes(N, K)
+        # few output tiles and a long contraction (x @ W_0 of a Cora-sized graph): planes of the split-K partial products
+        wsb = lib.cb_gemm_nn_splitk_workspace_bytes(M, N, K) if K >= 512 else 0
+    else:
+        wsb = lib.cb_gemm_nn_workspace_bytes(N, K)
     return (torch.empty(wsb, dtype=torch.uint8, device=device), wsb) if wsb else (None, 0)
 
 

@@ -168,6 +168,11 @@ int cb_adam_multi_f32(int32_t n_tensors, float* const* p, const float* const* g,
  * bf16 planes, pre-arranged as the kernel's LDS image — B is the small weight matrix, so this replaces the per-block,
  * per-K-step split of the same values by a straight 16-byte copy.  ws == NULL: every block splits its own copy. */
 size_t cb_gemm_nn_workspace_bytes(int64_t N, int64_t K);
+/* Few output tiles, long contraction (x @ W_0 of a Cora-sized graph, 2 708 x 1 433 x 64: GCN.py:105) on the fp32-input
+ * fallback kernel: with ws of cb_gemm_nn_splitk_workspace_bytes(M, N, K) bytes (0 = the shape is not split) the K range is
+ * cut into chunks contracted by different blocks and summed in a fixed order before the epilogue.  Without ws: one block
+ * per output tile walks the whole K range (same result up to the summation order). */
+size_t cb_gemm_nn_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int cb_gemm_nn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
                    int64_t K, const float* rowscale, const float* addend, int64_t ld_add, const float* bias, int relu,
                    void* ws, size_t ws_bytes, void* stream);

@@ -29,6 +29,29 @@ def test_gemm_nn_epilogues(M, K, N):
     torch.testing.assert_close(out.cpu().double(), ref2, **tol)
 
 
+@pytest.mark.parametrize('M,K,N', [(2708, 1433, 64), (3327, 3703, 256), (500, 2048, 128)])
+def test_gemm_nn_split_k_small_m_long_k(M, K, N):
+    """Input Linear of a Cora / Citeseer-sized graph (GCN.py:105): few output tiles, long contraction -> the fp32-input kernel cuts
+    K over blocks (cb_gemm_nn_splitk_workspace_bytes > 0) and applies the epilogue after the fixed-order sum of the planes."""
+    from gnn_tail_generalization_amd import _lib, gemm
+    lib = _lib.load()
+    a, b = _rand(M, K, seed=1).to(DEV), _rand(K, N, seed=2).to(DEV)
+    if K % 4 == 0:
+        a = torch.nn.functional.pad(a, (0, 1))[:, :K]          # odd leading dimension: keeps the shape on the fp32-input kernel
+    assert lib.cb_gemm_nn_splitk_workspace_bytes(M, N, K) > 0
+    rs, add, bias = (torch.rand(M) + 0.5).to(DEV), _rand(M, N, seed=3).to(DEV), _rand(N, seed=4).to(DEV)
+    ref = torch.relu((a.double() @ b.double()) * rs.double().unsqueeze(1) + add.double() + bias.double())
+    out = gemm.mm_nn(a, b, rowscale=rs, addend=add, bias=bias, relu=True)
+    torch.testing.assert_close(out.double(), ref, atol=2e-5 * K ** 0.5, rtol=2e-5)
+    assert torch.equal(out, gemm.mm_nn(a, b, rowscale=rs, addend=add, bias=bias, relu=True))      # fixed summation order
+    # same entry point without the workspace: one block per tile walks the whole K range
+    one = torch.empty_like(out)
+    _lib.check(lib.cb_gemm_nn_f32(_lib.ptr(a), a.stride(0), _lib.ptr(b), N, _lib.ptr(one), N, M, N, K, _lib.ptr(rs), _lib.ptr(add), N,
+                                  _lib.ptr(bias), 1, None, 0, _lib.stream_ptr()), 'cb_gemm_nn_f32')
+    torch.testing.assert_close(out, one, atol=2e-5 * K ** 0.5, rtol=2e-5)
+    assert lib.cb_gemm_nn_splitk_workspace_bytes(100000, N, K) == 0 and lib.cb_gemm_nn_splitk_workspace_bytes(M, N, 256) == 0
+
+
 def test_gemm_nn_asymmetric_identity_and_strides():
     """A = I against an asymmetric B catches a transposed C write; strided (non-16B) operands take the generic path."""
     from gnn_tail_generalization_amd import gemm
@@ -320,8 +343,8 @@ for M, K, N in [(4096, 256, 256), (5000, 128, 256), (3001, 40, 256), (2500, 100,
     scale = float((a.double().abs().cpu() @ b.double().abs().cpu()).max()) + 10
     err = float((got - ref).abs().max())
     assert err <= 3e-6 * scale, (M, K, N, err, scale)
-y, yd = gemm.mm_nn_drop2(torch.randn(9000, 128, device=dev), torch.randn(128, 256, device=dev), 0.3, 4242, row0=17, bias=None, relu=True)
-keep = ops.dropout_keep_mask((9000, 256), 0.3, 4242, dev, offset=17 * 256)
+y, yd = gemm.mm_nn_drop2(torch.randn(40000, 128, device=dev), torch.randn(128, 256, device=dev), 0.3, 4242, row0=17, bias=None, relu=True)
+keep = ops.dropout_keep_mask((40000, 256), 0.3, 4242, dev, offset=17 * 256)
 torch.testing.assert_close(yd, torch.where(keep, y / 0.7, torch.zeros_like(y)), atol=1e-6, rtol=1e-6)
 print('PRESPLIT_OK')
 ''' % root
@@ -330,7 +353,24 @@ print('PRESPLIT_OK')
     assert 'PRESPLIT_OK' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-@pytest.mark.parametrize('M,K,p', [(5000, 256, 0.3), (1031, 40, 0.0), (70001, 256, 0.1), (300, 128, 0.5)])
+@pytest.mark.parametrize('M,K,p', [(40001, 128, 0.3), (33000, 1000, 0.0), (5000, 128, 0.5)])
+def test_gemm_dropout_copy_epilogue_matches_two_kernels(M, K, p):
+    """cb_gemm_nn_drop2_f32: y = relu(a @ b + bias) and dropout_p(y) from one epilogue (>= 256 wide tiles: the dual-output kernel;
+    below that the entry point itself runs the two kernels) == cb_gemm_nn_f32 followed by cb_dropout_f32 with the same seed / offset."""
+    from gnn_tail_generalization_amd import gemm, ops
+    torch.manual_seed(M)
+    a, b, bias = torch.randn(M, K, device=DEV), torch.randn(K, 256, device=DEV), torch.randn(256, device=DEV)
+    y, yd = gemm.mm_nn_drop2(a, b, p, 777, row0=31, bias=bias, relu=True)
+    y_ref = gemm.mm_nn(a, b, bias=bias, relu=True)
+    assert torch.equal(y, y_ref)
+    if p > 0:
+        keep = ops.dropout_keep_mask((M, 256), p, 777, DEV, offset=31 * 256)
+        torch.testing.assert_close(yd, torch.where(keep, y / (1 - p), torch.zeros_like(y)), atol=1e-6, rtol=1e-6)
+    else:
+        assert torch.equal(yd, y)
+
+
+@pytest.mark.parametrize('M,K,p', [(5000, 256, 0.3), (1031, 40, 0.0), (70001, 256, 0.1), (300, 128, 0.5), (32768, 256, 0.2)])
 def test_gemm_trunk_backward_epilogue_matches_two_kernels(M, K, p):
     """cb_gemm_nn_trunkbwd_f32 (dX GEMM + the layer-below's trunk backward in one epilogue) == cb_gemm_nn_f32 followed by
     cb_trunk_layer_bwd_f32: same G bit for bit, same GR (the Philox keep-mask and the ReLU bits index the same elements), bias
