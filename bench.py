@@ -46,14 +46,16 @@ def parse():
     ap.add_argument('--pmc-traffic', type=int, default=1, help='collect roofline.traffic with two rocprofv3 --pmc passes of the aggregation (N=1 only)')
     ap.add_argument('--ref-epochs', type=int, default=2, help='epochs of the reference epoch (2 train fwd + 1 bwd + 1 eval fwd) to time; 0 = skip')
     ap.add_argument('--hip-graph', type=int, default=0, help='replay the step as one hipGraph (pays off on launch-bound small graphs)')
+    ap.add_argument('--se', default='000', help="whetherHasSE of the reference (per-layer structural embedding tables `le`): '000' or '111'")
+    ap.add_argument('--layers', type=int, default=3, help='num_layers (BASELINE config 2 = Pubmed, 2 layers)')
     ap.add_argument('--agg-dtype', default='f32', choices=['f32', 'bf16'], help='bf16 = build-extension storage of the gathered rows')
     return ap.parse_args()
 
 
-def make_args(dataset, extra=()):
+def make_args(dataset, extra=(), se='000', layers=3):
     from gnn_tail_generalization_amd.base_options import BaseOptions
-    argv = [f'--dataset={dataset}', '--train_which=TeacherGNN', '--num_layers=3', '--use_special_split=0', '--want_headtail=0',
-            '--whetherHasSE=000', '--do_deg_analyze=0'] + list(extra)
+    argv = [f'--dataset={dataset}', '--train_which=TeacherGNN', f'--num_layers={layers}', '--use_special_split=0', '--want_headtail=0',
+            f'--whetherHasSE={se}', '--do_deg_analyze=0'] + list(extra)
     with contextlib.redirect_stdout(io.StringIO()):
         return BaseOptions().get_arguments(argv)
 
@@ -301,7 +303,7 @@ def main():
         print(f'[bench] --gpus {a.gpus} but WORLD_SIZE={world}: using WORLD_SIZE', file=sys.stderr)
 
     from gnn_tail_generalization_amd import trainer_node_classification as tnc
-    args = make_args(a.dataset, [f'--manual_assign_GPU={local_rank}', f'--agg_dtype={a.agg_dtype}'])
+    args = make_args(a.dataset, [f'--manual_assign_GPU={local_rank}', f'--agg_dtype={a.agg_dtype}'], se=a.se, layers=a.layers)
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()):
         if sharded:
@@ -393,7 +395,7 @@ def main():
         'final_loss': float(loss),
         'config': {'workload': f'{a.dataset}: N={n_nodes} nodes, E={n_edges} edge_index columns ({graph_desc(a.dataset)}), '
                                f'F={args.num_feats} H={args.dim_hidden} '
-                               f'C={args.num_classes} L={L}, type_trick={args.type_trick} (residual mode), whetherHasSE=000, '
+                               f'C={args.num_classes} L={L}, type_trick={args.type_trick} (residual mode), whetherHasSE={a.se}, '
                                f'dropout={args.dropout}, Adam lr={args.lr}; step = fwd+loss+bwd+Adam, 2L={2 * L} aggregations',
                    'launch': 'one hipGraph replay per step' if use_graph else 'eager launches',
                    'gemm': ('fp32-input MFMA' if os.environ.get('CB_GEMM_PLAIN_F32') else

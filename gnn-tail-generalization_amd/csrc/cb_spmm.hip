@@ -84,6 +84,16 @@ __device__ __forceinline__ void gather_nt4(float (&v)[4], const float* __restric
   v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
 }
 
+// bf16 x4 source row chunk (8 bytes), streaming policy
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gather_nt4_bf16(float (&v)[4], const void* __restrict__ p) {
+  const u32x2_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p));
+  v[0] = __uint_as_float(t[0] << 16);
+  v[1] = __uint_as_float(t[0] & 0xFFFF0000u);
+  v[2] = __uint_as_float(t[1] << 16);
+  v[3] = __uint_as_float(t[1] & 0xFFFF0000u);
+}
+
 // Gather policy of the source-row loads (GP): 0 = default cache policy for every row; 1 = every row streaming (nt);
 // 2 = the CSR's column ids carry a "hot source" flag in bit 31 (set at graph build for the most-referenced source rows):
 // hot rows default policy, all others streaming, so that the rows that ARE re-used keep L2 / Infinity Cache to themselves.
@@ -194,14 +204,16 @@ __device__ __forceinline__ void write_row(float* __restrict__ out_row, const flo
 // wave-uniform `craw` = column id as stored (GP == 2: bit 31 = hot flag)
 template <int VEC, typename HT, int GP>
 __device__ __forceinline__ void gather_pol(float (&v)[VEC], const HT* __restrict__ h_lane, int64_t ld_h, int craw) {
-  if constexpr (GP == 0 || VEC != 4 || sizeof(HT) != 4) {
+  if constexpr (GP == 0 || VEC != 4) {
     gather_in<VEC, HT>(v, h_lane + (int64_t)craw * ld_h);
   } else if constexpr (GP == 1) {
-    gather_nt4(v, reinterpret_cast<const float*>(h_lane) + (int64_t)craw * ld_h);
+    if constexpr (sizeof(HT) == 4) gather_nt4(v, reinterpret_cast<const float*>(h_lane) + (int64_t)craw * ld_h);
+    else gather_nt4_bf16(v, h_lane + (int64_t)craw * ld_h);
   } else {
-    const float* p = reinterpret_cast<const float*>(h_lane) + (int64_t)(craw & kColMask) * ld_h;
-    if (craw < 0) gather_in<VEC, HT>(v, reinterpret_cast<const HT*>(p));
-    else gather_nt4(v, p);
+    const HT* p = h_lane + (int64_t)(craw & kColMask) * ld_h;
+    if (craw < 0) gather_in<VEC, HT>(v, p);
+    else if constexpr (sizeof(HT) == 4) gather_nt4(v, reinterpret_cast<const float*>(p));
+    else gather_nt4_bf16(v, p);
   }
 }
 
@@ -472,9 +484,9 @@ static int launch_spmm_cfg(const int32_t* rowptr, const int32_t* col, int64_t N,
                      ld_h, out, ld_out, (int)N, (int)d, ep, hub_T, fe)
 #define CB_ROWS_LAUNCH(FULL_, FUSED_, ACC_) CB_ROWS_LAUNCH_GP(FULL_, FUSED_, ACC_, 0)
     const bool acc = ep.acc_init != nullptr;
-    constexpr bool kGP = VEC == 4 && sizeof(HT) == 4 && RPW == 16 && U == 8;   // gather-policy variants: fp32 d % 256 == 0 kernels only
+    constexpr bool kGP = VEC == 4 && RPW == 16 && U == 8;   // gather-policy variants: the d % 256 == 0 kernels (fp32 and bf16-stored rows)
     const int gp = kGP && d % tile == 0 ? (acc ? (ep.col_flags ? 2 : 0) : gather_policy(ep.col_flags)) : 0;
-    CB_CHECK_ARG(!ep.col_flags || gp == 2, CB_E_INVALID, "flagged column ids are only understood by the fp32 d %% 256 == 0 kernels");
+    CB_CHECK_ARG(!ep.col_flags || gp == 2, CB_E_INVALID, "flagged column ids are only understood by the d %% 256 == 0 kernels");
     if constexpr (FUSED) {
       if (acc) { if constexpr (kGP) { if (gp == 2) CB_ROWS_LAUNCH_GP(true, true, true, 2); else CB_ROWS_LAUNCH(true, true, true); } else CB_ROWS_LAUNCH(true, true, true); }
       else if constexpr (kGP) { if (gp == 1) CB_ROWS_LAUNCH_GP(true, true, false, 1); else if (gp == 2) CB_ROWS_LAUNCH_GP(true, true, false, 2); else CB_ROWS_LAUNCH(true, true, false); }
@@ -493,7 +505,7 @@ static int launch_spmm_cfg(const int32_t* rowptr, const int32_t* col, int64_t N,
   if (n_hubs > 0) {
     const int64_t ld_p = partial_ld(d);
     dim3 grid((unsigned)((n_chunks + waves_per_block - 1) / waves_per_block), ny);
-    constexpr bool kGPh = VEC == 4 && sizeof(HT) == 4 && RPW == 16 && U == 8;
+    constexpr bool kGPh = VEC == 4 && RPW == 16 && U == 8;
     const int gph = kGPh && d % tile == 0 ? gather_policy(ep.col_flags) : 0;
 #define CB_HUB_LAUNCH(GP_)                                                                                                       \
   hipLaunchKernelGGL((k_spmm_hub_chunks<VEC, 8, HT, GP_>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h, (int)d, \
@@ -632,7 +644,6 @@ static int spmm_fused_impl(int h_bf16, const float* acc_init, int64_t ld_init, i
                CB_E_WORKSPACE, "cb_spmm_csr_fused_f32: hub plan given but workspace missing/too small");
   if (n_hubs == 0) hub_T = INT32_MAX;
   Epilogue ep{row_scale, bias, 1, acc_init, ld_init, col_flags};
-  CB_CHECK_ARG(!col_flags || !h_bf16, CB_E_INVALID, "cb_spmm_csr_fused_f32: flagged column ids: fp32 rows only");
   FusedEpi fe{};
   fe.mix_src = mix_src; fe.ld_mix = ld_mix; fe.c_act = c_act; fe.c_mix = c_mix;
   fe.thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
@@ -676,17 +687,17 @@ extern "C" int cb_spmm_csr_fused_acc_f32(const float* acc_init, int64_t ld_init,
   return spmm_fused_impl(0, acc_init, ld_init, col_flags, CB_FUSED_ARGS);
 }
 
-extern "C" int cb_spmm_csr_fused_bf16_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const uint16_t* h,
+extern "C" int cb_spmm_csr_fused_bf16_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const uint16_t* h,
                                           int64_t ld_h, int64_t d, const float* row_scale, const float* bias, const float* mix_src,
                                           int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed,
                                           const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
                                           int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
                                           const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
-  return spmm_fused_impl(1, nullptr, 0, 0, CB_FUSED_ARGS);
+  return spmm_fused_impl(1, nullptr, 0, col_flags, CB_FUSED_ARGS);
 }
 
 // bf16-stored source rows, fp32 accumulation and output (build extension: BASELINE config 2)
-extern "C" int cb_spmm_csr_bf16_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const uint16_t* h, int64_t ld_h,
+extern "C" int cb_spmm_csr_bf16_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const uint16_t* h, int64_t ld_h,
                                     int64_t d, const float* row_scale, const float* bias, int relu, float* out, int64_t ld_out,
                                     int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
                                     const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
@@ -698,11 +709,12 @@ extern "C" int cb_spmm_csr_bf16_f32(const int32_t* rowptr, const int32_t* col, i
   CB_CHECK_ARG(hub_T > 0 && n_hubs >= 0 && n_chunks >= 0, CB_E_INVALID, "cb_spmm_csr_bf16_f32: bad hub plan");
   CB_CHECK_ARG(n_hubs == 0 || (hub_rows && hub_chunk_ptr && ws && ws_bytes >= cb_spmm_workspace_bytes(n_chunks, d)),
                CB_E_WORKSPACE, "cb_spmm_csr_bf16_f32: hub plan given but workspace missing/too small");
-  Epilogue ep{row_scale, bias, relu, nullptr, 0, 0};
+  const bool al8 = ((uintptr_t)h % 8 == 0) && ((uintptr_t)out % 16 == 0) && (ld_h % 4 == 0) && (ld_out % 4 == 0) && (d % 4 == 0);
+  CB_CHECK_ARG(!col_flags || (al8 && d % 256 == 0), CB_E_INVALID, "cb_spmm_csr_bf16_f32: flagged column ids need d %% 256 == 0 and 8-byte aligned rows");
+  Epilogue ep{row_scale, bias, relu, nullptr, 0, col_flags};
   hipStream_t st = (hipStream_t)stream;
   if (n_hubs == 0) hub_T = INT32_MAX;
   const bf16_t* hb = (const bf16_t*)h;
-  const bool al8 = ((uintptr_t)h % 8 == 0) && ((uintptr_t)out % 16 == 0) && (ld_h % 4 == 0) && (ld_out % 4 == 0) && (d % 4 == 0);
   const bool al4 = ((uintptr_t)h % 4 == 0) && ((uintptr_t)out % 8 == 0) && (ld_h % 2 == 0) && (ld_out % 2 == 0) && (d % 2 == 0);
   float* partial = (float*)ws;
   if (al8 && d >= 256)

@@ -202,7 +202,7 @@ class CSRGraph:
             out = torch.empty((self.N, d), dtype=torch.float32, device=h.device)
         rowptr, col, plan = (self.rowptr_t, self.col_t, self._plan_t) if transpose else (self.rowptr, self.col, self._plan)
         col_k = self.col_t_k if transpose else self.col_k
-        flags = int(col_k is not None and not bf16 and d % 256 == 0 and h.data_ptr() % 16 == 0
+        flags = int(col_k is not None and d % 256 == 0 and h.data_ptr() % 16 == 0
                     and out.data_ptr() % 16 == 0 and h.stride(0) % 4 == 0 and out.stride(0) % 4 == 0)
         if flags:
             col = col_k
@@ -226,7 +226,7 @@ class CSRGraph:
                                                    _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
                            'cb_spmm_csr_acc_f32')
             else:
-                _lib.check(fn(_lib.ptr(rowptr), _lib.ptr(col), *([flags] if not bf16 else []), self.N, self.E, _lib.ptr(h), ld_h, d,
+                _lib.check(fn(_lib.ptr(rowptr), _lib.ptr(col), flags, self.N, self.E, _lib.ptr(h), ld_h, d,
                               _lib.ptr(row_scale), _lib.ptr(bias), int(bool(relu)), _lib.ptr(out), ld_o,
                               self.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows),
                               _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),

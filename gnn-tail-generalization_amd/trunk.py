@@ -60,8 +60,8 @@ def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     bf16 = z.dtype == torch.bfloat16
-    col_k = getattr(g, 'col_k', None) if not bf16 else None
-    head = (_lib.ptr(g.rowptr), _lib.ptr(col_k if col_k is not None else g.col)) + ((int(col_k is not None),) if not bf16 else ())
+    col_k = getattr(g, 'col_k', None)
+    head = (_lib.ptr(g.rowptr), _lib.ptr(col_k if col_k is not None else g.col), int(col_k is not None))
     args = head + (n, g.E, _lib.ptr(z), z.stride(0), d, _lib.ptr(graph.norm_in), _lib.ptr(bias),
             _lib.ptr(x0), x0.stride(0) if x0 is not None else 0, float(c_act), float(c_mix), float(p), ctypes.c_uint64(seed),
             ops.seed_dev_ptr(), int(getattr(graph, 'row_offset', 0)), _lib.ptr(bits), _lib.ptr(act), d, _lib.ptr(out_next), d, g.hub_threshold,

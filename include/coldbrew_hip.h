@@ -254,11 +254,11 @@ int cb_trunk_input_bwd_multi_f32(const float* g, uint64_t seed, int32_t n_mix, c
 int cb_gemm_nn_bf16out_f32(const float* A, int64_t lda, const float* B, int64_t ldb, uint16_t* C, int64_t ldc, int64_t M, int64_t N,
                            int64_t K, const float* rowscale, const float* addend, int64_t ld_add, const float* bias, int relu,
                            void* ws, size_t ws_bytes, void* stream);
-int cb_spmm_csr_bf16_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const uint16_t* h, int64_t ld_h, int64_t d,
+int cb_spmm_csr_bf16_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const uint16_t* h, int64_t ld_h, int64_t d,
                          const float* row_scale, const float* bias, int relu, float* out, int64_t ld_out, int32_t hub_threshold,
                          int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,
                          size_t ws_bytes, void* stream);
-int cb_spmm_csr_fused_bf16_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const uint16_t* h, int64_t ld_h,
+int cb_spmm_csr_fused_bf16_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const uint16_t* h, int64_t ld_h,
                                int64_t d, const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix,
                                float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0,
                                uint64_t* relu_bits, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,

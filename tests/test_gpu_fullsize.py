@@ -50,6 +50,29 @@ def _max_abs_diff_inplace(a, b):
     return float(a.max())
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_hot_source_flags_change_no_bit_full_size(pl10m_graph, dtype):
+    """The hot / cold gather policy (flagged column ids, bit 31) is a cache policy only: plain and fused aggregation at N = 10^7,
+    d = 256 are bit-identical with the flagged ids and with the plain ids — fp32 rows and bf16-stored rows."""
+    from gnn_tail_generalization_amd import trunk
+    G = pl10m_graph
+    assert G.col_k is not None and bool((G.col_k < 0).any()) and torch.equal(G.col_k & 0x7fffffff, G.col)
+    n, d = G.N, 256
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    z = torch.randn(n, d, device=DEV, generator=gen).to(dtype)
+    bias = torch.randn(d, device=DEV, generator=gen)
+    flagged = G.spmm(z, row_scale=G.norm_in, bias=bias, relu=True)
+    bits_f, nxt_f, _ = trunk._fused_spmm(G, z, bias, None, 1.0, 0.0, 0.1, 99)
+    keep = (G.col_k, G.col_t_k)
+    G.col_k = G.col_t_k = None
+    try:
+        plain = G.spmm(z, row_scale=G.norm_in, bias=bias, relu=True)
+        bits_p, nxt_p, _ = trunk._fused_spmm(G, z, bias, None, 1.0, 0.0, 0.1, 99)
+    finally:
+        G.col_k, G.col_t_k = keep
+    assert torch.equal(flagged, plain) and torch.equal(bits_f, bits_p) and torch.equal(nxt_f, nxt_p)
+
+
 def test_fused_aggregation_store_full_size(pl10m_graph):
     """cb_spmm_csr_fused_f32 at N = 10^7, d = 256, dropout on == plain aggregation + relu + mix + keep-mask."""
     from gnn_tail_generalization_amd import ops, trunk
