@@ -204,6 +204,7 @@ class GCNConv(nn.Module):
             raise NotImplementedError("only norm='both' is reachable from TricksComb")
         w = self._pick_weight(weight)
         h, se_reg = ops.transform(feat, graph.norm_out, w, self.le if self.whetherHasSE else None, graph)   # :213,225,230-236
+        self.se_norm = None if se_reg is None else se_reg.detach()      # last ||le||_F (ops.fold_se_reg)
         rst = ops.aggregate(graph, h, row_scale=graph.norm_in, bias=self.bias, relu=_fused_relu)            # :238,250,253
         return (rst if self._activation is None else self._activation(rst)), se_reg
 

@@ -40,7 +40,7 @@ SIGNATURES = {
     'cb_nll_logsoftmax_f32': (ctypes.c_int, [_P, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _P, _SZ, _P]),
     'cb_adam_step_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_float, ctypes.c_float, _I64, _P, _P]),
-    'cb_adam_multi_f32': (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+    'cb_adam_multi_f32': (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                          ctypes.c_float, _I64, _P, _P]),
     'cb_gemm_nn_workspace_bytes': (_SZ, [_I64, _I64]),
     'cb_gemm_nn_splitk_workspace_bytes': (_SZ, [_I64, _I64, _I64]),

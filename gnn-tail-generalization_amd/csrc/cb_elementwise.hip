@@ -476,6 +476,7 @@ struct AdamTable {
   float* m[kAdamMax];
   float* v[kAdamMax];
   int64_t n[kAdamMax];
+  const float* c[kAdamMax];   // per-tensor extra L2 coefficient read from device memory (null: none), added to weight_decay
 };
 
 __global__ void __launch_bounds__(kBlock) k_adam_multi(AdamTable t, float lr, float b1, float b2, float eps, float wd, float bc1,
@@ -492,6 +493,10 @@ __global__ void __launch_bounds__(kBlock) k_adam_multi(AdamTable t, float lr, fl
     bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, s));
   }
   const float step = lr / bc1;
+  if (t.c[ti]) {
+    const float c = *t.c[ti];
+    if (isfinite(c)) wd += c;    // se_reg / ||le|| with ||le|| == 0: no regulariser gradient (torch.norm's subgradient at 0)
+  }
   const bool vec_ok = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) == 0;
   const int64_t nq = (n + 3) / 4;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
@@ -635,8 +640,8 @@ extern "C" int cb_adam_step_f32(float* p, const float* g, float* m, float* v, in
 }
 
 extern "C" int cb_adam_multi_f32(int32_t n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
-                                 const int64_t* numel, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                                 const int64_t* step_dev, void* stream) {
+                                 const int64_t* numel, const float* const* extra_decay, float lr, float beta1, float beta2, float eps,
+                                 float weight_decay, int64_t step, const int64_t* step_dev, void* stream) {
   CB_CHECK_ARG(n_tensors >= 0 && (step >= 1 || step_dev) && (n_tensors == 0 || (p && g && m && v && numel)), CB_E_INVALID,
                "cb_adam_multi_f32: bad argument");
   if (step < 1) step = 1;
@@ -650,6 +655,7 @@ extern "C" int cb_adam_multi_f32(int32_t n_tensors, float* const* p, const float
       CB_CHECK_ARG(numel[base + i] >= 0 && (numel[base + i] == 0 || (p[base + i] && g[base + i] && m[base + i] && v[base + i])), CB_E_INVALID,
                    "cb_adam_multi_f32: null tensor %d", base + i);
       t.p[i] = p[base + i]; t.g[i] = g[base + i]; t.m[i] = m[base + i]; t.v[i] = v[base + i]; t.n[i] = numel[base + i];
+      t.c[i] = extra_decay ? extra_decay[base + i] : nullptr;
       if (t.n[i] > nmax) nmax = t.n[i];
     }
     if (nmax == 0) continue;

@@ -522,7 +522,9 @@ class ShardedTrainer:
             # local numerator / global count; the global loss is the sum over ranks
             loss = ops.nll_logsoftmax(out, self.y, self.train_mask, self.n_train)
             if m.se_reg_all is not None:
-                loss = loss + self.args.se_reg * m.se_reg_all / self.world   # se_reg_all is already global; count it once
+                folded = ops.fold_se_reg(m, self.optimizer, self.args.se_reg, m.se_reg_all)
+                # se_reg_all is already global; count it once
+                loss = loss + (folded if folded is not None else self.args.se_reg * m.se_reg_all) / self.world
             self.optimizer.zero_grad()
             loss.backward()
         allreduce_grads(self.replicated, self.group)

@@ -174,6 +174,31 @@ def frobenius_norm(x):
     return _FrobeniusFn.apply(x)
 
 
+def fold_se_reg(model, optimizer, coef, se_reg_all):
+    """The regulariser term `coef * sum_l ||le_l||_F` of the training loss (trainer_node_classification.py:393) WITHOUT its autograd
+    path: returns the detached value to add to the loss and hands `coef / ||le_l||` to the fused Adam (optim.Adam.extra_decay_buffer),
+    whose kernel then adds `coef * le / ||le||` — the term's gradient — to the data gradient it reads anyway (a non-finite
+    coefficient, i.e. an all-zero table, counts as 0: the subgradient torch.norm's backward picks).  Mathematically the update of
+    `loss.backward()` through `th.norm` (GCN.py:232); what is saved per table and step is the `le / ||le||` tensor (8 B/element)
+    and autograd's accumulation of it into le.grad (12 B/element).  One extra launch per table.  None if the model has no SE layer
+    or the optimiser is not the fused Adam (the caller then keeps the autograd path).  CB_SE_REG_FOLD=0 switches it off."""
+    import os
+    from . import optim
+    if not isinstance(optimizer, optim.Adam) or os.environ.get('CB_SE_REG_FOLD', '1') == '0':
+        return None
+    convs = [m for m in model.modules() if getattr(m, 'whetherHasSE', False) and getattr(m, 'se_norm', None) is not None]
+    if not convs or any(c.le.grad_fn is not None or not c.le.requires_grad for c in convs):
+        return None
+    for conv in convs:
+        buf = optimizer.extra_decay_buffer(conv.le)
+        c0 = getattr(conv, '_se_coef', None)
+        if c0 is None or float(conv._se_coef_val) != float(coef) or c0.device != buf.device:
+            c0 = conv._se_coef = torch.tensor(float(coef), dtype=torch.float32, device=buf.device)
+            conv._se_coef_val = float(coef)
+        torch.div(c0, conv.se_norm, out=buf.view(()))
+    return coef * se_reg_all.detach()
+
+
 def transform(feat, norm_out, weight, le=None, graph=None):
     """Z = (feat * a[:,None]) @ W (+ le) and se_reg = ||le||_F (GCN.py:213,225,230-236).  With a
     node-sharded graph `le` holds the local rows and the norm is taken over all ranks."""

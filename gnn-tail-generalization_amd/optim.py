@@ -12,6 +12,20 @@ class Adam(torch.optim.Optimizer):
             raise ValueError('invalid Adam hyper-parameter')
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._step_dev = None      # hipGraph mode: int64 device tensor holding the step count
+        self._extra_decay = {}     # parameter -> [1] float32 device tensor added to weight_decay for that tensor (see set_extra_decay)
+
+    def extra_decay_buffer(self, p):
+        """Persistent device scalar whose value the next step() adds to `weight_decay` for parameter `p` (the kernel reads it at
+        launch / hipGraph-replay time).  The trainer writes se_reg / ||le||_F into it every step: the structural-embedding
+        regulariser's gradient `se_reg * le / ||le||` then enters the update inside the fused Adam kernel instead of through
+        autograd (ops.fold_se_reg).  clear_extra_decay() removes every buffer."""
+        buf = self._extra_decay.get(p)
+        if buf is None:
+            buf = self._extra_decay[p] = torch.zeros(1, dtype=torch.float32, device=p.device)
+        return buf
+
+    def clear_extra_decay(self):
+        self._extra_decay.clear()
 
     def make_capturable(self, device):
         """Moves the step count to device memory so that step() can be captured in a hipGraph: the kernels read
@@ -43,7 +57,7 @@ class Adam(torch.optim.Optimizer):
         import ctypes
         for group in self.param_groups:
             b1, b2 = group['betas']
-            ps, gs, ms, vs, ns, keep, step = [], [], [], [], [], [], None
+            ps, gs, ms, vs, ns, cs, keep, step = [], [], [], [], [], [], [], None
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -59,22 +73,29 @@ class Adam(torch.optim.Optimizer):
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 if step is None:
                     step = st['step']
+                extra = self._extra_decay.get(p)
                 if st['step'] != step or p.device != group['params'][0].device:
                     # tensors that joined later (own bias correction) or live elsewhere: one launch of their own
+                    one = lambda t, ty=ctypes.c_void_p: (ty * 1)(t)       # noqa: E731
                     with torch.cuda.device(p.device):
-                        _lib.check(lib.cb_adam_step_f32(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st['exp_avg']), _lib.ptr(st['exp_avg_sq']),
-                                                        p.numel(), group['lr'], b1, b2, group['eps'], group['weight_decay'],
-                                                        st['step'], _lib.ptr(self._step_dev), _lib.stream_ptr()), 'cb_adam_step_f32')
+                        _lib.check(lib.cb_adam_multi_f32(1, one(p.data_ptr()), one(g.data_ptr()), one(st['exp_avg'].data_ptr()),
+                                                         one(st['exp_avg_sq'].data_ptr()), one(p.numel(), ctypes.c_int64),
+                                                         one(extra.data_ptr() if extra is not None else None), group['lr'], b1, b2,
+                                                         group['eps'], group['weight_decay'], st['step'], _lib.ptr(self._step_dev),
+                                                         _lib.stream_ptr()), 'cb_adam_multi_f32')
                     continue
                 ps.append(p.data_ptr()); gs.append(g.data_ptr()); ms.append(st['exp_avg'].data_ptr())
                 vs.append(st['exp_avg_sq'].data_ptr()); ns.append(p.numel())
+                cs.append(extra.data_ptr() if extra is not None else None)
                 keep.append(g)                               # contiguous copies stay alive until the launch below
             if ps:
                 n = len(ps)
                 arr = lambda vals, ty: (ty * n)(*vals)       # noqa: E731
                 with torch.cuda.device(group['params'][0].device):
                     _lib.check(lib.cb_adam_multi_f32(n, arr(ps, ctypes.c_void_p), arr(gs, ctypes.c_void_p), arr(ms, ctypes.c_void_p),
-                                                     arr(vs, ctypes.c_void_p), arr(ns, ctypes.c_int64), group['lr'], b1, b2, group['eps'],
+                                                     arr(vs, ctypes.c_void_p), arr(ns, ctypes.c_int64),
+                                                     arr(cs, ctypes.c_void_p) if any(c is not None for c in cs) else None,
+                                                     group['lr'], b1, b2, group['eps'],
                                                      group['weight_decay'], step, _lib.ptr(self._step_dev), _lib.stream_ptr()),
                                'cb_adam_multi_f32')
                 del keep

@@ -274,6 +274,7 @@ def forward(tc, x, graph):
             if hasattr(graph, 'part'):
                 from .dist import allreduce_sum
                 reg = allreduce_sum(reg * reg, graph.group).sqrt()
+            conv.se_norm = reg.detach()
             se_reg_all = reg if se_reg_all is None else se_reg_all + reg
     if not all(c._allow_zero_in_degree for c in tc.layers_GCN):      # GCN.py:187-197; set_allow_zero_in_degree(True) lifts it
         graph.check_zero_in_degree()

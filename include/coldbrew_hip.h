@@ -143,10 +143,14 @@ int cb_nll_logsoftmax_f32(const float* logits, int64_t ld, const int64_t* y, con
 int cb_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int64_t step, const int64_t* step_dev, void* stream);
 /* The same update for n_tensors parameter tensors in ONE launch (host arrays of device pointers; the table travels in the
- * kernel arguments, 24 tensors per launch).  Identical arithmetic to cb_adam_step_f32. */
+ * kernel arguments, 24 tensors per launch).  Identical arithmetic to cb_adam_step_f32.
+ * extra_decay (may be NULL, entries may be NULL): per tensor, a device float added to weight_decay for that tensor.  With
+ * extra_decay[i] = se_reg / ||le_i||_F the update of a structural-embedding table includes the gradient of the regulariser
+ * `se_reg * ||le||_F` (GCN.py:232,236; trainer_node_classification.py:393) without materialising `le / ||le||` and without the
+ * autograd accumulation into le.grad: 50 bytes / element less HBM traffic per table per step. */
 int cb_adam_multi_f32(int32_t n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* numel,
-                      float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, const int64_t* step_dev,
-                      void* stream);
+                      const float* const* extra_decay, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                      const int64_t* step_dev, void* stream);
 /* step_dev (may be NULL): the step count read from device memory instead of `step` (hipGraph replay). */
 
 /* ------------------------------------------------------------------------------------

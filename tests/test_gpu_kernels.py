@@ -191,6 +191,32 @@ def test_fused_adam_matches_oracle_and_torch():
         torch.testing.assert_close(m.detach().cpu(), orc_p[str(i)], rtol=1e-5, atol=1e-6)
 
 
+def test_fused_adam_extra_decay_is_the_frobenius_regulariser_gradient():
+    """optim.Adam.extra_decay_buffer(p) <- c / ||p||_F : the fused update equals torch.optim.Adam on the gradient g + c * p / ||p||_F
+    (what autograd produces for the loss term c * th.norm(p), GCN.py:232 / trainer_node_classification.py:393); tensors without a
+    buffer are untouched by it."""
+    from gnn_tail_generalization_amd.optim import Adam
+    shapes = [(300, 64), (77,), (1000, 256)]
+    ps = [_rand(*s, seed=40 + i) for i, s in enumerate(shapes)]
+    mine = [p.clone().to(DEV).requires_grad_(True) for p in ps]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    opt_m = Adam(mine, lr=0.01, weight_decay=5e-4)
+    opt_r = torch.optim.Adam(ref, lr=0.01, weight_decay=5e-4)
+    c = 0.3
+    for step in range(1, 5):
+        grads = [_rand(*s, seed=900 * step + i) for i, s in enumerate(shapes)]
+        for i, (p, g) in enumerate(zip(mine, grads)):
+            p.grad = g.to(DEV)
+            if i != 1:
+                opt_m.extra_decay_buffer(p).fill_(c / float(p.detach().norm()))
+        for i, (p, g) in enumerate(zip(ref, grads)):
+            p.grad = g.clone() if i == 1 else g + c * p.detach() / p.detach().norm()
+        opt_m.step()
+        opt_r.step()
+    for m, r in zip(mine, ref):
+        torch.testing.assert_close(m.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-6)
+
+
 def test_gather_rows_by_index():
     from gnn_tail_generalization_amd import ops
     for shape in [(100, 256), (57, 40), (9, 7)]:
