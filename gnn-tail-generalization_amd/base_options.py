@@ -134,6 +134,7 @@ def build_parser():
     a('--graph_dropout', type=float, default=0.2)
     a('--layerwise_dropout', action='store_true', default=False)
     a('--ckpt_every', type=int, default=0)   # build extension: write the resumable checkpoint every k epochs (0 = only at the end)
+    a('--hip_graph', type=int, default=0)    # build extension: 1 = the epoch loop replays the training step (and the eval forward) as hipGraphs
     a('--agg_dtype', type=str, default='f32', choices=['f32', 'bf16'])   # build extension: storage type of the aggregated rows
     # link-prediction (I2-GTL) flags: accepted for CLI compatibility, unused by this path
     a('--public_data_convert_overlapped_subgraph', type=bool, default=True)

@@ -99,6 +99,44 @@ def test_cli_end_to_end_tiny():
     assert len(recs) == 1 and recs[0].shape == (4, 3) and np.isfinite(recs[0]).all()
 
 
+@pytest.mark.parametrize('extra', [['--dataset=S-tiny', '--want_headtail=1', '--use_special_split=1', '--whetherHasSE=111', '--se_reg=0.5'],
+                                   ['--dataset=S-pubmed', '--want_headtail=0', '--use_special_split=0', '--do_deg_analyze=0']])
+def test_epoch_loop_replayed_as_hip_graphs_matches_eager(extra):
+    """--hip_graph=1: run_trainSet's step and run_testSet's eval forward replayed as hipGraphs give the records of the eager epoch
+    loop (dropout 0 so that both draw the same data gradients): test accuracy and head/tail/isolation rows, final weights."""
+    import contextlib
+    import io
+    import os
+    import tempfile
+    from gnn_tail_generalization_amd import ops
+    from gnn_tail_generalization_amd.base_options import BaseOptions
+    from gnn_tail_generalization_amd.trainer_node_classification import trainer
+    cwd = os.getcwd()
+    recs, sds = [], []
+    try:
+        for hg in (0, 1):
+            os.chdir(tempfile.mkdtemp())
+            with contextlib.redirect_stdout(io.StringIO()):
+                args = BaseOptions().get_arguments(extra + ['--epochs=6', '--manual_assign_GPU=0', f'--hip_graph={hg}'])
+                args.random_seed = 0
+                torch.manual_seed(0)
+                np.random.seed(0)
+                t = trainer(args, 0)
+                t.args.dropout = 0.0
+                torch.manual_seed(0)
+                recs.append(t.main())
+            assert (getattr(t, '_hip_graph', None) is not None) == bool(hg) and (getattr(t, '_eval_graph', None) is not None) == bool(hg)
+            sds.append({k: v.detach().clone() for k, v in t.teacherGNN.state_dict().items()})
+            ops.set_graph_seed(None)
+    finally:
+        os.chdir(cwd)
+    assert recs[0].shape == recs[1].shape and np.isfinite(recs[1]).all()
+    np.testing.assert_allclose(recs[1], recs[0], atol=1e-3)
+    for k, v in sds[0].items():
+        if v.dtype.is_floating_point:
+            torch.testing.assert_close(sds[1][k], v, atol=1e-5, rtol=1e-4, msg=lambda m, k=k: f'{k}: {m}')
+
+
 def test_sharded_trainer_world1_matches_plain_trainer():
     """The node-sharded code path (rectangular row-slice CSR, all-gather exchange, grad all-reduce) on one
     rank reproduces the plain trainer's losses on the same seeded data."""
