@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--ref-epochs', type=int, default=2, help='epochs of the reference epoch (2 train fwd + 1 bwd + 1 eval fwd) to time; 0 = skip')
     ap.add_argument('--hip-graph', type=int, default=0, help='replay the step as one hipGraph (pays off on launch-bound small graphs)')
     ap.add_argument('--se', default='000', help="whetherHasSE of the reference (per-layer structural embedding tables `le`): '000' or '111'")
+    ap.add_argument('--extra', default='', help='further reference CLI flags, space separated (e.g. "--force_set_to_best_config=0 --type_trick=Residual")')
     ap.add_argument('--layers', type=int, default=3, help='num_layers (BASELINE config 2 = Pubmed, 2 layers)')
     ap.add_argument('--agg-dtype', default='f32', choices=['f32', 'bf16'], help='bf16 = build-extension storage of the gathered rows')
     return ap.parse_args()
@@ -303,7 +304,7 @@ def main():
         print(f'[bench] --gpus {a.gpus} but WORLD_SIZE={world}: using WORLD_SIZE', file=sys.stderr)
 
     from gnn_tail_generalization_amd import trainer_node_classification as tnc
-    args = make_args(a.dataset, [f'--manual_assign_GPU={local_rank}', f'--agg_dtype={a.agg_dtype}'], se=a.se, layers=a.layers)
+    args = make_args(a.dataset, [f'--manual_assign_GPU={local_rank}', f'--agg_dtype={a.agg_dtype}'] + a.extra.split(), se=a.se, layers=a.layers)
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()):
         if sharded:

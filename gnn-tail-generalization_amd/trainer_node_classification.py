@@ -324,7 +324,9 @@ class trainer:
             if getattr(self, '_ht_key', None) != key:
                 self._ht_key, self._ht_sets = key, []
                 for name in names:
-                    idx = torch.as_tensor(np.asarray(getattr(self.data, name)), dtype=torch.long, device=all_node_logits.device).reshape(-1)
+                    idx = getattr(self.data, name)           # numpy (host analysis) or a device tensor (utils' device kernels)
+                    idx = idx if torch.is_tensor(idx) else torch.as_tensor(np.asarray(idx))
+                    idx = idx.to(device=all_node_logits.device, dtype=torch.long).reshape(-1)
                     on_test = idx[~self.data.train_mask[idx]]                     # eval_headtail__traintest_v2: the test part is what is kept
                     self._ht_sets.append((on_test, self.data.y[on_test]))
             pred = torch.max(all_node_logits.detach(), dim=1)[1]

@@ -43,6 +43,15 @@ def test_trainer_trajectory(name):
     for k, v in g['sd_final'].items():
         if v.dtype.is_floating_point:
             torch.testing.assert_close(model.state_dict()[k].cpu(), v, atol=2e-5, rtol=2e-4, msg=lambda m, k=k: f'{k}: {m}')
+    if g['want_headtail']:
+        # the metric groups may arrive as numpy arrays (host analysis) or as device tensors (utils' device kernels, bench.py)
+        model.eval()
+        t._headtail_metrics()
+        host = np.array(t.bag['head_tail_iso'], dtype=np.float64)
+        for k in ['zero_deg_idx', 'small_deg_idx', 'large_deg_idx']:
+            setattr(data, k, torch.as_tensor(getattr(data, k), device=DEV))
+        t._headtail_metrics()
+        np.testing.assert_array_equal(np.array(t.bag['head_tail_iso'], dtype=np.float64), host)
 
 
 @pytest.mark.parametrize('name', [n for n in golden_cases('trainer_') if 'se000' not in n])
