@@ -20,7 +20,8 @@ ids.  The row block is split by column owner into an INTERIOR CSR (columns = loc
     wait -> halo pass: starts from the interior sums, applies the epilogue once (cb_spmm_csr_acc_f32)
 
 COLDBREW_OVERLAP=0 keeps the single-pass form (one CSR over [local rows | halo rows] after a blocking
-exchange); COLDBREW_EXCHANGE=allgather the all-gather baseline (equal-row partition only).
+exchange); COLDBREW_EXCHANGE=allgather the all-gather baseline (equal-row partition only); COLDBREW_HALO_WIRE=bf16
+(opt-in, outside the 1e-4 parity) halves the bytes on the links by sending the halo rows as bfloat16.
 The backward of the aggregation is the same exchange on the gradient followed by the reverse-orientation
 passes (own plan; aliasing the forward one when the edge multiset is symmetric on every rank).  Everything
 else is row-local; small all-reduces cover the replicated weights' gradients, the loss numerator, sum(E^2)
@@ -203,6 +204,18 @@ class HaloPlan:
             raise RuntimeError('halo plan: a peer requested a row this rank does not own')
 
 
+class _WidenOnWait:
+    """Work handle of a bf16-wire exchange: wait() = the collective's wait + widening of the received rows into the fp32 buffer
+    the halo pass reads."""
+
+    def __init__(self, inner, wire_in, out):
+        self.inner, self.wire_in, self.out = inner, wire_in, out
+
+    def wait(self):
+        self.inner.wait()
+        self.out.copy_(self.wire_in)
+
+
 class _Orientation:
     """One CSR orientation of a rank's row block: the CSR(s) the local passes read and the plan that feeds them."""
     __slots__ = ('whole', 'interior', 'halo', 'plan', 'E', 'rowptr_key', 'col_key')
@@ -212,9 +225,15 @@ class ShardedGraph:
     """Row block [lo, hi) of both CSR orientations + local degree norms + the exchange plans.
     Quacks like graph.CSRGraph for GCNConv / ops.aggregate / the fused trunk."""
 
-    def __init__(self, edge_index, n_nodes, part, group=None, exchange='halo', overlap=True, compute=None):
+    def __init__(self, edge_index, n_nodes, part, group=None, exchange='halo', overlap=True, compute=None, wire='f32'):
         self.part, self.group = part, group
         self.exchange_kind = exchange
+        if wire not in ('f32', 'bf16'):
+            raise ValueError(f'unknown halo wire format {wire!r}')
+        # 'bf16' (opt-in, COLDBREW_HALO_WIRE=bf16): halo rows travel rounded to bfloat16 (RNE) and are widened on arrival — half the
+        # bytes on the xGMI links, the bound of the sharded step; the local rows stay fp32.  NOT within the 1e-4 logits parity
+        # (2^-9 relative rounding of every remote neighbour row), hence never the default.
+        self.wire = wire if exchange == 'halo' else 'f32'
         self.compute = compute if compute is not None else HipCompute()
         self.N_global, self.E_global = int(n_nodes), int(edge_index.shape[1])
         self.row_offset = part.lo()
@@ -302,6 +321,12 @@ class ShardedGraph:
         ext = torch.empty((plan.n_local + plan.n_halo, x_local.shape[1]), dtype=x_local.dtype, device=x_local.device)
         ext[:plan.n_local] = x_local
         send = self.compute.pack_rows(x_local, plan.send_idx)
+        if self.wire == 'bf16' and x_local.dtype == torch.float32:
+            wire_in = torch.empty((plan.n_halo, x_local.shape[1]), dtype=torch.bfloat16, device=x_local.device)
+            _all_to_all_single(wire_in.view(torch.uint8), send.to(torch.bfloat16).view(torch.uint8), plan.recv_counts, plan.send_counts,
+                               group=self.group)
+            ext[plan.n_local:] = wire_in
+            return ext
         _all_to_all_single(ext[plan.n_local:], send, plan.recv_counts, plan.send_counts, group=self.group)
         return ext
 
@@ -310,6 +335,12 @@ class ShardedGraph:
         plan = (self.b if transpose else self.f).plan
         send = self.compute.pack_rows(x_local, plan.send_idx)
         recv = torch.empty((max(plan.n_halo, 1), x_local.shape[1]), dtype=x_local.dtype, device=x_local.device)
+        if self.wire == 'bf16' and x_local.dtype == torch.float32:
+            send = send.to(torch.bfloat16)
+            wire_in = torch.empty((plan.n_halo, x_local.shape[1]), dtype=torch.bfloat16, device=x_local.device)
+            inner = _all_to_all_single(wire_in.view(torch.uint8), send.view(torch.uint8), plan.recv_counts, plan.send_counts,
+                                       group=self.group, async_op=True)
+            return recv, _WidenOnWait(inner, wire_in, recv[:plan.n_halo]), send
         work = _all_to_all_single(recv[:plan.n_halo], send, plan.recv_counts, plan.send_counts, group=self.group, async_op=True)
         return recv, work, send
 
@@ -467,7 +498,8 @@ class ShardedTrainer:
             self.part = Partition(self._n, self.world, self.rank)
         self.sgraph = ShardedGraph(data.edge_index, self._n, self.part, group, exchange=exchange,
                                    overlap=os.environ.get('COLDBREW_OVERLAP', '1') != '0'
-                                   and getattr(args, 'agg_dtype', 'f32') == 'f32')
+                                   and getattr(args, 'agg_dtype', 'f32') == 'f32',
+                                   wire=os.environ.get('COLDBREW_HALO_WIRE', 'f32'))
         self.n_train = int(data.train_mask.sum().item())
         p = self.part
         self.x = p.slice_rows(data.x).float().contiguous()

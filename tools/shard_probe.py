@@ -93,12 +93,21 @@ def main():
         part_sums = g_int.spmm(h)
         t_halo = timed(lambda: g_halo.spmm(halo, row_scale=scale, bias=bias, relu=True, acc_init=part_sums)) if P > 1 else 0.0
         t_whole = timed(lambda: g_whole.spmm(ext, row_scale=scale, bias=bias, relu=True))
+        # opt-in bf16 wire (COLDBREW_HALO_WIRE=bf16): narrowing of the packed rows + widening of the received ones, half the bytes
+        if P > 1:
+            packed = comp.pack_rows(h, send_idx)
+            halo16 = halo[:max(n_halo, 1)].to(torch.bfloat16)
+            t_cvt = timed(lambda: packed.to(torch.bfloat16)) + timed(lambda: halo16.float())
+            del packed, halo16
+        else:
+            t_cvt = 0.0
         bpr = a.d * 4
         link = a.link_gbs * a.link_eff * 1e6        # bytes per ms
         t_xchg = max(max(recv_counts), max(send_counts)) * bpr / link if P > 1 else 0.0
         agg_overlap = t_pack + max(t_int, t_xchg) + t_halo if P > 1 else t_whole
         agg_single = t_pack + t_xchg + t_whole
         L2 = 2 * a.layers
+        agg_bf16 = t_pack + t_cvt + max(t_int, t_xchg / 2) + t_halo if P > 1 else t_whole
         step_overlap = a.dense_ms / P + L2 * agg_overlap
         step_single = a.dense_ms / P + L2 * agg_single
         row = {'P': P, 'rank': r, 'partition': a.partition, 'rows_local': n_local, 'edges_local': e_local, 'edges_interior': e_int,
@@ -107,7 +116,9 @@ def main():
                'pack_ms': t_pack, 'interior_ms': t_int, 'halo_pass_ms': t_halo, 'single_pass_ms': t_whole,
                'exchange_ms_predicted': t_xchg, 'aggregation_ms_overlapped': agg_overlap, 'aggregation_ms_single_pass': agg_single,
                'step_ms_predicted_overlapped': step_overlap, 'step_ms_predicted_single_pass': step_single,
-               'steps_per_s_predicted': 1e3 / min(step_overlap, step_single)}
+               'steps_per_s_predicted': 1e3 / min(step_overlap, step_single),
+               'wire_convert_ms': t_cvt, 'aggregation_ms_bf16_wire': agg_bf16,
+               'steps_per_s_predicted_bf16_wire': 1e3 / (a.dense_ms / P + L2 * agg_bf16)}
         rows_out.append(row)
         print(json.dumps(row), flush=True)
         del g_int, g_halo, g_whole, h, halo, ext, part_sums
@@ -122,6 +133,9 @@ def main():
               f"{w['pack_ms']:.2f} | {w['interior_ms']:.2f} | {w['exchange_ms_predicted']:.2f} | {w['halo_pass_ms']:.2f} | {w['single_pass_ms']:.2f} | "
               f"{w['aggregation_ms_overlapped']:.2f} / {w['aggregation_ms_single_pass']:.2f} | "
               f"{min(w['step_ms_predicted_overlapped'], w['step_ms_predicted_single_pass']):.1f} | {w['steps_per_s_predicted']:.2f} | {eff} |")
+    print('\nopt-in bf16 halo wire (outside the 1e-4 parity): ' + ', '.join(
+        f"P={w['P']}: {w['steps_per_s_predicted_bf16_wire']:.2f} steps/s" + (f" ({w['steps_per_s_predicted_bf16_wire'] / base / w['P']:.2f})" if base else '')
+        for w in rows_out))
     print(f'\nassumptions: {a.name} (N={n}, E={E}), d={a.d}, link {a.link_gbs} GB/s x {a.link_eff} efficiency per peer pair, '
           f'dense part {a.dense_ms} ms at P=1 scaled 1/P, {2 * a.layers} aggregations per step, rank {a.rank} of each world')
 
