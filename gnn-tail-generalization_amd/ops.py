@@ -184,10 +184,14 @@ def fold_se_reg(model, optimizer, coef, se_reg_all):
     or the optimiser is not the fused Adam (the caller then keeps the autograd path).  CB_SE_REG_FOLD=0 switches it off."""
     import os
     from . import optim
-    if not isinstance(optimizer, optim.Adam) or os.environ.get('CB_SE_REG_FOLD', '1') == '0':
+    if not isinstance(optimizer, optim.Adam):
         return None
     convs = [m for m in model.modules() if getattr(m, 'whetherHasSE', False) and getattr(m, 'se_norm', None) is not None]
-    if not convs or any(c.le.grad_fn is not None or not c.le.requires_grad for c in convs):
+    if (os.environ.get('CB_SE_REG_FOLD', '1') == '0' or not convs
+            or any(c.le.grad_fn is not None or not c.le.requires_grad for c in convs)):
+        # the caller keeps the autograd path for this step: coefficients left over from an earlier folded step must not act again
+        for buf in optimizer._extra_decay.values():
+            buf.zero_()
         return None
     for conv in convs:
         buf = optimizer.extra_decay_buffer(conv.le)

@@ -12,7 +12,7 @@ class Adam(torch.optim.Optimizer):
             raise ValueError('invalid Adam hyper-parameter')
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._step_dev = None      # hipGraph mode: int64 device tensor holding the step count
-        self._extra_decay = {}     # parameter -> [1] float32 device tensor added to weight_decay for that tensor (see set_extra_decay)
+        self._extra_decay = {}     # parameter -> [1] float32 device tensor added to weight_decay for that tensor (see extra_decay_buffer)
 
     def extra_decay_buffer(self, p):
         """Persistent device scalar whose value the next step() adds to `weight_decay` for parameter `p` (the kernel reads it at

@@ -212,7 +212,7 @@ class trainer:
         loss = ops.nll_logsoftmax(res.emb4classi_full, self.data.y, self.data.train_mask, self._n_train)
         loss = loss * self.args.TeacherGNN.lossa_semantic
         if self.teacherGNN.se_reg_all is not None:
-            folded = ops.fold_se_reg(self.teacherGNN, self.optimizer, self.args.se_reg, self.teacherGNN.se_reg_all) if self.teacherGNN.training else None
+            folded = ops.fold_se_reg(self.teacherGNN, self.optimizer, self.args.se_reg, self.teacherGNN.se_reg_all)
             # folded: the regulariser's gradient enters inside the fused Adam kernel (same update, 20 B/element of `le` less traffic)
             loss = loss + (folded if folded is not None else self.args.se_reg * self.teacherGNN.se_reg_all)
         return loss
