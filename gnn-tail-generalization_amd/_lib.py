@@ -58,6 +58,8 @@ SIGNATURES = {
     'cb_trunk_layer_bwd_f32': (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, _P, ctypes.c_int, _I64, _I64, ctypes.c_float, ctypes.c_uint64,
                                               _P, _I64, ctypes.c_float, ctypes.c_float, _P, _P, _SZ, _P]),
     'cb_gemm_nn_bf16out_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int, _P, _SZ, _P]),
+    'cb_spmm_csr_masked_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_float, _P, _I64,
+                                              _I32, _I32, _I32, _P, _P, _P, _SZ, _P]),
     'cb_spmm_csr_bf16_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_int, _P, _I64,
                                             _I32, _I32, _I32, _P, _P, _P, _SZ, _P]),
     'cb_spmm_csr_fused_bf16_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,

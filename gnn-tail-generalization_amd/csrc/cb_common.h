@@ -38,6 +38,12 @@ static inline int blocks_for(int64_t n, int per_block) { return (int)((n + per_b
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// a*x + b*y and x*s + b with ONE fixed rounding sequence wherever they occur (residual mix: cb_axpby_f32 and the fused aggregation
+// store; aggregation epilogue: plain and fused store).  Left to the compiler's contraction choice, the fused and the operator-by-
+// operator forward differ in the last bit from one build to the next and the paths stop being bit-identical to each other.
+__device__ __forceinline__ float mix2(float a, float x, float b, float y) { return __fmaf_rn(a, x, __fmul_rn(b, y)); }
+__device__ __forceinline__ float scale_add(float x, float s, float b) { return __fmaf_rn(x, s, b); }
+
 // wave-uniform broadcast helpers (values land in SGPRs)
 __device__ __forceinline__ int bcast_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int bcast_lane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }

@@ -58,10 +58,10 @@ __global__ void __launch_bounds__(kBlock) k_axpby(float a, const float* __restri
     if (vec_ok && i + 4 <= n) {
       float4 u = *reinterpret_cast<const float4*>(x + i);
       float4 w = *reinterpret_cast<const float4*>(y + i);
-      *reinterpret_cast<float4*>(out + i) = make_float4(a * u.x + b * w.x, a * u.y + b * w.y, a * u.z + b * w.z, a * u.w + b * w.w);
+      *reinterpret_cast<float4*>(out + i) = make_float4(mix2(a, u.x, b, w.x), mix2(a, u.y, b, w.y), mix2(a, u.z, b, w.z), mix2(a, u.w, b, w.w));
     } else {
       for (int k = 0; k < 4; ++k)
-        if (i + k < n) out[i + k] = a * x[i + k] + b * y[i + k];
+        if (i + k < n) out[i + k] = mix2(a, x[i + k], b, y[i + k]);
     }
   }
 }
@@ -193,6 +193,7 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
       const float sc = row_scale ? row_scale[r] : 1.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) s[k] += gy[k];
+      if (!outv) continue;        // column sums only
       if constexpr (OUT_BF16)
         *reinterpret_cast<uint2*>((bf16_t*)outv + off) = pack4_bf16(gy[0] * sc, gy[1] * sc, gy[2] * sc, gy[3] * sc);
       else
@@ -696,7 +697,7 @@ extern "C" int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits,
                                       size_t ws_bytes, void* stream) {
   CB_CHECK_ARG(rows >= 0 && d > 0 && d % 256 == 0 && d < (1 << 20), CB_E_INVALID, "cb_trunk_layer_bwd_f32: d must be a multiple of 256");
   if (rows == 0) return CB_OK;
-  CB_CHECK_ARG(g && relu_bits && out && aligned16(g) && ((uintptr_t)out % (out_bf16 ? 8 : 16) == 0) && (!gx0 || aligned16(gx0)),
+  CB_CHECK_ARG(g && relu_bits && (out || colsum) && aligned16(g) && ((uintptr_t)out % (out_bf16 ? 8 : 16) == 0) && (!gx0 || aligned16(gx0)),
                CB_E_INVALID, "cb_trunk_layer_bwd_f32: null or misaligned pointer");
   CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, CB_E_INVALID, "cb_trunk_layer_bwd_f32: dropout p out of range");
   CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_colsum_workspace_bytes(rows, d)), CB_E_WORKSPACE, "cb_trunk_layer_bwd_f32: workspace too small");

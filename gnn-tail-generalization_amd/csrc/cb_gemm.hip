@@ -386,8 +386,9 @@ extern "C" int cb_gemm_nn_trunkbwd_f32(const float* A, int64_t lda, const float*
                "cb_gemm_nn_trunkbwd_f32: bad size (N must be a multiple of 256) or p");
   CB_CHECK_ARG(N < (1 << 20) && K < (1 << 24) && (M + 63) / 64 < (1 << 24), CB_E_RANGE, "cb_gemm_nn_trunkbwd_f32: size out of range");
   if (M == 0) return CB_OK;
-  CB_CHECK_ARG(G && GR && relu_bits && (K == 0 || (A && B)) && lda >= K && ldb >= N && ldg >= N && ldgr >= N, CB_E_INVALID,
+  CB_CHECK_ARG(G && (GR || colsum) && relu_bits && (K == 0 || (A && B)) && lda >= K && ldb >= N && ldg >= N && (!GR || ldgr >= N), CB_E_INVALID,
                "cb_gemm_nn_trunkbwd_f32: null pointer or leading dimension too small");
+  if (!GR) ldgr = N;      // column sums only (the reverse aggregation applies the store backward itself: cb_spmm_csr_masked_f32)
   CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_gemm_nn_trunkbwd_workspace_bytes(M, N)), CB_E_WORKSPACE, "cb_gemm_nn_trunkbwd_f32: workspace too small");
   GemmEpilogue ep{rowscale, nullptr, 0, nullptr, 0, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, nullptr, 0.f, nullptr, nullptr, gemm_nt_store(M, N)};
   hipStream_t st = (hipStream_t)stream;
@@ -406,6 +407,7 @@ extern "C" int cb_gemm_nn_trunkbwd_f32(const float* A, int64_t lda, const float*
   int rc = cb_gemm_nn_f32(A, lda, B, ldb, G, ldg, M, N, K, rowscale, nullptr, 0, nullptr, 0, nullptr, 0, stream);
   if (rc != CB_OK) return rc;
   CB_CHECK_ARG(ldg == N && ldgr == N, CB_E_INVALID, "cb_gemm_nn_trunkbwd_f32: the two-kernel form needs contiguous outputs");
+  if (!GR && !colsum) return CB_OK;
   return cb_trunk_layer_bwd_f32(G, relu_bits, row_scale2, GR, 0, nullptr, 0, M, N, drop_p, seed, seed_dev, row0, c_act, 0.f, colsum, ws, ws_bytes,
                                 stream);
 }

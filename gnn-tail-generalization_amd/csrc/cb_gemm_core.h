@@ -281,7 +281,7 @@ __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __rest
               gy[q] = ((bw[q] >> L) & 1ull) ? ep.c_act * gm[q] : 0.f;
               cs[q] += gy[q];
             }
-            store4(ep.out2 + m * ep.ld_out2 + n, gy[0] * sc2, gy[1] * sc2, gy[2] * sc2, gy[3] * sc2, ep.nt_store);
+            if (ep.out2) store4(ep.out2 + m * ep.ld_out2 + n, gy[0] * sc2, gy[1] * sc2, gy[2] * sc2, gy[3] * sc2, ep.nt_store);
           }
         }
       }

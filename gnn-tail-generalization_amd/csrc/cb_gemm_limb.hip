@@ -199,7 +199,8 @@ static int launch_nn_l3_t(const float* A, int64_t lda, const float* B, int64_t l
     }
   }
   if constexpr (!OUT_BF16 && WM == 2 && WTN == 4) {
-    if (ep.out2) {    // dual-output epilogues (dropped copy / trunk layer backward): the wide-tile fp32 kernel only, see limb3_nn_dual_eligible
+    if (ep.out2 || ep.bits) {    // dual-output epilogues (dropped copy / trunk layer backward, the latter also without its second
+                                 // output: column sums only): the wide-tile fp32 kernel only, see limb3_nn_dual_eligible
       if (ep.bits)
         hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, false, WTN, 1, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb,
                            ncb, c_vec_ok);
@@ -252,7 +253,7 @@ int launch_nn_limb3(const float* A, int64_t lda, const float* B, int64_t ldb, vo
   static const int wide = getenv("CB_LIMB_WIDE") ? atoi(getenv("CB_LIMB_WIDE")) : 1;   // 128 x 256 block tile (wave tile 64 x 128); 0: 128 x 128
   // fewer than one wide tile per CU (a Pubmed-sized M = 19 717: 155 tiles): the 128 x 128 tile doubles the blocks in flight (-6 % on
   // the S-pubmed step); the dual-output epilogues exist for the wide tile only
-  const bool fills = ((M + 127) / 128) * ((N + 255) / 256) >= 256 || ep.out2;
+  const bool fills = ((M + 127) / 128) * ((N + 255) / 256) >= 256 || ep.out2 || ep.bits;
   if (wide && N > 128 && fills)
     return out_bf16 ? launch_nn_l3_t<2, 2, true, 4>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes)
                     : launch_nn_l3_t<2, 2, false, 4>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes);

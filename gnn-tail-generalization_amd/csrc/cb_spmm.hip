@@ -135,7 +135,38 @@ struct Epilogue {
   const float* acc_init;
   int64_t ld_init;
   int col_flags;           // 1: bit 31 of every column id marks a hot source row (gather policy 2, see gather_pol)
+  // MASK kernels only (cb_spmm_csr_masked_f32): every gathered SOURCE row u enters the sum as src_scale[u] * (src_bits[u] ? h[u] : 0)
+  // and the finished row is multiplied by out_coef — the backward of the fused trunk store (dropout keep & ReLU mask, c_act / (1-p),
+  // the source row's degree norm) applied while the reverse aggregation gathers dL/dx_l, instead of in a pass of its own
+  const unsigned long long* src_bits;   // [n_cols][d / 256][4] mask words of the forward store (word k, bit L <-> column 256 t + 4 L + k)
+  const float* src_scale;               // [n_cols]
+  float out_coef;
 };
+
+// Uniform (scalar-cache) reads of the per-source-row mask words and scale: the row id is wave-uniform, the arrays are read-only
+// for the whole launch, so they are addressed through the constant address space (s_load)
+typedef const __attribute__((address_space(4))) unsigned long long* ConstU64Ptr;
+typedef const __attribute__((address_space(4))) float* ConstF32Ptr;
+
+// lane l keeps v when bit l of the wave-uniform 64-bit word is set: the word IS the lane mask of one v_cndmask
+__device__ __forceinline__ float keep_if_bit(float v, unsigned long long w) {
+  float r;
+  asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(w));
+  return r;
+}
+
+struct SrcRowMask {     // what the MASK kernels fetch per gathered source row (all wave-uniform: SGPRs)
+  unsigned long long w[4];
+  float s;
+};
+__device__ __forceinline__ SrcRowMask load_src_mask(const Epilogue& ep, int col_id, int tiles, int tile) {
+  SrcRowMask m;
+  ConstU64Ptr bw = (ConstU64Ptr)(ep.src_bits + ((int64_t)col_id * tiles + tile) * 4);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) m.w[k] = bw[k];
+  m.s = ((ConstF32Ptr)ep.src_scale)[col_id];
+  return m;
+}
 
 // Extended epilogue of the fused residual trunk (GCN.py:127-133 folded into the aggregation's store):
 //   act    = relu(row_scale * acc + bias)                      -> ReLU mask bits and/or the activation itself
@@ -161,25 +192,27 @@ struct FusedEpi {
 
 __device__ __forceinline__ void fused_store(const FusedEpi& fe, int64_t row, int c0, const float (&acc)[4], float scale,
                                             const float (&b)[4], const float (&rmix)[4]) {
-  float a[4], x[4];
+  float a[4], x[4], m[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) a[i] = fmaxf(acc[i] * scale + b[i], 0.f);
+  for (int i = 0; i < 4; ++i) a[i] = fmaxf(scale_add(acc[i], scale, b[i]), 0.f);
+  if (fe.thresh) keep4(fe.seed_dev ? fe.seed + *fe.seed_dev : fe.seed, ((fe.row0 + row) * fe.d + c0) >> 2, fe.thresh, fe.keep_scale, m);
   if (fe.bits) {
+    // mask word k of (row, tile), bit l: the element (column 4 l + k) passes gradient to the pre-activation — ReLU positive AND kept
+    // by the dropout.  The backward kernels that also regenerate the keep-mask are unaffected (masking twice is masking once);
+    // cb_spmm_csr_masked_f32 needs nothing but these words.
     const int lane = lane_id();
     unsigned long long mine = 0ull;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const unsigned long long m = __ballot(a[k] > 0.f);
-      if (lane == k) mine = m;
+      const unsigned long long w = __ballot(a[k] > 0.f && m[k] != 0.f);
+      if (lane == k) mine = w;
     }
     if (lane < 4) fe.bits[(row * (fe.d >> 8) + (c0 >> 8)) * 4 + lane] = mine;
   }
   if (fe.out_act) store_stream<4>(fe.out_act + row * fe.ld_act + c0, a);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) x[i] = fe.mix_src ? fe.c_act * a[i] + fe.c_mix * rmix[i] : a[i];
-  if (fe.thresh) {
-    float m[4];
-    keep4(fe.seed_dev ? fe.seed + *fe.seed_dev : fe.seed, ((fe.row0 + row) * fe.d + c0) >> 2, fe.thresh, fe.keep_scale, m);
+  for (int i = 0; i < 4; ++i) x[i] = fe.mix_src ? mix2(fe.c_act, a[i], fe.c_mix, rmix[i]) : a[i];
+  if (fe.thresh) {      // kept as a statement of its own: the same rounding sequence as cb_axpby_f32 followed by cb_dropout_f32
 #pragma unroll
     for (int i = 0; i < 4; ++i) x[i] *= m[i];
   }
@@ -192,8 +225,7 @@ __device__ __forceinline__ void write_row(float* __restrict__ out_row, const flo
   float r[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
-    float t = acc[i] * scale;   // rst * norm   (GCN.py:250)
-    t = t + b[i];               // rst + bias   (GCN.py:253)
+    const float t = scale_add(acc[i], scale, b[i]);   // rst * norm + bias   (GCN.py:250,253)
     r[i] = relu ? fmaxf(t, 0.f) : t;
   }
   store_stream<VEC>(out_row, r);
@@ -217,11 +249,13 @@ __device__ __forceinline__ void gather_pol(float (&v)[VEC], const HT* __restrict
   }
 }
 
-template <int VEC, int U, bool FULL, bool FUSED, bool ACC, typename HT, int GP = 0>
+template <int VEC, int U, bool FULL, bool FUSED, bool ACC, typename HT, int GP = 0, bool MASK = false>
 __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr, float my_scale, int r0, const int* __restrict__ col,
                                             const HT* __restrict__ h_lane, int64_t ld_h, float* __restrict__ out_lane,
                                             int64_t ld_out, bool active_in, int relu, const float (&bvec)[VEC], const FusedEpi& fe,
-                                            int c0, const float* __restrict__ init_lane, int64_t ld_init) {
+                                            int c0, const float* __restrict__ init_lane, int64_t ld_init, const Epilogue& ep) {
+  static_assert(!MASK || (VEC == 4 && FULL && !FUSED && !ACC), "masked gather: d % 256 == 0, plain store");
+  const int m_tiles = MASK ? (int)gridDim.y : 1, m_tile = MASK ? (int)blockIdx.y : 0;
   const bool active = FULL ? true : active_in;
   float ainit[VEC];                          // ACC: partial sums of local row `cur`, fetched one row ahead (read once: streaming)
   zero<VEC>(ainit);
@@ -278,18 +312,25 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
     int k = 0;
     for (; k + U <= cnt; k += U) {
       float v[U][VEC];
+      SrcRowMask sm[MASK ? U : 1];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int c = bcast_lane(my_col, k + u);
         if (active) gather_pol<VEC, HT, GP>(v[u], h_lane, ld_h, c);
         else zero<VEC>(v[u]);
+        if constexpr (MASK) sm[u] = load_src_mask(ep, GP == 2 ? (c & kColMask) : c, m_tiles, m_tile);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int e = base + k + u;
         while (e == cur_end) flush();
+        if constexpr (MASK) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
+          for (int i = 0; i < VEC; ++i) acc[i] += sm[u].s * keep_if_bit(v[u][i], sm[u].w[i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
+        }
       }
     }
     for (; k < cnt; ++k) {
@@ -299,14 +340,20 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
       else zero<VEC>(v);
       const int e = base + k;
       while (e == cur_end) flush();
+      if constexpr (MASK) {
+        const SrcRowMask m1 = load_src_mask(ep, GP == 2 ? (c & kColMask) : c, m_tiles, m_tile);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] += v[i];
+        for (int i = 0; i < VEC; ++i) acc[i] += m1.s * keep_if_bit(v[i], m1.w[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += v[i];
+      }
     }
   }
   while (cur < rhi) flush();  // last row + trailing empty rows
 }
 
-template <int VEC, int RPW, int U, bool FULL, bool FUSED, typename HT, bool ACC = false, int GP = 0>
+template <int VEC, int RPW, int U, bool FULL, bool FUSED, typename HT, bool ACC = false, int GP = 0, bool MASK = false>
 __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                    const HT* __restrict__ h, int64_t ld_h, float* __restrict__ out,
                                                    int64_t ld_out, int n_rows, int d, Epilogue ep, int hub_T, FusedEpi fe) {
@@ -323,6 +370,7 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
   int my_ptr = __builtin_nontemporal_load(rowptr + r0 + min(lane, nr));
   float my_scale = 1.f;  // lane i: row_scale[r0 + i], broadcast at flush time (no load on the flush path)
   if (ep.row_scale && lane < nr) my_scale = __builtin_nontemporal_load(ep.row_scale + r0 + lane);
+  if constexpr (MASK) my_scale *= ep.out_coef;
   const int nxt = __shfl_down(my_ptr, 1);
   const unsigned long long hubmask = __ballot(lane < nr && (nxt - my_ptr) > hub_T);
 
@@ -337,28 +385,29 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
   const float* init_lane = ACC ? ep.acc_init + c0 : nullptr;
 
   if (hubmask == 0) {
-    stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP>(0, nr, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0,
-                                              init_lane, ep.ld_init);
+    stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP, MASK>(0, nr, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0,
+                                                    init_lane, ep.ld_init, ep);
   } else {
     int r = 0;
     while (r < nr) {  // maximal hub-free runs; hub rows are written by the hub kernels
       unsigned long long m = hubmask >> r;
       int nh = m ? r + (__ffsll((long long)m) - 1) : nr;
       if (nh > r)
-        stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP>(r, nh, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe,
-                                                  c0, init_lane, ep.ld_init);
+        stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP, MASK>(r, nh, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe,
+                                                        c0, init_lane, ep.ld_init, ep);
       r = nh + 1;
     }
   }
 }
 
 // One wavefront per chunk of T edges of a hub row -> one partial row in `partial`.
-template <int VEC, int U, typename HT, int GP = 0>
+template <int VEC, int U, typename HT, int GP = 0, bool MASK = false>
 __global__ void __launch_bounds__(256) k_spmm_hub_chunks(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                          const HT* __restrict__ h, int64_t ld_h, int d, int hub_T,
                                                          int n_hubs, int n_chunks, const int* __restrict__ hub_rows,
                                                          const int* __restrict__ hub_chunk_ptr, float* __restrict__ partial,
-                                                         int64_t ld_p) {
+                                                         int64_t ld_p, Epilogue ep) {
+  const int m_tiles = MASK ? (int)gridDim.y : 1, m_tile = MASK ? (int)blockIdx.y : 0;
   const int lane = lane_id();
   const int chunk = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   if (chunk >= n_chunks) return;
@@ -384,24 +433,38 @@ __global__ void __launch_bounds__(256) k_spmm_hub_chunks(const int* __restrict__
     int k = 0;
     for (; k + U <= cnt; k += U) {
       float v[U][VEC];
+      SrcRowMask sm[MASK ? U : 1];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int c = bcast_lane(my_col, k + u);
         if (active) gather_pol<VEC, HT, GP>(v[u], h_lane, ld_h, c);
         else zero<VEC>(v[u]);
+        if constexpr (MASK) sm[u] = load_src_mask(ep, GP == 2 ? (c & kColMask) : c, m_tiles, m_tile);
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u)
+      for (int u = 0; u < U; ++u) {
+        if constexpr (MASK) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
+          for (int i = 0; i < VEC; ++i) acc[i] += sm[u].s * keep_if_bit(v[u][i], sm[u].w[i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
+        }
+      }
     }
     for (; k < cnt; ++k) {
       const int c = bcast_lane(my_col, k);
       float v[VEC];
       if (active) gather_pol<VEC, HT, GP>(v, h_lane, ld_h, c);
       else zero<VEC>(v);
+      if constexpr (MASK) {
+        const SrcRowMask m1 = load_src_mask(ep, GP == 2 ? (c & kColMask) : c, m_tiles, m_tile);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] += v[i];
+        for (int i = 0; i < VEC; ++i) acc[i] += m1.s * keep_if_bit(v[i], m1.w[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += v[i];
+      }
     }
   }
   if (active) {
@@ -444,6 +507,7 @@ __global__ void __launch_bounds__(256) k_spmm_hub_finish(int d, int n_hubs, cons
     for (int k = 0; k < VEC; ++k) bvec[k] = ep.bias[c0 + k];
   }
   float s = ep.row_scale ? ep.row_scale[row] : 1.f;
+  if (ep.src_bits) s *= ep.out_coef;
   if constexpr (FUSED) {
     float a4[4], b4[4], rmix[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -509,7 +573,7 @@ static int launch_spmm_cfg(const int32_t* rowptr, const int32_t* col, int64_t N,
     const int gph = kGPh && d % tile == 0 ? gather_policy(ep.col_flags) : 0;
 #define CB_HUB_LAUNCH(GP_)                                                                                                       \
   hipLaunchKernelGGL((k_spmm_hub_chunks<VEC, 8, HT, GP_>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h, (int)d, \
-                     hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, ld_p)
+                     hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, ld_p, ep)
     if constexpr (kGPh) { if (gph == 1) CB_HUB_LAUNCH(1); else if (gph == 2) CB_HUB_LAUNCH(2); else CB_HUB_LAUNCH(0); }
     else CB_HUB_LAUNCH(0);
 #undef CB_HUB_LAUNCH
@@ -558,6 +622,42 @@ static int launch_spmm(const int32_t* rowptr, const int32_t* col, int64_t N, con
   }
   return launch_spmm_cfg<VEC, FUSED, 16, 8, HT>(CB_SPMM_ARGS);
 #undef CB_SPMM_ARGS
+}
+
+// Masked-source launch (cb_spmm_csr_masked_f32): fp32 rows, d % 256 == 0, plain store.  MU = gathers in flight per wavefront
+// (each carries 9 SGPRs of mask words + scale next to its 4 VGPRs).
+template <int MU>
+static int launch_spmm_masked(const int32_t* rowptr, const int32_t* col, int64_t N, const float* h, int64_t ld_h, int64_t d, Epilogue ep,
+                              float* out, int64_t ld_out, int hub_T, int n_hubs, int n_chunks, const int32_t* hub_rows,
+                              const int32_t* hub_chunk_ptr, float* partial, hipStream_t st) {
+  constexpr int RPW = 16, waves_per_block = 4;
+  const int ny = (int)(d / 256);
+  const FusedEpi fe{};
+  const int64_t n_waves = (N + RPW - 1) / RPW;
+  const dim3 grid((unsigned)((n_waves + waves_per_block - 1) / waves_per_block), ny), blk(kWave * waves_per_block);
+  if (ep.col_flags)
+    hipLaunchKernelGGL((k_spmm_rows<4, RPW, MU, true, false, float, false, 2, true>), grid, blk, 0, st, rowptr, col, h, ld_h, out, ld_out, (int)N,
+                       (int)d, ep, hub_T, fe);
+  else
+    hipLaunchKernelGGL((k_spmm_rows<4, RPW, MU, true, false, float, false, 0, true>), grid, blk, 0, st, rowptr, col, h, ld_h, out, ld_out, (int)N,
+                       (int)d, ep, hub_T, fe);
+  CB_LAUNCH_CHECK();
+  if (n_hubs > 0) {
+    const int64_t ld_p = partial_ld(d);
+    const dim3 gridc((unsigned)((n_chunks + waves_per_block - 1) / waves_per_block), ny);
+    if (ep.col_flags)
+      hipLaunchKernelGGL((k_spmm_hub_chunks<4, MU, float, 2, true>), gridc, blk, 0, st, rowptr, col, h, ld_h, (int)d, hub_T, n_hubs, n_chunks,
+                         hub_rows, hub_chunk_ptr, partial, ld_p, ep);
+    else
+      hipLaunchKernelGGL((k_spmm_hub_chunks<4, MU, float, 0, true>), gridc, blk, 0, st, rowptr, col, h, ld_h, (int)d, hub_T, n_hubs, n_chunks,
+                         hub_rows, hub_chunk_ptr, partial, ld_p, ep);
+    CB_LAUNCH_CHECK();
+    const dim3 grid2((unsigned)((n_hubs + waves_per_block - 1) / waves_per_block), ny);
+    hipLaunchKernelGGL((k_spmm_hub_finish<4, false>), grid2, blk, 0, st, (int)d, n_hubs, hub_rows, hub_chunk_ptr, partial, ld_p, out, ld_out,
+                       ep, fe);
+    CB_LAUNCH_CHECK();
+  }
+  return CB_OK;
 }
 
 }  // namespace cb
@@ -620,6 +720,34 @@ extern "C" int cb_spmm_csr_acc_f32(const int32_t* rowptr, const int32_t* col, in
   CB_CHECK_ARG(acc_init != nullptr || N == 0 || d == 0, CB_E_INVALID, "cb_spmm_csr_acc_f32: acc_init is null");
   return spmm_plain_impl("cb_spmm_csr_acc_f32", rowptr, col, col_flags, N, E, h, ld_h, d, row_scale, bias, relu, acc_init, ld_init, out, ld_out, hub_T,
                          n_hubs, n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, stream);
+}
+
+// out[v] = out_coef * sum_{u in row v} src_scale[u] * (src_bits[u] ? h[u] : 0): the reverse aggregation of the fused trunk's
+// backward with the layer-below's store backward (dropout keep & ReLU mask bits of the forward store, c_act / (1 - p), degree norm
+// of the source row) applied to every gathered row — what cb_trunk_layer_bwd_f32 followed by cb_spmm_csr_f32 computes, without
+// the [N, d] intermediate (8 bytes / element less traffic per layer; + 36 bytes per edge of scalar-cache reads).
+extern "C" int cb_spmm_csr_masked_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h,
+                                      int64_t ld_h, int64_t d, const uint64_t* src_bits, const float* src_scale, float out_coef,
+                                      float* out, int64_t ld_out, int32_t hub_T, int32_t n_hubs, int32_t n_chunks,
+                                      const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(N >= 0 && E >= 0 && d > 0 && d % 256 == 0, CB_E_INVALID, "cb_spmm_csr_masked_f32: d must be a positive multiple of 256");
+  CB_CHECK_ARG(N < INT32_MAX && E < INT32_MAX && d < (1 << 20), CB_E_RANGE, "cb_spmm_csr_masked_f32: size exceeds the int32 contract");
+  if (N == 0) return CB_OK;
+  CB_CHECK_ARG(rowptr && h && out && src_bits && src_scale && (E == 0 || col), CB_E_INVALID, "cb_spmm_csr_masked_f32: null pointer");
+  CB_CHECK_ARG(((uintptr_t)h % 16 == 0) && ((uintptr_t)out % 16 == 0) && ld_h % 4 == 0 && ld_out % 4 == 0 && ld_h >= d && ld_out >= d &&
+                   ((uintptr_t)src_bits % 8 == 0) && ((uintptr_t)src_scale % 4 == 0),
+               CB_E_INVALID, "cb_spmm_csr_masked_f32: 16-byte aligned rows of at least d floats required");
+  CB_CHECK_ARG(hub_T > 0 && n_hubs >= 0 && n_chunks >= 0, CB_E_INVALID, "cb_spmm_csr_masked_f32: bad hub plan");
+  CB_CHECK_ARG(n_hubs == 0 || (hub_rows && hub_chunk_ptr && ws && ws_bytes >= cb_spmm_workspace_bytes(n_chunks, d)), CB_E_WORKSPACE,
+               "cb_spmm_csr_masked_f32: hub plan given but workspace missing/too small");
+  if (n_hubs == 0) hub_T = INT32_MAX;
+  Epilogue ep{nullptr, nullptr, 0, nullptr, 0, col_flags, (const unsigned long long*)src_bits, src_scale, out_coef};
+  static const int mu = getenv("CB_SPMM_MASK_U") ? atoi(getenv("CB_SPMM_MASK_U")) : 4;     // measurement hook
+  if (mu == 4)
+    return launch_spmm_masked<4>(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, (float*)ws,
+                                 (hipStream_t)stream);
+  return launch_spmm_masked<8>(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, (float*)ws,
+                               (hipStream_t)stream);
 }
 
 static int spmm_fused_impl(int h_bf16, const float* acc_init, int64_t ld_init, int col_flags, const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const void* h, int64_t ld_h,

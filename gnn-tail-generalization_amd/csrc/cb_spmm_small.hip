@@ -53,8 +53,7 @@ __device__ __forceinline__ void finish_row(bool on, float* __restrict__ out, int
   float r[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
-    float t = acc[i] * scale;   // rst * norm   (GCN.py:250)
-    t = t + b[i];               // rst + bias   (GCN.py:253)
+    const float t = scale_add(acc[i], scale, b[i]);   // rst * norm + bias   (GCN.py:250,253)
     r[i] = relu ? fmaxf(t, 0.f) : t;
   }
   strow<VEC>(out + row * ld_out + c0, r);
@@ -261,7 +260,7 @@ __global__ void __launch_bounds__(256) k_small_hub_finish(int d, int n_hubs, con
   const int row = hub_rows[i];
   float acc = 0.f;
   for (int k = hub_chunk_ptr[i]; k < hub_chunk_ptr[i + 1]; ++k) acc += partial[(int64_t)k * ld_p + c];
-  float v = acc * (ep.row_scale ? ep.row_scale[row] : 1.f) + (ep.bias ? ep.bias[c] : 0.f);
+  const float v = scale_add(acc, ep.row_scale ? ep.row_scale[row] : 1.f, ep.bias ? ep.bias[c] : 0.f);
   out[(int64_t)row * ld_out + c] = ep.relu ? fmaxf(v, 0.f) : v;
 }
 

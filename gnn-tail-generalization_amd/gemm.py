@@ -81,7 +81,7 @@ def mm_nn_drop2(a, b, p, seed, row0=0, bias=None, relu=False):
     return y, yd
 
 
-def mm_nn_trunkbwd(a, b, rowscale, bits, c_act, p, seed, row0, row_scale2, want_colsum):
+def mm_nn_trunkbwd(a, b, rowscale, bits, c_act, p, seed, row0, row_scale2, want_colsum, want_gr=True):
     """(G, GR, colsum): G = rowscale * (a @ b) and, from the same epilogue, GR = c_act * dropout_bwd(G) * relu_bits * row_scale2 with
     the column sums of the unscaled GR (cb_gemm_nn_trunkbwd_f32) — the dX GEMM + the layer-below's trunk backward in one kernel."""
     import ctypes
@@ -93,8 +93,10 @@ def mm_nn_trunkbwd(a, b, rowscale, bits, c_act, p, seed, row0, row_scale2, want_
     K2, N = b.shape
     if K != K2 or a.dtype != torch.float32 or b.dtype != torch.float32 or N % 256:
         raise ValueError(f'mm_nn_trunkbwd: bad operands {tuple(a.shape)} @ {tuple(b.shape)}')
+    if not want_gr and not want_colsum:
+        raise ValueError('mm_nn_trunkbwd: neither the second output nor the column sums requested')
     g = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    gr = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    gr = torch.empty((M, N), dtype=torch.float32, device=a.device) if want_gr else None      # None: column sums only
     colsum = torch.empty(N, dtype=torch.float32, device=a.device) if want_colsum else None
     wsb = lib.cb_gemm_nn_trunkbwd_workspace_bytes(M, N) if want_colsum else 0
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=a.device)

@@ -237,6 +237,41 @@ class CSRGraph:
                                                           src_elem=2 if bf16 else 4), 0))
         return out
 
+    def spmm_masked(self, h, src_bits, src_scale, out_coef, transpose=True):
+        """out[v] = out_coef * sum_{u in row v} src_scale[u] * (src_bits[u] ? h[u] : 0) (cb_spmm_csr_masked_f32): the reverse
+        aggregation of the fused trunk's backward with the layer-below's store backward applied to the gathered rows."""
+        lib = _lib.load()
+        _lib.require_device(h, src_bits, src_scale)
+        d = h.shape[1]
+        if (h.dtype != torch.float32 or h.dim() != 2 or h.shape[0] != self.n_cols or d % 256 or h.stride(1) != 1
+                or src_bits.dtype != torch.int64 or tuple(src_bits.shape) != (self.n_cols, d // 256, 4) or not src_bits.is_contiguous()
+                or src_scale.dtype != torch.float32 or src_scale.numel() != self.n_cols or not src_scale.is_contiguous()):
+            raise ValueError('spmm_masked: float32 [n_cols, d] rows (d % 256 == 0), int64 [n_cols, d/256, 4] mask words, float32 [n_cols] scales')
+        if transpose and self.rowptr_t is None:
+            raise ValueError('this graph holds the forward orientation only')
+        out = torch.empty((self.N, d), dtype=torch.float32, device=h.device)
+        rowptr, col, plan = (self.rowptr_t, self.col_t, self._plan_t) if transpose else (self.rowptr, self.col, self._plan)
+        col_k = self.col_t_k if transpose else self.col_k
+        flags = int(col_k is not None and h.data_ptr() % 16 == 0 and h.stride(0) % 4 == 0)
+        if flags:
+            col = col_k
+        ws_bytes = lib.cb_spmm_workspace_bytes(plan.n_chunks, d)
+        ws = self._workspace(ws_bytes)
+        prof = self.profile
+        if prof is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        with torch.cuda.device(h.device):
+            _lib.check(lib.cb_spmm_csr_masked_f32(_lib.ptr(rowptr), _lib.ptr(col), flags, self.N, self.E, _lib.ptr(h), h.stride(0), d,
+                                                  _lib.ptr(src_bits), _lib.ptr(src_scale), float(out_coef), _lib.ptr(out), d,
+                                                  self.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows),
+                                                  _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
+                       'cb_spmm_csr_masked_f32')
+        if prof is not None:
+            ev1.record()
+            prof.append((ev0, ev1, self.algorithmic_bytes(d, row_scale=False, bias=False), 0))
+        return out
+
     def algorithmic_bytes(self, d, elem=4, row_scale=True, bias=True, src_elem=None):
         """E*(d*s+4) + N*(d*s+4) [+4N row scale] [+d*s bias]; src_elem = bytes per gathered element
         when the source rows are stored narrower than the output (bf16 variant)."""

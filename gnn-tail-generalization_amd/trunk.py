@@ -137,6 +137,11 @@ import os
 # GEMM + cb_trunk_layer_bwd_f32 as a pass of its own (215.1-216.3 vs 212.4-214.1 ms on S-pl10M): the extra 10 GB leave through the
 # GEMM's store phase, its least efficient part.  Off unless CB_TRUNK_FUSE_BWD=1; both forms are tested.
 FUSE_BWD_EPILOGUE = os.environ.get('CB_TRUNK_FUSE_BWD', '0') == '1'
+# Store backward of the layer below applied by the reverse aggregation to the rows it gathers (cb_spmm_csr_masked_f32) + its bias
+# column sums from the dX GEMM's epilogue (one GPU, fp32 rows).  Measured on S-pl10M: 210.8-213.0 vs 214.7 ms per step (the 3 x 4.0 ms
+# passes go, the masked launches cost +1.7 ms each for their 36 bytes of mask words / scale per edge, the epilogue ~1 ms) — but the
+# reverse launches then move SURVEY 8(d)'s bytes at 0.78 instead of 0.90 of the roofline, so it stays opt-in: CB_TRUNK_MASKED_GATHER=1.
+MASKED_GATHER = os.environ.get('CB_TRUNK_MASKED_GATHER', '0') == '1'
 MIX_MAX = 7      # mixed-in gradients one cb_trunk_input_bwd_multi_f32 launch gathers (deeper trunks accumulate layer by layer)
 
 
@@ -204,9 +209,20 @@ class _TrunkFn(torch.autograd.Function):
         grads_layers = [None] * (3 * L)
         sharded = hasattr(graph, 'part')
 
+        # opt-in (CB_TRUNK_MASKED_GATHER=1; one GPU, fp32 rows): the store backward of the layer below is applied by the reverse aggregation
+        # to the rows it gathers (cb_spmm_csr_masked_f32) and its bias column sums leave the dX GEMM's epilogue — no [N, d] pass of its own
+        masked = gather and not agg_bf16 and not sharded and not fuse and MASKED_GATHER and hasattr(graph, 'spmm_masked')
+        coef = (1 - alpha) / (1 - p)
+
         def dx_gemm(src, wt, rowscale, below):
             """dL/dx of the stage above layer `below` (+ that layer's trunk backward when fused): (g, gr, dbias)."""
             sd = seeds[below + 2] if p > 0 else 0
+            if masked:
+                if need[7 + 3 * below + 1]:
+                    g_, _, db_ = gemm.mm_nn_trunkbwd(src, wt, rowscale, saved_bits[below], coef, 0.0, 0, row0, None, True, want_gr=False)
+                else:
+                    g_, db_ = gemm.mm_nn(src, wt, rowscale=rowscale), None
+                return g_, None, db_
             if fuse:
                 return gemm.mm_nn_trunkbwd(src, wt, rowscale, saved_bits[below], 1 - alpha, p, sd, row0, bnorm, need[7 + 3 * below + 1])
             g_ = gemm.mm_nn(src, wt, rowscale=rowscale)
@@ -221,13 +237,15 @@ class _TrunkFn(torch.autograd.Function):
             if gather:
                 g_mix.append(g)
                 seeds_mix.append(seeds[l + 2] if p > 0 else 0)
-            del g
             handle = graph.aggregate_start(gr, True) if sharded else None       # node-sharded: the exchange is in flight from here
             if deferred is not None:
                 grads_layers[3 * deferred[0]] = gemm.mm_tn(deferred[1], deferred[2], rowscale=a)
                 deferred = None
-            gz = graph.aggregate_finish(handle, True) if sharded else _spmm_t(graph, gr)     # dL/dZ_l = A (b * dY')
-            del gr
+            if masked:
+                gz = graph.spmm_masked(g, saved_bits[l], bnorm, coef)                         # dL/dZ_l = A (b * dY'), dY' formed on the fly
+            else:
+                gz = graph.aggregate_finish(handle, True) if sharded else _spmm_t(graph, gr)  # dL/dZ_l = A (b * dY')
+            del g, gr
             if need[7 + 3 * l]:
                 if sharded:
                     deferred = (l, saved_in[l], gz)

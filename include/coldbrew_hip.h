@@ -192,6 +192,8 @@ int cb_gemm_nn_drop2_f32(const float* A, int64_t lda, const float* B, int64_t ld
  *     G  = rowscale * (A @ B)                                   dL/dx_l   (kept: the input stage gathers it later)
  *     GR = c_act * dropout_bwd_seed(G) * relu_bits * row_scale2  input of the reverse aggregation of layer l-1
  *     colsum[n] = sum_m (the same without row_scale2)            bias gradient of layer l-1 (may be NULL)
+ * GR may be NULL when colsum is given: only the column sums leave the epilogue (the reverse aggregation then applies the store
+ * backward to the rows it gathers, cb_spmm_csr_masked_f32; pass drop_p = 0 and c_act / (1 - p): the mask words carry the keep bits).
  * Autograd of th.matmul GCN.py:225 / nn.Linear :138 followed by autograd of F.dropout :110,133, InitialConnection
  * res_tricks.py:23 and F.relu :128.  N % 256 == 0.  ws: cb_gemm_nn_trunkbwd_workspace_bytes(M, N) (column-sum partials).
  * Falls back to cb_gemm_nn_f32 + cb_trunk_layer_bwd_f32 when the fused epilogue does not cover the shape. */
@@ -214,7 +216,8 @@ int cb_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, con
  * and GCN.py:110 of layer l+1 into the aggregation's store:
  *     act      = relu(row_scale[v] * sum_j h[col[j]] + bias)                       (GCN.py:238-253,128)
  *     out_next = dropout_{seed,p}( c_act * act + c_mix * mix_src[v] )              (res_tricks.py:23, GCN.py:110/133)
- * relu_bits [N][d/256][4] uint64 receives the ReLU mask (word k, bit l = column 256*tile + 4*l + k), out_act
+ * relu_bits [N][d/256][4] uint64 receives the backward mask of the store (word k, bit l = column 256*tile + 4*l + k): set where
+ * the element passes gradient to the pre-activation, i.e. act > 0 AND the dropout keeps it (p = 0: the ReLU mask); out_act
  * (nullable) the activation itself.  d must be a multiple of 256; rows 16-byte aligned.  row0 = global index
  * of local row 0 (dropout mask of the unsharded tensor).  mix_src NULL: no mix; drop_p 0: no dropout.
  * ---------------------------------------------------------------------------------- */
@@ -268,6 +271,18 @@ int cb_spmm_csr_fused_bf16_f32(const int32_t* rowptr, const int32_t* col, int32_
                                uint64_t* relu_bits, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
                                int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
                                const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream);
+
+/* Reverse aggregation of the fused trunk's backward with the layer-below's store backward applied to every GATHERED row:
+ *     out[v] = out_coef * sum_{u in row v of the CSR} src_scale[u] * (src_bits[u] ? h[u] : 0)
+ * = cb_trunk_layer_bwd_f32 (autograd of F.dropout GCN.py:110,133, InitialConnection res_tricks.py:23, F.relu GCN.py:128, `* norm`
+ * :250) followed by cb_spmm_csr_f32 on the reverse CSR (autograd of the DGL aggregation :238), without the [N, d] intermediate.
+ * src_bits: the mask words cb_spmm_csr_fused_f32 wrote for the source rows ([n_cols][d/256][4], bit set = element passes: ReLU
+ * positive AND kept by the dropout); src_scale [n_cols]; out_coef = c_act / (1 - p).  fp32, d % 256 == 0, 16-byte aligned rows.
+ * col_flags as in cb_spmm_csr_f32. */
+int cb_spmm_csr_masked_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h,
+                           int64_t d, const uint64_t* src_bits, const float* src_scale, float out_coef, float* out, int64_t ld_out,
+                           int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
+                           const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Normalisation tricks (GNN_model/norm_tricks.py) as fused reductions; all matrices contiguous [rows, d].

@@ -91,18 +91,47 @@ def test_fused_aggregation_store_full_size(pl10m_graph):
     # mask bits on every row class: first / last wave blocks, hub rows, a random 200k sample
     rows = torch.cat([torch.arange(0, 64, device=DEV), torch.arange(n - 64, n, device=DEV),
                       G._plan.hub_rows[:4096].to(torch.int64), torch.randint(0, n, (200_000,), device=DEV, generator=gen)])
-    assert torch.equal(_unpack_bits(bits, rows, d), ref_act[rows] > 0)
-    # popcount over ALL rows equals the number of positive activations
-    pos_ref = int((ref_act > 0).sum())
+    # the words mark where gradient passes to the pre-activation: act > 0 AND kept by the dropout (same keep-mask: a pure function
+    # of seed and flat index)
+    keep = ops.dropout_keep_mask((n, d), p, seed, DEV)
+    assert torch.equal(_unpack_bits(bits, rows, d), (ref_act[rows] > 0) & keep[rows])
+    # popcount over ALL rows
+    pos_ref = int(((ref_act > 0) & keep).sum())
     tbl = torch.tensor([bin(i).count('1') for i in range(256)], dtype=torch.int64, device=DEV)
     assert int(tbl[bits.view(-1).view(torch.uint8).to(torch.int64)].sum()) == pos_ref     # byte-wise popcount
-    # x_next = dropout((1-a) act + a x0): same formula, same keep-mask (pure function of seed and flat index)
-    keep = ops.dropout_keep_mask((n, d), p, seed, DEV)
+    # x_next = dropout((1-a) act + a x0): same formula, same keep-mask
     ref_act.mul_(1 - alpha).add_(x0, alpha=alpha)
     ref_act.div_(1 - p)
     ref_act.mul_(keep)
     del keep
     assert _max_abs_diff_inplace(ref_act, nxt) <= 1e-5
+
+
+def test_masked_reverse_aggregation_full_size(pl10m_graph):
+    """cb_spmm_csr_masked_f32 at N = 10^7, d = 256 (the store backward applied to the gathered rows, mask words written by the
+    fused forward store with dropout on) == cb_trunk_layer_bwd_f32 followed by the plain reverse aggregation; the column sums
+    that leave the dX GEMM's epilogue (second output off) == the ones of the separate pass."""
+    from gnn_tail_generalization_amd import gemm, trunk
+    G = pl10m_graph
+    n, d, p, seed, alpha = G.N, 256, 0.1, 0xABCDE, 0.1
+    gen = torch.Generator(device=DEV).manual_seed(21)
+    z = torch.randn(n, d, device=DEV, generator=gen)
+    bias = torch.randn(d, device=DEV, generator=gen)
+    bits, nxt, _ = trunk._fused_spmm(G, z, bias, None, 1.0, 0.0, p, seed)
+    del nxt, z
+    src = torch.randn(n, d, device=DEV, generator=gen)
+    w = torch.randn(d, d, device=DEV, generator=gen) * 0.06
+    coef = (1 - alpha) / (1 - p)
+    g, none, cs = gemm.mm_nn_trunkbwd(src, w, G.norm_out, bits, coef, 0.0, 0, 0, None, True, want_gr=False)
+    assert none is None and torch.equal(g, gemm.mm_nn(src, w, rowscale=G.norm_out))
+    del src
+    gr, cs_ref = trunk._layer_bwd(g, bits, G.norm_in, None, False, p, seed, 0, 1 - alpha, alpha, True)
+    torch.testing.assert_close(cs, cs_ref, atol=2e-2, rtol=2e-4)            # 10^7-term sums in two different partial orders
+    ref = G.spmm(gr, transpose=True)
+    del gr
+    got = G.spmm_masked(g, bits, G.norm_in, coef)
+    scale = float(ref.abs().max())
+    assert _max_abs_diff_inplace(got, ref) <= 2e-6 * scale
 
 
 def test_trunk_backward_kernels_full_size(pl10m_graph):
@@ -180,14 +209,17 @@ def _teacher(argv, dataset, n_override=None, dropout=0.0, seed=0):
 
 def test_fused_step_equals_modular_step_s_pl1m():
     """One full training step (dropout on) of the fused trunk vs the modular operator path on S-pl1M (10^6 nodes,
-    10^7 edge_index columns): logits, loss and every weight gradient agree."""
-    from gnn_tail_generalization_amd import ops
+    10^7 edge_index columns): logits, loss and every weight gradient agree — also with the opt-in backward in which the reverse
+    aggregation applies the store backward to the rows it gathers (CB_TRUNK_MASKED_GATHER=1)."""
+    from gnn_tail_generalization_amd import ops, trunk
     from gnn_tail_generalization_amd.GNN_model.GCN import TricksComb
     args, model, data = _teacher(['--num_layers=3', '--use_special_split=0', '--whetherHasSE=000'], 'S-pl1M', dropout=0.1)
     assert model.model.model.type_trick == 'InitialBatchNorm' and data.x.shape[0] == 1_000_000
     res = {}
-    for fused in (True, False):
-        TricksComb.use_fused_trunk = fused
+    keep_masked = trunk.MASKED_GATHER
+    for mode in ('fused', 'masked', 'modular'):
+        TricksComb.use_fused_trunk = mode != 'modular'
+        trunk.MASKED_GATHER = mode == 'masked'
         try:
             model.train()
             model.zero_grad()
@@ -196,16 +228,18 @@ def test_fused_step_equals_modular_step_s_pl1m():
             ops._seed_override[:] = []
             loss = ops.nll_logsoftmax(out, data.y, data.train_mask)
             loss.backward()
-            res[fused] = (out.detach().clone(), loss.detach().clone(),
-                          {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+            res[mode] = (out.detach().clone(), loss.detach().clone(),
+                         {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
         finally:
             TricksComb.use_fused_trunk = True
-    torch.testing.assert_close(res[True][0], res[False][0], atol=5e-5, rtol=1e-5)
-    torch.testing.assert_close(res[True][1], res[False][1], atol=1e-6, rtol=1e-6)
-    assert set(res[True][2]) == set(res[False][2])
-    for k in res[True][2]:
-        a, b = res[True][2][k], res[False][2][k]
-        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-9, k
+            trunk.MASKED_GATHER = keep_masked
+    for mode, tol in (('fused', 1e-4), ('masked', 3e-4)):       # masked: fma accumulation + coefficient applied after the row sum
+        torch.testing.assert_close(res[mode][0], res['modular'][0], atol=5e-5, rtol=1e-5)
+        torch.testing.assert_close(res[mode][1], res['modular'][1], atol=1e-6, rtol=1e-6)
+        assert set(res[mode][2]) == set(res['modular'][2])
+        for k in res[mode][2]:
+            a, b = res[mode][2][k], res['modular'][2][k]
+            assert float((a - b).abs().max()) <= tol * float(b.abs().max()) + 1e-9, (mode, k)
 
 
 def _oracle_cfg(args):

@@ -77,7 +77,16 @@ def test_random_fused_epilogue_matches_composition(seed):
     cols = np.arange(d)
     tile, lane, k = cols // 256, (cols % 256) // 4, cols % 4
     got_mask = ((b[:, tile, k] >> lane.astype(np.uint64)) & np.uint64(1)).astype(bool)
-    assert np.array_equal(got_mask, (ref_act > 0).cpu().numpy())
+    want_mask = ref_act > 0                 # gradient passes where the activation is positive AND the dropout keeps the element
+    if p > 0:
+        want_mask &= ops.dropout_keep_mask((n, d), p, sd, DEV)
+    assert np.array_equal(got_mask, want_mask.cpu().numpy())
+    # reverse aggregation with the store backward applied to the gathered rows == cb_trunk_layer_bwd_f32 + plain reverse aggregation
+    g = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(DEV)
+    gr, _ = trunk._layer_bwd(g, bits, G.norm_in, None, False, p, sd, 0, 1 - alpha, alpha, False)
+    ref = G.spmm(gr, transpose=True)
+    got = G.spmm_masked(g, bits, G.norm_in, (1 - alpha) / (1 - p))
+    torch.testing.assert_close(got, ref, atol=2e-5, rtol=2e-5)
 
 
 @pytest.mark.parametrize('seed', range(16))
