@@ -298,8 +298,11 @@ __device__ __forceinline__ void limb_tile_step(const char* __restrict__ As, cons
   }
   bf16x8 a_hi[2], a_mid[2], a_lo[2];
   pr.dma_all();
+  static_assert(NH >= 1 && NH <= 4, "wave tiles of 64, 128 or 256 columns");
   CB_HALF(0)
   if constexpr (NH > 1) CB_HALF(1)
+  if constexpr (NH > 2) CB_HALF(2)
+  if constexpr (NH > 3) CB_HALF(3)
 #undef CB_HALF
 #undef CB_MFMA4
 }
