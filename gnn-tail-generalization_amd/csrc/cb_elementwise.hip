@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(kBlock) k_act_bwd(const float* __restrict__ g,
 // One wavefront per row per iteration, lane l owns columns 4l..4l+3 of each 256-wide tile (same mapping as
 // the forward epilogue, so mask word k is tested at bit l).
 // MODE 0: the layer kernel above.  MODE 1: trunk input stage  gy = (add + gm) * (act > 0); out = gy; colsum(gy).
-template <int MODE, bool OUT_BF16>
+template <int MODE, bool OUT_BF16, bool STORE = true>      // STORE = false: column sums only (no output row is written)
 __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ g, const unsigned long long* __restrict__ bits,
                                                       const float* __restrict__ act, const float* __restrict__ row_scale,
                                                       void* __restrict__ outv, float* __restrict__ gx0, int accumulate,
@@ -193,8 +193,8 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
       const float sc = row_scale ? row_scale[r] : 1.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) s[k] += gy[k];
-      if (!outv) continue;        // column sums only
-      if constexpr (OUT_BF16)
+      if constexpr (!STORE) continue;
+      else if constexpr (OUT_BF16)
         *reinterpret_cast<uint2*>((bf16_t*)outv + off) = pack4_bf16(gy[0] * sc, gy[1] * sc, gy[2] * sc, gy[3] * sc);
       else
         *reinterpret_cast<float4*>((float*)outv + off) = make_float4(gy[0] * sc, gy[1] * sc, gy[2] * sc, gy[3] * sc);
@@ -679,7 +679,8 @@ static int launch_trunk_bwd(int mode, int out_bf16, const float* g, const uint64
 #define CB_TB_ARGS g, (const unsigned long long*)bits, act, row_scale, out, gx0, accumulate, rows, (int)d, thresh, ks, seed, seed_dev, row0, c_act, c_mix, partial
   const dim3 grid((unsigned)nb), blk(kBlock);
   const size_t sh = kBlock * 4 * sizeof(float);
-  if (mode == 0 && out_bf16) hipLaunchKernelGGL((k_trunk_bwd<0, true>), grid, blk, sh, st, CB_TB_ARGS);
+  if (mode == 0 && !out) hipLaunchKernelGGL((k_trunk_bwd<0, false, false>), grid, blk, sh, st, CB_TB_ARGS);
+  else if (mode == 0 && out_bf16) hipLaunchKernelGGL((k_trunk_bwd<0, true>), grid, blk, sh, st, CB_TB_ARGS);
   else if (mode == 0) hipLaunchKernelGGL((k_trunk_bwd<0, false>), grid, blk, sh, st, CB_TB_ARGS);
   else hipLaunchKernelGGL((k_trunk_bwd<1, false>), grid, blk, sh, st, CB_TB_ARGS);
 #undef CB_TB_ARGS
