@@ -79,11 +79,11 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize('exchange,overlap,partition,argv,wire', [('halo', '1', 'edges', ARGV, 'f32'), ('halo', '0', 'rows', ARGV, 'f32'),
-                                                                  ('allgather', '0', 'rows', ARGV, 'f32'), ('halo', '1', 'edges', ARGV_BN, 'f32'),
-                                                                  ('halo', '1', 'edges', ARGV, 'bf16')],
-                         ids=['halo-overlap-edges', 'halo-singlepass-rows', 'allgather', 'batchnorm-halo-overlap', 'halo-bf16-wire'])
-def test_two_ranks_on_one_gpu_match_single_process(exchange, overlap, partition, argv, wire):
+@pytest.mark.parametrize('exchange,overlap,partition,argv,wire,world', [
+    ('halo', '1', 'edges', ARGV, 'f32', 2), ('halo', '0', 'rows', ARGV, 'f32', 2), ('allgather', '0', 'rows', ARGV, 'f32', 2),
+    ('halo', '1', 'edges', ARGV_BN, 'f32', 2), ('halo', '1', 'edges', ARGV, 'bf16', 2), ('halo', '1', 'edges', ARGV, 'f32', 3)],
+    ids=['halo-overlap-edges', 'halo-singlepass-rows', 'allgather', 'batchnorm-halo-overlap', 'halo-bf16-wire', 'three-ranks'])
+def test_two_ranks_on_one_gpu_match_single_process(exchange, overlap, partition, argv, wire, world):
     import contextlib
     import io
     sys.path.insert(0, ROOT)
@@ -108,7 +108,7 @@ def test_two_ranks_on_one_gpu_match_single_process(exchange, overlap, partition,
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, exchange, overlap, partition, argv, q, wire)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, exchange, overlap, partition, argv, q, wire)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
