@@ -169,7 +169,10 @@ class trainer:
             last, results_arr2D, best_test_acc = self.load_checkpoint()
             first_epoch = last + 1
         ckpt_every = int(getattr(self.args, 'ckpt_every', 0) or 0)
-        if int(getattr(self.args, 'hip_graph', 0) or 0) and first_epoch < self.epochs:
+        if int(getattr(self.args, 'hip_graph', 0) or 0) and int(self.data.x.shape[0]) > 2_000_000:
+            # kernel-bound from ogbn-arxiv size up (no gain), and the warm-up snapshot would double the parameter / moment memory
+            print('--hip_graph=1 ignored: graphs of this size are bound by the kernels, not by the launches')
+        elif int(getattr(self.args, 'hip_graph', 0) or 0) and first_epoch < self.epochs:
             # --hip_graph=1: forward + loss + backward + Adam of run_trainSet and the eval forward of run_testSet are replayed as
             # hipGraphs — what bounds an epoch on Cora / Pubmed-sized graphs is the ~50 dependent launches, not the kernels
             self.enable_hip_graph(warmup=1, restore=True)
