@@ -50,6 +50,8 @@ def parse():
     ap.add_argument('--extra', default='', help='further reference CLI flags, space separated (e.g. "--force_set_to_best_config=0 --type_trick=Residual")')
     ap.add_argument('--layers', type=int, default=3, help='num_layers (BASELINE config 2 = Pubmed, 2 layers)')
     ap.add_argument('--agg-dtype', default='f32', choices=['f32', 'bf16'], help='bf16 = build-extension storage of the gathered rows')
+    ap.add_argument('--check-n1', type=int, default=1, help='N > 1: rank 0 first computes the single-GPU training loss of the same model / seeds; '
+                                                             'the sharded forward must reproduce it (sharding.loss_matches_n1)')
     return ap.parse_args()
 
 
@@ -275,6 +277,90 @@ def reference_epoch_rate(t, args, epochs, sync):
             'head_tail_split_s': analyze_s}
 
 
+N1_SEEDS = list(range(424200, 424232))     # dropout seeds of the loss_matches_n1 forward (same on the single-GPU and the sharded side)
+
+
+def n1_reference(a, local_rank, rank):
+    """Rank 0: the single-GPU trainer on the whole graph -> (its initial state_dict + the training loss of one train-mode forward
+    with fixed dropout seeds, the loaded data).  Other ranks: (None, None).  Any failure (e.g. the whole graph does not fit next to
+    nothing else) turns the check off instead of ending the bench."""
+    if rank != 0:
+        return None, None
+    from gnn_tail_generalization_amd import ops
+    from gnn_tail_generalization_amd import trainer_node_classification as tnc
+    try:
+        args1 = make_args(a.dataset, [f'--manual_assign_GPU={local_rank}', f'--agg_dtype={a.agg_dtype}'] + a.extra.split(), se=a.se, layers=a.layers)
+        torch.manual_seed(0)
+        t1 = tnc.trainer(args1, 0)
+        t1.setup_teacherGNN()
+        sd = {k: v.detach().cpu().clone() for k, v in t1.teacherGNN.state_dict().items()}
+        t1.teacherGNN.train()
+        ops._seed_override[:] = list(N1_SEEDS)
+        with torch.no_grad():
+            loss = float(t1.training_loss())
+        ops._seed_override[:] = []
+        data = t1.data
+        t1.teacherGNN = t1.optimizer = None
+        del t1
+        torch.cuda.empty_cache()
+        return {'sd': sd, 'loss': loss}, data
+    except Exception as e:  # noqa: BLE001
+        ops._seed_override[:] = []
+        torch.cuda.empty_cache()
+        print(f'[bench] single-GPU reference for loss_matches_n1 failed: {type(e).__name__}: {e}', file=sys.stderr)
+        return None, None
+
+
+def sharding_report(t, n1, a, dev):
+    """Self-diagnosis of an N > 1 run, gathered from every rank: who took part, what each rank owns and exchanges, and whether the
+    sharded forward reproduces the single-GPU loss (same weights, same dropout seeds)."""
+    from gnn_tail_generalization_amd import dist as cbdist
+    from gnn_tail_generalization_amd import norms_hip, ops
+    world, rank = t.world, t.rank
+    sg = t.sgraph
+    plan = sg.f.plan
+    mine = torch.tensor([rank, sg.N, sg.f.E, plan.n_halo if plan is not None else 0,
+                         sg.f.interior.E if sg.f.interior is not None else sg.f.E,
+                         max(plan.recv_counts_all) if plan is not None and world > 1 else 0,
+                         max(plan.send_counts_all) if plan is not None and world > 1 else 0], dtype=torch.int64)
+    rows = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        if dist.get_backend() == 'gloo':
+            dist.all_gather(rows, mine)
+        else:
+            dr = [torch.zeros_like(mine, device=dev) for _ in range(world)]
+            dist.all_gather(dr, mine.to(dev))
+            rows = [r.cpu() for r in dr]
+    else:
+        rows = [mine]
+    rep = {'ranks_seen': [int(r[0]) for r in rows], 'rows_per_rank': [int(r[1]) for r in rows], 'edges_per_rank': [int(r[2]) for r in rows],
+           'halo_rows_per_rank': [int(r[3]) for r in rows], 'interior_edges_per_rank': [int(r[4]) for r in rows],
+           'max_rows_on_one_link_recv_send': [[int(r[5]), int(r[6])] for r in rows],
+           'partition': t.part.kind, 'exchange': sg.exchange_kind, 'overlap': bool(sg.overlap), 'wire': sg.wire,
+           'slices': plan.n_slices if plan is not None else 1, 'symmetric': bool(sg.symmetric),
+           'backend': dist.get_backend() if world > 1 or dist.is_initialized() else 'none'}
+    # loss_matches_n1: every rank must walk the same collectives, so the decision is broadcast
+    box = [None if n1 is None else {'loss': n1['loss'], 'sd': n1['sd']}]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    if box[0] is None:
+        rep['loss_matches_n1'] = None
+        return rep
+    keep = {k: v.detach().clone() for k, v in t.teacherGNN.state_dict().items()}
+    t.load_full_state_dict({k: v.to(dev) for k, v in box[0]['sd'].items()})
+    t.teacherGNN.train()
+    ops._seed_override[:] = list(N1_SEEDS)
+    with torch.no_grad(), norms_hip.row_sharding(t.group, t.global_nodes()):
+        loss = t.training_loss().detach().clone()
+    ops._seed_override[:] = []
+    cbdist._all_reduce(loss, group=t.group)
+    t.teacherGNN.load_state_dict(keep)
+    got, want = float(loss), box[0]['loss']
+    rep['loss_n1'], rep['loss_sharded'] = want, got
+    rep['loss_matches_n1'] = bool(abs(got - want) <= 1e-4 * max(1.0, abs(want)))
+    return rep
+
+
 def main():
     a = parse()
     # Libraries (RCCL banner, rocm notices) write to the C stdout and flush it at exit, i.e. AFTER Python's
@@ -306,13 +392,19 @@ def main():
     from gnn_tail_generalization_amd import trainer_node_classification as tnc
     args = make_args(a.dataset, [f'--manual_assign_GPU={local_rank}', f'--agg_dtype={a.agg_dtype}'] + a.extra.split(), se=a.se, layers=a.layers)
     torch.manual_seed(0)
+    n1 = None
     with contextlib.redirect_stdout(io.StringIO()):
         if sharded:
             from gnn_tail_generalization_amd import dist as cbdist
-            t = cbdist.ShardedTrainer(args, 0)
+            data0 = None
+            if a.check_n1 and a.se == '000':
+                n1, data0 = n1_reference(a, local_rank, rank)          # rank 0: single-GPU loss on the whole graph; its data is reused below
+            t = cbdist.ShardedTrainer(args, 0, data=data0)
+            del data0
         else:
             t = tnc.trainer(args, 0)
         t.setup_teacherGNN()
+    sharding = sharding_report(t, n1, a, dev) if sharded else None
     graph_obj = t.graph()
     n_nodes, n_edges = t.global_nodes(), t.global_edges()
     L = args.num_layers
@@ -342,6 +434,8 @@ def main():
         sync()
     else:
         graph_obj.profile = []
+    if sharded:
+        graph_obj.exchange_log = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = t.train_step()
@@ -371,6 +465,22 @@ def main():
     if a.ref_epochs > 0 and not sharded and not use_graph:
         ref_epoch = reference_epoch_rate(t, args, a.ref_epochs, sync)
     if sharded:
+        xlog, graph_obj.exchange_log = graph_obj.exchange_log, None
+        xm = [e0.elapsed_time(e1) for e0, e1 in xlog]
+        stat = torch.tensor([sum(xm) / max(len(xm), 1), float(len(xm)) / max(a.steps, 1), sum(spmm_ms) / max(a.steps, 1)], device=dev, dtype=torch.float64)
+        allst = [torch.zeros_like(stat) for _ in range(world)]
+        if world > 1:
+            if dist.get_backend() == 'gloo':
+                hs = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(hs, stat.cpu())
+                allst = hs
+            else:
+                dist.all_gather(allst, stat)
+        else:
+            allst = [stat]
+        sharding['exchange_span_ms_per_rank'] = [round(float(v[0]), 3) for v in allst]     # first send issued -> last slice waited for, per aggregation
+        sharding['exchanges_per_step'] = [round(float(v[1]), 2) for v in allst]
+        sharding['local_aggregation_kernel_ms_per_step_per_rank'] = [round(float(v[2]), 3) for v in allst]
         dist.barrier()
         dist.destroy_process_group()
     if rank != 0:
@@ -408,6 +518,8 @@ def main():
                      'fused_epilogue_bytes_per_launch': avg_extra, 'achieved_incl_fused_epilogue': achieved_incl},
     }
     out['peak_mem_gb'] = peak_mem / 2 ** 30
+    if sharding is not None:
+        out['sharding'] = sharding
     if ref_epoch is not None:
         out.update(ref_epoch)
     if a.cpu_baseline and world == 1 and not sharded:

@@ -315,6 +315,28 @@ __global__ void __launch_bounds__(kBlock) k_gather_rows(const float* __restrict_
   }
 }
 
+// The same row pack with the rows narrowed to bf16 (round-to-nearest-even) on their way out: the bf16 halo wire of the node-sharded
+// exchange leaves the pack kernel ready to send (no separate conversion pass over the packed rows).
+__global__ void __launch_bounds__(kBlock) k_gather_rows_bf16(const float* __restrict__ src, int64_t ld, const int64_t* __restrict__ idx,
+                                                             int64_t n_idx, int d, bf16_t* __restrict__ out, int vec_ok) {
+  if (vec_ok) {
+    const int q = d >> 2;
+    const int64_t total = n_idx * q;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t r = i / q;
+      const int c = (int)(i - r * q) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(src + idx[r] * ld + c);
+      *reinterpret_cast<uint2*>(out + r * d + c) = pack4_bf16(v.x, v.y, v.z, v.w);
+    }
+  } else {
+    const int64_t total = n_idx * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t r = i / d;
+      out[i] = f32_to_bf16(src[idx[r] * ld + (i - r * d)]);
+    }
+  }
+}
+
 // out[c] = sum_p partial[p][c]: one block per column, strided partial sums per thread then a fixed-order
 // LDS tree — the result does not depend on scheduling.
 __global__ void __launch_bounds__(kBlock) k_colsum_finish(const float* __restrict__ partial, int nparts, int d, float* __restrict__ out) {
@@ -771,6 +793,18 @@ extern "C" int cb_gather_rows_f32(const float* src, int64_t ld, const int64_t* i
   const int vec_ok = aligned16(src) && aligned16(out) && d % 4 == 0 && ld % 4 == 0;
   const int64_t work = vec_ok ? n_idx * (d / 4) : n_idx * d;
   hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(work)), dim3(kBlock), 0, (hipStream_t)stream, src, ld, idx, n_idx, (int)d, out, vec_ok);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
+extern "C" int cb_gather_rows_bf16_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, uint16_t* out,
+                                       void* stream) {
+  CB_CHECK_ARG(n_idx >= 0 && d >= 0 && d < (1 << 24) && ld >= d, CB_E_INVALID, "cb_gather_rows_bf16_f32: bad size");
+  if (n_idx == 0 || d == 0) return CB_OK;
+  CB_CHECK_ARG(src && idx && out, CB_E_INVALID, "cb_gather_rows_bf16_f32: null pointer");
+  const int vec_ok = aligned16(src) && ((uintptr_t)out % 8 == 0) && d % 4 == 0 && ld % 4 == 0;
+  const int64_t work = vec_ok ? n_idx * (d / 4) : n_idx * d;
+  hipLaunchKernelGGL(k_gather_rows_bf16, dim3(grid_for(work)), dim3(kBlock), 0, (hipStream_t)stream, src, ld, idx, n_idx, (int)d, out, vec_ok);
   CB_LAUNCH_CHECK();
   return CB_OK;
 }

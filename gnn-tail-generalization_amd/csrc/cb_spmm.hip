@@ -824,30 +824,63 @@ extern "C" int cb_spmm_csr_fused_bf16_f32(const int32_t* rowptr, const int32_t* 
   return spmm_fused_impl(1, nullptr, 0, col_flags, CB_FUSED_ARGS);
 }
 
-// bf16-stored source rows, fp32 accumulation and output (build extension: BASELINE config 2)
-extern "C" int cb_spmm_csr_bf16_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const uint16_t* h, int64_t ld_h,
-                                    int64_t d, const float* row_scale, const float* bias, int relu, float* out, int64_t ld_out,
-                                    int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
-                                    const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
-  CB_CHECK_ARG(N >= 0 && E >= 0 && d >= 0, CB_E_INVALID, "cb_spmm_csr_bf16_f32: negative size");
-  CB_CHECK_ARG(N < INT32_MAX && E < INT32_MAX && d < (1 << 20), CB_E_RANGE, "cb_spmm_csr_bf16_f32: size exceeds the int32 contract");
+// bf16-stored source rows, fp32 accumulation and output (build extension: BASELINE config 2; also the halo pass of the node-sharded
+// aggregation when the halo rows crossed the links as bf16: acc_init = the interior-column sums, dist.py)
+static int spmm_bf16_impl(const char* who, const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const uint16_t* h,
+                          int64_t ld_h, int64_t d, const float* row_scale, const float* bias, int relu, const float* acc_init, int64_t ld_init,
+                          float* out, int64_t ld_out, int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
+                          const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(N >= 0 && E >= 0 && d >= 0, CB_E_INVALID, "%s: negative size", who);
+  CB_CHECK_ARG(N < INT32_MAX && E < INT32_MAX && d < (1 << 20), CB_E_RANGE, "%s: size exceeds the int32 contract", who);
   if (N == 0 || d == 0) return CB_OK;
-  CB_CHECK_ARG(rowptr && h && out && (E == 0 || col), CB_E_INVALID, "cb_spmm_csr_bf16_f32: null pointer");
-  CB_CHECK_ARG(ld_h >= d && ld_out >= d, CB_E_INVALID, "cb_spmm_csr_bf16_f32: leading dimension smaller than d");
-  CB_CHECK_ARG(hub_T > 0 && n_hubs >= 0 && n_chunks >= 0, CB_E_INVALID, "cb_spmm_csr_bf16_f32: bad hub plan");
+  CB_CHECK_ARG(rowptr && h && out && (E == 0 || col), CB_E_INVALID, "%s: null pointer", who);
+  CB_CHECK_ARG(ld_h >= d && ld_out >= d && (!acc_init || ld_init >= d), CB_E_INVALID, "%s: leading dimension smaller than d", who);
+  CB_CHECK_ARG(hub_T > 0 && n_hubs >= 0 && n_chunks >= 0, CB_E_INVALID, "%s: bad hub plan", who);
   CB_CHECK_ARG(n_hubs == 0 || (hub_rows && hub_chunk_ptr && ws && ws_bytes >= cb_spmm_workspace_bytes(n_chunks, d)),
-               CB_E_WORKSPACE, "cb_spmm_csr_bf16_f32: hub plan given but workspace missing/too small");
-  const bool al8 = ((uintptr_t)h % 8 == 0) && ((uintptr_t)out % 16 == 0) && (ld_h % 4 == 0) && (ld_out % 4 == 0) && (d % 4 == 0);
-  CB_CHECK_ARG(!col_flags || (al8 && d % 256 == 0), CB_E_INVALID, "cb_spmm_csr_bf16_f32: flagged column ids need d %% 256 == 0 and 8-byte aligned rows");
-  Epilogue ep{row_scale, bias, relu, nullptr, 0, col_flags};
+               CB_E_WORKSPACE, "%s: hub plan given but workspace missing/too small", who);
+  const bool ini16 = !acc_init || (((uintptr_t)acc_init % 16 == 0) && ld_init % 4 == 0);
+  const bool ini8 = !acc_init || (((uintptr_t)acc_init % 8 == 0) && ld_init % 2 == 0);
+  const bool al8 = ((uintptr_t)h % 8 == 0) && ((uintptr_t)out % 16 == 0) && (ld_h % 4 == 0) && (ld_out % 4 == 0) && (d % 4 == 0) && ini16;
+  CB_CHECK_ARG(!col_flags || (al8 && d % 256 == 0), CB_E_INVALID, "%s: flagged column ids need d %% 256 == 0 and 8-byte aligned rows", who);
+  Epilogue ep{row_scale, bias, relu, acc_init, ld_init, col_flags};
   hipStream_t st = (hipStream_t)stream;
   if (n_hubs == 0) hub_T = INT32_MAX;
   const bf16_t* hb = (const bf16_t*)h;
-  const bool al4 = ((uintptr_t)h % 4 == 0) && ((uintptr_t)out % 8 == 0) && (ld_h % 2 == 0) && (ld_out % 2 == 0) && (d % 2 == 0);
+  const bool al4 = ((uintptr_t)h % 4 == 0) && ((uintptr_t)out % 8 == 0) && (ld_h % 2 == 0) && (ld_out % 2 == 0) && (d % 2 == 0) && ini8;
   float* partial = (float*)ws;
   if (al8 && d >= 256)
     return launch_spmm<4, false, bf16_t>(rowptr, col, N, hb, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st);
   if (al4 && d >= 128)
     return launch_spmm<2, false, bf16_t>(rowptr, col, N, hb, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st);
   return launch_spmm<1, false, bf16_t>(rowptr, col, N, hb, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st);
+}
+
+extern "C" int cb_spmm_csr_bf16_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const uint16_t* h, int64_t ld_h,
+                                    int64_t d, const float* row_scale, const float* bias, int relu, float* out, int64_t ld_out,
+                                    int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
+                                    const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
+  return spmm_bf16_impl("cb_spmm_csr_bf16_f32", rowptr, col, col_flags, N, E, h, ld_h, d, row_scale, bias, relu, nullptr, 0, out, ld_out, hub_T,
+                        n_hubs, n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, stream);
+}
+
+// cb_spmm_csr_acc_f32 over bf16-stored source rows: the halo-column pass when the halo rows travelled as bf16 (the wire buffer
+// is read as it arrived, no widening pass).  acc_init may alias out.
+extern "C" int cb_spmm_csr_acc_bf16_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const uint16_t* h,
+                                        int64_t ld_h, int64_t d, const float* row_scale, const float* bias, int relu, const float* acc_init,
+                                        int64_t ld_init, float* out, int64_t ld_out, int32_t hub_T, int32_t n_hubs, int32_t n_chunks,
+                                        const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(acc_init != nullptr || N == 0 || d == 0, CB_E_INVALID, "cb_spmm_csr_acc_bf16_f32: acc_init is null");
+  return spmm_bf16_impl("cb_spmm_csr_acc_bf16_f32", rowptr, col, col_flags, N, E, h, ld_h, d, row_scale, bias, relu, acc_init, ld_init, out, ld_out,
+                        hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, stream);
+}
+
+// cb_spmm_csr_fused_acc_f32 over bf16-stored source rows (fused trunk store on top of the interior sums, bf16 wire buffer)
+extern "C" int cb_spmm_csr_fused_acc_bf16_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int32_t col_flags,
+                                              int64_t N, int64_t E, const uint16_t* h, int64_t ld_h, int64_t d, const float* row_scale,
+                                              const float* bias, const float* mix_src, int64_t ld_mix, float c_act, float c_mix, float drop_p,
+                                              uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, float* out_act,
+                                              int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_T, int32_t n_hubs, int32_t n_chunks,
+                                              const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(acc_init != nullptr || N == 0, CB_E_INVALID, "cb_spmm_csr_fused_acc_bf16_f32: acc_init is null");
+  return spmm_fused_impl(1, acc_init, ld_init, col_flags, CB_FUSED_ARGS);
 }

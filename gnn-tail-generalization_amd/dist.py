@@ -12,16 +12,23 @@ and builds its row block from those — no rank ever builds the whole graph's CS
 Exchange (the only data-path collective) before each aggregation, 'halo' form (default): a rank receives
 exactly the remote rows its edges reference.  Per orientation a HaloPlan is built once — unique remote
 column ids grouped by owner, owners learn which rows to send through one all-to-all of counts and one of
-ids.  The row block is split by column owner into an INTERIOR CSR (columns = local rows) and a HALO CSR
-(columns = slots of the receive buffer), and the aggregation runs as
+ids.  The row block is split by column owner into an INTERIOR CSR (columns = local rows) and HALO CSRs
+(columns = slots of a receive buffer), and the aggregation runs as a pipeline of K time slices
+(COLDBREW_HALO_SLICES; slice k = the halo rows that live in the k-th row chunk of their owner's block, all
+peers at once, so every xGMI link carries 1/K of its traffic per slice — the links of a full mesh work in
+parallel, which a peer-by-peer order would give up):
 
-    pack rows for the peers -> all_to_all_single(async)      [RCCL stream, xGMI]
-    interior pass: raw sums over local columns                [compute stream, overlaps the exchange]
-    wait -> halo pass: starts from the interior sums, applies the epilogue once (cb_spmm_csr_acc_f32)
+    for k: [producer of row chunk k, e.g. the layer GEMM] -> pack slice k -> all_to_all_single(async)   [RCCL stream, xGMI]
+    interior pass: raw sums over local columns                [compute stream, under the exchange]
+    for k: wait(k) -> halo pass k on top of the running sums (cb_spmm_csr_acc_f32); the last one applies the epilogue
 
-COLDBREW_OVERLAP=0 keeps the single-pass form (one CSR over [local rows | halo rows] after a blocking
-exchange); COLDBREW_EXCHANGE=allgather the all-gather baseline (equal-row partition only); COLDBREW_HALO_WIRE=bf16
-(opt-in, outside the 1e-4 parity) halves the bytes on the links by sending the halo rows as bfloat16.
+so pack k+1, the GEMM rows of chunk k+1 and halo pass k-1 all run while slice k is on the links; what stays
+exposed is the first chunk's producer + pack and the last slice's halo pass.  K = 1 is the two-pass form of
+round 2 (bit for bit).  COLDBREW_OVERLAP=0 keeps the single-pass form (one CSR over [local rows | halo rows]
+after a blocking exchange); COLDBREW_EXCHANGE=allgather the all-gather baseline (equal-row partition only);
+COLDBREW_HALO_WIRE=bf16 (opt-in, outside the 1e-4 parity) halves the bytes on the links: the pack kernel
+writes bf16 (cb_gather_rows_bf16_f32) and the halo passes read the wire buffer as it arrived
+(cb_spmm_csr_acc_bf16_f32) — no conversion pass on either side.
 The backward of the aggregation is the same exchange on the gradient followed by the reverse-orientation
 passes (own plan; aliasing the forward one when the edge multiset is symmetric on every rank).  Everything
 else is row-local; small all-reduces cover the replicated weights' gradients, the loss numerator, sum(E^2)
@@ -162,12 +169,14 @@ class HipCompute:
         from .graph import CSRGraph
         return CSRGraph.from_pairs(rows, cols, n_rows, n_cols)
 
-    def spmm(self, g, h, row_scale=None, bias=None, relu=False, acc_init=None, profile=None):
+    def spmm(self, g, h, row_scale=None, bias=None, relu=False, acc_init=None, profile=None, out=None):
         g.profile = profile
-        return g.spmm(h, row_scale=row_scale, bias=bias, relu=relu, acc_init=acc_init)
+        return g.spmm(h, row_scale=row_scale, bias=bias, relu=relu, acc_init=acc_init, out=out)
 
-    def pack_rows(self, x, idx):
+    def pack_rows(self, x, idx, wire='f32'):
         from .ops import gather_rows_by_index
+        if wire == 'bf16' and x.dtype == torch.float32:                                  # narrowed by the pack kernel itself
+            return gather_rows_by_index(x, idx, out_bf16=True)
         if x.dtype == torch.bfloat16 and x.shape[1] % 2 == 0 and x.is_contiguous():     # bf16 rows move as packed 32-bit words
             return gather_rows_by_index(x.view(torch.float32), idx).view(torch.bfloat16)
         return gather_rows_by_index(x, idx)
@@ -180,40 +189,81 @@ class HipCompute:
         return deg.to(torch.float32).clamp_(min=1).pow_(-0.5)        # [n_local] vector (GCN.py:206-208,243-245)
 
 
+def chunk_bounds(lo, hi, k):
+    """k+1 ascending global row ids cutting the block [lo, hi) into k nearly equal row chunks."""
+    n = hi - lo
+    return [lo + (n * i) // k for i in range(k + 1)]
+
+
+def default_slices(n_halo_rows, d=256):
+    """Time slices of the exchange pipeline: COLDBREW_HALO_SLICES, else 4 once an aggregation moves >= 64 MiB of halo rows per rank
+    (below that a slice's kernels are launch-sized and the split only adds passes), else 1."""
+    env = os.environ.get('COLDBREW_HALO_SLICES')
+    if env:
+        return max(1, int(env))
+    return 4 if int(n_halo_rows) * d * 4 >= (64 << 20) else 1
+
+
 class HaloPlan:
-    """Who sends which rows to whom for one CSR orientation (built once per graph)."""
+    """Who sends which rows to whom for one CSR orientation (built once per graph), cut into n_slices time slices: slice k
+    holds the requested rows that live in the k-th row chunk of their OWNER's block (chunk_bounds), so an owner can ship
+    slice k as soon as rows of chunk k exist and every peer link carries about 1/n_slices of its bytes per slice.
 
-    def __init__(self, uniq_remote, part, group=None):
+    Requester side: recv_counts[k][q] rows arrive from peer q in slice k (ascending ids); slice_of / slot_of map a position in
+    `uniq_remote` to (slice, row of that slice's receive buffer).  Owner side: send_idx[k] = my local rows of slice k in
+    per-destination order, send_counts[k][q] of them go to peer q."""
+
+    def __init__(self, uniq_remote, part, group=None, n_slices=1):
         """uniq_remote: ascending unique remote column ids this rank's edges reference (= grouped by owner)."""
-        P = part.world
+        P, K = part.world, max(1, int(n_slices))
         dev = uniq_remote.device
+        self.n_slices = K
         self.n_local, self.n_halo = part.n_local, int(uniq_remote.numel())
-        recv_counts = torch.bincount(part.owner(uniq_remote), minlength=P)[:P]
-        send_counts = torch.empty_like(recv_counts)
+        # segment (q, k) = ids in chunk k of owner q; boundaries ascending over (q major, k minor)
+        bnd = [b for q in range(P) for b in chunk_bounds(part.lo(q), part.hi(q), K)[:-1]] + [part.N]
+        pos = torch.searchsorted(uniq_remote, torch.tensor(bnd, dtype=torch.int64, device=dev))       # [P*K + 1] positions in uniq
+        cnt = (pos[1:] - pos[:-1]).view(P, K)                                                          # cnt[q, k]
+        snd = torch.empty_like(cnt)
         if P > 1:
-            _all_to_all_single(send_counts, recv_counts, group=group)    # how many rows each peer wants from me
+            _all_to_all_single(snd.view(-1), cnt.contiguous().view(-1), group=group)                   # row q = what peer q wants from me
         else:
-            send_counts.copy_(recv_counts)
-        self.recv_counts = [int(v) for v in recv_counts.tolist()]
-        self.send_counts = [int(v) for v in send_counts.tolist()]
-        wanted = torch.empty(sum(self.send_counts), dtype=torch.int64, device=dev)
+            snd.copy_(cnt)
+        cnt_h, snd_h = cnt.tolist(), snd.tolist()
+        self.recv_counts = [[int(cnt_h[q][k]) for q in range(P)] for k in range(K)]
+        self.send_counts = [[int(snd_h[q][k]) for q in range(P)] for k in range(K)]
+        self.n_halo_slice = [sum(c) for c in self.recv_counts]
+        per_peer_out, per_peer_in = [sum(snd_h[q]) for q in range(P)], [sum(cnt_h[q]) for q in range(P)]
+        wanted = torch.empty(sum(per_peer_out), dtype=torch.int64, device=dev)
         if P > 1:
-            _all_to_all_single(wanted, uniq_remote, self.send_counts, self.recv_counts, group=group)
-        self.send_idx = (wanted - part.lo()).contiguous()                  # my local rows, in per-destination order
-        if self.send_idx.numel() and (int(self.send_idx.min()) < 0 or int(self.send_idx.max()) >= self.n_local):
+            _all_to_all_single(wanted, uniq_remote, per_peer_out, per_peer_in, group=group)            # peer-major, ascending per peer
+        local = wanted - part.lo()
+        if local.numel() and (int(local.min()) < 0 or int(local.max()) >= self.n_local):
             raise RuntimeError('halo plan: a peer requested a row this rank does not own')
-
-
-class _WidenOnWait:
-    """Work handle of a bf16-wire exchange: wait() = the collective's wait + widening of the received rows into the fp32 buffer
-    the halo pass reads."""
-
-    def __init__(self, inner, wire_in, out):
-        self.inner, self.wire_in, self.out = inner, wire_in, out
-
-    def wait(self):
-        self.inner.wait()
-        self.out.copy_(self.wire_in)
+        # wanted is laid out (peer q, slice k); the send lists are (slice k, peer q)
+        starts, off = {}, 0
+        for q in range(P):
+            for k in range(K):
+                starts[(q, k)] = off
+                off += snd_h[q][k]
+        mine = chunk_bounds(part.lo(), part.hi(), K)
+        self.chunks = [(mine[k] - part.lo(), mine[k + 1] - part.lo()) for k in range(K)]              # local row range of chunk k
+        self.send_idx = []
+        for k in range(K):
+            pieces = [local[starts[(q, k)]: starts[(q, k)] + snd_h[q][k]] for q in range(P)]
+            idx = torch.cat(pieces).contiguous() if pieces else local[:0]
+            r0, r1 = self.chunks[k]
+            if idx.numel() and (int(idx.min()) < r0 or int(idx.max()) >= r1):
+                raise RuntimeError('halo plan: the peers cut their requests at other chunk boundaries than this rank')
+            self.send_idx.append(idx)
+        # requester side: position j of uniq_remote -> (slice, slot in that slice's receive buffer [peer-major, ascending])
+        seg = torch.bucketize(torch.arange(self.n_halo, device=dev), pos[1:], right=True)              # segment q*K + k of position j
+        roff = torch.cumsum(cnt, 0) - cnt                                                              # rows of peers < q in slice k
+        base = (roff.reshape(-1) - pos[:-1])
+        self.slice_of = seg % K
+        self.slot_of = torch.arange(self.n_halo, device=dev) + base[seg] if self.n_halo else seg
+        # K = 1 views (the blocking / single-pass forms)
+        self.recv_counts_all, self.send_counts_all = per_peer_in, per_peer_out
+        self.send_idx_all = local.contiguous()
 
 
 class _Orientation:
@@ -225,44 +275,64 @@ class ShardedGraph:
     """Row block [lo, hi) of both CSR orientations + local degree norms + the exchange plans.
     Quacks like graph.CSRGraph for GCNConv / ops.aggregate / the fused trunk."""
 
-    def __init__(self, edge_index, n_nodes, part, group=None, exchange='halo', overlap=True, compute=None, wire='f32'):
+    def __init__(self, edge_index, n_nodes, part, group=None, exchange='halo', overlap=True, compute=None, wire='f32', n_slices=None,
+                 local_edges=None):
+        """edge_index: the whole [2, E] edge list (every rank filters its own blocks), or None with
+        local_edges = (fwd [2, Ef], rev [2, Er]): the edges whose DESTINATION / SOURCE this rank owns, as scattered by the
+        loading rank (ShardedTrainer: no rank but the loader ever holds the whole graph); E_global is then all-reduced."""
         self.part, self.group = part, group
         self.exchange_kind = exchange
         if wire not in ('f32', 'bf16'):
             raise ValueError(f'unknown halo wire format {wire!r}')
-        # 'bf16' (opt-in, COLDBREW_HALO_WIRE=bf16): halo rows travel rounded to bfloat16 (RNE) and are widened on arrival — half the
-        # bytes on the xGMI links, the bound of the sharded step; the local rows stay fp32.  NOT within the 1e-4 logits parity
-        # (2^-9 relative rounding of every remote neighbour row), hence never the default.
+        # 'bf16' (opt-in, COLDBREW_HALO_WIRE=bf16): halo rows leave the pack kernel rounded to bfloat16 (RNE) and the halo passes
+        # read them as they arrive — half the bytes on the xGMI links, the bound of the sharded step; the local rows stay fp32.
+        # NOT within the 1e-4 logits parity (2^-9 relative rounding of every remote neighbour row), hence never the default.
         self.wire = wire if exchange == 'halo' else 'f32'
         self.compute = compute if compute is not None else HipCompute()
-        self.N_global, self.E_global = int(n_nodes), int(edge_index.shape[1])
+        self.N_global = int(n_nodes)
         self.row_offset = part.lo()
         lo, hi = part.lo(), part.hi()
         self.N = hi - lo
         self.profile = None
+        self.exchange_log = None        # bench.py --gpus N sets a list: (event before the first send, event after the last wait) per aggregation
         if exchange not in ('halo', 'allgather'):
             raise ValueError(f'unknown exchange {exchange!r}')
         if exchange == 'allgather' and part.kind != 'rows':
             raise ValueError("the all-gather baseline needs the equal-row partition (COLDBREW_PARTITION=rows)")
         self.overlap = bool(overlap) and exchange == 'halo' and part.world > 1
-        src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
-        bad = int(((src < 0) | (src >= n_nodes) | (dst < 0) | (dst >= n_nodes)).sum()) if src.numel() else 0
-        if bad:
-            raise ValueError(f'edge_index has {bad} edges with an endpoint outside [0, {n_nodes})')
-        mf = (dst >= lo) & (dst < hi)                   # forward block: rows = destinations I own, columns = sources (GCN.py:238)
-        mb = (src >= lo) & (src < hi)                   # reverse block: rows = sources I own, columns = destinations
-        rf, cf = dst[mf] - lo, src[mf]
-        rb, cb = src[mb] - lo, dst[mb]
-        del mf, mb
+        self._n_slices_req = n_slices
+        if local_edges is None:
+            src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
+            bad = int(((src < 0) | (src >= n_nodes) | (dst < 0) | (dst >= n_nodes)).sum()) if src.numel() else 0
+            if bad:
+                raise ValueError(f'edge_index has {bad} edges with an endpoint outside [0, {n_nodes})')
+            mf = (dst >= lo) & (dst < hi)                   # forward block: rows = destinations I own, columns = sources (GCN.py:238)
+            mb = (src >= lo) & (src < hi)                   # reverse block: rows = sources I own, columns = destinations
+            rf, cf = dst[mf] - lo, src[mf]
+            rb, cb = src[mb] - lo, dst[mb]
+            del mf, mb
+            self.E_global = int(edge_index.shape[1])
+        else:
+            ef, eb = local_edges
+            rf, cf = ef[1].to(torch.int64) - lo, ef[0].to(torch.int64)
+            rb, cb = eb[0].to(torch.int64) - lo, eb[1].to(torch.int64)
+            for r_, c_ in ((rf, cf), (rb, cb)):
+                if r_.numel() and (int(r_.min()) < 0 or int(r_.max()) >= self.N or int(c_.min()) < 0 or int(c_.max()) >= n_nodes):
+                    raise ValueError('local_edges: an edge does not belong to this rank\'s row block / lies outside the graph')
+            tot = torch.tensor([int(rf.numel())], dtype=torch.int64, device=rf.device)
+            if part.world > 1:
+                _all_reduce(tot, group=group)
+            self.E_global = int(tot.item())
         self.E = int(rf.numel())
         in_deg = torch.bincount(rf, minlength=self.N)[:self.N]
         out_deg = torch.bincount(rb, minlength=self.N)[:self.N]
+        self.in_deg = in_deg
         self.norm_in = self.compute.deg_norm(in_deg)
         self.norm_out = self.compute.deg_norm(out_deg)
-        nz = torch.tensor([int((in_deg == 0).sum())], dtype=torch.int64, device=src.device)
+        nz = torch.tensor([int((in_deg == 0).sum())], dtype=torch.int64, device=rf.device)
         # one global decision each, or the ranks would disagree on which collectives follow
         same = bool(rf.numel() == rb.numel() and torch.equal(torch.sort(rf * n_nodes + cf)[0], torch.sort(rb * n_nodes + cb)[0]))
-        flag = torch.tensor([1 if same else 0], dtype=torch.int64, device=src.device)
+        flag = torch.tensor([1 if same else 0], dtype=torch.int64, device=rf.device)
         if part.world > 1:
             _all_reduce(nz, group=group)
             _all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
@@ -282,10 +352,24 @@ class ShardedGraph:
             return o
         remote = (cols < lo) | (cols >= hi)
         uniq, inv = torch.unique(cols[remote], return_inverse=True)       # ascending ids = grouped by owner
-        o.plan = HaloPlan(uniq, part, self.group)
+        K = 1
+        if self.overlap:
+            # every rank must cut its plans into the same number of slices: decide on the largest halo of the group
+            if self._n_slices_req is not None:
+                K = max(1, int(self._n_slices_req))
+            else:
+                nh = torch.tensor([int(uniq.numel())], dtype=torch.int64, device=uniq.device)
+                if part.world > 1:
+                    _all_reduce(nh, op=dist.ReduceOp.MAX, group=self.group)
+                K = default_slices(int(nh.item()))
+        o.plan = HaloPlan(uniq, part, self.group, K)
         if self.overlap:
             o.interior = self.compute.csr(rows[~remote], cols[~remote] - lo, self.N, self.N)
-            o.halo = self.compute.csr(rows[remote], inv, self.N, max(o.plan.n_halo, 1))
+            rr, sl, slot = rows[remote], o.plan.slice_of[inv], o.plan.slot_of[inv]
+            o.halo = []
+            for k in range(K):
+                m = sl == k if K > 1 else slice(None)
+                o.halo.append(self.compute.csr(rr[m], slot[m], self.N, max(o.plan.n_halo_slice[k], 1)))
         else:
             new_col = cols - lo
             new_col[remote] = self.N + inv
@@ -320,50 +404,83 @@ class ShardedGraph:
         plan = o.plan
         ext = torch.empty((plan.n_local + plan.n_halo, x_local.shape[1]), dtype=x_local.dtype, device=x_local.device)
         ext[:plan.n_local] = x_local
-        send = self.compute.pack_rows(x_local, plan.send_idx)
         if self.wire == 'bf16' and x_local.dtype == torch.float32:
+            send = self.compute.pack_rows(x_local, plan.send_idx_all, 'bf16')
             wire_in = torch.empty((plan.n_halo, x_local.shape[1]), dtype=torch.bfloat16, device=x_local.device)
-            _all_to_all_single(wire_in.view(torch.uint8), send.to(torch.bfloat16).view(torch.uint8), plan.recv_counts, plan.send_counts,
-                               group=self.group)
-            ext[plan.n_local:] = wire_in
+            _all_to_all_single(wire_in.view(torch.uint8), send.view(torch.uint8), plan.recv_counts_all, plan.send_counts_all, group=self.group)
+            ext[plan.n_local:] = wire_in          # the single-pass CSR reads ONE fp32 matrix: widened here (the overlapped form never widens)
             return ext
-        _all_to_all_single(ext[plan.n_local:], send, plan.recv_counts, plan.send_counts, group=self.group)
+        send = self.compute.pack_rows(x_local, plan.send_idx_all)
+        _all_to_all_single(ext[plan.n_local:], send, plan.recv_counts_all, plan.send_counts_all, group=self.group)
         return ext
 
-    def start_halo(self, x_local, transpose=False):
-        """Overlapped form, first half: pack + asynchronous all-to-all.  Returns (receive buffer, work handle, send buffer)."""
-        plan = (self.b if transpose else self.f).plan
-        send = self.compute.pack_rows(x_local, plan.send_idx)
-        recv = torch.empty((max(plan.n_halo, 1), x_local.shape[1]), dtype=x_local.dtype, device=x_local.device)
-        if self.wire == 'bf16' and x_local.dtype == torch.float32:
-            send = send.to(torch.bfloat16)
-            wire_in = torch.empty((plan.n_halo, x_local.shape[1]), dtype=torch.bfloat16, device=x_local.device)
-            inner = _all_to_all_single(wire_in.view(torch.uint8), send.view(torch.uint8), plan.recv_counts, plan.send_counts,
-                                       group=self.group, async_op=True)
-            return recv, _WidenOnWait(inner, wire_in, recv[:plan.n_halo]), send
-        work = _all_to_all_single(recv[:plan.n_halo], send, plan.recv_counts, plan.send_counts, group=self.group, async_op=True)
+    def _send_slice(self, x_local, plan, k):
+        """pack slice k -> asynchronous all-to-all.  Returns (receive buffer, work handle, send buffer kept alive)."""
+        bf16 = self.wire == 'bf16' and x_local.dtype == torch.float32
+        send = self.compute.pack_rows(x_local, plan.send_idx[k], 'bf16' if bf16 else 'f32')
+        n_k = plan.n_halo_slice[k]
+        recv = torch.empty((max(n_k, 1), x_local.shape[1]), dtype=send.dtype, device=x_local.device)
+        if send.dtype == torch.bfloat16:       # moves as bytes: not every backend knows bfloat16
+            work = _all_to_all_single(recv[:n_k].view(torch.uint8), send.view(torch.uint8), plan.recv_counts[k], plan.send_counts[k],
+                                      group=self.group, async_op=True)
+        else:
+            work = _all_to_all_single(recv[:n_k], send, plan.recv_counts[k], plan.send_counts[k], group=self.group, async_op=True)
         return recv, work, send
 
-    def aggregate_start(self, h_local, transpose=False):
+    def start_halo(self, x_local, transpose=False, produce=None):
+        """Overlapped form, first half: for every slice k — produce(k, r0, r1) fills local rows [r0, r1) of x_local (if given: the
+        layer GEMM / the trunk backward of row chunk k), then pack + asynchronous all-to-all of slice k, whose rows all lie in
+        that chunk.  Returns the list of (receive buffer, work handle, send buffer) per slice."""
+        plan = (self.b if transpose else self.f).plan
+        flights = []
+        if self.exchange_log is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._xev0 = ev
+        for k in range(plan.n_slices):
+            if produce is not None:
+                produce(k, *plan.chunks[k])
+            flights.append(self._send_slice(x_local, plan, k))
+        return flights
+
+    def aggregate_start(self, h_local, transpose=False, produce=None):
         """First half of aggregate(): starts the exchange (overlapped form) and returns a handle for aggregate_finish().  Work
-        issued between the two calls (e.g. the previous layer's weight-gradient GEMM in the trunk backward) runs under the exchange."""
+        issued between the two calls (e.g. the previous layer's weight-gradient GEMM in the trunk backward) runs under the
+        exchange.  produce: see start_halo (h_local is then an allocated, not yet filled matrix)."""
         if not self.overlap or h_local.dtype != torch.float32:
-            return (h_local, None, None, None)
-        recv, work, send = self.start_halo(h_local, transpose)
-        return (h_local, recv, work, send)
+            if produce is not None:
+                produce(0, 0, h_local.shape[0])
+            return (h_local, None)
+        return (h_local, self.start_halo(h_local, transpose, produce))
+
+    def finish_halo(self, flights, o, part_sums, last_pass):
+        """Second half: halo pass k (raw sums, in place) as slice k arrives; last_pass(csr, recv, acc) is the caller's final pass
+        (it applies the epilogue and always runs, also over an empty last slice)."""
+        c = self.compute
+        K = len(flights)
+        out = None
+        for k, (recv, work, _send) in enumerate(flights):
+            work.wait()
+            if k == K - 1:
+                if self.exchange_log is not None:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    self.exchange_log.append((self._xev0, ev))
+                out = last_pass(o.halo[k], recv, part_sums)
+            elif o.halo[k].E:
+                c.spmm(o.halo[k], recv, acc_init=part_sums, out=part_sums, profile=self.profile)
+        return out
 
     def aggregate_finish(self, handle, transpose=False, row_scale=None, bias=None, relu=False):
-        h_local, recv, work, send = handle
+        h_local, flights = handle
         o = self.b if transpose else self.f
         c = self.compute
-        if work is None:
+        if flights is None:
             return c.spmm(o.whole if o.whole is not None else self._whole(o), self.exchange(h_local, transpose), row_scale, bias, relu,
                           profile=self.profile)
         part = c.spmm(o.interior, h_local, profile=self.profile)             # raw sums over the local columns, overlaps the exchange
-        work.wait()
-        out = c.spmm(o.halo, recv, row_scale, bias, relu, acc_init=part, profile=self.profile)
-        del send
-        return out
+        return self.finish_halo(flights, o, part,
+                                lambda g, recv, acc: c.spmm(g, recv, row_scale, bias, relu, acc_init=acc, profile=self.profile))
 
     def aggregate(self, h_local, transpose=False, row_scale=None, bias=None, relu=False):
         """act(row_scale * (A_block . h) + bias) for this rank's rows; h_local = this rank's rows of h."""
@@ -451,7 +568,7 @@ def sync_initial_state(model, part, group=None, seed=0):
     have part.n_local rows, so ranks with different block sizes consume different amounts of the CPU RNG stream before the
     replicated layers are drawn.  (1) every replicated parameter and buffer is broadcast from rank 0; (2) the per-node
     tables are re-drawn from a generator keyed by (seed, first global row), so ranks do not hold identical shards."""
-    per_node = [(n, p) for n, p in model.named_parameters() if n.endswith('.le') or n == 'embs']
+    per_node = [(n, p) for n, p in model.named_parameters() if _per_node(n)]
     names = {n for n, _ in per_node}
     with torch.no_grad():
         for n, t in list(model.named_parameters()) + list(model.named_buffers()):
@@ -467,63 +584,145 @@ def sync_initial_state(model, part, group=None, seed=0):
             p.data.copy_(fresh.to(p.device))
 
 
+def scatter_rows(t_root, part, group=None, width=None, dtype=None, device=None):
+    """Rank 0 holds a [N, ...] tensor ordered by row; every rank receives its row block [lo, hi).  One all-to-all whose only
+    non-empty source is rank 0 (uneven splits), so no rank but the loader ever holds more than its block."""
+    P, r = part.world, part.rank
+    n_local = part.n_local
+    if r == 0:
+        inp = t_root.contiguous()
+        shape_tail, dtype, device = tuple(inp.shape[1:]), inp.dtype, inp.device
+        in_splits = [part.hi(q) - part.lo(q) for q in range(P)]
+    else:
+        shape_tail = tuple(width) if width is not None else ()
+        inp = torch.empty((0,) + shape_tail, dtype=dtype, device=device)
+        in_splits = [0] * P
+    out = torch.empty((n_local,) + shape_tail, dtype=dtype, device=device)
+    if P == 1:
+        out.copy_(inp)
+        return out
+    _all_to_all_single(out, inp, [n_local] + [0] * (P - 1), in_splits, group=group)
+    return out
+
+
+def scatter_by_owner(pairs_root, owner_root, counts, part, group=None, device=None):
+    """Rank 0 holds [E, 2] int64 pairs and the owning rank of each; rank q receives its `counts[q]` pairs (input order kept)."""
+    P, r = part.world, part.rank
+    if r == 0:
+        order = torch.sort(owner_root, stable=True)[1]
+        inp = pairs_root[order].contiguous()
+        in_splits = [int(c) for c in counts]
+        device = inp.device
+    else:
+        inp = torch.empty((0, 2), dtype=torch.int64, device=device)
+        in_splits = [0] * P
+    out = torch.empty((int(counts[r]), 2), dtype=torch.int64, device=device)
+    if P == 1:
+        out.copy_(inp)
+        return out
+    _all_to_all_single(out, inp, [int(counts[r])] + [0] * (P - 1), in_splits, group=group)
+    return out
+
+
 class ShardedTrainer:
     """Multi-GPU driver of the TeacherGNN path: bench.py (train_step) and `torchrun ... main.py` (main -> train_teacherGNN: the
-    reference's epoch loop with accuracy counts all-reduced).  Mirrors trainer.train_step / run_testSet / train_teacherGNN."""
+    reference's epoch — run_trainSet incl. the head/tail metrics forward, run_testSet, records, checkpoints — on row shards,
+    with hit counts / loss shares all-reduced).  Mirrors trainer.train_step / run_trainSet / run_testSet / train_teacherGNN
+    (trainer_node_classification.py:303-369,382-432,453-495).
 
-    def __init__(self, args, which_run, group=None):
+    Loading: rank 0 alone loads (data/<dataset>.pt) or generates the graph, runs the head/tail analysis and scatters every rank's
+    row block of x / y / masks / metric sets and its two edge blocks (edges by destination owner and by source owner); the other
+    ranks never hold more than their block.  `data` (rank 0; None elsewhere) injects a prepared Data object instead."""
+
+    NODE_COLS = ('y', 'train', 'test', 'large', 'small', 'zero')
+
+    def __init__(self, args, which_run, group=None, data=None):
         from . import optim as cb_optim
-        from .data import synthetic_data
-        from .utils import set_arch_configs
-        self.args, self.group = args, group
+        from .utils import save_graph_analyze, set_arch_configs
+        self.args, self.group, self.which_run = args, group, which_run
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.device = torch.device(f'cuda:{args.cuda_num}')
         args.device = self.device
-        # every rank generates the same seeded graph, keeps its row block and drops the rest
-        data = synthetic_data(args.dataset, seed=0, device=self.device)
-        self._n, self._e = int(data.x.shape[0]), int(data.edge_index.shape[1])
-        # all ranks must hold the same graph: compare a checksum before slicing
-        chk = torch.stack([data.edge_index.sum(), (data.edge_index[0] * 31 + data.edge_index[1]).sum(),
-                           data.train_mask.sum().to(torch.int64)]).to(torch.float64)
-        lo_, hi_ = chk.clone(), chk.clone()
-        _all_reduce(lo_, op=dist.ReduceOp.MIN, group=group)
-        _all_reduce(hi_, op=dist.ReduceOp.MAX, group=group)
-        if not torch.equal(lo_, hi_):
-            raise RuntimeError('ranks generated different graphs (seeded generator mismatch)')
+        self.bag = {}
+        dev = self.device
         exchange = os.environ.get('COLDBREW_EXCHANGE', 'halo')
         kind = os.environ.get('COLDBREW_PARTITION', 'rows' if exchange == 'allgather' else 'edges')
-        if kind == 'edges':
-            self.part = Partition.balanced(torch.bincount(data.edge_index[1], minlength=self._n), self.world, self.rank)
-        else:
-            self.part = Partition(self._n, self.world, self.rank)
-        self.sgraph = ShardedGraph(data.edge_index, self._n, self.part, group, exchange=exchange,
-                                   overlap=os.environ.get('COLDBREW_OVERLAP', '1') != '0'
-                                   and getattr(args, 'agg_dtype', 'f32') == 'f32',
-                                   wire=os.environ.get('COLDBREW_HALO_WIRE', 'f32'))
-        self.n_train = int(data.train_mask.sum().item())
-        p = self.part
-        self.x = p.slice_rows(data.x).float().contiguous()
-        self.y = p.slice_rows(data.y).contiguous()
-        self.train_mask = p.slice_rows(data.train_mask).contiguous()
-        test_mask = data.test_mask if getattr(data, 'test_mask', None) is not None else ~data.train_mask
-        self.test_mask = p.slice_rows(test_mask).contiguous()
-        self.n_test = int(test_mask.sum().item())
-        self.edge_index = data.edge_index[:, :1]     # placeholder: the cached sharded graph is injected below
-        del data
+        want_sets = bool(getattr(args, 'want_headtail', 0))
+        head = [None]
+        if self.rank == 0:
+            if data is None:
+                from .data import load_data
+                with contextlib.redirect_stdout(io.StringIO()):
+                    data = load_data(args.dataset, which_run, self)
+                data.x = data.x.float()
+                if want_sets or (getattr(args, 'do_deg_analyze', 0) and getattr(data, 'large_deg_idx', None) is None):
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        save_graph_analyze(int(data.x.shape[0]), data, args.use_special_split, verbose=False)
+            n = int(data.x.shape[0])
+            ei = data.edge_index.to(torch.int64)
+            bad = int(((ei < 0) | (ei >= n)).sum()) if ei.numel() else 0
+            if bad:
+                raise ValueError(f'edge_index has {bad} endpoints outside [0, {n})')
+            test_mask = data.test_mask if getattr(data, 'test_mask', None) is not None else ~data.train_mask
+            in_deg = torch.bincount(ei[1], minlength=n)
+            part0 = Partition.balanced(in_deg, self.world, 0) if kind == 'edges' else Partition(n, self.world, 0)
+            own_d, own_s = part0.owner(ei[1]), part0.owner(ei[0])
+            cols = torch.zeros((n, len(self.NODE_COLS)), dtype=torch.int64, device=ei.device)
+            cols[:, 0], cols[:, 1], cols[:, 2] = data.y.to(torch.int64), data.train_mask.to(torch.int64), test_mask.to(torch.int64)
+            has = []
+            for j, name in ((3, 'large_deg_idx'), (4, 'small_deg_idx'), (5, 'zero_deg_idx')):
+                idx = getattr(data, name, None)
+                if idx is not None:
+                    idx = idx if torch.is_tensor(idx) else torch.as_tensor(__import__('numpy').asarray(idx))
+                    cols[idx.to(device=ei.device, dtype=torch.long).reshape(-1), j] = 1
+                    has.append(name)
+            head[0] = {'n': n, 'e': int(ei.shape[1]), 'f': int(data.x.shape[1]), 'bounds': part0.bounds, 'kind': part0.kind,
+                       'n_train': int(data.train_mask.sum()), 'n_test': int(test_mask.sum()), 'sets': has,
+                       'cnt_d': torch.bincount(own_d, minlength=self.world).tolist(), 'cnt_s': torch.bincount(own_s, minlength=self.world).tolist()}
+        if self.world > 1:
+            dist.broadcast_object_list(head, src=0, group=group)
+        h = head[0]
+        self._n, self._e, self.n_train, self.n_test = h['n'], h['e'], h['n_train'], h['n_test']
+        self.part = Partition(self._n, self.world, self.rank, h['bounds'], kind=h['kind'])
+        root = self.rank == 0
+        ef = scatter_by_owner(ei.t() if root else None, own_d if root else None, h['cnt_d'], self.part, group, dev)
+        eb = scatter_by_owner(ei.t() if root else None, own_s if root else None, h['cnt_s'], self.part, group, dev)
+        self.x = scatter_rows(data.x.float() if root else None, self.part, group, (h['f'],), torch.float32, dev)
+        nc = scatter_rows(cols if root else None, self.part, group, (len(self.NODE_COLS),), torch.int64, dev)
+        if root:
+            del ei, own_d, own_s, cols, in_deg
+        data = None
+        self.y = nc[:, 0].contiguous()
+        self.train_mask, self.test_mask = nc[:, 1].bool().contiguous(), nc[:, 2].bool().contiguous()
+        # metric groups (large / small / zero degree): the local NON-training members, as eval_headtail__traintest_v2 keeps them
+        self.sets = {name: torch.where(nc[:, 3 + j].bool() & ~self.train_mask)[0]
+                     for j, name in enumerate(('large_deg_idx', 'small_deg_idx', 'zero_deg_idx')) if name in h['sets']}
+        del nc
+        self.sgraph = ShardedGraph(None, self._n, self.part, group, exchange=exchange,
+                                   overlap=os.environ.get('COLDBREW_OVERLAP', '1') != '0' and getattr(args, 'agg_dtype', 'f32') == 'f32',
+                                   wire=os.environ.get('COLDBREW_HALO_WIRE', 'f32'), local_edges=(ef.t(), eb.t()))
+        del ef, eb
+        self.edge_index = torch.zeros((2, 1), dtype=torch.int64, device=dev)     # placeholder: the cached sharded graph is injected below
         torch.cuda.empty_cache()
         self.optfun = cb_optim.resolve(args.optfun)
         set_arch_configs(args)
         args.N_nodes_global = self._n
         args.N_nodes = self.part.n_local             # structural-embedding tables are row-sharded
+        self.modeldir = f'saved_models/{args.task}/{args.dataset}'
+        self.resdir = f'{args.task}/{args.dataset}'
+        if self.rank == 0:
+            os.makedirs(self.modeldir, exist_ok=True)
 
     def setup_teacherGNN(self):
         from .GNN_model.GNN_normalizations import TeacherGNN
+        from .utils import getMLP
         torch.manual_seed(self.args.random_seed)
         with contextlib.redirect_stdout(io.StringIO()):
-            self.teacherGNN = TeacherGNN(self.args, None).to(self.device)
+            self.proj2class = getMLP(self.args.TeacherGNN.neurons_proj2class).to(self.device) if getattr(self.args, 'has_proj2class', 0) else None
+            self.teacherGNN = TeacherGNN(self.args, self.proj2class).to(self.device)
         sync_initial_state(self.teacherGNN, self.part, self.group, self.args.random_seed)
         self.teacherGNN.model.model.dglgraph = self.sgraph
-        self.replicated = [p for n, p in self.teacherGNN.named_parameters() if not n.endswith('.le') and n != 'embs']
+        self.replicated = [p for n, p in self.teacherGNN.named_parameters() if not _per_node(n)]
         self.optimizer = self.optfun(self.teacherGNN.parameters(), lr=self.args.lr, weight_decay=self.args.weight_decay)
 
     def load_full_state_dict(self, sd_full):
@@ -532,9 +731,33 @@ class ShardedTrainer:
         lo, hi = self.part.lo(), self.part.hi()
         sd = {}
         for k, v in sd_full.items():
-            per_node = (k.endswith('.le') or k == 'embs') and v.dim() == 2 and v.shape[0] == self._n
+            per_node = _per_node(k) and v.dim() == 2 and v.shape[0] == self._n
             sd[k] = v[lo:hi].clone() if per_node else v
         self.teacherGNN.load_state_dict(sd)
+
+    def full_state_dict(self):
+        """The unsharded state_dict on rank 0 (None elsewhere): per-node tables gathered block by block to rank 0's HOST memory
+        (the tables of all ranks together may not fit one device next to its own shard), everything else as rank 0 holds it."""
+        out = {} if self.rank == 0 else None
+        for k, v in self.teacherGNN.state_dict().items():
+            if not (_per_node(k) and v.dim() == 2):
+                if self.rank == 0:
+                    out[k] = v.detach().cpu()
+                continue
+            full = torch.empty((self._n, v.shape[1]), dtype=v.dtype) if self.rank == 0 else None
+            for q in range(self.world):
+                rows = self.part.hi(q) - self.part.lo(q)
+                if q == 0:
+                    if self.rank == 0:
+                        full[:rows] = v.detach().cpu()
+                    continue
+                if self.rank == q:
+                    _send_to(v.detach().contiguous(), 0, self.group)
+                elif self.rank == 0:
+                    full[self.part.lo(q):self.part.hi(q)] = _recv_from((rows, v.shape[1]), v.dtype, v.device, q, self.group).cpu()
+            if self.rank == 0:
+                out[k] = full
+        return out
 
     def graph(self):
         return self.sgraph
@@ -545,18 +768,96 @@ class ShardedTrainer:
     def global_edges(self):
         return self._e
 
-    def train_step(self):
-        from . import norms_hip, ops
+    # -- sharded resumable checkpoint ("sharded `le` tables"; utils.py:958-986 saves weights only) -------------
+    def checkpoint_path(self, rank=None):
+        r = self.rank if rank is None else rank
+        return os.path.join(self.modeldir, f'teacherGNN-ckpt.shard{r}of{self.world}')
+
+    def save_checkpoint(self, epoch, results, best_test_acc=0.):
+        """One file per rank: its rows of the per-node tables with their Adam moments; rank 0's file also carries the replicated
+        weights (once), their moments, the records and the RNG states.  Tensors and plain containers only (weights_only=True)."""
+        import numpy as np
+        names = {id(p): n for n, p in self.teacherGNN.named_parameters()}
+        sd = self.teacherGNN.state_dict()
+        keep = (lambda k: True) if self.rank == 0 else _per_node
+        opt = {}
+        for p_, st in self.optimizer.state.items():
+            n = names.get(id(p_))
+            if n is not None and keep(n):
+                opt[n] = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+        blob = {'model': {k: v for k, v in sd.items() if keep(k)}, 'optimizer': opt, 'epoch': int(epoch), 'world': self.world,
+                'bounds': list(self.part.bounds), 'torch_rng': torch.get_rng_state()}
+        if self.rank == 0:
+            np_state = np.random.get_state()
+            blob.update({'results': [[float(v) for v in row] for row in results], 'best_test_acc': float(best_test_acc),
+                         'numpy_rng': {'kind': str(np_state[0]), 'keys': torch.from_numpy(np_state[1].astype(np.int64)),
+                                       'pos': int(np_state[2]), 'has_gauss': int(np_state[3]), 'cached_gaussian': float(np_state[4])}})
+        torch.save(blob, self.checkpoint_path())
+        if self.world > 1:
+            dist.barrier(group=self.group)
+
+    def load_checkpoint(self):
+        """(last epoch, records, best accuracy) or (-1, [], 0.) without a complete set of shard files for THIS world / partition."""
+        import numpy as np
+        ok = torch.tensor([int(os.path.exists(self.checkpoint_path()) and os.path.exists(self.checkpoint_path(0)))], dtype=torch.int64)
+        if self.world > 1:
+            okd = ok.to(self.device)
+            _all_reduce(okd, op=dist.ReduceOp.MIN, group=self.group)
+            ok = okd.cpu()
+        if not int(ok):
+            return -1, [], 0.
+        mine = torch.load(self.checkpoint_path(), map_location='cpu', weights_only=True)
+        root = mine if self.rank == 0 else torch.load(self.checkpoint_path(0), map_location='cpu', weights_only=True)
+        if mine['world'] != self.world or list(mine['bounds']) != list(self.part.bounds):
+            raise RuntimeError(f"checkpoint was written for world {mine['world']} / bounds {mine['bounds']}, this run has world {self.world} / "
+                               f'{self.part.bounds}: re-shard through the single-file model (teacherGNN) instead')
+        sd = {k: v for k, v in root['model'].items() if not _per_node(k)}
+        sd.update({k: v for k, v in mine['model'].items() if _per_node(k)})
+        self.teacherGNN.load_state_dict(sd)
+        by_name = dict(self.teacherGNN.named_parameters())
+        for n, p_ in by_name.items():
+            st = (mine if _per_node(n) else root)['optimizer'].get(n)
+            if st is not None:
+                self.optimizer.state[p_] = {k: (v.to(p_.device) if torch.is_tensor(v) else v) for k, v in st.items()}
+        torch.set_rng_state(mine['torch_rng'])
+        if self.rank == 0:
+            r = root['numpy_rng']
+            np.random.set_state((r['kind'], r['keys'].numpy().astype(np.uint32), r['pos'], r['has_gauss'], r['cached_gaussian']))
+            print(f'---››››  RESUME from {self.checkpoint_path()} (+{self.world - 1} shard files) after epoch {root["epoch"]}')
+        return root['epoch'], root['results'], root.get('best_test_acc', 0.)
+
+    def save_model(self, name):
+        """The reference's artifact (utils.py:958-960: one state_dict file) from the shards, written by rank 0 — loads into the
+        single-GPU trainer / the student stage with utils.load_model."""
+        sd = self.full_state_dict()
+        if self.rank == 0:
+            path = os.path.join(self.modeldir, name)
+            torch.save(sd, path)
+            print(f'‹‹‹‹‹‹‹---  Saved @ :{path}')
+        if self.world > 1:
+            dist.barrier(group=self.group)
+
+    # -- one optimisation step ---------------------------------------------------------------------------------------------
+    def training_loss(self):
+        from . import ops
+        m = self.teacherGNN
+        out = m.get_3_embs(self.x, self.edge_index).emb4classi_full
+        # local numerator / global count; the global loss is the sum over ranks
+        loss = ops.nll_logsoftmax(out, self.y, self.train_mask, self.n_train) * self.args.TeacherGNN.lossa_semantic
+        if m.se_reg_all is not None:
+            folded = ops.fold_se_reg(m, self.optimizer, self.args.se_reg, m.se_reg_all)
+            # se_reg_all is already global; count it once
+            loss = loss + (folded if folded is not None else self.args.se_reg * m.se_reg_all) / self.world
+        return loss
+
+    def train_step(self, metrics=False):
+        from . import norms_hip
         m = self.teacherGNN
         m.train()
         with norms_hip.row_sharding(self.group, self._n):      # column statistics of the norm tricks span all ranks
-            out = m.get_3_embs(self.x, self.edge_index).emb4classi_full
-            # local numerator / global count; the global loss is the sum over ranks
-            loss = ops.nll_logsoftmax(out, self.y, self.train_mask, self.n_train)
-            if m.se_reg_all is not None:
-                folded = ops.fold_se_reg(m, self.optimizer, self.args.se_reg, m.se_reg_all)
-                # se_reg_all is already global; count it once
-                loss = loss + (folded if folded is not None else self.args.se_reg * m.se_reg_all) / self.world
+            loss = self.training_loss()
+            if metrics:
+                self._headtail_metrics()
             self.optimizer.zero_grad()
             loss.backward()
         allreduce_grads(self.replicated, self.group)
@@ -565,7 +866,35 @@ class ShardedTrainer:
         _all_reduce(total, group=self.group)
         return total
 
-    # -- the reference's epoch on row shards (trainer_node_classification.py:303-369,453-495,672-681) ----------------------
+    # -- the reference's epoch on row shards (trainer_node_classification.py:303-369,382-432,453-495,672-687) -----------------
+    def run_trainSet(self):
+        """loss (global), 0, 0 — with --want_headtail=1 the second train-mode forward of :397-413 runs between the loss forward and
+        the backward, as in the reference, and fills bag['head_tail_iso']."""
+        loss = self.train_step(metrics=True)
+        return float(loss), 0, 0
+
+    def _headtail_metrics(self):
+        """bag['head_tail_iso'] (:397-413): accuracy x 100 of a second train-mode (dropout-active) forward on the non-training
+        members of the large- / small- / zero-degree groups; per-rank hit counts and group sizes are all-reduced, the rounding is
+        cal_acc_rounded100's (float32, 3 decimals)."""
+        import numpy as np
+        result = []
+        if getattr(self.args, 'want_headtail', 0):
+            names = ['large_deg_idx', 'small_deg_idx'] + (['zero_deg_idx'] if self.args.use_special_split else [])
+            missing = [n for n in names if n not in self.sets]
+            if missing:
+                raise RuntimeError(f'--want_headtail=1 needs the degree groups {missing} (run with --do_deg_analyze=1 or provide them in the data)')
+            with torch.no_grad():        # metrics only: the reference tracks this forward in autograd and never uses its graph
+                logits = self.teacherGNN.get_3_embs(self.x, self.edge_index).emb4classi_full
+            pred = torch.max(logits, dim=1)[1]
+            cnt = torch.stack([torch.stack([(pred[self.sets[n]] == self.y[self.sets[n]]).sum(),
+                                            torch.tensor(self.sets[n].numel(), device=pred.device)]) for n in names]).to(torch.float64)
+            _all_reduce(cnt, group=self.group)
+            with np.errstate(invalid='ignore', divide='ignore'):
+                for hits, size in cnt.tolist():
+                    result.append(np.round(np.float32(np.float32(hits) / np.float32(size)) * np.float32(100), 3))
+        self.bag['head_tail_iso'] = result
+
     def run_testSet(self):
         """Eval forward + argmax accuracy on the train / test masks: per-rank hit counts, all-reduced."""
         from . import norms_hip
@@ -576,24 +905,70 @@ class ShardedTrainer:
         hit = out.argmax(dim=1) == self.y
         cnt = torch.stack([(hit & self.train_mask).sum(), (hit & self.test_mask).sum()]).to(torch.float64)
         _all_reduce(cnt, group=self.group)
-        acc_train, acc_test = (cnt / torch.tensor([max(self.n_train, 1), max(self.n_test, 1)], dtype=torch.float64, device=cnt.device)).tolist()
-        return acc_train, float('nan'), acc_test, float('nan')
+        h_train, h_test = cnt.tolist()
+        return h_train * 1.0 / max(self.n_train, 1), float('nan'), h_test * 1.0 / max(self.n_test, 1), float('nan')
 
     def train_teacherGNN(self):
-        """Epoch loop with the record layout of trainer.train_teacherGNN (want_headtail = 0): returns [[acc_test * 100 per epoch]].
-        Every rank returns the same array."""
+        """Epoch loop with the record layout and return rows of trainer.train_teacherGNN (:303-369): per epoch
+        [log(loss), acc_train*100, acc_test*100, 0, 0 (, head, tail, iso)]; returns rows [2] or [2,-3,-2,-1].  --resume / --ckpt_every
+        use the sharded checkpoint; the final model is also written as the reference's single-file artifact.  Every rank returns the
+        same array."""
         import numpy as np
+        from . import norms_hip
         self.setup_teacherGNN()
-        rows = []
-        for epoch in range(self.args.epochs):
-            loss = float(self.train_step())
+        results, best_test_acc, first_epoch = [], 0., 0
+        if getattr(self.args, 'resume', False):
+            last, results, best_test_acc = self.load_checkpoint()
+            first_epoch = last + 1
+        ckpt_every = int(getattr(self.args, 'ckpt_every', 0) or 0)
+        if int(getattr(self.args, 'hip_graph', 0) or 0) and self.rank == 0:
+            print('--hip_graph=1 ignored by the node-sharded trainer: the collectives of a step are not captured (eager launches)')
+        for epoch in range(first_epoch, self.args.epochs):
+            self.epoch = epoch
+            with norms_hip.row_sharding(self.group, self._n):
+                loss, _, _ = self.run_trainSet()
             acc_train, _, acc_test, _ = self.run_testSet()
-            rows.append([np.log(loss), acc_train * 100, acc_test * 100, 0, 0])
+            if 'SEMLP' in self.args.train_which and acc_test > best_test_acc:
+                best_test_acc = acc_test
+                self.save_model('best-teacherGNN')
+            results.append([float(np.log(loss)), acc_train * 100, acc_test * 100, 0, 0])
+            if self.args.want_headtail:
+                results[-1].extend(float(v) for v in self.bag['head_tail_iso'])
             if epoch % 20 == 0 and self.rank == 0:
                 print(f'Ep{epoch:03d}, acc @ train/test: {acc_train * 100:.1f}, {acc_test * 100:.1f} ')
-        return np.array(rows).T[[2]]
+            if ckpt_every and (epoch + 1) % ckpt_every == 0:
+                self.save_checkpoint(epoch, results, best_test_acc)
+        if first_epoch < self.args.epochs:
+            self.save_checkpoint(self.args.epochs - 1, results, best_test_acc)
+        self.save_model('teacherGNN')
+        arr = np.array(results).T
+        if not self.args.want_headtail:
+            return arr[[2]]
+        return arr[[2, -3, -2, -1]]
 
     def main(self):
-        if self.args.train_which != 'TeacherGNN' or self.args.want_headtail:
-            raise NotImplementedError('the node-sharded trainer runs --train_which=TeacherGNN with --want_headtail=0')
+        if self.args.train_which != 'TeacherGNN':
+            raise NotImplementedError('the node-sharded trainer runs --train_which=TeacherGNN')
         return self.train_teacherGNN()
+
+
+def _per_node(name):
+    return name.endswith('.le') or name == 'embs'
+
+
+def _send_to(t, dst, group=None):
+    if _staged(t, group):
+        dist.send(t.cpu(), dst, group=group)
+    else:
+        dist.send(t, dst, group=group)
+
+
+def _recv_from(shape, dtype, device, src, group=None):
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if _staged(t, group):
+        h = torch.empty(shape, dtype=dtype)
+        dist.recv(h, src, group=group)
+        t.copy_(h)
+    else:
+        dist.recv(t, src, group=group)
+    return t

@@ -35,9 +35,11 @@ def _b_workspace(lib, N, K, M, device):
     return (torch.empty(wsb, dtype=torch.uint8, device=device), wsb) if wsb else (None, 0)
 
 
-def mm_nn(a, b, rowscale=None, addend=None, bias=None, relu=False, out_bf16=False):
+def mm_nn(a, b, rowscale=None, addend=None, bias=None, relu=False, out_bf16=False, out=None):
     """act(rowscale[:,None] * (a @ b) + addend + bias) in one kernel; a [M,K], b [K,N] float32 on device.
-    out_bf16: store the result as bfloat16 (round-to-nearest-even) — the bf16 aggregation variant."""
+    out_bf16: store the result as bfloat16 (round-to-nearest-even) — the bf16 aggregation variant.
+    out: optional [M, N] destination with contiguous rows (a row chunk of a larger matrix: the chunked layer GEMM of the
+    node-sharded pipeline, dist.py)."""
     lib = _lib.load()
     _lib.require_device(a, b, rowscale, addend, bias)
     a, b = _rowmajor(a), _rowmajor(b)
@@ -49,11 +51,15 @@ def mm_nn(a, b, rowscale=None, addend=None, bias=None, relu=False, out_bf16=Fals
         raise TypeError('mm_nn expects float32')
     if addend is not None:
         addend = _rowmajor(addend)
-    out = torch.empty((M, N), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=a.device)
+    odt = torch.bfloat16 if out_bf16 else torch.float32
+    if out is None:
+        out = torch.empty((M, N), dtype=odt, device=a.device)
+    elif tuple(out.shape) != (M, N) or out.dtype != odt or (N > 1 and out.stride(1) != 1) or out.device != a.device:
+        raise ValueError(f'mm_nn: out must be a [{M}, {N}] {odt} matrix with contiguous rows on the operands\' device')
     fn = lib.cb_gemm_nn_bf16out_f32 if out_bf16 else lib.cb_gemm_nn_f32
     ws, wsb = _b_workspace(lib, N, K, M, a.device)
     with torch.cuda.device(a.device):
-        _lib.check(fn(_lib.ptr(a), _ld(a), _lib.ptr(b), _ld(b), _lib.ptr(out), N, M, N, K, _lib.ptr(rowscale),
+        _lib.check(fn(_lib.ptr(a), _ld(a), _lib.ptr(b), _ld(b), _lib.ptr(out), _ld(out), M, N, K, _lib.ptr(rowscale),
                       _lib.ptr(addend), _ld(addend) if addend is not None else 0, _lib.ptr(bias),
                       int(bool(relu)), _lib.ptr(ws), wsb, _lib.stream_ptr()), 'cb_gemm_nn')
     return out

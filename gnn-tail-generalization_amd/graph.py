@@ -217,9 +217,9 @@ class CSRGraph:
         fn = lib.cb_spmm_csr_bf16_f32 if bf16 else lib.cb_spmm_csr_f32
         with torch.cuda.device(h.device):
             if acc_init is not None:
-                if bf16 or acc_init.dtype != torch.float32 or acc_init.shape != (self.N, d) or acc_init.stride(1) != 1:
-                    raise ValueError('acc_init must be a float32 [N, d] matrix with contiguous rows (fp32 source rows only)')
-                _lib.check(lib.cb_spmm_csr_acc_f32(_lib.ptr(rowptr), _lib.ptr(col), flags, self.N, self.E, _lib.ptr(h), ld_h, d,
+                if acc_init.dtype != torch.float32 or acc_init.shape != (self.N, d) or acc_init.stride(1) != 1:
+                    raise ValueError('acc_init must be a float32 [N, d] matrix with contiguous rows')
+                _lib.check((lib.cb_spmm_csr_acc_bf16_f32 if bf16 else lib.cb_spmm_csr_acc_f32)(_lib.ptr(rowptr), _lib.ptr(col), flags, self.N, self.E, _lib.ptr(h), ld_h, d,
                                                    _lib.ptr(row_scale), _lib.ptr(bias), int(bool(relu)), _lib.ptr(acc_init),
                                                    acc_init.stride(0) if self.N > 1 else d, _lib.ptr(out), ld_o,
                                                    self.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows),

@@ -292,17 +292,19 @@ def nll_logsoftmax(logits, y, mask=None, count=None):
     return _NllFn.apply(logits, _c(y), _c(mask) if mask is not None else None, count)
 
 
-def gather_rows_by_index(x, idx):
-    """x[idx] for a float32 device matrix and an int64 index vector (row pack of the halo exchange)."""
+def gather_rows_by_index(x, idx, out_bf16=False):
+    """x[idx] for a float32 device matrix and an int64 index vector (row pack of the halo exchange).  out_bf16: the rows are
+    narrowed to bfloat16 (round-to-nearest-even) by the same kernel — the send buffer of the bf16 halo wire."""
     lib = _lib.load()
     _lib.require_device(x, idx)
     if x.stride(1) != 1:
         x = x.contiguous()
     idx = idx.to(torch.int64).contiguous()
-    out = torch.empty((idx.numel(), x.shape[1]), dtype=torch.float32, device=x.device)
+    out = torch.empty((idx.numel(), x.shape[1]), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    fn = lib.cb_gather_rows_bf16_f32 if out_bf16 else lib.cb_gather_rows_f32
     with torch.cuda.device(x.device):
-        _lib.check(lib.cb_gather_rows_f32(_lib.ptr(x), x.stride(0) if x.shape[0] > 1 else x.shape[1], _lib.ptr(idx), idx.numel(),
-                                          x.shape[1], _lib.ptr(out), _lib.stream_ptr()), 'cb_gather_rows_f32')
+        _lib.check(fn(_lib.ptr(x), x.stride(0) if x.shape[0] > 1 else x.shape[1], _lib.ptr(idx), idx.numel(),
+                      x.shape[1], _lib.ptr(out), _lib.stream_ptr()), 'cb_gather_rows_f32')
     return out
 
 

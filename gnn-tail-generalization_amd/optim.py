@@ -99,6 +99,10 @@ class Adam(torch.optim.Optimizer):
                                                      group['weight_decay'], step, _lib.ptr(self._step_dev), _lib.stream_ptr()),
                                'cb_adam_multi_f32')
                 del keep
+        # one-shot: a coefficient belongs to the step whose forward wrote it (ops.fold_se_reg rewrites it every step); a later step()
+        # after a different loss must not apply a stale one
+        for buf in self._extra_decay.values():
+            buf.zero_()
         return loss
 
 

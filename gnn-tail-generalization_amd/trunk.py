@@ -29,24 +29,28 @@ def eligible(tc, x, want_les):
             and tc.embedding_dropout == tc.dropout and tc.args.dropout == tc.dropout)
 
 
-def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False):
+def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False, produce=None):
     """(bits, out_next[, act]) of cb_spmm_csr_fused_f32 on the (possibly node-sharded) graph.  Node-sharded + overlapped:
-    the interior-column pass (plain kernel, raw sums) runs while the halo rows travel, the fused store then starts from
-    those sums (cb_spmm_csr_fused_acc_f32) on the halo-column CSR."""
+    the exchange runs as the sliced pipeline of dist.ShardedGraph (produce(k, r0, r1), if given, fills rows [r0, r1) of z — the
+    row-chunked layer GEMM — right before slice k is packed and sent); the interior-column pass (plain kernel, raw sums) and
+    the halo passes of the earlier slices run while the later slices travel, the fused store is the last slice's pass
+    (cb_spmm_csr_fused_acc_f32 / _bf16_f32 when the halo rows crossed the links as bf16)."""
     lib = _lib.load()
     sh = graph if hasattr(graph, 'part') else None
-    acc = None
-    if sh is None:
-        g = graph
-    elif sh.overlap and z.dtype == torch.float32:
-        recv, work, send = sh.start_halo(z, False)
+    if sh is not None and sh.overlap and z.dtype == torch.float32:
+        flights = sh.start_halo(z, False, produce)
         sh.f.interior.profile = getattr(graph, 'profile', None)
         acc = sh.f.interior.spmm(z)
-        work.wait()
-        g, z = sh.f.halo, recv
-        del send
-    else:
-        g, z = sh.f.whole, sh.exchange(z, False)
+        return sh.finish_halo(flights, sh.f, acc, lambda g, recv, a_: _fused_launch(lib, graph, g, recv, a_, bias, x0, c_act, c_mix, p, seed, want_act))
+    if produce is not None:
+        produce(0, 0, z.shape[0])
+    if sh is None:
+        return _fused_launch(lib, graph, graph, z, None, bias, x0, c_act, c_mix, p, seed, want_act)
+    return _fused_launch(lib, graph, sh.f.whole, sh.exchange(z, False), None, bias, x0, c_act, c_mix, p, seed, want_act)
+
+
+def _fused_launch(lib, graph, g, z, acc, bias, x0, c_act, c_mix, p, seed, want_act):
+    """One fused-store launch over CSR g (the whole graph, a rank's single-pass block, or the last halo slice on top of acc)."""
     n, d = g.N, z.shape[1]
     dev = z.device
     bits = torch.empty((n, d // 256, 4), dtype=torch.int64, device=dev)
@@ -68,7 +72,8 @@ def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False):
             plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), wsb, _lib.stream_ptr())
     with torch.cuda.device(dev):
         if acc is not None:
-            _lib.check(lib.cb_spmm_csr_fused_acc_f32(_lib.ptr(acc), d, *args), 'cb_spmm_csr_fused_acc_f32')
+            fn = lib.cb_spmm_csr_fused_acc_bf16_f32 if bf16 else lib.cb_spmm_csr_fused_acc_f32
+            _lib.check(fn(_lib.ptr(acc), d, *args), 'cb_spmm_csr_fused_acc_f32')
         else:
             fn = lib.cb_spmm_csr_fused_bf16_f32 if bf16 else lib.cb_spmm_csr_fused_f32
             _lib.check(fn(*args), 'cb_spmm_csr_fused_f32')
@@ -85,10 +90,11 @@ def _spmm_t(graph, gr):
     return graph.spmm(gr, transpose=True)
 
 
-def _layer_bwd(g, bits, row_scale, gx0, accumulate, p, seed, row0, c_act, c_mix, want_colsum, out_bf16=False):
+def _layer_bwd(g, bits, row_scale, gx0, accumulate, p, seed, row0, c_act, c_mix, want_colsum, out_bf16=False, out=None):
     lib = _lib.load()
     rows, d = g.shape
-    out = torch.empty(g.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=g.device)
+    if out is None:
+        out = torch.empty(g.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=g.device)
     colsum = torch.empty(d, dtype=torch.float32, device=g.device) if want_colsum else None
     wsb = lib.cb_colsum_workspace_bytes(rows, d) if want_colsum else 0
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=g.device)
@@ -145,6 +151,13 @@ MASKED_GATHER = os.environ.get('CB_TRUNK_MASKED_GATHER', '0') == '1'
 MIX_MAX = 7      # mixed-in gradients one cb_trunk_input_bwd_multi_f32 launch gathers (deeper trunks accumulate layer by layer)
 
 
+def _chunked(graph, agg_bf16):
+    """Row-chunk the producers of the exchanged matrices (layer GEMM forward; dX GEMM + trunk layer backward) so that chunk k
+    ships while chunk k+1 is computed: node-sharded overlapped graphs whose plans have more than one slice."""
+    return (hasattr(graph, 'part') and graph.overlap and not agg_bf16 and graph.f.plan is not None and graph.f.plan.n_slices > 1
+            and os.environ.get('COLDBREW_CHUNKED_PRODUCERS', '1') != '0')
+
+
 class _TrunkFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph, cfg, x, w_in, b_in, w_out, b_out, *layer_params):
@@ -162,8 +175,17 @@ class _TrunkFn(torch.autograd.Function):
         saved_in, saved_bits = [cur], []
         for l in range(L):
             w, b, le = layer_params[3 * l: 3 * l + 3]
-            z = gemm.mm_nn(cur, w, rowscale=a, addend=le, out_bf16=agg_bf16)
-            bits, cur, _ = _fused_spmm(graph, z, b, x0, 1 - alpha, alpha, p, seeds[l + 2] if p > 0 else 0)
+            if _chunked(graph, agg_bf16):
+                # node-sharded pipeline: row chunk k of Z leaves the GEMM, is packed and put on the links while chunk k+1 multiplies
+                z = torch.empty((cur.shape[0], w.shape[1]), dtype=torch.float32, device=cur.device)
+
+                def produce(k, r0, r1, cur=cur, w=w, le=le, z=z):
+                    if r1 > r0:
+                        gemm.mm_nn(cur[r0:r1], w, rowscale=a[r0:r1], addend=le[r0:r1] if le is not None else None, out=z[r0:r1])
+                bits, cur, _ = _fused_spmm(graph, z, b, x0, 1 - alpha, alpha, p, seeds[l + 2] if p > 0 else 0, produce=produce)
+            else:
+                z = gemm.mm_nn(cur, w, rowscale=a, addend=le, out_bf16=agg_bf16)
+                bits, cur, _ = _fused_spmm(graph, z, b, x0, 1 - alpha, alpha, p, seeds[l + 2] if p > 0 else 0)
             del z
             saved_bits.append(bits)
             saved_in.append(cur)
@@ -214,30 +236,53 @@ class _TrunkFn(torch.autograd.Function):
         masked = gather and not agg_bf16 and not sharded and not fuse and MASKED_GATHER and hasattr(graph, 'spmm_masked')
         coef = (1 - alpha) / (1 - p)
 
+        chunked = gather and not fuse and _chunked(graph, agg_bf16) and graph.b.plan.n_slices > 1
+
         def dx_gemm(src, wt, rowscale, below):
-            """dL/dx of the stage above layer `below` (+ that layer's trunk backward when fused): (g, gr, dbias)."""
+            """dL/dx of the stage above layer `below` (+ that layer's trunk backward when fused): (g, gr, dbias, handle); handle =
+            the already started exchange of gr (row-chunked producers of the node-sharded pipeline), else None."""
             sd = seeds[below + 2] if p > 0 else 0
+            if chunked:
+                g_ = torch.empty((src.shape[0], wt.shape[1]), dtype=torch.float32, device=src.device)
+                gr_ = torch.empty_like(g_)
+                want_b = need[7 + 3 * below + 1]
+                colsums = []
+
+                def produce(k, r0, r1):
+                    if r1 <= r0:
+                        return
+                    gemm.mm_nn(src[r0:r1], wt, rowscale=rowscale[r0:r1] if rowscale is not None else None, out=g_[r0:r1])
+                    _, cs = _layer_bwd(g_[r0:r1], saved_bits[below][r0:r1], bnorm[r0:r1], None, False, p, sd, row0 + r0, 1 - alpha, alpha,
+                                       want_b, out=gr_[r0:r1])
+                    if want_b:
+                        colsums.append(cs)
+                h_ = graph.aggregate_start(gr_, True, produce=produce)
+                db_ = None
+                if want_b:
+                    db_ = colsums[0] if len(colsums) == 1 else torch.stack(colsums).sum(0)
+                return g_, gr_, db_, h_
             if masked:
                 if need[7 + 3 * below + 1]:
                     g_, _, db_ = gemm.mm_nn_trunkbwd(src, wt, rowscale, saved_bits[below], coef, 0.0, 0, row0, None, True, want_gr=False)
                 else:
                     g_, db_ = gemm.mm_nn(src, wt, rowscale=rowscale), None
-                return g_, None, db_
+                return g_, None, db_, None
             if fuse:
-                return gemm.mm_nn_trunkbwd(src, wt, rowscale, saved_bits[below], 1 - alpha, p, sd, row0, bnorm, need[7 + 3 * below + 1])
+                return gemm.mm_nn_trunkbwd(src, wt, rowscale, saved_bits[below], 1 - alpha, p, sd, row0, bnorm, need[7 + 3 * below + 1]) + (None,)
             g_ = gemm.mm_nn(src, wt, rowscale=rowscale)
             gr_, db_ = _layer_bwd(g_, saved_bits[below], bnorm, gx0, below != L - 1, p, sd, row0, 1 - alpha, alpha,
                                   need[7 + 3 * below + 1], out_bf16=agg_bf16)
-            return g_, gr_, db_
+            return g_, gr_, db_, None
 
-        g, gr, dbias = dx_gemm(gout, w_out, None, L - 1)               # dL/d(dropped X_L) and the backward of layer L-1's store
+        g, gr, dbias, handle = dx_gemm(gout, w_out, None, L - 1)       # dL/d(dropped X_L) and the backward of layer L-1's store
         deferred = None        # (layer, X_l, dZ_l): weight gradient of the layer above, computed under this layer's halo exchange
         for l in range(L - 1, -1, -1):
             w, b, le = lp[l]
             if gather:
                 g_mix.append(g)
                 seeds_mix.append(seeds[l + 2] if p > 0 else 0)
-            handle = graph.aggregate_start(gr, True) if sharded else None       # node-sharded: the exchange is in flight from here
+            if sharded and handle is None:
+                handle = graph.aggregate_start(gr, True)                        # node-sharded: the exchange is in flight from here
             if deferred is not None:
                 grads_layers[3 * deferred[0]] = gemm.mm_tn(deferred[1], deferred[2], rowscale=a)
                 deferred = None
@@ -246,6 +291,7 @@ class _TrunkFn(torch.autograd.Function):
             else:
                 gz = graph.aggregate_finish(handle, True) if sharded else _spmm_t(graph, gr)  # dL/dZ_l = A (b * dY')
             del g, gr
+            handle = None
             if need[7 + 3 * l]:
                 if sharded:
                     deferred = (l, saved_in[l], gz)
@@ -253,7 +299,7 @@ class _TrunkFn(torch.autograd.Function):
                     grads_layers[3 * l] = gemm.mm_tn(saved_in[l], gz, rowscale=a)
             grads_layers[3 * l + 1] = dbias
             if l > 0:
-                g, gr, dbias = dx_gemm(gz, w.t().contiguous(), a, l - 1)      # dL/d(dropped X_l) and the backward of layer l-1's store
+                g, gr, dbias, handle = dx_gemm(gz, w.t().contiguous(), a, l - 1)      # dL/d(dropped X_l) and the backward of layer l-1's store
             else:
                 g = gemm.mm_nn(gz, w.t().contiguous(), rowscale=a)            # dL/d(dropped X_0): consumed by the input stage
             if le is not None and need[7 + 3 * l + 2]:

@@ -339,6 +339,22 @@ int cb_spmm_csr_fused_acc_f32(const float* acc_init, int64_t ld_init, const int3
                               float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
                               const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream);
 
+/* The halo-column pass over bf16-stored halo rows: with the bf16 wire (COLDBREW_HALO_WIRE=bf16, opt-in, outside the 1e-4
+ * parity) the rows leave cb_gather_rows_bf16_f32 narrowed (round-to-nearest-even), cross the links at 2 bytes per element and
+ * are read by these passes exactly as they arrived (widened in registers; accumulation and outputs fp32) — no conversion pass
+ * on either side.  Arguments as the fp32 forms, h = uint16_t rows (8-byte aligned for the vector paths). */
+int cb_spmm_csr_acc_bf16_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const uint16_t* h, int64_t ld_h,
+                             int64_t d, const float* row_scale, const float* bias, int relu, const float* acc_init, int64_t ld_init,
+                             float* out, int64_t ld_out, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
+                             const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream);
+int cb_spmm_csr_fused_acc_bf16_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int32_t col_flags,
+                                   int64_t N, int64_t E, const uint16_t* h, int64_t ld_h, int64_t d, const float* row_scale,
+                                   const float* bias, const float* mix_src, int64_t ld_mix, float c_act, float c_mix, float drop_p,
+                                   uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, float* out_act,
+                                   int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs,
+                                   int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes,
+                                   void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Device-side graph analysis in front of the path (per-edge Python dict / list loops in the reference).
  * Integer work, bit-exact, order-preserving (outputs list elements in input order, as np.where and the reference's append
@@ -369,6 +385,9 @@ int cb_symmetrize_i64(const int64_t* src, const int64_t* dst, int64_t E, int64_t
 /* out[i, :] = src[idx[i], :] (contiguous out [n_idx, d]) — packs the rows a peer asked for before the
  * all-to-all of the node-sharded halo exchange (new; the reference is single-device). */
 int cb_gather_rows_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, float* out, void* stream);
+
+/* The same pack with the rows narrowed to bf16 (round-to-nearest-even) as they are written: the send buffer of the bf16 halo wire. */
+int cb_gather_rows_bf16_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, uint16_t* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,20 +17,26 @@ class OracleCompute:
         np.cumsum(np.bincount(r, minlength=n_rows), out=rowptr[1:])
         return SimpleNamespace(rowptr=rowptr, col=c[order].astype(np.int32), N=int(n_rows), E=int(r.size), n_cols=int(n_cols))
 
-    def spmm(self, g, h, row_scale=None, bias=None, relu=False, acc_init=None, profile=None):
+    def spmm(self, g, h, row_scale=None, bias=None, relu=False, acc_init=None, profile=None, out=None):
         import oracle_c
         assert h.shape[0] == g.n_cols or g.E == 0, (h.shape, g.n_cols)
-        out = torch.from_numpy(oracle_c.spmm(g.rowptr, g.col, h.detach().numpy())) if g.E else torch.zeros((g.N, h.shape[1]))
+        h = h.detach().float()         # bf16 wire buffers are widened exactly (the HIP pass does it in registers)
+        res = torch.from_numpy(oracle_c.spmm(g.rowptr, g.col, h.numpy())) if g.E else torch.zeros((g.N, h.shape[1]))
         if acc_init is not None:
-            out = out + acc_init
+            res = res + acc_init
         if row_scale is not None:
-            out = out * row_scale.unsqueeze(1)
+            res = res * row_scale.unsqueeze(1)
         if bias is not None:
-            out = out + bias.detach()
-        return torch.relu(out) if relu else out
+            res = res + bias.detach()
+        res = torch.relu(res) if relu else res
+        if out is not None:            # in-place chaining of the per-slice halo passes (acc_init may alias out)
+            out.copy_(res)
+            return out
+        return res
 
-    def pack_rows(self, x, idx):
-        return x.index_select(0, idx)
+    def pack_rows(self, x, idx, wire='f32'):
+        rows = x.index_select(0, idx)
+        return rows.to(torch.bfloat16) if wire == 'bf16' else rows
 
     def act_bwd(self, g, act, row_scale, need_b):
         gm = g * (act > 0) if act is not None else g

@@ -33,7 +33,7 @@ def _setup(rank, world, port):
     torch.set_num_threads(1)
 
 
-def _worker(rank, world, port, name, q, exchange, overlap, kind, wire='f32'):
+def _worker(rank, world, port, name, q, exchange, overlap, kind, wire='f32', n_slices=None, chunked=False):
     _setup(rank, world, port)
     try:
         import coldbrew_oracle as orc
@@ -48,13 +48,20 @@ def _worker(rank, world, port, name, q, exchange, overlap, kind, wire='f32'):
             part = cbdist.Partition.balanced(torch.from_numpy(csr.in_deg), world, rank, node_weight=2)
         else:
             part = cbdist.Partition(n, world, rank)
-        sg = cbdist.ShardedGraph(ei, n, part, exchange=exchange, overlap=overlap, compute=OracleCompute(), wire=wire)
+        sg = cbdist.ShardedGraph(ei, n, part, exchange=exchange, overlap=overlap, compute=OracleCompute(), wire=wire, n_slices=n_slices)
         assert sg.overlap == (overlap and exchange == 'halo' and world > 1)
         if exchange == 'halo' and world > 1:
-            assert sg.f.plan.n_halo > 0 and sum(sg.f.plan.recv_counts) == sg.f.plan.n_halo
-            assert sg.f.plan.n_halo <= csr.N - part.n_local
+            plan = sg.f.plan
+            assert plan.n_halo > 0 and sum(plan.recv_counts_all) == plan.n_halo == sum(plan.n_halo_slice)
+            assert plan.n_halo <= csr.N - part.n_local
+            assert plan.n_slices == ((n_slices or 1) if sg.overlap else 1)
+            for k in range(plan.n_slices):      # slice k = the requested rows living in row chunk k of their owner
+                r0, r1 = plan.chunks[k]
+                assert plan.send_idx[k].numel() == sum(plan.send_counts[k])
+                assert plan.send_idx[k].numel() == 0 or (int(plan.send_idx[k].min()) >= r0 and int(plan.send_idx[k].max()) < r1)
+            assert [c[0] for c in plan.chunks] + [plan.chunks[-1][1]] == sorted({c for ch in plan.chunks for c in ch}) or part.n_local == 0
             if sg.overlap:
-                assert sg.f.interior.E + sg.f.halo.E == sg.E and sg.f.whole is None
+                assert sg.f.interior.E + sum(h.E for h in sg.f.halo) == sg.E and sg.f.whole is None and len(sg.f.halo) == plan.n_slices
         assert sg.N == part.n_local and sg.row_offset == part.lo()
         sym = np.array_equal(csr.rowptr, csr.rowptr_t) and np.array_equal(csr.col, csr.col_t)
         assert sg.symmetric == sym and (sg.b is sg.f) == sym
@@ -77,6 +84,17 @@ def _worker(rank, world, port, name, q, exchange, overlap, kind, wire='f32'):
         xl, yl, ml = part.slice_rows(x), part.slice_rows(y), part.slice_rows(mask)
         le_l = part.slice_rows(le).clone().requires_grad_(True)
         h = (xl * sg.norm_out.unsqueeze(1)) @ w1 + le_l
+        if chunked and sg.overlap:
+            # the producer form of the pipeline: row chunk k of the matrix is computed right before slice k is packed and sent
+            hh = torch.full_like(h, float('nan'))
+            filled = []
+
+            def produce(k, r0, r1, src=h.detach()):
+                hh[r0:r1] = src[r0:r1]
+                filled.append((k, r0, r1))
+            got = sg.aggregate_finish(sg.aggregate_start(hh, False, produce=produce), False, sg.norm_in, b1.detach(), True)
+            assert [f[0] for f in filled] == list(range(sg.f.plan.n_slices)) and filled[0][1] == 0 and filled[-1][2] == part.n_local
+            torch.testing.assert_close(got, cbdist.sharded_aggregate(sg, h.detach(), sg.norm_in, b1.detach(), relu=True), atol=0, rtol=0)
         h = cbdist.sharded_aggregate(sg, h, sg.norm_in, b1, relu=True)
         h = (h * sg.norm_out.unsqueeze(1)) @ w2
         out = cbdist.sharded_aggregate(sg, h, sg.norm_in, None, relu=False)
@@ -140,6 +158,19 @@ def _run(target, world, *args):
 ])
 def test_sharded_exchange_matches_unsharded_oracle(name, world, exchange, overlap, kind):
     _run(_worker, world, name, exchange, overlap, kind)
+
+
+@pytest.mark.parametrize('name,world,n_slices', [('case_graph_powerlaw_d7_d64', 2, 2), ('case_graph_powerlaw_d7_d64', 3, 4),
+                                                 ('case_graph_asym_multi', 2, 3), ('case_graph_asym_multi', 3, 7)])
+def test_sliced_exchange_pipeline_matches_unsharded_oracle(name, world, n_slices):
+    """The exchange cut into K time slices (slice k = halo rows of owner row chunk k, every peer at once; per-slice halo passes
+    chained through the running sums; producer callbacks per row chunk) gives the unsharded result, forward and backward — also
+    with more slices than a small block has rows (empty slices) and on the directed multigraph (own reverse plan)."""
+    _run(_worker, world, name, 'halo', True, 'edges', 'f32', n_slices, True)
+
+
+def test_sliced_exchange_bf16_wire():
+    _run(_worker, 2, 'case_graph_powerlaw_d7_d64', 'halo', True, 'edges', 'bf16', 3, True)
 
 
 @pytest.mark.parametrize('overlap', [True, False])
