@@ -189,10 +189,27 @@ class HipCompute:
         return deg.to(torch.float32).clamp_(min=1).pow_(-0.5)        # [n_local] vector (GCN.py:206-208,243-245)
 
 
+def slice_weights(k):
+    """Relative sizes of the k time slices.  Default: the first and the last slice are half as large as the ones between
+    (k >= 3) — the first slice's producer + pack is the pipeline's start-up and the last slice's halo pass its tail, both
+    exposed.  COLDBREW_SLICE_WEIGHTS="1,2,2,1" overrides (k comma-separated positive numbers; every rank must see the same)."""
+    env = os.environ.get('COLDBREW_SLICE_WEIGHTS')
+    if env:
+        w = [float(v) for v in env.split(',')]
+        if len(w) == k and all(v > 0 for v in w):
+            return w
+    return [1.0] * k if k < 3 else [1.0] + [2.0] * (k - 2) + [1.0]
+
+
 def chunk_bounds(lo, hi, k):
-    """k+1 ascending global row ids cutting the block [lo, hi) into k nearly equal row chunks."""
+    """k+1 ascending global row ids cutting the block [lo, hi) into k row chunks with the relative sizes slice_weights(k)."""
     n = hi - lo
-    return [lo + (n * i) // k for i in range(k + 1)]
+    w = slice_weights(k)
+    tot, acc, out = sum(w), 0.0, [lo]
+    for i in range(k - 1):
+        acc += w[i]
+        out.append(lo + min(n, int(n * acc / tot)))
+    return out + [hi]
 
 
 def default_slices(n_halo_rows, d=256):
@@ -843,7 +860,10 @@ class ShardedTrainer:
         m = self.teacherGNN
         out = m.get_3_embs(self.x, self.edge_index).emb4classi_full
         # local numerator / global count; the global loss is the sum over ranks
-        loss = ops.nll_logsoftmax(out, self.y, self.train_mask, self.n_train) * self.args.TeacherGNN.lossa_semantic
+        unit = float(self.args.TeacherGNN.lossa_semantic) == 1.0
+        loss = ops.nll_logsoftmax(out, self.y, self.train_mask, self.n_train, unit_grad=unit)
+        if not unit:
+            loss = loss * self.args.TeacherGNN.lossa_semantic
         if m.se_reg_all is not None:
             folded = ops.fold_se_reg(m, self.optimizer, self.args.se_reg, m.se_reg_all)
             # se_reg_all is already global; count it once

@@ -11,7 +11,8 @@ import torch
 from . import _lib
 
 HUB_THRESHOLD = 256
-HOT_ROWS = 262144          # 256 MiB of 1 KiB (d = 256 fp32) rows = the Infinity Cache; measured optimum on S-pl10M
+HOT_BYTES = 256 << 20      # the hot source rows of an aggregation should fill the 256 MiB Infinity Cache: count = HOT_BYTES / row bytes
+HOT_ROWS = HOT_BYTES // 1024   # 262 144 rows at d = 256 fp32 (1 KiB rows): the measured optimum on S-pl10M (profiles/r02_spmm_gather_policy.md)
 
 
 class ZeroInDegreeError(RuntimeError):
@@ -74,14 +75,27 @@ class CSRGraph:
 
     def _hot_cols(self):
         """Kernel-side column arrays with the hot-source flag in bit 31 (include/coldbrew_hip.h, cb_spmm_csr_f32 col_flags):
-        the HOT_ROWS most-referenced source rows of each orientation (referenced at least twice) keep the default cache
-        policy, every other gather streams.  self.col / self.col_t stay the plain ids (the bit-exact CSR contract).
-        CB_SPMM_GATHER=0 (measurement hook) switches the flags off, CB_SPMM_HOT_ROWS overrides the count."""
+        the most-referenced source rows of each orientation (referenced at least twice) — as many as fit the Infinity Cache at the
+        row size being gathered, HOT_BYTES / (d * element bytes) — keep the default cache policy, every other gather streams.
+        self.col / self.col_t stay the plain ids (the bit-exact CSR contract).  col_k / col_t_k hold the arrays for 1 KiB rows
+        (d = 256 fp32, built eagerly); other row sizes (bf16-stored rows, d = 512) are flagged on first use (flagged_cols).
+        CB_SPMM_GATHER=0 (measurement hook) switches the flags off, CB_SPMM_HOT_ROWS overrides the count for every row size."""
         import os
         self.col_k = self.col_t_k = None
+        self._hot_cache = {}
         if os.environ.get('CB_SPMM_GATHER', '2') != '2' or self.E == 0 or self.n_cols < 2 * HOT_ROWS:
             return      # small graphs: the whole feature matrix is cache resident anyway
-        k = min(int(os.environ.get('CB_SPMM_HOT_ROWS', HOT_ROWS)), self.n_cols)
+        self.col_k, self.col_t_k = self._flag_pair(self._hot_count(1024))
+
+    def _hot_count(self, row_bytes):
+        import os
+        k = int(os.environ.get('CB_SPMM_HOT_ROWS', 0)) or HOT_BYTES // max(int(row_bytes), 1)
+        return max(1, min(k, self.n_cols))
+
+    def _flag_pair(self, k):
+        hit = self._hot_cache.get(k)
+        if hit is not None:
+            return hit
 
         def flag(col):
             refs = torch.bincount(col[:self.E].long(), minlength=self.n_cols)          # how often each source row is gathered per launch
@@ -89,9 +103,23 @@ class CSRGraph:
             hot = (refs >= thr)[col.long()]
             return torch.where(hot, col | (-2 ** 31), col).to(torch.int32)
 
-        self.col_k = flag(self.col)
+        ck = flag(self.col)
+        ctk = None
         if self.rowptr_t is not None:
-            self.col_t_k = self.col_k if self.symmetric else flag(self.col_t)
+            ctk = ck if self.symmetric else flag(self.col_t)
+        self._hot_cache[k] = (ck, ctk)
+        return ck, ctk
+
+    def flagged_cols(self, transpose, row_bytes):
+        """Flagged column ids for source rows of `row_bytes` bytes (None: flags off / small graph)."""
+        if self.col_k is None:
+            return None
+        if row_bytes == 1024:
+            return self.col_t_k if transpose else self.col_k
+        if self.n_cols < 2 * self._hot_count(row_bytes):
+            return None
+        pair = self._flag_pair(self._hot_count(row_bytes))
+        return pair[1] if transpose else pair[0]
 
     @classmethod
     def from_csr(cls, rowptr, col, n_cols, hub_threshold=HUB_THRESHOLD):
@@ -201,7 +229,7 @@ class CSRGraph:
         if out is None:
             out = torch.empty((self.N, d), dtype=torch.float32, device=h.device)
         rowptr, col, plan = (self.rowptr_t, self.col_t, self._plan_t) if transpose else (self.rowptr, self.col, self._plan)
-        col_k = self.col_t_k if transpose else self.col_k
+        col_k = self.flagged_cols(transpose, d * h.element_size()) if d % 256 == 0 else None
         flags = int(col_k is not None and d % 256 == 0 and h.data_ptr() % 16 == 0
                     and out.data_ptr() % 16 == 0 and h.stride(0) % 4 == 0 and out.stride(0) % 4 == 0)
         if flags:
@@ -236,6 +264,46 @@ class CSRGraph:
             prof.append((ev0, ev1, self.algorithmic_bytes(d, row_scale=row_scale is not None, bias=bias is not None,
                                                           src_elem=2 if bf16 else 4), 0))
         return out
+
+    def spmm_gemm(self, h, image, transpose=False, row_scale=None, bias=None, relu=False, g_rowscale=None, g_addend=None):
+        """(out, g_out): out = act(row_scale * (A h) + bias) as spmm() and, from the same kernel, g_out = g_rowscale * (out @ B) +
+        g_addend with B the 256 x 256 matrix behind `image` (weight_image) — cb_spmm_gemm_f32: a block keeps its 64 aggregated rows
+        in LDS and multiplies them on the matrix cores while other blocks gather."""
+        lib = _lib.load()
+        _lib.require_device(h, image, row_scale, bias, g_rowscale, g_addend)
+        d = h.shape[1] if h.dim() == 2 else -1
+        if h.dtype != torch.float32 or d != 256 or h.shape[0] != self.n_cols or h.stride(1) != 1:
+            raise ValueError(f'spmm_gemm: float32 [{self.n_cols}, 256] rows expected, got {tuple(h.shape)} {h.dtype}')
+        if transpose and self.rowptr_t is None:
+            raise ValueError('this graph holds the forward orientation only')
+        out = torch.empty((self.N, d), dtype=torch.float32, device=h.device)
+        g_out = torch.empty((self.N, 256), dtype=torch.float32, device=h.device)
+        rowptr, col, plan = (self.rowptr_t, self.col_t, self._plan_t) if transpose else (self.rowptr, self.col, self._plan)
+        col_k = self.flagged_cols(transpose, d * 4)
+        flags = int(col_k is not None and h.data_ptr() % 16 == 0 and h.stride(0) % 4 == 0)
+        if flags:
+            col = col_k
+        ws_bytes = lib.cb_spmm_workspace_bytes(plan.n_chunks, d)
+        ws = self._workspace(ws_bytes)
+        prof = self.profile
+        if prof is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        if g_addend is not None and g_addend.stride(1) != 1:
+            g_addend = g_addend.contiguous()
+        with torch.cuda.device(h.device):
+            _lib.check(lib.cb_spmm_gemm_f32(_lib.ptr(rowptr), _lib.ptr(col), flags, self.N, self.E, _lib.ptr(h), h.stride(0), d,
+                                            _lib.ptr(row_scale), _lib.ptr(bias), int(bool(relu)), _lib.ptr(out), d, self.hub_threshold,
+                                            plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws),
+                                            ws_bytes, _lib.ptr(image), _lib.ptr(g_rowscale), _lib.ptr(g_addend),
+                                            g_addend.stride(0) if g_addend is not None else 0, _lib.ptr(g_out), 256, _lib.stream_ptr()),
+                       'cb_spmm_gemm_f32')
+        if prof is not None:
+            ev1.record()
+            # SURVEY §8(d) bytes of the aggregation; the dense tail's own stream (its [N, 256] output) is kept apart
+            prof.append((ev0, ev1, self.algorithmic_bytes(d, row_scale=row_scale is not None, bias=bias is not None), 0,
+                         self.N * 256 * 4 * (2 if g_addend is not None else 1) + (4 * self.N if g_rowscale is not None else 0)))
+        return out, g_out
 
     def spmm_masked(self, h, src_bits, src_scale, out_coef, transpose=True):
         """out[v] = out_coef * sum_{u in row v} src_scale[u] * (src_bits[u] ? h[u] : 0) (cb_spmm_csr_masked_f32): the reverse
@@ -281,3 +349,20 @@ class CSRGraph:
         if bias:
             b += d * elem
         return b
+
+
+def weight_image(w, transpose=False):
+    """The 256 x 256 matrix B = w (or w^T) split once into bf16 limbs in MFMA fragment order (cb_agg_gemm_image_f32): the B operand
+    of the dense tail of spmm_gemm / the fused trunk kernels.  384 KB, rebuilt every step (the weights change)."""
+    lib = _lib.load()
+    _lib.require_device(w)
+    if w.dtype != torch.float32 or tuple(w.shape) != (256, 256):
+        raise ValueError(f'weight_image: float32 [256, 256] expected, got {tuple(w.shape)} {w.dtype}')
+    if w.stride(1) != 1:
+        w = w.contiguous()
+    nbytes = lib.cb_agg_gemm_image_bytes(256, 256)
+    image = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(lib.cb_agg_gemm_image_f32(_lib.ptr(w), w.stride(0), 256, 256, int(bool(transpose)), _lib.ptr(image), nbytes,
+                                             _lib.stream_ptr()), 'cb_agg_gemm_image_f32')
+    return image

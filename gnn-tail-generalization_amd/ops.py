@@ -257,7 +257,8 @@ def axpby(a, x, b, y):
 # ---------------------------------------------------------------------------------------------
 class _NllFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, y, mask, count):
+    def forward(ctx, logits, y, mask, count, unit_grad=False):
+        ctx.unit_grad = bool(unit_grad)
         lib = _lib.load()
         z = logits if logits.stride(1) == 1 else logits.contiguous()
         rows, C = z.shape
@@ -276,12 +277,16 @@ class _NllFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return grad * g, None, None, None
+        # unit_grad: the caller promised that this loss enters its objective with coefficient 1 and that backward() is seeded
+        # with 1 (the trainers' own step): the [N, C] pass that would multiply by that 1 is skipped
+        return (grad if ctx.unit_grad else grad * g), None, None, None, None
 
 
-def nll_logsoftmax(logits, y, mask=None, count=None):
+def nll_logsoftmax(logits, y, mask=None, count=None, unit_grad=False):
     """mean_{r: mask[r]} nll(log_softmax(logits[r]), y[r]) without materialising logits[mask].
-    `count` = number of masked rows (precomputed once per dataset to avoid a per-step host sync)."""
+    `count` = number of masked rows (precomputed once per dataset to avoid a per-step host sync).
+    unit_grad=True: promise that the upstream gradient of this loss is exactly 1 (loss used with coefficient 1, backward() called on
+    the objective without a seed) — the backward then hands the stored gradient on without a pass over [N, C]."""
     _lib.require_device(logits, y, mask)
     if logits.dtype != torch.float32 or y.dtype != torch.int64:
         raise TypeError('nll_logsoftmax expects float32 logits and int64 labels')
@@ -289,7 +294,7 @@ def nll_logsoftmax(logits, y, mask=None, count=None):
         raise TypeError('mask must be a bool tensor')
     if count is None:
         count = int(mask.sum().item()) if mask is not None else logits.shape[0]
-    return _NllFn.apply(logits, _c(y), _c(mask) if mask is not None else None, count)
+    return _NllFn.apply(logits, _c(y), _c(mask) if mask is not None else None, count, bool(unit_grad))
 
 
 def gather_rows_by_index(x, idx, out_bf16=False):

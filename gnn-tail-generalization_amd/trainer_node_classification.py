@@ -3,8 +3,9 @@ trainer_node_classification.py (trainer.__init__ :252-301, train_teacherGNN :303
 run_trainSet :382-432, run_testSet :453-495, evaluate :672-681, cal_acc_rounded100 :683-687).
 
 Same class/method names, same per-epoch record layout and return shapes; the forward/backward
-runs on the HIP path.  The student / label-propagation modes (SEMLP, StudentBaseMLP, GraphMLP,
-LP) are outside this path and raise NotImplementedError.
+runs on the HIP path.  --train_which=LP (pure label propagation) and the TEACHER side of --train_which=SEMLP (train -> best
+checkpoint -> collect_SE -> top-K replacement hand-off) are built on the same kernels; the student MLP trainers (StudentBaseMLP,
+GraphMLP, the student half of SEMLP) are outside this path.
 """
 import contextlib
 import os
@@ -44,9 +45,42 @@ class trainer:
             return self.train_teacherGNN()
         if self.args.train_which in ['LP']:
             return self.run_pureLP()
+        if self.args.train_which in ['SEMLP']:
+            return self.train_seMLP_part1()
         raise NotImplementedError(f'--train_which={self.args.train_which}: only the TeacherGNN path is built '
                                   'and the pure label-propagation baseline (--train_which=LP) are built; the student MLP '
                                   'trainers are out of scope (SURVEY.md §8f)')
+
+    def train_seMLP_part1(self):
+        """TEACHER SIDE of the reference's train_seMLP_part1 (:66-87) — everything up to the point where the student MLP takes over:
+            train_teacherGNN()                       (:71; with 'SEMLP' in train_which the best-test-accuracy weights are saved, :331-334)
+            load_teacherGNN('best checkpoint')       (:72)
+            teacherSE = collect_SE(x, edge_index)    (:87, GCN.py:148-150: per-layer pre-activation outputs, [N, sum d_l])
+        and the hand-off the student consumes: `self.teacherSE`, written to <modeldir>/teacherSE.pt, and `self.replacement(le_guess)`
+        = SEMLP.replacement (MLP_model/__init__.py:143-156) on the fused scores + top-K + softmax-combine kernel.  The student MLP
+        trainers themselves (part-1 regression onto teacherSE, part 2) are outside this path; returns the teacher's
+        record rows, as train_teacherGNN does."""
+        print('-' * 30, '\n         Training TeacherGNN before train SEMLP\n', '-' * 30)
+        rows = self.train_teacherGNN()
+        self.load_teacherGNN('best checkpoint')
+        self.teacherGNN.eval()
+        with torch.no_grad():
+            self.teacherSE = self.teacherGNN.model.model.collect_SE(self.data.x, self.data.edge_index).detach()
+        self.topK_2_replace = int(self.args.SEMLP_topK_2_replace)
+        path = join(self.modeldir, 'teacherSE.pt')
+        torch.save({'teacherSE': self.teacherSE.cpu(), 'topK_2_replace': self.topK_2_replace}, path)
+        print(f'teacher -> student hand-off: teacherSE {tuple(self.teacherSE.shape)} @ {path}; the student MLP trainers are not part of this path')
+        return rows
+
+    def replacement(self, le_guess, node_idx=None, return_selection=False):
+        """SEMLP.replacement (MLP_model/__init__.py:143-156) for the rows `node_idx` of le_guess (all rows by default): softmax-weighted
+        mix of the topK_2_replace teacher embeddings with the largest inner product — one launch for the whole batch."""
+        if getattr(self, 'teacherSE', None) is None:
+            raise RuntimeError('replacement() needs the teacher embeddings: run train_seMLP_part1() first')
+        q = le_guess.detach()
+        if node_idx is not None:
+            q = q[torch.as_tensor(node_idx, device=q.device, dtype=torch.long)]
+        return ops.se_topk_replace(q.to(self.teacherSE.device), self.teacherSE, self.topK_2_replace, return_selection=return_selection)
 
     def run_pureLP(self):
         """Pure label propagation (reference trainer :33-63): 50 steps of result <- clamp(0.5 * D^-1/2 A D^-1/2 result
@@ -212,8 +246,10 @@ class trainer:
         if getattr(self, '_n_train', None) is None:
             self._n_train = int(self.data.train_mask.sum().item())      # once: keeps the step free of host syncs
         # == F.nll_loss(F.log_softmax(out[train_mask], 1), y[train_mask]) (:390-391), fused, no row gather
-        loss = ops.nll_logsoftmax(res.emb4classi_full, self.data.y, self.data.train_mask, self._n_train)
-        loss = loss * self.args.TeacherGNN.lossa_semantic
+        unit = float(self.args.TeacherGNN.lossa_semantic) == 1.0      # the step seeds backward() with 1: no [N, C] pass to multiply by it
+        loss = ops.nll_logsoftmax(res.emb4classi_full, self.data.y, self.data.train_mask, self._n_train, unit_grad=unit)
+        if not unit:
+            loss = loss * self.args.TeacherGNN.lossa_semantic
         if self.teacherGNN.se_reg_all is not None:
             folded = ops.fold_se_reg(self.teacherGNN, self.optimizer, self.args.se_reg, self.teacherGNN.se_reg_all)
             # folded: the regulariser's gradient enters inside the fused Adam kernel (same update, 20 B/element of `le` less traffic)
@@ -320,8 +356,10 @@ class trainer:
             if getattr(self, '_hip_graph', None) is not None:
                 all_node_logits = self._metrics_forward_replayed()
             else:
-                # a second train-mode, autograd-tracked forward purely for metrics, as in the reference
-                all_node_logits = self.teacherGNN.get_3_embs(self.data.x, self.data.edge_index).emb4classi
+                # a second train-mode forward purely for metrics (:397-413).  The reference tracks it in autograd and never uses the
+                # graph; here it runs under no_grad (same numbers: only argmax is read), so no mask bits / activations are kept
+                with torch.no_grad():
+                    all_node_logits = self.teacherGNN.get_3_embs(self.data.x, self.data.edge_index).emb4classi
             names = ['large_deg_idx', 'small_deg_idx'] + (['zero_deg_idx'] if self.args.use_special_split else [])
             key = (id(self.data), tuple(names), tuple(id(getattr(self.data, n)) for n in names))
             if getattr(self, '_ht_key', None) != key:

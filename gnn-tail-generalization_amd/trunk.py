@@ -29,7 +29,7 @@ def eligible(tc, x, want_les):
             and tc.embedding_dropout == tc.dropout and tc.args.dropout == tc.dropout)
 
 
-def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False, produce=None):
+def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False, produce=None, want_bits=True):
     """(bits, out_next[, act]) of cb_spmm_csr_fused_f32 on the (possibly node-sharded) graph.  Node-sharded + overlapped:
     the exchange runs as the sliced pipeline of dist.ShardedGraph (produce(k, r0, r1), if given, fills rows [r0, r1) of z — the
     row-chunked layer GEMM — right before slice k is packed and sent); the interior-column pass (plain kernel, raw sums) and
@@ -41,19 +41,63 @@ def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False, produ
         flights = sh.start_halo(z, False, produce)
         sh.f.interior.profile = getattr(graph, 'profile', None)
         acc = sh.f.interior.spmm(z)
-        return sh.finish_halo(flights, sh.f, acc, lambda g, recv, a_: _fused_launch(lib, graph, g, recv, a_, bias, x0, c_act, c_mix, p, seed, want_act))
+        return sh.finish_halo(flights, sh.f, acc, lambda g, recv, a_: _fused_launch(lib, graph, g, recv, a_, bias, x0, c_act, c_mix, p, seed, want_act, want_bits))
     if produce is not None:
         produce(0, 0, z.shape[0])
     if sh is None:
-        return _fused_launch(lib, graph, graph, z, None, bias, x0, c_act, c_mix, p, seed, want_act)
-    return _fused_launch(lib, graph, sh.f.whole, sh.exchange(z, False), None, bias, x0, c_act, c_mix, p, seed, want_act)
+        return _fused_launch(lib, graph, graph, z, None, bias, x0, c_act, c_mix, p, seed, want_act, want_bits)
+    return _fused_launch(lib, graph, sh.f.whole, sh.exchange(z, False), None, bias, x0, c_act, c_mix, p, seed, want_act, want_bits)
 
 
-def _fused_launch(lib, graph, g, z, acc, bias, x0, c_act, c_mix, p, seed, want_act):
-    """One fused-store launch over CSR g (the whole graph, a rank's single-pass block, or the last halo slice on top of acc)."""
+def _fused_gemm_launch(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowscale, g_addend, want_bits=True):
+    """(bits, out_next, z_next) of cb_spmm_gemm_fused_f32: the fused trunk store of layer l and Z_{l+1} = g_rowscale * (out_next @ W_{l+1})
+    + g_addend from one kernel (single GPU, d = 256, fp32 rows)."""
+    lib = _lib.load()
+    g = graph
     n, d = g.N, z.shape[1]
     dev = z.device
-    bits = torch.empty((n, d // 256, 4), dtype=torch.int64, device=dev)
+    bits = torch.empty((n, d // 256, 4), dtype=torch.int64, device=dev) if want_bits else None
+    out_next = torch.empty((n, d), dtype=torch.float32, device=dev)
+    z_next = torch.empty((n, 256), dtype=torch.float32, device=dev)
+    plan = g._plan
+    wsb = lib.cb_spmm_workspace_bytes(plan.n_chunks, d)
+    ws = g._workspace(wsb)
+    prof = getattr(graph, 'profile', None)
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    col_k = g.flagged_cols(False, d * 4)
+    if g_addend is not None and g_addend.stride(1) != 1:
+        g_addend = g_addend.contiguous()
+    with torch.cuda.device(dev):
+        _lib.check(lib.cb_spmm_gemm_fused_f32(_lib.ptr(g.rowptr), _lib.ptr(col_k if col_k is not None else g.col), int(col_k is not None), n, g.E,
+                                              _lib.ptr(z), z.stride(0), d, _lib.ptr(graph.norm_in), _lib.ptr(bias), _lib.ptr(x0),
+                                              x0.stride(0) if x0 is not None else 0, float(c_act), float(c_mix), float(p), ctypes.c_uint64(seed),
+                                              ops.seed_dev_ptr(), 0, _lib.ptr(bits), _lib.ptr(out_next), d, g.hub_threshold, plan.n_hubs,
+                                              plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), wsb,
+                                              _lib.ptr(image), _lib.ptr(g_rowscale), _lib.ptr(g_addend),
+                                              g_addend.stride(0) if g_addend is not None else 0, _lib.ptr(z_next), 256, _lib.stream_ptr()),
+                   'cb_spmm_gemm_fused_f32')
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, g.algorithmic_bytes(d), n * d * 4 + n * d // 8,
+                     n * 256 * 4 * (2 if g_addend is not None else 1) + (4 * n if g_rowscale is not None else 0)))
+    return bits, out_next, z_next
+
+
+def agg_gemm_eligible(graph, hidden, agg_bf16):
+    """The aggregation + next-dense-transform kernels (cb_agg_gemm.hip): one GPU, hidden = 256, fp32 rows.  CB_AGG_GEMM=0 keeps the
+    two-kernel form (aggregation, then GEMM)."""
+    return (os.environ.get('CB_AGG_GEMM', '1') != '0' and not hasattr(graph, 'part') and hidden == 256 and not agg_bf16
+            and hasattr(graph, 'spmm_gemm'))
+
+
+def _fused_launch(lib, graph, g, z, acc, bias, x0, c_act, c_mix, p, seed, want_act, want_bits=True):
+    """One fused-store launch over CSR g (the whole graph, a rank's single-pass block, or the last halo slice on top of acc).
+    want_bits=False (forward without a backward: eval / metrics forwards): the backward's mask words are not written."""
+    n, d = g.N, z.shape[1]
+    dev = z.device
+    bits = torch.empty((n, d // 256, 4), dtype=torch.int64, device=dev) if want_bits else None
     out_next = torch.empty((n, d), dtype=torch.float32, device=dev)
     act = torch.empty((n, d), dtype=torch.float32, device=dev) if want_act else None
     plan = g._plan
@@ -64,7 +108,7 @@ def _fused_launch(lib, graph, g, z, acc, bias, x0, c_act, c_mix, p, seed, want_a
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     bf16 = z.dtype == torch.bfloat16
-    col_k = getattr(g, 'col_k', None)
+    col_k = g.flagged_cols(False, d * z.element_size()) if hasattr(g, 'flagged_cols') else None
     head = (_lib.ptr(g.rowptr), _lib.ptr(col_k if col_k is not None else g.col), int(col_k is not None))
     args = head + (n, g.E, _lib.ptr(z), z.stride(0), d, _lib.ptr(graph.norm_in), _lib.ptr(bias),
             _lib.ptr(x0), x0.stride(0) if x0 is not None else 0, float(c_act), float(c_mix), float(p), ctypes.c_uint64(seed),
@@ -173,26 +217,41 @@ class _TrunkFn(torch.autograd.Function):
             x0 = cur = gemm.mm_nn(xd, w_in.t().contiguous(), bias=b_in, relu=True)
         h = x0.shape[1]
         saved_in, saved_bits = [cur], []
+        bwd = any(ctx.needs_input_grad)          # eval / metrics forwards (no_grad): no mask words, nothing kept
+        ag = agg_gemm_eligible(graph, h, agg_bf16)
+        z_ready = None                           # Z_l already produced by layer l-1's aggregation kernel (cb_spmm_gemm_fused_f32)
         for l in range(L):
             w, b, le = layer_params[3 * l: 3 * l + 3]
-            if _chunked(graph, agg_bf16):
+            if ag:
+                from .graph import weight_image
+                z = z_ready if z_ready is not None else gemm.mm_nn(cur, w, rowscale=a, addend=le)
+                z_ready = None
+                sd_l = seeds[l + 2] if p > 0 else 0
+                if l + 1 < L:     # this layer's store + the next layer's transform in one kernel
+                    w1, _, le1 = layer_params[3 * (l + 1): 3 * (l + 1) + 3]
+                    bits, cur, z_ready = _fused_gemm_launch(graph, z, b, x0, 1 - alpha, alpha, p, sd_l, weight_image(w1), a, le1, want_bits=bwd)
+                else:
+                    bits, cur, _ = _fused_spmm(graph, z, b, x0, 1 - alpha, alpha, p, sd_l, want_bits=bwd)
+            elif _chunked(graph, agg_bf16):
                 # node-sharded pipeline: row chunk k of Z leaves the GEMM, is packed and put on the links while chunk k+1 multiplies
                 z = torch.empty((cur.shape[0], w.shape[1]), dtype=torch.float32, device=cur.device)
 
                 def produce(k, r0, r1, cur=cur, w=w, le=le, z=z):
                     if r1 > r0:
                         gemm.mm_nn(cur[r0:r1], w, rowscale=a[r0:r1], addend=le[r0:r1] if le is not None else None, out=z[r0:r1])
-                bits, cur, _ = _fused_spmm(graph, z, b, x0, 1 - alpha, alpha, p, seeds[l + 2] if p > 0 else 0, produce=produce)
+                bits, cur, _ = _fused_spmm(graph, z, b, x0, 1 - alpha, alpha, p, seeds[l + 2] if p > 0 else 0, produce=produce, want_bits=bwd)
             else:
                 z = gemm.mm_nn(cur, w, rowscale=a, addend=le, out_bf16=agg_bf16)
-                bits, cur, _ = _fused_spmm(graph, z, b, x0, 1 - alpha, alpha, p, seeds[l + 2] if p > 0 else 0)
+                bits, cur, _ = _fused_spmm(graph, z, b, x0, 1 - alpha, alpha, p, seeds[l + 2] if p > 0 else 0, want_bits=bwd)
             del z
-            saved_bits.append(bits)
-            saved_in.append(cur)
+            if bwd:
+                saved_bits.append(bits)
+                saved_in.append(cur)
         out = gemm.mm_nn(cur, w_out.t().contiguous(), bias=b_out)
         ctx.graph, ctx.cfg, ctx.row0 = graph, cfg, row0
         ctx.n_layer_params = len(layer_params)
-        ctx.save_for_backward(xd, x0, w_in, w_out, *saved_in, *saved_bits, *[t for t in layer_params if t is not None])
+        if bwd:
+            ctx.save_for_backward(xd, x0, w_in, w_out, *saved_in, *saved_bits, *[t for t in layer_params if t is not None])
         ctx.le_present = [layer_params[3 * l + 2] is not None for l in range(L)]
         return out
 
@@ -238,7 +297,9 @@ class _TrunkFn(torch.autograd.Function):
 
         chunked = gather and not fuse and _chunked(graph, agg_bf16) and graph.b.plan.n_slices > 1
 
-        def dx_gemm(src, wt, rowscale, below):
+        ag_bwd = agg_gemm_eligible(graph, h, agg_bf16) and not masked and not fuse
+
+        def dx_gemm(src, wt, rowscale, below, g_ready=None):
             """dL/dx of the stage above layer `below` (+ that layer's trunk backward when fused): (g, gr, dbias, handle); handle =
             the already started exchange of gr (row-chunked producers of the node-sharded pipeline), else None."""
             sd = seeds[below + 2] if p > 0 else 0
@@ -269,7 +330,7 @@ class _TrunkFn(torch.autograd.Function):
                 return g_, None, db_, None
             if fuse:
                 return gemm.mm_nn_trunkbwd(src, wt, rowscale, saved_bits[below], 1 - alpha, p, sd, row0, bnorm, need[7 + 3 * below + 1]) + (None,)
-            g_ = gemm.mm_nn(src, wt, rowscale=rowscale)
+            g_ = g_ready if g_ready is not None else gemm.mm_nn(src, wt, rowscale=rowscale)     # g_ready: left the reverse aggregation's kernel
             gr_, db_ = _layer_bwd(g_, saved_bits[below], bnorm, gx0, below != L - 1, p, sd, row0, 1 - alpha, alpha,
                                   need[7 + 3 * below + 1], out_bf16=agg_bf16)
             return g_, gr_, db_, None
@@ -286,8 +347,13 @@ class _TrunkFn(torch.autograd.Function):
             if deferred is not None:
                 grads_layers[3 * deferred[0]] = gemm.mm_tn(deferred[1], deferred[2], rowscale=a)
                 deferred = None
+            g_fused = None
             if masked:
                 gz = graph.spmm_masked(g, saved_bits[l], bnorm, coef)                         # dL/dZ_l = A (b * dY'), dY' formed on the fly
+            elif ag_bwd:
+                # dL/dZ_l = A (b * dY') and a * (dL/dZ_l @ W_l^T) from one kernel (cb_spmm_gemm_f32)
+                from .graph import weight_image
+                gz, g_fused = graph.spmm_gemm(gr, weight_image(w, transpose=True), transpose=True, g_rowscale=a)
             else:
                 gz = graph.aggregate_finish(handle, True) if sharded else _spmm_t(graph, gr)  # dL/dZ_l = A (b * dY')
             del g, gr
@@ -299,9 +365,9 @@ class _TrunkFn(torch.autograd.Function):
                     grads_layers[3 * l] = gemm.mm_tn(saved_in[l], gz, rowscale=a)
             grads_layers[3 * l + 1] = dbias
             if l > 0:
-                g, gr, dbias, handle = dx_gemm(gz, w.t().contiguous(), a, l - 1)      # dL/d(dropped X_l) and the backward of layer l-1's store
+                g, gr, dbias, handle = dx_gemm(gz, w.t().contiguous(), a, l - 1, g_fused)   # dL/d(dropped X_l) and the backward of layer l-1's store
             else:
-                g = gemm.mm_nn(gz, w.t().contiguous(), rowscale=a)            # dL/d(dropped X_0): consumed by the input stage
+                g = g_fused if g_fused is not None else gemm.mm_nn(gz, w.t().contiguous(), rowscale=a)   # dL/d(dropped X_0): consumed by the input stage
             if le is not None and need[7 + 3 * l + 2]:
                 grads_layers[3 * l + 2] = gz
             else:

@@ -156,18 +156,30 @@ def to_undirected(edge_index, num_nodes=None):
     return torch.stack([key // n, key % n])
 
 
+class HipLinear(nn.Linear):
+    """nn.Linear (same parameters, initialisation and state_dict keys) whose product with a device matrix runs on the hand-written
+    MFMA GEMM (gemm.linear: forward and both backward contractions) — the Linear layers of the proj2class head (trainer :304-305).
+    CPU tensors (construction-time shape probes, host-side tests) fall through to torch."""
+
+    def forward(self, x):
+        if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
+            from . import gemm
+            return gemm.linear(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 def getMLP(neurons, activation=nn.GELU, bias=True, dropout=0.1, last_dropout=False, normfun='layernorm'):
     """utils.py:885-908: Linear/Norm/Act/Dropout stack; len<2 -> Identity, len==2 -> one Linear."""
     if len(neurons) in [0, 1]:
         return nn.Identity()
     if len(neurons) == 2:
-        return nn.Linear(*neurons)
+        return HipLinear(*neurons)
     layers = []
     n = len(neurons) - 1
     for i in range(n - 1):
         norm = nn.LayerNorm(neurons[i + 1]) if normfun == 'layernorm' else nn.BatchNorm1d(neurons[i + 1])
-        layers.extend([nn.Linear(neurons[i], neurons[i + 1], bias=bias), norm, activation(), nn.Dropout(dropout)])
-    layers.append(nn.Linear(neurons[n - 1], neurons[n], bias=bias))
+        layers.extend([HipLinear(neurons[i], neurons[i + 1], bias=bias), norm, activation(), nn.Dropout(dropout)])
+    layers.append(HipLinear(neurons[n - 1], neurons[n], bias=bias))
     if last_dropout:
         layers.append(nn.Dropout(dropout))
     return nn.Sequential(*layers)

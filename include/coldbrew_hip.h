@@ -386,6 +386,30 @@ int cb_symmetrize_i64(const int64_t* src, const int64_t* dst, int64_t E, int64_t
  * all-to-all of the node-sharded halo exchange (new; the reference is single-device). */
 int cb_gather_rows_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Aggregation + the NEXT dense transform in one kernel (csrc/cb_agg_gemm.hip): a block aggregates 64 rows exactly as
+ * cb_spmm_csr_f32 / cb_spmm_csr_fused_f32 do (same stores: the aggregated matrix still goes to memory), keeps them in LDS and
+ * multiplies the tile by a 256 x 256 matrix B on the matrix cores before anything else is read:
+ *     g_out[v, :] = g_rowscale[v] * (out[v, :] @ B) + g_addend[v, :]           (bit-identical to cb_gemm_nn_f32 on `out`)
+ * Replaces, per layer of the residual trunk: forward  GCN.py:238-253,127-133 followed by :213,225,230-235 of the next layer
+ * (cb_spmm_csr_fused_f32 + cb_gemm_nn_f32); backward autograd of :238 followed by autograd of :213,225
+ * (cb_spmm_csr_f32 on the reverse CSR + cb_gemm_nn_f32 with W^T).  d must be 256; fp32 rows, 16-byte aligned.
+ * image: B split once into bf16 limbs in MFMA fragment order by cb_agg_gemm_image_f32 (transpose = 1: B = W^T);
+ * cb_agg_gemm_image_bytes(256, 256) bytes, 16-byte aligned, L2 resident (384 KB).
+ * ---------------------------------------------------------------------------------- */
+size_t cb_agg_gemm_image_bytes(int64_t K, int64_t N);
+int cb_agg_gemm_image_f32(const float* W, int64_t ld, int64_t K, int64_t N, int transpose, void* image, size_t image_bytes, void* stream);
+int cb_spmm_gemm_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h, int64_t d,
+                     const float* row_scale, const float* bias, int relu, float* out, int64_t ld_out, int32_t hub_threshold, int32_t n_hubs,
+                     int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, const void* image,
+                     const float* g_rowscale, const float* g_addend, int64_t ld_add, float* g_out, int64_t ld_gout, void* stream);
+int cb_spmm_gemm_fused_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h,
+                           int64_t d, const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix, float c_act,
+                           float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits,
+                           float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
+                           const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, const void* image,
+                           const float* g_rowscale, const float* g_addend, int64_t ld_add, float* g_out, int64_t ld_gout, void* stream);
+
 /* The same pack with the rows narrowed to bf16 (round-to-nearest-even) as they are written: the send buffer of the bf16 halo wire. */
 int cb_gather_rows_bf16_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, uint16_t* out, void* stream);
 

@@ -341,6 +341,18 @@ def teacher_forward(cfg, sd, x, csr, training=False, dropout_masks=None, buffers
     return trickscomb_forward(cfg, strip_prefix(sd), x, csr, training, dropout_masks, False, buffers_out)
 
 
+def proj2class_head(sd, common, training=False):
+    """TeacherGNN.proj2class with --has_proj2class=1 (GNN_normalizations.py:13,28,42; built by utils.getMLP :885-908 from
+    neurons_proj2class = [dim_commonEmb = 128, 20, C], utils.py:613-624): Linear -> LayerNorm -> GELU -> Dropout(0.1) -> Linear.
+    Eval-mode restatement (the head's dropout draws from torch's CPU stream in train mode)."""
+    if training:
+        raise NotImplementedError('the oracle restates the proj2class head in eval mode only')
+    h = F.linear(common, sd['proj2class.0.weight'], sd['proj2class.0.bias'])
+    h = F.layer_norm(h, (h.shape[1],), sd['proj2class.1.weight'], sd['proj2class.1.bias'], 1e-5)
+    h = F.gelu(h)
+    return F.linear(h, sd['proj2class.4.weight'], sd['proj2class.4.bias'])
+
+
 def training_loss(cfg, out, se_reg_all, y, train_mask):
     """nll_loss(log_softmax(out[mask])) + se_reg * se_reg_all (trainer_node_classification.py:390-394)."""
     logits = F.log_softmax(out[train_mask], 1)

@@ -355,6 +355,54 @@ def semlp_fixture(ns):
     return out
 
 
+def proj2class_fixture(ns):
+    """--has_proj2class=1 (GNN_normalizations.py:11-29, utils.py:613-624, trainer :304-305): the GNN emits a 128-wide common embedding
+    and the getMLP([128, 20, C]) head turns it into logits.  Eval mode (the head's own Dropout(0.1) draws from torch's CPU stream
+    in train mode): common embedding, logits, loss and every gradient, for a non-residual and a residual trunk."""
+    out = {}
+    for name, kw in {'nr_se100': dict(se='100', layers=2), 'r_initial_se111': dict(dataset='Pubmed', se='111', h=32, layers=2)}.items():
+        c = dict(name=name, dataset='Cora', graph='powerlaw', n=140, f=24, h=16, c=5, layers=2, se='000', type_trick=None, force_best=1,
+                 extra=('--has_proj2class=1',), layer_agg='concat', learnable=0, featureless=0, node_norm_type='n', se_reg=0.5, seed=11)
+        c.update(kw)
+        extra = [f'--num_layers={c["layers"]}', f'--whetherHasSE={c["se"]}', f'--force_set_to_best_config={c["force_best"]}',
+                 f'--se_reg={c["se_reg"]}'] + list(c['extra'])
+        args = ref_args(ns, c['dataset'], extra)
+        ei, n = make_graph(c['graph'], c['n'], c['seed'])
+        args.N_nodes, args.num_feats, args.dim_hidden, args.num_classes = n, c['f'], c['h'], c['c']
+        args.dropout = 0.0
+        ns.utils.set_arch_configs(args)
+        assert args.dim_commonEmb == 128 and args.TeacherGNN.neurons_proj2class == [128, 20, c['c']]
+        g = torch.Generator().manual_seed(1000 + c['seed'])
+        x = torch.rand(n, c['f'], generator=g)
+        y = torch.randint(0, c['c'], (n,), generator=g)
+        train_mask = torch.rand(n, generator=g) < 0.5
+        train_mask[0] = True
+        torch.manual_seed(c['seed'])
+        head = ns.utils.getMLP(args.TeacherGNN.neurons_proj2class)          # trainer :304-305
+        model = ns.GNN_normalizations.TeacherGNN(args, head)
+        with torch.no_grad():
+            gg = torch.Generator().manual_seed(78)
+            for k, p in model.named_parameters():
+                if k.endswith('bias'):
+                    p.add_(0.1 * torch.randn(p.shape, generator=gg))
+        sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        model.eval()
+        with torch.autograd.graph.allow_mutation_on_saved_tensors():
+            res = model.get_3_embs(x, ei, train_mask)
+            loss = torch.nn.functional.nll_loss(torch.nn.functional.log_softmax(res.emb4classi, 1), y[train_mask])
+            if model.se_reg_all is not None:
+                loss = loss + args.se_reg * model.se_reg_all
+            model.zero_grad()
+            loss.backward()
+        cfg = cfg_of(args, c)
+        cfg['num_classes'] = c['c']              # cfg_of reads args.num_classes AFTER TeacherGNN replaced it by dim_commonEmb
+        cfg['dim_commonEmb'] = 128
+        out[name] = dict(cfg=cfg, x=x, edge_index=ei, y=y, train_mask=train_mask, sd=sd0, common=res.commonEmb.detach().clone(),
+                         logits=res.emb4classi_full.detach().clone(), loss=loss.detach().clone(),
+                         grads={k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='')
@@ -362,7 +410,7 @@ def main():
     ns = ref_import.load_reference()
     torch.set_num_threads(1)
     for c in CASES:
-        if a.only and (a.only in ('utils', 'options', 'trainer', 'lp', 'semlp') or a.only not in c['name']):
+        if a.only and (a.only in ('utils', 'options', 'trainer', 'lp', 'semlp', 'proj2class') or a.only not in c['name']):
             continue
         out = run_case(ns, c)
         torch.save(out, os.path.join(HERE, f'case_{c["name"]}.pt'))
@@ -380,7 +428,10 @@ def main():
     if not a.only or 'semlp' in a.only:
         torch.save(semlp_fixture(ns), os.path.join(HERE, 'semlp_fixture.pt'))
         print('wrote semlp_fixture.pt')
-    if not a.only or 'lp' in a.only:
+    if not a.only or 'proj2class' in a.only:
+        torch.save(proj2class_fixture(ns), os.path.join(HERE, 'proj2class_fixture.pt'))
+        print('wrote proj2class_fixture.pt')
+    if not a.only or a.only == 'lp':
         torch.save(lp_fixture(ns), os.path.join(HERE, 'lp_fixture.pt'))
         print('wrote lp_fixture.pt')
     if not a.only or 'options' in a.only:

@@ -1,0 +1,171 @@
+"""GPU: aggregation + next dense transform in one kernel (csrc/cb_agg_gemm.hip) against the two kernels it
+replaces.  The aggregation part is k_spmm_rows' own edge-stream walk and the dense part repeats cb_gemm_limb.hip's limb products
+in the same order, so everything is compared BIT FOR BIT with cb_spmm_csr_f32 / cb_spmm_csr_fused_f32 followed by cb_gemm_nn_f32
+(which are pinned to the oracle in test_gpu_graph_spmm.py / test_gpu_kernels.py); the oracle itself is compared once more at the
+end to end (logits, loss, gradients of a golden case through the fused trunk with the kernels on)."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+import coldbrew_oracle as orc
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _powerlaw_graph(n, seed, T, sym=True):
+    from gnn_tail_generalization_amd.data import synthetic_data
+    from gnn_tail_generalization_amd.graph import CSRGraph
+    data = synthetic_data('S-pl1M', seed=seed, device=DEV, n_override=n)
+    ei = data.edge_index
+    if not sym:      # directed multigraph: drop a third of the edges, duplicate some (own reverse orientation, duplicates counted)
+        gen = torch.Generator(device=DEV).manual_seed(seed)
+        keep = torch.rand(ei.shape[1], device=DEV, generator=gen) < 0.66
+        ei = torch.cat([ei[:, keep], ei[:, :ei.shape[1] // 7], torch.arange(n, device=DEV).repeat(2, 1)], dim=1)
+    return CSRGraph(ei, n, hub_threshold=T)
+
+
+@pytest.mark.parametrize('n,T,sym', [(5003, 16, True), (64, 256, True), (20000, 256, True), (9001, 8, False), (1, 256, True)])
+@pytest.mark.parametrize('transpose', [False, True])
+def test_spmm_gemm_equals_aggregation_then_gemm(n, T, sym, transpose):
+    """cb_spmm_gemm_f32: out and g_out bit-identical to cb_spmm_csr_f32 followed by cb_gemm_nn_f32 — ragged last tile (N % 64 != 0),
+    hub rows (tiny threshold: most blocks contain rows finished by the hub kernels), directed multigraph / reverse orientation."""
+    from gnn_tail_generalization_amd import gemm
+    from gnn_tail_generalization_amd.graph import CSRGraph, weight_image
+    if n == 1:
+        G = CSRGraph(torch.zeros((2, 1), dtype=torch.int64, device=DEV), 1)
+    else:
+        G = _powerlaw_graph(n, 3, T, sym)
+    if T <= 16:
+        assert G._plan.n_hubs > 0
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    h = torch.randn(n, 256, device=DEV, generator=gen)
+    w = torch.randn(256, 256, device=DEV, generator=gen) * 0.07
+    rs = torch.rand(n, device=DEV, generator=gen) + 0.5
+    bias = torch.randn(256, device=DEV, generator=gen)
+    a = torch.rand(n, device=DEV, generator=gen) + 0.5
+    le = torch.randn(n, 256, device=DEV, generator=gen)
+    for tw in (False, True):
+        B = w.t().contiguous() if tw else w
+        img = weight_image(w, transpose=tw)
+        out, g = G.spmm_gemm(h, img, transpose=transpose, row_scale=rs, bias=bias, relu=True, g_rowscale=a, g_addend=le)
+        ref = G.spmm(h, transpose=transpose, row_scale=rs, bias=bias, relu=True)
+        assert torch.equal(out, ref)
+        assert torch.equal(g, gemm.mm_nn(ref, B, rowscale=a, addend=le))
+    # the backward's form: raw sums, scale only
+    out, g = G.spmm_gemm(h, weight_image(w, transpose=True), transpose=transpose, g_rowscale=a)
+    ref = G.spmm(h, transpose=transpose)
+    assert torch.equal(out, ref) and torch.equal(g, gemm.mm_nn(ref, w.t().contiguous(), rowscale=a))
+    # and against fp64 (the dense tail is an fp32-grade GEMM)
+    want = (ref.double() @ w.t().double()) * a.double().unsqueeze(1)
+    torch.testing.assert_close(g.double(), want, atol=2e-5 * float(want.abs().max()) + 1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize('n,T,p', [(5003, 16, 0.1), (20000, 256, 0.0), (777, 8, 0.3)])
+def test_fused_store_gemm_equals_fused_store_then_gemm(n, T, p):
+    """cb_spmm_gemm_fused_f32: mask words, out_next and Z_next bit-identical to cb_spmm_csr_fused_f32 followed by cb_gemm_nn_f32."""
+    from gnn_tail_generalization_amd import gemm, trunk
+    from gnn_tail_generalization_amd.graph import weight_image
+    G = _powerlaw_graph(n, 9, T)
+    gen = torch.Generator(device=DEV).manual_seed(6)
+    z = torch.randn(n, 256, device=DEV, generator=gen)
+    x0 = torch.randn(n, 256, device=DEV, generator=gen)
+    w = torch.randn(256, 256, device=DEV, generator=gen) * 0.07
+    bias = torch.randn(256, device=DEV, generator=gen)
+    le = torch.randn(n, 256, device=DEV, generator=gen)
+    a = G.norm_out
+    for mix, addend in ((x0, le), (None, None)):
+        bits, nxt, zn = trunk._fused_gemm_launch(G, z, bias, mix, 0.9, 0.1, p, 4242, weight_image(w), a, addend)
+        bits_r, nxt_r, _ = trunk._fused_spmm(G, z, bias, mix, 0.9, 0.1, p, 4242)
+        assert torch.equal(bits, bits_r) and torch.equal(nxt, nxt_r)
+        assert torch.equal(zn, gemm.mm_nn(nxt_r, w, rowscale=a, addend=addend))
+    b2, n2, z2 = trunk._fused_gemm_launch(G, z, bias, x0, 0.9, 0.1, p, 4242, weight_image(w), a, le, want_bits=False)
+    assert b2 is None and torch.equal(n2, nxt_r if False else trunk._fused_spmm(G, z, bias, x0, 0.9, 0.1, p, 4242)[1])
+
+
+def _step_losses(monkeypatch, flag, steps=3, n=30000):
+    from gnn_tail_generalization_amd import ops
+    from gnn_tail_generalization_amd.base_options import BaseOptions
+    from gnn_tail_generalization_amd.data import synthetic_data
+    from gnn_tail_generalization_amd.trainer_node_classification import trainer
+    monkeypatch.setenv('CB_AGG_GEMM', flag)
+    with contextlib.redirect_stdout(io.StringIO()):
+        args = BaseOptions().get_arguments(['--dataset=S-pl1M', '--num_layers=3', '--use_special_split=0', '--want_headtail=0',
+                                            '--manual_assign_GPU=0', '--do_deg_analyze=0', '--whetherHasSE=111', '--se_reg=0.3'])
+        t = trainer.__new__(trainer)
+        t.args, t.bag, t.device = args, {}, torch.device(DEV)
+        args.device = t.device
+        t.data = synthetic_data('S-pl1M', seed=0, device=DEV, n_override=n)
+        args.N_nodes = n
+        from gnn_tail_generalization_amd.utils import set_arch_configs
+        from gnn_tail_generalization_amd import optim
+        set_arch_configs(args)
+        torch.manual_seed(0)
+        from gnn_tail_generalization_amd.GNN_model import TeacherGNN
+        t.teacherGNN = TeacherGNN(args).to(DEV)
+        t.optimizer = optim.resolve(args.optfun)(t.teacherGNN.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+    ops._seed_override[:] = list(range(9100, 9100 + 8 * steps))
+    losses = [float(t.train_step()) for _ in range(steps)]
+    ops._seed_override[:] = []
+    sd = {k: v.detach().clone() for k, v in t.teacherGNN.state_dict().items()}
+    return losses, sd
+
+
+def test_training_step_with_fused_kernels_equals_two_kernel_form(monkeypatch):
+    """Three optimisation steps of the 3-layer 'Initial' trunk (hidden 256, structural embeddings on, dropout on) with the
+    aggregation + GEMM kernels (CB_AGG_GEMM=1, default) and with the separate kernels (=0): same losses and parameters, bit for bit."""
+    l1, sd1 = _step_losses(monkeypatch, '1')
+    l0, sd0 = _step_losses(monkeypatch, '0')
+    assert l1 == l0
+    for k in sd0:
+        assert torch.equal(sd1[k], sd0[k]), k
+
+
+def test_fused_kernels_against_the_oracle(monkeypatch):
+    """End to end against the ORACLE (not against the product's other path): the benchmark configuration (3-layer 'InitialBatchNorm'
+    trunk, hidden 256, structural embeddings on) on a 3000-node power-law graph with the aggregation + GEMM kernels on — logits 1e-4,
+    loss 1e-5, every parameter gradient to the golden-case tolerances."""
+    from gnn_tail_generalization_amd import ops, trunk
+    from gnn_tail_generalization_amd.base_options import BaseOptions
+    from gnn_tail_generalization_amd.data import synthetic_data
+    from gnn_tail_generalization_amd.GNN_model import TeacherGNN
+    from gnn_tail_generalization_amd.utils import set_arch_configs
+    monkeypatch.setenv('CB_AGG_GEMM', '1')
+    monkeypatch.setenv('CB_SE_REG_FOLD', '0')           # the regulariser's gradient through autograd, so that le.grad is complete
+    n = 3000
+    with contextlib.redirect_stdout(io.StringIO()):
+        a = BaseOptions().get_arguments(['--dataset=S-pl1M', '--num_layers=3', '--use_special_split=0', '--manual_assign_GPU=0',
+                                         '--whetherHasSE=111', '--se_reg=0.5'])
+    data = synthetic_data('S-pl1M', seed=1, device=DEV, n_override=n)
+    a.N_nodes, a.dropout, a.device = n, 0.0, torch.device(DEV)
+    set_arch_configs(a)
+    torch.manual_seed(0)
+    m = TeacherGNN(a).to(DEV)
+    m.train()
+    out = m(data.x, data.edge_index)
+    graph = m.model.model._graph(data.edge_index)
+    assert trunk.agg_gemm_eligible(graph, 256, False) and not trunk.agg_gemm_eligible(graph, 64, False)
+    loss = ops.nll_logsoftmax(out, data.y, data.train_mask) + a.se_reg * m.se_reg_all
+    loss.backward()
+    cfg = orc.make_cfg(type_trick=a.type_trick, num_layers=3, num_feats=a.num_feats, dim_hidden=a.dim_hidden, num_classes=a.num_classes,
+                       res_alpha=a.res_alpha, whetherHasSE=(1, 1, 1), se_reg=a.se_reg)
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in m.state_dict().items()}
+    csr = orc.build_csr(data.edge_index.cpu(), n)
+    o, reg = orc.teacher_forward(cfg, sd, data.x.cpu(), csr, training=True)
+    ref = orc.training_loss(cfg, o, reg, data.y.cpu(), data.train_mask.cpu())
+    ref.backward()
+    torch.testing.assert_close(out.detach().cpu(), o.detach(), atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(loss.detach().cpu(), ref.detach(), atol=1e-5, rtol=1e-5)
+    checked = 0
+    for k, p_ in m.named_parameters():
+        if p_.grad is None:
+            continue
+        want = sd[k].grad
+        assert want is not None, k
+        torch.testing.assert_close(p_.grad.cpu(), want, atol=2e-5, rtol=2e-4, msg=lambda s_, k=k: f'{k}: {s_}')
+        checked += 1
+    assert checked >= 10

@@ -241,3 +241,34 @@ def test_fused_trunk_learnable_input_and_featureless():
         assert set(res[True][1]) == set(res[False][1]) and (('embs' in res[True][1]) == bool(args.dim_learnable_input))
         for k in res[True][1]:
             torch.testing.assert_close(res[True][1][k], res[False][1][k], atol=2e-6, rtol=2e-4, msg=lambda m, k=k: f'{extra} {k}: {m}')
+
+
+@pytest.mark.parametrize('name', ['nr_se100', 'r_initial_se111'])
+def test_proj2class_head_matches_reference(name):
+    """--has_proj2class=1: 128-wide common embedding + getMLP([128, 20, C]) head whose Linear layers run on the
+    MFMA GEMM (utils.HipLinear) — common embedding, logits 1e-4, loss, every gradient (trunk AND head) against the unmodified reference."""
+    from helpers import product_args
+    from gnn_tail_generalization_amd.GNN_model import TeacherGNN
+    from gnn_tail_generalization_amd.utils import HipLinear, getMLP
+    g = load_golden('proj2class_fixture')[name]
+    args = product_args(g['cfg'], extra=['--has_proj2class=1'])
+    assert args.dim_commonEmb == 128 and args.TeacherGNN.neurons_proj2class == [128, 20, g['cfg']['num_classes']]
+    args.device = torch.device(DEV)
+    head = getMLP(args.TeacherGNN.neurons_proj2class)
+    assert isinstance(head[0], HipLinear) and isinstance(head[4], HipLinear)
+    model = TeacherGNN(args, head)
+    model.load_state_dict(g['sd'], strict=True)
+    model = model.to(DEV).eval()
+    x, ei, y, mask = g['x'].to(DEV), g['edge_index'].to(DEV), g['y'].to(DEV), g['train_mask'].to(DEV)
+    res = model.get_3_embs(x, ei, mask)
+    torch.testing.assert_close(res.commonEmb.detach().cpu(), g['common'], atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(res.emb4classi_full.detach().cpu(), g['logits'], atol=1e-4, rtol=1e-4)
+    loss = torch.nn.functional.nll_loss(torch.nn.functional.log_softmax(res.emb4classi, 1), y[mask])
+    if model.se_reg_all is not None:
+        loss = loss + args.se_reg * model.se_reg_all
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), g['loss'], atol=1e-5, rtol=1e-5)
+    for k, p in model.named_parameters():
+        if k in g['grads']:
+            torch.testing.assert_close(p.grad.cpu(), g['grads'][k], atol=2e-5, rtol=2e-4, msg=lambda m, k=k: f'{k}: {m}')
+    assert sum(1 for k in g['grads'] if k.startswith('proj2class')) == 6

@@ -112,3 +112,19 @@ def test_oracle_semlp_replacement_matches_reference():
         out, sel, w = orc.semlp_replacement(g['q'], g['teacher'], g['k'])
         torch.testing.assert_close(out, g['out'], atol=1e-6, rtol=1e-6, msg=lambda m, name=name: f'{name}: {m}')
         assert sel.shape == (g['q'].shape[0], g['k'])
+
+
+def test_oracle_proj2class_head_matches_reference():
+    """--has_proj2class=1: the oracle's trunk + head restatement against the unmodified reference (common embedding, logits, loss)."""
+    from helpers import oracle_cfg
+    fx = load_golden('proj2class_fixture')
+    assert set(fx) == {'nr_se100', 'r_initial_se111'}
+    for name, g in fx.items():
+        cfg = dict(g['cfg'], num_classes=g['cfg']['dim_commonEmb'])        # the GNN's last layer emits the 128-wide common embedding
+        csr = orc.build_csr(g['edge_index'], g['cfg']['N_nodes'])
+        common, reg = orc.teacher_forward(oracle_cfg(cfg), g['sd'], g['x'], csr, training=False)
+        torch.testing.assert_close(common, g['common'], atol=1e-5, rtol=1e-5, msg=lambda m: f'{name} common: {m}')
+        logits = orc.proj2class_head(g['sd'], common)
+        torch.testing.assert_close(logits, g['logits'], atol=1e-5, rtol=1e-5, msg=lambda m: f'{name} logits: {m}')
+        loss = orc.training_loss(oracle_cfg(cfg), logits, reg, g['y'], g['train_mask'])
+        torch.testing.assert_close(loss, g['loss'], atol=1e-5, rtol=1e-5)
