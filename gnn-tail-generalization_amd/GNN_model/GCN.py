@@ -198,14 +198,14 @@ class GCNConv(nn.Module):
     def forward(self, graph, feat, weight=None, edge_weight=None, _fused_relu=False):
         if not self._allow_zero_in_degree:
             graph.check_zero_in_degree()                       # GCN.py:187-197
-        if edge_weight is not None:
-            raise NotImplementedError('edge_weight (u_mul_e) is never passed by TricksComb (GCN.py:115,199-202)')
+        if edge_weight is not None:                            # GCN.py:199-202: u_mul_e instead of copy_src (TricksComb never passes one)
+            assert edge_weight.shape[0] == graph.number_of_edges()
         if self._norm != 'both':
             raise NotImplementedError("only norm='both' is reachable from TricksComb")
         w = self._pick_weight(weight)
         h, se_reg = ops.transform(feat, graph.norm_out, w, self.le if self.whetherHasSE else None, graph)   # :213,225,230-236
         self.se_norm = None if se_reg is None else se_reg.detach()      # last ||le||_F (ops.fold_se_reg)
-        rst = ops.aggregate(graph, h, row_scale=graph.norm_in, bias=self.bias, relu=_fused_relu)            # :238,250,253
+        rst = ops.aggregate(graph, h, row_scale=graph.norm_in, bias=self.bias, relu=_fused_relu, edge_weight=edge_weight)   # :238,250,253
         return (rst if self._activation is None else self._activation(rst)), se_reg
 
     def extra_repr(self):

@@ -28,20 +28,41 @@ struct Cand {
 
 __device__ __forceinline__ bool better(float v, int i, float w, int j) { return v > w || (v == w && i > j); }
 
-// insert (v,i) into the descending list best[0..K)
+// K-th best of a list without indexing it at run time
+template <int K_>
+__device__ __forceinline__ float best_kth_v(const Cand (&best)[K_], int K) {
+  float r = best[0].v;
+#pragma unroll
+  for (int s = 1; s < K_; ++s) r = (s == K - 1) ? best[s].v : r;
+  return r;
+}
+template <int K_>
+__device__ __forceinline__ int best_kth_i(const Cand (&best)[K_], int K) {
+  int r = best[0].i;
+#pragma unroll
+  for (int s = 1; s < K_; ++s) r = (s == K - 1) ? best[s].i : r;
+  return r;
+}
+
+// insert (v,i) into the descending list best[0..K): a chain of compare-and-swaps with compile-time indices (the element carried
+// along is always the smaller one, so the list stays sorted and the K-th falls off the end).  Register-only: an insertion point
+// computed at run time indexes the array dynamically, which puts `best` into scratch memory — every fold then waits on scratch
+// round trips (measured: 464 -> 331 ms at arxiv scale only by filtering, the rest of the gap was this).
 template <int K_>
 __device__ __forceinline__ void push(Cand (&best)[K_], int K, float v, int i) {
-  if (!better(v, i, best[K - 1].v, best[K - 1].i)) return;
-  int p = K - 1;
+  if (!better(v, i, best_kth_v(best, K), best_kth_i(best, K))) return;
 #pragma unroll
-  for (int s = K_ - 1; s > 0; --s) {
-    if (s < K && s <= p && better(v, i, best[s - 1].v, best[s - 1].i)) {
-      best[s] = best[s - 1];
-      p = s - 1;
+  for (int s = 0; s < K_; ++s) {
+    if (s < K) {
+      const bool b = better(v, i, best[s].v, best[s].i);
+      const float tv = best[s].v;
+      const int ti = best[s].i;
+      best[s].v = b ? v : tv;
+      best[s].i = b ? i : ti;
+      v = b ? tv : v;
+      i = b ? ti : i;
     }
   }
-  best[p].v = v;
-  best[p].i = i;
 }
 
 // fold one 128x128 score tile (accumulators of the four wavefronts) into the running top-K lists, 32 query rows per pass
@@ -90,6 +111,76 @@ __device__ __forceinline__ void fold_tile(f32x16 (&acc)[2][2], float* __restrict
   }
 }
 
+// The fold above costs as much as the K loop of a 128 x 128 x 768 tile (measured: 464 ms with it, 240 ms without, arxiv scale):
+// it stages and scans all 16 384 scores of every tile although, once a query has seen n teacher rows, a new score enters its top K
+// with probability K / n.  Filtered fold: every lane compares its 64 accumulator values with the K-th best value of their rows
+// (s_thr) where they sit — no staging — and the few that pass are appended to a small LDS queue; one thread per query row then
+// merges its queue entries.  The candidate set is exactly "scores not worse than the current K-th best", insertion uses the same
+// strict total order (value, then index), so the lists equal the unfiltered fold's whatever order the queue was filled in.  A
+// tile with more than QCAP candidates (the first tiles of a block) takes the unfiltered fold.
+constexpr int QCAP = 1024;
+struct QCand {
+  float v;
+  int i, row;
+};
+
+struct FoldState {
+  Cand (*cand)[8][KMAX];     // [32][8][KMAX] scratch of the unfiltered fold
+  Cand (*run)[KMAX];         // [128][KMAX] running lists
+  float* thr;                // [128] value of the K-th best of each row (-inf while the list is short)
+  QCand* q;                  // [QCAP]
+  int* qn;
+};
+
+__device__ __forceinline__ void fold_filtered(f32x16 (&acc)[2][2], float* __restrict__ Cs, const FoldState& fs, int n0, int N, int K, int t) {
+  const int lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  // (entry: a block barrier separates this call from the last writes to thr / qn == 0)
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int rbase = wr * 64 + ti * 32 + 8 * q4 + 4 * lh;
+      const float4 th = *reinterpret_cast<const float4*>(fs.thr + rbase);
+      const float thv[4] = {th.x, th.y, th.z, th.w};
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+          const float v = acc[ti][tj][4 * q4 + r4];
+          const int n = n0 + wc * 64 + tj * 32 + l31;
+          if (v >= thv[r4] && n < N) {
+            const int slot = atomicAdd(fs.qn, 1);
+            if (slot < QCAP) fs.q[slot] = QCand{v, n, rbase + r4};
+          }
+        }
+    }
+  __syncthreads();
+  const int qn = *fs.qn;
+  if (qn > QCAP) {                      // block-uniform: too many candidates for the queue -> the unfiltered fold of the whole tile
+    fold_tile(acc, Cs, *reinterpret_cast<Cand (*)[32][8][KMAX]>(fs.cand), *reinterpret_cast<Cand (*)[128][KMAX]>(fs.run), n0, N, K, t);
+  } else if (qn > 0 && t < 128) {
+    Cand best[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) best[k] = fs.run[t][k];
+    bool touched = false;
+    for (int c = 0; c < qn; ++c) {
+      const QCand x = fs.q[c];
+      if (x.row == t) { push<KMAX>(best, K, x.v, x.i); touched = true; }
+    }
+    if (touched) {
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) fs.run[t][k] = best[k];
+    }
+  }
+  if (qn > 0) {
+    __syncthreads();
+    if (t < 128) fs.thr[t] = fs.run[t][K - 1].v;
+    if (t == 0) *fs.qn = 0;
+    __syncthreads();
+  }
+}
+
 __global__ void __launch_bounds__(256) k_topk_scores(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ T, int64_t ldt,
                                                      int64_t B, int N, int D, int K, int tiles_per_split, int n_col_tiles,
                                                      Cand* __restrict__ partial, int aligned) {
@@ -98,6 +189,10 @@ __global__ void __launch_bounds__(256) k_topk_scores(const float* __restrict__ Q
   __shared__ __attribute__((aligned(16))) float smem[TL::SMEM_FLOATS];
   __shared__ Cand s_cand[32][8][KMAX];
   __shared__ Cand s_run[BM][KMAX];
+  __shared__ __attribute__((aligned(16))) float s_thr[BM];
+  __shared__ int s_qn;
+  static_assert(sizeof(QCand) * QCAP <= sizeof(s_cand), "the candidate queue lives in the unfiltered fold's scratch (never used together)");
+  const FoldState fs{s_cand, s_run, s_thr, reinterpret_cast<QCand*>(&s_cand[0][0][0]), &s_qn};
   auto As = [&](int b) { return smem + b * (BK * LDA); };
   auto Bs = [&](int b) { return smem + 2 * BK * LDA + b * (BK * LDB); };
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
@@ -107,6 +202,8 @@ __global__ void __launch_bounds__(256) k_topk_scores(const float* __restrict__ Q
     s_run[i / KMAX][i % KMAX].v = -INFINITY;
     s_run[i / KMAX][i % KMAX].i = -1;
   }
+  if (t < BM) s_thr[t] = -INFINITY;
+  if (t == 0) s_qn = 0;
   __syncthreads();
   const int ct_begin = split * tiles_per_split, ct_end = min(n_col_tiles, ct_begin + tiles_per_split);
   const int nk = (D + BK - 1) / BK;
@@ -144,7 +241,7 @@ __global__ void __launch_bounds__(256) k_topk_scores(const float* __restrict__ Q
       }
       __syncthreads();
     }
-    fold_tile(acc, smem, s_cand, s_run, n0, N, K, t);
+    fold_filtered(acc, smem, fs, n0, N, K, t);
   }
   for (int i = t; i < BM * K; i += 256) {
     const int row = i / K, k = i % K;
@@ -164,6 +261,10 @@ __global__ void __launch_bounds__(256, 2) k_topk_scores_l3(const float* __restri
   static_assert(32 * (BN + 4) * 4 <= 2 * (OA::BYTES + OB::BYTES), "fold staging must fit");
   __shared__ Cand s_cand[32][8][KMAX];
   __shared__ Cand s_run[BM][KMAX];
+  __shared__ __attribute__((aligned(16))) float s_thr[BM];
+  __shared__ int s_qn;
+  static_assert(sizeof(QCand) * QCAP <= sizeof(s_cand), "the candidate queue lives in the unfiltered fold's scratch (never used together)");
+  const FoldState fs{s_cand, s_run, s_thr, reinterpret_cast<QCand*>(&s_cand[0][0][0]), &s_qn};
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int split = blockIdx.y;
@@ -171,6 +272,8 @@ __global__ void __launch_bounds__(256, 2) k_topk_scores_l3(const float* __restri
     s_run[i / KMAX][i % KMAX].v = -INFINITY;
     s_run[i / KMAX][i % KMAX].i = -1;
   }
+  if (t < BM) s_thr[t] = -INFINITY;
+  if (t == 0) s_qn = 0;
   __syncthreads();
   OA oa;
   oa.init(ldq, B - m0, t);
@@ -184,7 +287,8 @@ __global__ void __launch_bounds__(256, 2) k_topk_scores_l3(const float* __restri
     f32x16 acc[2][2];
     zero_acc_n<2>(acc);
     limb_k_loop<2, 1, OA, OB>(oa, ob, smem, Q + m0 * ldq, KS, ldq, T + (int64_t)n0 * ldt, KS, ldt, nullptr, D, aaddr, baddr, acc, t);
-    fold_tile(acc, reinterpret_cast<float*>(smem), s_cand, s_run, n0, N, K, t);
+    if (K > 0) fold_filtered(acc, reinterpret_cast<float*>(smem), fs, n0, N, K, t);
+    else if (acc[0][0][0] == 12345.678f) s_run[0][0].v = 1.f;      // (K = -1: measurement launch without the fold, see cb_topk_replace_f32)
   }
   for (int i = t; i < BM * K; i += 256) {
     const int row = i / K, k = i % K;
@@ -276,13 +380,15 @@ extern "C" int cb_topk_replace_f32(const float* q, int64_t ldq, const float* t, 
   hipStream_t st = (hipStream_t)stream;
   const int aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)t % 16 == 0) && ldq % 4 == 0 && ldt % 4 == 0;
   static const bool plain = getenv("CB_GEMM_PLAIN_F32") != nullptr;
+  static const bool nofold = getenv("CB_TOPK_NOFOLD") != nullptr;      // measurement hook: the score sweep alone (results are garbage)
   if (aligned && !plain && D % 4 == 0 && ldq < (1 << 22) && ldt < (1 << 22))
-    hipLaunchKernelGGL(k_topk_scores_l3, dim3((unsigned)rb, (unsigned)ns), dim3(256), 0, st, q, ldq, t, ldt, B, (int)N, (int)D, (int)K,
+    hipLaunchKernelGGL(k_topk_scores_l3, dim3((unsigned)rb, (unsigned)ns), dim3(256), 0, st, q, ldq, t, ldt, B, (int)N, (int)D, nofold ? -1 : (int)K,
                        tps, ctl, (Cand*)ws);
   else
     hipLaunchKernelGGL(k_topk_scores, dim3((unsigned)rb, (unsigned)ns), dim3(256), 0, st, q, ldq, t, ldt, B, (int)N, (int)D, (int)K,
                        tps, ctl, (Cand*)ws, aligned);
   CB_LAUNCH_CHECK();
+  if (nofold) return CB_OK;
   hipLaunchKernelGGL(k_topk_finish, dim3((unsigned)((B * 64 + 255) / 256)), dim3(256), 0, st, (const Cand*)ws, ns, B, (int)K, t, ldt,
                      (int)D, out, out_idx, out_w);
   CB_LAUNCH_CHECK();

@@ -341,6 +341,14 @@ class ShardedGraph:
                 _all_reduce(tot, group=group)
             self.E_global = int(tot.item())
         self.E = int(rf.numel())
+        # SURVEY.md 8(b) for E >= 2^31: the int32 guarantee is per rank — every rank's two blocks must stay below 2^31 edges (checked on
+        # all ranks together, so that no rank walks into a collective the others skip)
+        big = torch.tensor([int(max(rf.numel(), rb.numel()) >= 2 ** 31 - 1 or n_nodes >= 2 ** 31 - 1)], dtype=torch.int64, device=rf.device)
+        if part.world > 1:
+            _all_reduce(big, op=dist.ReduceOp.MAX, group=group)
+        if int(big.item()):
+            raise ValueError(f'a rank\'s row block holds >= 2^31 edges (this rank: {int(rf.numel())} of {self.E_global}) or the graph >= 2^31 nodes: '
+                             f'int32 device indices need more ranks (world = {part.world})')
         in_deg = torch.bincount(rf, minlength=self.N)[:self.N]
         out_deg = torch.bincount(rb, minlength=self.N)[:self.N]
         self.in_deg = in_deg

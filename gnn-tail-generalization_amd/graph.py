@@ -11,6 +11,7 @@ import torch
 from . import _lib
 
 HUB_THRESHOLD = 256
+INT32_EDGE_LIMIT = 2 ** 31 - 1   # edge offsets (rowptr) and column ids are int32 on the device (include/coldbrew_hip.h); see CSRGraph.__init__
 HOT_BYTES = 256 << 20      # the hot source rows of an aggregation should fill the 256 MiB Infinity Cache: count = HOT_BYTES / row bytes
 HOT_ROWS = HOT_BYTES // 1024   # 262 144 rows at d = 256 fp32 (1 KiB rows): the measured optimum on S-pl10M (profiles/r02_spmm_gather_policy.md)
 
@@ -35,11 +36,18 @@ class CSRGraph:
         ei = edge_index.to(torch.int64).contiguous()      # may arrive as a transposed view (utils.py:745)
         dev = ei.device
         E = ei.shape[1]
+        if E >= INT32_EDGE_LIMIT:
+            # indices are int32.  The guarantee for larger graphs is PER RANK, not per graph: the node-sharded path
+            # (torchrun, dist.ShardedGraph) builds one CSR per row block, and an edge-balanced partition keeps a block at about E / P
+            # edges (dist.Partition.balanced) — a 2^31-edge graph needs P >= 2 anyway for its 8.6 GB of column ids + 2 TB of gathers
+            raise ValueError(f'edge_index has {E} columns: one device CSR holds fewer than 2^31 (int32 edge offsets); shard the graph '
+                             f'(torchrun --nproc-per-node P main.py ...: every rank then indexes only its own row block, < 2^31 edges each)')
         if num_nodes is None:                               # DGL infers max id + 1 (GCN.py:94)
             num_nodes = int(ei.max().item()) + 1 if E else 0
         N = int(num_nodes)
         self.N, self.E, self.device = N, E, dev
         self.n_cols, self.row_offset = N, 0
+        self._ei, self._perm, self._perm_t = ei, None, None      # edge ids behind the CSR positions are derived on demand (edge_weight only)
         self.hub_threshold = int(hub_threshold)
         self.rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
         self.col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
@@ -151,6 +159,8 @@ class CSRGraph:
         dev = rows.device
         rows, cols = rows.to(torch.int64).contiguous(), cols.to(torch.int64).contiguous()
         E, n = int(rows.numel()), max(int(n_rows), int(n_cols), 1)
+        if E >= INT32_EDGE_LIMIT or n >= INT32_EDGE_LIMIT:
+            raise ValueError(f'this row block holds {E} edges / {n} columns: a rank\'s CSR is int32-indexed (< 2^31); use more ranks')
         rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
         col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
         rowptr_t = torch.empty(n + 1, dtype=torch.int32, device=dev)      # the ingest builds both orientations; the transposed
@@ -264,6 +274,56 @@ class CSRGraph:
             prof.append((ev0, ev1, self.algorithmic_bytes(d, row_scale=row_scale is not None, bias=bias is not None,
                                                           src_elem=2 if bf16 else 4), 0))
         return out
+
+    def edge_perm(self, transpose=False):
+        """CSR position -> column of edge_index (int64 [E]) for the by-dst (transpose=False) or by-src orientation: the stable sort of
+        the (row, col) keys, i.e. the order cb_csr_from_coo_i64 lays the edges out in (duplicates of a multigraph keep their input
+        order; which duplicate sits where is immaterial for sums over them).  Needed only by the edge_weight form (GCN.py:199-202)."""
+        if getattr(self, '_ei', None) is None:
+            raise ValueError('edge permutation requested on a CSR that was not built from an edge list')
+        which = '_perm_t' if transpose else '_perm'
+        if getattr(self, which) is None:
+            src, dst = self._ei[0], self._ei[1]
+            key = (src * self.N + dst) if transpose else (dst * self.N + src)
+            setattr(self, which, torch.sort(key, stable=True)[1])
+        return getattr(self, which)
+
+    def spmm_weighted(self, h, w_csr, transpose=False, row_scale=None, bias=None, relu=False):
+        """out[v] = act(row_scale[v] * sum_j w_csr[j] * h[col[j]] + bias) (cb_spmm_csr_weighted_f32); w_csr: fp32 [E] in the order of the
+        chosen orientation's CSR (edge_weight[edge_perm(transpose)])."""
+        lib = _lib.load()
+        _lib.require_device(h, w_csr, row_scale, bias)
+        if h.dtype != torch.float32 or h.dim() != 2 or h.shape[0] != self.n_cols:
+            raise ValueError(f'spmm_weighted: float32 [{self.n_cols}, d] rows expected, got {tuple(h.shape)} {h.dtype}')
+        if w_csr.dtype != torch.float32 or w_csr.numel() != self.E:
+            raise ValueError(f'spmm_weighted: {self.E} float32 edge weights expected, got {tuple(w_csr.shape)} {w_csr.dtype}')
+        if transpose and self.rowptr_t is None:
+            raise ValueError('this graph holds the forward orientation only')
+        if h.stride(1) != 1 and h.shape[1] > 1:
+            h = h.contiguous()
+        w_csr = w_csr.contiguous()
+        d = h.shape[1]
+        out = torch.empty((self.N, d), dtype=torch.float32, device=h.device)
+        rowptr, col = (self.rowptr_t, self.col_t) if transpose else (self.rowptr, self.col)
+        with torch.cuda.device(h.device):
+            _lib.check(lib.cb_spmm_csr_weighted_f32(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(w_csr), self.N, self.E, _lib.ptr(h),
+                                                    h.stride(0) if h.shape[0] > 1 else d, d, _lib.ptr(row_scale), _lib.ptr(bias),
+                                                    int(bool(relu)), _lib.ptr(out), d, _lib.stream_ptr()), 'cb_spmm_csr_weighted_f32')
+        return out
+
+    def edge_dot(self, h, g, transpose=False):
+        """dw[j] = <h[col[j]], g[row of j]> over the chosen orientation's CSR (cb_spmm_edge_dot_f32): gradient of the edge weights."""
+        lib = _lib.load()
+        _lib.require_device(h, g)
+        h, g = (t if t.stride(1) == 1 else t.contiguous() for t in (h, g))
+        d = h.shape[1]
+        dw = torch.empty(max(self.E, 1), dtype=torch.float32, device=h.device)
+        rowptr, col = (self.rowptr_t, self.col_t) if transpose else (self.rowptr, self.col)
+        with torch.cuda.device(h.device):
+            _lib.check(lib.cb_spmm_edge_dot_f32(_lib.ptr(rowptr), _lib.ptr(col), self.N, self.E, _lib.ptr(h), h.stride(0) if h.shape[0] > 1 else d,
+                                                _lib.ptr(g), g.stride(0) if g.shape[0] > 1 else d, d, _lib.ptr(dw), _lib.stream_ptr()),
+                       'cb_spmm_edge_dot_f32')
+        return dw[:self.E]
 
     def spmm_gemm(self, h, image, transpose=False, row_scale=None, bias=None, relu=False, g_rowscale=None, g_addend=None):
         """(out, g_out): out = act(row_scale * (A h) + bias) as spmm() and, from the same kernel, g_out = g_rowscale * (out @ B) +

@@ -136,8 +136,42 @@ class _AggregateFn(torch.autograd.Function):
         return None, dh, None, dbias, None
 
 
-def aggregate(graph, h, row_scale=None, bias=None, relu=False):
+class _WeightedAggregateFn(torch.autograd.Function):
+    """The `edge_weight` form of the aggregation (GCN.py:199-202, fn.u_mul_e + fn.sum): Y = act(b * (sum_e w_e h[src_e]) + bias).
+    edge_weight is indexed like the columns of edge_index (as graph.edata in DGL).  Backward: dh = sum over the reverse CSR with the
+    same weights; dw_e = <h[src_e], b[dst_e] * dY'[dst_e]>."""
+
+    @staticmethod
+    def forward(ctx, graph, h, edge_weight, row_scale, bias, relu):
+        w = edge_weight.detach().to(torch.float32)
+        out = graph.spmm_weighted(h, w[graph.edge_perm(False)], False, row_scale=row_scale, bias=bias, relu=relu)
+        ctx.graph, ctx.relu, ctx.has_bias = graph, relu, bias is not None
+        ctx.save_for_backward(h, w, out if relu else None, row_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h, w, out, row_scale = ctx.saved_tensors
+        graph = ctx.graph
+        need_h, need_w, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.has_bias and ctx.needs_input_grad[4]
+        if ctx.relu or row_scale is not None or need_b:
+            gs, dbias = act_bwd(g, out if ctx.relu else None, row_scale, want_out=True, want_colsum=need_b)
+        else:
+            gs, dbias = _c(g), None
+        dh = graph.spmm_weighted(gs, w[graph.edge_perm(True)], True) if need_h else None
+        dw = None
+        if need_w:
+            dw = torch.empty_like(w)
+            dw[graph.edge_perm(False)] = graph.edge_dot(h, gs, False)
+        return None, dh, dw, None, dbias, None
+
+
+def aggregate(graph, h, row_scale=None, bias=None, relu=False, edge_weight=None):
     _lib.require_device(h)
+    if edge_weight is not None:
+        if hasattr(graph, 'part'):
+            raise NotImplementedError('edge_weight on a node-sharded graph (never passed by TricksComb, GCN.py:115)')
+        return _WeightedAggregateFn.apply(graph, h, edge_weight, row_scale, bias, bool(relu))
     if hasattr(graph, 'part'):      # node-sharded graph: all-gather exchange + local rows (dist.py)
         from .dist import sharded_aggregate
         return sharded_aggregate(graph, h, row_scale, bias, relu)

@@ -410,6 +410,15 @@ int cb_spmm_gemm_fused_f32(const int32_t* rowptr, const int32_t* col, int32_t co
                            const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, const void* image,
                            const float* g_rowscale, const float* g_addend, int64_t ld_add, float* g_out, int64_t ld_gout, void* stream);
 
+/* Edge-weighted aggregation — the `edge_weight` argument of GCNConv.forward (GNN_model/GCN.py:199-202: fn.u_mul_e + fn.sum):
+ *     out[v, :] = act( row_scale[v] * sum_{j in row v} w[j] * h[col[j], :] + bias[:] ),   w in CSR order ([E], fp32)
+ * and the gradient of the weights, dw[j] = <h[col[j], :], g[row of j, :]>.  The reference asserts len(edge_weight) == E (:200);
+ * TricksComb never passes one, so these are plain one-wavefront-per-row kernels (exact, deterministic), not the tuned stream. */
+int cb_spmm_csr_weighted_f32(const int32_t* rowptr, const int32_t* col, const float* w, int64_t N, int64_t E, const float* h, int64_t ld_h,
+                             int64_t d, const float* row_scale, const float* bias, int relu, float* out, int64_t ld_out, void* stream);
+int cb_spmm_edge_dot_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h, const float* g,
+                         int64_t ld_g, int64_t d, float* dw, void* stream);
+
 /* The same pack with the rows narrowed to bf16 (round-to-nearest-even) as they are written: the send buffer of the bf16 halo wire. */
 int cb_gather_rows_bf16_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, uint16_t* out, void* stream);
 

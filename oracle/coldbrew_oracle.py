@@ -112,7 +112,15 @@ class _QuantGradBf16(torch.autograd.Function):
         return g.to(torch.bfloat16).to(g.dtype)
 
 
-def gcnconv_forward(csr, feat, weight, bias=None, le=None, a=None, b=None, quant_bf16=False):
+def aggregate_sum_weighted(csr, h, edge_weight):
+    """rst[v,:] = sum_{e:(u->v)} w_e * h[u,:]  (GCN.py:199-202; DGL u_mul_e + sum; w indexed like edge_index's columns)."""
+    src = torch.from_numpy(csr.src)
+    dst = torch.from_numpy(csr.dst)
+    out = torch.zeros((csr.N,) + tuple(h.shape[1:]), dtype=h.dtype)
+    return out.index_add(0, dst, h.index_select(0, src) * edge_weight.reshape(-1, 1))
+
+
+def gcnconv_forward(csr, feat, weight, bias=None, le=None, a=None, b=None, quant_bf16=False, edge_weight=None):
     """quant_bf16 (build extension, not in the reference): the rows the aggregation gathers — Z in the forward,
     the scaled gradient in the backward — are rounded to bf16 (RNE), everything else stays fp32."""
     check_no_zero_in_degree(csr)
@@ -128,7 +136,11 @@ def gcnconv_forward(csr, feat, weight, bias=None, le=None, a=None, b=None, quant
         se_reg = None
     if quant_bf16:
         h = h + (h.detach().to(torch.bfloat16).to(h.dtype) - h.detach())    # value rounded, gradient passes straight through
-    rst = _AGGREGATE[0](csr, h)                              # :238
+    if edge_weight is not None:
+        assert edge_weight.shape[0] == csr.E                 # :200
+        rst = aggregate_sum_weighted(csr, h, edge_weight)    # :199-202,238
+    else:
+        rst = _AGGREGATE[0](csr, h)                          # :238
     if quant_bf16:
         rst = _QuantGradBf16.apply(rst)
     rst = rst * b.reshape(-1, 1)                             # :250

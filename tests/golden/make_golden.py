@@ -403,6 +403,34 @@ def proj2class_fixture(ns):
     return out
 
 
+def edge_weight_fixture(ns):
+    """GCNConv.forward(graph, feat, edge_weight=w) of the unmodified reference (GCN.py:199-202: u_mul_e) on the directed multigraph and
+    the power-law graph: output, regulariser and the gradients w.r.t. feat, weight, bias, le AND edge_weight."""
+    import dgl
+    out = {}
+    for name, (kind, n, d_in, d_out, se) in {'asym_multi': ('asym_multi', 70, 12, 20, True), 'powerlaw': ('powerlaw', 120, 9, 33, False)}.items():
+        args = ref_args(ns, 'Cora', [])
+        ei, n = make_graph(kind, n, 13)
+        args.N_nodes = n
+        g = torch.Generator().manual_seed(500 + n)
+        torch.manual_seed(7)
+        conv = ns.GCN.GCNConv(d_in, d_out, args=args, whetherHasSE=se)
+        with torch.no_grad():
+            conv.bias.add_(0.1 * torch.randn(d_out, generator=g))
+        feat = torch.randn(n, d_in, generator=g, requires_grad=True)
+        w = (torch.rand(ei.shape[1], generator=g) + 0.25).requires_grad_(True)
+        graph = dgl.graph((ei[0].tolist(), ei[1].tolist()))
+        gout = torch.randn(n, d_out, generator=g)
+        rst, se_reg = conv(graph, feat, edge_weight=w)
+        loss = (rst * gout).sum() + (0.5 * se_reg if se_reg is not None else 0.0)
+        loss.backward()
+        out[name] = dict(edge_index=ei, n=n, feat=feat.detach().clone(), edge_weight=w.detach().clone(), gout=gout,
+                         sd={k: v.detach().clone() for k, v in conv.state_dict().items()}, out=rst.detach().clone(),
+                         se_reg=None if se_reg is None else se_reg.detach().clone(), d_feat=feat.grad.clone(), d_edge_weight=w.grad.clone(),
+                         grads={k: p.grad.clone() for k, p in conv.named_parameters()})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='')
@@ -410,7 +438,7 @@ def main():
     ns = ref_import.load_reference()
     torch.set_num_threads(1)
     for c in CASES:
-        if a.only and (a.only in ('utils', 'options', 'trainer', 'lp', 'semlp', 'proj2class') or a.only not in c['name']):
+        if a.only and (a.only in ('utils', 'options', 'trainer', 'lp', 'semlp', 'proj2class', 'edge_weight') or a.only not in c['name']):
             continue
         out = run_case(ns, c)
         torch.save(out, os.path.join(HERE, f'case_{c["name"]}.pt'))
@@ -428,6 +456,9 @@ def main():
     if not a.only or 'semlp' in a.only:
         torch.save(semlp_fixture(ns), os.path.join(HERE, 'semlp_fixture.pt'))
         print('wrote semlp_fixture.pt')
+    if not a.only or 'edge_weight' in a.only:
+        torch.save(edge_weight_fixture(ns), os.path.join(HERE, 'edge_weight_fixture.pt'))
+        print('wrote edge_weight_fixture.pt')
     if not a.only or 'proj2class' in a.only:
         torch.save(proj2class_fixture(ns), os.path.join(HERE, 'proj2class_fixture.pt'))
         print('wrote proj2class_fixture.pt')

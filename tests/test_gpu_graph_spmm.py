@@ -212,3 +212,35 @@ def test_spmm_narrow_large_graph_vs_c_oracle(d):
     got3 = G2.spmm(h, transpose=True)
     ref3 = oracle_c.spmm(G2.rowptr_t.cpu().numpy().astype(np.int64), G2.col_t.cpu().numpy()[:G2.E], h.cpu().numpy())
     torch.testing.assert_close(got3.cpu(), torch.from_numpy(ref3), atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('name', ['asym_multi', 'powerlaw'])
+def test_edge_weight_form_matches_reference(name):
+    """GCNConv.forward(graph, feat, edge_weight=w) — the u_mul_e variant of the aggregation (GCN.py:199-202) on the
+    HIP kernels (cb_spmm_csr_weighted_f32 forward, the same on the reverse CSR + cb_spmm_edge_dot_f32 backward) against the
+    unmodified reference: output 1e-4, gradients w.r.t. features, weight, bias, le and the edge weights."""
+    from types import SimpleNamespace
+    from gnn_tail_generalization_amd.GNN_model.GCN import GCNConv
+    g = load_golden('edge_weight_fixture')[name]
+    n = g['n']
+    d_in, d_out = g['sd']['weight'].shape
+    conv = GCNConv(d_in, d_out, args=SimpleNamespace(N_nodes=n), whetherHasSE='le' in g['sd'])
+    conv.load_state_dict(g['sd'])
+    conv = conv.to(DEV)
+    G = _graph(g['edge_index'], n)
+    feat = g['feat'].to(DEV).requires_grad_(True)
+    w = g['edge_weight'].to(DEV).requires_grad_(True)
+    out, reg = conv(G, feat, edge_weight=w)
+    torch.testing.assert_close(out.detach().cpu(), g['out'], atol=1e-4, rtol=1e-4)
+    loss = (out * g['gout'].to(DEV)).sum() + (0.5 * reg if reg is not None else 0.0)
+    loss.backward()
+    torch.testing.assert_close(feat.grad.cpu(), g['d_feat'], atol=2e-5, rtol=2e-4)
+    torch.testing.assert_close(w.grad.cpu(), g['d_edge_weight'], atol=2e-5, rtol=2e-4)
+    for k, v in g['grads'].items():
+        torch.testing.assert_close(getattr(conv, k).grad.cpu(), v, atol=5e-5, rtol=2e-4, msg=lambda m, k=k: f'{k}: {m}')
+    with pytest.raises(AssertionError):                       # :200 — the reference asserts the length
+        conv(G, feat, edge_weight=w[:-1])
+    # wide rows (two column sweeps) + unit weights == the unweighted kernel
+    h = torch.randn(n, 600, device=DEV)
+    ones = torch.ones(G.E, device=DEV)
+    torch.testing.assert_close(G.spmm_weighted(h, ones, False, row_scale=G.norm_in), G.spmm(h, row_scale=G.norm_in), atol=1e-5, rtol=1e-5)

@@ -290,7 +290,8 @@ def test_teacher_side_of_semlp_part1_handoff(tmp_path):
             torch.manual_seed(0)
             t = trainer(args, 0)
             rows = t.main()
-        assert rows.shape == (1, 6) and args.SEMLP_topK_2_replace == 3 and t.topK_2_replace == 3
+        K = args.SEMLP_topK_2_replace          # 2 by default; 3 only under --unify_mlps (base_options.py:450-471)
+        assert rows.shape == (1, 6) and K == 2 and t.topK_2_replace == K
         files = set(os.listdir(t.modeldir))
         assert {'best-teacherGNN', 'teacherGNN', 'teacherSE.pt'} <= files, files
         best = torch.load(os.path.join(t.modeldir, 'best-teacherGNN'), map_location='cpu')
@@ -305,12 +306,12 @@ def test_teacher_side_of_semlp_part1_handoff(tmp_path):
         assert tuple(t.teacherSE.shape) == tuple(les.shape) and t.teacherSE.shape[1] == t.teacherGNN.model.model.get_se_dim(t.data.x, t.data.edge_index)
         torch.testing.assert_close(t.teacherSE.cpu(), les, atol=1e-4, rtol=1e-4)
         saved = torch.load(os.path.join(t.modeldir, 'teacherSE.pt'), weights_only=True)
-        assert torch.equal(saved['teacherSE'], t.teacherSE.cpu()) and saved['topK_2_replace'] == 3
+        assert torch.equal(saved['teacherSE'], t.teacherSE.cpu()) and saved['topK_2_replace'] == K
         # the student's part-1 output stand-in: noisy teacher rows -> virtual-neighbour replacement
         gen = torch.Generator().manual_seed(5)
         guess = (t.teacherSE.cpu()[:50] + 0.05 * torch.randn(50, les.shape[1], generator=gen))
         out, idx, wgt = t.replacement(guess.to(DEV), return_selection=True)
-        want, sel, w = orc.semlp_replacement(guess, t.teacherSE.cpu(), 3)
+        want, sel, w = orc.semlp_replacement(guess, t.teacherSE.cpu(), K)
         assert torch.equal(torch.sort(idx.cpu().long(), 1)[0], torch.sort(sel, 1)[0])
         torch.testing.assert_close(out.cpu(), want, atol=1e-4, rtol=1e-4)
         sub = t.replacement(guess.to(DEV), node_idx=[3, 7])

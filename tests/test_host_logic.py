@@ -220,3 +220,48 @@ def test_public_header_is_plain_c(tmp_path):
     inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include')
     r = subprocess.run([gcc, '-std=c99', '-Wall', '-Wextra', '-Werror', '-fsyntax-only', '-I' + inc, str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_int32_edge_contract_is_a_per_rank_guarantee():
+    """SURVEY.md 8(b) 'int64 rowptr if E >= 2^31': indices stay int32 on the device; what is guaranteed instead is per RANK — a graph
+    with 2^31 or more edge_index columns is refused by the single-device graph with the remedy spelled out, and the edge-balanced
+    partition keeps every rank's block at E / P (+ one row) edges, i.e. below the limit from P = 2 on for anything up to 2^32."""
+    import torch
+    from gnn_tail_generalization_amd import graph as cbgraph
+    from gnn_tail_generalization_amd.dist import Partition
+    assert cbgraph.INT32_EDGE_LIMIT == 2 ** 31 - 1
+
+    class FakeEdges:          # a [2, 2^31] edge_index without allocating 32 GB: only what __init__ touches before the size check
+        shape = (2, 2 ** 31)
+        is_cuda = True
+
+        def dim(self):
+            return 2
+
+        def to(self, *_a, **_k):
+            return self
+
+        def contiguous(self):
+            return self
+
+        device = 'cuda:0'
+    import pytest
+    from gnn_tail_generalization_amd import _lib
+    real = (_lib.load, _lib.require_device)
+    _lib.load, _lib.require_device = (lambda: None), (lambda *a: None)
+    try:
+        with pytest.raises(ValueError, match='shard the graph'):
+            cbgraph.CSRGraph(FakeEdges(), 10)
+    finally:
+        _lib.load, _lib.require_device = real
+    # per-rank edge counts of the balanced partition on a heavy-tailed degree vector scaled to 3 * 2^30 edges
+    gen = torch.Generator().manual_seed(1)
+    deg = (torch.rand(1_000_000, generator=gen) ** -0.7).to(torch.int64)
+    scale = (3 * 2 ** 30) // int(deg.sum()) + 1
+    deg = deg * scale
+    total = int(deg.sum())
+    assert total >= 3 * 2 ** 30
+    for world in (2, 4, 8):
+        shares = [int(deg[Partition.balanced(deg, world, r).lo():Partition.balanced(deg, world, r).hi()].sum()) for r in range(world)]
+        assert sum(shares) == total and max(shares) <= total // world + int(deg.max()) + 12 * deg.numel()
+        assert max(shares) < 2 ** 31 - 1

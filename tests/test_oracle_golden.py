@@ -128,3 +128,22 @@ def test_oracle_proj2class_head_matches_reference():
         torch.testing.assert_close(logits, g['logits'], atol=1e-5, rtol=1e-5, msg=lambda m: f'{name} logits: {m}')
         loss = orc.training_loss(oracle_cfg(cfg), logits, reg, g['y'], g['train_mask'])
         torch.testing.assert_close(loss, g['loss'], atol=1e-5, rtol=1e-5)
+
+
+def test_oracle_edge_weight_form_matches_reference():
+    """GCNConv.forward(..., edge_weight=w) (GCN.py:199-202, u_mul_e): the oracle's restatement against the unmodified reference —
+    output, regulariser and the gradients w.r.t. features, parameters and the edge weights themselves."""
+    fx = load_golden('edge_weight_fixture')
+    for name, g in fx.items():
+        csr = orc.build_csr(g['edge_index'], g['n'])
+        feat = g['feat'].clone().requires_grad_(True)
+        w = g['edge_weight'].clone().requires_grad_(True)
+        p = {k: v.clone().requires_grad_(True) for k, v in g['sd'].items()}
+        out, reg = orc.gcnconv_forward(csr, feat, p['weight'], p['bias'], p.get('le'), edge_weight=w)
+        torch.testing.assert_close(out, g['out'], atol=1e-5, rtol=1e-5, msg=lambda m: f'{name}: {m}')
+        loss = (out * g['gout']).sum() + (0.5 * reg if reg is not None else 0.0)
+        loss.backward()
+        torch.testing.assert_close(feat.grad, g['d_feat'], atol=2e-5, rtol=1e-4)
+        torch.testing.assert_close(w.grad, g['d_edge_weight'], atol=2e-5, rtol=1e-4)
+        for k, v in g['grads'].items():
+            torch.testing.assert_close(p[k].grad, v, atol=2e-5, rtol=1e-4, msg=lambda m, k=k: f'{name} {k}: {m}')
