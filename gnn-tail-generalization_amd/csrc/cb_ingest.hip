@@ -60,9 +60,11 @@ struct CraftPred {      // craft_isolation_v2 keeps an edge unless (ori != dst) 
   const int64_t* src;
   const int64_t* dst;
   const uint8_t* flag;
+  int64_t n;            // node count: an endpoint outside [0, n) never indexes `flag` (the edge is kept; the caller's degree pass reports it)
   __device__ __forceinline__ bool operator()(int64_t e) const {
     const int64_t a = src[e], b = dst[e];
-    return !(a != b && (flag[a] | flag[b]));
+    const bool fa = a >= 0 && a < n && flag[a], fb = b >= 0 && b < n && flag[b];
+    return !(a != b && (fa | fb));
   }
 };
 
@@ -267,7 +269,7 @@ extern "C" int cb_craft_isolation_i64(const int64_t* src, const int64_t* dst, in
   CB_CHECK_ARG(E >= 0 && N >= 0 && count && (E == 0 || (src && dst && node_flag && out_src && out_dst)), CB_E_INVALID,
                "cb_craft_isolation_i64: bad argument");
   CB_CHECK_ARG(ws && ws_bytes >= cb_compact_workspace_bytes(E), CB_E_WORKSPACE, "cb_craft_isolation_i64: workspace too small");
-  return run_compact(CraftPred{src, dst, node_flag}, EdgeWriter{src, dst, out_src, out_dst}, E, count, ws, ws_bytes, (hipStream_t)stream);
+  return run_compact(CraftPred{src, dst, node_flag, N}, EdgeWriter{src, dst, out_src, out_dst}, E, count, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" size_t cb_symmetrize_workspace_bytes(int64_t E, int64_t N) {

@@ -31,18 +31,28 @@ _seed_override = []
 _graph_seed = None      # hipGraph mode: int64 device tensor [1]; kernels add its value to the per-site host seed
 
 
+_graph_site = 0         # hipGraph mode: running number of the dropout site whose host seed is being fixed
+
+
 def next_seed():
-    """63-bit seed drawn from torch's CPU generator: follows torch.manual_seed, costs no device sync."""
+    """63-bit seed drawn from torch's CPU generator: follows torch.manual_seed, costs no device sync.  In hipGraph mode the per-site
+    host seeds are baked into the captured kernels and all variation comes from the device seed word, so they are taken from a fixed
+    sequence instead: a resumed run then captures the very same graphs as the run that wrote the checkpoint."""
+    global _graph_site
     if _seed_override:
         return _seed_override.pop(0)
+    if _graph_seed is not None:
+        _graph_site += 1
+        return (0x9E3779B97F4A7C15 * _graph_site) % (2 ** 62)
     return int(torch.randint(0, 2 ** 62, (1,)).item())
 
 
 def set_graph_seed(t):
     """Install (or clear with None) the device-resident per-step seed word used while a training step is
     captured / replayed as a hipGraph: the captured kernels keep their per-site host seeds and add *t."""
-    global _graph_seed
+    global _graph_seed, _graph_site
     _graph_seed = t
+    _graph_site = 0
 
 
 def seed_dev_ptr():

@@ -167,13 +167,15 @@ class trainer:
         return join(self.modeldir, 'teacherGNN-ckpt')
 
     def save_checkpoint(self, epoch, results, best_test_acc=0.):
-        """Weights + fused-Adam moments/step + RNG states (CPU, numpy, every device generator) + per-epoch records + the best test
-        accuracy: enough to continue bit-for-bit.  Tensors and plain containers only, so that the file loads with
+        """Weights + fused-Adam moments/step + RNG states (CPU, numpy, every device generator, the device-resident dropout seed word of
+        --hip_graph=1) + per-epoch records + the best test accuracy: enough to continue bit-for-bit.  Tensors and plain containers only, so that the file loads with
         weights_only=True (no pickled code is executed when a checkpoint is read)."""
         np_state = np.random.get_state()
         torch.save({'model': self.teacherGNN.state_dict(), 'optimizer': self.optimizer.state_dict(), 'epoch': int(epoch),
                     'results': [[float(v) for v in row] for row in results], 'best_test_acc': float(best_test_acc),
                     'torch_rng': torch.get_rng_state(), 'cuda_rng': list(torch.cuda.get_rng_state_all()),
+                    # --hip_graph=1: the dropout seed word that lives on the device and advances inside the replayed graphs
+                    'seed_dev': int(self._seed_dev.item()) if getattr(self, '_seed_dev', None) is not None else -1,
                     'numpy_rng': {'kind': str(np_state[0]), 'keys': torch.from_numpy(np_state[1].astype(np.int64)),
                                   'pos': int(np_state[2]), 'has_gauss': int(np_state[3]), 'cached_gaussian': float(np_state[4])}},
                    self.checkpoint_path())
@@ -187,8 +189,11 @@ class trainer:
         self.optimizer.load_state_dict(ck['optimizer'])
         torch.set_rng_state(ck['torch_rng'])
         if ck.get('cuda_rng'):
-            with contextlib.suppress(Exception):
+            try:
                 torch.cuda.set_rng_state_all([t for t in ck['cuda_rng']])
+            except Exception as e:  # noqa: BLE001  (another device count than at save time: say so instead of diverging silently)
+                print(f'---››››  WARNING: device RNG state not restored ({type(e).__name__}: {e}); torch device generators restart from their seeds')
+        self._resume_rng = (ck['torch_rng'], int(ck.get('seed_dev', -1)))
         r = ck['numpy_rng']
         np.random.set_state((r['kind'], r['keys'].numpy().astype(np.uint32), r['pos'], r['has_gauss'], r['cached_gaussian']))
         print(f'---››››  RESUME from {path} after epoch {ck["epoch"]}')
@@ -210,6 +215,12 @@ class trainer:
             # --hip_graph=1: forward + loss + backward + Adam of run_trainSet and the eval forward of run_testSet are replayed as
             # hipGraphs — what bounds an epoch on Cora / Pubmed-sized graphs is the ~50 dependent launches, not the kernels
             self.enable_hip_graph(warmup=1, restore=True)
+            if getattr(self, '_resume_rng', None) is not None:
+                # the warm-up above drew dropout seeds and a fresh device seed word: put both back to the checkpointed values, so that a
+                # resumed --hip_graph run replays the masks the straight run would have drawn
+                torch.set_rng_state(self._resume_rng[0])
+                if self._resume_rng[1] >= 0:
+                    self._seed_dev.fill_(self._resume_rng[1])
         for epoch in range(first_epoch, self.epochs):
             self.epoch = epoch
             acc_train, acc_val, acc_test, loss_train, loss_val, linkp_train, linkp_test = self.train_net()
@@ -223,7 +234,8 @@ class trainer:
                 print(f'Ep{epoch:03d}, acc @ train/test: {acc_train * 100:.1f}, {acc_test * 100:.1f} ')
             if ckpt_every and (epoch + 1) % ckpt_every == 0:
                 self.save_checkpoint(epoch, results_arr2D, best_test_acc)
-        self.save_checkpoint(self.epochs - 1, results_arr2D, best_test_acc)
+        if first_epoch < self.epochs:      # (a checkpoint from a longer run is not relabelled as epoch `epochs - 1`)
+            self.save_checkpoint(self.epochs - 1, results_arr2D, best_test_acc)
         print('train_loss: {:.4f},  test_acc:{:.4f}'.format(best_train_loss, best_test_acc))
         save_model(self.teacherGNN, join(self.modeldir, 'teacherGNN'))
         results_arr2D = np.array(results_arr2D).T

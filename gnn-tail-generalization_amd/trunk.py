@@ -195,6 +195,23 @@ MASKED_GATHER = os.environ.get('CB_TRUNK_MASKED_GATHER', '0') == '1'
 MIX_MAX = 7      # mixed-in gradients one cb_trunk_input_bwd_multi_f32 launch gathers (deeper trunks accumulate layer by layer)
 
 
+_GATHER_OK = {}
+
+
+def _gather_fits(L, x0):
+    """Gather mode keeps every layer's [N, d] gradient alive until the input stage: (L - 1) * N * d * 4 bytes more than accumulating
+    layer by layer.  Allowed while that stays below a quarter of the device memory that is free at the first backward of
+    this shape (decided once per shape: no driver query per step); otherwise the in-place accumulate path."""
+    key = (L, tuple(x0.shape), x0.device.index)
+    ok = _GATHER_OK.get(key)
+    if ok is None:
+        free, _total = torch.cuda.mem_get_info(x0.device)
+        ok = _GATHER_OK[key] = (L - 1) * x0.numel() * 4 <= 0.25 * free or os.environ.get('CB_TRUNK_GATHER') == '1'
+        if os.environ.get('CB_TRUNK_GATHER') == '0':
+            ok = _GATHER_OK[key] = False
+    return ok
+
+
 def _chunked(graph, agg_bf16):
     """Row-chunk the producers of the exchanged matrices (layer GEMM forward; dX GEMM + trunk layer backward) so that chunk k
     ships while chunk k+1 is computed: node-sharded overlapped graphs whose plans have more than one slice."""
@@ -282,7 +299,7 @@ class _TrunkFn(torch.autograd.Function):
         d_b_out = ops.act_bwd(gout, None, None, want_out=False, want_colsum=True)[1] if need[6] else None
         # the gradient reaching X0 through the L mixes: gathered in one pass by the input stage (the per-layer gradients stay
         # alive until then) when L <= MIX_MAX, else accumulated in place layer by layer
-        gather = L <= MIX_MAX
+        gather = L <= MIX_MAX and _gather_fits(L, x0)
         # opt-in (CB_TRUNK_FUSE_BWD=1): the layer-below's trunk backward leaves the epilogue of the GEMM that produces dL/dx
         fuse = gather and not agg_bf16 and FUSE_BWD_EPILOGUE
         gx0 = None if gather else torch.empty_like(x0)

@@ -215,8 +215,11 @@ def _degrees_device(N_nodes, edge_index):
             bad = torch.zeros(1, dtype=torch.int32, device=dev)
             _lib.check(lib.cb_id_count_i64(_lib.ptr(ids), int(ids.numel()), N_nodes, _lib.ptr(cnt), _lib.ptr(bad), _lib.stream_ptr()),
                        'cb_id_count_i64')
-            out.append(cnt)
-    return out[0], out[1]
+            out.append((cnt, bad))
+    n_bad = int(out[0][1].item()) + int(out[1][1].item())
+    if n_bad:      # as _symmetrize_device: ids outside [0, N) are an input error, not something to drop silently
+        raise ValueError(f'edge_index has {n_bad} endpoints outside [0, {N_nodes})')
+    return out[0][0], out[1][0]
 
 
 def graph_analyze(N_nodes, edge_index):

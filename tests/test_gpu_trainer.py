@@ -247,8 +247,10 @@ def test_label_propagation_matches_reference_fixture():
     assert res.shape == (1, 2) and res[0].tolist() == g['acc'].tolist()
 
 
-def test_resume_from_checkpoint_continues_bit_for_bit():
-    """§8f row 3: weights + fused-Adam state + RNG are checkpointed; 3 epochs, resume, 2 more == 5 straight epochs."""
+@pytest.mark.parametrize('hip_graph', [0, 1])
+def test_resume_from_checkpoint_continues_bit_for_bit(hip_graph):
+    """§8f row 3: weights + fused-Adam state + RNG are checkpointed; 3 epochs, resume, 2 more == 5 straight epochs — also when the
+    epochs are replayed as hipGraphs (--hip_graph=1: the device-resident dropout seed word is part of the checkpoint)."""
     import os
     import sys
     import tempfile
@@ -256,7 +258,7 @@ def test_resume_from_checkpoint_continues_bit_for_bit():
     sys.path.insert(0, root)
     import main as cli
     common = ['--dataset=S-tiny', '--whetherHasSE=111', '--se_reg=0.5', '--want_headtail=0', '--use_special_split=0',
-              '--do_deg_analyze=0', '--manual_assign_GPU=0']
+              '--do_deg_analyze=0', '--manual_assign_GPU=0', f'--hip_graph={hip_graph}']
     cwd = os.getcwd()
     try:
         os.chdir(tempfile.mkdtemp())
