@@ -261,7 +261,7 @@ static int launch_nn(const float* A, int64_t lda, const float* B, int64_t ldb, v
 
 template <int WM, int WN>
 static int launch_tn(const float* A, int64_t lda, const float* G, int64_t ldg, const float* rowscale, float* C, int64_t M,
-                     int64_t K1, int64_t K2, float* ws, hipStream_t st) {
+                     int64_t K1, int64_t K2, float* ws, hipStream_t st, const DropSpec* gdrop = nullptr) {
   using T = Tile<WM, WN>;
   const int tiles_i = (int)((K1 + T::BM - 1) / T::BM), tiles_j = (int)((K2 + T::BN - 1) / T::BN);
   const int nsplit = tn_splits(M, tiles_i * tiles_j);
@@ -269,8 +269,10 @@ static int launch_tn(const float* A, int64_t lda, const float* G, int64_t ldg, c
   rows_per_split = (rows_per_split + 31) / 32 * 32;   // whole K steps of either kernel family
   const bool aligned = al16(A) && al16(G) && lda % 4 == 0 && ldg % 4 == 0;
   const dim3 grid((unsigned)(tiles_i * tiles_j), (unsigned)nsplit);
+  CB_CHECK_ARG(!gdrop || (use_limb3() && limb3_tn_eligible(A, lda, G, ldg, K1, K2)), CB_E_INVALID,
+               "TN contraction with operand dropout: three-limb path only (check cb_gemm_tn_gdrop_supported first)");
   if (use_limb3() && limb3_tn_eligible(A, lda, G, ldg, K1, K2)) {
-    const int rc = launch_tn_limb3(A, lda, G, ldg, rowscale, ws, M, K1, K2, T::BM, nsplit, rows_per_split, st);
+    const int rc = launch_tn_limb3(A, lda, G, ldg, rowscale, ws, M, K1, K2, T::BM, nsplit, rows_per_split, st, gdrop);
     if (rc != CB_OK) return rc;
     const int64_t n = K1 * K2;
     hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsplit, n, C);
@@ -350,6 +352,32 @@ extern "C" int cb_gemm_nn_drop2_f32(const float* A, int64_t lda, const float* B,
   if (rc != CB_OK) return rc;
   CB_CHECK_ARG(ldc == N && ldc2 == N, CB_E_INVALID, "cb_gemm_nn_drop2_f32: the two-kernel form needs contiguous outputs");
   return cb_dropout_f32(C, C2, M * N, drop_p, seed, seed_dev, row0 * N, stream);
+}
+
+// The same with the dropout IN FRONT of the Linear applied to A as it is staged (GCN.py:104: x = F.dropout(x) before layers_MLP[0]):
+// C = act((dropout_{a_seed}(A)) @ B + bias), C2 = dropout_{seed}(C).  A's dropped copy is never written (nor kept for the backward:
+// cb_gemm_tn_gdrop_f32 regenerates the mask).  Only where the fused form exists — ask cb_gemm_nn_indrop_supported first.
+extern "C" int cb_gemm_nn_indrop_supported(const float* A, int64_t lda, const float* B, int64_t ldb, const float* C, int64_t ldc, const float* C2,
+                                           int64_t ldc2, int64_t M, int64_t N, int64_t K) {
+  GemmEpilogue ep{};
+  return use_limb3() && K % 4 == 0 && limb3_nn_dual_eligible(A, lda, B, ldb, C, ldc, C2, ldc2, M, N, K, ep) ? 1 : 0;
+}
+
+extern "C" int cb_gemm_nn_indrop_drop2_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, float* C2, int64_t ldc2,
+                                           int64_t M, int64_t N, int64_t K, const float* bias, int relu, float a_drop_p, uint64_t a_seed,
+                                           float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, void* stream) {
+  CB_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && drop_p > 0.f && drop_p < 1.f && a_drop_p > 0.f && a_drop_p < 1.f && row0 >= 0, CB_E_INVALID,
+               "cb_gemm_nn_indrop_drop2_f32: bad size or p");
+  CB_CHECK_ARG(N < (1 << 24) && K < (1 << 24) && (M + 63) / 64 < (1 << 24), CB_E_RANGE, "cb_gemm_nn_indrop_drop2_f32: size out of range");
+  if (M == 0 || N == 0) return CB_OK;
+  CB_CHECK_ARG(C && C2 && A && B && lda >= K && ldb >= N && ldc >= N && ldc2 >= N, CB_E_INVALID, "cb_gemm_nn_indrop_drop2_f32: null pointer or bad ld");
+  CB_CHECK_ARG(cb_gemm_nn_indrop_supported(A, lda, B, ldb, C, ldc, C2, ldc2, M, N, K), CB_E_INVALID,
+               "cb_gemm_nn_indrop_drop2_f32: shape / alignment outside the fused form (cb_gemm_nn_indrop_supported)");
+  GemmEpilogue ep{nullptr, nullptr, 0, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, nullptr, 0.f, nullptr, nullptr, gemm_nt_store(M, N)};
+  ep.out2 = C2; ep.ld_out2 = ldc2; ep.thresh = dropout_threshold(drop_p); ep.keep_scale = 1.f / (1.f - drop_p);
+  ep.seed = seed; ep.seed_dev = seed_dev; ep.row0 = row0;
+  ep.adrop = DropSpec{dropout_threshold(a_drop_p), 1.f / (1.f - a_drop_p), a_seed, seed_dev, row0, K};
+  return launch_nn_limb3(A, lda, B, ldb, C, ldc, M, N, K, ep, false, (hipStream_t)stream, nullptr, 0);
 }
 
 // one block per column: strided partial sums per thread, fixed-order LDS tree (the result does not depend on scheduling)
@@ -452,4 +480,32 @@ extern "C" int cb_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64
   if (bm == 64) return launch_tn<1, 4>(A, lda, G, ldg, rowscale, C, M, K1, K2, (float*)ws, st);
   if (bm == 256) return launch_tn<4, 1>(A, lda, G, ldg, rowscale, C, M, K1, K2, (float*)ws, st);
   return launch_tn<2, 2>(A, lda, G, ldg, rowscale, C, M, K1, K2, (float*)ws, st);
+}
+
+// C = A^T @ dropout_{g_seed}(G): the weight gradient of the input Linear from the UNdropped features (mask regenerated while G is
+// staged; the forward's cb_gemm_nn_indrop_drop2_f32 drew the same one).  Three-limb path only: cb_gemm_tn_gdrop_supported.
+extern "C" int cb_gemm_tn_gdrop_supported(const float* A, int64_t lda, const float* G, int64_t ldg, int64_t K1, int64_t K2) {
+  return use_limb3() && K2 % 4 == 0 && limb3_tn_eligible(A, lda, G, ldg, K1, K2) ? 1 : 0;
+}
+
+extern "C" int cb_gemm_tn_gdrop_f32(const float* A, int64_t lda, const float* G, int64_t ldg, float* C, int64_t M, int64_t K1, int64_t K2,
+                                    float g_drop_p, uint64_t g_seed, const uint64_t* seed_dev, int64_t row0, void* ws, size_t ws_bytes,
+                                    void* stream) {
+  CB_CHECK_ARG(M >= 0 && K1 >= 0 && K2 >= 0 && g_drop_p > 0.f && g_drop_p < 1.f && row0 >= 0, CB_E_INVALID, "cb_gemm_tn_gdrop_f32: bad size or p");
+  CB_CHECK_ARG(K1 < (1 << 20) && K2 < (1 << 20), CB_E_RANGE, "cb_gemm_tn_gdrop_f32: size out of range");
+  if (K1 == 0 || K2 == 0) return CB_OK;
+  CB_CHECK_ARG(C && (M == 0 || (A && G)) && lda >= K1 && ldg >= K2, CB_E_INVALID, "cb_gemm_tn_gdrop_f32: null pointer or bad ld");
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) {
+    CB_HIP(hipMemsetAsync(C, 0, (size_t)K1 * K2 * sizeof(float), st));
+    return CB_OK;
+  }
+  CB_CHECK_ARG(cb_gemm_tn_gdrop_supported(A, lda, G, ldg, K1, K2), CB_E_INVALID, "cb_gemm_tn_gdrop_f32: operands outside the three-limb path");
+  CB_CHECK_ARG(ws && ws_bytes >= cb_gemm_tn_workspace_bytes(M, K1, K2), CB_E_WORKSPACE, "cb_gemm_tn_gdrop_f32: workspace too small");
+  const DropSpec gd{dropout_threshold(g_drop_p), 1.f / (1.f - g_drop_p), g_seed, seed_dev, row0, K2};
+  int bm, bn;
+  tn_tile(K1, K2, bm, bn);
+  if (bm == 64) return launch_tn<1, 4>(A, lda, G, ldg, nullptr, C, M, K1, K2, (float*)ws, st, &gd);
+  if (bm == 256) return launch_tn<4, 1>(A, lda, G, ldg, nullptr, C, M, K1, K2, (float*)ws, st, &gd);
+  return launch_tn<2, 2>(A, lda, G, ldg, nullptr, C, M, K1, K2, (float*)ws, st, &gd);
 }

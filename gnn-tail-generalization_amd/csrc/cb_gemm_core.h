@@ -10,6 +10,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 16;   // default K step (BKT template parameter; 32 selectable for measurement)
 
+// F.dropout applied to an OPERAND on its way into LDS (value * keep(seed, flat index) / (1 - p), the mask cb_dropout_f32 draws): the
+// dropped copy of the matrix is never written or read (the input features' dropout of the residual trunk, GCN.py:104).
+struct DropSpec {
+  uint32_t thresh;           // 0 = off
+  float scale;               // 1 / (1 - p)
+  uint64_t seed;
+  const uint64_t* seed_dev;  // hipGraph mode: per-step part in device memory (added to `seed`), or null
+  int64_t row0;              // global index of the matrix's row 0 (node-sharded runs draw the unsharded mask)
+  int64_t width;             // row length of the dropped matrix in elements (multiple of 4)
+};
+
 struct GemmEpilogue {
   const float* rowscale;  // [M] or null
   const float* addend;    // [M, ld_add] or null
@@ -33,6 +44,7 @@ struct GemmEpilogue {
   const float* rowscale2;           // [M]
   float* colsum_partial;            // [row blocks][N] or null
   int nt_store;                     // fp32 C leaves with the streaming (nt) policy
+  DropSpec adrop;                   // ADROP kernels only: dropout of the A operand (thresh = 0: off)
 };
 
 template <int WM, int WN, int BKT = BK, int WTN = 2>

@@ -16,6 +16,6 @@ bool limb3_nn_dual_eligible(const float* A, int64_t lda, const float* B, int64_t
 bool limb3_tn_eligible(const float* A, int64_t lda, const float* G, int64_t ldg, int64_t K1, int64_t K2);
 // partial slabs [nsplit][K1][K2] exactly as k_gemm_tn writes them; bm = tile rows chosen by tn_tile()
 int launch_tn_limb3(const float* A, int64_t lda, const float* G, int64_t ldg, const float* rowscale, float* partial, int64_t M,
-                    int64_t K1, int64_t K2, int bm, int nsplit, int64_t rows_per_split, hipStream_t st);
+                    int64_t K1, int64_t K2, int bm, int nsplit, int64_t rows_per_split, hipStream_t st, const DropSpec* gdrop = nullptr);
 
 }  // namespace cb

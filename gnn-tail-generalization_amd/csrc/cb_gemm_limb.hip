@@ -55,14 +55,15 @@ struct LTile {
 };
 
 // ---- NN ------------------------------------------------------------------------------------
-template <int WM, int WN, bool OUT_BF16, int WTN = 2, int PD = 2, int EPI = 0, bool BPRE = false>
+// ADROP: F.dropout of the A operand while it is staged (ep.adrop) — the dropout of the input features in front of the input Linear
+template <int WM, int WN, bool OUT_BF16, int WTN = 2, int PD = 2, int EPI = 0, bool BPRE = false, bool ADROP = false>
 __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_nn_l3(const float* __restrict__ A, int64_t lda,
                                                                                  const float* __restrict__ B, int64_t ldb,
                                                                                  void* __restrict__ Cv, int64_t ldc, int64_t M, int N,
                                                                                  int K, GemmEpilogue ep, int n_row_blocks,
                                                                                  int n_col_blocks, int c_vec_ok) {
   using T = LTile<WM, WN, WTN>;
-  using OA = RowOperand<T::BM>;
+  using OA = RowOperand<T::BM, ADROP>;
   using OB = std::conditional_t<BPRE, ColOperandPre<T::BN>, ColOperand<T::BN, false>>;   // BPRE: B = image of k_presplit_cols
   constexpr int BM = T::BM, BN = T::BN;
   constexpr int SMEM = 2 * (OA::BYTES + OB::BYTES);
@@ -81,6 +82,7 @@ __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_nn
   OA oa;
   OB ob;
   oa.init(lda, M - m0, t);
+  if constexpr (ADROP) oa.set_drop(ep.adrop, m0, K, t);
   ob.init(ldb, N - n0, t);
   const uint32_t aaddr[2] = {OA::frag_addr(wr * 64, lane), OA::frag_addr(wr * 64 + 32, lane)};
   uint32_t baddr[WTN];
@@ -101,16 +103,17 @@ __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_nn
 // ---- TN ------------------------------------------------------------------------------------
 // 1-D grid, XCD-aware: the tiles of one row split get block ids congruent mod 8 (same XCD / L2), so each operand
 // panel is fetched from HBM once although tiles_i (tiles_j) tiles consume it.
-template <int WM, int WN, bool SCALED, int WTN = 2, int PD = 2>
+// GDROP: F.dropout of the G operand while it is staged (gd): the weight gradient of the input Linear reads the undropped features
+template <int WM, int WN, bool SCALED, int WTN = 2, int PD = 2, bool GDROP = false>
 __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_tn_l3(const float* __restrict__ A, int64_t lda,
                                                                                  const float* __restrict__ G, int64_t ldg,
                                                                                  const float* __restrict__ rowscale,
                                                                                  float* __restrict__ partial, int64_t M, int K1, int K2,
                                                                                  int64_t rows_per_split, int tiles_j, int n_tiles,
-                                                                                 int nsplit) {
+                                                                                 int nsplit, DropSpec gd) {
   using T = LTile<WM, WN, WTN>;
   using OA = ColOperand<T::BM, false>;
-  using OB = ColOperand<T::BN, SCALED>;
+  using OB = ColOperand<T::BN, SCALED, GDROP>;
   constexpr int BM = T::BM, BN = T::BN;
   __shared__ __attribute__((aligned(16))) char smem[2 * (OA::BYTES + OB::BYTES)];
   const int b = blockIdx.x;
@@ -127,6 +130,7 @@ __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_tn
   OB ob;
   oa.init(lda, K1 - i0, t);
   ob.init(ldg, K2 - j0, t);
+  if constexpr (GDROP) ob.set_drop(gd, r_begin, r_end - r_begin, j0, t);
   const uint32_t aaddr[2] = {OA::frag_addr(wr * 64, lane), OA::frag_addr(wr * 64 + 32, lane)};
   uint32_t baddr[WTN];
 #pragma unroll
@@ -179,7 +183,7 @@ static int launch_nn_l3_t(const float* A, int64_t lda, const float* B, int64_t l
   const dim3 grid((unsigned)(groups * 8 * ncb));
   if constexpr (T::BN >= 128) {
     // weight operand split once per launch instead of once per block per K step (rows >> the 128-row tile make that worthwhile)
-    if (presplit_on() && !ep.bits && ws && ws_bytes >= presplit_bytes(K, N, T::BN) && M >= 8 * T::BM && limb_pd() == 1) {
+    if (presplit_on() && !ep.bits && !ep.adrop.thresh && ws && ws_bytes >= presplit_bytes(K, N, T::BN) && M >= 8 * T::BM && limb_pd() == 1) {
       const int nks = (int)((K + KS - 1) / KS);
       hipLaunchKernelGGL((k_presplit_cols<T::BN>), dim3((unsigned)nks, (unsigned)ncb), dim3(256), 0, st, B, ldb, (int)K, (int)N, nks, (char*)ws);
       CB_LAUNCH_CHECK();
@@ -201,6 +205,12 @@ static int launch_nn_l3_t(const float* A, int64_t lda, const float* B, int64_t l
   if constexpr (!OUT_BF16 && WM == 2 && WTN == 4) {
     if (ep.out2 || ep.bits) {    // dual-output epilogues (dropped copy / trunk layer backward, the latter also without its second
                                  // output: column sums only): the wide-tile fp32 kernel only, see limb3_nn_dual_eligible
+      if (!ep.bits && ep.adrop.thresh) {      // + dropout of the A operand in its staging (input Linear of the residual trunk)
+        hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, false, WTN, 1, 1, false, true>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep,
+                           nrb, ncb, c_vec_ok);
+        CB_LAUNCH_CHECK();
+        return CB_OK;
+      }
       if (ep.bits)
         hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, false, WTN, 1, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb,
                            ncb, c_vec_ok);
@@ -263,13 +273,18 @@ int launch_nn_limb3(const float* A, int64_t lda, const float* B, int64_t ldb, vo
 
 template <int WM, int WN, int WTN = 2>
 static void launch_tn_l3_t(const float* A, int64_t lda, const float* G, int64_t ldg, const float* rowscale, float* partial, int64_t M,
-                           int64_t K1, int64_t K2, int nsplit, int64_t rows_per_split, hipStream_t st) {
+                           int64_t K1, int64_t K2, int nsplit, int64_t rows_per_split, hipStream_t st, const DropSpec& gd) {
   using T = LTile<WM, WN, WTN>;
   const int ti = (int)((K1 + T::BM - 1) / T::BM), tj = (int)((K2 + T::BN - 1) / T::BN);
   const dim3 grid((unsigned)(((nsplit + 7) / 8) * 8 * ti * tj));
+  if (gd.thresh) {      // (launch_tn_limb3 admits it without a row scale only)
+    hipLaunchKernelGGL((k_gemm_tn_l3<WM, WN, false, WTN, 1, true>), grid, dim3(256), 0, st, A, lda, G, ldg, rowscale, partial, M, (int)K1, (int)K2,
+                       rows_per_split, tj, ti * tj, nsplit, gd);
+    return;
+  }
 #define CB_TN_LAUNCH(SC_, PD_)                                                                                                   \
   hipLaunchKernelGGL((k_gemm_tn_l3<WM, WN, SC_, WTN, PD_>), grid, dim3(256), 0, st, A, lda, G, ldg, rowscale, partial, M, (int)K1, \
-                     (int)K2, rows_per_split, tj, ti * tj, nsplit)
+                     (int)K2, rows_per_split, tj, ti * tj, nsplit, gd)
   const int pd = limb_pd();
   if (rowscale) { if (pd == 1) CB_TN_LAUNCH(true, 1); else if (pd == 3) CB_TN_LAUNCH(true, 3); else CB_TN_LAUNCH(true, 2); }
   else { if (pd == 1) CB_TN_LAUNCH(false, 1); else if (pd == 3) CB_TN_LAUNCH(false, 3); else CB_TN_LAUNCH(false, 2); }
@@ -281,13 +296,15 @@ bool limb3_tn_eligible(const float* A, int64_t lda, const float* G, int64_t ldg,
 }
 
 int launch_tn_limb3(const float* A, int64_t lda, const float* G, int64_t ldg, const float* rowscale, float* partial, int64_t M,
-                    int64_t K1, int64_t K2, int bm, int nsplit, int64_t rows_per_split, hipStream_t st) {
-  if (bm == 64) launch_tn_l3_t<1, 4>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st);
-  else if (bm == 256) launch_tn_l3_t<4, 1>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st);
+                    int64_t K1, int64_t K2, int bm, int nsplit, int64_t rows_per_split, hipStream_t st, const DropSpec* gdrop) {
+  const DropSpec gd = gdrop ? *gdrop : DropSpec{};
+  CB_CHECK_ARG(!gd.thresh || (!rowscale && gd.width % 4 == 0), CB_E_INVALID, "TN contraction: operand dropout needs width %% 4 == 0 and no row scale");
+  if (bm == 64) launch_tn_l3_t<1, 4>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd);
+  else if (bm == 256) launch_tn_l3_t<4, 1>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd);
   else {
     static const int wide = getenv("CB_LIMB_WIDE") ? atoi(getenv("CB_LIMB_WIDE")) : 1;
-    if (wide && K2 > 128 && ((K1 + 127) / 128) * ((K2 + 255) / 256) * nsplit >= 256) launch_tn_l3_t<2, 2, 4>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st);
-    else launch_tn_l3_t<2, 2>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st);
+    if (wide && K2 > 128 && ((K1 + 127) / 128) * ((K2 + 255) / 256) * nsplit >= 256) launch_tn_l3_t<2, 2, 4>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd);
+    else launch_tn_l3_t<2, 2>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd);
   }
   CB_LAUNCH_CHECK();
   return CB_OK;

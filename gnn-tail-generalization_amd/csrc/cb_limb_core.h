@@ -6,6 +6,7 @@
 
 #include "cb_common.h"
 #include "cb_gemm_core.h"
+#include "cb_philox.h"
 
 namespace cb {
 
@@ -42,10 +43,19 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 constexpr int KS = 16;   // K step
 
+// x * m rounded to fp32 as a value of its own: what cb_dropout_f32 stores.  Left to the compiler, the product is contracted into the
+// first residual of the limb split (fma(x, m, -hi)), i.e. the limbs then describe the UNROUNDED product — more exact, but no longer
+// the bits of dropout-then-GEMM (HIP's __fmul_rn is a plain multiply and contracts just the same).
+__device__ __forceinline__ float mul_rounded(float x, float m) {
+  float r = x * m;
+  asm volatile("" : "+v"(r));
+  return r;
+}
+
 // ---- "row" operand: global [rows][k] (k contiguous) -> LDS planes [R rows][16 k] -------------------
 // The K step's data moves in NV pieces (one float4 per lane each): load() only brings raw data into registers, stage()
 // masks out-of-range elements, splits and writes the three planes.
-template <int R>
+template <int R, bool DROP = false>
 struct RowOperand {
   static constexpr int PLANE = R * 32, BYTES = 3 * PLANE, NV = R / 64;   // float4 per thread per K step
   static_assert(NV >= 1, "tile rows");
@@ -56,6 +66,19 @@ struct RowOperand {
   static constexpr bool HAS_SC = false;
   static constexpr bool PIN = false, DMA = false;
   float sc[1];        // (interface shared with ColOperand: no per-k scale here)
+  // DROP: F.dropout of this operand while it is staged (DropSpec)
+  uint64_t dseed;
+  uint32_t dthresh;
+  float dscale;
+  int64_t dK, dbase[NV];      // flat index of this lane's j-th float4 at K step 0
+  __device__ __forceinline__ void set_drop(const DropSpec& d, int64_t m0, int64_t Ktot, int t) {
+    dseed = d.seed_dev ? d.seed + *d.seed_dev : d.seed;
+    dthresh = d.thresh;
+    dscale = d.scale;
+    dK = Ktot;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) dbase[j] = (d.row0 + m0 + (t >> 2) + 64 * j) * d.width + (t & 3) * 4;
+  }
   __device__ __forceinline__ void init(int64_t ld, int64_t rows_left, int t) {
     const int row = t >> 2, kq = t & 3;
     woff = row * 32 + (((kq >> 1) ^ ((row >> 3) & 1)) << 4) + ((kq & 1) << 3);
@@ -76,7 +99,13 @@ struct RowOperand {
   template <int J>
   __device__ __forceinline__ void stage(const float4 (&f)[NV], char* __restrict__ S, int64_t k_left, int t) const {
     const bool live = ((rmask >> J) & 1) && (t & 3) * 4 < k_left;
-    const float v[4] = {live ? f[J].x : 0.f, live ? f[J].y : 0.f, live ? f[J].z : 0.f, live ? f[J].w : 0.f};
+    float v[4] = {live ? f[J].x : 0.f, live ? f[J].y : 0.f, live ? f[J].z : 0.f, live ? f[J].w : 0.f};
+    if constexpr (DROP) {      // the same product cb_dropout_f32 forms: x * (keep ? 1 / (1 - p) : 0)
+      float mk[4];
+      keep4(dseed, (dbase[J] + (dK - k_left)) >> 2, dthresh, dscale, mk);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = mul_rounded(v[i], mk[i]);
+    }
     uint2 pl[3];
     split4(v, pl);
 #pragma unroll
@@ -93,7 +122,7 @@ struct RowOperand {
 };
 
 // ---- "col" operand: global [k][cols] (cols contiguous) -> LDS planes [16 k][C cols] ------------------
-template <int C, bool SCALED>
+template <int C, bool SCALED, bool DROP = false>
 struct ColOperand {
   static constexpr int ROWB = C * 2, PLANE = 16 * ROWB, BYTES = 3 * PLANE;
   static constexpr int TPR = C / 4, KPP = 256 / TPR, NV = 16 / KPP;   // threads per k row, k rows per pass, float4 per thread
@@ -106,6 +135,21 @@ struct ColOperand {
   static constexpr bool HAS_SC = SCALED;
   static constexpr bool PIN = false, DMA = false;
   float sc[SCALED ? NV : 1];   // raw per-row scales of the loaded step
+  // DROP: F.dropout of this operand while it is staged (DropSpec); rows of the operand = the reduction axis
+  uint64_t dseed;
+  uint32_t dthresh;
+  float dscale;
+  int64_t drow, dtot, dwidth;
+  int dcol;
+  __device__ __forceinline__ void set_drop(const DropSpec& d, int64_t r_begin, int64_t total, int j0, int t) {
+    dseed = d.seed_dev ? d.seed + *d.seed_dev : d.seed;
+    dthresh = d.thresh;
+    dscale = d.scale;
+    drow = d.row0 + r_begin + t / TPR;
+    dtot = total;
+    dwidth = d.width;
+    dcol = j0 + (t % TPR) * 4;
+  }
   __device__ __forceinline__ void init(int64_t ld, int cols_left, int t) {
     const int k = t / TPR, nq = t % TPR;
     cok = nq * 4 < cols_left;
@@ -127,7 +171,14 @@ struct ColOperand {
   __device__ __forceinline__ void stage(const float4 (&f)[NV], char* __restrict__ S, int64_t k_left, int t) const {
     const bool live = cok && t / TPR + KPP * J < k_left;
     const float m = SCALED ? sc[SCALED ? J : 0] : 1.f;
-    const float v[4] = {live ? f[J].x * m : 0.f, live ? f[J].y * m : 0.f, live ? f[J].z * m : 0.f, live ? f[J].w * m : 0.f};
+    float v[4] = {live ? f[J].x * m : 0.f, live ? f[J].y * m : 0.f, live ? f[J].z * m : 0.f, live ? f[J].w * m : 0.f};
+    if constexpr (DROP) {
+      static_assert(!SCALED, "dropout of a row-scaled operand is not needed anywhere");
+      float mk[4];
+      keep4(dseed, ((drow + KPP * J + (dtot - k_left)) * dwidth + dcol) >> 2, dthresh, dscale, mk);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = mul_rounded(v[i], mk[i]);
+    }
     uint2 pl[3];
     split4(v, pl);
 #pragma unroll
@@ -156,7 +207,7 @@ struct ColOperand {
 // global (L2-resident: 3 * K * N * 2 bytes) -> LDS: no conversion, subtraction or masking per block per K step.
 template <int C>
 struct ColOperandPre {
-  using Base = ColOperand<C, false>;
+  using Base = ColOperand<C, false, false>;
   static constexpr int PLANE = Base::PLANE, BYTES = Base::BYTES;
   static constexpr int NV = BYTES / (256 * 16);          // 16-byte pieces per thread per K step (C = 256: 6, C = 128: 3)
   static_assert(BYTES % (256 * 16) == 0, "tile widths 128 / 256");

@@ -87,6 +87,50 @@ def mm_nn_drop2(a, b, p, seed, row0=0, bias=None, relu=False):
     return y, yd
 
 
+def mm_nn_indrop_drop2(a, b, p, a_seed, seed, row0=0, bias=None, relu=False):
+    """(y, dropout_seed(y)) with y = act(dropout_{a_seed}(a) @ b + bias): the dropout in front of the input Linear (GCN.py:104) is
+    applied to `a` while the GEMM stages it (cb_gemm_nn_indrop_drop2_f32) — bit-identical to ops._dropout_raw(a, p, a_seed, row0 * K)
+    followed by mm_nn_drop2.  Returns None where the fused form does not exist for the shape (the caller keeps the two-kernel form)."""
+    import ctypes
+    from . import ops
+    lib = _lib.load()
+    _lib.require_device(a, b, bias)
+    a, b = _rowmajor(a), _rowmajor(b)
+    M, K = a.shape
+    K2, N = b.shape
+    if K != K2 or a.dtype != torch.float32 or b.dtype != torch.float32 or not (0.0 < p < 1.0):
+        return None
+    y = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    yd = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if not lib.cb_gemm_nn_indrop_supported(_lib.ptr(a), _ld(a), _lib.ptr(b), _ld(b), _lib.ptr(y), N, _lib.ptr(yd), N, M, N, K):
+        return None
+    with torch.cuda.device(a.device):
+        _lib.check(lib.cb_gemm_nn_indrop_drop2_f32(_lib.ptr(a), _ld(a), _lib.ptr(b), _ld(b), _lib.ptr(y), N, _lib.ptr(yd), N, M, N, K, _lib.ptr(bias),
+                                                   int(bool(relu)), float(p), ctypes.c_uint64(a_seed), float(p), ctypes.c_uint64(seed),
+                                                   ops.seed_dev_ptr(), int(row0), _lib.stream_ptr()), 'cb_gemm_nn_indrop_drop2_f32')
+    return y, yd
+
+
+def mm_tn_gdrop(a, g, p, g_seed, row0=0):
+    """a^T @ dropout_{g_seed}(g) with the keep-mask regenerated while g is staged (cb_gemm_tn_gdrop_f32); None where unsupported."""
+    import ctypes
+    from . import ops
+    lib = _lib.load()
+    _lib.require_device(a, g)
+    a, g = _rowmajor(a), _rowmajor(g)
+    M, K1 = a.shape
+    M2, K2 = g.shape
+    if M != M2 or not (0.0 < p < 1.0) or not lib.cb_gemm_tn_gdrop_supported(_lib.ptr(a), _ld(a), _lib.ptr(g), _ld(g), K1, K2):
+        return None
+    out = torch.empty((K1, K2), dtype=torch.float32, device=a.device)
+    wsb = lib.cb_gemm_tn_workspace_bytes(M, K1, K2)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.cb_gemm_tn_gdrop_f32(_lib.ptr(a), _ld(a), _lib.ptr(g), _ld(g), _lib.ptr(out), M, K1, K2, float(p), ctypes.c_uint64(g_seed),
+                                            ops.seed_dev_ptr(), int(row0), _lib.ptr(ws), wsb, _lib.stream_ptr()), 'cb_gemm_tn_gdrop_f32')
+    return out
+
+
 def mm_nn_trunkbwd(a, b, rowscale, bits, c_act, p, seed, row0, row_scale2, want_colsum, want_gr=True):
     """(G, GR, colsum): G = rowscale * (a @ b) and, from the same epilogue, GR = c_act * dropout_bwd(G) * relu_bits * row_scale2 with
     the column sums of the unscaled GR (cb_gemm_nn_trunkbwd_f32) — the dX GEMM + the layer-below's trunk backward in one kernel."""

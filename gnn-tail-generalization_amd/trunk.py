@@ -227,11 +227,21 @@ class _TrunkFn(torch.autograd.Function):
         row0 = int(getattr(graph, 'row_offset', 0))
         a = graph.norm_out
         x = x.contiguous()
-        xd = ops._dropout_raw(x, p, seeds[0], row0 * x.shape[1]) if p > 0 else x
-        if p > 0:    # X0 and its dropped copy leave the same GEMM epilogue (X0 is not re-read by a dropout pass)
-            x0, cur = gemm.mm_nn_drop2(xd, w_in.t().contiguous(), p, seeds[1], row0, bias=b_in, relu=True)
+        # the dropout of the input features (GCN.py:104) is applied by the input Linear's GEMM while it stages x (no dropped copy of x
+        # is written, kept or re-read: the weight gradient regenerates the mask) where that form exists; CB_TRUNK_INDROP=0 keeps the pass
+        fused_in = None
+        if p > 0 and os.environ.get('CB_TRUNK_INDROP', '1') != '0':
+            fused_in = gemm.mm_nn_indrop_drop2(x, w_in.t().contiguous(), p, seeds[0], seeds[1], row0, bias=b_in, relu=True)
+        if fused_in is not None:
+            x0, cur = fused_in
+            xd = x                    # saved for the backward: the UNdropped features
         else:
-            x0 = cur = gemm.mm_nn(xd, w_in.t().contiguous(), bias=b_in, relu=True)
+            xd = ops._dropout_raw(x, p, seeds[0], row0 * x.shape[1]) if p > 0 else x
+            if p > 0:    # X0 and its dropped copy leave the same GEMM epilogue (X0 is not re-read by a dropout pass)
+                x0, cur = gemm.mm_nn_drop2(xd, w_in.t().contiguous(), p, seeds[1], row0, bias=b_in, relu=True)
+            else:
+                x0 = cur = gemm.mm_nn(xd, w_in.t().contiguous(), bias=b_in, relu=True)
+        ctx.indrop = fused_in is not None
         h = x0.shape[1]
         saved_in, saved_bits = [cur], []
         bwd = any(ctx.needs_input_grad)          # eval / metrics forwards (no_grad): no mask words, nothing kept
@@ -398,7 +408,14 @@ class _TrunkFn(torch.autograd.Function):
         else:
             gpre, d_b_in = _input_bwd(g, gx0, x0, p, seeds[1] if p > 0 else 0, row0)
         del g, gx0, g_mix
-        d_w_in = gemm.mm_tn(gpre, xd) if need[3] else None
+        d_w_in = None
+        if need[3]:
+            if ctx.indrop:      # xd holds the undropped features: the mask is regenerated while the GEMM stages them
+                d_w_in = gemm.mm_tn_gdrop(gpre, xd, p, seeds[0], row0)
+                if d_w_in is None:
+                    d_w_in = gemm.mm_tn(gpre, ops._dropout_raw(xd, p, seeds[0], row0 * xd.shape[1]))
+            else:
+                d_w_in = gemm.mm_tn(gpre, xd)
         d_x = None
         if need[2]:
             d_x = gemm.mm_nn(gpre, w_in)

@@ -419,6 +419,21 @@ int cb_spmm_csr_weighted_f32(const int32_t* rowptr, const int32_t* col, const fl
 int cb_spmm_edge_dot_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h, const float* g,
                          int64_t ld_g, int64_t d, float* dw, void* stream);
 
+/* Dropout of an OPERAND while it is staged (GCN.py:104: `x = F.dropout(x)` in front of layers_MLP[0] of the residual trunk): the input
+ * Linear reads the undropped features and applies the keep-mask cb_dropout_f32(x, ..., a_seed, seed_dev, offset = row0 * K) draws as it
+ * splits them into limbs — no dropped copy is written, kept or re-read; the weight gradient regenerates the same mask:
+ *     C = act(dropout(A) @ B + bias), C2 = dropout_{seed}(C)            cb_gemm_nn_indrop_drop2_f32   (else: cb_dropout_f32 + cb_gemm_nn_drop2_f32)
+ *     C = A^T @ dropout(G)                                              cb_gemm_tn_gdrop_f32          (else: cb_dropout_f32 + cb_gemm_tn_f32)
+ * Results are bit-identical to the two-kernel forms.  The *_supported queries (1 / 0) say whether the fused form exists for a shape. */
+int cb_gemm_nn_indrop_supported(const float* A, int64_t lda, const float* B, int64_t ldb, const float* C, int64_t ldc, const float* C2, int64_t ldc2,
+                                int64_t M, int64_t N, int64_t K);
+int cb_gemm_nn_indrop_drop2_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, float* C2, int64_t ldc2,
+                                int64_t M, int64_t N, int64_t K, const float* bias, int relu, float a_drop_p, uint64_t a_seed, float drop_p,
+                                uint64_t seed, const uint64_t* seed_dev, int64_t row0, void* stream);
+int cb_gemm_tn_gdrop_supported(const float* A, int64_t lda, const float* G, int64_t ldg, int64_t K1, int64_t K2);
+int cb_gemm_tn_gdrop_f32(const float* A, int64_t lda, const float* G, int64_t ldg, float* C, int64_t M, int64_t K1, int64_t K2, float g_drop_p,
+                         uint64_t g_seed, const uint64_t* seed_dev, int64_t row0, void* ws, size_t ws_bytes, void* stream);
+
 /* The same pack with the rows narrowed to bf16 (round-to-nearest-even) as they are written: the send buffer of the bf16 halo wire. */
 int cb_gather_rows_bf16_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, uint16_t* out, void* stream);
 

@@ -423,3 +423,25 @@ def test_gemm_trunk_backward_epilogue_matches_two_kernels(M, K, p):
     # no column sums requested
     g2, gr2, none = gemm.mm_nn_trunkbwd(a, b, rs, bits, c_act, p, seed, row0, rs2, False)
     assert none is None and torch.equal(gr2, gr)
+
+
+@pytest.mark.parametrize('M,K,N,row0', [(40000, 128, 256, 0), (33001, 100, 256, 77)])
+def test_operand_dropout_gemms_equal_dropout_then_gemm(M, K, N, row0):
+    """the dropout of the input features applied by the input Linear's GEMM while it stages x
+    (cb_gemm_nn_indrop_drop2_f32) and regenerated by the weight-gradient GEMM (cb_gemm_tn_gdrop_f32) — both bit-identical to
+    cb_dropout_f32 followed by the plain GEMMs (same keep-mask: a pure function of seed and flat index, also for a row-sharded x)."""
+    from gnn_tail_generalization_amd import gemm, ops
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.rand(M, K, device=DEV, generator=gen)
+    w = torch.randn(K, N, device=DEV, generator=gen) * 0.1
+    b = torch.randn(N, device=DEV, generator=gen)
+    g = torch.randn(M, N, device=DEV, generator=gen)
+    p, s_in, s_out = 0.1, 0x1234ABCD5, 0x77
+    fused = gemm.mm_nn_indrop_drop2(x, w, p, s_in, s_out, row0, bias=b, relu=True)
+    assert fused is not None
+    xd = ops._dropout_raw(x, p, s_in, row0 * K)
+    y, yd = gemm.mm_nn_drop2(xd, w, p, s_out, row0, bias=b, relu=True)
+    assert torch.equal(fused[0], y) and torch.equal(fused[1], yd)
+    dw = gemm.mm_tn_gdrop(g, x, p, s_in, row0)
+    assert dw is not None and torch.equal(dw, gemm.mm_tn(g, xd))
+    assert gemm.mm_nn_indrop_drop2(x[:100], w, p, s_in, s_out, 0, bias=b, relu=True) is None       # too few tiles: no fused form, caller falls back
