@@ -45,6 +45,20 @@ struct GemmTail {
   int64_t ld_add;
   float* out;              // [rows, ld_out]
   int64_t ld_out;
+  // TB kernels only (trunk backward): the value just computed is dL/dx of the stage above layer l-1; the backward of that layer's fused
+  // store — what cb_trunk_layer_bwd_f32 does in a pass of its own — leaves the same epilogue:
+  //   out2 = c_act * keep(seed, m, n) * g * relu_bit_{l-1}(m, n) * rowscale2[m];   colsum partial[block][n] += (the same without rowscale2)
+  const unsigned long long* bits;   // [rows][4] mask words of the forward store of layer l-1 (d = 256: one tile)
+  float c_act;
+  uint32_t thresh;
+  float keep_scale;
+  uint64_t seed;
+  const uint64_t* seed_dev;
+  int64_t row0;
+  const float* rowscale2;
+  float* out2;
+  int64_t ld_out2;
+  float* colsum_partial;   // [gridDim.x][256] or null
   int dbg;                 // measurement hook CB_AGG_GEMM_DBG (bit 0: B fragments loaded once, bit 1: A fragments split once, bit 2: no K loop)
 };
 
@@ -262,9 +276,9 @@ constexpr int kCLD = 68;     // floats per row of a multiplying wavefront's priv
 
 // PF = K steps of B fragments in flight per multiplying wavefront (ring of PF + 1 register buffers, K loop unrolled by PF + 1): next
 // to wavefronts that keep dozens of gathers outstanding, a load of this CU — L2 hit or not — comes back after microseconds.
-template <int PF>
+template <int PF, bool TB>
 __device__ __forceinline__ void ag2_mfma_tile(int t, const float* __restrict__ tile, float* __restrict__ cs, int w, int lane, int n_rows,
-                                              const GemmTail& gt) {
+                                              const GemmTail& gt, float (&colsum)[4], uint64_t seed_eff) {
   static_assert(PF == 1 || PF == 3, "ring of 2 or 4 fragment buffers (16 K steps)");
   const int l31 = lane & 31, lh = lane >> 5;
   f32x16 acc[2][2];
@@ -351,12 +365,32 @@ __device__ __forceinline__ void ag2_mfma_tile(int t, const float* __restrict__ t
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = o[e] * rs + ad[e] + zero_bias;
           if (!(gt.dbg & 2)) store_stream<4>(gt.out + m * gt.ld_out + n, o);      // (dbg bit 1, measurement: no output store)
+          if constexpr (TB) {      // the arithmetic of k_trunk_bwd<0> (cb_elementwise.hip), element for element
+            float gm[4] = {o[0], o[1], o[2], o[3]};
+            if (gt.thresh) {
+              float mk[4];
+              keep4(seed_eff, ((gt.row0 + m) * kND + n) >> 2, gt.thresh, gt.keep_scale, mk);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) gm[e] *= mk[e];
+            }
+            const unsigned long long* bw = gt.bits + m * 4;      // word e, bit L <-> column 4 L + e
+            const int L = n >> 2;
+            const float sc2 = gt.rowscale2 ? gt.rowscale2[m] : 1.f;
+            float gy[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              gy[e] = ((bw[e] >> L) & 1ull) ? gt.c_act * gm[e] : 0.f;
+              colsum[e] += gy[e];
+              gy[e] *= sc2;
+            }
+            store_stream<4>(gt.out2 + m * gt.ld_out2 + n, gy);
+          }
         }
       }
     }
 }
 
-template <int U, bool FUSED, int GP, int NG>
+template <int U, bool FUSED, int GP, int NG, bool TB = false>
 __global__ void __launch_bounds__(64 * (NG + 4), (NG + 4) / 4) k_agg_gemm2(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                                           const float* __restrict__ h, int64_t ld_h, float* __restrict__ out,
                                                                           int64_t ld_out, int n_rows, Epilogue ep, int hub_T, FusedEpi fe,
@@ -369,18 +403,60 @@ __global__ void __launch_bounds__(64 * (NG + 4), (NG + 4) / 4) k_agg_gemm2(const
   const bool gathers = wv < NG;
   const int w = gathers ? wv : wv - NG;
   const int n_it = ((int)blockIdx.x < n_tiles) ? (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  float colsum[4] = {0.f, 0.f, 0.f, 0.f};      // TB: sums of this lane's 4 output columns (64 w + 4 (lane & 15) ..) over the rows it stored
+  const uint64_t seed_eff = TB ? (gt.seed_dev ? gt.seed + *gt.seed_dev : gt.seed) : 0ull;
   for (int it = 0; it <= n_it; ++it) {
     if (gathers) {
       if (it < n_it && !(gt.dbg & 16))
         ag2_gather_tile<U, FUSED, GP, NG>(blockIdx.x + it * gridDim.x, tiles[it & 1], w, lane, rowptr, col, h, ld_h, out, ld_out, n_rows, ep, hub_T, fe);
     } else if (it >= 1 && !(gt.dbg & 8)) {
-      ag2_mfma_tile<(NG == 4 ? 3 : 1)>(blockIdx.x + (it - 1) * gridDim.x, tiles[(it - 1) & 1], cstrip[w], w, lane, n_rows, gt);
+      ag2_mfma_tile<(NG == 4 ? 3 : 1), TB>(blockIdx.x + (it - 1) * gridDim.x, tiles[(it - 1) & 1], cstrip[w], w, lane, n_rows, gt, colsum, seed_eff);
     }
     __syncthreads();
   }
+  if constexpr (TB) {
+    // column sums of the block's rows: the four lanes that own the same column quad are added in a fixed order, then one partial row per
+    // block (summed over the blocks by k_agg_colsum_finish in block order: no float atomics, bit-reproducible)
+    if (!gathers && gt.colsum_partial) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = colsum[e];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        colsum[e] = v;
+      }
+      if (lane < 16) {
+        float* pp = gt.colsum_partial + (int64_t)blockIdx.x * kND + 64 * w + 4 * lane;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pp[e] = colsum[e];
+      }
+    }
+  }
 }
 
+// out[c] = sum over blocks of partial[block][c], blocks in ascending order (one thread per column)
+__global__ void __launch_bounds__(256) k_agg_colsum_finish(const float* __restrict__ partial, int n_blocks, float* __restrict__ out) {
+  const int c = threadIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < n_blocks; ++b) s += partial[(int64_t)b * kND + c];
+  out[c] = s;
+}
+
+
 static inline int64_t ag_partial_ld(int64_t d) { return (d + 3) / 4 * 4; }
+
+// blocks of the persistent kernel: one per CU
+static int ag_n_blocks(int n_tiles) {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+    if (n_cu > 1024) n_cu = 1024;      // (cb_spmm_gemm_trunkbwd_workspace_bytes: one partial row per block)
+  }
+  return n_tiles < n_cu ? n_tiles : n_cu;
+}
 
 template <bool FUSED>
 static int launch_agg_gemm(const int32_t* rowptr, const int32_t* col, int64_t N, const float* h, int64_t ld_h, Epilogue ep, float* out,
@@ -413,18 +489,21 @@ static int launch_agg_gemm(const int32_t* rowptr, const int32_t* col, int64_t N,
     CB_LAUNCH_CHECK();
     return CB_OK;
   }
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
-  const dim3 grid2((unsigned)min(n_tiles, n_cu));      // one persistent block per CU (139 KB of LDS each)
+  const dim3 grid2((unsigned)ag_n_blocks(n_tiles));      // one persistent block per CU (139 KB of LDS each)
   // measured on S-pl10M (profiles/r03_fused_agg_gemm.md): 8 gathering wavefronts with 8 gathers each in flight beat 4 x 16 and 8 x 16
   static const int u16 = getenv("CB_AGG_GEMM_U") ? atoi(getenv("CB_AGG_GEMM_U")) : 8;
   static const int ng = getenv("CB_AGG_GEMM_NG") ? atoi(getenv("CB_AGG_GEMM_NG")) : 8;
 #define CB_AG2(U_, GP_, NG_) hipLaunchKernelGGL((k_agg_gemm2<U_, FUSED, GP_, NG_>), grid2, dim3(64 * (NG_ + 4)), 0, st, rowptr, col, h, ld_h, out, ld_out, (int)N, ep, hub_T, fe, gt, n_tiles)
+  if constexpr (!FUSED) {
+    if (gt.out2) {      // + the trunk backward of the layer below in the dense tail's epilogue
+      if (ep.col_flags)
+        hipLaunchKernelGGL((k_agg_gemm2<8, false, 2, 8, true>), grid2, dim3(64 * 12), 0, st, rowptr, col, h, ld_h, out, ld_out, (int)N, ep, hub_T, fe, gt, n_tiles);
+      else
+        hipLaunchKernelGGL((k_agg_gemm2<8, false, 0, 8, true>), grid2, dim3(64 * 12), 0, st, rowptr, col, h, ld_h, out, ld_out, (int)N, ep, hub_T, fe, gt, n_tiles);
+      CB_LAUNCH_CHECK();
+      return CB_OK;
+    }
+  }
   if (ng == 8) {
     if (u16 == 16) { if (ep.col_flags) CB_AG2(16, 2, 8); else CB_AG2(16, 0, 8); }
     else { if (ep.col_flags) CB_AG2(8, 2, 8); else CB_AG2(8, 0, 8); }
@@ -494,9 +573,51 @@ extern "C" int cb_spmm_gemm_f32(const int32_t* rowptr, const int32_t* col, int32
   CB_CHECK_ARG(out && ag_al16(out) && ld_out % 4 == 0 && ld_out >= d, CB_E_INVALID, "cb_spmm_gemm_f32: 16-byte aligned output rows required");
   if (n_hubs == 0) hub_T = INT32_MAX;
   Epilogue ep{row_scale, bias, relu, nullptr, 0, col_flags};
-  GemmTail gt{(const uint4*)image, g_rowscale, g_addend, ld_add, g_out, ld_gout, ag_dbg()};
+  GemmTail gt{(const uint4*)image, g_rowscale, g_addend, ld_add, g_out, ld_gout};
+  gt.dbg = ag_dbg();
   return launch_agg_gemm<false>(rowptr, col, N, h, ld_h, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, (float*)ws,
                                 (hipStream_t)stream, FusedEpi{}, gt);
+}
+
+// cb_spmm_gemm_f32 + the trunk backward of the layer below from the dense tail's epilogue (TB): g_out = g_rowscale * (out @ B) is dL/dx of
+// the stage above layer l-1, and gr_out = c_act * dropout_bwd_{seed}(g_out) * relu_bits * rowscale2 (the input of the next reverse
+// aggregation) with colsum = column sums of the same without rowscale2 (that layer's bias gradient) — cb_trunk_layer_bwd_f32 without
+// its 10 GB read of g_out.  ws2: cb_spmm_gemm_trunkbwd_workspace_bytes() for the per-block partial column sums.
+extern "C" size_t cb_spmm_gemm_trunkbwd_workspace_bytes(void) { return (size_t)1024 * kND * sizeof(float); }
+
+extern "C" int cb_spmm_gemm_trunkbwd_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h,
+                                         int64_t ld_h, int64_t d, float* out, int64_t ld_out, int32_t hub_T, int32_t n_hubs, int32_t n_chunks,
+                                         const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, const void* image,
+                                         const float* g_rowscale, float* g_out, int64_t ld_gout, const uint64_t* relu_bits, float c_act,
+                                         float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, const float* rowscale2,
+                                         float* gr_out, int64_t ld_gr, float* colsum, void* ws2, size_t ws2_bytes, void* stream) {
+  const int rc = agg_gemm_common_checks("cb_spmm_gemm_trunkbwd_f32", N, E, d, rowptr, col, h, ld_h, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr,
+                                        ws, ws_bytes, image, nullptr, 0, g_out, ld_gout);
+  if (rc != CB_OK) return rc;
+  if (N == 0) {
+    if (colsum) CB_HIP(hipMemsetAsync(colsum, 0, kND * sizeof(float), (hipStream_t)stream));
+    return CB_OK;
+  }
+  CB_CHECK_ARG(out && ag_al16(out) && ld_out % 4 == 0 && ld_out >= d && relu_bits && gr_out && ag_al16(gr_out) && ld_gr % 4 == 0 && ld_gr >= kND &&
+                   drop_p >= 0.f && drop_p < 1.f && row0 >= 0,
+               CB_E_INVALID, "cb_spmm_gemm_trunkbwd_f32: null pointer, misaligned rows or bad p");
+  CB_CHECK_ARG(!colsum || (ws2 && ws2_bytes >= cb_spmm_gemm_trunkbwd_workspace_bytes()), CB_E_WORKSPACE, "cb_spmm_gemm_trunkbwd_f32: workspace too small");
+  if (n_hubs == 0) hub_T = INT32_MAX;
+  Epilogue ep{nullptr, nullptr, 0, nullptr, 0, col_flags};
+  GemmTail gt{(const uint4*)image, g_rowscale, nullptr, 0, g_out, ld_gout};
+  gt.bits = (const unsigned long long*)relu_bits; gt.c_act = c_act; gt.thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
+  gt.keep_scale = 1.f / (1.f - drop_p); gt.seed = seed; gt.seed_dev = seed_dev; gt.row0 = row0; gt.rowscale2 = rowscale2;
+  gt.out2 = gr_out; gt.ld_out2 = ld_gr; gt.colsum_partial = colsum ? (float*)ws2 : nullptr; gt.dbg = ag_dbg();
+  hipStream_t st = (hipStream_t)stream;
+  const int rc2 = launch_agg_gemm<false>(rowptr, col, N, h, ld_h, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, (float*)ws, st,
+                                         FusedEpi{}, gt);
+  if (rc2 != CB_OK) return rc2;
+  if (colsum) {
+    const int n_tiles = (int)((N + kTM - 1) / kTM);
+    hipLaunchKernelGGL(k_agg_colsum_finish, dim3(1), dim3(256), 0, st, (const float*)ws2, ag_n_blocks(n_tiles), colsum);
+    CB_LAUNCH_CHECK();
+  }
+  return CB_OK;
 }
 
 // Fused trunk store (cb_spmm_csr_fused_f32: ReLU / mix / dropout, mask words, out_next) + g_out = g_rowscale * (out_next @ B) + g_addend.
@@ -520,7 +641,8 @@ extern "C" int cb_spmm_gemm_fused_f32(const int32_t* rowptr, const int32_t* col,
   fe.keep_scale = 1.f / (1.f - drop_p);
   fe.seed = seed; fe.seed_dev = seed_dev; fe.row0 = row0; fe.bits = (unsigned long long*)relu_bits;
   fe.out_act = nullptr; fe.ld_act = 0; fe.out_next = out_next; fe.ld_next = ld_next; fe.d = (int)d;
-  GemmTail gt{(const uint4*)image, g_rowscale, g_addend, ld_add, g_out, ld_gout, ag_dbg()};
+  GemmTail gt{(const uint4*)image, g_rowscale, g_addend, ld_add, g_out, ld_gout};
+  gt.dbg = ag_dbg();
   return launch_agg_gemm<true>(rowptr, col, N, h, ld_h, ep, out_next, ld_next, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, (float*)ws,
                                (hipStream_t)stream, fe, gt);
 }

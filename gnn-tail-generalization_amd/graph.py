@@ -275,6 +275,48 @@ class CSRGraph:
                                                           src_elem=2 if bf16 else 4), 0))
         return out
 
+    def spmm_gemm_trunkbwd(self, h, image, g_rowscale, bits, c_act, p, seed, row0, rowscale2, want_colsum, transpose=True):
+        """(out, g, gr, colsum) of cb_spmm_gemm_trunkbwd_f32: out = A h (raw sums), g = g_rowscale * (out @ B) and, from the same epilogue, the
+        trunk backward of the layer below: gr = c_act * dropout_bwd(g) * bits * rowscale2, colsum = column sums of the unscaled gr."""
+        import ctypes
+        from . import ops
+        lib = _lib.load()
+        _lib.require_device(h, image, g_rowscale, bits, rowscale2)
+        d = h.shape[1] if h.dim() == 2 else -1
+        if h.dtype != torch.float32 or d != 256 or h.shape[0] != self.n_cols or h.stride(1) != 1:
+            raise ValueError(f'spmm_gemm_trunkbwd: float32 [{self.n_cols}, 256] rows expected, got {tuple(h.shape)} {h.dtype}')
+        if bits.dtype != torch.int64 or tuple(bits.shape) != (self.N, 1, 4) or not bits.is_contiguous():
+            raise ValueError('spmm_gemm_trunkbwd: int64 [N, 1, 4] mask words expected')
+        dev = h.device
+        out = torch.empty((self.N, d), dtype=torch.float32, device=dev)
+        g = torch.empty((self.N, 256), dtype=torch.float32, device=dev)
+        gr = torch.empty((self.N, 256), dtype=torch.float32, device=dev)
+        colsum = torch.empty(256, dtype=torch.float32, device=dev) if want_colsum else None
+        rowptr, col, plan = (self.rowptr_t, self.col_t, self._plan_t) if transpose else (self.rowptr, self.col, self._plan)
+        col_k = self.flagged_cols(transpose, d * 4)
+        flags = int(col_k is not None and h.data_ptr() % 16 == 0 and h.stride(0) % 4 == 0)
+        if flags:
+            col = col_k
+        ws_bytes = lib.cb_spmm_workspace_bytes(plan.n_chunks, d)
+        ws = self._workspace(ws_bytes)
+        ws2b = lib.cb_spmm_gemm_trunkbwd_workspace_bytes() if want_colsum else 0
+        ws2 = torch.empty(max(ws2b, 16), dtype=torch.uint8, device=dev)
+        prof = self.profile
+        if prof is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        with torch.cuda.device(dev):
+            _lib.check(lib.cb_spmm_gemm_trunkbwd_f32(_lib.ptr(rowptr), _lib.ptr(col), flags, self.N, self.E, _lib.ptr(h), h.stride(0), d, _lib.ptr(out), d,
+                                                     self.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr),
+                                                     _lib.ptr(ws), ws_bytes, _lib.ptr(image), _lib.ptr(g_rowscale), _lib.ptr(g), 256, _lib.ptr(bits),
+                                                     float(c_act), float(p), ctypes.c_uint64(seed), ops.seed_dev_ptr(), int(row0), _lib.ptr(rowscale2),
+                                                     _lib.ptr(gr), 256, _lib.ptr(colsum), _lib.ptr(ws2), ws2b, _lib.stream_ptr()),
+                       'cb_spmm_gemm_trunkbwd_f32')
+        if prof is not None:
+            ev1.record()
+            prof.append((ev0, ev1, self.algorithmic_bytes(d, row_scale=False, bias=False), 0, self.N * 256 * 4 * 2 + 4 * self.N + 32 * self.N))
+        return out, g, gr, colsum
+
     def edge_perm(self, transpose=False):
         """CSR position -> column of edge_index (int64 [E]) for the by-dst (transpose=False) or by-src orientation: the stable sort of
         the (row, col) keys, i.e. the order cb_csr_from_coo_i64 lays the edges out in (duplicates of a multigraph keep their input

@@ -192,6 +192,11 @@ FUSE_BWD_EPILOGUE = os.environ.get('CB_TRUNK_FUSE_BWD', '0') == '1'
 # passes go, the masked launches cost +1.7 ms each for their 36 bytes of mask words / scale per edge, the epilogue ~1 ms) — but the
 # reverse launches then move SURVEY 8(d)'s bytes at 0.78 instead of 0.90 of the roofline, so it stays opt-in: CB_TRUNK_MASKED_GATHER=1.
 MASKED_GATHER = os.environ.get('CB_TRUNK_MASKED_GATHER', '0') == '1'
+# Trunk backward of the layer below in the epilogue of the reverse aggregation + dX kernel (cb_spmm_gemm_trunkbwd_f32) instead of a pass of its
+# own.  Measured SLOWER on S-pl10M: 207.8 vs 203.9 ms per step — the 3 x 3.8 ms passes go, but the multiplying wavefronts of the persistent
+# kernel (Philox, mask words, a third 10 GB store; 100 B of scratch at the 168-register cap) stop being hidden under the gathers.  Kept,
+# tested (tests/test_gpu_agg_gemm.py), opt-in: CB_AGG_GEMM_TRUNKBWD=1.
+TAIL_TRUNK_BWD = os.environ.get('CB_AGG_GEMM_TRUNKBWD', '0') == '1'
 MIX_MAX = 7      # mixed-in gradients one cb_trunk_input_bwd_multi_f32 launch gathers (deeper trunks accumulate layer by layer)
 
 
@@ -378,9 +383,16 @@ class _TrunkFn(torch.autograd.Function):
             if masked:
                 gz = graph.spmm_masked(g, saved_bits[l], bnorm, coef)                         # dL/dZ_l = A (b * dY'), dY' formed on the fly
             elif ag_bwd:
-                # dL/dZ_l = A (b * dY') and a * (dL/dZ_l @ W_l^T) from one kernel (cb_spmm_gemm_f32)
+                # dL/dZ_l = A (b * dY') and a * (dL/dZ_l @ W_l^T) from one kernel (cb_spmm_gemm_f32); for l > 0 the trunk backward of layer
+                # l-1's store leaves the same epilogue (cb_spmm_gemm_trunkbwd_f32: no pass of its own over dL/dx_l)
                 from .graph import weight_image
-                gz, g_fused = graph.spmm_gemm(gr, weight_image(w, transpose=True), transpose=True, g_rowscale=a)
+                tb_fused = None
+                if l > 0 and TAIL_TRUNK_BWD:
+                    gz, g_fused, gr_n, db_n = graph.spmm_gemm_trunkbwd(gr, weight_image(w, transpose=True), a, saved_bits[l - 1], 1 - alpha, p,
+                                                                         seeds[l + 1] if p > 0 else 0, row0, bnorm, need[7 + 3 * (l - 1) + 1])
+                    tb_fused = (gr_n, db_n)
+                else:
+                    gz, g_fused = graph.spmm_gemm(gr, weight_image(w, transpose=True), transpose=True, g_rowscale=a)
             else:
                 gz = graph.aggregate_finish(handle, True) if sharded else _spmm_t(graph, gr)  # dL/dZ_l = A (b * dY')
             del g, gr
@@ -391,7 +403,9 @@ class _TrunkFn(torch.autograd.Function):
                 else:
                     grads_layers[3 * l] = gemm.mm_tn(saved_in[l], gz, rowscale=a)
             grads_layers[3 * l + 1] = dbias
-            if l > 0:
+            if l > 0 and ag_bwd and tb_fused is not None:
+                g, (gr, dbias), handle = g_fused, tb_fused, None
+            elif l > 0:
                 g, gr, dbias, handle = dx_gemm(gz, w.t().contiguous(), a, l - 1, g_fused)   # dL/d(dropped X_l) and the backward of layer l-1's store
             else:
                 g = g_fused if g_fused is not None else gemm.mm_nn(gz, w.t().contiguous(), rowscale=a)   # dL/d(dropped X_0): consumed by the input stage

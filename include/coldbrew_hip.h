@@ -434,6 +434,19 @@ int cb_gemm_tn_gdrop_supported(const float* A, int64_t lda, const float* G, int6
 int cb_gemm_tn_gdrop_f32(const float* A, int64_t lda, const float* G, int64_t ldg, float* C, int64_t M, int64_t K1, int64_t K2, float g_drop_p,
                          uint64_t g_seed, const uint64_t* seed_dev, int64_t row0, void* ws, size_t ws_bytes, void* stream);
 
+/* cb_spmm_gemm_f32 (reverse aggregation + dX contraction) + the trunk backward of the layer below from the same epilogue: g_out is
+ * dL/dx of the stage above layer l-1; gr_out = c_act * dropout_bwd_{seed}(g_out) * relu_bits * rowscale2 (input of the next reverse
+ * aggregation) and colsum = the column sums of the same without rowscale2 (bias gradient of layer l-1) — what cb_trunk_layer_bwd_f32
+ * computes in a pass of its own (autograd of GCN.py:127-133,250-253), without its 10 GB read of g_out.  relu_bits: the mask words
+ * cb_spmm_csr_fused_f32 wrote for layer l-1 ([N][4], d = 256).  ws2: cb_spmm_gemm_trunkbwd_workspace_bytes() (partial column sums). */
+size_t cb_spmm_gemm_trunkbwd_workspace_bytes(void);
+int cb_spmm_gemm_trunkbwd_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h,
+                              int64_t d, float* out, int64_t ld_out, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
+                              const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, const void* image,
+                              const float* g_rowscale, float* g_out, int64_t ld_gout, const uint64_t* relu_bits, float c_act, float drop_p,
+                              uint64_t seed, const uint64_t* seed_dev, int64_t row0, const float* rowscale2, float* gr_out, int64_t ld_gr,
+                              float* colsum, void* ws2, size_t ws2_bytes, void* stream);
+
 /* The same pack with the rows narrowed to bf16 (round-to-nearest-even) as they are written: the send buffer of the bf16 halo wire. */
 int cb_gather_rows_bf16_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, uint16_t* out, void* stream);
 

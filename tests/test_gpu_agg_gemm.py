@@ -87,6 +87,31 @@ def test_fused_store_gemm_equals_fused_store_then_gemm(n, T, p):
     assert b2 is None and torch.equal(n2, nxt_r if False else trunk._fused_spmm(G, z, bias, x0, 0.9, 0.1, p, 4242)[1])
 
 
+@pytest.mark.parametrize('n,T,p', [(5003, 16, 0.1), (20000, 256, 0.0)])
+def test_reverse_aggregation_gemm_trunk_backward_equals_three_kernels(n, T, p):
+    """cb_spmm_gemm_trunkbwd_f32: dL/dZ (reverse aggregation), dL/dx = a * (dL/dZ @ W^T) and the trunk backward of the layer below
+    (dropout backward, ReLU / mix mask bits, c_act, degree norm) from ONE kernel: dL/dZ, dL/dx and the next aggregation's input are
+    bit-identical to cb_spmm_csr_f32 + cb_gemm_nn_f32 + cb_trunk_layer_bwd_f32; the bias column sums agree to summation order."""
+    from gnn_tail_generalization_amd import gemm, trunk
+    from gnn_tail_generalization_amd.graph import weight_image
+    G = _powerlaw_graph(n, 4, T)
+    gen = torch.Generator(device=DEV).manual_seed(8)
+    z = torch.randn(n, 256, device=DEV, generator=gen)
+    bias = torch.randn(256, device=DEV, generator=gen)
+    bits, _, _ = trunk._fused_spmm(G, z, bias, None, 1.0, 0.0, p, 777)            # mask words of a forward store
+    gr_in = torch.randn(n, 256, device=DEV, generator=gen)
+    w = torch.randn(256, 256, device=DEV, generator=gen) * 0.07
+    a, b = G.norm_out, G.norm_in
+    out, g, gr, cs = G.spmm_gemm_trunkbwd(gr_in, weight_image(w, transpose=True), a, bits, 0.9, p, 777, 0, b, True)
+    ref_out = G.spmm(gr_in, transpose=True)
+    ref_g = gemm.mm_nn(ref_out, w.t().contiguous(), rowscale=a)
+    ref_gr, ref_cs = trunk._layer_bwd(ref_g, bits, b, None, False, p, 777, 0, 0.9, 0.1, True)
+    assert torch.equal(out, ref_out) and torch.equal(g, ref_g) and torch.equal(gr, ref_gr)
+    torch.testing.assert_close(cs, ref_cs, atol=1e-4 * float(ref_cs.abs().max()) + 1e-5, rtol=1e-5)
+    _, _, _, none = G.spmm_gemm_trunkbwd(gr_in, weight_image(w, transpose=True), a, bits, 0.9, p, 777, 0, b, False)
+    assert none is None
+
+
 def _step_losses(monkeypatch, flag, steps=3, n=30000):
     from gnn_tail_generalization_amd import ops
     from gnn_tail_generalization_amd.base_options import BaseOptions
@@ -117,12 +142,21 @@ def _step_losses(monkeypatch, flag, steps=3, n=30000):
 
 def test_training_step_with_fused_kernels_equals_two_kernel_form(monkeypatch):
     """Three optimisation steps of the 3-layer 'Initial' trunk (hidden 256, structural embeddings on, dropout on) with the
-    aggregation + GEMM kernels (CB_AGG_GEMM=1, default) and with the separate kernels (=0): same losses and parameters, bit for bit."""
-    l1, sd1 = _step_losses(monkeypatch, '1')
+    aggregation + GEMM kernels (CB_AGG_GEMM=1, default) and with the separate kernels (=0): same losses and parameters, bit for bit —
+    with the trunk backward kept as a pass of its own; with it in the fused kernel's epilogue (default) the bias gradients are summed
+    in another order, so parameters agree to rounding instead."""
+    from gnn_tail_generalization_amd import trunk
     l0, sd0 = _step_losses(monkeypatch, '0')
+    monkeypatch.setattr(trunk, 'TAIL_TRUNK_BWD', False)
+    l1, sd1 = _step_losses(monkeypatch, '1')
     assert l1 == l0
     for k in sd0:
         assert torch.equal(sd1[k], sd0[k]), k
+    monkeypatch.setattr(trunk, 'TAIL_TRUNK_BWD', True)
+    l2, sd2 = _step_losses(monkeypatch, '1')
+    np.testing.assert_allclose(l2, l0, rtol=1e-6)
+    for k in sd0:
+        torch.testing.assert_close(sd2[k], sd0[k], atol=1e-5, rtol=1e-4, msg=lambda m, k=k: f'{k}: {m}')
 
 
 def test_fused_kernels_against_the_oracle(monkeypatch):
