@@ -32,6 +32,12 @@
 
 namespace cb {
 
+// rows of 17 .. 64 floats: sub-wave streams (cb_spmm_sub.hip)
+bool spmm_sub_eligible(int64_t d, bool al16);
+int launch_spmm_sub(const int32_t* rowptr, const int32_t* col, int64_t N, const float* h, int64_t ld_h, int64_t d, const Epilogue& ep, float* out,
+                    int64_t ld_out, int hub_T, int n_hubs, int n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, float* partial,
+                    int64_t ld_p, hipStream_t st);
+
 static inline int64_t partial_ld(int64_t d) { return (d + 3) / 4 * 4; }
 
 // Gather policy of a launch: 2 when the caller hands over flagged column ids (col_flags), else 0; the measurement hook
@@ -211,6 +217,8 @@ static int spmm_plain_impl(const char* who, const int32_t* rowptr, const int32_t
   if (!small_off && !acc_init && spmm_small_eligible(d, al16))
     return launch_spmm_small(rowptr, col, N, h, ld_h, d, row_scale, bias, relu, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows,
                              hub_chunk_ptr, partial, partial_ld(d), al16, st);
+  if (!acc_init && !col_flags && spmm_sub_eligible(d, al16))
+    return launch_spmm_sub(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, partial_ld(d), st);
   if (al16 && d >= 256)
     return launch_spmm<4>(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st);
   if (al8 && d >= 128)
@@ -224,6 +232,35 @@ extern "C" int cb_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, int32_
                                const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
   return spmm_plain_impl("cb_spmm_csr_f32", rowptr, col, col_flags, N, E, h, ld_h, d, row_scale, bias, relu, nullptr, 0, out, ld_out, hub_T, n_hubs,
                          n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, stream);
+}
+
+// One label-propagation step with its two elementwise passes folded into the store (Label_propagation_model/outcome_correlation.py:137-143,
+// alpha_term = True, post_step = clamp(0, 1); trainer :33-63):
+//     out[v, :] = post_scale[v] * clamp(row_scale[v] * sum_{u in row v} h[u, :] + c_mix * mix[v, :], 0, 1)
+// With h = D^-1/2 result_t, row_scale = alpha D^-1/2, mix = y0, c_mix = 1 - alpha and post_scale = D^-1/2 the output IS the next step's
+// gather operand D^-1/2 result_{t+1}; post_scale = NULL on the last step returns result itself.  Narrow rows (d = number of classes):
+// one lane per column (the VEC = 1 instantiation of k_spmm_rows + hub kernels).
+extern "C" int cb_spmm_csr_lp_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h, int64_t d,
+                                  const float* row_scale, const float* mix, int64_t ld_mix, float c_mix, const float* post_scale, float* out,
+                                  int64_t ld_out, int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
+                                  const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(N >= 0 && E >= 0 && d >= 0, CB_E_INVALID, "cb_spmm_csr_lp_f32: negative size");
+  CB_CHECK_ARG(N < INT32_MAX && E < INT32_MAX && d < (1 << 20), CB_E_RANGE, "cb_spmm_csr_lp_f32: size exceeds the int32 contract");
+  if (N == 0 || d == 0) return CB_OK;
+  CB_CHECK_ARG(rowptr && h && out && mix && (E == 0 || col), CB_E_INVALID, "cb_spmm_csr_lp_f32: null pointer");
+  CB_CHECK_ARG(ld_h >= d && ld_out >= d && ld_mix >= d, CB_E_INVALID, "cb_spmm_csr_lp_f32: leading dimension smaller than d");
+  CB_CHECK_ARG(hub_T > 0 && n_hubs >= 0 && n_chunks >= 0, CB_E_INVALID, "cb_spmm_csr_lp_f32: bad hub plan");
+  CB_CHECK_ARG(n_hubs == 0 || (hub_rows && hub_chunk_ptr && ws && ws_bytes >= cb_spmm_workspace_bytes(n_chunks, d)), CB_E_WORKSPACE,
+               "cb_spmm_csr_lp_f32: hub plan given but workspace missing/too small");
+  if (n_hubs == 0) hub_T = INT32_MAX;
+  Epilogue ep{row_scale, nullptr, 0, nullptr, 0, 0};
+  ep.lp_mix = mix; ep.ld_lp = ld_mix; ep.lp_c_mix = c_mix; ep.lp_post = post_scale;
+  const bool al16 = ((uintptr_t)h % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)mix % 16 == 0) && ld_h % 4 == 0 && ld_out % 4 == 0 &&
+                    ld_mix % 4 == 0;
+  if (spmm_sub_eligible(d, al16))      // d = number of classes padded to a multiple of 4 (ops.label_propagation pads to 16)
+    return launch_spmm_sub(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, (float*)ws, partial_ld(d),
+                           (hipStream_t)stream);
+  return launch_spmm<1>(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, (float*)ws, (hipStream_t)stream);
 }
 
 // out = act(row_scale * (acc_init + sum over this CSR's columns) + bias): the second (halo-column) pass of the node-sharded

@@ -118,7 +118,30 @@ struct Epilogue {
   const unsigned long long* src_bits;   // [n_cols][d / 256][4] mask words of the forward store (word k, bit L <-> column 256 t + 4 L + k)
   const float* src_scale;               // [n_cols]
   float out_coef;
+  // label-propagation step (outcome_correlation.py:137-143 with alpha_term, post_step = clamp(0, 1)), narrow rows (VEC < 4 kernels) only:
+  //   out[v] = lp_post[v] * clamp(row_scale[v] * acc + lp_c_mix * lp_mix[v], 0, 1)        (lp_post = null: 1)
+  // i.e. alpha * D^-1/2 A (.) + (1 - alpha) * y0, clamped, and already scaled by D^-1/2 for the next step's gather
+  const float* lp_mix;      // [N, ld_lp] or null (null: plain epilogue)
+  int64_t ld_lp;
+  float lp_c_mix;
+  const float* lp_post;     // [N] or null
 };
+
+template <int VEC>
+__device__ __forceinline__ void write_row_lp(float* __restrict__ out_row, const float (&acc)[VEC], float scale, const Epilogue& ep, int64_t row,
+                                             int c0, bool (&on)[VEC]) {
+  const float post = ep.lp_post ? ep.lp_post[row] : 1.f;
+  float r[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    if (!on[i]) continue;
+    float t = acc[i] * scale;
+    t = t + ep.lp_c_mix * ep.lp_mix[row * ep.ld_lp + c0 + i];
+    t = fminf(fmaxf(t, 0.f), 1.f);
+    r[i] = t * post;
+    __builtin_nontemporal_store(r[i], out_row + i);
+  }
+}
 
 // Uniform (scalar-cache) reads of the per-source-row mask words and scale: the row id is wave-uniform, the arrays are read-only
 // for the whole launch, so they are addressed through the constant address space (s_load)
@@ -290,9 +313,21 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
         for (int i = 0; i < VEC; ++i) rmix[i] = t[i];
       }
     } else if (active) {
-      float rv[VEC];
-      write_row<VEC>(out_lane + (int64_t)(r0 + cur) * ld_out, acc, s, bvec, relu, rv);
-      if constexpr (TLD > 0) *reinterpret_cast<float4*>(tile_lane + cur * TLD) = make_float4(rv[0], rv[1], rv[2], rv[3]);
+      bool lp_done = false;
+      if constexpr (VEC < 4 && !ACC && !MASK && TLD == 0) {
+        if (ep.lp_mix) {
+          bool on[VEC];
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) on[i] = true;
+          write_row_lp<VEC>(out_lane + (int64_t)(r0 + cur) * ld_out, acc, s, ep, (int64_t)(r0 + cur), c0, on);
+          lp_done = true;
+        }
+      }
+      if (!lp_done) {
+        float rv[VEC];
+        write_row<VEC>(out_lane + (int64_t)(r0 + cur) * ld_out, acc, s, bvec, relu, rv);
+        if constexpr (TLD > 0) *reinterpret_cast<float4*>(tile_lane + cur * TLD) = make_float4(rv[0], rv[1], rv[2], rv[3]);
+      }
     }
     zero<VEC>(acc);
     ++cur;
@@ -546,6 +581,15 @@ __global__ void __launch_bounds__(256) k_spmm_hub_finish(int d, int n_hubs, cons
     float x4[4];
     fused_store(fe, (int64_t)row, c0, a4, s, b4, rmix, x4);
   } else {
+    {
+      if (ep.lp_mix) {      // label-propagation store (narrow rows only ever set it)
+        bool on[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) on[k] = true;
+        write_row_lp<VEC>(out + (int64_t)row * ld_out + c0, acc, s, ep, (int64_t)row, c0, on);
+        return;
+      }
+    }
     float rv[VEC];
     write_row<VEC>(out + (int64_t)row * ld_out + c0, acc, s, bvec, ep.relu, rv);
   }

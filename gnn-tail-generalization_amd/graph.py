@@ -317,6 +317,29 @@ class CSRGraph:
             prof.append((ev0, ev1, self.algorithmic_bytes(d, row_scale=False, bias=False), 0, self.N * 256 * 4 * 2 + 4 * self.N + 32 * self.N))
         return out, g, gr, colsum
 
+    def spmm_lp(self, h, row_scale, mix, c_mix, post_scale=None, out=None):
+        """out = post_scale * clamp(row_scale * (A h) + c_mix * mix, 0, 1): one label-propagation step with both elementwise passes in the
+        aggregation's store (cb_spmm_csr_lp_f32)."""
+        lib = _lib.load()
+        _lib.require_device(h, row_scale, mix, post_scale, out)
+        if h.dtype != torch.float32 or h.dim() != 2 or h.shape[0] != self.n_cols or mix.shape != (self.N, h.shape[1]) or mix.dtype != torch.float32:
+            raise ValueError('spmm_lp: float32 [n_cols, d] rows and a float32 [N, d] mix matrix expected')
+        h = h if h.stride(1) == 1 else h.contiguous()
+        mix = mix if mix.stride(1) == 1 else mix.contiguous()
+        d = h.shape[1]
+        if out is None:
+            out = torch.empty((self.N, d), dtype=torch.float32, device=h.device)
+        plan = self._plan
+        ws_bytes = lib.cb_spmm_workspace_bytes(plan.n_chunks, d)
+        ws = self._workspace(ws_bytes)
+        with torch.cuda.device(h.device):
+            _lib.check(lib.cb_spmm_csr_lp_f32(_lib.ptr(self.rowptr), _lib.ptr(self.col), self.N, self.E, _lib.ptr(h), h.stride(0) if h.shape[0] > 1 else d,
+                                              d, _lib.ptr(row_scale), _lib.ptr(mix), mix.stride(0) if self.N > 1 else d, float(c_mix),
+                                              _lib.ptr(post_scale), _lib.ptr(out), out.stride(0) if self.N > 1 else d, self.hub_threshold, plan.n_hubs,
+                                              plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), ws_bytes,
+                                              _lib.stream_ptr()), 'cb_spmm_csr_lp_f32')
+        return out
+
     def edge_perm(self, transpose=False):
         """CSR position -> column of edge_index (int64 [E]) for the by-dst (transpose=False) or by-src orientation: the stable sort of
         the (row, col) keys, i.e. the order cb_csr_from_coo_i64 lays the edges out in (duplicates of a multigraph keep their input

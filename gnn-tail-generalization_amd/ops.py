@@ -365,12 +365,31 @@ def label_propagation(graph, y0, deg_inv_sqrt, alpha, num_propagations):
     y0 = _c(y0.float())
     dis = _c(deg_inv_sqrt.float())
     a_dis = _c(dis * float(alpha))
-    result = y0.clone()
-    for _ in range(int(num_propagations)):
-        h, _ = act_bwd(result, None, dis, want_out=True, want_colsum=False)          # D^-1/2 result
-        prop = graph.spmm(h, row_scale=a_dis)                                        # alpha * D^-1/2 A (.)
-        result = _axpby_raw(1.0, prop, 1.0 - float(alpha), y0).clamp_(0, 1)
-    return result
+    T = int(num_propagations)
+    if T <= 0:
+        return y0.clone()
+    if not hasattr(graph, 'spmm_lp'):            # (a graph object without the fused step: three passes per step)
+        result = y0.clone()
+        for _ in range(T):
+            h, _ = act_bwd(result, None, dis, want_out=True, want_colsum=False)          # D^-1/2 result
+            prop = graph.spmm(h, row_scale=a_dis)                                        # alpha * D^-1/2 A (.)
+            result = _axpby_raw(1.0, prop, 1.0 - float(alpha), y0).clamp_(0, 1)
+        return result
+    # rows padded to a multiple of 16 floats (64-byte rows: a 47-class row of 188 bytes straddles sectors — 5.16 vs 4.26 ms per
+    # aggregation on the ogbn-products shape, profiles/r03_spmm_narrow_widths.md); the padding columns stay exactly zero
+    c = y0.shape[1]
+    cp = (c + 15) // 16 * 16 if c > 16 else c
+    if cp != c:
+        y0 = torch.nn.functional.pad(y0, (0, cp - c))
+    # the state carried from step to step is h_t = D^-1/2 result_t: the aggregation's store forms clamp(alpha D^-1/2 (A h_t) + (1 - alpha) y0,
+    # 0, 1) and scales it by D^-1/2 for the next gather (cb_spmm_csr_lp_f32); the last step leaves the scale off and returns result_T
+    h, _ = act_bwd(y0, None, dis, want_out=True, want_colsum=False)                      # h_0 = D^-1/2 y0
+    buf = torch.empty_like(h)
+    for t in range(T):
+        last = t == T - 1
+        graph.spmm_lp(h, a_dis, y0, 1.0 - float(alpha), None if last else dis, out=buf)
+        h, buf = buf, h
+    return h[:, :c].contiguous() if cp != c else h
 
 
 def se_topk_replace(le_guess, teacher_se, k, return_selection=False):

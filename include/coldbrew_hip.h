@@ -447,6 +447,14 @@ int cb_spmm_gemm_trunkbwd_f32(const int32_t* rowptr, const int32_t* col, int32_t
                               uint64_t seed, const uint64_t* seed_dev, int64_t row0, const float* rowscale2, float* gr_out, int64_t ld_gr,
                               float* colsum, void* ws2, size_t ws2_bytes, void* stream);
 
+/* One label-propagation step, elementwise passes folded into the aggregation's store (Label_propagation_model/outcome_correlation.py:137-143
+ * with alpha_term and post_step = clamp(0, 1), as trainer_node_classification.py:33-63 drives it):
+ *     out[v, :] = post_scale[v] * clamp(row_scale[v] * sum_{u in row v} h[u, :] + c_mix * mix[v, :], 0, 1)      (post_scale NULL: 1) */
+int cb_spmm_csr_lp_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const float* h, int64_t ld_h, int64_t d,
+                       const float* row_scale, const float* mix, int64_t ld_mix, float c_mix, const float* post_scale, float* out,
+                       int64_t ld_out, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
+                       const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream);
+
 /* The same pack with the rows narrowed to bf16 (round-to-nearest-even) as they are written: the send buffer of the bf16 halo wire. */
 int cb_gather_rows_bf16_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, uint16_t* out, void* stream);
 
