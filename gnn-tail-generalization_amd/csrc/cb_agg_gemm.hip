@@ -25,6 +25,7 @@
 // Hub rows (more edges than the hub threshold) are reduced by the hub kernels, which run BEFORE this kernel here; their finished
 // rows are read back from memory into the tile.
 #include <stdlib.h>
+#include <string.h>
 
 #include "cb_common.h"
 #include "cb_limb_core.h"
@@ -219,6 +220,28 @@ __global__ void __launch_bounds__(256, 2) k_agg_gemm(const int* __restrict__ row
   }
 }
 
+// Hand-over of the LDS tile buffers WITHOUT a block barrier (ASYNC form of k_agg_gemm2): two counters per buffer in LDS.
+//   ready[b]: +1 by every gathering wavefront that has written its rows of the tile in buffer b   (tile complete at NG * (use + 1))
+//   freed[b]: +1 by every multiplying wavefront that has read the tile in buffer b for the last time (buffer reusable at 4 * use)
+// A wavefront's LDS instructions are executed in order, so a counter increment issued after the tile writes (or reads) is seen after them;
+// the asm statements only keep the COMPILER from moving LDS accesses across the hand-over.  No wait on outstanding global loads / stores
+// (a block barrier drains them): a gathering wavefront that has finished its rows moves on to the next tile while its row stores are still
+// in flight and while the other wavefronts finish theirs, so the eight gathering wavefronts of a CU drift apart and cover each other's
+// start-of-tile latencies (rowptr -> column ids -> first gathers), which a barrier lines up.  Spins are bounded: a lost hand-over produces
+// wrong numbers that the parity tests catch, never a hung GPU.
+__device__ __forceinline__ void ag_wait(int* flag, int target) {
+  int spins = 0;
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1 << 22)) break;
+  }
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void ag_signal(int* flag, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // ---- version 2: one persistent 8-wavefront block per CU, wavefront-specialised ------------------------------------------------
 // Two co-resident blocks that each alternate gather / MFMA phases fall into lock step (both gather, then both multiply: measured,
 // profiles/r03_fused_agg_gemm.md), so nothing overlaps.  Here the roles are fixed instead: wavefronts 0-3 only gather (tile t+1
@@ -278,7 +301,7 @@ constexpr int kCLD = 68;     // floats per row of a multiplying wavefront's priv
 // to wavefronts that keep dozens of gathers outstanding, a load of this CU — L2 hit or not — comes back after microseconds.
 template <int PF, bool TB>
 __device__ __forceinline__ void ag2_mfma_tile(int t, const float* __restrict__ tile, float* __restrict__ cs, int w, int lane, int n_rows,
-                                              const GemmTail& gt, float (&colsum)[4], uint64_t seed_eff) {
+                                              const GemmTail& gt, float (&colsum)[4], uint64_t seed_eff, int* freed = nullptr) {
   static_assert(PF == 1 || PF == 3, "ring of 2 or 4 fragment buffers (16 K steps)");
   const int l31 = lane & 31, lh = lane >> 5;
   f32x16 acc[2][2];
@@ -313,8 +336,14 @@ __device__ __forceinline__ void ag2_mfma_tile(int t, const float* __restrict__ t
     bp += kNT * 192;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {      // one 32-row block of A at a time: its limbs live only across its twelve MFMAs
-      const float4 x0 = *reinterpret_cast<const float4*>(a_row[i] + 16 * s);
-      const float4 x1 = *reinterpret_cast<const float4*>(a_row[i] + 16 * s + 4);
+      float4 x0, x1;
+      if (!(gt.dbg & 64)) {
+        x0 = *reinterpret_cast<const float4*>(a_row[i] + 16 * s);
+        x1 = *reinterpret_cast<const float4*>(a_row[i] + 16 * s + 4);
+      } else {      // (dbg bit 6, measurement: no LDS reads of the tile, no limb split in the loop)
+        x0 = make_float4(1.f + lane, 2.f, 3.f, 4.f);
+        x1 = x0;
+      }
       uint32_t hh[4], mm[4], ll[4];
       split3x2(x0.x, x0.y, hh[0], mm[0], ll[0]);
       split3x2(x0.z, x0.w, hh[1], mm[1], ll[1]);
@@ -335,6 +364,7 @@ __device__ __forceinline__ void ag2_mfma_tile(int t, const float* __restrict__ t
 #undef CB_AG_MFMA2
     }
   }
+  if (freed) ag_signal(freed, lane);      // ASYNC form: the tile has been read for the last time
   // epilogue through a WAVE-PRIVATE staging strip (the tile itself is still being read by the other three multiplying wavefronts
   // and there is no barrier among four of eight wavefronts): 8 rows x 64 columns per pass, transposed so that a lane applies
   // `rowscale * acc + addend` on a float4 and the strip leaves as 256-byte row segments
@@ -390,7 +420,7 @@ __device__ __forceinline__ void ag2_mfma_tile(int t, const float* __restrict__ t
     }
 }
 
-template <int U, bool FUSED, int GP, int NG, bool TB = false>
+template <int U, bool FUSED, int GP, int NG, bool TB = false, bool ASYNC = false>
 __global__ void __launch_bounds__(64 * (NG + 4), (NG + 4) / 4) k_agg_gemm2(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                                           const float* __restrict__ h, int64_t ld_h, float* __restrict__ out,
                                                                           int64_t ld_out, int n_rows, Epilogue ep, int hub_T, FusedEpi fe,
@@ -399,20 +429,44 @@ __global__ void __launch_bounds__(64 * (NG + 4), (NG + 4) / 4) k_agg_gemm2(const
   // (deep B look-ahead); NG = 8 -> 3 per SIMD and 168 registers (one K step of look-ahead), but twice the gathers in flight
   __shared__ __attribute__((aligned(16))) float tiles[2][kTM * kTLD];
   __shared__ __attribute__((aligned(16))) float cstrip[4][8 * kCLD];
+  __shared__ int ready[2], freed[2];
   const int lane = lane_id(), wv = threadIdx.x >> 6;
   const bool gathers = wv < NG;
   const int w = gathers ? wv : wv - NG;
   const int n_it = ((int)blockIdx.x < n_tiles) ? (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
   float colsum[4] = {0.f, 0.f, 0.f, 0.f};      // TB: sums of this lane's 4 output columns (64 w + 4 (lane & 15) ..) over the rows it stored
   const uint64_t seed_eff = TB ? (gt.seed_dev ? gt.seed + *gt.seed_dev : gt.seed) : 0ull;
-  for (int it = 0; it <= n_it; ++it) {
-    if (gathers) {
-      if (it < n_it && !(gt.dbg & 16))
-        ag2_gather_tile<U, FUSED, GP, NG>(blockIdx.x + it * gridDim.x, tiles[it & 1], w, lane, rowptr, col, h, ld_h, out, ld_out, n_rows, ep, hub_T, fe);
-    } else if (it >= 1 && !(gt.dbg & 8)) {
-      ag2_mfma_tile<(NG == 4 ? 3 : 1), TB>(blockIdx.x + (it - 1) * gridDim.x, tiles[(it - 1) & 1], cstrip[w], w, lane, n_rows, gt, colsum, seed_eff);
-    }
+  if constexpr (ASYNC) {
+    if (threadIdx.x < 2) ready[threadIdx.x] = freed[threadIdx.x] = 0;
     __syncthreads();
+    if (gathers) {
+      for (int it = 0; it < n_it; ++it) {
+        const int b = it & 1, use = it >> 1;
+        if (use > 0) ag_wait(&freed[b], 4 * use);
+        if (!(gt.dbg & 16))
+          ag2_gather_tile<U, FUSED, GP, NG>(blockIdx.x + it * gridDim.x, tiles[b], w, lane, rowptr, col, h, ld_h, out, ld_out, n_rows, ep, hub_T, fe);
+        ag_signal(&ready[b], lane);
+      }
+    } else {
+      for (int it = 0; it < n_it; ++it) {
+        const int b = it & 1, use = it >> 1;
+        ag_wait(&ready[b], NG * (use + 1));
+        if (!(gt.dbg & 8))
+          ag2_mfma_tile<(NG == 4 ? 3 : 1), TB>(blockIdx.x + it * gridDim.x, tiles[b], cstrip[w], w, lane, n_rows, gt, colsum, seed_eff, &freed[b]);
+        else
+          ag_signal(&freed[b], lane);
+      }
+    }
+  } else {
+    for (int it = 0; it <= n_it; ++it) {
+      if (gathers) {
+        if (it < n_it && !(gt.dbg & 16))
+          ag2_gather_tile<U, FUSED, GP, NG>(blockIdx.x + it * gridDim.x, tiles[it & 1], w, lane, rowptr, col, h, ld_h, out, ld_out, n_rows, ep, hub_T, fe);
+      } else if (it >= 1 && !(gt.dbg & 8)) {
+        ag2_mfma_tile<(NG == 4 ? 3 : 1), TB>(blockIdx.x + (it - 1) * gridDim.x, tiles[(it - 1) & 1], cstrip[w], w, lane, n_rows, gt, colsum, seed_eff);
+      }
+      __syncthreads();
+    }
   }
   if constexpr (TB) {
     // column sums of the block's rows: the four lanes that own the same column quad are added in a fixed order, then one partial row per
@@ -490,10 +544,13 @@ static int launch_agg_gemm(const int32_t* rowptr, const int32_t* col, int64_t N,
     return CB_OK;
   }
   const dim3 grid2((unsigned)ag_n_blocks(n_tiles));      // one persistent block per CU (139 KB of LDS each)
-  // measured on S-pl10M (profiles/r03_fused_agg_gemm.md): 8 gathering wavefronts with 8 gathers each in flight beat 4 x 16 and 8 x 16
-  static const int u16 = getenv("CB_AGG_GEMM_U") ? atoi(getenv("CB_AGG_GEMM_U")) : 8;
+  // measured on S-pl10M (profiles/r03_fused_agg_gemm.md): 8 gathering wavefronts; with the flag hand-over 12 gathers in flight per wavefront
+  // (160 registers, no scratch) = 16 (168 + 20-92 B of scratch) > 8; with the block barrier 8 (16 spills there)
+  static const bool async = !(getenv("CB_AGG_GEMM_SYNC") && !strcmp(getenv("CB_AGG_GEMM_SYNC"), "barrier"));      // measurement hook: the block-barrier hand-over
+  static const int u16 = getenv("CB_AGG_GEMM_U") ? atoi(getenv("CB_AGG_GEMM_U")) : (async ? 12 : 8);
   static const int ng = getenv("CB_AGG_GEMM_NG") ? atoi(getenv("CB_AGG_GEMM_NG")) : 8;
 #define CB_AG2(U_, GP_, NG_) hipLaunchKernelGGL((k_agg_gemm2<U_, FUSED, GP_, NG_>), grid2, dim3(64 * (NG_ + 4)), 0, st, rowptr, col, h, ld_h, out, ld_out, (int)N, ep, hub_T, fe, gt, n_tiles)
+#define CB_AG2A(U_, GP_) hipLaunchKernelGGL((k_agg_gemm2<U_, FUSED, GP_, 8, false, true>), grid2, dim3(64 * 12), 0, st, rowptr, col, h, ld_h, out, ld_out, (int)N, ep, hub_T, fe, gt, n_tiles)
   if constexpr (!FUSED) {
     if (gt.out2) {      // + the trunk backward of the layer below in the dense tail's epilogue
       if (ep.col_flags)
@@ -504,7 +561,11 @@ static int launch_agg_gemm(const int32_t* rowptr, const int32_t* col, int64_t N,
       return CB_OK;
     }
   }
-  if (ng == 8) {
+  if (async && ng == 8) {
+    if (u16 == 16) { if (ep.col_flags) CB_AG2A(16, 2); else CB_AG2A(16, 0); }
+    else if (u16 == 12) { if (ep.col_flags) CB_AG2A(12, 2); else CB_AG2A(12, 0); }
+    else { if (ep.col_flags) CB_AG2A(8, 2); else CB_AG2A(8, 0); }
+  } else if (ng == 8) {
     if (u16 == 16) { if (ep.col_flags) CB_AG2(16, 2, 8); else CB_AG2(16, 0, 8); }
     else { if (ep.col_flags) CB_AG2(8, 2, 8); else CB_AG2(8, 0, 8); }
   } else {
@@ -512,6 +573,7 @@ static int launch_agg_gemm(const int32_t* rowptr, const int32_t* col, int64_t N,
     else { if (ep.col_flags) CB_AG2(16, 2, 4); else CB_AG2(16, 0, 4); }
   }
 #undef CB_AG2
+#undef CB_AG2A
   CB_LAUNCH_CHECK();
   return CB_OK;
 }

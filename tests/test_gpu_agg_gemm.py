@@ -29,7 +29,8 @@ def _powerlaw_graph(n, seed, T, sym=True):
     return CSRGraph(ei, n, hub_threshold=T)
 
 
-@pytest.mark.parametrize('n,T,sym', [(5003, 16, True), (64, 256, True), (20000, 256, True), (9001, 8, False), (1, 256, True)])
+# 70001 rows = 1094 tiles on 256 persistent blocks: every block re-uses both LDS buffers (the freed / ready counters of the flag hand-over)
+@pytest.mark.parametrize('n,T,sym', [(5003, 16, True), (64, 256, True), (20000, 256, True), (9001, 8, False), (1, 256, True), (70001, 64, True)])
 @pytest.mark.parametrize('transpose', [False, True])
 def test_spmm_gemm_equals_aggregation_then_gemm(n, T, sym, transpose):
     """cb_spmm_gemm_f32: out and g_out bit-identical to cb_spmm_csr_f32 followed by cb_gemm_nn_f32 — ragged last tile (N % 64 != 0),
@@ -65,7 +66,7 @@ def test_spmm_gemm_equals_aggregation_then_gemm(n, T, sym, transpose):
     torch.testing.assert_close(g.double(), want, atol=2e-5 * float(want.abs().max()) + 1e-6, rtol=1e-5)
 
 
-@pytest.mark.parametrize('n,T,p', [(5003, 16, 0.1), (20000, 256, 0.0), (777, 8, 0.3)])
+@pytest.mark.parametrize('n,T,p', [(5003, 16, 0.1), (20000, 256, 0.0), (777, 8, 0.3), (70001, 64, 0.2)])
 def test_fused_store_gemm_equals_fused_store_then_gemm(n, T, p):
     """cb_spmm_gemm_fused_f32: mask words, out_next and Z_next bit-identical to cb_spmm_csr_fused_f32 followed by cb_gemm_nn_f32."""
     from gnn_tail_generalization_amd import gemm, trunk
