@@ -553,7 +553,13 @@ static int launch_agg_gemm(const int32_t* rowptr, const int32_t* col, int64_t N,
 #define CB_AG2A(U_, GP_) hipLaunchKernelGGL((k_agg_gemm2<U_, FUSED, GP_, 8, false, true>), grid2, dim3(64 * 12), 0, st, rowptr, col, h, ld_h, out, ld_out, (int)N, ep, hub_T, fe, gt, n_tiles)
   if constexpr (!FUSED) {
     if (gt.out2) {      // + the trunk backward of the layer below in the dense tail's epilogue
-      if (ep.col_flags)
+      static const bool tb_async = !(getenv("CB_AGG_GEMM_SYNC") && !strcmp(getenv("CB_AGG_GEMM_SYNC"), "barrier"));
+      if (tb_async) {
+        if (ep.col_flags)
+          hipLaunchKernelGGL((k_agg_gemm2<12, false, 2, 8, true, true>), grid2, dim3(64 * 12), 0, st, rowptr, col, h, ld_h, out, ld_out, (int)N, ep, hub_T, fe, gt, n_tiles);
+        else
+          hipLaunchKernelGGL((k_agg_gemm2<12, false, 0, 8, true, true>), grid2, dim3(64 * 12), 0, st, rowptr, col, h, ld_h, out, ld_out, (int)N, ep, hub_T, fe, gt, n_tiles);
+      } else if (ep.col_flags)
         hipLaunchKernelGGL((k_agg_gemm2<8, false, 2, 8, true>), grid2, dim3(64 * 12), 0, st, rowptr, col, h, ld_h, out, ld_out, (int)N, ep, hub_T, fe, gt, n_tiles);
       else
         hipLaunchKernelGGL((k_agg_gemm2<8, false, 0, 8, true>), grid2, dim3(64 * 12), 0, st, rowptr, col, h, ld_h, out, ld_out, (int)N, ep, hub_T, fe, gt, n_tiles);

@@ -193,10 +193,12 @@ FUSE_BWD_EPILOGUE = os.environ.get('CB_TRUNK_FUSE_BWD', '0') == '1'
 # reverse launches then move SURVEY 8(d)'s bytes at 0.78 instead of 0.90 of the roofline, so it stays opt-in: CB_TRUNK_MASKED_GATHER=1.
 MASKED_GATHER = os.environ.get('CB_TRUNK_MASKED_GATHER', '0') == '1'
 # Trunk backward of the layer below in the epilogue of the reverse aggregation + dX kernel (cb_spmm_gemm_trunkbwd_f32) instead of a pass of its
-# own.  Measured SLOWER on S-pl10M: 207.8 vs 203.9 ms per step — the 3 x 3.8 ms passes go, but the multiplying wavefronts of the persistent
-# kernel (Philox, mask words, a third 10 GB store; 100 B of scratch at the 168-register cap) stop being hidden under the gathers.  Kept,
-# tested (tests/test_gpu_agg_gemm.py), opt-in: CB_AGG_GEMM_TRUNKBWD=1.
-TAIL_TRUNK_BWD = os.environ.get('CB_AGG_GEMM_TRUNKBWD', '0') == '1'
+# own: the three 3.8 ms k_trunk_bwd passes go, the kernel's multiplying wavefronts take a Philox round per float4, the mask words and a third
+# 10 GB store.  With the block-barrier form of the kernel this measured SLOWER (207.8 vs 203.9 ms per step on S-pl10M: 168 registers + 100 B of
+# scratch); with the flag hand-over (gathering and multiplying wavefronts allocate registers per role, 28 B of scratch) it is 202.2 vs 203.6 ms
+# on the same box, so it is on.  The bias gradients are summed in another order than by the pass (block partials): results agree with the
+# three-kernel form to rounding, not bit for bit (tests/test_gpu_agg_gemm.py).  CB_AGG_GEMM_TRUNKBWD=0 switches it off.
+TAIL_TRUNK_BWD = os.environ.get('CB_AGG_GEMM_TRUNKBWD', '1') == '1'
 MIX_MAX = 7      # mixed-in gradients one cb_trunk_input_bwd_multi_f32 launch gathers (deeper trunks accumulate layer by layer)
 
 
