@@ -199,6 +199,8 @@ MASKED_GATHER = os.environ.get('CB_TRUNK_MASKED_GATHER', '0') == '1'
 # on the same box, so it is on.  The bias gradients are summed in another order than by the pass (block partials): results agree with the
 # three-kernel form to rounding, not bit for bit (tests/test_gpu_agg_gemm.py).  CB_AGG_GEMM_TRUNKBWD=0 switches it off.
 TAIL_TRUNK_BWD = os.environ.get('CB_AGG_GEMM_TRUNKBWD', '1') == '1'
+# The same epilogue on the output Linear's dX GEMM only (K = num_classes: store-bound, not MFMA-bound).  CB_TRUNK_FUSE_OUT_BWD=0: off.
+FUSE_OUT_BWD = os.environ.get('CB_TRUNK_FUSE_OUT_BWD', '1') == '1'
 MIX_MAX = 7      # mixed-in gradients one cb_trunk_input_bwd_multi_f32 launch gathers (deeper trunks accumulate layer by layer)
 
 
@@ -333,7 +335,7 @@ class _TrunkFn(torch.autograd.Function):
 
         ag_bwd = agg_gemm_eligible(graph, h, agg_bf16) and not masked and not fuse
 
-        def dx_gemm(src, wt, rowscale, below, g_ready=None):
+        def dx_gemm(src, wt, rowscale, below, g_ready=None, fuse=fuse):
             """dL/dx of the stage above layer `below` (+ that layer's trunk backward when fused): (g, gr, dbias, handle); handle =
             the already started exchange of gr (row-chunked producers of the node-sharded pipeline), else None."""
             sd = seeds[below + 2] if p > 0 else 0
@@ -369,7 +371,10 @@ class _TrunkFn(torch.autograd.Function):
                                   need[7 + 3 * below + 1], out_bf16=agg_bf16)
             return g_, gr_, db_, None
 
-        g, gr, dbias, handle = dx_gemm(gout, w_out, None, L - 1)       # dL/d(dropped X_L) and the backward of layer L-1's store
+        # dL/d(dropped X_L) and the backward of layer L-1's store.  The output Linear's dX GEMM has K = C (40): it is bound by its 10 GB store, so
+        # the trunk backward leaves its epilogue (no re-read of the matrix just written) where the later, MFMA-bound dX GEMMs keep the pass
+        fuse_out = FUSE_OUT_BWD and gather and not agg_bf16 and not sharded and not masked and not chunked and h % 256 == 0
+        g, gr, dbias, handle = dx_gemm(gout, w_out, None, L - 1, fuse=fuse or fuse_out)
         deferred = None        # (layer, X_l, dZ_l): weight gradient of the layer above, computed under this layer's halo exchange
         for l in range(L - 1, -1, -1):
             w, b, le = lp[l]
