@@ -60,6 +60,7 @@ struct GemmTail {
   float* out2;
   int64_t ld_out2;
   float* colsum_partial;   // [gridDim.x][256] or null
+  int out_masked;          // TB: `out` itself leaves as keep(seed, m, n) * g (dropout backward applied: the form the trunk's input stage consumes)
   int dbg;                 // measurement hook CB_AGG_GEMM_DBG (bit 0: B fragments loaded once, bit 1: A fragments split once, bit 2: no K loop)
 };
 
@@ -394,15 +395,21 @@ __device__ __forceinline__ void ag2_mfma_tile(int t, const float* __restrict__ t
           float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = o[e] * rs + ad[e] + zero_bias;
-          if (!(gt.dbg & 2)) store_stream<4>(gt.out + m * gt.ld_out + n, o);      // (dbg bit 1, measurement: no output store)
+          float gm[4] = {o[0], o[1], o[2], o[3]};
           if constexpr (TB) {      // the arithmetic of k_trunk_bwd<0> (cb_elementwise.hip), element for element
-            float gm[4] = {o[0], o[1], o[2], o[3]};
             if (gt.thresh) {
               float mk[4];
               keep4(seed_eff, ((gt.row0 + m) * kND + n) >> 2, gt.thresh, gt.keep_scale, mk);
 #pragma unroll
               for (int e = 0; e < 4; ++e) gm[e] *= mk[e];
             }
+            if (gt.out_masked) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = gm[e];
+            }
+          }
+          if (!(gt.dbg & 2)) store_stream<4>(gt.out + m * gt.ld_out + n, o);      // (dbg bit 1, measurement: no output store)
+          if constexpr (TB) {
             const unsigned long long* bw = gt.bits + m * 4;      // word e, bit L <-> column 4 L + e
             const int L = n >> 2;
             const float sc2 = gt.rowscale2 ? gt.rowscale2[m] : 1.f;
@@ -658,7 +665,7 @@ extern "C" int cb_spmm_gemm_trunkbwd_f32(const int32_t* rowptr, const int32_t* c
                                          const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, const void* image,
                                          const float* g_rowscale, float* g_out, int64_t ld_gout, const uint64_t* relu_bits, float c_act,
                                          float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, const float* rowscale2,
-                                         float* gr_out, int64_t ld_gr, float* colsum, void* ws2, size_t ws2_bytes, void* stream) {
+                                         float* gr_out, int64_t ld_gr, float* colsum, void* ws2, size_t ws2_bytes, int32_t g_masked, void* stream) {
   const int rc = agg_gemm_common_checks("cb_spmm_gemm_trunkbwd_f32", N, E, d, rowptr, col, h, ld_h, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr,
                                         ws, ws_bytes, image, nullptr, 0, g_out, ld_gout);
   if (rc != CB_OK) return rc;
@@ -675,7 +682,7 @@ extern "C" int cb_spmm_gemm_trunkbwd_f32(const int32_t* rowptr, const int32_t* c
   GemmTail gt{(const uint4*)image, g_rowscale, nullptr, 0, g_out, ld_gout};
   gt.bits = (const unsigned long long*)relu_bits; gt.c_act = c_act; gt.thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
   gt.keep_scale = 1.f / (1.f - drop_p); gt.seed = seed; gt.seed_dev = seed_dev; gt.row0 = row0; gt.rowscale2 = rowscale2;
-  gt.out2 = gr_out; gt.ld_out2 = ld_gr; gt.colsum_partial = colsum ? (float*)ws2 : nullptr; gt.dbg = ag_dbg();
+  gt.out2 = gr_out; gt.ld_out2 = ld_gr; gt.colsum_partial = colsum ? (float*)ws2 : nullptr; gt.out_masked = g_masked; gt.dbg = ag_dbg();
   hipStream_t st = (hipStream_t)stream;
   const int rc2 = launch_agg_gemm<false>(rowptr, col, N, h, ld_h, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, (float*)ws, st,
                                          FusedEpi{}, gt);

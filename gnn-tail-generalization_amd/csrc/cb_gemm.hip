@@ -409,7 +409,7 @@ extern "C" size_t cb_gemm_nn_trunkbwd_workspace_bytes(int64_t M, int64_t N) {
 extern "C" int cb_gemm_nn_trunkbwd_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* G, int64_t ldg, float* GR, int64_t ldgr,
                                        int64_t M, int64_t N, int64_t K, const float* rowscale, const uint64_t* relu_bits, float c_act,
                                        float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, const float* row_scale2,
-                                       float* colsum, void* ws, size_t ws_bytes, void* stream) {
+                                       float* colsum, void* ws, size_t ws_bytes, int32_t g_masked, void* stream) {
   CB_CHECK_ARG(M >= 0 && N > 0 && K >= 0 && N % 256 == 0 && drop_p >= 0.f && drop_p < 1.f && row0 >= 0, CB_E_INVALID,
                "cb_gemm_nn_trunkbwd_f32: bad size (N must be a multiple of 256) or p");
   CB_CHECK_ARG(N < (1 << 20) && K < (1 << 24) && (M + 63) / 64 < (1 << 24), CB_E_RANGE, "cb_gemm_nn_trunkbwd_f32: size out of range");
@@ -424,6 +424,7 @@ extern "C" int cb_gemm_nn_trunkbwd_f32(const float* A, int64_t lda, const float*
     ep.out2 = GR; ep.ld_out2 = ldgr; ep.thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u; ep.keep_scale = 1.f / (1.f - drop_p);
     ep.seed = seed; ep.seed_dev = seed_dev; ep.row0 = row0;
     ep.bits = (const unsigned long long*)relu_bits; ep.c_act = c_act; ep.rowscale2 = row_scale2; ep.colsum_partial = colsum ? (float*)ws : nullptr;
+    ep.g_masked = g_masked;
     const int rc = launch_nn_limb3(A, lda, B, ldb, G, ldg, M, N, K, ep, false, st);
     if (rc != CB_OK) return rc;
     if (colsum) {
@@ -435,9 +436,12 @@ extern "C" int cb_gemm_nn_trunkbwd_f32(const float* A, int64_t lda, const float*
   int rc = cb_gemm_nn_f32(A, lda, B, ldb, G, ldg, M, N, K, rowscale, nullptr, 0, nullptr, 0, nullptr, 0, stream);
   if (rc != CB_OK) return rc;
   CB_CHECK_ARG(ldg == N && ldgr == N, CB_E_INVALID, "cb_gemm_nn_trunkbwd_f32: the two-kernel form needs contiguous outputs");
-  if (!GR && !colsum) return CB_OK;
-  return cb_trunk_layer_bwd_f32(G, relu_bits, row_scale2, GR, 0, nullptr, 0, M, N, drop_p, seed, seed_dev, row0, c_act, 0.f, colsum, ws, ws_bytes,
-                                stream);
+  if (GR || colsum) {
+    rc = cb_trunk_layer_bwd_f32(G, relu_bits, row_scale2, GR, 0, nullptr, 0, M, N, drop_p, seed, seed_dev, row0, c_act, 0.f, colsum, ws, ws_bytes, stream);
+    if (rc != CB_OK) return rc;
+  }
+  if (g_masked && drop_p > 0.f) return cb_dropout_f32(G, G, M * N, drop_p, seed, seed_dev, row0 * N, stream);      // G := its dropout backward, in place
+  return CB_OK;
 }
 
 extern "C" int cb_gemm_nn_bf16out_f32(const float* A, int64_t lda, const float* B, int64_t ldb, uint16_t* C, int64_t ldc, int64_t M,

@@ -45,6 +45,8 @@ struct GemmEpilogue {
   float* colsum_partial;            // [row blocks][N] or null
   int nt_store;                     // fp32 C leaves with the streaming (nt) policy
   DropSpec adrop;                   // ADROP kernels only: dropout of the A operand (thresh = 0: off)
+  int g_masked;                     // EPI == 2 only: C itself leaves as keep(seed, m, n) * o (its dropout backward applied: the only form in which
+                                    // the residual trunk's input stage needs it — no Philox round per mixed-in gradient there)
 };
 
 template <int WM, int WN, int BKT = BK, int WTN = 2>
@@ -265,6 +267,19 @@ __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __rest
           }
         } else {
           float* cp = C + m * ldc + n;
+          float gm[4] = {o[0], o[1], o[2], o[3]};
+          if constexpr (EPI == 2) {   // launch contract: N % 256 == 0, 16-byte aligned out2 rows
+            if (ep.thresh) {
+              float mk[4];
+              keep4(ep.seed_dev ? ep.seed + *ep.seed_dev : ep.seed, ((ep.row0 + m) * N + n) >> 2, ep.thresh, ep.keep_scale, mk);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) gm[q] *= mk[q];
+            }
+            if (ep.g_masked) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o[q] = gm[q];
+            }
+          }
           if (full4 && c_vec_ok) {
             store4(cp, o[0], o[1], o[2], o[3], ep.nt_store);
           } else {
@@ -276,14 +291,7 @@ __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __rest
             keep4(ep.seed_dev ? ep.seed + *ep.seed_dev : ep.seed, ((ep.row0 + m) * N + n) >> 2, ep.thresh, ep.keep_scale, mk);
             store4(ep.out2 + m * ep.ld_out2 + n, o[0] * mk[0], o[1] * mk[1], o[2] * mk[2], o[3] * mk[3], ep.nt_store);
           }
-          if constexpr (EPI == 2) {   // launch contract: N % 256 == 0, 16-byte aligned out2 rows
-            float gm[4] = {o[0], o[1], o[2], o[3]};
-            if (ep.thresh) {
-              float mk[4];
-              keep4(ep.seed_dev ? ep.seed + *ep.seed_dev : ep.seed, ((ep.row0 + m) * N + n) >> 2, ep.thresh, ep.keep_scale, mk);
-#pragma unroll
-              for (int q = 0; q < 4; ++q) gm[q] *= mk[q];
-            }
+          if constexpr (EPI == 2) {
             const unsigned long long* bw = ep.bits + (m * (N >> 8) + (n >> 8)) * 4;   // word q, bit L <-> column 256 * tile + 4 L + q
             const int L = (n & 255) >> 2;
             const float sc2 = ep.rowscale2 ? ep.rowscale2[m] : 1.f;

@@ -131,9 +131,10 @@ def mm_tn_gdrop(a, g, p, g_seed, row0=0):
     return out
 
 
-def mm_nn_trunkbwd(a, b, rowscale, bits, c_act, p, seed, row0, row_scale2, want_colsum, want_gr=True):
+def mm_nn_trunkbwd(a, b, rowscale, bits, c_act, p, seed, row0, row_scale2, want_colsum, want_gr=True, g_masked=False):
     """(G, GR, colsum): G = rowscale * (a @ b) and, from the same epilogue, GR = c_act * dropout_bwd(G) * relu_bits * row_scale2 with
-    the column sums of the unscaled GR (cb_gemm_nn_trunkbwd_f32) — the dX GEMM + the layer-below's trunk backward in one kernel."""
+    the column sums of the unscaled GR (cb_gemm_nn_trunkbwd_f32) — the dX GEMM + the layer-below's trunk backward in one kernel.
+    g_masked: G is returned as dropout_bwd(G) (the form the trunk's input stage consumes; see cb_trunk_input_bwd_multi_f32's `premasked`)."""
     import ctypes
     from . import ops
     lib = _lib.load()
@@ -154,7 +155,7 @@ def mm_nn_trunkbwd(a, b, rowscale, bits, c_act, p, seed, row0, row_scale2, want_
         _lib.check(lib.cb_gemm_nn_trunkbwd_f32(_lib.ptr(a), _ld(a), _lib.ptr(b), _ld(b), _lib.ptr(g), N, _lib.ptr(gr), N, M, N, K,
                                                _lib.ptr(rowscale), _lib.ptr(bits), float(c_act), float(p), ctypes.c_uint64(seed),
                                                ops.seed_dev_ptr(), int(row0), _lib.ptr(row_scale2), _lib.ptr(colsum), _lib.ptr(ws), wsb,
-                                               _lib.stream_ptr()), 'cb_gemm_nn_trunkbwd_f32')
+                                               int(bool(g_masked)), _lib.stream_ptr()), 'cb_gemm_nn_trunkbwd_f32')
     return g, gr, colsum
 
 

@@ -275,7 +275,7 @@ class CSRGraph:
                                                           src_elem=2 if bf16 else 4), 0))
         return out
 
-    def spmm_gemm_trunkbwd(self, h, image, g_rowscale, bits, c_act, p, seed, row0, rowscale2, want_colsum, transpose=True):
+    def spmm_gemm_trunkbwd(self, h, image, g_rowscale, bits, c_act, p, seed, row0, rowscale2, want_colsum, transpose=True, g_masked=False):
         """(out, g, gr, colsum) of cb_spmm_gemm_trunkbwd_f32: out = A h (raw sums), g = g_rowscale * (out @ B) and, from the same epilogue, the
         trunk backward of the layer below: gr = c_act * dropout_bwd(g) * bits * rowscale2, colsum = column sums of the unscaled gr."""
         import ctypes
@@ -310,7 +310,7 @@ class CSRGraph:
                                                      self.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr),
                                                      _lib.ptr(ws), ws_bytes, _lib.ptr(image), _lib.ptr(g_rowscale), _lib.ptr(g), 256, _lib.ptr(bits),
                                                      float(c_act), float(p), ctypes.c_uint64(seed), ops.seed_dev_ptr(), int(row0), _lib.ptr(rowscale2),
-                                                     _lib.ptr(gr), 256, _lib.ptr(colsum), _lib.ptr(ws2), ws2b, _lib.stream_ptr()),
+                                                     _lib.ptr(gr), 256, _lib.ptr(colsum), _lib.ptr(ws2), ws2b, int(bool(g_masked)), _lib.stream_ptr()),
                        'cb_spmm_gemm_trunkbwd_f32')
         if prof is not None:
             ev1.record()

@@ -164,8 +164,9 @@ def _input_bwd(g, add, act, p, seed, row0):
     return out, colsum
 
 
-def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0):
-    """cb_trunk_input_bwd_multi_f32: (dropout_bwd(g) + c_mix * sum_l dropout_bwd_l(g_mix[l])) * (act > 0) and its column sums."""
+def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0, premasked=0):
+    """cb_trunk_input_bwd_multi_f32: (dropout_bwd(g) + c_mix * sum_l dropout_bwd_l(g_mix[l])) * (act > 0) and its column sums.
+    premasked: bit l set = g_mix[l] already is dropout_bwd_l(.) (stored so by the kernel that produced it)."""
     lib = _lib.load()
     rows, d = g.shape
     out = torch.empty_like(g)
@@ -178,7 +179,7 @@ def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0):
     with torch.cuda.device(g.device):
         _lib.check(lib.cb_trunk_input_bwd_multi_f32(_lib.ptr(g), ctypes.c_uint64(seed), n, ptrs, seeds, float(c_mix), _lib.ptr(act), _lib.ptr(out),
                                                     rows, d, float(p), ops.seed_dev_ptr(), int(row0), _lib.ptr(colsum), _lib.ptr(ws), wsb,
-                                                    _lib.stream_ptr()), 'cb_trunk_input_bwd_multi_f32')
+                                                    int(premasked), _lib.stream_ptr()), 'cb_trunk_input_bwd_multi_f32')
     return out, colsum
 
 
@@ -192,15 +193,25 @@ FUSE_BWD_EPILOGUE = os.environ.get('CB_TRUNK_FUSE_BWD', '0') == '1'
 # passes go, the masked launches cost +1.7 ms each for their 36 bytes of mask words / scale per edge, the epilogue ~1 ms) — but the
 # reverse launches then move SURVEY 8(d)'s bytes at 0.78 instead of 0.90 of the roofline, so it stays opt-in: CB_TRUNK_MASKED_GATHER=1.
 MASKED_GATHER = os.environ.get('CB_TRUNK_MASKED_GATHER', '0') == '1'
-# Trunk backward of the layer below in the epilogue of the reverse aggregation + dX kernel (cb_spmm_gemm_trunkbwd_f32) instead of a pass of its
-# own: the three 3.8 ms k_trunk_bwd passes go, the kernel's multiplying wavefronts take a Philox round per float4, the mask words and a third
-# 10 GB store.  With the block-barrier form of the kernel this measured SLOWER (207.8 vs 203.9 ms per step on S-pl10M: 168 registers + 100 B of
-# scratch); with the flag hand-over (gathering and multiplying wavefronts allocate registers per role, 28 B of scratch) it is 202.2 vs 203.6 ms
-# on the same box, so it is on.  The bias gradients are summed in another order than by the pass (block partials): results agree with the
-# three-kernel form to rounding, not bit for bit (tests/test_gpu_agg_gemm.py).  CB_AGG_GEMM_TRUNKBWD=0 switches it off.
-TAIL_TRUNK_BWD = os.environ.get('CB_AGG_GEMM_TRUNKBWD', '1') == '1'
-# The same epilogue on the output Linear's dX GEMM only (K = num_classes: store-bound, not MFMA-bound).  CB_TRUNK_FUSE_OUT_BWD=0: off.
-FUSE_OUT_BWD = os.environ.get('CB_TRUNK_FUSE_OUT_BWD', '1') == '1'
+# Three ways of sparing the trunk backward its own [N, d] passes.  All are built, tested bit for bit / to summation order
+# (tests/test_gpu_agg_gemm.py, tests/test_gpu_kernels.py) and OFF by default: alternating runs on one box (tools/probes/ab.sh, 3 rounds of 6 steps,
+# S-pl10M; box-to-box spread of the step time is ~1.5 %) give
+#     all off                                    202.2 / 201.8 / 202.1 ms      (= CB_AGG_GEMM_TRUNKBWD=0 CB_TRUNK_FUSE_OUT_BWD=0: 198.3 / 201.7 / 202.0)
+#     CB_AGG_GEMM_TRUNKBWD=1                     = the first line above (it was on in those runs)
+#     + CB_TRUNK_FUSE_OUT_BWD=1                  202.0 / 202.7 / 202.4
+#     + CB_TRUNK_PREMASKED=1                     203.1 / 203.2 / 202.3
+# i.e. nothing outside the noise: the passes that go (3 x 3.9 ms of k_trunk_bwd, 10 GB re-reads) come back as longer epilogues of kernels whose
+# multiplying wavefronts are not hidden (profiles/r03_fused_agg_gemm.md), and the input stage is bound by its six 10 GB streams (5.3 TB/s), not by
+# the Philox rounds CB_TRUNK_PREMASKED removes (11.66 -> 11.41 ms).
+#  * CB_AGG_GEMM_TRUNKBWD=1: trunk backward of the layer below in the epilogue of the reverse aggregation + dX kernel (cb_spmm_gemm_trunkbwd_f32).
+#    With the block-barrier form of that kernel it measured slower (207.8 vs 203.9 ms); with the flag hand-over (registers allocated per role) it
+#    is neutral.  Bias gradients are summed in another order than by the pass (block partials): equal to rounding, not bit for bit.
+#  * CB_TRUNK_FUSE_OUT_BWD=1: the same epilogue on the output Linear's dX GEMM (K = num_classes: store-bound) — cb_gemm_nn_trunkbwd_f32.
+#  * CB_TRUNK_PREMASKED=1: those kernels store dL/d(dropped X_{l+1}) as its dropout backward keep * g / (1 - p), the only form it is consumed
+#    in, so the input stage draws one mask per row quad instead of one per layer.  Same products in the same order: bit-identical.
+TAIL_TRUNK_BWD = os.environ.get('CB_AGG_GEMM_TRUNKBWD', '0') == '1'
+FUSE_OUT_BWD = os.environ.get('CB_TRUNK_FUSE_OUT_BWD', '0') == '1'
+PREMASKED = os.environ.get('CB_TRUNK_PREMASKED', '0') == '1'
 MIX_MAX = 7      # mixed-in gradients one cb_trunk_input_bwd_multi_f32 launch gathers (deeper trunks accumulate layer by layer)
 
 
@@ -364,8 +375,9 @@ class _TrunkFn(torch.autograd.Function):
                 else:
                     g_, db_ = gemm.mm_nn(src, wt, rowscale=rowscale), None
                 return g_, None, db_, None
-            if fuse:
-                return gemm.mm_nn_trunkbwd(src, wt, rowscale, saved_bits[below], 1 - alpha, p, sd, row0, bnorm, need[7 + 3 * below + 1]) + (None,)
+            if fuse:      # (gather mode: g is consumed by the input stage only, as its dropout backward — stored in that form, PREMASKED)
+                return gemm.mm_nn_trunkbwd(src, wt, rowscale, saved_bits[below], 1 - alpha, p, sd, row0, bnorm, need[7 + 3 * below + 1],
+                                           g_masked=PREMASKED) + (None,)
             g_ = g_ready if g_ready is not None else gemm.mm_nn(src, wt, rowscale=rowscale)     # g_ready: left the reverse aggregation's kernel
             gr_, db_ = _layer_bwd(g_, saved_bits[below], bnorm, gx0, below != L - 1, p, sd, row0, 1 - alpha, alpha,
                                   need[7 + 3 * below + 1], out_bf16=agg_bf16)
@@ -375,10 +387,13 @@ class _TrunkFn(torch.autograd.Function):
         # the trunk backward leaves its epilogue (no re-read of the matrix just written) where the later, MFMA-bound dX GEMMs keep the pass
         fuse_out = FUSE_OUT_BWD and gather and not agg_bf16 and not sharded and not masked and not chunked and h % 256 == 0
         g, gr, dbias, handle = dx_gemm(gout, w_out, None, L - 1, fuse=fuse or fuse_out)
+        g_pm = PREMASKED and (fuse or fuse_out)      # g already is dropout_bwd(g): no mask drawn for it by the input stage
+        premasked = 0
         deferred = None        # (layer, X_l, dZ_l): weight gradient of the layer above, computed under this layer's halo exchange
         for l in range(L - 1, -1, -1):
             w, b, le = lp[l]
             if gather:
+                premasked |= int(bool(g_pm)) << len(g_mix)
                 g_mix.append(g)
                 seeds_mix.append(seeds[l + 2] if p > 0 else 0)
             if sharded and handle is None:
@@ -394,9 +409,10 @@ class _TrunkFn(torch.autograd.Function):
                 # l-1's store leaves the same epilogue (cb_spmm_gemm_trunkbwd_f32: no pass of its own over dL/dx_l)
                 from .graph import weight_image
                 tb_fused = None
-                if l > 0 and TAIL_TRUNK_BWD:
+                if l > 0 and TAIL_TRUNK_BWD and gather:      # (the accumulate-in-place form needs the pass: it also adds into gx0)
                     gz, g_fused, gr_n, db_n = graph.spmm_gemm_trunkbwd(gr, weight_image(w, transpose=True), a, saved_bits[l - 1], 1 - alpha, p,
-                                                                         seeds[l + 1] if p > 0 else 0, row0, bnorm, need[7 + 3 * (l - 1) + 1])
+                                                                         seeds[l + 1] if p > 0 else 0, row0, bnorm, need[7 + 3 * (l - 1) + 1],
+                                                                         g_masked=PREMASKED and gather)
                     tb_fused = (gr_n, db_n)
                 else:
                     gz, g_fused = graph.spmm_gemm(gr, weight_image(w, transpose=True), transpose=True, g_rowscale=a)
@@ -412,8 +428,10 @@ class _TrunkFn(torch.autograd.Function):
             grads_layers[3 * l + 1] = dbias
             if l > 0 and ag_bwd and tb_fused is not None:
                 g, (gr, dbias), handle = g_fused, tb_fused, None
+                g_pm = PREMASKED and gather
             elif l > 0:
                 g, gr, dbias, handle = dx_gemm(gz, w.t().contiguous(), a, l - 1, g_fused)   # dL/d(dropped X_l) and the backward of layer l-1's store
+                g_pm = PREMASKED and fuse
             else:
                 g = g_fused if g_fused is not None else gemm.mm_nn(gz, w.t().contiguous(), rowscale=a)   # dL/d(dropped X_0): consumed by the input stage
             if le is not None and need[7 + 3 * l + 2]:
@@ -425,7 +443,7 @@ class _TrunkFn(torch.autograd.Function):
             deferred = None
         # input stage: X0 feeds layer 0 (through its dropout) and every mix
         if gather:
-            gpre, d_b_in = _input_bwd_multi(g, seeds[1] if p > 0 else 0, g_mix, seeds_mix, alpha, x0, p, row0)
+            gpre, d_b_in = _input_bwd_multi(g, seeds[1] if p > 0 else 0, g_mix, seeds_mix, alpha, x0, p, row0, premasked)
         else:
             gpre, d_b_in = _input_bwd(g, gx0, x0, p, seeds[1] if p > 0 else 0, row0)
         del g, gx0, g_mix

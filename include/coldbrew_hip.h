@@ -196,12 +196,14 @@ int cb_gemm_nn_drop2_f32(const float* A, int64_t lda, const float* B, int64_t ld
  * backward to the rows it gathers, cb_spmm_csr_masked_f32; pass drop_p = 0 and c_act / (1 - p): the mask words carry the keep bits).
  * Autograd of th.matmul GCN.py:225 / nn.Linear :138 followed by autograd of F.dropout :110,133, InitialConnection
  * res_tricks.py:23 and F.relu :128.  N % 256 == 0.  ws: cb_gemm_nn_trunkbwd_workspace_bytes(M, N) (column-sum partials).
- * Falls back to cb_gemm_nn_f32 + cb_trunk_layer_bwd_f32 when the fused epilogue does not cover the shape. */
+ * Falls back to cb_gemm_nn_f32 + cb_trunk_layer_bwd_f32 when the fused epilogue does not cover the shape.
+ * g_masked != 0: G itself is stored as its dropout backward keep(seed, m, n) * G / (1 - p) — the only form the residual trunk consumes it in
+ * (cb_trunk_input_bwd_multi_f32 with the matching `premasked` bit draws no mask for it). */
 size_t cb_gemm_nn_trunkbwd_workspace_bytes(int64_t M, int64_t N);
 int cb_gemm_nn_trunkbwd_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* G, int64_t ldg, float* GR, int64_t ldgr,
                             int64_t M, int64_t N, int64_t K, const float* rowscale, const uint64_t* relu_bits, float c_act, float drop_p,
                             uint64_t seed, const uint64_t* seed_dev, int64_t row0, const float* row_scale2, float* colsum, void* ws,
-                            size_t ws_bytes, void* stream);
+                            size_t ws_bytes, int32_t g_masked, void* stream);
 
 /* C[K1,K2] = sum_m A[m,K1] * rowscale[m] * G[m,K2] — the weight gradients (autograd of GCN.py:225 and
  * of nn.Linear): a reduction over the node axis, split into row slabs whose partial products are summed
@@ -246,10 +248,13 @@ int cb_trunk_input_bwd_f32(const float* g, const float* add, const float* act, f
 /* The same input stage with the X0 gradient gathered in one pass (no [rows, d] accumulator is read-modify-written per layer):
  *     out = ( dropout_bwd_seed(g) + c_mix * sum_{l < n_mix} dropout_bwd_seeds_mix[l](g_mix[l]) ) * (act > 0)
  * g_mix[l] = gradient w.r.t. the output of layer l's fused store (host array of n_mix <= 7 device pointers); used with
- * cb_trunk_layer_bwd_f32(gx0 = NULL).  Autograd of GCN.py:104-110 + res_tricks.py:23 for every layer at once. */
+ * cb_trunk_layer_bwd_f32(gx0 = NULL).  Autograd of GCN.py:104-110 + res_tricks.py:23 for every layer at once.
+ * premasked: bit l set = g_mix[l] already IS dropout_bwd_seeds_mix[l](.) (written so by cb_spmm_gemm_trunkbwd_f32 / cb_gemm_nn_trunkbwd_f32 with
+ * g_masked): no mask is drawn for it. */
 int cb_trunk_input_bwd_multi_f32(const float* g, uint64_t seed, int32_t n_mix, const float* const* g_mix, const uint64_t* seeds_mix,
                                  float c_mix, const float* act, float* out, int64_t rows, int64_t d, float drop_p,
-                                 const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes, void* stream);
+                                 const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes, uint32_t premasked,
+                                 void* stream);
 
 /* ------------------------------------------------------------------------------------
  * bf16-storage variant of the aggregation (build extension = BASELINE config 2; the reference is fp32-only):
@@ -438,14 +443,15 @@ int cb_gemm_tn_gdrop_f32(const float* A, int64_t lda, const float* G, int64_t ld
  * dL/dx of the stage above layer l-1; gr_out = c_act * dropout_bwd_{seed}(g_out) * relu_bits * rowscale2 (input of the next reverse
  * aggregation) and colsum = the column sums of the same without rowscale2 (bias gradient of layer l-1) — what cb_trunk_layer_bwd_f32
  * computes in a pass of its own (autograd of GCN.py:127-133,250-253), without its 10 GB read of g_out.  relu_bits: the mask words
- * cb_spmm_csr_fused_f32 wrote for layer l-1 ([N][4], d = 256).  ws2: cb_spmm_gemm_trunkbwd_workspace_bytes() (partial column sums). */
+ * cb_spmm_csr_fused_f32 wrote for layer l-1 ([N][4], d = 256).  ws2: cb_spmm_gemm_trunkbwd_workspace_bytes() (partial column sums).
+ * g_masked != 0: g_out is stored as keep(seed, m, n) * g_out / (1 - p), see cb_gemm_nn_trunkbwd_f32. */
 size_t cb_spmm_gemm_trunkbwd_workspace_bytes(void);
 int cb_spmm_gemm_trunkbwd_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h,
                               int64_t d, float* out, int64_t ld_out, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
                               const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, const void* image,
                               const float* g_rowscale, float* g_out, int64_t ld_gout, const uint64_t* relu_bits, float c_act, float drop_p,
                               uint64_t seed, const uint64_t* seed_dev, int64_t row0, const float* rowscale2, float* gr_out, int64_t ld_gr,
-                              float* colsum, void* ws2, size_t ws2_bytes, void* stream);
+                              float* colsum, void* ws2, size_t ws2_bytes, int32_t g_masked, void* stream);
 
 /* One label-propagation step, elementwise passes folded into the aggregation's store (Label_propagation_model/outcome_correlation.py:137-143
  * with alpha_term and post_step = clamp(0, 1), as trainer_node_classification.py:33-63 drives it):

@@ -111,6 +111,11 @@ def test_reverse_aggregation_gemm_trunk_backward_equals_three_kernels(n, T, p):
     torch.testing.assert_close(cs, ref_cs, atol=1e-4 * float(ref_cs.abs().max()) + 1e-5, rtol=1e-5)
     _, _, _, none = G.spmm_gemm_trunkbwd(gr_in, weight_image(w, transpose=True), a, bits, 0.9, p, 777, 0, b, False)
     assert none is None
+    # g_masked: dL/dx leaves as its dropout backward (the form the trunk's input stage consumes), everything else unchanged
+    from gnn_tail_generalization_amd import ops
+    out_m, g_m, gr_m, cs_m = G.spmm_gemm_trunkbwd(gr_in, weight_image(w, transpose=True), a, bits, 0.9, p, 777, 0, b, True, g_masked=True)
+    assert torch.equal(out_m, ref_out) and torch.equal(gr_m, ref_gr) and torch.equal(cs_m, cs)
+    assert torch.equal(g_m, ops._dropout_raw(ref_g, p, 777, 0) if p > 0 else ref_g)
 
 
 def _step_losses(monkeypatch, flag, steps=3, n=30000):
@@ -158,6 +163,13 @@ def test_training_step_with_fused_kernels_equals_two_kernel_form(monkeypatch):
     np.testing.assert_allclose(l2, l0, rtol=1e-6)
     for k in sd0:
         torch.testing.assert_close(sd2[k], sd0[k], atol=1e-5, rtol=1e-4, msg=lambda m, k=k: f'{k}: {m}')
+    # + the output Linear's dX GEMM with the same epilogue, gradients stored as their dropout backward (CB_TRUNK_FUSE_OUT_BWD, CB_TRUNK_PREMASKED)
+    monkeypatch.setattr(trunk, 'FUSE_OUT_BWD', True)
+    monkeypatch.setattr(trunk, 'PREMASKED', True)
+    l3, sd3 = _step_losses(monkeypatch, '1')
+    np.testing.assert_allclose(l3, l0, rtol=1e-6)
+    for k in sd0:
+        torch.testing.assert_close(sd3[k], sd0[k], atol=1e-5, rtol=1e-4, msg=lambda m, k=k: f'{k}: {m}')
 
 
 def test_fused_kernels_against_the_oracle(monkeypatch):

@@ -423,6 +423,16 @@ def test_gemm_trunk_backward_epilogue_matches_two_kernels(M, K, p):
     # no column sums requested
     g2, gr2, none = gemm.mm_nn_trunkbwd(a, b, rs, bits, c_act, p, seed, row0, rs2, False)
     assert none is None and torch.equal(gr2, gr)
+    # g_masked: G leaves as its dropout backward (cb_dropout_f32 of the plain G, bit for bit), GR / column sums unchanged; the input stage
+    # takes it with its `premasked` bit and reproduces the pass that draws the mask itself
+    from gnn_tail_generalization_amd import ops
+    g3, gr3, cs3 = gemm.mm_nn_trunkbwd(a, b, rs, bits, c_act, p, seed, row0, rs2, True, g_masked=True)
+    assert torch.equal(g3, ops._dropout_raw(g_ref, p, seed, row0 * N) if p > 0 else g_ref)
+    assert torch.equal(gr3, gr) and torch.equal(cs3, cs)
+    top = torch.randn(M, N, device=DEV)
+    o_a, c_a = trunk._input_bwd_multi(top, seed + 5, [g_ref, act], [seed, seed + 9], 0.1, act, p, row0)
+    o_b, c_b = trunk._input_bwd_multi(top, seed + 5, [g3, act], [seed, seed + 9], 0.1, act, p, row0, premasked=1)
+    assert torch.equal(o_a, o_b) and torch.equal(c_a, c_b)
 
 
 @pytest.mark.parametrize('M,K,N,row0', [(40000, 128, 256, 0), (33001, 100, 256, 77)])

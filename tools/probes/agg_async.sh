@@ -1,9 +1,9 @@
 R=$GRAFT_REPO_ROOT
 cd $R
-timeout 900 python -m pytest tests/test_gpu_agg_gemm.py tests/test_gpu_model.py -x -q 2>&1 | grep -E "passed|failed|Error" | tail -3
-for e in "CB_TRUNK_FUSE_OUT_BWD=0" "CB_TRUNK_FUSE_OUT_BWD=1"; do
-  echo "--- $e"
-  env $e timeout 600 python bench.py --steps 5 --warmup 2 --cpu-baseline 0 --ref-epochs 0 --pmc-traffic 0 2>/dev/null | python -c "
-import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['roofline']['frac'], d.get('final_loss'))"
+export TMPDIR=/tmp
+for v in 0 1; do
+  ( cd /tmp && CB_TRUNK_PREMASKED=$v rocprofv3 --kernel-trace --stats -d /tmp/prof_pm$v -o pm$v -- python $R/bench.py --steps 3 --warmup 1 --cpu-baseline 0 --ref-epochs 0 --pmc-traffic 0 > /dev/null 2>&1 )
+  DB=$(find /tmp/prof_pm$v -name "*.db" | head -1)
+  python tools/prof_summary.py $DB /tmp/pm$v.md "premasked=$v" > /dev/null 2>&1
+  echo "=== premasked=$v"; grep -E "k_agg_gemm2|input_bwd_multi|k_gemm_nn_l3<2, 2, false, 4, 1, 2|trunk_bwd" /tmp/pm$v.md | cut -c1-140
 done
