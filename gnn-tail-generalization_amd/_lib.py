@@ -100,6 +100,8 @@ SIGNATURES = {
     'cb_gemm_tn_gdrop_supported': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I64]),
     'cb_gemm_tn_gdrop_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _SZ, _P]),
     'cb_spmm_gemm_trunkbwd_workspace_bytes': (_SZ, []),
+    'cb_agg_gemm_set_cu_limit': (ctypes.c_int, [_I32]),
+    'cb_stream_create_cu_mask': (ctypes.c_int, [_P, _I32, _P]),
     'cb_spmm_gemm_trunkbwd_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _SZ, _P, _P, _P,
                                                  _I64, _P, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _P, _I64, _P, _P, _SZ, _I32, _P]),
     'cb_spmm_csr_lp_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, _I64, ctypes.c_float, _P, _P, _I64, _I32, _I32, _I32, _P, _P,

@@ -507,7 +507,10 @@ __global__ void __launch_bounds__(256) k_agg_colsum_finish(const float* __restri
 static inline int64_t ag_partial_ld(int64_t d) { return (d + 3) / 4 * 4; }
 
 // blocks of the persistent kernel: one per CU
+static int g_cu_limit = 0;      // cb_agg_gemm_set_cu_limit: CUs the launching stream may use (0 = all)
+
 static int ag_n_blocks(int n_tiles) {
+  if (g_cu_limit > 0) return n_tiles < g_cu_limit ? n_tiles : g_cu_limit;
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
@@ -600,6 +603,24 @@ static int ag_dbg() {
 }  // namespace cb
 
 using namespace cb;
+
+// The persistent kernels launch one block per CU.  On a stream confined to a CU subset (hipExtStreamCreateWithCUMask: the backward runs its
+// weight-gradient GEMMs beside the aggregation chain on disjoint CU sets) more blocks than CUs would queue behind whole blocks: the host tells
+// how many CUs the stream has.  0 restores "all CUs of the device".  Not thread-safe (one training loop per process, as in the reference).
+extern "C" int cb_agg_gemm_set_cu_limit(int32_t n_cus) {
+  CB_CHECK_ARG(n_cus >= 0 && n_cus <= 1024, CB_E_INVALID, "cb_agg_gemm_set_cu_limit: 0 .. 1024");
+  g_cu_limit = n_cus;
+  return CB_OK;
+}
+
+// A stream whose kernels run on the CUs whose bit is set in mask[0 .. words) only (bit i of word j = CU 32 j + i).
+extern "C" int cb_stream_create_cu_mask(const uint32_t* mask, int32_t words, void** stream) {
+  CB_CHECK_ARG(mask && stream && words > 0 && words <= 32, CB_E_INVALID, "cb_stream_create_cu_mask: bad argument");
+  hipStream_t st = nullptr;
+  CB_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask));
+  *stream = (void*)st;
+  return CB_OK;
+}
 
 extern "C" size_t cb_agg_gemm_image_bytes(int64_t K, int64_t N) {
   if (K != kKD || N != kND) return 0;

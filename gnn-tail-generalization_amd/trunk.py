@@ -16,7 +16,7 @@ import ctypes
 
 import torch
 
-from . import _lib, gemm, ops
+from . import _lib, gemm, ops, streams
 
 
 def eligible(tc, x, want_les):
@@ -239,6 +239,55 @@ def _chunked(graph, agg_bf16):
             and os.environ.get('COLDBREW_CHUNKED_PRODUCERS', '1') != '0')
 
 
+OVERLAP_MIN_ROWS = int(os.environ.get('CB_BWD_OVERLAP_MIN_ROWS', 1 << 20))      # smaller graphs: a handful of events costs what the overlap buys
+
+
+class _Overlap:
+    """The backward on two CU-partitioned streams (streams.py).  Everything the chain enqueues goes to `main` (the caller's stream waits
+    for both at the end); side(fn, ...) enqueues a weight-gradient GEMM on `sidestream` after what the chain has produced so far."""
+
+    def __init__(self, device):
+        self.main, self.sidestream, self.main_cus = streams.partition(device)
+        self.device = device
+        self.caller = torch.cuda.current_stream(device)
+        self._ctx = None
+
+    def __enter__(self):
+        ev = torch.cuda.Event()
+        ev.record(self.caller)
+        self.main.wait_event(ev)
+        self.sidestream.wait_event(ev)
+        _lib.check(_lib.load().cb_agg_gemm_set_cu_limit(self.main_cus), 'cb_agg_gemm_set_cu_limit')      # persistent kernels: one block per CU of `main`
+        self._ctx = torch.cuda.stream(self.main)
+        self._ctx.__enter__()
+        return self
+
+    def side(self, fn, *produced):
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.sidestream.wait_event(ev)
+        for t in produced:
+            t.record_stream(self.sidestream)      # (the caching allocator must not hand the block to the chain while the GEMM reads it)
+        with torch.cuda.stream(self.sidestream):
+            return fn()
+
+    def finish(self, grads):
+        """Called inside the `with`: the caller's stream continues after both streams; the gradients are used there."""
+        for ev_stream in (self.main, self.sidestream):
+            ev = torch.cuda.Event()
+            ev.record(ev_stream)
+            self.caller.wait_event(ev)
+        for t in grads:
+            if isinstance(t, torch.Tensor):
+                t.record_stream(self.caller)
+        return grads
+
+    def __exit__(self, *exc):
+        self._ctx.__exit__(*exc)
+        _lib.check(_lib.load().cb_agg_gemm_set_cu_limit(0), 'cb_agg_gemm_set_cu_limit')
+        return False
+
+
 class _TrunkFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph, cfg, x, w_in, b_in, w_out, b_out, *layer_params):
@@ -304,6 +353,22 @@ class _TrunkFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
+        """Runs the backward either on the caller's stream, or — one GPU, aggregation + GEMM kernels on, a graph large enough for a few
+        events not to matter, no hipGraph capture — with the chain on a stream confined to three quarters of the CUs and the weight-gradient
+        GEMMs beside it on the rest (streams.py)."""
+        graph, (L, alpha, p, seeds, agg_bf16) = ctx.graph, ctx.cfg
+        x0 = ctx.saved_tensors[1]
+        ov = None
+        if (streams.enabled() and not hasattr(graph, 'part') and ops._graph_seed is None and not torch.cuda.is_current_stream_capturing()
+                and agg_gemm_eligible(graph, x0.shape[1], agg_bf16) and x0.shape[0] >= OVERLAP_MIN_ROWS):
+            ov = _Overlap(x0.device)
+        if ov is None:
+            return _TrunkFn._backward_impl(ctx, gout, None)
+        with ov:
+            return ov.finish(_TrunkFn._backward_impl(ctx, gout, ov))
+
+    @staticmethod
+    def _backward_impl(ctx, gout, ov):
         graph, (L, alpha, p, seeds, agg_bf16), row0 = ctx.graph, ctx.cfg, ctx.row0
         sv = list(ctx.saved_tensors)
         xd, x0, w_in, w_out = sv[:4]
@@ -325,7 +390,12 @@ class _TrunkFn(torch.autograd.Function):
         h = x0.shape[1]
         # output Linear (GCN.py:138)
         xl = saved_in[L]
-        d_w_out = gemm.mm_tn(gout, xl) if need[5] else None
+        def side(fn, *produced):
+            """A weight-gradient GEMM: beside the chain when the backward runs on CU-partitioned streams (`produced`: operands written by
+            the chain so far)."""
+            return ov.side(fn, *produced) if ov is not None else fn()
+
+        d_w_out = side(lambda: gemm.mm_tn(gout, xl)) if need[5] else None
         d_b_out = ops.act_bwd(gout, None, None, want_out=False, want_colsum=True)[1] if need[6] else None
         # the gradient reaching X0 through the L mixes: gathered in one pass by the input stage (the per-layer gradients stay
         # alive until then) when L <= MIX_MAX, else accumulated in place layer by layer
@@ -424,7 +494,7 @@ class _TrunkFn(torch.autograd.Function):
                 if sharded:
                     deferred = (l, saved_in[l], gz)
                 else:
-                    grads_layers[3 * l] = gemm.mm_tn(saved_in[l], gz, rowscale=a)
+                    grads_layers[3 * l] = side(lambda gz=gz, l=l: gemm.mm_tn(saved_in[l], gz, rowscale=a), gz)
             grads_layers[3 * l + 1] = dbias
             if l > 0 and ag_bwd and tb_fused is not None:
                 g, (gr, dbias), handle = g_fused, tb_fused, None

@@ -391,6 +391,14 @@ int cb_symmetrize_i64(const int64_t* src, const int64_t* dst, int64_t E, int64_t
  * all-to-all of the node-sharded halo exchange (new; the reference is single-device). */
 int cb_gather_rows_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, float* out, void* stream);
 
+/* The aggregation + GEMM kernels are persistent (one block per CU).  A caller that launches them on a stream confined to a CU subset
+ * (hipExtStreamCreateWithCUMask) states the number of CUs of that stream here; 0 = all CUs of the device (default).  New relative to the
+ * reference (scheduling of GNN_model/GCN.py:238 + :225 on this device). */
+int cb_agg_gemm_set_cu_limit(int32_t n_cus);
+/* A HIP stream confined to the CUs whose bit is set in mask[0 .. words) (bit i of word j = CU 32 j + i): hipExtStreamCreateWithCUMask.  The
+ * trunk backward runs the weight-gradient GEMMs (MFMA-bound) on one such stream beside the aggregation chain (HBM-bound) on the complement. */
+int cb_stream_create_cu_mask(const uint32_t* mask, int32_t words, void** stream);
+
 /* ------------------------------------------------------------------------------------
  * Aggregation + the NEXT dense transform in one kernel (csrc/cb_agg_gemm.hip): a block aggregates 64 rows exactly as
  * cb_spmm_csr_f32 / cb_spmm_csr_fused_f32 do (same stores: the aggregated matrix still goes to memory), keeps them in LDS and

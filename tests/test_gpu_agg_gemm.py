@@ -163,6 +163,18 @@ def test_training_step_with_fused_kernels_equals_two_kernel_form(monkeypatch):
     np.testing.assert_allclose(l2, l0, rtol=1e-6)
     for k in sd0:
         torch.testing.assert_close(sd2[k], sd0[k], atol=1e-5, rtol=1e-4, msg=lambda m, k=k: f'{k}: {m}')
+    # the backward on CU-partitioned streams (chain on 3/4 of the CUs, weight-gradient GEMMs beside it on the rest; streams.py) — forced on for
+    # this small graph: the same kernels on the same data, bit for bit
+    monkeypatch.setattr(trunk, 'TAIL_TRUNK_BWD', False)
+    monkeypatch.setattr(trunk, 'OVERLAP_MIN_ROWS', 0)
+    monkeypatch.setenv('CB_BWD_OVERLAP', '1')
+    l4, sd4 = _step_losses(monkeypatch, '1')
+    assert l4 == l0
+    for k in sd0:
+        assert torch.equal(sd4[k], sd0[k]), k
+    monkeypatch.setattr(trunk, 'OVERLAP_MIN_ROWS', 1 << 40)
+    monkeypatch.setenv('CB_BWD_OVERLAP', '0')
+    monkeypatch.setattr(trunk, 'TAIL_TRUNK_BWD', True)
     # + the output Linear's dX GEMM with the same epilogue, gradients stored as their dropout backward (CB_TRUNK_FUSE_OUT_BWD, CB_TRUNK_PREMASKED)
     monkeypatch.setattr(trunk, 'FUSE_OUT_BWD', True)
     monkeypatch.setattr(trunk, 'PREMASKED', True)
