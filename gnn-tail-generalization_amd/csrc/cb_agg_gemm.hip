@@ -234,7 +234,7 @@ __device__ __forceinline__ void ag_wait(int* flag, int target) {
   int spins = 0;
   while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
     __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1 << 22)) break;
+    if (++spins > (1 << 26)) break;      // ~7 s of s_sleep: only a lost hand-over gets here
   }
   asm volatile("" ::: "memory");
 }
