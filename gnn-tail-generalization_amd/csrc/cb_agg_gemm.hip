@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(64 * (NG + 4), (NG + 4) / 4) k_agg_gemm2(const
   __shared__ __attribute__((aligned(16))) float tiles[2][kTM * kTLD];
   __shared__ __attribute__((aligned(16))) float cstrip[4][8 * kCLD];
   __shared__ int ready[2], freed[2];
-  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform by construction: tell the compiler, so that what derives from it stays in SGPRs)
   const bool gathers = wv < NG;
   const int w = gathers ? wv : wv - NG;
   const int n_it = ((int)blockIdx.x < n_tiles) ? (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
