@@ -66,6 +66,29 @@ def test_spmm_gemm_equals_aggregation_then_gemm(n, T, sym, transpose):
     torch.testing.assert_close(g.double(), want, atol=2e-5 * float(want.abs().max()) + 1e-6, rtol=1e-5)
 
 
+def test_tile_hand_over_is_race_free_under_repetition():
+    """The LDS tiles of the persistent kernel change hands through two counters per buffer instead of a block barrier.  200 003 rows = 3126 tiles
+    = 12 per block: every launch makes ~37 000 hand-overs; 40 launches (plain and reverse orientation alternating) all reproduce the two-kernel
+    result bit for bit — a lost or early hand-over would show as a wrong 64-row tile."""
+    from gnn_tail_generalization_amd import gemm
+    from gnn_tail_generalization_amd.graph import weight_image
+    n = 200003
+    G = _powerlaw_graph(n, 9, 256)
+    gen = torch.Generator(device=DEV).manual_seed(21)
+    h = torch.randn(n, 256, device=DEV, generator=gen)
+    w = torch.randn(256, 256, device=DEV, generator=gen) * 0.07
+    a = torch.rand(n, device=DEV, generator=gen) + 0.5
+    img = weight_image(w)
+    refs = {}
+    for tr in (False, True):
+        ro = G.spmm(h, transpose=tr)
+        refs[tr] = (ro, gemm.mm_nn(ro, w, rowscale=a))
+    for i in range(40):
+        tr = bool(i & 1)
+        out, g = G.spmm_gemm(h, img, transpose=tr, g_rowscale=a)
+        assert torch.equal(out, refs[tr][0]) and torch.equal(g, refs[tr][1]), f'launch {i}'
+
+
 @pytest.mark.parametrize('n,T,p', [(5003, 16, 0.1), (20000, 256, 0.0), (777, 8, 0.3), (70001, 64, 0.2)])
 def test_fused_store_gemm_equals_fused_store_then_gemm(n, T, p):
     """cb_spmm_gemm_fused_f32: mask words, out_next and Z_next bit-identical to cb_spmm_csr_fused_f32 followed by cb_gemm_nn_f32."""
