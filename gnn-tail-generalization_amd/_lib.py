@@ -96,7 +96,7 @@ SIGNATURES = {
     'cb_spmm_edge_dot_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, _P, _I64, _I64, _P, _P]),
     'cb_gemm_nn_indrop_supported': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64]),
     'cb_gemm_nn_indrop_drop2_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, ctypes.c_int, ctypes.c_float,
-                                                   ctypes.c_uint64, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P]),
+                                                   ctypes.c_uint64, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _P]),
     'cb_gemm_tn_gdrop_supported': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I64]),
     'cb_gemm_tn_gdrop_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _SZ, _P]),
     'cb_spmm_gemm_trunkbwd_workspace_bytes': (_SZ, []),
@@ -107,7 +107,7 @@ SIGNATURES = {
     'cb_spmm_csr_lp_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, _I64, ctypes.c_float, _P, _P, _I64, _I32, _I32, _I32, _P, _P,
                                           _P, _SZ, _P]),
     'cb_trunk_input_bwd_multi_f32': (ctypes.c_int, [_P, ctypes.c_uint64, _I32, _P, _P, ctypes.c_float, _P, _P, _I64, _I64, ctypes.c_float,
-                                                    _P, _I64, _P, _P, _SZ, ctypes.c_uint32, _P]),
+                                                    _P, _I64, _P, _P, _SZ, ctypes.c_uint32, _P, _P]),
     'cb_id_count_i64': (ctypes.c_int, [_P, _I64, _I64, _P, _P, _P]),
     'cb_value_hist_i32': (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P]),
     'cb_compact_workspace_bytes': (_SZ, [_I64]),

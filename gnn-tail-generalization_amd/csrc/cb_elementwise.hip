@@ -231,6 +231,7 @@ struct MixTable {
 
 template <int NMIX>   // number of mixed-in gradients, compile-time so that all row loads are issued before the first Philox round
 __global__ void __launch_bounds__(kBlock) k_trunk_input_bwd_multi(const float* __restrict__ g, MixTable mt, const float* __restrict__ act,
+                                                                  const unsigned long long* __restrict__ act_bits,
                                                                   float* __restrict__ out, int64_t rows, int d, uint32_t thresh,
                                                                   float keep_scale, uint64_t seed, const uint64_t* __restrict__ seed_dev,
                                                                   int64_t row0, float c_mix, float* __restrict__ partial) {
@@ -273,8 +274,15 @@ __global__ void __launch_bounds__(kBlock) k_trunk_input_bwd_multi(const float* _
 #pragma unroll
         for (int k = 0; k < 4; ++k) t[k] += c_mix * u[l][k];
       }
-      const float4 x = *reinterpret_cast<const float4*>(act + off);
-      const float gy[4] = {x.x > 0.f ? t[0] : 0.f, x.y > 0.f ? t[1] : 0.f, x.z > 0.f ? t[2] : 0.f, x.w > 0.f ? t[3] : 0.f};
+      float gy[4];
+      if (act_bits) {      // mask words of (act > 0) instead of act itself: word k of (row, tile), bit `lane` <-> column 256 tile + 4 lane + k
+        const unsigned long long* bw = act_bits + (r * tiles + tile) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gy[k] = ((bw[k] >> lane) & 1ull) ? t[k] : 0.f;
+      } else {
+        const float4 x = *reinterpret_cast<const float4*>(act + off);
+        gy[0] = x.x > 0.f ? t[0] : 0.f; gy[1] = x.y > 0.f ? t[1] : 0.f; gy[2] = x.z > 0.f ? t[2] : 0.f; gy[3] = x.w > 0.f ? t[3] : 0.f;
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) s[k] += gy[k];
       *reinterpret_cast<float4*>(out + off) = make_float4(gy[0], gy[1], gy[2], gy[3]);
@@ -745,13 +753,13 @@ extern "C" int cb_trunk_input_bwd_f32(const float* g, const float* add, const fl
 extern "C" int cb_trunk_input_bwd_multi_f32(const float* g, uint64_t seed, int32_t n_mix, const float* const* g_mix, const uint64_t* seeds_mix,
                                             float c_mix, const float* act, float* out, int64_t rows, int64_t d, float drop_p,
                                             const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes, uint32_t premasked,
-                                            void* stream) {
+                                            const uint64_t* act_bits, void* stream) {
   CB_CHECK_ARG(rows >= 0 && d > 0 && d % 256 == 0 && d < (1 << 20), CB_E_INVALID, "cb_trunk_input_bwd_multi_f32: d must be a multiple of 256");
   CB_CHECK_ARG(n_mix >= 0 && n_mix <= kMixMax && (n_mix == 0 || (g_mix && seeds_mix)), CB_E_INVALID,
                "cb_trunk_input_bwd_multi_f32: 0..%d mixed-in gradients", kMixMax);
   if (rows == 0) return CB_OK;
-  CB_CHECK_ARG(g && act && out && aligned16(g) && aligned16(act) && aligned16(out), CB_E_INVALID,
-               "cb_trunk_input_bwd_multi_f32: null or misaligned pointer");
+  CB_CHECK_ARG(g && (act || act_bits) && out && aligned16(g) && (!act || aligned16(act)) && aligned16(out) && ((uintptr_t)act_bits % 8 == 0),
+               CB_E_INVALID, "cb_trunk_input_bwd_multi_f32: null or misaligned pointer");
   CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, CB_E_INVALID, "cb_trunk_input_bwd_multi_f32: dropout p out of range");
   CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_colsum_workspace_bytes(rows, d)), CB_E_WORKSPACE, "cb_trunk_input_bwd_multi_f32: workspace too small");
   MixTable mt{};
@@ -767,7 +775,7 @@ extern "C" int cb_trunk_input_bwd_multi_f32(const float* g, uint64_t seed, int32
   const uint32_t thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
   hipStream_t st = (hipStream_t)stream;
 #define CB_MIX_LAUNCH(N_)                                                                                                        \
-  hipLaunchKernelGGL((k_trunk_input_bwd_multi<N_>), dim3((unsigned)nb), dim3(kBlock), kBlock * 4 * sizeof(float), st, g, mt, act, out, rows, \
+  hipLaunchKernelGGL((k_trunk_input_bwd_multi<N_>), dim3((unsigned)nb), dim3(kBlock), kBlock * 4 * sizeof(float), st, g, mt, act, (const unsigned long long*)act_bits, out, rows, \
                      (int)d, thresh, 1.f / (1.f - drop_p), seed, seed_dev, row0, c_mix, colsum ? (float*)ws : nullptr)
   switch (n_mix) {
     case 0: CB_MIX_LAUNCH(0); break;

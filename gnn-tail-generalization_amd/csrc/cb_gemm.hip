@@ -365,9 +365,12 @@ extern "C" int cb_gemm_nn_indrop_supported(const float* A, int64_t lda, const fl
 
 extern "C" int cb_gemm_nn_indrop_drop2_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, float* C2, int64_t ldc2,
                                            int64_t M, int64_t N, int64_t K, const float* bias, int relu, float a_drop_p, uint64_t a_seed,
-                                           float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, void* stream) {
+                                           float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits,
+                                           void* stream) {
   CB_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && drop_p > 0.f && drop_p < 1.f && a_drop_p > 0.f && a_drop_p < 1.f && row0 >= 0, CB_E_INVALID,
                "cb_gemm_nn_indrop_drop2_f32: bad size or p");
+  CB_CHECK_ARG(!relu_bits || (N == 256 && relu && (uintptr_t)relu_bits % 8 == 0), CB_E_INVALID,
+               "cb_gemm_nn_indrop_drop2_f32: mask words of the ReLU exist for N == 256 with relu only");
   CB_CHECK_ARG(N < (1 << 24) && K < (1 << 24) && (M + 63) / 64 < (1 << 24), CB_E_RANGE, "cb_gemm_nn_indrop_drop2_f32: size out of range");
   if (M == 0 || N == 0) return CB_OK;
   CB_CHECK_ARG(C && C2 && A && B && lda >= K && ldb >= N && ldc >= N && ldc2 >= N, CB_E_INVALID, "cb_gemm_nn_indrop_drop2_f32: null pointer or bad ld");
@@ -377,6 +380,7 @@ extern "C" int cb_gemm_nn_indrop_drop2_f32(const float* A, int64_t lda, const fl
   ep.out2 = C2; ep.ld_out2 = ldc2; ep.thresh = dropout_threshold(drop_p); ep.keep_scale = 1.f / (1.f - drop_p);
   ep.seed = seed; ep.seed_dev = seed_dev; ep.row0 = row0;
   ep.adrop = DropSpec{dropout_threshold(a_drop_p), 1.f / (1.f - a_drop_p), a_seed, seed_dev, row0, K};
+  ep.relu_bits_out = (unsigned long long*)relu_bits;
   return launch_nn_limb3(A, lda, B, ldb, C, ldc, M, N, K, ep, false, (hipStream_t)stream, nullptr, 0);
 }
 

@@ -45,6 +45,8 @@ struct GemmEpilogue {
   float* colsum_partial;            // [row blocks][N] or null
   int nt_store;                     // fp32 C leaves with the streaming (nt) policy
   DropSpec adrop;                   // ADROP kernels only: dropout of the A operand (thresh = 0: off)
+  unsigned long long* relu_bits_out;   // EPI == 1, 256-column tiles only: [M][4] mask words of (C > 0) after the ReLU (word q, bit L <-> column 4 L + q:
+                                    // the layout of the aggregation's fused store) — the trunk's input stage reads them instead of C itself
   int g_masked;                     // EPI == 2 only: C itself leaves as keep(seed, m, n) * o (its dropout backward applied: the only form in which
                                     // the residual trunk's input stage needs it — no Philox round per mixed-in gradient there)
 };
@@ -285,6 +287,17 @@ __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __rest
           } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (n + q < N) cp[q] = o[q];
+          }
+          if constexpr (EPI == 1 && TPR == 64) {   // a wavefront holds one whole 256-column row: four ballots are its mask words
+            if (ep.relu_bits_out) {
+              unsigned long long mine = 0ull;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const unsigned long long wq = __ballot(o[q] > 0.f);
+                if ((t & 63) == q) mine = wq;
+              }
+              if ((t & 63) < 4) ep.relu_bits_out[m * 4 + (t & 63)] = mine;
+            }
           }
           if constexpr (EPI == 1) {   // launch contract: N % 4 == 0, 16-byte aligned out2 rows
             float mk[4];

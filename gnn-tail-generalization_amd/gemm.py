@@ -87,10 +87,11 @@ def mm_nn_drop2(a, b, p, seed, row0=0, bias=None, relu=False):
     return y, yd
 
 
-def mm_nn_indrop_drop2(a, b, p, a_seed, seed, row0=0, bias=None, relu=False):
+def mm_nn_indrop_drop2(a, b, p, a_seed, seed, row0=0, bias=None, relu=False, want_bits=False):
     """(y, dropout_seed(y)) with y = act(dropout_{a_seed}(a) @ b + bias): the dropout in front of the input Linear (GCN.py:104) is
     applied to `a` while the GEMM stages it (cb_gemm_nn_indrop_drop2_f32) — bit-identical to ops._dropout_raw(a, p, a_seed, row0 * K)
-    followed by mm_nn_drop2.  Returns None where the fused form does not exist for the shape (the caller keeps the two-kernel form)."""
+    followed by mm_nn_drop2.  Returns None where the fused form does not exist for the shape (the caller keeps the two-kernel form).
+    want_bits (N == 256, relu): a third result, the int64 [M, 1, 4] mask words of (y > 0) in the layout of the aggregation's fused store."""
     import ctypes
     from . import ops
     lib = _lib.load()
@@ -104,11 +105,12 @@ def mm_nn_indrop_drop2(a, b, p, a_seed, seed, row0=0, bias=None, relu=False):
     yd = torch.empty((M, N), dtype=torch.float32, device=a.device)
     if not lib.cb_gemm_nn_indrop_supported(_lib.ptr(a), _ld(a), _lib.ptr(b), _ld(b), _lib.ptr(y), N, _lib.ptr(yd), N, M, N, K):
         return None
+    bits = torch.empty((M, 1, 4), dtype=torch.int64, device=a.device) if (want_bits and N == 256 and relu) else None
     with torch.cuda.device(a.device):
         _lib.check(lib.cb_gemm_nn_indrop_drop2_f32(_lib.ptr(a), _ld(a), _lib.ptr(b), _ld(b), _lib.ptr(y), N, _lib.ptr(yd), N, M, N, K, _lib.ptr(bias),
                                                    int(bool(relu)), float(p), ctypes.c_uint64(a_seed), float(p), ctypes.c_uint64(seed),
-                                                   ops.seed_dev_ptr(), int(row0), _lib.stream_ptr()), 'cb_gemm_nn_indrop_drop2_f32')
-    return y, yd
+                                                   ops.seed_dev_ptr(), int(row0), _lib.ptr(bits), _lib.stream_ptr()), 'cb_gemm_nn_indrop_drop2_f32')
+    return (y, yd, bits) if want_bits else (y, yd)
 
 
 def mm_tn_gdrop(a, g, p, g_seed, row0=0):

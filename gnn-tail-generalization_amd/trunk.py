@@ -164,9 +164,10 @@ def _input_bwd(g, add, act, p, seed, row0):
     return out, colsum
 
 
-def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0, premasked=0):
+def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0, premasked=0, act_bits=None):
     """cb_trunk_input_bwd_multi_f32: (dropout_bwd(g) + c_mix * sum_l dropout_bwd_l(g_mix[l])) * (act > 0) and its column sums.
-    premasked: bit l set = g_mix[l] already is dropout_bwd_l(.) (stored so by the kernel that produced it)."""
+    premasked: bit l set = g_mix[l] already is dropout_bwd_l(.) (stored so by the kernel that produced it).  act_bits: int64 [rows, d/256, 4] mask
+    words of (act > 0), read instead of act."""
     lib = _lib.load()
     rows, d = g.shape
     out = torch.empty_like(g)
@@ -177,9 +178,9 @@ def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0, premasked=0
     ptrs = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in g_mix])
     seeds = (ctypes.c_uint64 * max(n, 1))(*[int(s) for s in seeds_mix])
     with torch.cuda.device(g.device):
-        _lib.check(lib.cb_trunk_input_bwd_multi_f32(_lib.ptr(g), ctypes.c_uint64(seed), n, ptrs, seeds, float(c_mix), _lib.ptr(act), _lib.ptr(out),
+        _lib.check(lib.cb_trunk_input_bwd_multi_f32(_lib.ptr(g), ctypes.c_uint64(seed), n, ptrs, seeds, float(c_mix), _lib.ptr(None if act_bits is not None else act), _lib.ptr(out),
                                                     rows, d, float(p), ops.seed_dev_ptr(), int(row0), _lib.ptr(colsum), _lib.ptr(ws), wsb,
-                                                    int(premasked), _lib.stream_ptr()), 'cb_trunk_input_bwd_multi_f32')
+                                                    int(premasked), _lib.ptr(act_bits), _lib.stream_ptr()), 'cb_trunk_input_bwd_multi_f32')
     return out, colsum
 
 
@@ -212,6 +213,9 @@ MASKED_GATHER = os.environ.get('CB_TRUNK_MASKED_GATHER', '0') == '1'
 TAIL_TRUNK_BWD = os.environ.get('CB_AGG_GEMM_TRUNKBWD', '0') == '1'
 FUSE_OUT_BWD = os.environ.get('CB_TRUNK_FUSE_OUT_BWD', '0') == '1'
 PREMASKED = os.environ.get('CB_TRUNK_PREMASKED', '0') == '1'
+# The input Linear's GEMM writes the mask words of (X0 > 0) from its epilogue (a wavefront holds a whole 256-column row there: four ballots),
+# and the input stage of the backward reads those 32 bytes per row instead of X0's 1 KiB (one of its six 10 GB streams).  CB_TRUNK_X0_BITS=0: off.
+X0_BITS = os.environ.get('CB_TRUNK_X0_BITS', '1') == '1'
 MIX_MAX = 7      # mixed-in gradients one cb_trunk_input_bwd_multi_f32 launch gathers (deeper trunks accumulate layer by layer)
 
 
@@ -300,9 +304,12 @@ class _TrunkFn(torch.autograd.Function):
         # is written, kept or re-read: the weight gradient regenerates the mask) where that form exists; CB_TRUNK_INDROP=0 keeps the pass
         fused_in = None
         if p > 0 and os.environ.get('CB_TRUNK_INDROP', '1') != '0':
-            fused_in = gemm.mm_nn_indrop_drop2(x, w_in.t().contiguous(), p, seeds[0], seeds[1], row0, bias=b_in, relu=True)
+            fused_in = gemm.mm_nn_indrop_drop2(x, w_in.t().contiguous(), p, seeds[0], seeds[1], row0, bias=b_in, relu=True,
+                                               want_bits=w_in.shape[0] == 256 and X0_BITS)
+        x0_bits = None
         if fused_in is not None:
-            x0, cur = fused_in
+            x0, cur = fused_in[0], fused_in[1]
+            x0_bits = fused_in[2] if len(fused_in) > 2 else None      # mask words of (X0 > 0): what the input stage of the backward reads instead of X0
             xd = x                    # saved for the backward: the UNdropped features
         else:
             xd = ops._dropout_raw(x, p, seeds[0], row0 * x.shape[1]) if p > 0 else x
@@ -347,7 +354,9 @@ class _TrunkFn(torch.autograd.Function):
         ctx.graph, ctx.cfg, ctx.row0 = graph, cfg, row0
         ctx.n_layer_params = len(layer_params)
         if bwd:
-            ctx.save_for_backward(xd, x0, w_in, w_out, *saved_in, *saved_bits, *[t for t in layer_params if t is not None])
+            ctx.save_for_backward(xd, x0, w_in, w_out, *saved_in, *saved_bits, *[t for t in layer_params if t is not None],
+                                  *([x0_bits] if x0_bits is not None else []))
+        ctx.has_x0_bits = bwd and x0_bits is not None
         ctx.le_present = [layer_params[3 * l + 2] is not None for l in range(L)]
         return out
 
@@ -375,6 +384,7 @@ class _TrunkFn(torch.autograd.Function):
         saved_in = sv[4: 4 + L + 1]
         saved_bits = sv[4 + L + 1: 4 + 2 * L + 1]
         rest = sv[4 + 2 * L + 1:]
+        x0_bits = rest.pop() if ctx.has_x0_bits else None
         lp, k = [], 0
         for l in range(L):
             w, b = rest[k], rest[k + 1]
@@ -513,7 +523,7 @@ class _TrunkFn(torch.autograd.Function):
             deferred = None
         # input stage: X0 feeds layer 0 (through its dropout) and every mix
         if gather:
-            gpre, d_b_in = _input_bwd_multi(g, seeds[1] if p > 0 else 0, g_mix, seeds_mix, alpha, x0, p, row0, premasked)
+            gpre, d_b_in = _input_bwd_multi(g, seeds[1] if p > 0 else 0, g_mix, seeds_mix, alpha, x0, p, row0, premasked, act_bits=x0_bits)
         else:
             gpre, d_b_in = _input_bwd(g, gx0, x0, p, seeds[1] if p > 0 else 0, row0)
         del g, gx0, g_mix

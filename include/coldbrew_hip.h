@@ -250,11 +250,11 @@ int cb_trunk_input_bwd_f32(const float* g, const float* add, const float* act, f
  * g_mix[l] = gradient w.r.t. the output of layer l's fused store (host array of n_mix <= 7 device pointers); used with
  * cb_trunk_layer_bwd_f32(gx0 = NULL).  Autograd of GCN.py:104-110 + res_tricks.py:23 for every layer at once.
  * premasked: bit l set = g_mix[l] already IS dropout_bwd_seeds_mix[l](.) (written so by cb_spmm_gemm_trunkbwd_f32 / cb_gemm_nn_trunkbwd_f32 with
- * g_masked): no mask is drawn for it. */
+ * g_masked): no mask is drawn for it.  act_bits (may be NULL): [rows][d / 256][4] mask words of (act > 0) used instead of act (act may then be NULL). */
 int cb_trunk_input_bwd_multi_f32(const float* g, uint64_t seed, int32_t n_mix, const float* const* g_mix, const uint64_t* seeds_mix,
                                  float c_mix, const float* act, float* out, int64_t rows, int64_t d, float drop_p,
                                  const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes, uint32_t premasked,
-                                 void* stream);
+                                 const uint64_t* act_bits, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * bf16-storage variant of the aggregation (build extension = BASELINE config 2; the reference is fp32-only):
@@ -437,12 +437,13 @@ int cb_spmm_edge_dot_f32(const int32_t* rowptr, const int32_t* col, int64_t N, i
  * splits them into limbs — no dropped copy is written, kept or re-read; the weight gradient regenerates the same mask:
  *     C = act(dropout(A) @ B + bias), C2 = dropout_{seed}(C)            cb_gemm_nn_indrop_drop2_f32   (else: cb_dropout_f32 + cb_gemm_nn_drop2_f32)
  *     C = A^T @ dropout(G)                                              cb_gemm_tn_gdrop_f32          (else: cb_dropout_f32 + cb_gemm_tn_f32)
- * Results are bit-identical to the two-kernel forms.  The *_supported queries (1 / 0) say whether the fused form exists for a shape. */
+ * Results are bit-identical to the two-kernel forms.  The *_supported queries (1 / 0) say whether the fused form exists for a shape.  * relu_bits (may be NULL; N == 256 and relu only): [M][4] mask words of (C > 0), in the layout of the aggregation's fused store — the input stage
+ * of the trunk backward (cb_trunk_input_bwd_multi_f32, act_bits) then reads 32 bytes per row instead of C's 1 KiB. */
 int cb_gemm_nn_indrop_supported(const float* A, int64_t lda, const float* B, int64_t ldb, const float* C, int64_t ldc, const float* C2, int64_t ldc2,
                                 int64_t M, int64_t N, int64_t K);
 int cb_gemm_nn_indrop_drop2_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, float* C2, int64_t ldc2,
                                 int64_t M, int64_t N, int64_t K, const float* bias, int relu, float a_drop_p, uint64_t a_seed, float drop_p,
-                                uint64_t seed, const uint64_t* seed_dev, int64_t row0, void* stream);
+                                uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, void* stream);
 int cb_gemm_tn_gdrop_supported(const float* A, int64_t lda, const float* G, int64_t ldg, int64_t K1, int64_t K2);
 int cb_gemm_tn_gdrop_f32(const float* A, int64_t lda, const float* G, int64_t ldg, float* C, int64_t M, int64_t K1, int64_t K2, float g_drop_p,
                          uint64_t g_seed, const uint64_t* seed_dev, int64_t row0, void* ws, size_t ws_bytes, void* stream);

@@ -455,3 +455,17 @@ def test_operand_dropout_gemms_equal_dropout_then_gemm(M, K, N, row0):
     dw = gemm.mm_tn_gdrop(g, x, p, s_in, row0)
     assert dw is not None and torch.equal(dw, gemm.mm_tn(g, xd))
     assert gemm.mm_nn_indrop_drop2(x[:100], w, p, s_in, s_out, 0, bias=b, relu=True) is None       # too few tiles: no fused form, caller falls back
+    # the mask words of (y > 0) from the same epilogue (N == 256), in the layout of the aggregation's fused store; the input stage of the trunk
+    # backward gives the same result from them as from y itself
+    if N == 256:
+        from gnn_tail_generalization_amd import trunk
+        y3, yd3, bits = gemm.mm_nn_indrop_drop2(x, w, p, s_in, s_out, row0, bias=b, relu=True, want_bits=True)
+        assert torch.equal(y3, y) and torch.equal(yd3, yd)
+        pos = y > 0
+        for kk in range(4):
+            ref_w = (pos[:, kk::4].to(torch.int64) << torch.arange(64, device=DEV, dtype=torch.int64)).sum(dim=1)
+            assert torch.equal(bits[:, 0, kk], ref_w), kk
+        g1 = torch.randn(M, N, device=DEV, generator=gen)
+        o_a, c_a = trunk._input_bwd_multi(g, 5, [g1], [6], 0.1, y, p, row0)
+        o_b, c_b = trunk._input_bwd_multi(g, 5, [g1], [6], 0.1, y, p, row0, act_bits=bits)
+        assert torch.equal(o_a, o_b) and torch.equal(c_a, c_b)

@@ -1,6 +1,4 @@
 R=$GRAFT_REPO_ROOT
 cd $R
-export TMPDIR=/tmp
-( cd /tmp && CB_BWD_OVERLAP=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_ov -o ov -- python $R/bench.py --steps 3 --warmup 2 --cpu-baseline 0 --ref-epochs 0 --pmc-traffic 0 2>/dev/null | tail -1 | cut -c1-200 )
-DB=$(find /tmp/prof_ov -name "*.db" | head -1)
-python tools/step_trace.py $DB 2>&1 | tail -75 | cut -c1-130
+timeout 1200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_agg_gemm.py tests/test_gpu_model.py tests/test_gpu_fullsize.py -x -q 2>&1 | grep -E "passed|failed|Error|assert" | tail -5
+bash tools/probes/ab.sh 2 "CB_TRUNK_X0_BITS=0" "CB_TRUNK_X0_BITS=1"
