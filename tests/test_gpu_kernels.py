@@ -148,7 +148,7 @@ def test_axpby_act_bwd_frobenius():
         torch.testing.assert_close(le.grad.cpu(), 3.0 * le.detach().cpu() / torch.norm(le.detach().cpu()), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize('rows,C', [(1, 2), (50, 3), (1000, 7), (5000, 40), (777, 47), (300, 128)])
+@pytest.mark.parametrize('rows,C', [(1, 2), (50, 3), (1000, 7), (5000, 40), (777, 47), (300, 128), (4099, 48), (513, 8), (2000, 64), (70000, 4)])
 def test_nll_logsoftmax_fused(rows, C):
     from gnn_tail_generalization_amd import ops
     z = (3 * _rand(rows, C, seed=rows)).requires_grad_(True)
