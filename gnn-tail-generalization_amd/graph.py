@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 
-HUB_THRESHOLD = 256
+HUB_THRESHOLD = int(__import__('os').environ.get('CB_HUB_THRESHOLD', 256))      # rows with more edges are reduced in chunks of this size by the hub kernels (measurement hook: CB_HUB_THRESHOLD)
 INT32_EDGE_LIMIT = 2 ** 31 - 1   # edge offsets (rowptr) and column ids are int32 on the device (include/coldbrew_hip.h); see CSRGraph.__init__
 HOT_BYTES = 256 << 20      # the hot source rows of an aggregation should fill the 256 MiB Infinity Cache: count = HOT_BYTES / row bytes
 HOT_ROWS = HOT_BYTES // 1024   # 262 144 rows at d = 256 fp32 (1 KiB rows): the measured optimum on S-pl10M (profiles/r02_spmm_gather_policy.md)
