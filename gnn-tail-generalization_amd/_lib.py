@@ -23,6 +23,8 @@ _P = ctypes.c_void_p
 SIGNATURES = {
     'cb_version': (ctypes.c_int, []),
     'cb_last_error': (ctypes.c_char_p, []),
+    'cb_device_status': (ctypes.c_int, []),
+    'cb_agg_gemm_handover_selftest': (ctypes.c_int, [_P]),
     'cb_csr_workspace_bytes': (_SZ, [_I64, _I64]),
     'cb_csr_from_coo_i64': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'cb_deg_norm_f32': (ctypes.c_int, [_P, _I64, _P, _P]),
@@ -47,9 +49,6 @@ SIGNATURES = {
     'cb_gemm_nn_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int, _P, _SZ, _P]),
     'cb_gemm_nn_drop2_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int,
                                             ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _SZ, _P]),
-    'cb_gemm_nn_trunkbwd_workspace_bytes': (_SZ, [_I64, _I64]),
-    'cb_gemm_nn_trunkbwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, ctypes.c_float, ctypes.c_float,
-                                               ctypes.c_uint64, _P, _I64, _P, _P, _P, _SZ, _I32, _P]),
     'cb_gemm_tn_workspace_bytes': (_SZ, [_I64, _I64, _I64]),
     'cb_gemm_tn_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _SZ, _P]),
     'cb_spmm_csr_fused_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,
@@ -58,8 +57,6 @@ SIGNATURES = {
     'cb_trunk_layer_bwd_f32': (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, _P, ctypes.c_int, _I64, _I64, ctypes.c_float, ctypes.c_uint64,
                                               _P, _I64, ctypes.c_float, ctypes.c_float, _P, _P, _SZ, _P]),
     'cb_gemm_nn_bf16out_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int, _P, _SZ, _P]),
-    'cb_spmm_csr_masked_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_float, _P, _I64,
-                                              _I32, _I32, _I32, _P, _P, _P, _SZ, _P]),
     'cb_spmm_csr_bf16_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_int, _P, _I64,
                                             _I32, _I32, _I32, _P, _P, _P, _SZ, _P]),
     'cb_spmm_csr_fused_bf16_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,
@@ -87,11 +84,13 @@ SIGNATURES = {
     'cb_gather_rows_bf16_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _P, _P]),
     'cb_agg_gemm_image_bytes': (_SZ, [_I64, _I64]),
     'cb_agg_gemm_image_f32': (ctypes.c_int, [_P, _I64, _I64, _I64, ctypes.c_int, _P, _SZ, _P]),
-    'cb_spmm_gemm_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_int, _P, _I64, _I32, _I32, _I32, _P, _P,
+    'cb_spmm_gemm_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_int, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P,
                                         _P, _SZ, _P, _P, _P, _I64, _P, _I64, _P]),
-    'cb_spmm_gemm_fused_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,
+    'cb_spmm_gemm_fused_f32': (ctypes.c_int, [_P, _I64, _P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,
                                               ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _SZ,
                                               _P, _P, _P, _I64, _P, _I64, _P]),
+    'cb_spmm_gemm_trunkbwd_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _SZ, _P, _P,
+                                                 _P, _I64, _P, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _P, _I64, _P, _P, _SZ, _P]),
     'cb_spmm_csr_weighted_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_int, _P, _I64, _P]),
     'cb_spmm_edge_dot_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, _P, _I64, _I64, _P, _P]),
     'cb_gemm_nn_indrop_supported': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64]),
@@ -100,14 +99,10 @@ SIGNATURES = {
     'cb_gemm_tn_gdrop_supported': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I64]),
     'cb_gemm_tn_gdrop_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _SZ, _P]),
     'cb_spmm_gemm_trunkbwd_workspace_bytes': (_SZ, []),
-    'cb_agg_gemm_set_cu_limit': (ctypes.c_int, [_I32]),
-    'cb_stream_create_cu_mask': (ctypes.c_int, [_P, _I32, _P]),
-    'cb_spmm_gemm_trunkbwd_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _SZ, _P, _P, _P,
-                                                 _I64, _P, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _P, _I64, _P, _P, _SZ, _I32, _P]),
     'cb_spmm_csr_lp_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, _I64, ctypes.c_float, _P, _P, _I64, _I32, _I32, _I32, _P, _P,
                                           _P, _SZ, _P]),
     'cb_trunk_input_bwd_multi_f32': (ctypes.c_int, [_P, ctypes.c_uint64, _I32, _P, _P, ctypes.c_float, _P, _P, _I64, _I64, ctypes.c_float,
-                                                    _P, _I64, _P, _P, _SZ, ctypes.c_uint32, _P, _P]),
+                                                    _P, _I64, _P, _P, _SZ, _P, _P]),
     'cb_id_count_i64': (ctypes.c_int, [_P, _I64, _I64, _P, _P, _P]),
     'cb_value_hist_i32': (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P]),
     'cb_compact_workspace_bytes': (_SZ, [_I64]),
@@ -147,6 +142,17 @@ def check(rc, what):
     if rc != 0:
         msg = load().cb_last_error()
         raise HipExtensionError(f'{what} failed (rc={rc}): {msg.decode() if msg else ""}')
+
+
+def device_status():
+    """Raises HipExtensionError if a kernel recorded a device-side error since the last call (a tile hand-over of the aggregation + GEMM
+    kernel that timed out: the results of that launch are invalid).  Does not synchronise: the trainer calls it after the
+    synchronisation that ends a step (where it reads the loss)."""
+    lib = load()
+    rc = lib.cb_device_status()
+    if rc != 0:
+        msg = lib.cb_last_error()
+        raise HipExtensionError(f'device-side error (rc={rc}): {msg.decode() if msg else ""}')
 
 
 def stream_ptr():

@@ -12,6 +12,8 @@ namespace cb {
 constexpr int kWave = 64;  // CDNA wavefront
 
 void set_error(const char* fmt, ...);
+int* device_error_word();            // cb_error.hip: four ints of device-visible host memory (null if the allocation failed)
+const char* device_error_text();     // what the word currently says
 
 #define CB_CHECK_ARG(cond, code, ...)  \
   do {                                 \

@@ -226,7 +226,6 @@ struct MixTable {
   const float* g[kMixMax];
   uint64_t seed[kMixMax];
   int n;
-  uint32_t premasked;      // bit l: g[l] already is its dropout backward (written so by the kernel that produced it): no Philox round for it
 };
 
 template <int NMIX>   // number of mixed-in gradients, compile-time so that all row loads are issued before the first Philox round
@@ -265,7 +264,7 @@ __global__ void __launch_bounds__(kBlock) k_trunk_input_bwd_multi(const float* _
       }
 #pragma unroll
       for (int l = 0; l < NMIX; ++l) {
-        if (thresh && !((mt.premasked >> l) & 1u)) {
+        if (thresh) {
           float m[4];
           keep4(mt.seed[l] + sd, quad, thresh, keep_scale, m);
 #pragma unroll
@@ -819,7 +818,7 @@ extern "C" int cb_trunk_input_bwd_f32(const float* g, const float* add, const fl
 
 extern "C" int cb_trunk_input_bwd_multi_f32(const float* g, uint64_t seed, int32_t n_mix, const float* const* g_mix, const uint64_t* seeds_mix,
                                             float c_mix, const float* act, float* out, int64_t rows, int64_t d, float drop_p,
-                                            const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes, uint32_t premasked,
+                                            const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes,
                                             const uint64_t* act_bits, void* stream) {
   CB_CHECK_ARG(rows >= 0 && d > 0 && d % 256 == 0 && d < (1 << 20), CB_E_INVALID, "cb_trunk_input_bwd_multi_f32: d must be a multiple of 256");
   CB_CHECK_ARG(n_mix >= 0 && n_mix <= kMixMax && (n_mix == 0 || (g_mix && seeds_mix)), CB_E_INVALID,
@@ -831,7 +830,6 @@ extern "C" int cb_trunk_input_bwd_multi_f32(const float* g, uint64_t seed, int32
   CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_colsum_workspace_bytes(rows, d)), CB_E_WORKSPACE, "cb_trunk_input_bwd_multi_f32: workspace too small");
   MixTable mt{};
   mt.n = n_mix;
-  mt.premasked = premasked;
   for (int i = 0; i < n_mix; ++i) {
     CB_CHECK_ARG(g_mix[i] && aligned16(g_mix[i]), CB_E_INVALID, "cb_trunk_input_bwd_multi_f32: null or misaligned mixed-in gradient %d", i);
     mt.g[i] = g_mix[i];

@@ -176,11 +176,8 @@ static inline bool use_limb3() {
 }
 
 // fp32 outputs too large to stay cached (> 256 MiB: the Infinity Cache) leave with the streaming policy: measured -1.5 % per launch
-// on 10M x 256 outputs (7.96 -> 7.84 ms); CB_GEMM_NT_STORE=0/1 forces it off / on
-static inline int gemm_nt_store(int64_t M, int64_t N) {
-  static const int v = getenv("CB_GEMM_NT_STORE") ? atoi(getenv("CB_GEMM_NT_STORE")) : -1;
-  return v >= 0 ? v : (M * N * 4 > ((int64_t)256 << 20));
-}
+// on 10M x 256 outputs (7.96 -> 7.84 ms)
+static inline int gemm_nt_store(int64_t M, int64_t N) { return M * N * 4 > ((int64_t)256 << 20); }
 
 // tile shape by output width: 2x2 (128x128) by default; for TN 1x4 (64x256) when K1 <= 64, 4x1 (256x64) when K2 <= 64
 static inline void tn_tile(int64_t K1, int64_t K2, int& bm, int& bn) {
@@ -248,10 +245,7 @@ static int launch_nn(const float* A, int64_t lda, const float* B, int64_t ldb, v
       return CB_OK;
     }
   }
-  static const int bk32 = getenv("CB_GEMM_BK32") != nullptr;   // measurement hook: K step 32 instead of 16
-  if (aligned && bk32 && WM == 2 && WTN == 2)
-    hipLaunchKernelGGL((k_gemm_nn<WM, WN, true, OUT_BF16, 32, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok, 0);
-  else if (aligned)
+  if (aligned)
     hipLaunchKernelGGL((k_gemm_nn<WM, WN, true, OUT_BF16, BK, WTN>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok, 0);
   else
     hipLaunchKernelGGL((k_gemm_nn<WM, WN, false, OUT_BF16, BK, WTN>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok, 0);
@@ -279,14 +273,11 @@ static int launch_tn(const float* A, int64_t lda, const float* G, int64_t ldg, c
     CB_LAUNCH_CHECK();
     return CB_OK;
   }
-  // Measurement hook: extra (unused) dynamic LDS caps the blocks per CU, leaving registers for a concurrently running
-  // HBM-bound kernel on another stream (see tools/overlap_probe.py).
-  static const int pad_lds = getenv("CB_GEMM_TN_PADLDS") ? atoi(getenv("CB_GEMM_TN_PADLDS")) : 0;
   if (aligned)
-    hipLaunchKernelGGL((k_gemm_tn<WM, WN, true>), grid, dim3(256), pad_lds, st, A, lda, G, ldg, rowscale, ws, M, (int)K1, (int)K2,
+    hipLaunchKernelGGL((k_gemm_tn<WM, WN, true>), grid, dim3(256), 0, st, A, lda, G, ldg, rowscale, ws, M, (int)K1, (int)K2,
                        rows_per_split, tiles_j);
   else
-    hipLaunchKernelGGL((k_gemm_tn<WM, WN, false>), grid, dim3(256), pad_lds, st, A, lda, G, ldg, rowscale, ws, M, (int)K1, (int)K2,
+    hipLaunchKernelGGL((k_gemm_tn<WM, WN, false>), grid, dim3(256), 0, st, A, lda, G, ldg, rowscale, ws, M, (int)K1, (int)K2,
                        rows_per_split, tiles_j);
   CB_LAUNCH_CHECK();
   const int64_t n = K1 * K2;
@@ -319,12 +310,10 @@ extern "C" int cb_gemm_nn_f32(const float* A, int64_t lda, const float* B, int64
   if (M == 0 || N == 0) return CB_OK;
   CB_CHECK_ARG(C && (K == 0 || (A && B)) && lda >= K && ldb >= N && ldc >= N && (!addend || ld_add >= N), CB_E_INVALID,
                "cb_gemm_nn_f32: null pointer or leading dimension too small");
-  GemmEpilogue ep{rowscale, addend, ld_add, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, nullptr, 0.f, nullptr, nullptr, gemm_nt_store(M, N)};
+  GemmEpilogue ep{rowscale, addend, ld_add, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, gemm_nt_store(M, N)};
   hipStream_t st = (hipStream_t)stream;
   if (use_limb3() && limb3_nn_eligible(A, lda, B, ldb, N, K)) return launch_nn_limb3(A, lda, B, ldb, C, ldc, M, N, K, ep, false, st, ws, ws_bytes);
   if (N <= 64) return launch_nn<4, 1>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes);
-  static const int wide = getenv("CB_GEMM_WIDE") != nullptr;   // measurement hook: 128x256 block tile (wave tile 64x128)
-  if (wide && N > 128) return launch_nn<2, 2, false, 4>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
   return launch_nn<2, 2>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes);
 }
 
@@ -341,7 +330,7 @@ extern "C" int cb_gemm_nn_drop2_f32(const float* A, int64_t lda, const float* B,
   if (M == 0 || N == 0) return CB_OK;
   CB_CHECK_ARG(C && C2 && (K == 0 || (A && B)) && lda >= K && ldb >= N && ldc >= N && ldc2 >= N && (!addend || ld_add >= N), CB_E_INVALID,
                "cb_gemm_nn_drop2_f32: null pointer or leading dimension too small");
-  GemmEpilogue ep{rowscale, addend, ld_add, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, nullptr, 0.f, nullptr, nullptr, gemm_nt_store(M, N)};
+  GemmEpilogue ep{rowscale, addend, ld_add, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, gemm_nt_store(M, N)};
   hipStream_t st = (hipStream_t)stream;
   if (use_limb3() && drop_p > 0.f && limb3_nn_dual_eligible(A, lda, B, ldb, C, ldc, C2, ldc2, M, N, K, ep)) {
     ep.out2 = C2; ep.ld_out2 = ldc2; ep.thresh = dropout_threshold(drop_p); ep.keep_scale = 1.f / (1.f - drop_p);
@@ -376,76 +365,12 @@ extern "C" int cb_gemm_nn_indrop_drop2_f32(const float* A, int64_t lda, const fl
   CB_CHECK_ARG(C && C2 && A && B && lda >= K && ldb >= N && ldc >= N && ldc2 >= N, CB_E_INVALID, "cb_gemm_nn_indrop_drop2_f32: null pointer or bad ld");
   CB_CHECK_ARG(cb_gemm_nn_indrop_supported(A, lda, B, ldb, C, ldc, C2, ldc2, M, N, K), CB_E_INVALID,
                "cb_gemm_nn_indrop_drop2_f32: shape / alignment outside the fused form (cb_gemm_nn_indrop_supported)");
-  GemmEpilogue ep{nullptr, nullptr, 0, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, nullptr, 0.f, nullptr, nullptr, gemm_nt_store(M, N)};
+  GemmEpilogue ep{nullptr, nullptr, 0, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, gemm_nt_store(M, N)};
   ep.out2 = C2; ep.ld_out2 = ldc2; ep.thresh = dropout_threshold(drop_p); ep.keep_scale = 1.f / (1.f - drop_p);
   ep.seed = seed; ep.seed_dev = seed_dev; ep.row0 = row0;
   ep.adrop = DropSpec{dropout_threshold(a_drop_p), 1.f / (1.f - a_drop_p), a_seed, seed_dev, row0, K};
   ep.relu_bits_out = (unsigned long long*)relu_bits;
   return launch_nn_limb3(A, lda, B, ldb, C, ldc, M, N, K, ep, false, (hipStream_t)stream, nullptr, 0);
-}
-
-// one block per column: strided partial sums per thread, fixed-order LDS tree (the result does not depend on scheduling)
-__global__ void __launch_bounds__(256) k_col_finish(const float* __restrict__ partial, int64_t nparts, int d, float* __restrict__ out) {
-  __shared__ float s_t[256];
-  const int c = blockIdx.x;
-  float s = 0.f;
-  for (int64_t p = threadIdx.x; p < nparts; p += 256) s += partial[p * d + c];
-  s_t[threadIdx.x] = s;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) s_t[threadIdx.x] += s_t[threadIdx.x + off];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[c] = s_t[0];
-}
-
-extern "C" size_t cb_gemm_nn_trunkbwd_workspace_bytes(int64_t M, int64_t N) {
-  if (M <= 0 || N <= 0) return 0;
-  const size_t a = (size_t)((M + 127) / 128) * (size_t)N * sizeof(float);      // one partial row of column sums per 128-row block
-  const size_t b = cb_colsum_workspace_bytes(M, N);                            // two-kernel fallback
-  return (a > b ? a : b) + 256;
-}
-
-// G = rowscale * (A @ B)   (dL/dx_l = a * (dL/dZ_l @ W_l^T), the dX GEMM of a GCNConv, or dL/dX_L = dL/dlogits @ W_out) AND, from the
-// same epilogue, the backward of the fused aggregation store of the layer below (cb_trunk_layer_bwd_f32 with gx0 = NULL):
-//   GR = c_act * dropout_bwd(G) * relu_bits * row_scale2,   colsum = column sums of the same without row_scale2.
-// G is not re-read by a pass of its own.  Shapes the fused epilogue does not cover run the two kernels one after the other.
-extern "C" int cb_gemm_nn_trunkbwd_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* G, int64_t ldg, float* GR, int64_t ldgr,
-                                       int64_t M, int64_t N, int64_t K, const float* rowscale, const uint64_t* relu_bits, float c_act,
-                                       float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, const float* row_scale2,
-                                       float* colsum, void* ws, size_t ws_bytes, int32_t g_masked, void* stream) {
-  CB_CHECK_ARG(M >= 0 && N > 0 && K >= 0 && N % 256 == 0 && drop_p >= 0.f && drop_p < 1.f && row0 >= 0, CB_E_INVALID,
-               "cb_gemm_nn_trunkbwd_f32: bad size (N must be a multiple of 256) or p");
-  CB_CHECK_ARG(N < (1 << 20) && K < (1 << 24) && (M + 63) / 64 < (1 << 24), CB_E_RANGE, "cb_gemm_nn_trunkbwd_f32: size out of range");
-  if (M == 0) return CB_OK;
-  CB_CHECK_ARG(G && (GR || colsum) && relu_bits && (K == 0 || (A && B)) && lda >= K && ldb >= N && ldg >= N && (!GR || ldgr >= N), CB_E_INVALID,
-               "cb_gemm_nn_trunkbwd_f32: null pointer or leading dimension too small");
-  if (!GR) ldgr = N;      // column sums only (the reverse aggregation applies the store backward itself: cb_spmm_csr_masked_f32)
-  CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_gemm_nn_trunkbwd_workspace_bytes(M, N)), CB_E_WORKSPACE, "cb_gemm_nn_trunkbwd_f32: workspace too small");
-  GemmEpilogue ep{rowscale, nullptr, 0, nullptr, 0, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, nullptr, 0.f, nullptr, nullptr, gemm_nt_store(M, N)};
-  hipStream_t st = (hipStream_t)stream;
-  if (use_limb3() && limb3_nn_dual_eligible(A, lda, B, ldb, G, ldg, GR, ldgr, M, N, K, ep)) {
-    ep.out2 = GR; ep.ld_out2 = ldgr; ep.thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u; ep.keep_scale = 1.f / (1.f - drop_p);
-    ep.seed = seed; ep.seed_dev = seed_dev; ep.row0 = row0;
-    ep.bits = (const unsigned long long*)relu_bits; ep.c_act = c_act; ep.rowscale2 = row_scale2; ep.colsum_partial = colsum ? (float*)ws : nullptr;
-    ep.g_masked = g_masked;
-    const int rc = launch_nn_limb3(A, lda, B, ldb, G, ldg, M, N, K, ep, false, st);
-    if (rc != CB_OK) return rc;
-    if (colsum) {
-      hipLaunchKernelGGL(k_col_finish, dim3((unsigned)N), dim3(256), 0, st, (const float*)ws, (M + 127) / 128, (int)N, colsum);
-      CB_LAUNCH_CHECK();
-    }
-    return CB_OK;
-  }
-  int rc = cb_gemm_nn_f32(A, lda, B, ldb, G, ldg, M, N, K, rowscale, nullptr, 0, nullptr, 0, nullptr, 0, stream);
-  if (rc != CB_OK) return rc;
-  CB_CHECK_ARG(ldg == N && ldgr == N, CB_E_INVALID, "cb_gemm_nn_trunkbwd_f32: the two-kernel form needs contiguous outputs");
-  if (GR || colsum) {
-    rc = cb_trunk_layer_bwd_f32(G, relu_bits, row_scale2, GR, 0, nullptr, 0, M, N, drop_p, seed, seed_dev, row0, c_act, 0.f, colsum, ws, ws_bytes, stream);
-    if (rc != CB_OK) return rc;
-  }
-  if (g_masked && drop_p > 0.f) return cb_dropout_f32(G, G, M * N, drop_p, seed, seed_dev, row0 * N, stream);      // G := its dropout backward, in place
-  return CB_OK;
 }
 
 extern "C" int cb_gemm_nn_bf16out_f32(const float* A, int64_t lda, const float* B, int64_t ldb, uint16_t* C, int64_t ldc, int64_t M,
@@ -456,7 +381,7 @@ extern "C" int cb_gemm_nn_bf16out_f32(const float* A, int64_t lda, const float* 
   if (M == 0 || N == 0) return CB_OK;
   CB_CHECK_ARG(C && (K == 0 || (A && B)) && lda >= K && ldb >= N && ldc >= N && (!addend || ld_add >= N), CB_E_INVALID,
                "cb_gemm_nn_bf16out_f32: null pointer or leading dimension too small");
-  GemmEpilogue ep{rowscale, addend, ld_add, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, nullptr, 0.f, nullptr, nullptr, gemm_nt_store(M, N)};
+  GemmEpilogue ep{rowscale, addend, ld_add, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, gemm_nt_store(M, N)};
   hipStream_t st = (hipStream_t)stream;
   if (use_limb3() && limb3_nn_eligible(A, lda, B, ldb, N, K)) return launch_nn_limb3(A, lda, B, ldb, C, ldc, M, N, K, ep, true, st, ws, ws_bytes);
   if (N <= 64) return launch_nn<4, 1, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);

@@ -8,7 +8,7 @@ namespace cb {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;   // default K step (BKT template parameter; 32 selectable for measurement)
+constexpr int BK = 16;   // K step (32 measured slower: 100 vs 115 TF/s, profiles/r01_*)
 
 // F.dropout applied to an OPERAND on its way into LDS (value * keep(seed, flat index) / (1 - p), the mask cb_dropout_f32 draws): the
 // dropped copy of the matrix is never written or read (the input features' dropout of the residual trunk, GCN.py:104).
@@ -36,19 +36,10 @@ struct GemmEpilogue {
   uint64_t seed;
   const uint64_t* seed_dev;
   int64_t row0;
-  // EPI == 2 kernels only (backward of the residual trunk): the value just computed is dL/dx_l; the backward of the fused
-  // aggregation store of layer l-1 (dropout, mix, ReLU: what k_trunk_bwd<0> does in a pass of its own) is applied on the way out:
-  //   out2 = c_act * keep(seed, m, n) * o * relu_bit_{l-1}(m, n) * rowscale2[m],   colsum_partial[row block][n] += (the same without rowscale2)
-  const unsigned long long* bits;   // [M][N / 256][4] mask words of the forward store (N % 256 == 0)
-  float c_act;
-  const float* rowscale2;           // [M]
-  float* colsum_partial;            // [row blocks][N] or null
   int nt_store;                     // fp32 C leaves with the streaming (nt) policy
   DropSpec adrop;                   // ADROP kernels only: dropout of the A operand (thresh = 0: off)
   unsigned long long* relu_bits_out;   // EPI == 1, 256-column tiles only: [M][4] mask words of (C > 0) after the ReLU (word q, bit L <-> column 4 L + q:
                                     // the layout of the aggregation's fused store) — the trunk's input stage reads them instead of C itself
-  int g_masked;                     // EPI == 2 only: C itself leaves as keep(seed, m, n) * o (its dropout backward applied: the only form in which
-                                    // the residual trunk's input stage needs it — no Philox round per mixed-in gradient there)
 };
 
 template <int WM, int WN, int BKT = BK, int WTN = 2>
@@ -191,14 +182,12 @@ __device__ __forceinline__ void store4(float* __restrict__ p, float a, float b, 
   }
 }
 
-// EPI: 0 = plain; 1 = second output out2 = dropout(C); 2 = second output = trunk layer backward of C (see GemmEpilogue)
-// CS_FLOATS = floats available at Cs: when all WM wave rows fit (32 * WM staged rows), every wavefront stages in every pass
-// (2 passes with 2 barriers each instead of 2 * WM passes in which only one wave row writes).
-template <int WM, int WN, int WTN, bool OUT_BF16, int EPI = 0, int CS_FLOATS = 0>
+// EPI: 0 = plain; 1 = second output out2 = dropout(C) (+ the mask words of C > 0) (see GemmEpilogue)
+template <int WM, int WN, int WTN, bool OUT_BF16, int EPI = 0>
 __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __restrict__ Cs, void* __restrict__ Cv, int64_t ldc,
                                             int64_t m0, int n0, int64_t M, int N, const GemmEpilogue& ep, int c_vec_ok, int t) {
   constexpr int BN = 32 * WTN * WN, LDB = BN + 4;
-  constexpr int G = (32 * WM * LDB <= CS_FLOATS) ? WM : 1;     // wave rows staged per pass
+  constexpr int G = 1;     // wave rows staged per pass (all WM at once measured neutral and pushed the dual-output epilogue into scratch)
   float* C = (float*)Cv;
   const int lane = t & 63, w = t >> 6, wr = w / WN, wc = w % WN;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -212,8 +201,6 @@ __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __rest
 #pragma unroll
     for (int q = 0; q < 4; ++q) if (n + q < N) bfix[q] = ep.bias[n + q];
   }
-  float cs[4] = {0.f, 0.f, 0.f, 0.f};     // EPI == 2: column sums of this thread's 4 columns (the same 4 in every pass: 256 % TPR == 0)
-  static_assert(EPI != 2 || 256 % TPR == 0, "fixed column quad per thread");
 #pragma unroll
   for (int pass = 0; pass < 2 * (WM / G); ++pass) {
     const int grp = pass >> 1, ti = pass & 1;
@@ -269,19 +256,6 @@ __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __rest
           }
         } else {
           float* cp = C + m * ldc + n;
-          float gm[4] = {o[0], o[1], o[2], o[3]};
-          if constexpr (EPI == 2) {   // launch contract: N % 256 == 0, 16-byte aligned out2 rows
-            if (ep.thresh) {
-              float mk[4];
-              keep4(ep.seed_dev ? ep.seed + *ep.seed_dev : ep.seed, ((ep.row0 + m) * N + n) >> 2, ep.thresh, ep.keep_scale, mk);
-#pragma unroll
-              for (int q = 0; q < 4; ++q) gm[q] *= mk[q];
-            }
-            if (ep.g_masked) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) o[q] = gm[q];
-            }
-          }
           if (full4 && c_vec_ok) {
             store4(cp, o[0], o[1], o[2], o[3], ep.nt_store);
           } else {
@@ -304,42 +278,10 @@ __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __rest
             keep4(ep.seed_dev ? ep.seed + *ep.seed_dev : ep.seed, ((ep.row0 + m) * N + n) >> 2, ep.thresh, ep.keep_scale, mk);
             store4(ep.out2 + m * ep.ld_out2 + n, o[0] * mk[0], o[1] * mk[1], o[2] * mk[2], o[3] * mk[3], ep.nt_store);
           }
-          if constexpr (EPI == 2) {
-            const unsigned long long* bw = ep.bits + (m * (N >> 8) + (n >> 8)) * 4;   // word q, bit L <-> column 256 * tile + 4 L + q
-            const int L = (n & 255) >> 2;
-            const float sc2 = ep.rowscale2 ? ep.rowscale2[m] : 1.f;
-            float gy[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              gy[q] = ((bw[q] >> L) & 1ull) ? ep.c_act * gm[q] : 0.f;
-              cs[q] += gy[q];
-            }
-            if (ep.out2) store4(ep.out2 + m * ep.ld_out2 + n, gy[0] * sc2, gy[1] * sc2, gy[2] * sc2, gy[3] * sc2, ep.nt_store);
-          }
         }
       }
     }
     __syncthreads();
-  }
-  if constexpr (EPI == 2) {
-    // column sums of the block's rows: the 256 / TPR threads that own the same column quad are added in a fixed order, then one
-    // partial row per row block (summed over the row blocks by a finish kernel: no float atomics, bit-reproducible)
-    if (ep.colsum_partial) {
-      constexpr int RPP = 256 / TPR;
-      const int cq = t % TPR, rr = t / TPR;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) Cs[(rr * TPR + cq) * 4 + q] = cs[q];
-      __syncthreads();
-      if (rr == 0 && n0 + cq * 4 < N) {
-        float tot[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < RPP; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) tot[q] += Cs[(j * TPR + cq) * 4 + q];
-        float* pp = ep.colsum_partial + (m0 / (64 * WM)) * (int64_t)N + n0 + cq * 4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pp[q] = tot[q];
-      }
-    }
   }
 }
 

@@ -34,9 +34,6 @@
 // memory pipeline are therefore all busy at any instant instead of taking turns (thread blocks that share a CU fall
 // into lock step, so phases that use only one of these units are not hidden by the neighbours).
 // Addressing inside the K loop: a wave-uniform base pointer (scalar registers) per K step plus lane offsets that never change.
-#include <stdlib.h>
-
-#include <type_traits>
 #include <utility>
 
 #include "cb_common.h"
@@ -47,7 +44,7 @@
 namespace cb {
 
 // wave tile 64 x (32 * WTN); block tile (64 * WM) x (32 * WTN * WN)
-template <int WM, int WN, int WTN = 2, int PD = 2>
+template <int WM, int WN, int WTN = 2, int PD = 1>
 struct LTile {
   static constexpr int BM = 64 * WM, BN = 32 * WTN * WN;
   static constexpr int MINW = (WM == 2 && WTN == 2 && PD < 3 ? 3 : 2);   // wavefronts per SIMD the registers must allow
@@ -56,7 +53,7 @@ struct LTile {
 
 // ---- NN ------------------------------------------------------------------------------------
 // ADROP: F.dropout of the A operand while it is staged (ep.adrop) — the dropout of the input features in front of the input Linear
-template <int WM, int WN, bool OUT_BF16, int WTN = 2, int PD = 2, int EPI = 0, bool BPRE = false, bool ADROP = false>
+template <int WM, int WN, bool OUT_BF16, int WTN = 2, int PD = 1, int EPI = 0, bool ADROP = false>
 __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_nn_l3(const float* __restrict__ A, int64_t lda,
                                                                                  const float* __restrict__ B, int64_t ldb,
                                                                                  void* __restrict__ Cv, int64_t ldc, int64_t M, int N,
@@ -64,7 +61,7 @@ __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_nn
                                                                                  int n_col_blocks, int c_vec_ok) {
   using T = LTile<WM, WN, WTN>;
   using OA = RowOperand<T::BM, ADROP>;
-  using OB = std::conditional_t<BPRE, ColOperandPre<T::BN>, ColOperand<T::BN, false>>;   // BPRE: B = image of k_presplit_cols
+  using OB = ColOperand<T::BN, false>;
   constexpr int BM = T::BM, BN = T::BN;
   constexpr int SMEM = 2 * (OA::BYTES + OB::BYTES);
   static_assert(32 * (BN + 4) * 4 <= SMEM, "epilogue staging must fit");
@@ -88,15 +85,7 @@ __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_nn
   uint32_t baddr[WTN];
 #pragma unroll
   for (int j = 0; j < WTN; ++j) baddr[j] = OB::frag_addr(wc * (32 * WTN) + 32 * j, lane);
-  if constexpr (BPRE) {
-    const int64_t nks = (K + KS - 1) / KS;
-    limb_k_loop<WTN, PD, OA, OB>(oa, ob, smem, A + m0 * lda, KS, lda, B + (int64_t)col_blk * nks * OB::STEP_FLOATS, OB::STEP_FLOATS, ldb, nullptr,
-                                 K, aaddr, baddr, acc, t);
-  } else {
-    limb_k_loop<WTN, PD, OA, OB>(oa, ob, smem, A + m0 * lda, KS, lda, B + n0, (int64_t)KS * ldb, ldb, nullptr, K, aaddr, baddr, acc, t);
-  }
-  // (staging all wave rows per pass — CS_FLOATS = SMEM / 4 — measured neutral for the plain epilogue and pushes the dual-output ones
-  //  into scratch: 17.8 vs 7.7 ms; one wave row per pass it stays)
+  limb_k_loop<WTN, PD, OA, OB>(oa, ob, smem, A + m0 * lda, KS, lda, B + n0, (int64_t)KS * ldb, ldb, nullptr, K, aaddr, baddr, acc, t);
   nn_epilogue<WM, WN, WTN, OUT_BF16, EPI>(acc, reinterpret_cast<float*>(smem), Cv, ldc, m0, n0, M, N, ep, c_vec_ok, t);
 }
 
@@ -104,7 +93,7 @@ __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_nn
 // 1-D grid, XCD-aware: the tiles of one row split get block ids congruent mod 8 (same XCD / L2), so each operand
 // panel is fetched from HBM once although tiles_i (tiles_j) tiles consume it.
 // GDROP: F.dropout of the G operand while it is staged (gd): the weight gradient of the input Linear reads the undropped features
-template <int WM, int WN, bool SCALED, int WTN = 2, int PD = 2, bool GDROP = false>
+template <int WM, int WN, bool SCALED, int WTN = 2, int PD = 1, bool GDROP = false>
 __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_tn_l3(const float* __restrict__ A, int64_t lda,
                                                                                  const float* __restrict__ G, int64_t ldg,
                                                                                  const float* __restrict__ rowscale,
@@ -155,24 +144,9 @@ __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_tn
 
 static inline bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
-static inline int limb_pd() {
-  static const int pd = getenv("CB_LIMB_PD") ? atoi(getenv("CB_LIMB_PD")) : 1;   // measurement hook: register prefetch depth
-  return pd;
-}
-
-// Weight operand split once per launch + LDS-DMA staging (ColOperandPre): measured NEUTRAL (8.23 vs 8.08 ms on 10M x 256 x 256,
-// profiles/r02_gemm_presplit.md) although it removes 36 % of the kernel's VALU instructions — the K loop is bound by the six MFMA
-// passes at the power-limited clock, not by instruction issue — so it stays off unless CB_LIMB_PRESPLIT=1 (and a workspace) is given.
-static inline bool presplit_on() {
-  static const bool on = getenv("CB_LIMB_PRESPLIT") != nullptr && atoi(getenv("CB_LIMB_PRESPLIT")) != 0;
-  return on;
-}
-
-// bytes of the pre-split image of a [K, N] column operand for block width BN
-static inline size_t presplit_bytes(int64_t K, int64_t N, int BN) {
-  return (size_t)((N + BN - 1) / BN) * (size_t)((K + KS - 1) / KS) * (size_t)(3 * 16 * BN * 2);
-}
-
+// Register prefetch depth 1 everywhere (2 / 3 measured no gain: profiles/r01_*); the weight operand split once per launch and staged by
+// LDS-DMA measured neutral (8.23 vs 8.08 ms on 10M x 256 x 256, profiles/r02_gemm_presplit.md: the K loop is bound by the six MFMA passes
+// at the power-limited clock, not by instruction issue) and is not kept.
 template <int WM, int WN, bool OUT_BF16, int WTN = 2>
 static int launch_nn_l3_t(const float* A, int64_t lda, const float* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
                           int64_t K, GemmEpilogue ep, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
@@ -181,39 +155,11 @@ static int launch_nn_l3_t(const float* A, int64_t lda, const float* B, int64_t l
   const int64_t groups = (nrb + 7) / 8;
   const int c_vec_ok = ((uintptr_t)C % (OUT_BF16 ? 8 : 16) == 0) && ldc % 4 == 0 && (!ep.addend || (al16(ep.addend) && ep.ld_add % 4 == 0));
   const dim3 grid((unsigned)(groups * 8 * ncb));
-  if constexpr (T::BN >= 128) {
-    // weight operand split once per launch instead of once per block per K step (rows >> the 128-row tile make that worthwhile)
-    if (presplit_on() && !ep.bits && !ep.adrop.thresh && ws && ws_bytes >= presplit_bytes(K, N, T::BN) && M >= 8 * T::BM && limb_pd() == 1) {
-      const int nks = (int)((K + KS - 1) / KS);
-      hipLaunchKernelGGL((k_presplit_cols<T::BN>), dim3((unsigned)nks, (unsigned)ncb), dim3(256), 0, st, B, ldb, (int)K, (int)N, nks, (char*)ws);
-      CB_LAUNCH_CHECK();
-      const float* img = reinterpret_cast<const float*>(ws);
-      if constexpr (!OUT_BF16 && WM == 2 && WTN == 4) {
-        if (ep.out2) {
-          hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, false, WTN, 1, 1, true>), grid, dim3(256), 0, st, A, lda, img, ldb, C, ldc, M, (int)N, (int)K,
-                             ep, nrb, ncb, c_vec_ok);
-          CB_LAUNCH_CHECK();
-          return CB_OK;
-        }
-      }
-      hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, OUT_BF16, WTN, 1, 0, true>), grid, dim3(256), 0, st, A, lda, img, ldb, C, ldc, M, (int)N, (int)K,
-                         ep, nrb, ncb, c_vec_ok);
-      CB_LAUNCH_CHECK();
-      return CB_OK;
-    }
-  }
   if constexpr (!OUT_BF16 && WM == 2 && WTN == 4) {
-    if (ep.out2 || ep.bits) {    // dual-output epilogues (dropped copy / trunk layer backward, the latter also without its second
-                                 // output: column sums only): the wide-tile fp32 kernel only, see limb3_nn_dual_eligible
-      if (!ep.bits && ep.adrop.thresh) {      // + dropout of the A operand in its staging (input Linear of the residual trunk)
-        hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, false, WTN, 1, 1, false, true>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep,
+    if (ep.out2) {    // dual-output epilogue (dropped copy): the wide-tile fp32 kernel only, see limb3_nn_dual_eligible
+      if (ep.adrop.thresh)      // + dropout of the A operand in its staging (input Linear of the residual trunk)
+        hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, false, WTN, 1, 1, true>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep,
                            nrb, ncb, c_vec_ok);
-        CB_LAUNCH_CHECK();
-        return CB_OK;
-      }
-      if (ep.bits)
-        hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, false, WTN, 1, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb,
-                           ncb, c_vec_ok);
       else
         hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, false, WTN, 1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb,
                            ncb, c_vec_ok);
@@ -221,15 +167,8 @@ static int launch_nn_l3_t(const float* A, int64_t lda, const float* B, int64_t l
       return CB_OK;
     }
   }
-  if (limb_pd() == 1)
-    hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, OUT_BF16, WTN, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb,
-                       ncb, c_vec_ok);
-  else if (limb_pd() == 3)
-    hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, OUT_BF16, WTN, 3>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb,
-                       ncb, c_vec_ok);
-  else
-    hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, OUT_BF16, WTN, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb,
-                       ncb, c_vec_ok);
+  hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, OUT_BF16, WTN, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb,
+                     c_vec_ok);
   CB_LAUNCH_CHECK();
   return CB_OK;
 }
@@ -242,17 +181,12 @@ bool limb3_nn_eligible(const float* A, int64_t lda, const float* B, int64_t ldb,
 // the dual-output epilogue exists for the wide (128 x 256) fp32 tile with vector stores on both outputs
 bool limb3_nn_dual_eligible(const float* A, int64_t lda, const float* B, int64_t ldb, const float* C, int64_t ldc, const float* C2, int64_t ldc2,
                             int64_t M, int64_t N, int64_t K, const GemmEpilogue& ep) {
-  static const int wide = getenv("CB_LIMB_WIDE") ? atoi(getenv("CB_LIMB_WIDE")) : 1;
   // below one wide tile per CU the 128 x 128 tile + a separate elementwise pass is faster (see launch_nn_limb3)
-  return wide && N > 128 && ((M + 127) / 128) * ((N + 255) / 256) >= 256 && limb3_nn_eligible(A, lda, B, ldb, N, K) && al16(C) && al16(C2) && ldc % 4 == 0 && ldc2 % 4 == 0 &&
+  return N > 128 && ((M + 127) / 128) * ((N + 255) / 256) >= 256 && limb3_nn_eligible(A, lda, B, ldb, N, K) && al16(C) && al16(C2) && ldc % 4 == 0 && ldc2 % 4 == 0 &&
          (!ep.addend || (al16(ep.addend) && ep.ld_add % 4 == 0));
 }
 
-size_t limb3_nn_workspace_bytes(int64_t N, int64_t K) {
-  if (N <= 64) return 0;
-  const size_t a = presplit_bytes(K, N, 128), b = presplit_bytes(K, N, 256);
-  return (a > b ? a : b) + 256;
-}
+size_t limb3_nn_workspace_bytes(int64_t, int64_t) { return 0; }      // (the three-limb NN kernels need no workspace)
 
 int launch_nn_limb3(const float* A, int64_t lda, const float* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                     const GemmEpilogue& ep, bool out_bf16, hipStream_t st, void* ws, size_t ws_bytes) {
@@ -260,11 +194,11 @@ int launch_nn_limb3(const float* A, int64_t lda, const float* B, int64_t ldb, vo
     return out_bf16 ? launch_nn_l3_t<4, 1, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, st)
                     : launch_nn_l3_t<4, 1, false>(A, lda, B, ldb, C, ldc, M, N, K, ep, st);
   }
-  static const int wide = getenv("CB_LIMB_WIDE") ? atoi(getenv("CB_LIMB_WIDE")) : 1;   // 128 x 256 block tile (wave tile 64 x 128); 0: 128 x 128
+  // 128 x 256 block tile (wave tile 64 x 128) where it fills the chip, else 128 x 128:
   // fewer than one wide tile per CU (a Pubmed-sized M = 19 717: 155 tiles): the 128 x 128 tile doubles the blocks in flight (-6 % on
   // the S-pubmed step); the dual-output epilogues exist for the wide tile only
-  const bool fills = ((M + 127) / 128) * ((N + 255) / 256) >= 256 || ep.out2 || ep.bits;
-  if (wide && N > 128 && fills)
+  const bool fills = ((M + 127) / 128) * ((N + 255) / 256) >= 256 || ep.out2;
+  if (N > 128 && fills)
     return out_bf16 ? launch_nn_l3_t<2, 2, true, 4>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes)
                     : launch_nn_l3_t<2, 2, false, 4>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes);
   return out_bf16 ? launch_nn_l3_t<2, 2, true>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes)
@@ -285,9 +219,7 @@ static void launch_tn_l3_t(const float* A, int64_t lda, const float* G, int64_t 
 #define CB_TN_LAUNCH(SC_, PD_)                                                                                                   \
   hipLaunchKernelGGL((k_gemm_tn_l3<WM, WN, SC_, WTN, PD_>), grid, dim3(256), 0, st, A, lda, G, ldg, rowscale, partial, M, (int)K1, \
                      (int)K2, rows_per_split, tj, ti * tj, nsplit, gd)
-  const int pd = limb_pd();
-  if (rowscale) { if (pd == 1) CB_TN_LAUNCH(true, 1); else if (pd == 3) CB_TN_LAUNCH(true, 3); else CB_TN_LAUNCH(true, 2); }
-  else { if (pd == 1) CB_TN_LAUNCH(false, 1); else if (pd == 3) CB_TN_LAUNCH(false, 3); else CB_TN_LAUNCH(false, 2); }
+  if (rowscale) CB_TN_LAUNCH(true, 1); else CB_TN_LAUNCH(false, 1);
 #undef CB_TN_LAUNCH
 }
 
@@ -302,8 +234,7 @@ int launch_tn_limb3(const float* A, int64_t lda, const float* G, int64_t ldg, co
   if (bm == 64) launch_tn_l3_t<1, 4>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd);
   else if (bm == 256) launch_tn_l3_t<4, 1>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd);
   else {
-    static const int wide = getenv("CB_LIMB_WIDE") ? atoi(getenv("CB_LIMB_WIDE")) : 1;
-    if (wide && K2 > 128 && ((K1 + 127) / 128) * ((K2 + 255) / 256) * nsplit >= 256) launch_tn_l3_t<2, 2, 4>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd);
+    if (K2 > 128 && ((K1 + 127) / 128) * ((K2 + 255) / 256) * nsplit >= 256) launch_tn_l3_t<2, 2, 4>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd);
     else launch_tn_l3_t<2, 2>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd);
   }
   CB_LAUNCH_CHECK();

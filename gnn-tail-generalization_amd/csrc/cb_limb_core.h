@@ -64,7 +64,6 @@ struct RowOperand {
   uint32_t woff;      // LDS byte offset of its 8-byte store in plane 0; j-th store: + j * 64 * 32
   uint32_t rmask;     // bit j: tile row t/4 + 64 j lies inside the matrix
   static constexpr bool HAS_SC = false;
-  static constexpr bool PIN = false, DMA = false;
   float sc[1];        // (interface shared with ColOperand: no per-k scale here)
   // DROP: F.dropout of this operand while it is staged (DropSpec)
   uint64_t dseed;
@@ -133,7 +132,6 @@ struct ColOperand {
   uint32_t woff;      // LDS byte offset of its 8-byte store in plane 0; j-th store: + j * KPP * ROWB  (KPP % 4 == 0)
   bool cok;           // its 4 columns lie inside the matrix (N % 4 == 0)
   static constexpr bool HAS_SC = SCALED;
-  static constexpr bool PIN = false, DMA = false;
   float sc[SCALED ? NV : 1];   // raw per-row scales of the loaded step
   // DROP: F.dropout of this operand while it is staged (DropSpec); rows of the operand = the reduction axis
   uint64_t dseed;
@@ -201,63 +199,6 @@ struct ColOperand {
   }
 };
 
-// ---- "col" operand split ONCE per launch (the small weight matrix of an NN contraction) ------------------------
-// k_presplit_cols writes, per (column block, K step), the three bf16 planes exactly as ColOperand<C>::stage would lay them out
-// in LDS (same swizzle, rows past K and columns past N zero-filled).  Staging in the GEMM is then a straight 16-byte copy
-// global (L2-resident: 3 * K * N * 2 bytes) -> LDS: no conversion, subtraction or masking per block per K step.
-template <int C>
-struct ColOperandPre {
-  using Base = ColOperand<C, false, false>;
-  static constexpr int PLANE = Base::PLANE, BYTES = Base::BYTES;
-  static constexpr int NV = BYTES / (256 * 16);          // 16-byte pieces per thread per K step (C = 256: 6, C = 128: 3)
-  static_assert(BYTES % (256 * 16) == 0, "tile widths 128 / 256");
-  static constexpr int STEP_FLOATS = BYTES / 4;          // advance of the image per K step, in floats (the loop's pointer unit)
-  static constexpr bool HAS_SC = false;
-  // LDS-DMA operand: a piece is ONE global_load_lds_dwordx4 (global -> LDS without passing through VGPRs; wave w of the block
-  // fills bytes [1024 w, 1024 w + 1024) of each 4 KiB slice, lane l its 16 bytes).  Going through registers instead (6 float4
-  // per thread on top of a kernel already at the 256-VGPR cap) made the compiler keep the pieces in scratch: 12.0 vs 8.0 ms.
-  static constexpr bool DMA = true;
-  static constexpr bool PIN = false;
-  float sc[1];
-  __device__ __forceinline__ void init(int64_t, int, int) {}
-  template <int J>
-  __device__ __forceinline__ void load(float4 (&)[NV], const float* __restrict__, int64_t, int64_t, const float*, int) {}
-  template <int J>
-  __device__ __forceinline__ void stage(const float4 (&)[NV], char* __restrict__, int64_t, int) const {}
-  // step_base = image of the K step to bring in (uniform); S = LDS stage that receives it
-  template <int J>
-  static __device__ __forceinline__ void dma(const float* __restrict__ step_base, char* __restrict__ S, int t) {
-    const char* g = reinterpret_cast<const char*>(step_base) + t * 16 + J * 4096;
-    char* d = S + (t & ~63) * 16 + J * 4096;               // wave-uniform LDS base; the hardware adds lane * 16
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 0);
-  }
-  static __device__ __forceinline__ uint32_t frag_addr(int c0, int lane) { return Base::frag_addr(c0, lane); }
-  static __device__ __forceinline__ bf16x8 frag(const char* __restrict__ S, uint32_t addr, int plane) { return Base::frag(S, addr, plane); }
-};
-
-// image[(col_blk * nks + kstep) * BYTES ...]: one block per (kstep, col_blk), thread mapping of ColOperand<C>::stage
-template <int C>
-__global__ void __launch_bounds__(256) k_presplit_cols(const float* __restrict__ B, int64_t ldb, int K, int N, int nks, char* __restrict__ image) {
-  using OP = ColOperand<C, false>;
-  const int ks = blockIdx.x, cb = blockIdx.y, t = threadIdx.x;
-  const int k = t / OP::TPR, nq = t % OP::TPR;
-  char* S = image + ((int64_t)cb * nks + ks) * OP::BYTES;
-  const uint32_t woff = k * OP::ROWB + ((((nq >> 3) ^ OP::swz(k)) & (OP::NC - 1)) << 6) + ((nq & 7) << 3);
-#pragma unroll
-  for (int j = 0; j < OP::NV; ++j) {
-    const int kk = ks * 16 + k + OP::KPP * j, n = cb * C + nq * 4;
-    float v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = (kk < K && n + q < N) ? B[(int64_t)kk * ldb + n + q] : 0.f;
-    uint2 pl[3];
-    split4(v, pl);
-#pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(S + p * OP::PLANE + woff + j * (OP::KPP * OP::ROWB)) = pl[p];
-  }
-}
-
 // The producer side of the software pipeline: registers fa / fb hold K step s+1 on entry to the MFMAs of step s; piece p
 // stages its float4 into the LDS stage `dst` (if step s+1 exists) and re-fills it with step s+2 (if that exists).
 template <class OPA, class OPB>
@@ -275,9 +216,7 @@ struct Producer {
   int64_t left1, left2;        // operand rows / k left from the staged / the loaded step on (left1 <= 0: stage zeros; left2 > 0)
   int t;
   bool do_stage = true;        // compile-time constant at every use (prologue only)
-  const float* bbase1 = nullptr;   // LDS-DMA col operand: image of the step being staged (s+1)
   static constexpr int P = OPA::NV + OPB::NV;
-  static constexpr bool PIN = OPA::PIN || OPB::PIN;
   // branch-free on purpose: the K loop body must stay one basic block so that the compiler's vmcnt bookkeeping can let
   // older loads be consumed while younger ones are still in flight (a step that does not exist stages zeros into a stage
   // nobody reads / re-loads a clamped, valid address)
@@ -288,25 +227,8 @@ struct Producer {
       oa.template load<PIECE>(fa, abase, lda, left2, nullptr, t);
     } else {
       constexpr int J = PIECE - OPA::NV;
-      if constexpr (OPB::DMA) {
-        // issued by dma_all() at the top of the K step
-      } else {
-        if (do_stage) ob.template stage<J>(fb, dstB, left1, t);
-        ob.template load<J>(fb, bbase, ldb, left2, bscale, t);
-      }
-    }
-  }
-  // LDS-DMA col operand: the whole step s+1 is requested at the top of step s (its LDS stage was released by the barrier that
-  // ended step s-1) and has the entire step to land; branch-free — past the end the clamped last step lands in a stage nobody
-  // reads.  Fenced, because left alone the compiler sinks the requests to the end of the step, right in front of the wait.
-  template <int... Js>
-  __device__ __forceinline__ void dma_impl(std::integer_sequence<int, Js...>) {
-    (OPB::template dma<Js>(bbase1, dstB, t), ...);
-  }
-  __device__ __forceinline__ void dma_all() {
-    if constexpr (OPB::DMA) {
-      if (do_stage) dma_impl(std::make_integer_sequence<int, OPB::NV>{});
-      __builtin_amdgcn_sched_barrier(0);
+      if (do_stage) ob.template stage<J>(fb, dstB, left1, t);
+      ob.template load<J>(fb, bbase, ldb, left2, bscale, t);
     }
   }
   template <int G, int NG, int... Is>
@@ -329,8 +251,7 @@ __device__ __forceinline__ void limb_tile_step(const char* __restrict__ As, cons
 #define CB_MFMA4(A_, B_, H_, G_)                                                                             \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
       acc[i][2 * H_ + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[i], B_[j], acc[i][2 * H_ + j], 0, 0, 0); \
-  pr.template group<G_, NG>();                                                                               \
-  if constexpr (PR::PIN) __builtin_amdgcn_sched_barrier(0);
+  pr.template group<G_, NG>();
 #define CB_HALF(H_)                                                                                                          \
   {                                                                                                                          \
     bf16x8 b_hi[2], b_mid[2], b_lo[2];                                                                                       \
@@ -348,7 +269,6 @@ __device__ __forceinline__ void limb_tile_step(const char* __restrict__ As, cons
     CB_MFMA4(a_hi, b_hi, H_, H_ * 6 + 5)                                                                                     \
   }
   bf16x8 a_hi[2], a_mid[2], a_lo[2];
-  pr.dma_all();
   static_assert(NH >= 1 && NH <= 4, "wave tiles of 64, 128 or 256 columns");
   CB_HALF(0)
   if constexpr (NH > 1) CB_HALF(1)
@@ -386,11 +306,9 @@ __device__ __forceinline__ void limb_k_loop(OA& oa, OB& ob, char* __restrict__ s
   auto clampi = [&](int64_t step) { return step < nk ? step : nk - 1; };   // loads of steps past the end re-read the last one
   {  // prologue: step 0 -> LDS stage 0; steps 1..PD -> register slots 1 % PD .. PD % PD
     Producer<OA, OB> p0{oa, ob, fa[0], fb[0], smem, smem + OA::BYTES, a0, b0, bscale0, lda, ldb, 0, total, t, false};
-    p0.bbase1 = b0;
     p0.template group<0, 1>();                        // load step 0
     p0.left1 = total; p0.do_stage = true;
     p0.template group<0, 1>();                        // stage it (and load it once more: keeps one() branch-free)
-    p0.dma_all();                                     // (LDS-DMA col operand: step 0 -> stage 0)
 #pragma unroll
     for (int d = 1; d <= PD; ++d) {
       const int64_t st = clampi(d);
@@ -414,7 +332,6 @@ __device__ __forceinline__ void limb_k_loop(OA& oa, OB& ob, char* __restrict__ s
       const int64_t st = clampi(kt + 1 + PD);
       Producer<OA, OB> pr{oa, ob, fa[slot], fb[slot], nxt, nxt + OA::BYTES, a0 + st * astep, b0 + st * bstep,
                           bscale0 ? bscale0 + st * KS : nullptr, lda, ldb, total - (kt + 1) * KS, total - st * KS, t};
-      pr.bbase1 = b0 + clampi(kt + 1) * bstep;
       limb_tile_step<WTN, OA, OB>(cur, cur + OA::BYTES, aaddr, baddr, acc, pr);
 #pragma unroll
       for (int j = 0; j < OB::NV; ++j) if (OB::HAS_SC) scs[slot][j] = ob.sc[j];

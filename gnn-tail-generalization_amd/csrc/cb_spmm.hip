@@ -32,27 +32,11 @@
 
 namespace cb {
 
-// rows of 17 .. 64 floats: sub-wave streams (cb_spmm_sub.hip)
-bool spmm_sub_eligible(int64_t d, bool al16);
-int launch_spmm_sub(const int32_t* rowptr, const int32_t* col, int64_t N, const float* h, int64_t ld_h, int64_t d, const Epilogue& ep, float* out,
-                    int64_t ld_out, int hub_T, int n_hubs, int n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, float* partial,
-                    int64_t ld_p, hipStream_t st);
-
 static inline int64_t partial_ld(int64_t d) { return (d + 3) / 4 * 4; }
 
-// Gather policy of a launch: 2 when the caller hands over flagged column ids (col_flags), else 0; the measurement hook
-// CB_SPMM_GATHER=1 turns plain-id launches into all-streaming ones (measured slower: profiles/r02_spmm_gather_policy.md).
-static int gather_policy(int col_flags) {
-  static const int env = getenv("CB_SPMM_GATHER") ? atoi(getenv("CB_SPMM_GATHER")) : 0;
-  return col_flags ? 2 : (env == 1 ? 1 : 0);
-}
-
-// Measurement hook: CB_SPMM_LDS_PAD = bytes of (unused) dynamic LDS per block of the row kernel — caps the resident blocks per CU, i.e.
-// shows how the aggregation reacts to the occupancy a fused aggregation + GEMM kernel could afford (profiles/r03_fused_agg_gemm.md).
-static unsigned lds_pad() {
-  static const unsigned v = getenv("CB_SPMM_LDS_PAD") ? (unsigned)atoi(getenv("CB_SPMM_LDS_PAD")) : 0u;
-  return v;
-}
+// Gather policy of a launch: 2 when the caller hands over flagged column ids (col_flags: hot source rows keep the default cache policy,
+// every other gather streams), else 0 (all-streaming measured slower: profiles/r02_spmm_gather_policy.md).
+static inline int gather_policy(int col_flags) { return col_flags ? 2 : 0; }
 
 template <int VEC, bool FUSED, int RPW, int U, typename HT>
 static int launch_spmm_cfg(const int32_t* rowptr, const int32_t* col, int64_t N, const HT* h, int64_t ld_h, int64_t d,
@@ -65,7 +49,7 @@ static int launch_spmm_cfg(const int32_t* rowptr, const int32_t* col, int64_t N,
     int64_t n_waves = (N + RPW - 1) / RPW;
     dim3 grid((unsigned)((n_waves + waves_per_block - 1) / waves_per_block), ny);
 #define CB_ROWS_LAUNCH_GP(FULL_, FUSED_, ACC_, GP_)                                                                                 \
-  hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, FULL_, FUSED_, HT, ACC_, GP_>), grid, dim3(kWave * waves_per_block), lds_pad(), st, rowptr, col, h, \
+  hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, FULL_, FUSED_, HT, ACC_, GP_>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, \
                      ld_h, out, ld_out, (int)N, (int)d, ep, hub_T, fe)
 #define CB_ROWS_LAUNCH(FULL_, FUSED_, ACC_) CB_ROWS_LAUNCH_GP(FULL_, FUSED_, ACC_, 0)
     const bool acc = ep.acc_init != nullptr;
@@ -74,11 +58,11 @@ static int launch_spmm_cfg(const int32_t* rowptr, const int32_t* col, int64_t N,
     CB_CHECK_ARG(!ep.col_flags || gp == 2, CB_E_INVALID, "flagged column ids are only understood by the d %% 256 == 0 kernels");
     if constexpr (FUSED) {
       if (acc) { if constexpr (kGP) { if (gp == 2) CB_ROWS_LAUNCH_GP(true, true, true, 2); else CB_ROWS_LAUNCH(true, true, true); } else CB_ROWS_LAUNCH(true, true, true); }
-      else if constexpr (kGP) { if (gp == 1) CB_ROWS_LAUNCH_GP(true, true, false, 1); else if (gp == 2) CB_ROWS_LAUNCH_GP(true, true, false, 2); else CB_ROWS_LAUNCH(true, true, false); }
+      else if constexpr (kGP) { if (gp == 2) CB_ROWS_LAUNCH_GP(true, true, false, 2); else CB_ROWS_LAUNCH(true, true, false); }
       else CB_ROWS_LAUNCH(true, true, false);
     } else if (d % tile == 0) {
       if (acc) { if constexpr (kGP) { if (gp == 2) CB_ROWS_LAUNCH_GP(true, false, true, 2); else CB_ROWS_LAUNCH(true, false, true); } else CB_ROWS_LAUNCH(true, false, true); }
-      else if constexpr (kGP) { if (gp == 1) CB_ROWS_LAUNCH_GP(true, false, false, 1); else if (gp == 2) CB_ROWS_LAUNCH_GP(true, false, false, 2); else CB_ROWS_LAUNCH(true, false, false); }
+      else if constexpr (kGP) { if (gp == 2) CB_ROWS_LAUNCH_GP(true, false, false, 2); else CB_ROWS_LAUNCH(true, false, false); }
       else CB_ROWS_LAUNCH(true, false, false);
     } else {
       if (acc) CB_ROWS_LAUNCH(false, false, true); else CB_ROWS_LAUNCH(false, false, false);
@@ -95,7 +79,7 @@ static int launch_spmm_cfg(const int32_t* rowptr, const int32_t* col, int64_t N,
 #define CB_HUB_LAUNCH(GP_)                                                                                                       \
   hipLaunchKernelGGL((k_spmm_hub_chunks<VEC, 8, HT, GP_>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h, (int)d, \
                      hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, ld_p, ep)
-    if constexpr (kGPh) { if (gph == 1) CB_HUB_LAUNCH(1); else if (gph == 2) CB_HUB_LAUNCH(2); else CB_HUB_LAUNCH(0); }
+    if constexpr (kGPh) { if (gph == 2) CB_HUB_LAUNCH(2); else CB_HUB_LAUNCH(0); }
     else CB_HUB_LAUNCH(0);
 #undef CB_HUB_LAUNCH
     CB_LAUNCH_CHECK();
@@ -107,78 +91,13 @@ static int launch_spmm_cfg(const int32_t* rowptr, const int32_t* col, int64_t N,
   return CB_OK;
 }
 
-// Tuning hook (measurement only): CB_SPMM_VARIANT = "<RPW>x<U>" selects another row-block / unroll shape of the
-// d = 256 kernel; unset = the tuned default.
-static int spmm_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CB_SPMM_VARIANT");
-    v = 0;
-    if (e) {
-      if (!strcmp(e, "8x8")) v = 1;
-      else if (!strcmp(e, "32x8")) v = 2;
-      else if (!strcmp(e, "16x4")) v = 3;
-      else if (!strcmp(e, "16x16")) v = 4;
-      else if (!strcmp(e, "8x4")) v = 5;
-    }
-  }
-  return v;
-}
-
 template <int VEC, bool FUSED = false, typename HT = float>
 static int launch_spmm(const int32_t* rowptr, const int32_t* col, int64_t N, const HT* h, int64_t ld_h, int64_t d,
                        Epilogue ep, float* out, int64_t ld_out, int hub_T, int n_hubs, int n_chunks,
                        const int32_t* hub_rows, const int32_t* hub_chunk_ptr, float* partial, hipStream_t st,
                        FusedEpi fe = FusedEpi{}) {
-#define CB_SPMM_ARGS rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st, fe
-  if constexpr (VEC == 4 && !FUSED && sizeof(HT) == 4) {
-    switch (spmm_variant()) {
-      case 1: return launch_spmm_cfg<VEC, FUSED, 8, 8, HT>(CB_SPMM_ARGS);
-      case 2: return launch_spmm_cfg<VEC, FUSED, 32, 8, HT>(CB_SPMM_ARGS);
-      case 3: return launch_spmm_cfg<VEC, FUSED, 16, 4, HT>(CB_SPMM_ARGS);
-      case 4: return launch_spmm_cfg<VEC, FUSED, 16, 16, HT>(CB_SPMM_ARGS);
-      case 5: return launch_spmm_cfg<VEC, FUSED, 8, 4, HT>(CB_SPMM_ARGS);
-      default: break;
-    }
-  }
-  return launch_spmm_cfg<VEC, FUSED, 16, 8, HT>(CB_SPMM_ARGS);
-#undef CB_SPMM_ARGS
-}
-
-// Masked-source launch (cb_spmm_csr_masked_f32): fp32 rows, d % 256 == 0, plain store.  MU = gathers in flight per wavefront
-// (each carries 9 SGPRs of mask words + scale next to its 4 VGPRs).
-template <int MU>
-static int launch_spmm_masked(const int32_t* rowptr, const int32_t* col, int64_t N, const float* h, int64_t ld_h, int64_t d, Epilogue ep,
-                              float* out, int64_t ld_out, int hub_T, int n_hubs, int n_chunks, const int32_t* hub_rows,
-                              const int32_t* hub_chunk_ptr, float* partial, hipStream_t st) {
-  constexpr int RPW = 16, waves_per_block = 4;
-  const int ny = (int)(d / 256);
-  const FusedEpi fe{};
-  const int64_t n_waves = (N + RPW - 1) / RPW;
-  const dim3 grid((unsigned)((n_waves + waves_per_block - 1) / waves_per_block), ny), blk(kWave * waves_per_block);
-  if (ep.col_flags)
-    hipLaunchKernelGGL((k_spmm_rows<4, RPW, MU, true, false, float, false, 2, true>), grid, blk, 0, st, rowptr, col, h, ld_h, out, ld_out, (int)N,
-                       (int)d, ep, hub_T, fe);
-  else
-    hipLaunchKernelGGL((k_spmm_rows<4, RPW, MU, true, false, float, false, 0, true>), grid, blk, 0, st, rowptr, col, h, ld_h, out, ld_out, (int)N,
-                       (int)d, ep, hub_T, fe);
-  CB_LAUNCH_CHECK();
-  if (n_hubs > 0) {
-    const int64_t ld_p = partial_ld(d);
-    const dim3 gridc((unsigned)((n_chunks + waves_per_block - 1) / waves_per_block), ny);
-    if (ep.col_flags)
-      hipLaunchKernelGGL((k_spmm_hub_chunks<4, MU, float, 2, true>), gridc, blk, 0, st, rowptr, col, h, ld_h, (int)d, hub_T, n_hubs, n_chunks,
-                         hub_rows, hub_chunk_ptr, partial, ld_p, ep);
-    else
-      hipLaunchKernelGGL((k_spmm_hub_chunks<4, MU, float, 0, true>), gridc, blk, 0, st, rowptr, col, h, ld_h, (int)d, hub_T, n_hubs, n_chunks,
-                         hub_rows, hub_chunk_ptr, partial, ld_p, ep);
-    CB_LAUNCH_CHECK();
-    const dim3 grid2((unsigned)((n_hubs + waves_per_block - 1) / waves_per_block), ny);
-    hipLaunchKernelGGL((k_spmm_hub_finish<4, false>), grid2, blk, 0, st, (int)d, n_hubs, hub_rows, hub_chunk_ptr, partial, ld_p, out, ld_out,
-                       ep, fe);
-    CB_LAUNCH_CHECK();
-  }
-  return CB_OK;
+  // 16 rows per wavefront, 8 gathers in flight: the sweep of row-block / unroll shapes is in profiles/r01_* (all within +-1 %)
+  return launch_spmm_cfg<VEC, FUSED, 16, 8, HT>(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st, fe);
 }
 
 }  // namespace cb
@@ -212,13 +131,10 @@ static int spmm_plain_impl(const char* who, const int32_t* rowptr, const int32_t
   const bool al16 = ((uintptr_t)h % 16 == 0) && ((uintptr_t)out % 16 == 0) && (ld_h % 4 == 0) && (ld_out % 4 == 0) && (d % 4 == 0) && ini16;
   const bool al8 = ((uintptr_t)h % 8 == 0) && ((uintptr_t)out % 8 == 0) && (ld_h % 2 == 0) && (ld_out % 2 == 0) && (d % 2 == 0) && ini8;
   float* partial = (float*)ws;
-  static const bool small_off = getenv("CB_SPMM_NO_SMALL") != nullptr;   // measurement hook: one wavefront per gathered row at every width
   CB_CHECK_ARG(!col_flags || al16, CB_E_INVALID, "%s: flagged column ids need 16-byte aligned rows", who);
-  if (!small_off && !acc_init && spmm_small_eligible(d, al16))
+  if (!acc_init && spmm_small_eligible(d, al16))
     return launch_spmm_small(rowptr, col, N, h, ld_h, d, row_scale, bias, relu, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows,
                              hub_chunk_ptr, partial, partial_ld(d), al16, st);
-  if (!acc_init && !col_flags && spmm_sub_eligible(d, al16))
-    return launch_spmm_sub(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, partial_ld(d), st);
   if (al16 && d >= 256)
     return launch_spmm<4>(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st);
   if (al8 && d >= 128)
@@ -255,11 +171,6 @@ extern "C" int cb_spmm_csr_lp_f32(const int32_t* rowptr, const int32_t* col, int
   if (n_hubs == 0) hub_T = INT32_MAX;
   Epilogue ep{row_scale, nullptr, 0, nullptr, 0, 0};
   ep.lp_mix = mix; ep.ld_lp = ld_mix; ep.lp_c_mix = c_mix; ep.lp_post = post_scale;
-  const bool al16 = ((uintptr_t)h % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)mix % 16 == 0) && ld_h % 4 == 0 && ld_out % 4 == 0 &&
-                    ld_mix % 4 == 0;
-  if (spmm_sub_eligible(d, al16))      // d = number of classes padded to a multiple of 4 (ops.label_propagation pads to 16)
-    return launch_spmm_sub(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, (float*)ws, partial_ld(d),
-                           (hipStream_t)stream);
   return launch_spmm<1>(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, (float*)ws, (hipStream_t)stream);
 }
 
@@ -272,34 +183,6 @@ extern "C" int cb_spmm_csr_acc_f32(const int32_t* rowptr, const int32_t* col, in
   CB_CHECK_ARG(acc_init != nullptr || N == 0 || d == 0, CB_E_INVALID, "cb_spmm_csr_acc_f32: acc_init is null");
   return spmm_plain_impl("cb_spmm_csr_acc_f32", rowptr, col, col_flags, N, E, h, ld_h, d, row_scale, bias, relu, acc_init, ld_init, out, ld_out, hub_T,
                          n_hubs, n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, stream);
-}
-
-// out[v] = out_coef * sum_{u in row v} src_scale[u] * (src_bits[u] ? h[u] : 0): the reverse aggregation of the fused trunk's
-// backward with the layer-below's store backward (dropout keep & ReLU mask bits of the forward store, c_act / (1 - p), degree norm
-// of the source row) applied to every gathered row — what cb_trunk_layer_bwd_f32 followed by cb_spmm_csr_f32 computes, without
-// the [N, d] intermediate (8 bytes / element less traffic per layer; + 36 bytes per edge of scalar-cache reads).
-extern "C" int cb_spmm_csr_masked_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h,
-                                      int64_t ld_h, int64_t d, const uint64_t* src_bits, const float* src_scale, float out_coef,
-                                      float* out, int64_t ld_out, int32_t hub_T, int32_t n_hubs, int32_t n_chunks,
-                                      const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
-  CB_CHECK_ARG(N >= 0 && E >= 0 && d > 0 && d % 256 == 0, CB_E_INVALID, "cb_spmm_csr_masked_f32: d must be a positive multiple of 256");
-  CB_CHECK_ARG(N < INT32_MAX && E < INT32_MAX && d < (1 << 20), CB_E_RANGE, "cb_spmm_csr_masked_f32: size exceeds the int32 contract");
-  if (N == 0) return CB_OK;
-  CB_CHECK_ARG(rowptr && h && out && src_bits && src_scale && (E == 0 || col), CB_E_INVALID, "cb_spmm_csr_masked_f32: null pointer");
-  CB_CHECK_ARG(((uintptr_t)h % 16 == 0) && ((uintptr_t)out % 16 == 0) && ld_h % 4 == 0 && ld_out % 4 == 0 && ld_h >= d && ld_out >= d &&
-                   ((uintptr_t)src_bits % 8 == 0) && ((uintptr_t)src_scale % 4 == 0),
-               CB_E_INVALID, "cb_spmm_csr_masked_f32: 16-byte aligned rows of at least d floats required");
-  CB_CHECK_ARG(hub_T > 0 && n_hubs >= 0 && n_chunks >= 0, CB_E_INVALID, "cb_spmm_csr_masked_f32: bad hub plan");
-  CB_CHECK_ARG(n_hubs == 0 || (hub_rows && hub_chunk_ptr && ws && ws_bytes >= cb_spmm_workspace_bytes(n_chunks, d)), CB_E_WORKSPACE,
-               "cb_spmm_csr_masked_f32: hub plan given but workspace missing/too small");
-  if (n_hubs == 0) hub_T = INT32_MAX;
-  Epilogue ep{nullptr, nullptr, 0, nullptr, 0, col_flags, (const unsigned long long*)src_bits, src_scale, out_coef};
-  static const int mu = getenv("CB_SPMM_MASK_U") ? atoi(getenv("CB_SPMM_MASK_U")) : 4;     // measurement hook
-  if (mu == 4)
-    return launch_spmm_masked<4>(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, (float*)ws,
-                                 (hipStream_t)stream);
-  return launch_spmm_masked<8>(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, (float*)ws,
-                               (hipStream_t)stream);
 }
 
 static int spmm_fused_impl(int h_bf16, const float* acc_init, int64_t ld_init, int col_flags, const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const void* h, int64_t ld_h,

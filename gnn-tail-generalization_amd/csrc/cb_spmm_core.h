@@ -112,12 +112,6 @@ struct Epilogue {
   const float* acc_init;
   int64_t ld_init;
   int col_flags;           // 1: bit 31 of every column id marks a hot source row (gather policy 2, see gather_pol)
-  // MASK kernels only (cb_spmm_csr_masked_f32): every gathered SOURCE row u enters the sum as src_scale[u] * (src_bits[u] ? h[u] : 0)
-  // and the finished row is multiplied by out_coef — the backward of the fused trunk store (dropout keep & ReLU mask, c_act / (1-p),
-  // the source row's degree norm) applied while the reverse aggregation gathers dL/dx_l, instead of in a pass of its own
-  const unsigned long long* src_bits;   // [n_cols][d / 256][4] mask words of the forward store (word k, bit L <-> column 256 t + 4 L + k)
-  const float* src_scale;               // [n_cols]
-  float out_coef;
   // label-propagation step (outcome_correlation.py:137-143 with alpha_term, post_step = clamp(0, 1)), narrow rows (VEC < 4 kernels) only:
   //   out[v] = lp_post[v] * clamp(row_scale[v] * acc + lp_c_mix * lp_mix[v], 0, 1)        (lp_post = null: 1)
   // i.e. alpha * D^-1/2 A (.) + (1 - alpha) * y0, clamped, and already scaled by D^-1/2 for the next step's gather
@@ -141,31 +135,6 @@ __device__ __forceinline__ void write_row_lp(float* __restrict__ out_row, const 
     r[i] = t * post;
     __builtin_nontemporal_store(r[i], out_row + i);
   }
-}
-
-// Uniform (scalar-cache) reads of the per-source-row mask words and scale: the row id is wave-uniform, the arrays are read-only
-// for the whole launch, so they are addressed through the constant address space (s_load)
-typedef const __attribute__((address_space(4))) unsigned long long* ConstU64Ptr;
-typedef const __attribute__((address_space(4))) float* ConstF32Ptr;
-
-// lane l keeps v when bit l of the wave-uniform 64-bit word is set: the word IS the lane mask of one v_cndmask
-__device__ __forceinline__ float keep_if_bit(float v, unsigned long long w) {
-  float r;
-  asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(w));
-  return r;
-}
-
-struct SrcRowMask {     // what the MASK kernels fetch per gathered source row (all wave-uniform: SGPRs)
-  unsigned long long w[4];
-  float s;
-};
-__device__ __forceinline__ SrcRowMask load_src_mask(const Epilogue& ep, int col_id, int tiles, int tile) {
-  SrcRowMask m;
-  ConstU64Ptr bw = (ConstU64Ptr)(ep.src_bits + ((int64_t)col_id * tiles + tile) * 4);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) m.w[k] = bw[k];
-  m.s = ((ConstF32Ptr)ep.src_scale)[col_id];
-  return m;
 }
 
 // Extended epilogue of the fused residual trunk (GCN.py:127-133 folded into the aggregation's store):
@@ -199,8 +168,7 @@ __device__ __forceinline__ void fused_store(const FusedEpi& fe, int64_t row, int
   if (fe.thresh) keep4(fe.seed_dev ? fe.seed + *fe.seed_dev : fe.seed, ((fe.row0 + row) * fe.d + c0) >> 2, fe.thresh, fe.keep_scale, m);
   if (fe.bits) {
     // mask word k of (row, tile), bit l: the element (column 4 l + k) passes gradient to the pre-activation — ReLU positive AND kept
-    // by the dropout.  The backward kernels that also regenerate the keep-mask are unaffected (masking twice is masking once);
-    // cb_spmm_csr_masked_f32 needs nothing but these words.
+    // by the dropout.  The backward kernels that also regenerate the keep-mask are unaffected (masking twice is masking once).
     const int lane = lane_id();
     unsigned long long mine = 0ull;
 #pragma unroll
@@ -252,7 +220,7 @@ __device__ __forceinline__ void gather_pol(float (&v)[VEC], const HT* __restrict
 // TLD > 0 (cb_agg_gemm.hip): every finished row is also written to an LDS tile — tile_lane = this lane's 4 columns of the
 // wavefront's local row 0, TLD floats per tile row.
 // P65 (64-row blocks, cb_agg_gemm.hip): lane i holds rowptr[r0 + i] for i < 64 and ptr_hi = rowptr[r0 + 64].
-template <int VEC, int U, bool FULL, bool FUSED, bool ACC, typename HT, int GP = 0, bool MASK = false, int TLD = 0, bool P65 = false>
+template <int VEC, int U, bool FULL, bool FUSED, bool ACC, typename HT, int GP = 0, int TLD = 0, bool P65 = false>
 __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr_v, float my_scale, int r0, const int* __restrict__ col,
                                             const HT* __restrict__ h_lane, int64_t ld_h, float* __restrict__ out_lane,
                                             int64_t ld_out, bool active_in, int relu, const float (&bvec)[VEC], const FusedEpi& fe,
@@ -267,8 +235,6 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
     }
   };
   const PtrAt my_ptr_at{my_ptr_v, ptr_hi};
-  static_assert(!MASK || (VEC == 4 && FULL && !FUSED && !ACC), "masked gather: d % 256 == 0, plain store");
-  const int m_tiles = MASK ? (int)gridDim.y : 1, m_tile = MASK ? (int)blockIdx.y : 0;
   const bool active = FULL ? true : active_in;
   float ainit[VEC];                          // ACC: partial sums of local row `cur`, fetched one row ahead (read once: streaming)
   zero<VEC>(ainit);
@@ -314,7 +280,7 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
       }
     } else if (active) {
       bool lp_done = false;
-      if constexpr (VEC < 4 && !ACC && !MASK && TLD == 0) {
+      if constexpr (VEC < 4 && !ACC && TLD == 0) {
         if (ep.lp_mix) {
           bool on[VEC];
 #pragma unroll
@@ -352,28 +318,21 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
     int k = 0;
     for (; k + U <= cnt; k += U) {
       float v[U][VEC];
-      SrcRowMask sm[MASK ? U : 1];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int c = bcast_lane(my_col, k + u);
         if (active) gather_pol<VEC, HT, GP>(v[u], h_lane, ld_h, c);
         else zero<VEC>(v[u]);
-        if constexpr (MASK) sm[u] = load_src_mask(ep, GP == 2 ? (c & kColMask) : c, m_tiles, m_tile);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int e = base + k + u;
         while (e == cur_end) flush();
-        if constexpr (MASK) {
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[i] += sm[u].s * keep_if_bit(v[u][i], sm[u].w[i]);
-        } else {
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
-        }
+        for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
       }
     }
-    if constexpr (P65 && !MASK) {
+    if constexpr (P65) {
       if (k < cnt) {
         const int nb = cnt - k;      // 1 .. U-1 edges left in this window
         float v[U][VEC];
@@ -400,20 +359,14 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
       else zero<VEC>(v);
       const int e = base + k;
       while (e == cur_end) flush();
-      if constexpr (MASK) {
-        const SrcRowMask m1 = load_src_mask(ep, GP == 2 ? (c & kColMask) : c, m_tiles, m_tile);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] += m1.s * keep_if_bit(v[i], m1.w[i]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] += v[i];
-      }
+      for (int i = 0; i < VEC; ++i) acc[i] += v[i];
     }
   }
   while (cur < rhi) flush();  // last row + trailing empty rows
 }
 
-template <int VEC, int RPW, int U, bool FULL, bool FUSED, typename HT, bool ACC = false, int GP = 0, bool MASK = false>
+template <int VEC, int RPW, int U, bool FULL, bool FUSED, typename HT, bool ACC = false, int GP = 0>
 __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                    const HT* __restrict__ h, int64_t ld_h, float* __restrict__ out,
                                                    int64_t ld_out, int n_rows, int d, Epilogue ep, int hub_T, FusedEpi fe) {
@@ -430,7 +383,6 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
   int my_ptr = __builtin_nontemporal_load(rowptr + r0 + min(lane, nr));
   float my_scale = 1.f;  // lane i: row_scale[r0 + i], broadcast at flush time (no load on the flush path)
   if (ep.row_scale && lane < nr) my_scale = __builtin_nontemporal_load(ep.row_scale + r0 + lane);
-  if constexpr (MASK) my_scale *= ep.out_coef;
   const int nxt = __shfl_down(my_ptr, 1);
   const unsigned long long hubmask = __ballot(lane < nr && (nxt - my_ptr) > hub_T);
 
@@ -445,7 +397,7 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
   const float* init_lane = ACC ? ep.acc_init + c0 : nullptr;
 
   if (hubmask == 0) {
-    stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP, MASK>(0, nr, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0,
+    stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP>(0, nr, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0,
                                                     init_lane, ep.ld_init, ep);
   } else {
     int r = 0;
@@ -453,7 +405,7 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
       unsigned long long m = hubmask >> r;
       int nh = m ? r + (__ffsll((long long)m) - 1) : nr;
       if (nh > r)
-        stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP, MASK>(r, nh, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe,
+        stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP>(r, nh, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe,
                                                         c0, init_lane, ep.ld_init, ep);
       r = nh + 1;
     }
@@ -461,13 +413,12 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
 }
 
 // One wavefront per chunk of T edges of a hub row -> one partial row in `partial`.
-template <int VEC, int U, typename HT, int GP = 0, bool MASK = false>
+template <int VEC, int U, typename HT, int GP = 0>
 __global__ void __launch_bounds__(256) k_spmm_hub_chunks(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                          const HT* __restrict__ h, int64_t ld_h, int d, int hub_T,
                                                          int n_hubs, int n_chunks, const int* __restrict__ hub_rows,
                                                          const int* __restrict__ hub_chunk_ptr, float* __restrict__ partial,
                                                          int64_t ld_p, Epilogue ep) {
-  const int m_tiles = MASK ? (int)gridDim.y : 1, m_tile = MASK ? (int)blockIdx.y : 0;
   const int lane = lane_id();
   const int chunk = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   if (chunk >= n_chunks) return;
@@ -493,23 +444,16 @@ __global__ void __launch_bounds__(256) k_spmm_hub_chunks(const int* __restrict__
     int k = 0;
     for (; k + U <= cnt; k += U) {
       float v[U][VEC];
-      SrcRowMask sm[MASK ? U : 1];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int c = bcast_lane(my_col, k + u);
         if (active) gather_pol<VEC, HT, GP>(v[u], h_lane, ld_h, c);
         else zero<VEC>(v[u]);
-        if constexpr (MASK) sm[u] = load_src_mask(ep, GP == 2 ? (c & kColMask) : c, m_tiles, m_tile);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if constexpr (MASK) {
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[i] += sm[u].s * keep_if_bit(v[u][i], sm[u].w[i]);
-        } else {
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
-        }
+        for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
       }
     }
     for (; k < cnt; ++k) {
@@ -517,14 +461,8 @@ __global__ void __launch_bounds__(256) k_spmm_hub_chunks(const int* __restrict__
       float v[VEC];
       if (active) gather_pol<VEC, HT, GP>(v, h_lane, ld_h, c);
       else zero<VEC>(v);
-      if constexpr (MASK) {
-        const SrcRowMask m1 = load_src_mask(ep, GP == 2 ? (c & kColMask) : c, m_tiles, m_tile);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] += m1.s * keep_if_bit(v[i], m1.w[i]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] += v[i];
-      }
+      for (int i = 0; i < VEC; ++i) acc[i] += v[i];
     }
   }
   if (active) {
@@ -566,8 +504,7 @@ __global__ void __launch_bounds__(256) k_spmm_hub_finish(int d, int n_hubs, cons
 #pragma unroll
     for (int k = 0; k < VEC; ++k) bvec[k] = ep.bias[c0 + k];
   }
-  float s = ep.row_scale ? ep.row_scale[row] : 1.f;
-  if (ep.src_bits) s *= ep.out_coef;
+  const float s = ep.row_scale ? ep.row_scale[row] : 1.f;
   if constexpr (FUSED) {
     float a4[4], b4[4], rmix[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -29,6 +29,17 @@ after a blocking exchange); COLDBREW_EXCHANGE=allgather the all-gather baseline 
 COLDBREW_HALO_WIRE=bf16 (opt-in, outside the 1e-4 parity) halves the bytes on the links: the pack kernel
 writes bf16 (cb_gather_rows_bf16_f32) and the halo passes read the wire buffer as it arrived
 (cb_spmm_csr_acc_bf16_f32) — no conversion pass on either side.
+Push / pull cover (default, COLDBREW_HALO_COVER=0 switches it off): a remote edge u -> v can be served by shipping the SOURCE row h[u]
+(pull: what the plain halo does) or by shipping the owner-side PARTIAL SUM of the destination row, sum of h[u] over the owner's sources
+of v (push).  Per ordered rank pair the requester picks a vertex cover of the pair's remote-edge bipartite graph (every edge to its
+higher-degree endpoint, one absorb round, never worse than all-pull or all-push): hubs cover most edges of a power-law graph, and the
+busiest link carries 26 - 32 % fewer rows on the permuted-id power-law benchmark graph (profiles/r04_halo_cover_study.md; = the pull
+on the ogbn-products shape, where the optimum is the pull).  The owner's pack becomes one aggregation over a "send CSR" (a pulled row
+= a row with one edge, a pushed row = a row with the edges it sums), the requester's halo CSRs hold one edge per pushed row.  Results
+differ from the pull form only in summation order (inside the 1e-4 contract; not bit-identical to it).  With the cover on, a pair's
+send list is cut into the K time slices by POSITION (pushed partial sums need all of the owner's rows, so slices cannot follow the
+owner's row chunks — and need not: the aggregation + GEMM kernel of the previous stage delivers the whole matrix at once).
+
 The backward of the aggregation is the same exchange on the gradient followed by the reverse-orientation
 passes (own plan; aliasing the forward one when the edge multiset is symmetric on every rank).  Everything
 else is row-local; small all-reduces cover the replicated weights' gradients, the loss numerator, sum(E^2)
@@ -181,6 +192,10 @@ class HipCompute:
             return gather_rows_by_index(x.view(torch.float32), idx).view(torch.bfloat16)
         return gather_rows_by_index(x, idx)
 
+    def to_wire(self, x, wire):
+        """fp32 send buffer -> the wire format (bf16 wire of a cover plan: its pack is an aggregation, which writes fp32)."""
+        return x.to(torch.bfloat16) if wire == 'bf16' and x.dtype == torch.float32 else x
+
     def act_bwd(self, g, act, row_scale, need_b):
         from .ops import act_bwd
         return act_bwd(g, act, row_scale, want_out=True, want_colsum=need_b)
@@ -283,6 +298,168 @@ class HaloPlan:
         self.send_idx_all = local.contiguous()
 
 
+    cover = False
+
+    def pack(self, compute, x_local, k, wire):
+        """Send buffer of slice k: the requested rows of x_local in per-destination order (cb_gather_rows_f32 / _bf16_f32)."""
+        return compute.pack_rows(x_local, self.send_idx[k], wire)
+
+    def halo_edges(self, rows, inv):
+        """(rows, slice, slot) of the requester's halo edges: remote edge e reads slot slot_of[inv[e]] of slice slice_of[inv[e]]."""
+        return rows, self.slice_of[inv], self.slot_of[inv]
+
+
+def cover_slices_enabled():
+    return os.environ.get('COLDBREW_HALO_COVER', '1') != '0'
+
+
+def choose_cover(u_idx, v_idx, q_u, q_v, n_u, n_v, P):
+    """Push / pull assignment of the remote edges of one requester.  u_idx / v_idx: per edge, index of its source among the n_u distinct
+    remote sources / of its (owner, destination) pair among the n_v distinct pairs; q_u / q_v: owner of each distinct source / pair.
+    Returns pull [E] bool (True: the source row is shipped; False: the edge is summed by the owner into the destination's partial row).
+    Heuristic vertex cover per owner: each edge goes to its higher-degree endpoint (ties: pull), sources that are shipped anyway absorb
+    all their edges, then destinations that are pushed anyway absorb theirs; per owner the result competes with all-pull and all-push and
+    the smallest row count wins (within 1 - 3 % of the Hopcroft-Karp optimum on the power-law graphs, profiles/r04_halo_cover_study.md)."""
+    dev = u_idx.device
+    du = torch.bincount(u_idx, minlength=n_u)
+    dv = torch.bincount(v_idx, minlength=n_v)
+    pull = du[u_idx] >= dv[v_idx]
+    S = torch.zeros(n_u, dtype=torch.bool, device=dev)
+    S[u_idx[pull]] = True
+    pull = pull | S[u_idx]
+    T = torch.zeros(n_v, dtype=torch.bool, device=dev)
+    T[v_idx[~pull]] = True
+    pull = pull & ~T[v_idx]
+    S = torch.zeros(n_u, dtype=torch.bool, device=dev)
+    S[u_idx[pull]] = True
+    c_pull = torch.bincount(q_u, minlength=P)
+    c_push = torch.bincount(q_v, minlength=P)
+    c_mix = torch.bincount(q_u[S], minlength=P) + torch.bincount(q_v[T], minlength=P)
+    all_pull = (c_pull <= c_mix) & (c_pull <= c_push)
+    all_push = ~all_pull & (c_push <= c_mix)
+    q_e = q_u[u_idx]
+    return (pull | all_pull[q_e]) & ~all_push[q_e]
+
+
+class CoverPlan:
+    """Push / pull exchange plan of one CSR orientation (module docstring).  Per owner q the requester's list L_q of pulled source rows
+    and pushed partial rows is cut into n_slices pieces by position (slice_weights); slice k's
+    receive buffer is the concatenation over q of L_q's k-th piece (pulled and pushed rows interleaved in proportion inside L_q).
+
+    Requester side: recv_counts[k][q]; halo_edges() = the edges of the halo CSRs (a pulled source keeps its edges, a pushed destination
+    has ONE edge to its partial row).  Owner side: send_csr[k] = CSR over the rows of slice k's send buffer (columns = local rows: one
+    per pulled row, the summed sources per pushed row), send_counts[k][p]; pack() is an aggregation over it."""
+    cover = True
+
+    def __init__(self, rows, cols, part, group, n_slices, compute):
+        """rows / cols: local destination / global source of this rank's REMOTE edges (this orientation)."""
+        P, K, me = part.world, max(1, int(n_slices)), part.rank
+        dev = cols.device
+        nl = max(part.n_local, 1)
+        self.n_slices, self.n_local = K, part.n_local
+        q_e = part.owner(cols)
+        uu, ui = torch.unique(cols, return_inverse=True)                         # distinct remote sources (ascending: grouped by owner)
+        vv, vi = torch.unique(q_e * nl + rows, return_inverse=True)              # distinct (owner, destination) pairs (owner-major)
+        q_u, q_v = part.owner(uu), vv // nl
+        pull = choose_cover(ui, vi, q_u, q_v, int(uu.numel()), int(vv.numel()), P)
+        self.n_pull_only = int(uu.numel())                                       # rows the plain pull would move (diagnostics)
+        S = torch.zeros(uu.numel(), dtype=torch.bool, device=dev)
+        S[ui[pull]] = True
+        T = torch.zeros(vv.numel(), dtype=torch.bool, device=dev)
+        T[vi[~pull]] = True
+        su, tv = torch.nonzero(S).reshape(-1), torch.nonzero(T).reshape(-1)      # shipped sources / pushed pairs, owner-major ascending
+        n_pull = torch.bincount(q_u[su], minlength=P)
+        n_push = torch.bincount(q_v[tv], minlength=P)
+        n_qt = n_pull + n_push
+        n_q = n_qt.tolist()
+        excl = lambda c: torch.cumsum(c, 0) - c      # noqa: E731
+        # position of every item in its owner's list L_q: pulled and pushed rows INTERLEAVED in proportion (an item's key is its relative
+        # rank inside its kind), so that every positional slice carries the same mix — a pushed row is cheap for the requester (one edge)
+        # and dear for the owner (the edges it sums); kinds laid end to end would pile the owners' summing into the last, exposed slice
+        q_it = torch.cat([q_u[su], q_v[tv]])
+        rk = torch.cat([(torch.arange(su.numel(), device=dev) - excl(n_pull)[q_u[su]]).double() + 0.5,
+                        (torch.arange(tv.numel(), device=dev) - excl(n_push)[q_v[tv]]).double() + 0.5])
+        frac = rk / torch.cat([n_pull[q_u[su]], n_push[q_v[tv]]]).clamp(min=1).double()
+        order_it = torch.sort(q_it.double() + frac, stable=True)[1]
+        pos_it = torch.empty_like(order_it)
+        pos_it[order_it] = torch.arange(order_it.numel(), device=dev) - excl(n_qt)[q_it[order_it]]
+        pos_u, pos_t = pos_it[:su.numel()], pos_it[su.numel():]
+        w = slice_weights(K)
+        tot, acc, wfrac = sum(w), 0.0, [0.0]
+        for k in range(K - 1):
+            acc += w[k]
+            wfrac.append(acc / tot)
+        cuts_h = [[min(n, int(n * f)) for f in wfrac] + [n] for n in n_q]         # cuts_h[q][k]: first position of slice k in L_q
+        cuts = torch.tensor(cuts_h, dtype=torch.int64, device=dev).view(P, K + 1)
+        cnt = cuts[:, 1:] - cuts[:, :-1]                                          # cnt[q, k] rows of slice k from owner q
+        base = (torch.cumsum(cnt, 0) - cnt).t().contiguous()                      # base[k, q]: first slot of owner q in slice k's buffer
+
+        def place(qi, pos):      # (slice, slot) of items (owner qi, position pos)
+            k_ = (pos.unsqueeze(1) >= cuts[qi][:, 1:K]).sum(1) if K > 1 else torch.zeros_like(pos)
+            return k_, base[k_, qi] + pos - cuts[qi, k_], pos - cuts[qi, k_]
+        k_u, slot_u, r_u = place(q_u[su], pos_u)
+        k_t, slot_t, r_t = place(q_v[tv], pos_t)
+        self.recv_counts = [[int(c) for c in row] for row in cnt.t().tolist()]
+        self.n_halo_slice = [sum(c) for c in self.recv_counts]
+        self.n_halo = sum(self.n_halo_slice)
+        self.n_pulled, self.n_pushed = int(su.numel()), int(tv.numel())
+        # requester's halo edges: pulled sources keep their edges, every pushed pair has one edge to its partial row
+        u_item = torch.full((max(int(uu.numel()), 1),), -1, dtype=torch.int64, device=dev)
+        u_item[su] = torch.arange(su.numel(), device=dev)
+        it = u_item[ui[pull]]
+        self._h_rows = torch.cat([rows[pull], vv[tv] % nl])
+        self._h_slice = torch.cat([k_u[it], k_t])
+        self._h_slot = torch.cat([slot_u[it], slot_t])
+        # what the owners must know: per (slice, row of my segment in their send buffer) the local rows to sum — (k, r, column) triples
+        t_item = torch.full((max(int(vv.numel()), 1),), -1, dtype=torch.int64, device=dev)
+        t_item[tv] = torch.arange(tv.numel(), device=dev)
+        pe = t_item[vi[~pull]]
+        trip = torch.stack([torch.cat([k_u, k_t[pe]]), torch.cat([r_u, r_t[pe]]), torch.cat([uu[su], cols[~pull]])], 1)
+        owner_of = torch.cat([q_u[su], q_e[~pull]])
+        order = torch.sort(owner_of, stable=True)[1]
+        trip = trip[order].contiguous()
+        n_out = torch.bincount(owner_of, minlength=P)
+        snd, n_in = torch.empty_like(cnt), torch.empty_like(n_out)
+        if P > 1:
+            _all_to_all_single(snd.view(-1), cnt.contiguous().view(-1), group=group)              # row p = what requester p expects from me per slice
+            _all_to_all_single(n_in, n_out, group=group)
+        else:
+            snd.copy_(cnt)
+            n_in.copy_(n_out)
+        n_in_h, n_out_h = n_in.tolist(), n_out.tolist()
+        got = torch.empty((sum(n_in_h), 3), dtype=torch.int64, device=dev)
+        if P > 1:
+            _all_to_all_single(got.view(-1), trip.view(-1), [3 * c for c in n_in_h], [3 * c for c in n_out_h], group=group)
+        snd_h = snd.tolist()
+        self.send_counts = [[int(snd_h[p_][k]) for p_ in range(P)] for k in range(K)]
+        sbase = (torch.cumsum(snd, 0) - snd).t().contiguous()                                      # sbase[k, p]: first row of requester p in slice k's send buffer
+        req = torch.repeat_interleave(torch.arange(P, device=dev), n_in)
+        gk, gr, gc = got[:, 0], got[:, 1], got[:, 2] - part.lo()
+        if got.numel() and (int(gc.min()) < 0 or int(gc.max()) >= part.n_local or int(gk.min()) < 0 or int(gk.max()) >= K):
+            raise RuntimeError('cover plan: a peer requested a row this rank does not own')
+        self.send_csr, self.n_send_slice = [], []
+        for k in range(K):
+            m = gk == k if K > 1 else slice(None)
+            n_rows_k = sum(self.send_counts[k])
+            srow = sbase[k][req[m]] + gr[m]
+            if srow.numel() and int(srow.max()) >= n_rows_k:
+                raise RuntimeError('cover plan: a peer addressed a row beyond its segment of the send buffer')
+            self.send_csr.append(compute.csr(srow, gc[m], max(n_rows_k, 1), nl))
+            self.n_send_slice.append(n_rows_k)
+        self.chunks = [(0, part.n_local)] + [(part.n_local, part.n_local)] * (K - 1)      # a producer, if any, delivers the whole matrix before slice 0
+        self.recv_counts_all = [sum(self.recv_counts[k][q] for k in range(K)) for q in range(P)]
+        self.send_counts_all = [sum(self.send_counts[k][q] for k in range(K)) for q in range(P)]
+
+    def pack(self, compute, x_local, k, wire):
+        """Send buffer of slice k = an aggregation over the send CSR (pulled rows: one edge, i.e. a copy; pushed rows: the partial sums)."""
+        n_k = self.n_send_slice[k]
+        out = compute.spmm(self.send_csr[k], x_local if x_local.shape[0] else x_local.new_zeros((1, x_local.shape[1])))
+        return compute.to_wire(out[:n_k], wire)
+
+    def halo_edges(self, rows=None, inv=None):
+        return self._h_rows, self._h_slice, self._h_slot
+
+
 class _Orientation:
     """One CSR orientation of a rank's row block: the CSR(s) the local passes read and the plan that feeds them."""
     __slots__ = ('whole', 'interior', 'halo', 'plan', 'E', 'rowptr_key', 'col_key')
@@ -293,7 +470,7 @@ class ShardedGraph:
     Quacks like graph.CSRGraph for GCNConv / ops.aggregate / the fused trunk."""
 
     def __init__(self, edge_index, n_nodes, part, group=None, exchange='halo', overlap=True, compute=None, wire='f32', n_slices=None,
-                 local_edges=None):
+                 local_edges=None, cover=None):
         """edge_index: the whole [2, E] edge list (every rank filters its own blocks), or None with
         local_edges = (fwd [2, Ef], rev [2, Er]): the edges whose DESTINATION / SOURCE this rank owns, as scattered by the
         loading rank (ShardedTrainer: no rank but the loader ever holds the whole graph); E_global is then all-reduced."""
@@ -317,6 +494,8 @@ class ShardedGraph:
         if exchange == 'allgather' and part.kind != 'rows':
             raise ValueError("the all-gather baseline needs the equal-row partition (COLDBREW_PARTITION=rows)")
         self.overlap = bool(overlap) and exchange == 'halo' and part.world > 1
+        # push / pull cover of the remote edges (module docstring): overlapped halo form only; None = COLDBREW_HALO_COVER (default on)
+        self.cover = self.overlap and (cover_slices_enabled() if cover is None else bool(cover))
         self._n_slices_req = n_slices
         if local_edges is None:
             src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
@@ -387,10 +566,10 @@ class ShardedGraph:
                 if part.world > 1:
                     _all_reduce(nh, op=dist.ReduceOp.MAX, group=self.group)
                 K = default_slices(int(nh.item()))
-        o.plan = HaloPlan(uniq, part, self.group, K)
+        o.plan = CoverPlan(rows[remote], cols[remote], part, self.group, K, self.compute) if self.cover else HaloPlan(uniq, part, self.group, K)
         if self.overlap:
             o.interior = self.compute.csr(rows[~remote], cols[~remote] - lo, self.N, self.N)
-            rr, sl, slot = rows[remote], o.plan.slice_of[inv], o.plan.slot_of[inv]
+            rr, sl, slot = o.plan.halo_edges(rows[remote], inv)
             o.halo = []
             for k in range(K):
                 m = sl == k if K > 1 else slice(None)
@@ -442,7 +621,7 @@ class ShardedGraph:
     def _send_slice(self, x_local, plan, k):
         """pack slice k -> asynchronous all-to-all.  Returns (receive buffer, work handle, send buffer kept alive)."""
         bf16 = self.wire == 'bf16' and x_local.dtype == torch.float32
-        send = self.compute.pack_rows(x_local, plan.send_idx[k], 'bf16' if bf16 else 'f32')
+        send = plan.pack(self.compute, x_local, k, 'bf16' if bf16 else 'f32')
         n_k = plan.n_halo_slice[k]
         recv = torch.empty((max(n_k, 1), x_local.shape[1]), dtype=send.dtype, device=x_local.device)
         if send.dtype == torch.bfloat16:       # moves as bytes: not every backend knows bfloat16
@@ -496,16 +675,21 @@ class ShardedGraph:
                 c.spmm(o.halo[k], recv, acc_init=part_sums, out=part_sums, profile=self.profile)
         return out
 
-    def aggregate_finish(self, handle, transpose=False, row_scale=None, bias=None, relu=False):
+    def aggregate_finish(self, handle, transpose=False, row_scale=None, bias=None, relu=False, last_pass=None):
+        """last_pass(csr, recv, acc) (overlapped form only): the caller's own final pass over the last slice on top of the running sums
+        (the fused trunk: aggregation + GEMM kernel, cb_spmm_gemm_f32 with acc_init) instead of the plain epilogue pass."""
         h_local, flights = handle
         o = self.b if transpose else self.f
         c = self.compute
         if flights is None:
+            if last_pass is not None:
+                raise ValueError('aggregate_finish: last_pass needs the overlapped exchange')
             return c.spmm(o.whole if o.whole is not None else self._whole(o), self.exchange(h_local, transpose), row_scale, bias, relu,
                           profile=self.profile)
         part = c.spmm(o.interior, h_local, profile=self.profile)             # raw sums over the local columns, overlaps the exchange
-        return self.finish_halo(flights, o, part,
-                                lambda g, recv, acc: c.spmm(g, recv, row_scale, bias, relu, acc_init=acc, profile=self.profile))
+        if last_pass is None:
+            last_pass = lambda g, recv, acc: c.spmm(g, recv, row_scale, bias, relu, acc_init=acc, profile=self.profile)      # noqa: E731
+        return self.finish_halo(flights, o, part, last_pass)
 
     def aggregate(self, h_local, transpose=False, row_scale=None, bias=None, relu=False):
         """act(row_scale * (A_block . h) + bias) for this rank's rows; h_local = this rank's rows of h."""
@@ -898,8 +1082,9 @@ class ShardedTrainer:
     def run_trainSet(self):
         """loss (global), 0, 0 — with --want_headtail=1 the second train-mode forward of :397-413 runs between the loss forward and
         the backward, as in the reference, and fills bag['head_tail_iso']."""
-        loss = self.train_step(metrics=True)
-        return float(loss), 0, 0
+        loss = float(self.train_step(metrics=True))
+        _lib.device_status()            # (the loss has just been read: a device-side error of this step is raised here, never trained through)
+        return loss, 0, 0
 
     def _headtail_metrics(self):
         """bag['head_tail_iso'] (:397-413): accuracy x 100 of a second train-mode (dropout-active) forward on the non-training

@@ -23,15 +23,9 @@ def _ld(t):
 
 
 def _b_workspace(lib, N, K, M, device):
-    """Workspace of an NN launch: split-K partial planes for small-M / long-K shapes (cb_gemm_nn_splitk_workspace_bytes), or — only
-    when CB_LIMB_PRESPLIT=1 asks for it, measured neutral (profiles/r02_gemm_presplit.md) — room for the right operand split once
-    per launch (cb_gemm_nn_workspace_bytes)."""
-    import os
-    if os.environ.get('CB_LIMB_PRESPLIT', '0') in ('', '0') or M < 1024 or K * N > (1 << 22):
-        # few output tiles and a long contraction (x @ W_0 of a Cora-sized graph): planes of the split-K partial products
-        wsb = lib.cb_gemm_nn_splitk_workspace_bytes(M, N, K) if K >= 512 else 0
-    else:
-        wsb = lib.cb_gemm_nn_workspace_bytes(N, K)
+    """Workspace of an NN launch: split-K partial planes for small-M / long-K shapes on the fp32-input fallback kernel
+    (cb_gemm_nn_splitk_workspace_bytes: x @ W_0 of a Cora-sized graph); nothing otherwise."""
+    wsb = lib.cb_gemm_nn_splitk_workspace_bytes(M, N, K) if K >= 512 else 0
     return (torch.empty(wsb, dtype=torch.uint8, device=device), wsb) if wsb else (None, 0)
 
 
@@ -131,34 +125,6 @@ def mm_tn_gdrop(a, g, p, g_seed, row0=0):
         _lib.check(lib.cb_gemm_tn_gdrop_f32(_lib.ptr(a), _ld(a), _lib.ptr(g), _ld(g), _lib.ptr(out), M, K1, K2, float(p), ctypes.c_uint64(g_seed),
                                             ops.seed_dev_ptr(), int(row0), _lib.ptr(ws), wsb, _lib.stream_ptr()), 'cb_gemm_tn_gdrop_f32')
     return out
-
-
-def mm_nn_trunkbwd(a, b, rowscale, bits, c_act, p, seed, row0, row_scale2, want_colsum, want_gr=True, g_masked=False):
-    """(G, GR, colsum): G = rowscale * (a @ b) and, from the same epilogue, GR = c_act * dropout_bwd(G) * relu_bits * row_scale2 with
-    the column sums of the unscaled GR (cb_gemm_nn_trunkbwd_f32) — the dX GEMM + the layer-below's trunk backward in one kernel.
-    g_masked: G is returned as dropout_bwd(G) (the form the trunk's input stage consumes; see cb_trunk_input_bwd_multi_f32's `premasked`)."""
-    import ctypes
-    from . import ops
-    lib = _lib.load()
-    _lib.require_device(a, b, rowscale, bits, row_scale2)
-    a, b = _rowmajor(a), _rowmajor(b)
-    M, K = a.shape
-    K2, N = b.shape
-    if K != K2 or a.dtype != torch.float32 or b.dtype != torch.float32 or N % 256:
-        raise ValueError(f'mm_nn_trunkbwd: bad operands {tuple(a.shape)} @ {tuple(b.shape)}')
-    if not want_gr and not want_colsum:
-        raise ValueError('mm_nn_trunkbwd: neither the second output nor the column sums requested')
-    g = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    gr = torch.empty((M, N), dtype=torch.float32, device=a.device) if want_gr else None      # None: column sums only
-    colsum = torch.empty(N, dtype=torch.float32, device=a.device) if want_colsum else None
-    wsb = lib.cb_gemm_nn_trunkbwd_workspace_bytes(M, N) if want_colsum else 0
-    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=a.device)
-    with torch.cuda.device(a.device):
-        _lib.check(lib.cb_gemm_nn_trunkbwd_f32(_lib.ptr(a), _ld(a), _lib.ptr(b), _ld(b), _lib.ptr(g), N, _lib.ptr(gr), N, M, N, K,
-                                               _lib.ptr(rowscale), _lib.ptr(bits), float(c_act), float(p), ctypes.c_uint64(seed),
-                                               ops.seed_dev_ptr(), int(row0), _lib.ptr(row_scale2), _lib.ptr(colsum), _lib.ptr(ws), wsb,
-                                               int(bool(g_masked)), _lib.stream_ptr()), 'cb_gemm_nn_trunkbwd_f32')
-    return g, gr, colsum
 
 
 def mm_tn(a, g, rowscale=None):

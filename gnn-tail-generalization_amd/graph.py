@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 
-HUB_THRESHOLD = int(__import__('os').environ.get('CB_HUB_THRESHOLD', 256))      # rows with more edges are reduced in chunks of this size by the hub kernels (measurement hook: CB_HUB_THRESHOLD)
+HUB_THRESHOLD = 256      # rows with more edges are reduced in chunks of this size by the hub kernels (64 / 128 / 512 / 1024 measured equal or slower)
 INT32_EDGE_LIMIT = 2 ** 31 - 1   # edge offsets (rowptr) and column ids are int32 on the device (include/coldbrew_hip.h); see CSRGraph.__init__
 HOT_BYTES = 256 << 20      # the hot source rows of an aggregation should fill the 256 MiB Infinity Cache: count = HOT_BYTES / row bytes
 HOT_ROWS = HOT_BYTES // 1024   # 262 144 rows at d = 256 fp32 (1 KiB rows): the measured optimum on S-pl10M (profiles/r02_spmm_gather_policy.md)
@@ -28,7 +28,10 @@ class _Plan:
 
 
 class CSRGraph:
-    def __init__(self, edge_index, num_nodes=None, hub_threshold=HUB_THRESHOLD):
+    def __init__(self, edge_index, num_nodes=None, hub_threshold=HUB_THRESHOLD, keep_edge_order=False):
+        """keep_edge_order: keep the int64 edge list (16 bytes per edge) so that edge_perm() can map CSR positions back to columns of
+        edge_index — needed only by the `edge_weight` form of GCNConv.forward (GCN.py:199-202), which TricksComb never uses; the cached graph
+        of the training path is built without it (nothing but the CSR outlives the ingest)."""
         lib = _lib.load()
         _lib.require_device(edge_index)
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
@@ -47,7 +50,7 @@ class CSRGraph:
         N = int(num_nodes)
         self.N, self.E, self.device = N, E, dev
         self.n_cols, self.row_offset = N, 0
-        self._ei, self._perm, self._perm_t = ei, None, None      # edge ids behind the CSR positions are derived on demand (edge_weight only)
+        self._ei, self._perm, self._perm_t = (ei.clone() if keep_edge_order and ei.data_ptr() == edge_index.data_ptr() else ei) if keep_edge_order else None, None, None
         self.hub_threshold = int(hub_threshold)
         self.rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
         self.col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
@@ -87,7 +90,7 @@ class CSRGraph:
         row size being gathered, HOT_BYTES / (d * element bytes) — keep the default cache policy, every other gather streams.
         self.col / self.col_t stay the plain ids (the bit-exact CSR contract).  col_k / col_t_k hold the arrays for 1 KiB rows
         (d = 256 fp32, built eagerly); other row sizes (bf16-stored rows, d = 512) are flagged on first use (flagged_cols).
-        CB_SPMM_GATHER=0 (measurement hook) switches the flags off, CB_SPMM_HOT_ROWS overrides the count for every row size."""
+        CB_SPMM_GATHER=0 switches the flags off (every gather then uses the default cache policy)."""
         import os
         self.col_k = self.col_t_k = None
         self._hot_cache = {}
@@ -96,9 +99,7 @@ class CSRGraph:
         self.col_k, self.col_t_k = self._flag_pair(self._hot_count(1024))
 
     def _hot_count(self, row_bytes):
-        import os
-        k = int(os.environ.get('CB_SPMM_HOT_ROWS', 0)) or HOT_BYTES // max(int(row_bytes), 1)
-        return max(1, min(k, self.n_cols))
+        return max(1, min(HOT_BYTES // max(int(row_bytes), 1), self.n_cols))
 
     def _flag_pair(self, k):
         hit = self._hot_cache.get(k)
@@ -275,20 +276,21 @@ class CSRGraph:
                                                           src_elem=2 if bf16 else 4), 0))
         return out
 
-    def spmm_gemm_trunkbwd(self, h, image, g_rowscale, bits, c_act, p, seed, row0, rowscale2, want_colsum, transpose=True, g_masked=False):
+    def spmm_gemm_trunkbwd(self, h, image, g_rowscale, bits, c_act, p, seed, row0, rowscale2, want_colsum, transpose=True, acc_init=None):
         """(out, g, gr, colsum) of cb_spmm_gemm_trunkbwd_f32: out = A h (raw sums), g = g_rowscale * (out @ B) and, from the same epilogue, the
-        trunk backward of the layer below: gr = c_act * dropout_bwd(g) * bits * rowscale2, colsum = column sums of the unscaled gr."""
+        trunk backward of the layer below: gr = c_act * dropout_bwd(g) * bits * rowscale2, colsum = column sums of the unscaled gr.
+        acc_init: partial sums of the earlier passes of a node-sharded aggregation (the row sums start from them; overwritten by `out`)."""
         import ctypes
         from . import ops
         lib = _lib.load()
-        _lib.require_device(h, image, g_rowscale, bits, rowscale2)
+        _lib.require_device(h, image, g_rowscale, bits, rowscale2, acc_init)
         d = h.shape[1] if h.dim() == 2 else -1
         if h.dtype != torch.float32 or d != 256 or h.shape[0] != self.n_cols or h.stride(1) != 1:
             raise ValueError(f'spmm_gemm_trunkbwd: float32 [{self.n_cols}, 256] rows expected, got {tuple(h.shape)} {h.dtype}')
         if bits.dtype != torch.int64 or tuple(bits.shape) != (self.N, 1, 4) or not bits.is_contiguous():
             raise ValueError('spmm_gemm_trunkbwd: int64 [N, 1, 4] mask words expected')
         dev = h.device
-        out = torch.empty((self.N, d), dtype=torch.float32, device=dev)
+        out = self._acc_out(acc_init, d, dev)
         g = torch.empty((self.N, 256), dtype=torch.float32, device=dev)
         gr = torch.empty((self.N, 256), dtype=torch.float32, device=dev)
         colsum = torch.empty(256, dtype=torch.float32, device=dev) if want_colsum else None
@@ -306,11 +308,12 @@ class CSRGraph:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         with torch.cuda.device(dev):
-            _lib.check(lib.cb_spmm_gemm_trunkbwd_f32(_lib.ptr(rowptr), _lib.ptr(col), flags, self.N, self.E, _lib.ptr(h), h.stride(0), d, _lib.ptr(out), d,
+            _lib.check(lib.cb_spmm_gemm_trunkbwd_f32(_lib.ptr(rowptr), _lib.ptr(col), flags, self.N, self.E, _lib.ptr(h), h.stride(0), d,
+                                                     _lib.ptr(acc_init), acc_init.stride(0) if acc_init is not None else 0, _lib.ptr(out), d,
                                                      self.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr),
                                                      _lib.ptr(ws), ws_bytes, _lib.ptr(image), _lib.ptr(g_rowscale), _lib.ptr(g), 256, _lib.ptr(bits),
                                                      float(c_act), float(p), ctypes.c_uint64(seed), ops.seed_dev_ptr(), int(row0), _lib.ptr(rowscale2),
-                                                     _lib.ptr(gr), 256, _lib.ptr(colsum), _lib.ptr(ws2), ws2b, int(bool(g_masked)), _lib.stream_ptr()),
+                                                     _lib.ptr(gr), 256, _lib.ptr(colsum), _lib.ptr(ws2), ws2b, _lib.stream_ptr()),
                        'cb_spmm_gemm_trunkbwd_f32')
         if prof is not None:
             ev1.record()
@@ -345,7 +348,7 @@ class CSRGraph:
         the (row, col) keys, i.e. the order cb_csr_from_coo_i64 lays the edges out in (duplicates of a multigraph keep their input
         order; which duplicate sits where is immaterial for sums over them).  Needed only by the edge_weight form (GCN.py:199-202)."""
         if getattr(self, '_ei', None) is None:
-            raise ValueError('edge permutation requested on a CSR that was not built from an edge list')
+            raise ValueError('edge permutation requested on a graph built without keep_edge_order=True (CSRGraph(edge_index, n, keep_edge_order=True))')
         which = '_perm_t' if transpose else '_perm'
         if getattr(self, which) is None:
             src, dst = self._ei[0], self._ei[1]
@@ -390,18 +393,19 @@ class CSRGraph:
                        'cb_spmm_edge_dot_f32')
         return dw[:self.E]
 
-    def spmm_gemm(self, h, image, transpose=False, row_scale=None, bias=None, relu=False, g_rowscale=None, g_addend=None):
+    def spmm_gemm(self, h, image, transpose=False, row_scale=None, bias=None, relu=False, g_rowscale=None, g_addend=None, acc_init=None):
         """(out, g_out): out = act(row_scale * (A h) + bias) as spmm() and, from the same kernel, g_out = g_rowscale * (out @ B) +
         g_addend with B the 256 x 256 matrix behind `image` (weight_image) — cb_spmm_gemm_f32: a block keeps its 64 aggregated rows
-        in LDS and multiplies them on the matrix cores while other blocks gather."""
+        in LDS and multiplies them on the matrix cores while other wavefronts gather.  acc_init (fp32 [N, 256], overwritten by `out`): the
+        partial sums of the earlier passes of a node-sharded aggregation — the last halo pass then also yields the next dense transform."""
         lib = _lib.load()
-        _lib.require_device(h, image, row_scale, bias, g_rowscale, g_addend)
+        _lib.require_device(h, image, row_scale, bias, g_rowscale, g_addend, acc_init)
         d = h.shape[1] if h.dim() == 2 else -1
         if h.dtype != torch.float32 or d != 256 or h.shape[0] != self.n_cols or h.stride(1) != 1:
             raise ValueError(f'spmm_gemm: float32 [{self.n_cols}, 256] rows expected, got {tuple(h.shape)} {h.dtype}')
         if transpose and self.rowptr_t is None:
             raise ValueError('this graph holds the forward orientation only')
-        out = torch.empty((self.N, d), dtype=torch.float32, device=h.device)
+        out = self._acc_out(acc_init, d, h.device)
         g_out = torch.empty((self.N, 256), dtype=torch.float32, device=h.device)
         rowptr, col, plan = (self.rowptr_t, self.col_t, self._plan_t) if transpose else (self.rowptr, self.col, self._plan)
         col_k = self.flagged_cols(transpose, d * 4)
@@ -418,7 +422,8 @@ class CSRGraph:
             g_addend = g_addend.contiguous()
         with torch.cuda.device(h.device):
             _lib.check(lib.cb_spmm_gemm_f32(_lib.ptr(rowptr), _lib.ptr(col), flags, self.N, self.E, _lib.ptr(h), h.stride(0), d,
-                                            _lib.ptr(row_scale), _lib.ptr(bias), int(bool(relu)), _lib.ptr(out), d, self.hub_threshold,
+                                            _lib.ptr(row_scale), _lib.ptr(bias), int(bool(relu)), _lib.ptr(acc_init),
+                                            acc_init.stride(0) if acc_init is not None else 0, _lib.ptr(out), d, self.hub_threshold,
                                             plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws),
                                             ws_bytes, _lib.ptr(image), _lib.ptr(g_rowscale), _lib.ptr(g_addend),
                                             g_addend.stride(0) if g_addend is not None else 0, _lib.ptr(g_out), 256, _lib.stream_ptr()),
@@ -430,40 +435,13 @@ class CSRGraph:
                          self.N * 256 * 4 * (2 if g_addend is not None else 1) + (4 * self.N if g_rowscale is not None else 0)))
         return out, g_out
 
-    def spmm_masked(self, h, src_bits, src_scale, out_coef, transpose=True):
-        """out[v] = out_coef * sum_{u in row v} src_scale[u] * (src_bits[u] ? h[u] : 0) (cb_spmm_csr_masked_f32): the reverse
-        aggregation of the fused trunk's backward with the layer-below's store backward applied to the gathered rows."""
-        lib = _lib.load()
-        _lib.require_device(h, src_bits, src_scale)
-        d = h.shape[1]
-        if (h.dtype != torch.float32 or h.dim() != 2 or h.shape[0] != self.n_cols or d % 256 or h.stride(1) != 1
-                or src_bits.dtype != torch.int64 or tuple(src_bits.shape) != (self.n_cols, d // 256, 4) or not src_bits.is_contiguous()
-                or src_scale.dtype != torch.float32 or src_scale.numel() != self.n_cols or not src_scale.is_contiguous()):
-            raise ValueError('spmm_masked: float32 [n_cols, d] rows (d % 256 == 0), int64 [n_cols, d/256, 4] mask words, float32 [n_cols] scales')
-        if transpose and self.rowptr_t is None:
-            raise ValueError('this graph holds the forward orientation only')
-        out = torch.empty((self.N, d), dtype=torch.float32, device=h.device)
-        rowptr, col, plan = (self.rowptr_t, self.col_t, self._plan_t) if transpose else (self.rowptr, self.col, self._plan)
-        col_k = self.col_t_k if transpose else self.col_k
-        flags = int(col_k is not None and h.data_ptr() % 16 == 0 and h.stride(0) % 4 == 0)
-        if flags:
-            col = col_k
-        ws_bytes = lib.cb_spmm_workspace_bytes(plan.n_chunks, d)
-        ws = self._workspace(ws_bytes)
-        prof = self.profile
-        if prof is not None:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
-        with torch.cuda.device(h.device):
-            _lib.check(lib.cb_spmm_csr_masked_f32(_lib.ptr(rowptr), _lib.ptr(col), flags, self.N, self.E, _lib.ptr(h), h.stride(0), d,
-                                                  _lib.ptr(src_bits), _lib.ptr(src_scale), float(out_coef), _lib.ptr(out), d,
-                                                  self.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows),
-                                                  _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
-                       'cb_spmm_csr_masked_f32')
-        if prof is not None:
-            ev1.record()
-            prof.append((ev0, ev1, self.algorithmic_bytes(d, row_scale=False, bias=False), 0))
-        return out
+    def _acc_out(self, acc_init, d, device):
+        """Output matrix of an aggregation that starts from partial sums: the sums themselves (in place), else a fresh [N, d] matrix."""
+        if acc_init is None:
+            return torch.empty((self.N, d), dtype=torch.float32, device=device)
+        if acc_init.dtype != torch.float32 or tuple(acc_init.shape) != (self.N, d) or acc_init.stride(1) != 1 or acc_init.stride(0) % 4:
+            raise ValueError('acc_init must be a float32 [N, d] matrix with contiguous, 16-byte aligned rows')
+        return acc_init
 
     def algorithmic_bytes(self, d, elem=4, row_scale=True, bias=True, src_elem=None):
         """E*(d*s+4) + N*(d*s+4) [+4N row scale] [+d*s bias]; src_elem = bytes per gathered element

@@ -55,7 +55,8 @@ class trainer:
         """TEACHER SIDE of the reference's train_seMLP_part1 (:66-87) — everything up to the point where the student MLP takes over:
             train_teacherGNN()                       (:71; with 'SEMLP' in train_which the best-test-accuracy weights are saved, :331-334)
             load_teacherGNN('best checkpoint')       (:72)
-            teacherSE = collect_SE(x, edge_index)    (:87, GCN.py:148-150: per-layer pre-activation outputs, [N, sum d_l])
+            teacherSE = collect_SE(x, edge_index)    (:87, GCN.py:148-150: per-layer pre-activation outputs, [N, sum d_l]; TRAIN mode,
+                                                      as in the reference: the freshly built module is never put into eval mode)
         and the hand-off the student consumes: `self.teacherSE`, written to <modeldir>/teacherSE.pt, and `self.replacement(le_guess)`
         = SEMLP.replacement (MLP_model/__init__.py:143-156) on the fused scores + top-K + softmax-combine kernel.  The student MLP
         trainers themselves (part-1 regression onto teacherSE, part 2) are outside this path; returns the teacher's
@@ -63,7 +64,11 @@ class trainer:
         print('-' * 30, '\n         Training TeacherGNN before train SEMLP\n', '-' * 30)
         rows = self.train_teacherGNN()
         self.load_teacherGNN('best checkpoint')
-        self.teacherGNN.eval()
+        # The reference never calls eval() here: load_teacherGNN builds a NEW module (train mode), so the targets are drawn with the
+        # dropout of GCN.py:104,110,133 ACTIVE (:87).  Same mode here; the masks come from the product's counter-based
+        # generator (seeds from torch's CPU stream: torch.manual_seed makes the hand-off reproducible), since torch's own dropout stream
+        # cannot be matched on any device.  collect_SE returns detached clones (GCN.py:124), so no graph is kept.
+        self.teacherGNN.train()
         with torch.no_grad():
             self.teacherSE = self.teacherGNN.model.model.collect_SE(self.data.x, self.data.edge_index).detach()
         self.topK_2_replace = int(self.args.SEMLP_topK_2_replace)
@@ -350,13 +355,21 @@ class trainer:
             # Adam as one graph launch
             self._headtail_metrics()
             self._hip_graph.replay()
-            return self._graph_loss.item(), linkp_train, linkp_test
+            return self._checked(self._graph_loss.item()), linkp_train, linkp_test
         loss = self.training_loss()
         self._headtail_metrics()
         self.optimizer.zero_grad()
         loss.backward()
         self.optimizer.step()
-        return loss.item(), linkp_train, linkp_test
+        return self._checked(loss.item()), linkp_train, linkp_test
+
+    @staticmethod
+    def _checked(value):
+        """The loss has just been read (host synchronisation): a device-side error recorded by a kernel of this step — a tile hand-over
+        of the aggregation + GEMM kernel that timed out — is raised here instead of training on (include/coldbrew_hip.h, cb_device_status)."""
+        from . import _lib
+        _lib.device_status()
+        return value
 
     def _headtail_metrics(self):
         """bag['head_tail_iso'] of run_trainSet (:397-413): accuracy (x100, rounded as cal_acc_rounded100 does) of a second train-mode

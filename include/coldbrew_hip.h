@@ -34,9 +34,20 @@ extern "C" {
 #define CB_E_RANGE (-2)     /* size does not fit the int32 index contract              */
 #define CB_E_WORKSPACE (-3) /* workspace too small                                     */
 #define CB_E_HIP (-4)       /* a HIP runtime call / kernel launch failed               */
+#define CB_E_DEVICE (-5)    /* a kernel recorded a device-side error (cb_device_status) */
+
+/* device-side error codes (first int of the device error word) */
+#define CB_DEVERR_HANDOVER 1 /* the LDS tile hand-over of the aggregation + GEMM kernel gave up its bounded wait */
 
 int cb_version(void);
 const char* cb_last_error(void);
+/* Device-side errors are never silent: a kernel that gives up a bounded wait (the only such wait is the LDS tile hand-over of the
+ * cb_spmm_gemm_* kernels: a lost hand-over would otherwise mean wrong numbers in a training run that has no parity test beside it)
+ * records the reason in a word of device-visible host memory.  Every later cb_spmm_gemm_* call returns CB_E_DEVICE until
+ * cb_device_status() has been called; cb_device_status() returns CB_OK, or CB_E_DEVICE with the reason in cb_last_error(), and clears
+ * the word.  It does not synchronise — call it after the synchronisation that ends a step.  New relative to the reference (torch raises
+ * on device faults by itself; GNN_model/GCN.py:238 + :225 are the work of those kernels). */
+int cb_device_status(void);
 
 /* ------------------------------------------------------------------------------------
  * Graph ingest — replaces `dgl.graph((src_list, dst_list))` built through Python lists
@@ -187,24 +198,6 @@ int cb_gemm_nn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, flo
 int cb_gemm_nn_drop2_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, float* C2, int64_t ldc2,
                          int64_t M, int64_t N, int64_t K, const float* rowscale, const float* addend, int64_t ld_add, const float* bias,
                          int relu, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, void* ws, size_t ws_bytes, void* stream);
-/* The dX GEMM of a GCNConv (or of the output Linear) with the backward of the fused aggregation store of the layer below
- * applied by the same epilogue (what cb_trunk_layer_bwd_f32 with gx0 = NULL does in a pass of its own):
- *     G  = rowscale * (A @ B)                                   dL/dx_l   (kept: the input stage gathers it later)
- *     GR = c_act * dropout_bwd_seed(G) * relu_bits * row_scale2  input of the reverse aggregation of layer l-1
- *     colsum[n] = sum_m (the same without row_scale2)            bias gradient of layer l-1 (may be NULL)
- * GR may be NULL when colsum is given: only the column sums leave the epilogue (the reverse aggregation then applies the store
- * backward to the rows it gathers, cb_spmm_csr_masked_f32; pass drop_p = 0 and c_act / (1 - p): the mask words carry the keep bits).
- * Autograd of th.matmul GCN.py:225 / nn.Linear :138 followed by autograd of F.dropout :110,133, InitialConnection
- * res_tricks.py:23 and F.relu :128.  N % 256 == 0.  ws: cb_gemm_nn_trunkbwd_workspace_bytes(M, N) (column-sum partials).
- * Falls back to cb_gemm_nn_f32 + cb_trunk_layer_bwd_f32 when the fused epilogue does not cover the shape.
- * g_masked != 0: G itself is stored as its dropout backward keep(seed, m, n) * G / (1 - p) — the only form the residual trunk consumes it in
- * (cb_trunk_input_bwd_multi_f32 with the matching `premasked` bit draws no mask for it). */
-size_t cb_gemm_nn_trunkbwd_workspace_bytes(int64_t M, int64_t N);
-int cb_gemm_nn_trunkbwd_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* G, int64_t ldg, float* GR, int64_t ldgr,
-                            int64_t M, int64_t N, int64_t K, const float* rowscale, const uint64_t* relu_bits, float c_act, float drop_p,
-                            uint64_t seed, const uint64_t* seed_dev, int64_t row0, const float* row_scale2, float* colsum, void* ws,
-                            size_t ws_bytes, int32_t g_masked, void* stream);
-
 /* C[K1,K2] = sum_m A[m,K1] * rowscale[m] * G[m,K2] — the weight gradients (autograd of GCN.py:225 and
  * of nn.Linear): a reduction over the node axis, split into row slabs whose partial products are summed
  * in a fixed order (ws: cb_gemm_tn_workspace_bytes).  rowscale may be NULL. */
@@ -249,11 +242,10 @@ int cb_trunk_input_bwd_f32(const float* g, const float* add, const float* act, f
  *     out = ( dropout_bwd_seed(g) + c_mix * sum_{l < n_mix} dropout_bwd_seeds_mix[l](g_mix[l]) ) * (act > 0)
  * g_mix[l] = gradient w.r.t. the output of layer l's fused store (host array of n_mix <= 7 device pointers); used with
  * cb_trunk_layer_bwd_f32(gx0 = NULL).  Autograd of GCN.py:104-110 + res_tricks.py:23 for every layer at once.
- * premasked: bit l set = g_mix[l] already IS dropout_bwd_seeds_mix[l](.) (written so by cb_spmm_gemm_trunkbwd_f32 / cb_gemm_nn_trunkbwd_f32 with
- * g_masked): no mask is drawn for it.  act_bits (may be NULL): [rows][d / 256][4] mask words of (act > 0) used instead of act (act may then be NULL). */
+ * act_bits (may be NULL): [rows][d / 256][4] mask words of (act > 0) used instead of act (act may then be NULL). */
 int cb_trunk_input_bwd_multi_f32(const float* g, uint64_t seed, int32_t n_mix, const float* const* g_mix, const uint64_t* seeds_mix,
                                  float c_mix, const float* act, float* out, int64_t rows, int64_t d, float drop_p,
-                                 const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes, uint32_t premasked,
+                                 const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes,
                                  const uint64_t* act_bits, void* stream);
 
 /* ------------------------------------------------------------------------------------
@@ -276,18 +268,6 @@ int cb_spmm_csr_fused_bf16_f32(const int32_t* rowptr, const int32_t* col, int32_
                                uint64_t* relu_bits, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
                                int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
                                const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream);
-
-/* Reverse aggregation of the fused trunk's backward with the layer-below's store backward applied to every GATHERED row:
- *     out[v] = out_coef * sum_{u in row v of the CSR} src_scale[u] * (src_bits[u] ? h[u] : 0)
- * = cb_trunk_layer_bwd_f32 (autograd of F.dropout GCN.py:110,133, InitialConnection res_tricks.py:23, F.relu GCN.py:128, `* norm`
- * :250) followed by cb_spmm_csr_f32 on the reverse CSR (autograd of the DGL aggregation :238), without the [N, d] intermediate.
- * src_bits: the mask words cb_spmm_csr_fused_f32 wrote for the source rows ([n_cols][d/256][4], bit set = element passes: ReLU
- * positive AND kept by the dropout); src_scale [n_cols]; out_coef = c_act / (1 - p).  fp32, d % 256 == 0, 16-byte aligned rows.
- * col_flags as in cb_spmm_csr_f32. */
-int cb_spmm_csr_masked_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h,
-                           int64_t d, const uint64_t* src_bits, const float* src_scale, float out_coef, float* out, int64_t ld_out,
-                           int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
-                           const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Normalisation tricks (GNN_model/norm_tricks.py) as fused reductions; all matrices contiguous [rows, d].
@@ -391,14 +371,6 @@ int cb_symmetrize_i64(const int64_t* src, const int64_t* dst, int64_t E, int64_t
  * all-to-all of the node-sharded halo exchange (new; the reference is single-device). */
 int cb_gather_rows_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, float* out, void* stream);
 
-/* The aggregation + GEMM kernels are persistent (one block per CU).  A caller that launches them on a stream confined to a CU subset
- * (hipExtStreamCreateWithCUMask) states the number of CUs of that stream here; 0 = all CUs of the device (default).  New relative to the
- * reference (scheduling of GNN_model/GCN.py:238 + :225 on this device). */
-int cb_agg_gemm_set_cu_limit(int32_t n_cus);
-/* A HIP stream confined to the CUs whose bit is set in mask[0 .. words) (bit i of word j = CU 32 j + i): hipExtStreamCreateWithCUMask.  The
- * trunk backward runs the weight-gradient GEMMs (MFMA-bound) on one such stream beside the aggregation chain (HBM-bound) on the complement. */
-int cb_stream_create_cu_mask(const uint32_t* mask, int32_t words, void** stream);
-
 /* ------------------------------------------------------------------------------------
  * Aggregation + the NEXT dense transform in one kernel (csrc/cb_agg_gemm.hip): a block aggregates 64 rows exactly as
  * cb_spmm_csr_f32 / cb_spmm_csr_fused_f32 do (same stores: the aggregated matrix still goes to memory), keeps them in LDS and
@@ -409,19 +381,27 @@ int cb_stream_create_cu_mask(const uint32_t* mask, int32_t words, void** stream)
  * (cb_spmm_csr_f32 on the reverse CSR + cb_gemm_nn_f32 with W^T).  d must be 256; fp32 rows, 16-byte aligned.
  * image: B split once into bf16 limbs in MFMA fragment order by cb_agg_gemm_image_f32 (transpose = 1: B = W^T);
  * cb_agg_gemm_image_bytes(256, 256) bytes, 16-byte aligned, L2 resident (384 KB).
+ * acc_init (may be NULL; [N, ld_init] fp32, may alias the aggregated output): the reduction of a row starts from these partial sums — the
+ * LAST pass of a node-sharded aggregation (cb_spmm_csr_acc_f32 / cb_spmm_csr_fused_acc_f32 + the GEMM), so that a rank's last halo pass
+ * also produces the next layer's Z / this layer's dX.
+ * A tile hand-over that times out is recorded in the device error word (cb_device_status); these calls return CB_E_DEVICE while it is set.
  * ---------------------------------------------------------------------------------- */
 size_t cb_agg_gemm_image_bytes(int64_t K, int64_t N);
 int cb_agg_gemm_image_f32(const float* W, int64_t ld, int64_t K, int64_t N, int transpose, void* image, size_t image_bytes, void* stream);
 int cb_spmm_gemm_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h, int64_t d,
-                     const float* row_scale, const float* bias, int relu, float* out, int64_t ld_out, int32_t hub_threshold, int32_t n_hubs,
-                     int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, const void* image,
-                     const float* g_rowscale, const float* g_addend, int64_t ld_add, float* g_out, int64_t ld_gout, void* stream);
-int cb_spmm_gemm_fused_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h,
-                           int64_t d, const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix, float c_act,
-                           float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits,
-                           float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
+                     const float* row_scale, const float* bias, int relu, const float* acc_init, int64_t ld_init, float* out, int64_t ld_out,
+                     int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,
+                     size_t ws_bytes, const void* image, const float* g_rowscale, const float* g_addend, int64_t ld_add, float* g_out,
+                     int64_t ld_gout, void* stream);
+int cb_spmm_gemm_fused_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N,
+                           int64_t E, const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias, const float* mix_src,
+                           int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0,
+                           uint64_t* relu_bits, float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
                            const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, const void* image,
                            const float* g_rowscale, const float* g_addend, int64_t ld_add, float* g_out, int64_t ld_gout, void* stream);
+/* Fault injection for the failure path above (tests): one wavefront waits with a short spin bound for a hand-over that never comes;
+ * cb_device_status() must then report CB_E_DEVICE. */
+int cb_agg_gemm_handover_selftest(void* stream);
 
 /* Edge-weighted aggregation — the `edge_weight` argument of GCNConv.forward (GNN_model/GCN.py:199-202: fn.u_mul_e + fn.sum):
  *     out[v, :] = act( row_scale[v] * sum_{j in row v} w[j] * h[col[j], :] + bias[:] ),   w in CSR order ([E], fp32)
@@ -453,14 +433,14 @@ int cb_gemm_tn_gdrop_f32(const float* A, int64_t lda, const float* G, int64_t ld
  * aggregation) and colsum = the column sums of the same without rowscale2 (bias gradient of layer l-1) — what cb_trunk_layer_bwd_f32
  * computes in a pass of its own (autograd of GCN.py:127-133,250-253), without its 10 GB read of g_out.  relu_bits: the mask words
  * cb_spmm_csr_fused_f32 wrote for layer l-1 ([N][4], d = 256).  ws2: cb_spmm_gemm_trunkbwd_workspace_bytes() (partial column sums).
- * g_masked != 0: g_out is stored as keep(seed, m, n) * g_out / (1 - p), see cb_gemm_nn_trunkbwd_f32. */
+ * acc_init: as for cb_spmm_gemm_f32 (node-sharded: the last halo pass of the reverse aggregation). */
 size_t cb_spmm_gemm_trunkbwd_workspace_bytes(void);
 int cb_spmm_gemm_trunkbwd_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h,
-                              int64_t d, float* out, int64_t ld_out, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
-                              const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, const void* image,
-                              const float* g_rowscale, float* g_out, int64_t ld_gout, const uint64_t* relu_bits, float c_act, float drop_p,
-                              uint64_t seed, const uint64_t* seed_dev, int64_t row0, const float* rowscale2, float* gr_out, int64_t ld_gr,
-                              float* colsum, void* ws2, size_t ws2_bytes, int32_t g_masked, void* stream);
+                              int64_t d, const float* acc_init, int64_t ld_init, float* out, int64_t ld_out, int32_t hub_threshold,
+                              int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes,
+                              const void* image, const float* g_rowscale, float* g_out, int64_t ld_gout, const uint64_t* relu_bits, float c_act,
+                              float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, const float* rowscale2, float* gr_out,
+                              int64_t ld_gr, float* colsum, void* ws2, size_t ws2_bytes, void* stream);
 
 /* One label-propagation step, elementwise passes folded into the aggregation's store (Label_propagation_model/outcome_correlation.py:137-143
  * with alpha_term and post_step = clamp(0, 1), as trainer_node_classification.py:33-63 drives it):

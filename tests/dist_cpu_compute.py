@@ -38,6 +38,9 @@ class OracleCompute:
         rows = x.index_select(0, idx)
         return rows.to(torch.bfloat16) if wire == 'bf16' else rows
 
+    def to_wire(self, x, wire):
+        return x.to(torch.bfloat16) if wire == 'bf16' else x
+
     def act_bwd(self, g, act, row_scale, need_b):
         gm = g * (act > 0) if act is not None else g
         return (gm * row_scale.unsqueeze(1) if row_scale is not None else gm), (gm.sum(0) if need_b else None)

@@ -33,7 +33,7 @@ def _setup(rank, world, port):
     torch.set_num_threads(1)
 
 
-def _worker(rank, world, port, name, q, exchange, overlap, kind, wire='f32', n_slices=None, chunked=False):
+def _worker(rank, world, port, name, q, exchange, overlap, kind, wire='f32', n_slices=None, chunked=False, cover=False):
     _setup(rank, world, port)
     try:
         import coldbrew_oracle as orc
@@ -48,9 +48,23 @@ def _worker(rank, world, port, name, q, exchange, overlap, kind, wire='f32', n_s
             part = cbdist.Partition.balanced(torch.from_numpy(csr.in_deg), world, rank, node_weight=2)
         else:
             part = cbdist.Partition(n, world, rank)
-        sg = cbdist.ShardedGraph(ei, n, part, exchange=exchange, overlap=overlap, compute=OracleCompute(), wire=wire, n_slices=n_slices)
+        sg = cbdist.ShardedGraph(ei, n, part, exchange=exchange, overlap=overlap, compute=OracleCompute(), wire=wire, n_slices=n_slices, cover=cover)
         assert sg.overlap == (overlap and exchange == 'halo' and world > 1)
-        if exchange == 'halo' and world > 1:
+        assert sg.cover == (bool(cover) and sg.overlap)
+        if sg.cover:
+            # push / pull cover: never more rows than the pull, every remote edge served exactly once (a pulled source keeps its edges on
+            # the requester, a pushed destination has one edge to its partial row and its edges in the owner's send CSR)
+            plan = sg.f.plan
+            assert plan.cover and plan.n_slices == (n_slices or 1) and len(sg.f.halo) == plan.n_slices == len(plan.send_csr)
+            assert 0 < plan.n_halo == plan.n_pulled + plan.n_pushed <= plan.n_pull_only and sum(plan.recv_counts_all) == plan.n_halo
+            assert [sum(c) for c in plan.send_counts] == plan.n_send_slice and sum(plan.send_counts_all) == sum(plan.n_send_slice)
+            served = torch.tensor([sum(h.E for h in sg.f.halo) - plan.n_pushed + sum(c.E for c in plan.send_csr) - sum(plan.n_send_slice),
+                                   sg.E - sg.f.interior.E, plan.n_pushed, sum(plan.n_send_slice), plan.n_pulled])
+            dist.all_reduce(served)
+            # sum over ranks: (pulled edges kept by requesters) + (edges summed by owners beyond one per shipped row) + (rows shipped)
+            #                 - (pulled rows, which are one-edge rows of the send CSRs) == remote edges
+            assert int(served[0]) + int(served[3]) - int(served[4]) == int(served[1]), served.tolist()
+        elif exchange == 'halo' and world > 1:
             plan = sg.f.plan
             assert plan.n_halo > 0 and sum(plan.recv_counts_all) == plan.n_halo == sum(plan.n_halo_slice)
             assert plan.n_halo <= csr.N - part.n_local
@@ -171,6 +185,48 @@ def test_sliced_exchange_pipeline_matches_unsharded_oracle(name, world, n_slices
 
 def test_sliced_exchange_bf16_wire():
     _run(_worker, 2, 'case_graph_powerlaw_d7_d64', 'halo', True, 'edges', 'bf16', 3, True)
+
+
+@pytest.mark.parametrize('name,world,n_slices,kind,wire', [
+    ('case_graph_powerlaw_d7_d64', 2, 1, 'edges', 'f32'), ('case_graph_powerlaw_d7_d64', 3, 4, 'edges', 'f32'),
+    ('case_graph_asym_multi', 2, 3, 'edges', 'f32'),            # directed multigraph: own reverse plan, duplicate edges counted
+    ('case_graph_asym_multi', 3, 7, 'rows', 'f32'),             # more slices than some lists have rows (empty slices)
+    ('case_r_initialbn_se111_L3_powerlaw', 2, 2, 'edges', 'f32'), ('case_graph_powerlaw_d7_d64', 2, 2, 'edges', 'bf16')])
+def test_push_pull_cover_exchange_matches_unsharded_oracle(name, world, n_slices, kind, wire):
+    """per rank pair a vertex cover of the remote-edge bipartite graph decides which source rows are shipped (pull)
+    and which destination rows arrive as owner-side partial sums (push); the send buffer is an aggregation over a send CSR, the time
+    slices cut a pair's list by position.  Forward, backward (own reverse plan on the directed multigraph) and every gradient equal the
+    unsharded oracle's within the fp32 contract; never more rows on a link than the pull; every remote edge served exactly once."""
+    _run(_worker, world, name, 'halo', True, kind, wire, n_slices, True, True)
+
+
+def test_cover_heuristic_never_worse_than_pull_or_push():
+    """choose_cover on hand-made pair graphs: a star (one hub destination: push one row instead of pulling its leaves), its mirror (one hub
+    source: pull one row), a perfect matching (pull, by the tie rule) and a dense block (all-pull fallback: the heuristic alone would open
+    both sides)."""
+    from gnn_tail_generalization_amd.dist import choose_cover
+
+    def rows_moved(u, v, pull):
+        return len(set(u[pull].tolist())) + len(set(v[~pull].tolist()))
+    z = lambda n: torch.zeros(n, dtype=torch.int64)      # noqa: E731  (one owner: index 0 of a world of 2)
+    u, v = torch.arange(6), z(6)                                          # 6 sources -> 1 destination
+    pull = choose_cover(u, v, z(6), z(1), 6, 1, 2)
+    assert rows_moved(u, v, pull) == 1 and not pull.any()
+    u, v = z(6), torch.arange(6)                                          # 1 source -> 6 destinations
+    pull = choose_cover(u, v, z(1), z(6), 1, 6, 2)
+    assert rows_moved(u, v, pull) == 1 and pull.all()
+    u = v = torch.arange(5)                                               # matching
+    pull = choose_cover(u, v, z(5), z(5), 5, 5, 2)
+    assert rows_moved(u, v, pull) == 5 and pull.all()
+    gen = torch.Generator().manual_seed(0)
+    u, v = torch.randint(0, 40, (2000,), generator=gen), torch.randint(0, 50, (2000,), generator=gen)       # dense 40 x 50 block
+    pull = choose_cover(u, v, z(40), z(50), 40, 50, 2)
+    assert rows_moved(u, v, pull) <= 40
+    # two hubs + leaves on both sides: the cover beats both pure forms
+    u = torch.cat([torch.arange(10), z(10) + 10, torch.tensor([11])])
+    v = torch.cat([z(10), torch.arange(1, 11), torch.tensor([11])])
+    pull = choose_cover(u, v, z(12), z(12), 12, 12, 2)
+    assert rows_moved(u, v, pull) == 3
 
 
 @pytest.mark.parametrize('overlap', [True, False])

@@ -134,11 +134,71 @@ def test_reverse_aggregation_gemm_trunk_backward_equals_three_kernels(n, T, p):
     torch.testing.assert_close(cs, ref_cs, atol=1e-4 * float(ref_cs.abs().max()) + 1e-5, rtol=1e-5)
     _, _, _, none = G.spmm_gemm_trunkbwd(gr_in, weight_image(w, transpose=True), a, bits, 0.9, p, 777, 0, b, False)
     assert none is None
-    # g_masked: dL/dx leaves as its dropout backward (the form the trunk's input stage consumes), everything else unchanged
-    from gnn_tail_generalization_amd import ops
-    out_m, g_m, gr_m, cs_m = G.spmm_gemm_trunkbwd(gr_in, weight_image(w, transpose=True), a, bits, 0.9, p, 777, 0, b, True, g_masked=True)
-    assert torch.equal(out_m, ref_out) and torch.equal(gr_m, ref_gr) and torch.equal(cs_m, cs)
-    assert torch.equal(g_m, ops._dropout_raw(ref_g, p, 777, 0) if p > 0 else ref_g)
+
+
+def test_lost_tile_hand_over_is_reported_not_silent():
+    """VERDICT r03 item 1b / ADVICE r03: a wavefront that gives up the bounded wait for an LDS tile hand-over records it in the device error
+    word; cb_device_status() (and every later cb_spmm_gemm_* launch) returns CB_E_DEVICE with the reason, then the word is clear again.
+    Fault injection: cb_agg_gemm_handover_selftest waits, with a short spin bound, for a counter nobody increments."""
+    from gnn_tail_generalization_amd import _lib, gemm
+    from gnn_tail_generalization_amd.graph import weight_image
+    lib = _lib.load()
+    torch.cuda.synchronize()
+    _lib.device_status()                                       # clear
+    G = _powerlaw_graph(5003, 3, 256)
+    h = torch.randn(5003, 256, device=DEV)
+    img = weight_image(torch.randn(256, 256, device=DEV))
+    ref = G.spmm_gemm(h, img)
+    with torch.cuda.device(DEV):
+        _lib.check(lib.cb_agg_gemm_handover_selftest(_lib.stream_ptr()), 'cb_agg_gemm_handover_selftest')
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.HipExtensionError, match='device-side error'):      # the NEXT launch refuses to run on top of invalid results
+        G.spmm_gemm(h, img)
+    with pytest.raises(_lib.HipExtensionError, match='hand-over timed out'):
+        _lib.device_status()
+    _lib.device_status()                                       # cleared by the report
+    out = G.spmm_gemm(h, img)
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+
+
+@pytest.mark.parametrize('n,T,p,fused', [(5003, 16, 0.1, True), (20000, 256, 0.0, True), (70001, 64, 0.2, False), (777, 8, 0.3, False)])
+def test_acc_init_forms_equal_the_two_kernel_forms(n, T, p, fused):
+    """The ACC forms (node-sharded path: the last halo pass of a rank's aggregation is the aggregation + GEMM kernel on top of the running
+    sums of the earlier passes): cb_spmm_gemm_f32 / cb_spmm_gemm_fused_f32 / cb_spmm_gemm_trunkbwd_f32 with acc_init are bit-identical to
+    cb_spmm_csr_acc_f32 / cb_spmm_csr_fused_acc_f32 followed by cb_gemm_nn_f32 (and cb_trunk_layer_bwd_f32) — hub rows included (the hub
+    finish kernel adds the partial sums of its rows)."""
+    from gnn_tail_generalization_amd import _lib, gemm, trunk
+    from gnn_tail_generalization_amd.graph import weight_image
+    G = _powerlaw_graph(n, 5, T)
+    gen = torch.Generator(device=DEV).manual_seed(17)
+    h = torch.randn(n, 256, device=DEV, generator=gen)
+    acc = torch.randn(n, 256, device=DEV, generator=gen)
+    w = torch.randn(256, 256, device=DEV, generator=gen) * 0.07
+    bias = torch.randn(256, device=DEV, generator=gen)
+    le = torch.randn(n, 256, device=DEV, generator=gen)
+    x0 = torch.randn(n, 256, device=DEV, generator=gen)
+    a, b = G.norm_out, G.norm_in
+    if fused:
+        lib = _lib.load()
+        ref_bits, ref_next, _ = trunk._fused_launch(lib, G, G, h, acc.clone(), bias, x0, 0.9, 0.1, p, 4242, False)
+        bits, nxt, zn = trunk._fused_gemm_launch(G, h, bias, x0, 0.9, 0.1, p, 4242, weight_image(w), a, le, g=G, acc=acc.clone())
+        assert torch.equal(bits, ref_bits) and torch.equal(nxt, ref_next)
+        assert torch.equal(zn, gemm.mm_nn(ref_next, w, rowscale=a, addend=le))
+    else:
+        ref = G.spmm(h, row_scale=b, bias=bias, relu=True, acc_init=acc.clone())
+        buf = acc.clone()
+        out, g = G.spmm_gemm(h, weight_image(w), row_scale=b, bias=bias, relu=True, g_rowscale=a, g_addend=le, acc_init=buf)
+        assert out.data_ptr() == buf.data_ptr()               # the running sums are finished in place
+        assert torch.equal(out, ref) and torch.equal(g, gemm.mm_nn(ref, w, rowscale=a, addend=le))
+        # + the trunk backward from the tail's epilogue
+        bits, _, _ = trunk._fused_spmm(G, h, bias, None, 1.0, 0.0, p, 777)
+        ref_out = G.spmm(h, acc_init=acc.clone())
+        ref_g = gemm.mm_nn(ref_out, w.t().contiguous(), rowscale=a)
+        ref_gr, ref_cs = trunk._layer_bwd(ref_g, bits, b, None, False, p, 777, 0, 0.9, 0.1, True)
+        out, g, gr, cs = G.spmm_gemm_trunkbwd(h, weight_image(w, transpose=True), a, bits, 0.9, p, 777, 0, b, True, transpose=False,
+                                              acc_init=acc.clone())
+        assert torch.equal(out, ref_out) and torch.equal(g, ref_g) and torch.equal(gr, ref_gr)
+        torch.testing.assert_close(cs, ref_cs, atol=1e-4 * float(ref_cs.abs().max()) + 1e-5, rtol=1e-5)
 
 
 def _step_losses(monkeypatch, flag, steps=3, n=30000):
@@ -172,39 +232,22 @@ def _step_losses(monkeypatch, flag, steps=3, n=30000):
 def test_training_step_with_fused_kernels_equals_two_kernel_form(monkeypatch):
     """Three optimisation steps of the 3-layer 'Initial' trunk (hidden 256, structural embeddings on, dropout on) with the
     aggregation + GEMM kernels (CB_AGG_GEMM=1, default) and with the separate kernels (=0): same losses and parameters, bit for bit —
-    with the trunk backward kept as a pass of its own; with it in the fused kernel's epilogue (default) the bias gradients are summed
-    in another order, so parameters agree to rounding instead."""
-    from gnn_tail_generalization_amd import trunk
+    with the trunk backward kept as a pass of its own (one-GPU default); with it in the fused kernel's epilogue (CB_AGG_GEMM_TRUNKBWD=1, the
+    node-sharded default) the bias gradients are summed in another order, so parameters agree to rounding instead."""
     l0, sd0 = _step_losses(monkeypatch, '0')
-    monkeypatch.setattr(trunk, 'TAIL_TRUNK_BWD', False)
+    monkeypatch.setenv('CB_AGG_GEMM_TRUNKBWD', '0')
     l1, sd1 = _step_losses(monkeypatch, '1')
     assert l1 == l0
     for k in sd0:
         assert torch.equal(sd1[k], sd0[k]), k
-    monkeypatch.setattr(trunk, 'TAIL_TRUNK_BWD', True)
+    monkeypatch.delenv('CB_AGG_GEMM_TRUNKBWD')
+    l1b, sd1b = _step_losses(monkeypatch, '1')                 # default == '0' on one GPU
+    assert l1b == l0 and all(torch.equal(sd1b[k], sd0[k]) for k in sd0)
+    monkeypatch.setenv('CB_AGG_GEMM_TRUNKBWD', '1')
     l2, sd2 = _step_losses(monkeypatch, '1')
     np.testing.assert_allclose(l2, l0, rtol=1e-6)
     for k in sd0:
         torch.testing.assert_close(sd2[k], sd0[k], atol=1e-5, rtol=1e-4, msg=lambda m, k=k: f'{k}: {m}')
-    # the backward on CU-partitioned streams (chain on 3/4 of the CUs, weight-gradient GEMMs beside it on the rest; streams.py) — forced on for
-    # this small graph: the same kernels on the same data, bit for bit
-    monkeypatch.setattr(trunk, 'TAIL_TRUNK_BWD', False)
-    monkeypatch.setattr(trunk, 'OVERLAP_MIN_ROWS', 0)
-    monkeypatch.setenv('CB_BWD_OVERLAP', '1')
-    l4, sd4 = _step_losses(monkeypatch, '1')
-    assert l4 == l0
-    for k in sd0:
-        assert torch.equal(sd4[k], sd0[k]), k
-    monkeypatch.setattr(trunk, 'OVERLAP_MIN_ROWS', 1 << 40)
-    monkeypatch.setenv('CB_BWD_OVERLAP', '0')
-    monkeypatch.setattr(trunk, 'TAIL_TRUNK_BWD', True)
-    # + the output Linear's dX GEMM with the same epilogue, gradients stored as their dropout backward (CB_TRUNK_FUSE_OUT_BWD, CB_TRUNK_PREMASKED)
-    monkeypatch.setattr(trunk, 'FUSE_OUT_BWD', True)
-    monkeypatch.setattr(trunk, 'PREMASKED', True)
-    l3, sd3 = _step_losses(monkeypatch, '1')
-    np.testing.assert_allclose(l3, l0, rtol=1e-6)
-    for k in sd0:
-        torch.testing.assert_close(sd3[k], sd0[k], atol=1e-5, rtol=1e-4, msg=lambda m, k=k: f'{k}: {m}')
 
 
 def test_fused_kernels_against_the_oracle(monkeypatch):

@@ -115,31 +115,50 @@ def test_fused_aggregation_store_full_size(pl10m_graph):
     assert _max_abs_diff_inplace(ref_act, nxt) <= 1e-5
 
 
-def test_masked_reverse_aggregation_full_size(pl10m_graph):
-    """cb_spmm_csr_masked_f32 at N = 10^7, d = 256 (the store backward applied to the gathered rows, mask words written by the
-    fused forward store with dropout on) == cb_trunk_layer_bwd_f32 followed by the plain reverse aggregation; the column sums
-    that leave the dX GEMM's epilogue (second output off) == the ones of the separate pass."""
-    from gnn_tail_generalization_amd import gemm, trunk
+def test_aggregation_gemm_kernels_full_size(pl10m_graph):
+    """the dominant kernel of the headline bench AT the headline size.  cb_spmm_gemm_f32 (both orientations, with the
+    row scale / bias / ReLU epilogue, the dense tail's row scale and addend) and cb_spmm_gemm_fused_f32 (trunk._fused_gemm_launch: fused
+    store + next layer's transform) at N = 10^7, E = 10^8, d = 256 are BIT-identical to the two kernels each replaces — cb_spmm_csr_f32 /
+    cb_spmm_csr_fused_f32 followed by cb_gemm_nn_f32, which are pinned to the oracle at small sizes (test_gpu_graph_spmm.py,
+    test_gpu_kernels.py) and by properties at this size (above).  39 063 tiles per launch on 256 persistent blocks: ~153 uses of every LDS
+    buffer per block; the hand-over's error word must stay clear."""
+    from gnn_tail_generalization_amd import _lib, gemm, trunk
+    from gnn_tail_generalization_amd.graph import weight_image
     G = pl10m_graph
-    n, d, p, seed, alpha = G.N, 256, 0.1, 0xABCDE, 0.1
-    gen = torch.Generator(device=DEV).manual_seed(21)
-    z = torch.randn(n, d, device=DEV, generator=gen)
-    bias = torch.randn(d, device=DEV, generator=gen)
-    bits, nxt, _ = trunk._fused_spmm(G, z, bias, None, 1.0, 0.0, p, seed)
-    del nxt, z
-    src = torch.randn(n, d, device=DEV, generator=gen)
+    n, d = G.N, 256
+    gen = torch.Generator(device=DEV).manual_seed(31)
+    h = torch.randn(n, d, device=DEV, generator=gen)
     w = torch.randn(d, d, device=DEV, generator=gen) * 0.06
-    coef = (1 - alpha) / (1 - p)
-    g, none, cs = gemm.mm_nn_trunkbwd(src, w, G.norm_out, bits, coef, 0.0, 0, 0, None, True, want_gr=False)
-    assert none is None and torch.equal(g, gemm.mm_nn(src, w, rowscale=G.norm_out))
-    del src
-    gr, cs_ref = trunk._layer_bwd(g, bits, G.norm_in, None, False, p, seed, 0, 1 - alpha, alpha, True)
-    torch.testing.assert_close(cs, cs_ref, atol=2e-2, rtol=2e-4)            # 10^7-term sums in two different partial orders
-    ref = G.spmm(gr, transpose=True)
-    del gr
-    got = G.spmm_masked(g, bits, G.norm_in, coef)
-    scale = float(ref.abs().max())
-    assert _max_abs_diff_inplace(got, ref) <= 2e-6 * scale
+    bias = torch.randn(d, device=DEV, generator=gen)
+    le = torch.randn(n, d, device=DEV, generator=gen)
+    a = G.norm_out
+    for tr in (False, True):
+        img = weight_image(w, transpose=tr)
+        out, g = G.spmm_gemm(h, img, transpose=tr, row_scale=G.norm_in, bias=bias, relu=True, g_rowscale=a, g_addend=le)
+        ref = G.spmm(h, transpose=tr, row_scale=G.norm_in, bias=bias, relu=True)
+        assert torch.equal(out, ref)
+        del out
+        ref_g = gemm.mm_nn(ref, w.t().contiguous() if tr else w, rowscale=a, addend=le)
+        del ref
+        assert torch.equal(g, ref_g)
+        del g, ref_g
+    # the backward's form: raw sums, dense tail with the row scale only
+    out, g = G.spmm_gemm(h, weight_image(w, transpose=True), transpose=True, g_rowscale=a)
+    ref = G.spmm(h, transpose=True)
+    assert torch.equal(out, ref)
+    del out
+    assert torch.equal(g, gemm.mm_nn(ref, w.t().contiguous(), rowscale=a))
+    del g, ref
+    # forward form: fused trunk store (ReLU / mix / dropout, mask words) + Z_next
+    x0 = torch.randn(n, d, device=DEV, generator=gen)
+    p, seed, alpha = 0.1, 0x5EED77, 0.1
+    bits, nxt, zn = trunk._fused_gemm_launch(G, h, bias, x0, 1 - alpha, alpha, p, seed, weight_image(w), a, le)
+    bits_r, nxt_r, _ = trunk._fused_spmm(G, h, bias, x0, 1 - alpha, alpha, p, seed)
+    assert torch.equal(bits, bits_r) and torch.equal(nxt, nxt_r)
+    del bits, bits_r, nxt, x0
+    assert torch.equal(zn, gemm.mm_nn(nxt_r, w, rowscale=a, addend=le))
+    torch.cuda.synchronize()
+    _lib.device_status()              # raises if any tile hand-over timed out
 
 
 def test_trunk_backward_kernels_full_size(pl10m_graph):
@@ -217,17 +236,17 @@ def _teacher(argv, dataset, n_override=None, dropout=0.0, seed=0):
 
 def test_fused_step_equals_modular_step_s_pl1m():
     """One full training step (dropout on) of the fused trunk vs the modular operator path on S-pl1M (10^6 nodes,
-    10^7 edge_index columns): logits, loss and every weight gradient agree — also with the opt-in backward in which the reverse
-    aggregation applies the store backward to the rows it gathers (CB_TRUNK_MASKED_GATHER=1)."""
+    10^7 edge_index columns): logits, loss and every weight gradient agree — also with the trunk backward of the layer below in the
+    epilogue of the reverse aggregation + dX kernel (CB_AGG_GEMM_TRUNKBWD=1: the node-sharded default)."""
     from gnn_tail_generalization_amd import ops, trunk
     from gnn_tail_generalization_amd.GNN_model.GCN import TricksComb
     args, model, data = _teacher(['--num_layers=3', '--use_special_split=0', '--whetherHasSE=000'], 'S-pl1M', dropout=0.1)
     assert model.model.model.type_trick == 'InitialBatchNorm' and data.x.shape[0] == 1_000_000
     res = {}
-    keep_masked = trunk.MASKED_GATHER
-    for mode in ('fused', 'masked', 'modular'):
+    import os
+    for mode in ('fused', 'tailtb', 'modular'):
         TricksComb.use_fused_trunk = mode != 'modular'
-        trunk.MASKED_GATHER = mode == 'masked'
+        os.environ['CB_AGG_GEMM_TRUNKBWD'] = '1' if mode == 'tailtb' else '0'
         try:
             model.train()
             model.zero_grad()
@@ -240,8 +259,8 @@ def test_fused_step_equals_modular_step_s_pl1m():
                          {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
         finally:
             TricksComb.use_fused_trunk = True
-            trunk.MASKED_GATHER = keep_masked
-    for mode, tol in (('fused', 1e-4), ('masked', 3e-4)):       # masked: fma accumulation + coefficient applied after the row sum
+            os.environ.pop('CB_AGG_GEMM_TRUNKBWD', None)
+    for mode, tol in (('fused', 1e-4), ('tailtb', 1e-4)):
         torch.testing.assert_close(res[mode][0], res['modular'][0], atol=5e-5, rtol=1e-5)
         torch.testing.assert_close(res[mode][1], res['modular'][1], atol=1e-6, rtol=1e-6)
         assert set(res[mode][2]) == set(res['modular'][2])

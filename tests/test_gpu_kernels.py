@@ -396,45 +396,6 @@ def test_gemm_dropout_copy_epilogue_matches_two_kernels(M, K, p):
         assert torch.equal(yd, y)
 
 
-@pytest.mark.parametrize('M,K,p', [(5000, 256, 0.3), (1031, 40, 0.0), (70001, 256, 0.1), (300, 128, 0.5), (32768, 256, 0.2)])
-def test_gemm_trunk_backward_epilogue_matches_two_kernels(M, K, p):
-    """cb_gemm_nn_trunkbwd_f32 (dX GEMM + the layer-below's trunk backward in one epilogue) == cb_gemm_nn_f32 followed by
-    cb_trunk_layer_bwd_f32: same G bit for bit, same GR (the Philox keep-mask and the ReLU bits index the same elements), bias
-    column sums within the tolerance of a different partial order; ragged M (partial last row block), K = 40 (output Linear)."""
-    from gnn_tail_generalization_amd import gemm, trunk
-    torch.manual_seed(M)
-    N = 256
-    a = torch.randn(M, K, device=DEV)
-    b = torch.randn(K, N, device=DEV)
-    rs = torch.rand(M, device=DEV) + 0.5
-    rs2 = torch.rand(M, device=DEV) + 0.5
-    act = torch.randn(M, N, device=DEV)
-    bits = torch.zeros((M, 1, 4), dtype=torch.int64, device=DEV)
-    pos = act > 0
-    for kk in range(4):
-        bits[:, 0, kk] = (pos[:, kk::4].to(torch.int64) << torch.arange(64, device=DEV, dtype=torch.int64)).sum(dim=1)
-    seed, row0, c_act = 991 + M, 12345, 0.9
-    g, gr, cs = gemm.mm_nn_trunkbwd(a, b, rs, bits, c_act, p, seed, row0, rs2, True)
-    g_ref = gemm.mm_nn(a, b, rowscale=rs)
-    assert torch.equal(g, g_ref)
-    gr_ref, cs_ref = trunk._layer_bwd(g_ref, bits, rs2, None, False, p, seed, row0, c_act, 0.1, True)
-    torch.testing.assert_close(gr, gr_ref, atol=1e-6, rtol=1e-6)
-    torch.testing.assert_close(cs, cs_ref, atol=1e-3 * (M ** 0.5), rtol=1e-4)
-    # no column sums requested
-    g2, gr2, none = gemm.mm_nn_trunkbwd(a, b, rs, bits, c_act, p, seed, row0, rs2, False)
-    assert none is None and torch.equal(gr2, gr)
-    # g_masked: G leaves as its dropout backward (cb_dropout_f32 of the plain G, bit for bit), GR / column sums unchanged; the input stage
-    # takes it with its `premasked` bit and reproduces the pass that draws the mask itself
-    from gnn_tail_generalization_amd import ops
-    g3, gr3, cs3 = gemm.mm_nn_trunkbwd(a, b, rs, bits, c_act, p, seed, row0, rs2, True, g_masked=True)
-    assert torch.equal(g3, ops._dropout_raw(g_ref, p, seed, row0 * N) if p > 0 else g_ref)
-    assert torch.equal(gr3, gr) and torch.equal(cs3, cs)
-    top = torch.randn(M, N, device=DEV)
-    o_a, c_a = trunk._input_bwd_multi(top, seed + 5, [g_ref, act], [seed, seed + 9], 0.1, act, p, row0)
-    o_b, c_b = trunk._input_bwd_multi(top, seed + 5, [g3, act], [seed, seed + 9], 0.1, act, p, row0, premasked=1)
-    assert torch.equal(o_a, o_b) and torch.equal(c_a, c_b)
-
-
 @pytest.mark.parametrize('M,K,N,row0', [(40000, 128, 256, 0), (33001, 100, 256, 77)])
 def test_operand_dropout_gemms_equal_dropout_then_gemm(M, K, N, row0):
     """the dropout of the input features applied by the input Linear's GEMM while it stages x

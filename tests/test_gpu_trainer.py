@@ -276,7 +276,7 @@ def test_teacher_side_of_semlp_part1_handoff(tmp_path):
     """--train_which=SEMLP runs the teacher side of the reference's train_seMLP_part1 (:66-87) as one path —
     train_teacherGNN (best-test-accuracy weights saved, :331-334) -> load_teacherGNN('best checkpoint') -> collect_SE -> the
     replacement hand-off — and every link is checked: the best checkpoint is the state of the best epoch, teacherSE equals the
-    ORACLE's collect_SE of those weights, replacement() equals the oracle's restatement of SEMLP.replacement (same selections)."""
+    ORACLE's TRAIN-mode collect_SE of those weights (the reference draws the targets with dropout active), replacement() equals the oracle's restatement of SEMLP.replacement (same selections)."""
     import contextlib
     import io
     import os
@@ -291,7 +291,14 @@ def test_teacher_side_of_semlp_part1_handoff(tmp_path):
                                                 '--want_headtail=0', '--use_special_split=0', '--do_deg_analyze=0', '--manual_assign_GPU=0'])
             torch.manual_seed(0)
             t = trainer(args, 0)
-            rows = t.main()
+            # dropout seeds of the hand-off forward (drawn after training from torch's CPU stream) are recorded as they are drawn
+            from gnn_tail_generalization_amd import ops
+            drawn, real_next = [], ops.next_seed
+            ops.next_seed = lambda: drawn.append(real_next()) or drawn[-1]
+            try:
+                rows = t.main()
+            finally:
+                ops.next_seed = real_next
         K = args.SEMLP_topK_2_replace          # 2 by default; 3 only under --unify_mlps (base_options.py:450-471)
         assert rows.shape == (1, 6) and K == 2 and t.topK_2_replace == K
         files = set(os.listdir(t.modeldir))
@@ -304,7 +311,17 @@ def test_teacher_side_of_semlp_part1_handoff(tmp_path):
         cfg = orc.make_cfg(type_trick=args.type_trick, num_layers=args.num_layers, num_feats=args.num_feats, dim_hidden=args.dim_hidden,
                            num_classes=args.num_classes, res_alpha=args.res_alpha, whetherHasSE=tuple(args.TeacherGNN.whetherHasSE))
         csr = orc.build_csr(t.data.edge_index.cpu(), n)
-        _, _, les = orc.trickscomb_forward(cfg, orc.strip_prefix(best), t.data.x.cpu(), csr, training=False, want_les=True)
+        # ... in TRAIN mode, as the reference draws them (its load_teacherGNN builds a new module and never calls eval(): ADVICE r03), with
+        # the product's keep-masks of that forward injected into the oracle (the last L + 2 seeds drawn: x, X0, the layer outputs)
+        assert t.teacherGNN.training and args.dropout > 0
+        L, H, F_ = args.num_layers, args.dim_hidden, args.num_feats
+        shapes = [(n, F_)] + [(n, H)] * L + [(n, H)]
+        seeds = drawn[-len(shapes):]
+        masks = [ops.dropout_keep_mask(sh, args.dropout, sd_, DEV).cpu() for sh, sd_ in zip(shapes, seeds)]
+        cfg.dropout = args.dropout
+        _, _, les = orc.trickscomb_forward(cfg, orc.strip_prefix(best), t.data.x.cpu(), csr, training=True, dropout_masks=masks, want_les=True)
+        _, _, les_eval = orc.trickscomb_forward(cfg, orc.strip_prefix(best), t.data.x.cpu(), csr, training=False, want_les=True)
+        assert float((les - les_eval).abs().max()) > 1e-3          # the dropout really is part of the targets
         assert tuple(t.teacherSE.shape) == tuple(les.shape) and t.teacherSE.shape[1] == t.teacherGNN.model.model.get_se_dim(t.data.x, t.data.edge_index)
         torch.testing.assert_close(t.teacherSE.cpu(), les, atol=1e-4, rtol=1e-4)
         saved = torch.load(os.path.join(t.modeldir, 'teacherSE.pt'), weights_only=True)

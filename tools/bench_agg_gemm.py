@@ -1,5 +1,5 @@
 """Aggregation + dense tail in one kernel (cb_spmm_gemm_f32) against its two parts on the headline graph, HIP events.
-usage: python tools/bench_agg_gemm.py [--iters 5]     (CB_AGG_GEMM_DBG = 1 / 2 / 4 / 3 ... : measurement variants of the dense tail)"""
+usage: python tools/bench_agg_gemm.py [--iters 5]"""
 import argparse
 import os
 import sys
@@ -38,7 +38,6 @@ def main():
     h = torch.rand(G.N, 256, device=dev)
     w = torch.rand(256, 256, device=dev) * 0.1
     img = weight_image(w)
-    dbg = os.environ.get('CB_AGG_GEMM_DBG', '0')
     if a.parts:
         out = G.spmm(h)
         t_s = timed(lambda: G.spmm(h), a.iters)
@@ -46,7 +45,7 @@ def main():
         print(f'aggregation alone {t_s[0]:.2f} ms (best {t_s[1]:.2f}); GEMM alone {t_g[0]:.2f} ms (best {t_g[1]:.2f}); sum {t_s[0] + t_g[0]:.2f} ms', flush=True)
         del out
     t_f = timed(lambda: G.spmm_gemm(h, img, g_rowscale=G.norm_out), a.iters)
-    print(f'CB_AGG_GEMM_DBG={dbg}: aggregation + dense tail in one kernel (incl. hub kernels) {t_f[0]:.2f} ms (best {t_f[1]:.2f})', flush=True)
+    print(f'aggregation + dense tail in one kernel (incl. hub kernels) {t_f[0]:.2f} ms (best {t_f[1]:.2f})', flush=True)
 
 
 if __name__ == '__main__':
