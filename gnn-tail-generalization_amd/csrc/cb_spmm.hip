@@ -123,6 +123,7 @@ static int spmm_plain_impl(const char* who, const int32_t* rowptr, const int32_t
                CB_E_WORKSPACE, "%s: hub plan given but workspace missing/too small (%zu < %zu)", who, ws_bytes,
                cb_spmm_workspace_bytes(n_chunks, d));
   Epilogue ep{row_scale, bias, relu, acc_init, ld_init, col_flags};
+  ep.acc_skip_empty = acc_init && acc_init == out && ld_init == ld_out && !row_scale && !bias && !relu;      // raw in-place pass: rows without edges stay untouched
   CB_CHECK_ARG(!col_flags || d % 256 == 0, CB_E_INVALID, "%s: flagged column ids need d %% 256 == 0", who);
   hipStream_t st = (hipStream_t)stream;
   if (n_hubs == 0) hub_T = INT32_MAX;  // no plan given (or no hub rows): every row is reduced whole by one wavefront
@@ -278,6 +279,7 @@ static int spmm_bf16_impl(const char* who, const int32_t* rowptr, const int32_t*
   const bool al8 = ((uintptr_t)h % 8 == 0) && ((uintptr_t)out % 16 == 0) && (ld_h % 4 == 0) && (ld_out % 4 == 0) && (d % 4 == 0) && ini16;
   CB_CHECK_ARG(!col_flags || (al8 && d % 256 == 0), CB_E_INVALID, "%s: flagged column ids need d %% 256 == 0 and 8-byte aligned rows", who);
   Epilogue ep{row_scale, bias, relu, acc_init, ld_init, col_flags};
+  ep.acc_skip_empty = acc_init && acc_init == out && ld_init == ld_out && !row_scale && !bias && !relu;
   hipStream_t st = (hipStream_t)stream;
   if (n_hubs == 0) hub_T = INT32_MAX;
   const bf16_t* hb = (const bf16_t*)h;

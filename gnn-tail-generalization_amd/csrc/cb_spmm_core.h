@@ -119,6 +119,10 @@ struct Epilogue {
   int64_t ld_lp;
   float lp_c_mix;
   const float* lp_post;     // [N] or null
+  // ACC kernels, raw in-place accumulation only (out == acc_init, no scale / bias / ReLU: the intermediate halo passes of the node-sharded
+  // aggregation): a row without edges in THIS CSR keeps its running sums as they are — neither read nor written (a halo slice touches only a
+  // fraction of the rows; the passes are otherwise bound by reading and re-writing all of them)
+  int acc_skip_empty;
 };
 
 template <int VEC>
@@ -238,8 +242,9 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
   const bool active = FULL ? true : active_in;
   float ainit[VEC];                          // ACC: partial sums of local row `cur`, fetched one row ahead (read once: streaming)
   zero<VEC>(ainit);
+  const bool skip_empty = ACC && !FUSED && ep.acc_skip_empty;
   if constexpr (ACC) {
-    if (active) gather_stream<VEC>(ainit, init_lane + (int64_t)(r0 + rlo) * ld_init);
+    if (active && !(skip_empty && my_ptr_at(rlo) == my_ptr_at(rlo + 1))) gather_stream<VEC>(ainit, init_lane + (int64_t)(r0 + rlo) * ld_init);
   }
   float rmix[4] = {0.f, 0.f, 0.f, 0.f};   // FUSED: mix_src row of local row `cur`, fetched one row ahead
   if constexpr (FUSED) {
@@ -258,12 +263,22 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
   float acc[VEC];
   zero<VEC>(acc);
 
+  int cur_begin = e_begin;                   // first edge of local row `cur`
   auto flush = [&]() {
     const float s = __int_as_float(bcast_lane(__float_as_int(my_scale), cur));  // row scale of local row `cur`
     if constexpr (ACC) {
+      const int nxt_end = my_ptr_at(cur + 2);      // (clamped beyond the block's last row: lanes past nr hold the block's end pointer)
+      const bool fetch_next = active && cur + 1 < rhi && !(skip_empty && cur_end == nxt_end);
+      if (skip_empty && cur_begin == cur_end) {      // raw in-place pass, row without edges here: its running sums stay untouched
+        if (fetch_next) gather_stream<VEC>(ainit, init_lane + (int64_t)(r0 + cur + 1) * ld_init);
+        ++cur;
+        cur_begin = cur_end;
+        cur_end = nxt_end;
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] += ainit[i];
-      if (active && cur + 1 < rhi) gather_stream<VEC>(ainit, init_lane + (int64_t)(r0 + cur + 1) * ld_init);
+      if (fetch_next) gather_stream<VEC>(ainit, init_lane + (int64_t)(r0 + cur + 1) * ld_init);
     }
     if constexpr (FUSED) {
       float a4[4], b4[4];
@@ -297,6 +312,7 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
     }
     zero<VEC>(acc);
     ++cur;
+    cur_begin = cur_end;
     cur_end = my_ptr_at(cur + 1);
   };
 

@@ -310,7 +310,9 @@ int cb_topk_replace_f32(const float* q, int64_t ldq, const float* t, int64_t ldt
  * rows travel over xGMI; the halo-column pass starts from those raw sums and applies the epilogue once:
  *     out[v, :] = act( row_scale[v] * (acc_init[v, :] + sum_{j in row v of THIS csr} h[col[j], :]) + bias[:] )
  * Same arguments as cb_spmm_csr_f32 / cb_spmm_csr_fused_f32 plus acc_init [N, ld_init] (fp32, read once; the plain
- * variant allows acc_init == out).  Replaces the same reference lines as those two (GCN.py:198,238-253,127-133).
+ * variant allows acc_init == out; a raw in-place pass — acc_init == out, no row scale / bias / ReLU: the intermediate halo slices —
+ * neither reads nor writes rows that have no edge in this CSR).  Replaces the same reference lines as those two
+ * (GCN.py:198,238-253,127-133).
  * ---------------------------------------------------------------------------------- */
 int cb_spmm_csr_acc_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h, int64_t d,
                         const float* row_scale, const float* bias, int relu, const float* acc_init, int64_t ld_init, float* out,

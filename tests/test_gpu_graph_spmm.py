@@ -247,3 +247,32 @@ def test_edge_weight_form_matches_reference(name):
     h = torch.randn(n, 600, device=DEV)
     ones = torch.ones(G.E, device=DEV)
     torch.testing.assert_close(G.spmm_weighted(h, ones, False, row_scale=G.norm_in), G.spmm(h, row_scale=G.norm_in), atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('d,dtype', [(256, torch.float32), (512, torch.float32), (40, torch.float32), (7, torch.float32), (256, torch.bfloat16)])
+def test_in_place_accumulation_skips_rows_without_edges(d, dtype):
+    """Intermediate halo passes of the node-sharded aggregation: cb_spmm_csr_acc_f32 with out == acc_init and no epilogue neither reads nor
+    writes rows that have no edge in the slice's CSR.  A rectangular CSR in which most rows are empty (runs of empty rows at the start, in the
+    middle and at the end of wavefront row blocks, a hub row, an empty row right after a hub row) gives, in place, exactly the out-of-place
+    sums — and the same through the bf16-stored source rows of the bf16 wire."""
+    from gnn_tail_generalization_amd.graph import CSRGraph
+    n_rows, n_cols = 3001, 777
+    gen = torch.Generator(device=DEV).manual_seed(d)
+    rows = torch.randint(0, n_rows, (2500,), device=DEV, generator=gen)
+    rows = rows[(rows % 16 != 3) & (rows % 16 != 4) & (rows < 2900) & ((rows < 1000) | (rows >= 1100))]      # holes: rows 1000..1099, 2900.. and two per block
+    rows = torch.cat([rows, torch.full((700,), 41, device=DEV)])                                              # a hub row (T = 256); row 42 has few or no edges
+    cols = torch.randint(0, n_cols, (rows.numel(),), device=DEV, generator=gen)
+    G = CSRGraph.from_pairs(rows, cols, n_rows, n_cols)
+    assert G._plan.n_hubs >= 1 and int((G.in_degrees() == 0).sum()) > n_rows // 3
+    h = torch.randn(n_cols, d, device=DEV, generator=gen).to(dtype)
+    acc = torch.randn(n_rows, d, device=DEV, generator=gen)
+    want = G.spmm(h, acc_init=acc.clone(), out=torch.empty_like(acc))       # out-of-place: every row written
+    assert torch.equal(want[G.in_degrees() == 0], acc[G.in_degrees() == 0])
+    buf = acc.clone()
+    got = G.spmm(h, acc_init=buf, out=buf)
+    assert got.data_ptr() == buf.data_ptr() and torch.equal(got, want)
+    # with an epilogue nothing is skipped (every row gets its scale / bias)
+    rs = torch.rand(n_rows, device=DEV, generator=gen) + 0.5
+    buf2 = acc.clone()
+    got2 = G.spmm(h, row_scale=rs, acc_init=buf2, out=buf2)
+    torch.testing.assert_close(got2, want * rs.unsqueeze(1), atol=1e-5, rtol=1e-5)

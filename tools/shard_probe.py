@@ -1,21 +1,27 @@
-"""What one rank of a P-way node-sharded run does per aggregation, measured on ONE MI355X (no multi-GPU box needed):
-builds rank r's row block of the synthetic graph exactly as dist.ShardedGraph does (edge-balanced partition, interior /
-halo column split, halo plan cut into K time slices by owner row chunk, incl. the exact send lists derived from every other
-rank's request list), times the LOCAL kernels of the sliced pipeline with HIP events at d = 256 (row-chunk layer GEMM, pack per
-slice — fp32 and bf16 out —, interior pass, per-slice halo passes chained through the running sums, the last one with the
-epilogue) and turns the halo byte counts into predicted link times.
+"""What one rank of a P-way node-sharded run does per aggregation, measured on ONE MI355X (no multi-GPU box needed): builds rank r's
+row block of the synthetic graph as dist.ShardedGraph does — edge-balanced partition, interior / halo column split, the exchange plan
+INCLUDING the owner side (what every other rank asks of rank r) — times the LOCAL kernels of the sliced pipeline with HIP events at
+d = 256 and turns the rows on the busiest peer link into predicted link times.
 
-    python tools/shard_probe.py [--name S-pl10M] [--d 256] [--worlds 1,2,4,8] [--rank 0] [--slices 4] [--link-gbs 153] [--link-eff 0.8]
-                                [--dense-ms <ms of the non-aggregation part of the 1-GPU step>] [--partition edges|rows|degree|greedy]
+Two pipelines are probed side by side (--mode both):
+  pull   round 3's: pull-only halo plan cut by owner row chunk, row-chunked producers (layer GEMM chunk k -> pack k -> send k), interior
+         pass, per-slice halo passes (cb_spmm_csr_acc_f32), the last one with the epilogue; the layer GEMM is a kernel of its own.
+  cover  this round's default: push / pull vertex cover per rank pair (dist.choose_cover; pack = aggregation over the send CSR),
+         positional slices, and the LAST halo pass is the aggregation + GEMM kernel on top of the running sums (cb_spmm_gemm_f32 /
+         cb_spmm_gemm_fused_f32 / cb_spmm_gemm_trunkbwd_f32 with acc_init) — the next stage's matrix exists when that kernel ends.
 
-Prediction model (stated, not hidden): every ordered peer pair has its own xGMI link (7 links x 153 GB/s per GPU, full duplex),
-all-to-all traffic to different peers moves in parallel, so a slice's link time = max over peers of (bytes on that link) /
-(link_gbs * link_eff); slices queue on the links in order.  Timeline of one aggregation (dist.py):
-    compute stream:  [producer chunk k -> pack k] for k < K, interior pass, then halo pass k as soon as slice k has landed
+    python tools/shard_probe.py [--name S-pl10M] [--worlds 1,2,4,8] [--rank 0] [--slices 4] [--link-gbs 153] [--link-eff 0.8]
+                                [--n1-ms <the driver's 1-GPU ms/step>] [--mode both|pull|cover] [--halo-only 1]
+
+Prediction model (stated, not hidden): every ordered peer pair has its own xGMI link (7 links x 153 GB/s per GPU, full duplex), traffic
+to different peers moves in parallel, a slice's link time = max over peers of (bytes on that link) / (link_gbs * link_eff), slices queue
+on the links in order.  Timeline of one aggregation (dist.py):
+    compute stream:  [producer chunk k ->] pack k for k < K, interior pass, then halo pass k as soon as slice k has landed
     links:           slice k starts when pack k is done and slice k-1 has left
-The aggregation's EXPOSED time = end of the last halo pass - (time the producers alone would have taken), i.e. what the step
-pays on top of its dense part; step = dense part / P + 2L exposed aggregations; the tiny all-reduces are ignored.
-K = 1 without producers is round 2's two-pass form (pack + max(interior, exchange) + halo pass)."""
+Step = D_rest / P + sum over the 2L aggregations of (end of the last pass - producers' own time).  D_rest = what a 1-GPU step spends
+outside its aggregation (+ fused GEMM) launches, taken from the 1-GPU bench line: `pull` keeps the L layer GEMMs + L-1 dX GEMMs + trunk
+backward passes in it (--dense-pull-ms), `cover` has them inside the timed last passes (--dense-cover-ms).  Efficiency is computed against
+--n1-ms, the DRIVER's 1-GPU step, not against the probe's own P = 1 model.  The tiny all-reduces are ignored."""
 import argparse
 import json
 import os
@@ -25,11 +31,12 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gnn_tail_generalization_amd import dist as cbdist  # noqa: E402
-from gnn_tail_generalization_amd import gemm  # noqa: E402
+from gnn_tail_generalization_amd import _lib, gemm, trunk  # noqa: E402
 from gnn_tail_generalization_amd.data import synthetic_data  # noqa: E402
+from gnn_tail_generalization_amd.graph import weight_image  # noqa: E402
 
 
-def timed(fn, iters=5):
+def timed(fn, iters=4):
     fn()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
@@ -56,209 +63,285 @@ def pipeline(prod, pack, link, interior, passes):
     return t
 
 
-def relabel(kind, src, dst, n, in_deg, P):
-    """Internal relabelling (new id per node) evaluated for halo volume: 'degree' = ids sorted by in-degree (descending);
-    'greedy' = streaming LDG-style assignment (nodes in descending-degree order go to the block holding most of their already
-    placed neighbours, weighted by the remaining capacity), blocks then laid out contiguously.  Returns perm with new_id = perm[old]."""
-    dev = src.device
-    if kind == 'degree':
-        order = torch.argsort(in_deg, descending=True, stable=True)
-        perm = torch.empty(n, dtype=torch.int64, device=dev)
-        perm[order] = torch.arange(n, device=dev)
-        return perm
-    # greedy, vectorised in rounds: nodes are processed in R batches of descending degree; a batch is scored against the labels
-    # assigned so far (a streaming heuristic with a batch-sized look-back error)
-    order = torch.argsort(in_deg, descending=True, stable=True)
-    label = torch.full((n,), -1, dtype=torch.int64, device=dev)
-    cap = float(int(in_deg.sum()) + 12 * n) / P * 1.02
-    load = torch.zeros(P, dtype=torch.float64, device=dev)
-    R = 64
-    bsz = (n + R - 1) // R
-    cost = (in_deg + 12).to(torch.float64)
-    for b in range(R):
-        batch = order[b * bsz:(b + 1) * bsz]
-        if batch.numel() == 0:
-            break
-        inb = torch.zeros(n, dtype=torch.bool, device=dev)
-        inb[batch] = True
-        m = inb[dst] & (label[src] >= 0)
-        loc = torch.full((n,), -1, dtype=torch.int64, device=dev)
-        loc[batch] = torch.arange(batch.numel(), device=dev)
-        score = torch.zeros((batch.numel(), P), dtype=torch.float32, device=dev)
-        score.index_put_((loc[dst[m]], label[src[m]]), torch.ones(int(m.sum()), device=dev), accumulate=True)
-        score = (score + 1e-3) * (1.0 - load / cap).clamp(min=0).to(torch.float32).unsqueeze(0)
-        choice = score.argmax(1)
-        label[batch] = choice
-        load += torch.zeros(P, dtype=torch.float64, device=dev).index_add_(0, choice, cost[batch])
-        del inb, m, loc, score
-    order2 = torch.argsort(label * n + torch.arange(n, device=dev))          # blocks contiguous, original order inside a block
-    perm = torch.empty(n, dtype=torch.int64, device=dev)
-    perm[order2] = torch.arange(n, device=dev)
-    return perm
+def positional(n_items, K):
+    """Slice of every position of a list of n_items cut by dist.slice_weights(K) (CoverPlan's cut)."""
+    w = cbdist.slice_weights(K)
+    tot, acc, cuts = sum(w), 0.0, [0]
+    for k in range(K - 1):
+        acc += w[k]
+        cuts.append(min(n_items, int(n_items * acc / tot)))
+    cuts.append(n_items)
+    return cuts
+
+
+def pair_cover(u, v):
+    """choose_cover on ONE ordered rank pair: u / v = source / destination ids of its remote edges.  Returns (pull mask, pulled ids,
+    pushed ids, item of every edge in the pair's interleaved list, list length)."""
+    dev = u.device
+    uu, ui = torch.unique(u, return_inverse=True)
+    vv, vi = torch.unique(v, return_inverse=True)
+    z = lambda n: torch.zeros(n, dtype=torch.int64, device=dev)      # noqa: E731
+    pull = cbdist.choose_cover(ui, vi, z(uu.numel()), z(vv.numel()), int(uu.numel()), int(vv.numel()), 1)
+    S = torch.zeros(uu.numel(), dtype=torch.bool, device=dev)
+    S[ui[pull]] = True
+    T = torch.zeros(vv.numel(), dtype=torch.bool, device=dev)
+    T[vi[~pull]] = True
+    su, tv = torch.nonzero(S).reshape(-1), torch.nonzero(T).reshape(-1)
+    # interleave the two kinds in proportion (CoverPlan): position = rank of (relative rank inside the kind)
+    frac = torch.cat([(torch.arange(su.numel(), device=dev).double() + 0.5) / max(su.numel(), 1),
+                      (torch.arange(tv.numel(), device=dev).double() + 0.5) / max(tv.numel(), 1)])
+    order = torch.sort(frac, stable=True)[1]
+    pos = torch.empty_like(order)
+    pos[order] = torch.arange(order.numel(), device=dev)
+    u_item = torch.full((max(int(uu.numel()), 1),), -1, dtype=torch.int64, device=dev)
+    u_item[su] = pos[:su.numel()]
+    t_item = torch.full((max(int(vv.numel()), 1),), -1, dtype=torch.int64, device=dev)
+    t_item[tv] = pos[su.numel():]
+    item = torch.where(pull, u_item[ui], t_item[vi])
+    return pull, int(uu.numel()), int(su.numel()), int(tv.numel()), item, int(order.numel())
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--name', default='S-pl10M')
-    ap.add_argument('--d', type=int, default=256)
     ap.add_argument('--worlds', default='1,2,4,8')
     ap.add_argument('--rank', type=int, default=0)
     ap.add_argument('--slices', type=int, default=4)
     ap.add_argument('--link-gbs', type=float, default=153.0)
     ap.add_argument('--link-eff', type=float, default=0.8)
-    ap.add_argument('--dense-ms', type=float, default=113.0, help='non-aggregation part of the 1-GPU step (GEMMs, elementwise, loss, Adam)')
+    ap.add_argument('--n1-ms', type=float, default=195.7, help="the DRIVER's 1-GPU ms/step (BENCH_r03.json: 195.7): efficiency = n1 / (P * step)")
+    ap.add_argument('--dense-pull-ms', type=float, default=113.0, help='1-GPU step outside the six plain aggregations (pull pipeline: GEMMs stay kernels of their own)')
+    ap.add_argument('--dense-cover-ms', type=float, default=62.0,
+                    help='1-GPU step outside the aggregation (+ GEMM, + trunk backward) launches: 191 ms - 5 x 20.8 (fused) - 17.3 (plain) - 2 x 3.8 (trunk backward passes that move into the tails)')
     ap.add_argument('--layers', type=int, default=3)
-    ap.add_argument('--partition', default='edges', choices=['edges', 'rows', 'degree', 'greedy'])
-    ap.add_argument('--halo-only', type=int, default=0, help='1: only count halo rows / link bytes (partition study), no kernel timing')
+    ap.add_argument('--mode', default='both', choices=['both', 'pull', 'cover'])
+    ap.add_argument('--halo-only', type=int, default=0, help='1: only count rows per link (pull vs cover), no kernel timing')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     data = synthetic_data(a.name, seed=0, device=dev)
     n, E = int(data.x.shape[0]), int(data.edge_index.shape[1])
-    src0, dst0 = data.edge_index[0], data.edge_index[1]
+    src, dst = data.edge_index[0], data.edge_index[1]
     del data
-    in_deg0 = torch.bincount(dst0, minlength=n)
+    in_deg = torch.bincount(dst, minlength=n)
     comp = cbdist.HipCompute()
-    K = max(1, a.slices)
-    rows_out = []
+    K, d, L = max(1, a.slices), 256, a.layers
+    link = a.link_gbs * a.link_eff * 1e6        # bytes per ms
+    bpr = d * 4
+    out_rows = []
     for P in [int(w) for w in a.worlds.split(',')]:
         r = min(a.rank, P - 1)
-        if a.partition in ('degree', 'greedy') and P > 1:
-            perm = relabel(a.partition, src0, dst0, n, in_deg0, P)
-            src, dst = perm[src0], perm[dst0]
-            in_deg = torch.bincount(dst, minlength=n)
-            del perm
-        else:
-            src, dst, in_deg = src0, dst0, in_deg0
-        balanced = a.partition != 'rows'
-        parts = [cbdist.Partition.balanced(in_deg, P, q) if balanced else cbdist.Partition(n, P, q) for q in range(P)]
+        parts = [cbdist.Partition.balanced(in_deg, P, q) for q in range(P)]
         part = parts[r]
         lo, hi = part.lo(), part.hi()
+        n_local = hi - lo
         m = (dst >= lo) & (dst < hi)
         rr, cc = dst[m] - lo, src[m]
         del m
         remote = (cc < lo) | (cc >= hi)
-        uniq, inv = torch.unique(cc[remote], return_inverse=True)
-        n_local, n_halo, e_local = hi - lo, int(uniq.numel()), int(rr.numel())
-        # requester side: slices by owner row chunk
-        bnd = [b for q in range(P) for b in cbdist.chunk_bounds(parts[q].lo(), parts[q].hi(), K)[:-1]] + [n]
-        pos = torch.searchsorted(uniq, torch.tensor(bnd, dtype=torch.int64, device=dev))
-        cnt = (pos[1:] - pos[:-1]).view(P, K)
-        recv = cnt.t().tolist()                                                       # recv[k][q]
-        # owner side: what every other rank asks of rank r, cut at rank r's chunk bounds
-        mine = torch.tensor(cbdist.chunk_bounds(lo, hi, K), dtype=torch.int64, device=dev)
-        send = [[0] * P for _ in range(K)]
-        for q in range(P):
-            if q == r:
-                continue
-            pq = parts[q]
-            mq = (dst >= pq.lo()) & (dst < pq.hi()) & (src >= lo) & (src < hi)
-            ids = torch.unique(src[mq])
-            p2 = torch.searchsorted(ids, mine)
-            for k in range(K):
-                send[k][q] = int(p2[k + 1] - p2[k])
-            del mq, ids
-        link_rows = [max(max(recv[k]), max(send[k])) if P > 1 else 0 for k in range(K)]
-        row = {'P': P, 'rank': r, 'partition': a.partition, 'slices': K, 'rows_local': n_local, 'edges_local': e_local,
-               'halo_rows': n_halo, 'halo_frac_of_N': n_halo / n, 'send_rows': sum(sum(s) for s in send),
-               'max_link_rows': sum(link_rows), 'edges_remote': int(remote.sum())}
-        if a.halo_only:
-            rows_out.append(row)
-            print(json.dumps(row), flush=True)
-            continue
-        seg = torch.bucketize(torch.arange(n_halo, device=dev), pos[1:], right=True)
-        roff = torch.cumsum(cnt, 0) - cnt
-        base = roff.reshape(-1) - pos[:-1]
-        slice_of = (seg % K)[inv]
-        slot = (torch.arange(n_halo, device=dev) + base[seg])[inv] if n_halo else inv
-        n_k = [sum(recv[k]) for k in range(K)]
-        g_int = comp.csr(rr[~remote], cc[~remote] - lo, n_local, n_local)
-        rrem = rr[remote]
-        g_halo = [comp.csr(rrem[slice_of == k], slot[slice_of == k], n_local, max(n_k[k], 1)) for k in range(K)] if P > 1 else []
-        row['edges_interior'] = g_int.E
-        del rr, cc, remote, inv, seg, slot, slice_of, rrem
-        d = a.d
+        row = {'P': P, 'rank': r, 'rows_local': n_local, 'edges_local': int(rr.numel()), 'edges_remote': int(remote.sum()), 'slices': K}
         h = torch.rand(n_local, d, device=dev)
         scale = torch.rand(n_local, device=dev)
         bias = torch.rand(d, device=dev)
-        w = torch.rand(d, d, device=dev)
-        chunks = [(int(mine[k]) - lo, int(mine[k + 1]) - lo) for k in range(K)]
-        t_int = timed(lambda: g_int.spmm(h))
-        acc = g_int.spmm(h)
+        w = torch.rand(d, d, device=dev) * 0.06
+        x0 = torch.rand(n_local, d, device=dev)
+        g_int = comp.csr(rr[~remote], cc[~remote] - lo, n_local, n_local)
+        row['edges_interior'] = g_int.E
         if P == 1:
-            t_whole = timed(lambda: g_int.spmm(h, row_scale=scale, bias=bias, relu=True))
-            row.update({'single_gpu_aggregation_ms': t_whole, 'aggregation_exposed_ms': t_whole,
-                        'step_ms_predicted': a.dense_ms + 2 * a.layers * t_whole, 'steps_per_s_predicted': 1e3 / (a.dense_ms + 2 * a.layers * t_whole)})
-            row['steps_per_s_predicted_bf16_wire'] = row['steps_per_s_predicted']
-            rows_out.append(row)
+            img = weight_image(w)
+            g_int.norm_in = scale
+            t_plain = timed(lambda: g_int.spmm(h, row_scale=scale, bias=bias, relu=True))
+            t_fused = timed(lambda: trunk._fused_gemm_launch(g_int, h, bias, x0, 0.9, 0.1, 0.1, 7, img, scale, None))
+            row.update({'aggregation_ms': t_plain, 'aggregation_plus_gemm_ms': t_fused})
+            out_rows.append(row)
             print(json.dumps(row), flush=True)
             continue
-        z = torch.empty(n_local, d, device=dev)
-        t_gemm_whole = timed(lambda: gemm.mm_nn(h, w, rowscale=scale, out=z))
-        t_prod = [timed(lambda k=k: gemm.mm_nn(h[chunks[k][0]:chunks[k][1]], w, rowscale=scale[chunks[k][0]:chunks[k][1]], out=z[chunks[k][0]:chunks[k][1]]))
-                  for k in range(K)]
-        send_idx = [torch.randint(chunks[k][0], max(chunks[k][1], chunks[k][0] + 1), (sum(send[k]),), device=dev) for k in range(K)]
-        t_pack = [timed(lambda k=k: comp.pack_rows(h, send_idx[k])) for k in range(K)]
-        t_pack16 = [timed(lambda k=k: comp.pack_rows(h, send_idx[k], 'bf16')) for k in range(K)]
-        halos = [torch.rand(max(n_k[k], 1), d, device=dev) for k in range(K)]
-        halos16 = [t.to(torch.bfloat16) for t in halos]
+        own_c = part.owner(cc)
+        t_int = 0.0 if a.halo_only else timed(lambda: g_int.spmm(h))
+        row['interior_ms'] = t_int
+        # ============================ pull pipeline (round 3) ============================
+        if a.mode in ('both', 'pull'):
+            uniq, inv = torch.unique(cc[remote], return_inverse=True)
+            bnd = [b for q in range(P) for b in cbdist.chunk_bounds(parts[q].lo(), parts[q].hi(), K)[:-1]] + [n]
+            pos = torch.searchsorted(uniq, torch.tensor(bnd, dtype=torch.int64, device=dev))
+            cnt = (pos[1:] - pos[:-1]).view(P, K)
+            recv = cnt.t().tolist()
+            mine = torch.tensor(cbdist.chunk_bounds(lo, hi, K), dtype=torch.int64, device=dev)
+            send = [[0] * P for _ in range(K)]
+            for q in range(P):
+                if q == r:
+                    continue
+                mq = (dst >= parts[q].lo()) & (dst < parts[q].hi()) & (src >= lo) & (src < hi)
+                p2 = torch.searchsorted(torch.unique(src[mq]), mine)
+                for k in range(K):
+                    send[k][q] = int(p2[k + 1] - p2[k])
+                del mq
+            link_rows = [max(max(recv[k]), max(send[k])) for k in range(K)]
+            row['pull'] = {'halo_rows': int(uniq.numel()), 'send_rows': sum(sum(s) for s in send), 'max_link_rows': sum(link_rows)}
+            if not a.halo_only:
+                seg = torch.bucketize(torch.arange(uniq.numel(), device=dev), pos[1:], right=True)
+                roff = torch.cumsum(cnt, 0) - cnt
+                base = roff.reshape(-1) - pos[:-1]
+                slice_of = (seg % K)[inv]
+                slot = (torch.arange(uniq.numel(), device=dev) + base[seg])[inv]
+                n_k = [sum(recv[k]) for k in range(K)]
+                rrem = rr[remote]
+                g_halo = [comp.csr(rrem[slice_of == k], slot[slice_of == k], n_local, max(n_k[k], 1)) for k in range(K)]
+                chunks = [(int(mine[k]) - lo, int(mine[k + 1]) - lo) for k in range(K)]
+                z = torch.empty(n_local, d, device=dev)
+                t_gemm = timed(lambda: gemm.mm_nn(h, w, rowscale=scale, out=z))
+                t_prod = [timed(lambda k=k: gemm.mm_nn(h[chunks[k][0]:chunks[k][1]], w, rowscale=scale[chunks[k][0]:chunks[k][1]],
+                                                       out=z[chunks[k][0]:chunks[k][1]])) for k in range(K)]
+                send_idx = [torch.randint(chunks[k][0], max(chunks[k][1], chunks[k][0] + 1), (sum(send[k]),), device=dev) for k in range(K)]
+                t_pack = [timed(lambda k=k: comp.pack_rows(h, send_idx[k])) for k in range(K)]
+                halos = [torch.rand(max(n_k[k], 1), d, device=dev) for k in range(K)]
+                acc = g_int.spmm(h)
+                t_pass = [timed(lambda k=k: g_halo[k].spmm(halos[k], row_scale=scale, bias=bias, relu=True, acc_init=acc)) if k == K - 1
+                          else timed(lambda k=k: g_halo[k].spmm(halos[k], acc_init=acc, out=acc)) for k in range(K)]
+                t_link = [link_rows[k] * bpr / link for k in range(K)]
+                exposed = pipeline(t_prod, t_pack, t_link, t_int, t_pass) - sum(t_prod)
+                pen = sum(t_prod) - t_gemm
+                step = a.dense_pull_ms / P + 2 * L * (exposed + pen)
+                row['pull'].update({'pack_ms': t_pack, 'halo_pass_ms': t_pass, 'gemm_chunk_ms': t_prod, 'gemm_whole_ms': t_gemm, 'link_ms': t_link,
+                                    'exposed_ms': exposed, 'step_ms': step, 'steps_per_s': 1e3 / step, 'efficiency_vs_driver_n1': a.n1_ms / (P * step)})
+                del g_halo, halos, acc, z, send_idx, seg, slot, slice_of, rrem
+            del uniq, inv
+            torch.cuda.empty_cache()
+        # ============================ cover pipeline (this round) ============================
+        if a.mode in ('both', 'cover'):
+            # requester side: per owner q the pair graph (sources in q -> my destinations)
+            e_rows, e_slot_local, e_slice, e_owner = [], [], [], []
+            recv = [[0] * P for _ in range(K)]
+            n_pull_only = n_pulled = n_pushed = 0
+            rrem, crem, orem = rr[remote], cc[remote], own_c[remote]
+            for q in range(P):
+                if q == r:
+                    continue
+                mq = orem == q
+                u, v = crem[mq], rrem[mq]
+                pull, n_u, n_s, n_t, item, n_items = pair_cover(u, v)
+                n_pull_only += n_u
+                n_pulled += n_s
+                n_pushed += n_t
+                cuts = torch.tensor(positional(n_items, K), dtype=torch.int64, device=dev)
+                # halo edges: every pulled edge, ONE edge per pushed destination
+                keep = pull.clone()
+                first = torch.zeros_like(pull)
+                if (~pull).any():
+                    pv = v[~pull]
+                    _, inv_t = torch.unique(pv, return_inverse=True)
+                    firsts = torch.zeros(int(inv_t.max()) + 1, dtype=torch.int64, device=dev).scatter_reduce_(
+                        0, inv_t, torch.arange(pv.numel(), device=dev), 'amin', include_self=False)
+                    idx_np = torch.nonzero(~pull).reshape(-1)
+                    first[idx_np[firsts]] = True
+                keep |= first
+                it = item[keep]
+                k_of = (it.unsqueeze(1) >= cuts[1:K]).sum(1) if K > 1 else torch.zeros_like(it)
+                for k in range(K):
+                    recv[k][q] = int(cuts[k + 1] - cuts[k])
+                e_rows.append(v[keep])
+                e_slot_local.append(it - cuts[k_of])
+                e_slice.append(k_of)
+                e_owner.append(torch.full_like(it, q))
+            e_rows, e_slot_local, e_slice, e_owner = (torch.cat(t_) for t_ in (e_rows, e_slot_local, e_slice, e_owner))
+            n_k = [sum(recv[k]) for k in range(K)]
+            base = torch.tensor([[sum(recv[k][:q]) for q in range(P)] for k in range(K)], dtype=torch.int64, device=dev)
+            e_slot = base[e_slice, e_owner] + e_slot_local
+            # owner side: per requester q the pair graph (my sources -> q's destinations): rows of my send buffer
+            s_rows, s_cols, s_slice, s_owner = [], [], [], []
+            send = [[0] * P for _ in range(K)]
+            for q in range(P):
+                if q == r:
+                    continue
+                mq = (dst >= parts[q].lo()) & (dst < parts[q].hi()) & (src >= lo) & (src < hi)
+                u, v = src[mq] - lo, dst[mq]
+                del mq
+                pull, n_u, n_s, n_t, item, n_items = pair_cover(u, v)
+                cuts = torch.tensor(positional(n_items, K), dtype=torch.int64, device=dev)
+                # send-CSR edges: ONE edge per pulled source, every pushed edge
+                keep = ~pull
+                if pull.any():
+                    pu = u[pull]
+                    _, inv_s = torch.unique(pu, return_inverse=True)
+                    firsts = torch.zeros(int(inv_s.max()) + 1, dtype=torch.int64, device=dev).scatter_reduce_(
+                        0, inv_s, torch.arange(pu.numel(), device=dev), 'amin', include_self=False)
+                    idx_p = torch.nonzero(pull).reshape(-1)
+                    keep[idx_p[firsts]] = True
+                it = item[keep]
+                k_of = (it.unsqueeze(1) >= cuts[1:K]).sum(1) if K > 1 else torch.zeros_like(it)
+                for k in range(K):
+                    send[k][q] = int(cuts[k + 1] - cuts[k])
+                s_rows.append(it - cuts[k_of])
+                s_cols.append(u[keep])
+                s_slice.append(k_of)
+                s_owner.append(torch.full_like(it, q))
+            s_rows, s_cols, s_slice, s_owner = (torch.cat(t_) for t_ in (s_rows, s_cols, s_slice, s_owner))
+            sbase = torch.tensor([[sum(send[k][:q]) for q in range(P)] for k in range(K)], dtype=torch.int64, device=dev)
+            s_rows = sbase[s_slice, s_owner] + s_rows
+            n_send = [sum(send[k]) for k in range(K)]
+            link_rows = [max(max(recv[k]), max(send[k])) for k in range(K)]
+            row['cover'] = {'rows_pull_only': n_pull_only, 'halo_rows': n_pulled + n_pushed, 'pulled': n_pulled, 'pushed': n_pushed,
+                            'send_rows': sum(n_send), 'max_link_rows': sum(link_rows), 'halo_edges': int(e_rows.numel()), 'send_edges': int(s_rows.numel())}
+            if not a.halo_only:
+                g_halo = [comp.csr(e_rows[e_slice == k], e_slot[e_slice == k], n_local, max(n_k[k], 1)) for k in range(K)]
+                g_send = [comp.csr(s_rows[s_slice == k], s_cols[s_slice == k], max(n_send[k], 1), n_local) for k in range(K)]
+                del e_rows, e_slot, e_slice, e_owner, s_rows, s_cols, s_slice, s_owner, e_slot_local
+                t_pack = [timed(lambda k=k: g_send[k].spmm(h)) for k in range(K)]
+                halos = [torch.rand(max(n_k[k], 1), d, device=dev) for k in range(K)]
+                acc = g_int.spmm(h)
+                t_pass = [timed(lambda k=k: g_halo[k].spmm(halos[k], acc_init=acc, out=acc)) for k in range(K - 1)]
+                gl = g_halo[K - 1]
+                gl.norm_in, gl.row_offset = scale, 0
+                img, img_t = weight_image(w), weight_image(w, transpose=True)
+                bits = torch.randint(-2 ** 62, 2 ** 62, (n_local, 1, 4), dtype=torch.int64, device=dev)
+                last = {
+                    'plain_epilogue': timed(lambda: gl.spmm(halos[K - 1], row_scale=scale, bias=bias, relu=True, acc_init=acc.clone())),
+                    'fused_store': timed(lambda: trunk._fused_launch(_lib.load(), gl, gl, halos[K - 1], acc.clone(), bias, x0, 0.9, 0.1, 0.1, 7, False)),
+                    'fused_store_gemm': timed(lambda: trunk._fused_gemm_launch(gl, halos[K - 1], bias, x0, 0.9, 0.1, 0.1, 7, img, scale, None, g=gl,
+                                                                                acc=acc.clone())),
+                    'reverse_gemm': timed(lambda: gl.spmm_gemm(halos[K - 1], img_t, g_rowscale=scale, acc_init=acc.clone())),
+                    'reverse_gemm_trunkbwd': timed(lambda: gl.spmm_gemm_trunkbwd(halos[K - 1], img_t, scale, bits, 0.9, 0.1, 7, 0, scale, True,
+                                                                                  transpose=False, acc_init=acc.clone())),
+                    'clone_only': timed(lambda: acc.clone()),
+                }
+                t_link = [link_rows[k] * bpr / link for k in range(K)]
+                zero = [0.0] * K
 
-        def passes(bufs):
-            out = []
-            for k in range(K):
-                if k == K - 1:
-                    out.append(timed(lambda k=k: g_halo[k].spmm(bufs[k], row_scale=scale, bias=bias, relu=True, acc_init=acc)))
-                else:
-                    out.append(timed(lambda k=k: g_halo[k].spmm(bufs[k], acc_init=acc, out=acc)))
-            return out
-        t_pass, t_pass16 = passes(halos), passes(halos16)
-        bpr = d * 4
-        link = a.link_gbs * a.link_eff * 1e6        # bytes per ms
-        t_link = [link_rows[k] * bpr / link for k in range(K)]
-        t_link16 = [v / 2 for v in t_link]
-        zero = [0.0] * K
-        # exposed aggregation time = pipeline end - the producers' own time (already part of the dense share of the step)
-        exp_f32 = pipeline(t_prod, t_pack, t_link, t_int, t_pass) - sum(t_prod)
-        exp_f32_noprod = pipeline(zero, t_pack, t_link, t_int, t_pass)               # exchange starts only after the whole GEMM
-        exp_bf16 = pipeline(t_prod, t_pack16, t_link16, t_int, t_pass16) - sum(t_prod)
-        # chunking the GEMM costs something on its own: K launches instead of one
-        gemm_penalty = sum(t_prod) - t_gemm_whole
-        L2 = 2 * a.layers
-        dense = a.dense_ms / P
-        row.update({'pack_ms': t_pack, 'pack_bf16_ms': t_pack16, 'interior_ms': t_int, 'halo_pass_ms': t_pass, 'halo_pass_bf16_ms': t_pass16,
-                    'gemm_chunk_ms': t_prod, 'gemm_whole_ms': t_gemm_whole, 'link_ms_predicted': t_link,
-                    'aggregation_exposed_ms': exp_f32, 'aggregation_exposed_ms_without_chunked_producers': exp_f32_noprod,
-                    'aggregation_exposed_ms_bf16_wire': exp_bf16, 'gemm_chunking_penalty_ms': gemm_penalty,
-                    'step_ms_predicted': dense + L2 * (exp_f32 + gemm_penalty),
-                    'steps_per_s_predicted': 1e3 / (dense + L2 * (exp_f32 + gemm_penalty)),
-                    'steps_per_s_predicted_without_chunked_producers': 1e3 / (dense + L2 * exp_f32_noprod),
-                    'steps_per_s_predicted_bf16_wire': 1e3 / (dense + L2 * (exp_bf16 + gemm_penalty))})
-        rows_out.append(row)
+                def exposed(last_ms):
+                    return pipeline(zero, t_pack, t_link, t_int, t_pass + [last_ms - last['clone_only']])
+                # forward: layers 0 .. L-2 store + next GEMM, layer L-1 store only; backward: layers L-1 .. 1 with the trunk backward in the tail,
+                # layer 0 with the plain dX tail
+                per = ([exposed(last['fused_store_gemm'])] * (L - 1) + [exposed(last['fused_store'])]
+                       + [exposed(last['reverse_gemm_trunkbwd'])] * (L - 1) + [exposed(last['reverse_gemm'])])
+                step = a.dense_cover_ms / P + sum(per)
+                row['cover'].update({'pack_ms': t_pack, 'halo_pass_ms': t_pass, 'last_pass_ms': last, 'link_ms': t_link, 'exposed_ms_per_aggregation': per,
+                                     'step_ms': step, 'steps_per_s': 1e3 / step, 'efficiency_vs_driver_n1': a.n1_ms / (P * step),
+                                     'link_bound_step_ms': a.dense_cover_ms / P + 2 * L * sum(t_link)})
+                del g_halo, g_send, halos, acc
+            torch.cuda.empty_cache()
+        out_rows.append(row)
         print(json.dumps(row), flush=True)
-        del g_int, g_halo, h, halos, halos16, acc, z
+        del g_int, h, rr, cc, remote
         torch.cuda.empty_cache()
-    if a.halo_only:
-        print('\n| P | partition | rows/rank | edges/rank | remote edges | halo rows (x N) | rows on the busiest link |')
-        print('|---|---|---|---|---|---|---|')
-        for w_ in rows_out:
-            print(f"| {w_['P']} | {w_['partition']} | {w_['rows_local']} | {w_['edges_local']} | {w_['edges_remote']} | {w_['halo_rows']} ({w_['halo_frac_of_N']:.3f}) | {w_['max_link_rows']} |")
-        return
-    base = rows_out[0]['steps_per_s_predicted'] if rows_out and rows_out[0]['P'] == 1 else None
-    print(f'\n| P | rows / rank | edges / rank (interior) | halo rows (x N) | slices | pack (sum) | interior | link time (sum, pred.) | halo passes (sum; last) | '
-          'GEMM chunks (sum; whole) | exposed per aggregation: fp32 wire / no chunked producers / bf16 wire | step (pred.) | steps/s (pred.) | efficiency | bf16 wire steps/s |')
-    print('|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|')
-    for w_ in rows_out:
-        eff = f"{w_['steps_per_s_predicted'] / base / w_['P']:.2f}" if base else '-'
+    print(f'\n{a.name} (N={n}, E={E}), d={d}, rank {a.rank} of each world, {K} slices, link {a.link_gbs} GB/s x {a.link_eff}, driver 1-GPU step {a.n1_ms} ms')
+    print('| P | rows / rank | remote edges | pull: rows on the busiest link | cover: rows on the busiest link (pulled + pushed of all peers) | cover / pull |'
+          + ('' if a.halo_only else ' pull: exposed / step / steps/s / eff. | cover: exposed (fwd+GEMM, fwd last, bwd+TB, bwd last) / step / steps/s / eff. | link-bound step (cover) |'))
+    print('|---|---|---|---|---|---|' + ('' if a.halo_only else '---|---|---|'))
+    for w_ in out_rows:
         if w_['P'] == 1:
-            print(f"| 1 | {w_['rows_local']} | {w_['edges_local']} | - | - | - | - | - | - | - | {w_['aggregation_exposed_ms']:.2f} | {w_['step_ms_predicted']:.1f} | "
-                  f"{w_['steps_per_s_predicted']:.2f} | 1.00 | - |")
+            print(f"| 1 | {w_['rows_local']} | 0 | - | - | - |" + ('' if a.halo_only else f" aggregation {w_['aggregation_ms']:.2f} ms, + GEMM {w_['aggregation_plus_gemm_ms']:.2f} ms | step {a.n1_ms} ms = {1e3 / a.n1_ms:.2f} steps/s (driver) | - |"))
             continue
-        print(f"| {w_['P']} | {w_['rows_local']} | {w_['edges_local']} ({w_['edges_interior']}) | {w_['halo_rows']} ({w_['halo_frac_of_N']:.2f}) | {w_['slices']} | "
-              f"{sum(w_['pack_ms']):.2f} | {w_['interior_ms']:.2f} | {sum(w_['link_ms_predicted']):.2f} | {sum(w_['halo_pass_ms']):.2f}; {w_['halo_pass_ms'][-1]:.2f} | "
-              f"{sum(w_['gemm_chunk_ms']):.2f}; {w_['gemm_whole_ms']:.2f} | {w_['aggregation_exposed_ms']:.2f} / {w_['aggregation_exposed_ms_without_chunked_producers']:.2f} / "
-              f"{w_['aggregation_exposed_ms_bf16_wire']:.2f} | {w_['step_ms_predicted']:.1f} | {w_['steps_per_s_predicted']:.2f} | {eff} | "
-              f"{w_['steps_per_s_predicted_bf16_wire']:.2f} |")
-    print(f'\nassumptions: {a.name} (N={n}, E={E}), d={a.d}, link {a.link_gbs} GB/s x {a.link_eff} efficiency per peer pair, '
-          f'dense part {a.dense_ms} ms at P=1 scaled 1/P, {2 * a.layers} aggregations per step, rank {a.rank} of each world, partition {a.partition}')
+        pl, cv = w_.get('pull'), w_.get('cover')
+        line = (f"| {w_['P']} | {w_['rows_local']} | {w_['edges_remote']} | {pl['max_link_rows'] if pl else '-'} | "
+                f"{cv['max_link_rows'] if cv else '-'} ({cv['pulled']} + {cv['pushed']}) | " + (f"{cv['max_link_rows'] / pl['max_link_rows']:.3f}" if pl and cv else '-') + ' |')
+        if not a.halo_only:
+            line += (f" {pl['exposed_ms']:.2f} / {pl['step_ms']:.1f} / {pl['steps_per_s']:.2f} / {pl['efficiency_vs_driver_n1']:.2f} |" if pl else ' - |')
+            if cv:
+                e = cv['exposed_ms_per_aggregation']
+                line += (f" {e[0]:.2f}, {e[L - 1]:.2f}, {e[L]:.2f}, {e[-1]:.2f} / {cv['step_ms']:.1f} / {cv['steps_per_s']:.2f} / {cv['efficiency_vs_driver_n1']:.2f} | "
+                         f"{cv['link_bound_step_ms']:.1f} |")
+            else:
+                line += ' - | - |'
+        print(line)
 
 
 if __name__ == '__main__':
