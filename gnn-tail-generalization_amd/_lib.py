@@ -96,6 +96,10 @@ SIGNATURES = {
     'cb_gemm_nn_indrop_supported': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64]),
     'cb_gemm_nn_indrop_drop2_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, ctypes.c_int, ctypes.c_float,
                                                    ctypes.c_uint64, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _P]),
+    'cb_gemm_nn_indrop_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int, ctypes.c_float,
+                                             ctypes.c_uint64, _P, _I64, _P, _P]),
+    'cb_gemm_tn_adrop_supported': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I64]),
+    'cb_gemm_tn_adrop_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _SZ, _P]),
     'cb_gemm_tn_gdrop_supported': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I64]),
     'cb_gemm_tn_gdrop_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _SZ, _P]),
     'cb_spmm_gemm_trunkbwd_workspace_bytes': (_SZ, []),

@@ -255,7 +255,7 @@ static int launch_nn(const float* A, int64_t lda, const float* B, int64_t ldb, v
 
 template <int WM, int WN>
 static int launch_tn(const float* A, int64_t lda, const float* G, int64_t ldg, const float* rowscale, float* C, int64_t M,
-                     int64_t K1, int64_t K2, float* ws, hipStream_t st, const DropSpec* gdrop = nullptr) {
+                     int64_t K1, int64_t K2, float* ws, hipStream_t st, const DropSpec* gdrop = nullptr, const DropSpec* adrop = nullptr) {
   using T = Tile<WM, WN>;
   const int tiles_i = (int)((K1 + T::BM - 1) / T::BM), tiles_j = (int)((K2 + T::BN - 1) / T::BN);
   const int nsplit = tn_splits(M, tiles_i * tiles_j);
@@ -263,10 +263,10 @@ static int launch_tn(const float* A, int64_t lda, const float* G, int64_t ldg, c
   rows_per_split = (rows_per_split + 31) / 32 * 32;   // whole K steps of either kernel family
   const bool aligned = al16(A) && al16(G) && lda % 4 == 0 && ldg % 4 == 0;
   const dim3 grid((unsigned)(tiles_i * tiles_j), (unsigned)nsplit);
-  CB_CHECK_ARG(!gdrop || (use_limb3() && limb3_tn_eligible(A, lda, G, ldg, K1, K2)), CB_E_INVALID,
+  CB_CHECK_ARG(!(gdrop || adrop) || (use_limb3() && limb3_tn_eligible(A, lda, G, ldg, K1, K2)), CB_E_INVALID,
                "TN contraction with operand dropout: three-limb path only (check cb_gemm_tn_gdrop_supported first)");
   if (use_limb3() && limb3_tn_eligible(A, lda, G, ldg, K1, K2)) {
-    const int rc = launch_tn_limb3(A, lda, G, ldg, rowscale, ws, M, K1, K2, T::BM, nsplit, rows_per_split, st, gdrop);
+    const int rc = launch_tn_limb3(A, lda, G, ldg, rowscale, ws, M, K1, K2, T::BM, nsplit, rows_per_split, st, gdrop, adrop);
     if (rc != CB_OK) return rc;
     const int64_t n = K1 * K2;
     hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, nsplit, n, C);
@@ -441,4 +441,52 @@ extern "C" int cb_gemm_tn_gdrop_f32(const float* A, int64_t lda, const float* G,
   if (bm == 64) return launch_tn<1, 4>(A, lda, G, ldg, nullptr, C, M, K1, K2, (float*)ws, st, &gd);
   if (bm == 256) return launch_tn<4, 1>(A, lda, G, ldg, nullptr, C, M, K1, K2, (float*)ws, st, &gd);
   return launch_tn<2, 2>(A, lda, G, ldg, nullptr, C, M, K1, K2, (float*)ws, st, &gd);
+}
+
+// C = act(rowscale * (dropout_{a_seed}(A) @ B) + addend + bias) with the dropout applied to A while it is staged (no dropped copy of A is
+// written, kept or re-read) — the input Linear of the residual trunk (GCN.py:104-107: A = x) and the first GCNConv's transform
+// (GCN.py:110 then :213,225,230-235: A = X0, the dropout in front of layer 0).  relu_bits (may be NULL; N == 256 and relu): [M][4] mask words
+// of (C > 0).  Bit-identical to cb_dropout_f32 followed by cb_gemm_nn_f32.  Only where the fused form exists: cb_gemm_nn_indrop_supported
+// (pass C for C2).
+extern "C" int cb_gemm_nn_indrop_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                     const float* rowscale, const float* addend, int64_t ld_add, const float* bias, int relu, float a_drop_p,
+                                     uint64_t a_seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, void* stream) {
+  CB_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && a_drop_p > 0.f && a_drop_p < 1.f && row0 >= 0, CB_E_INVALID, "cb_gemm_nn_indrop_f32: bad size or p");
+  CB_CHECK_ARG(!relu_bits || (N == 256 && relu && (uintptr_t)relu_bits % 8 == 0), CB_E_INVALID,
+               "cb_gemm_nn_indrop_f32: mask words of the ReLU exist for N == 256 with relu only");
+  CB_CHECK_ARG(N < (1 << 24) && K < (1 << 24) && (M + 63) / 64 < (1 << 24), CB_E_RANGE, "cb_gemm_nn_indrop_f32: size out of range");
+  if (M == 0 || N == 0) return CB_OK;
+  CB_CHECK_ARG(C && A && B && lda >= K && ldb >= N && ldc >= N && (!addend || ld_add >= N), CB_E_INVALID, "cb_gemm_nn_indrop_f32: null pointer or bad ld");
+  CB_CHECK_ARG(cb_gemm_nn_indrop_supported(A, lda, B, ldb, C, ldc, C, ldc, M, N, K) && (!addend || (al16(addend) && ld_add % 4 == 0)), CB_E_INVALID,
+               "cb_gemm_nn_indrop_f32: shape / alignment outside the fused form (cb_gemm_nn_indrop_supported)");
+  GemmEpilogue ep{rowscale, addend, ld_add, bias, relu, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, gemm_nt_store(M, N)};
+  ep.adrop = DropSpec{dropout_threshold(a_drop_p), 1.f / (1.f - a_drop_p), a_seed, seed_dev, row0, K};
+  ep.relu_bits_out = (unsigned long long*)relu_bits;
+  return launch_nn_limb3(A, lda, B, ldb, C, ldc, M, N, K, ep, false, (hipStream_t)stream, nullptr, 0);
+}
+
+// C = dropout_{a_seed}(A)^T @ (rowscale * G): the weight gradient of the first GCNConv (autograd of GCN.py:225 behind the dropout of :110)
+// from the UNdropped X0 — the mask cb_gemm_nn_indrop_f32 drew is regenerated while A is staged.  cb_gemm_tn_adrop_supported first.
+extern "C" int cb_gemm_tn_adrop_supported(const float* A, int64_t lda, const float* G, int64_t ldg, int64_t K1, int64_t K2) {
+  int bm, bn;
+  tn_tile(K1, K2, bm, bn);
+  return use_limb3() && K1 % 4 == 0 && bm == 128 && limb3_tn_eligible(A, lda, G, ldg, K1, K2) ? 1 : 0;
+}
+
+extern "C" int cb_gemm_tn_adrop_f32(const float* A, int64_t lda, const float* G, int64_t ldg, const float* rowscale, float* C, int64_t M, int64_t K1,
+                                    int64_t K2, float a_drop_p, uint64_t a_seed, const uint64_t* seed_dev, int64_t row0, void* ws, size_t ws_bytes,
+                                    void* stream) {
+  CB_CHECK_ARG(M >= 0 && K1 >= 0 && K2 >= 0 && a_drop_p > 0.f && a_drop_p < 1.f && row0 >= 0, CB_E_INVALID, "cb_gemm_tn_adrop_f32: bad size or p");
+  CB_CHECK_ARG(K1 < (1 << 20) && K2 < (1 << 20), CB_E_RANGE, "cb_gemm_tn_adrop_f32: size out of range");
+  if (K1 == 0 || K2 == 0) return CB_OK;
+  CB_CHECK_ARG(C && (M == 0 || (A && G)) && lda >= K1 && ldg >= K2, CB_E_INVALID, "cb_gemm_tn_adrop_f32: null pointer or bad ld");
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) {
+    CB_HIP(hipMemsetAsync(C, 0, (size_t)K1 * K2 * sizeof(float), st));
+    return CB_OK;
+  }
+  CB_CHECK_ARG(cb_gemm_tn_adrop_supported(A, lda, G, ldg, K1, K2), CB_E_INVALID, "cb_gemm_tn_adrop_f32: operands outside the three-limb 128-row tile path");
+  CB_CHECK_ARG(ws && ws_bytes >= cb_gemm_tn_workspace_bytes(M, K1, K2), CB_E_WORKSPACE, "cb_gemm_tn_adrop_f32: workspace too small");
+  const DropSpec ad{dropout_threshold(a_drop_p), 1.f / (1.f - a_drop_p), a_seed, seed_dev, row0, K1};
+  return launch_tn<2, 2>(A, lda, G, ldg, rowscale, C, M, K1, K2, (float*)ws, st, nullptr, &ad);
 }

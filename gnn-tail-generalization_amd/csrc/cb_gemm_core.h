@@ -38,7 +38,7 @@ struct GemmEpilogue {
   int64_t row0;
   int nt_store;                     // fp32 C leaves with the streaming (nt) policy
   DropSpec adrop;                   // ADROP kernels only: dropout of the A operand (thresh = 0: off)
-  unsigned long long* relu_bits_out;   // EPI == 1, 256-column tiles only: [M][4] mask words of (C > 0) after the ReLU (word q, bit L <-> column 4 L + q:
+  unsigned long long* relu_bits_out;   // 256-column tiles only: [M][4] mask words of (C > 0) after the ReLU (word q, bit L <-> column 4 L + q:
                                     // the layout of the aggregation's fused store) — the trunk's input stage reads them instead of C itself
 };
 
@@ -262,7 +262,7 @@ __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __rest
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (n + q < N) cp[q] = o[q];
           }
-          if constexpr (EPI == 1 && TPR == 64) {   // a wavefront holds one whole 256-column row: four ballots are its mask words
+          if constexpr (TPR == 64) {   // a wavefront holds one whole 256-column row: four ballots are its mask words
             if (ep.relu_bits_out) {
               unsigned long long mine = 0ull;
 #pragma unroll

@@ -93,7 +93,8 @@ __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_nn
 // 1-D grid, XCD-aware: the tiles of one row split get block ids congruent mod 8 (same XCD / L2), so each operand
 // panel is fetched from HBM once although tiles_i (tiles_j) tiles consume it.
 // GDROP: F.dropout of the G operand while it is staged (gd): the weight gradient of the input Linear reads the undropped features
-template <int WM, int WN, bool SCALED, int WTN = 2, int PD = 1, bool GDROP = false>
+// ADROP: the same for the A operand (ad): the weight gradient of the first GCNConv reads X0 and regenerates the mask of F.dropout(X0)
+template <int WM, int WN, bool SCALED, int WTN = 2, int PD = 1, bool GDROP = false, bool ADROP = false>
 __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_tn_l3(const float* __restrict__ A, int64_t lda,
                                                                                  const float* __restrict__ G, int64_t ldg,
                                                                                  const float* __restrict__ rowscale,
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_tn
                                                                                  int64_t rows_per_split, int tiles_j, int n_tiles,
                                                                                  int nsplit, DropSpec gd) {
   using T = LTile<WM, WN, WTN>;
-  using OA = ColOperand<T::BM, false>;
+  using OA = ColOperand<T::BM, false, ADROP>;
   using OB = ColOperand<T::BN, SCALED, GDROP>;
   constexpr int BM = T::BM, BN = T::BN;
   __shared__ __attribute__((aligned(16))) char smem[2 * (OA::BYTES + OB::BYTES)];
@@ -120,6 +121,7 @@ __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_tn
   oa.init(lda, K1 - i0, t);
   ob.init(ldg, K2 - j0, t);
   if constexpr (GDROP) ob.set_drop(gd, r_begin, r_end - r_begin, j0, t);
+  if constexpr (ADROP) oa.set_drop(gd, r_begin, r_end - r_begin, i0, t);      // (one DropSpec: the two operand dropouts never occur together)
   const uint32_t aaddr[2] = {OA::frag_addr(wr * 64, lane), OA::frag_addr(wr * 64 + 32, lane)};
   uint32_t baddr[WTN];
 #pragma unroll
@@ -166,7 +168,14 @@ static int launch_nn_l3_t(const float* A, int64_t lda, const float* B, int64_t l
       CB_LAUNCH_CHECK();
       return CB_OK;
     }
+    if (ep.adrop.thresh) {      // single output, dropout of the A operand in its staging (no dropped copy of A anywhere)
+      hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, false, WTN, 1, 0, true>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb,
+                         ncb, c_vec_ok);
+      CB_LAUNCH_CHECK();
+      return CB_OK;
+    }
   }
+  CB_CHECK_ARG(!ep.adrop.thresh, CB_E_INVALID, "NN contraction with operand dropout: wide fp32 tile only (check cb_gemm_nn_indrop_supported first)");
   hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, OUT_BF16, WTN, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb,
                      c_vec_ok);
   CB_LAUNCH_CHECK();
@@ -197,7 +206,7 @@ int launch_nn_limb3(const float* A, int64_t lda, const float* B, int64_t ldb, vo
   // 128 x 256 block tile (wave tile 64 x 128) where it fills the chip, else 128 x 128:
   // fewer than one wide tile per CU (a Pubmed-sized M = 19 717: 155 tiles): the 128 x 128 tile doubles the blocks in flight (-6 % on
   // the S-pubmed step); the dual-output epilogues exist for the wide tile only
-  const bool fills = ((M + 127) / 128) * ((N + 255) / 256) >= 256 || ep.out2;
+  const bool fills = ((M + 127) / 128) * ((N + 255) / 256) >= 256 || ep.out2 || ep.adrop.thresh;
   if (N > 128 && fills)
     return out_bf16 ? launch_nn_l3_t<2, 2, true, 4>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes)
                     : launch_nn_l3_t<2, 2, false, 4>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes);
@@ -207,19 +216,18 @@ int launch_nn_limb3(const float* A, int64_t lda, const float* B, int64_t ldb, vo
 
 template <int WM, int WN, int WTN = 2>
 static void launch_tn_l3_t(const float* A, int64_t lda, const float* G, int64_t ldg, const float* rowscale, float* partial, int64_t M,
-                           int64_t K1, int64_t K2, int nsplit, int64_t rows_per_split, hipStream_t st, const DropSpec& gd) {
+                           int64_t K1, int64_t K2, int nsplit, int64_t rows_per_split, hipStream_t st, const DropSpec& gd, const DropSpec& ad) {
   using T = LTile<WM, WN, WTN>;
   const int ti = (int)((K1 + T::BM - 1) / T::BM), tj = (int)((K2 + T::BN - 1) / T::BN);
   const dim3 grid((unsigned)(((nsplit + 7) / 8) * 8 * ti * tj));
-  if (gd.thresh) {      // (launch_tn_limb3 admits it without a row scale only)
-    hipLaunchKernelGGL((k_gemm_tn_l3<WM, WN, false, WTN, 1, true>), grid, dim3(256), 0, st, A, lda, G, ldg, rowscale, partial, M, (int)K1, (int)K2,
-                       rows_per_split, tj, ti * tj, nsplit, gd);
-    return;
-  }
-#define CB_TN_LAUNCH(SC_, PD_)                                                                                                   \
-  hipLaunchKernelGGL((k_gemm_tn_l3<WM, WN, SC_, WTN, PD_>), grid, dim3(256), 0, st, A, lda, G, ldg, rowscale, partial, M, (int)K1, \
-                     (int)K2, rows_per_split, tj, ti * tj, nsplit, gd)
-  if (rowscale) CB_TN_LAUNCH(true, 1); else CB_TN_LAUNCH(false, 1);
+#define CB_TN_LAUNCH(SC_, GD_, AD_)                                                                                                  \
+  hipLaunchKernelGGL((k_gemm_tn_l3<WM, WN, SC_, WTN, 1, GD_, AD_>), grid, dim3(256), 0, st, A, lda, G, ldg, rowscale, partial, M, (int)K1, \
+                     (int)K2, rows_per_split, tj, ti * tj, nsplit, gd.thresh ? gd : ad)
+  if (gd.thresh) CB_TN_LAUNCH(false, true, false);      // (launch_tn_limb3 admits it without a row scale only)
+  else if (ad.thresh) {
+    if constexpr (WM == 2 && WN == 2 && WTN == 2) { if (rowscale) CB_TN_LAUNCH(true, false, true); else CB_TN_LAUNCH(false, false, true); }
+  } else if (rowscale) CB_TN_LAUNCH(true, false, false);
+  else CB_TN_LAUNCH(false, false, false);
 #undef CB_TN_LAUNCH
 }
 
@@ -228,14 +236,18 @@ bool limb3_tn_eligible(const float* A, int64_t lda, const float* G, int64_t ldg,
 }
 
 int launch_tn_limb3(const float* A, int64_t lda, const float* G, int64_t ldg, const float* rowscale, float* partial, int64_t M,
-                    int64_t K1, int64_t K2, int bm, int nsplit, int64_t rows_per_split, hipStream_t st, const DropSpec* gdrop) {
+                    int64_t K1, int64_t K2, int bm, int nsplit, int64_t rows_per_split, hipStream_t st, const DropSpec* gdrop, const DropSpec* adrop) {
   const DropSpec gd = gdrop ? *gdrop : DropSpec{};
-  CB_CHECK_ARG(!gd.thresh || (!rowscale && gd.width % 4 == 0), CB_E_INVALID, "TN contraction: operand dropout needs width %% 4 == 0 and no row scale");
-  if (bm == 64) launch_tn_l3_t<1, 4>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd);
-  else if (bm == 256) launch_tn_l3_t<4, 1>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd);
+  const DropSpec ad = adrop ? *adrop : DropSpec{};
+  CB_CHECK_ARG(!gd.thresh || (!rowscale && gd.width % 4 == 0 && !ad.thresh), CB_E_INVALID,
+               "TN contraction: dropout of the G operand needs width %% 4 == 0, no row scale and no dropout of A");
+  CB_CHECK_ARG(!ad.thresh || (ad.width % 4 == 0 && bm == 128), CB_E_INVALID, "TN contraction: dropout of the A operand needs width %% 4 == 0 and the 128-row tile");
+  if (bm == 64) launch_tn_l3_t<1, 4>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd, ad);
+  else if (bm == 256) launch_tn_l3_t<4, 1>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd, ad);
   else {
-    if (K2 > 128 && ((K1 + 127) / 128) * ((K2 + 255) / 256) * nsplit >= 256) launch_tn_l3_t<2, 2, 4>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd);
-    else launch_tn_l3_t<2, 2>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd);
+    // (operand dropout: the 128 x 128 tile — the wide one is at the register cap and the mask's Philox rounds would spill)
+    if (!ad.thresh && K2 > 128 && ((K1 + 127) / 128) * ((K2 + 255) / 256) * nsplit >= 256) launch_tn_l3_t<2, 2, 4>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd, ad);
+    else launch_tn_l3_t<2, 2>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd, ad);
   }
   CB_LAUNCH_CHECK();
   return CB_OK;

@@ -107,6 +107,57 @@ def mm_nn_indrop_drop2(a, b, p, a_seed, seed, row0=0, bias=None, relu=False, wan
     return (y, yd, bits) if want_bits else (y, yd)
 
 
+def mm_nn_indrop(a, b, p, a_seed, row0=0, rowscale=None, addend=None, bias=None, relu=False, want_bits=False, out=None):
+    """act(rowscale * (dropout_{a_seed}(a) @ b) + addend + bias) with the dropout applied to `a` while the GEMM stages it
+    (cb_gemm_nn_indrop_f32): no dropped copy of `a` exists — bit-identical to ops._dropout_raw(a, p, a_seed, row0 * K) followed by mm_nn.
+    Returns y, or (y, bits) with want_bits (N == 256, relu: the int64 [M, 1, 4] mask words of y > 0); None where the fused form does not
+    exist for the shape (few rows, narrow outputs, misaligned operands)."""
+    import ctypes
+    from . import ops
+    lib = _lib.load()
+    _lib.require_device(a, b, rowscale, addend, bias, out)
+    a, b = _rowmajor(a), _rowmajor(b)
+    M, K = a.shape
+    K2, N = b.shape
+    if K != K2 or a.dtype != torch.float32 or b.dtype != torch.float32 or not (0.0 < p < 1.0):
+        return None
+    if addend is not None:
+        addend = _rowmajor(addend)
+        if addend.data_ptr() % 16 or _ld(addend) % 4:
+            return None
+    y = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if not lib.cb_gemm_nn_indrop_supported(_lib.ptr(a), _ld(a), _lib.ptr(b), _ld(b), _lib.ptr(y), _ld(y), _lib.ptr(y), _ld(y), M, N, K):
+        return None
+    bits = torch.empty((M, 1, 4), dtype=torch.int64, device=a.device) if (want_bits and N == 256 and relu) else None
+    with torch.cuda.device(a.device):
+        _lib.check(lib.cb_gemm_nn_indrop_f32(_lib.ptr(a), _ld(a), _lib.ptr(b), _ld(b), _lib.ptr(y), _ld(y), M, N, K, _lib.ptr(rowscale), _lib.ptr(addend),
+                                             _ld(addend) if addend is not None else 0, _lib.ptr(bias), int(bool(relu)), float(p),
+                                             ctypes.c_uint64(a_seed), ops.seed_dev_ptr(), int(row0), _lib.ptr(bits), _lib.stream_ptr()),
+                   'cb_gemm_nn_indrop_f32')
+    return (y, bits) if want_bits else y
+
+
+def mm_tn_adrop(a, g, p, a_seed, row0=0, rowscale=None):
+    """dropout_{a_seed}(a)^T @ (rowscale * g) with the keep-mask regenerated while a is staged (cb_gemm_tn_adrop_f32); None where unsupported."""
+    import ctypes
+    from . import ops
+    lib = _lib.load()
+    _lib.require_device(a, g, rowscale)
+    a, g = _rowmajor(a), _rowmajor(g)
+    M, K1 = a.shape
+    M2, K2 = g.shape
+    if M != M2 or not (0.0 < p < 1.0) or not lib.cb_gemm_tn_adrop_supported(_lib.ptr(a), _ld(a), _lib.ptr(g), _ld(g), K1, K2):
+        return None
+    out = torch.empty((K1, K2), dtype=torch.float32, device=a.device)
+    wsb = lib.cb_gemm_tn_workspace_bytes(M, K1, K2)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.cb_gemm_tn_adrop_f32(_lib.ptr(a), _ld(a), _lib.ptr(g), _ld(g), _lib.ptr(rowscale), _lib.ptr(out), M, K1, K2, float(p),
+                                            ctypes.c_uint64(a_seed), ops.seed_dev_ptr(), int(row0), _lib.ptr(ws), wsb, _lib.stream_ptr()),
+                   'cb_gemm_tn_adrop_f32')
+    return out
+
+
 def mm_tn_gdrop(a, g, p, g_seed, row0=0):
     """a^T @ dropout_{g_seed}(g) with the keep-mask regenerated while g is staged (cb_gemm_tn_gdrop_f32); None where unsupported."""
     import ctypes

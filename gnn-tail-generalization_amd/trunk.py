@@ -266,15 +266,26 @@ class _TrunkFn(torch.autograd.Function):
         x = x.contiguous()
         bwd = bool(track) and any(ctx.needs_input_grad)          # eval / metrics forwards (no_grad): no mask words, nothing kept
         # the dropout of the input features (GCN.py:104) is applied by the input Linear's GEMM while it stages x (no dropped copy of x
-        # is written, kept or re-read: the weight gradient regenerates the mask) where that form exists; CB_TRUNK_INDROP=0 keeps the pass
-        fused_in = None
-        if p > 0 and os.environ.get('CB_TRUNK_INDROP', '1') != '0':
-            fused_in = gemm.mm_nn_indrop_drop2(x, w_in.t().contiguous(), p, seeds[0], seeds[1], row0, bias=b_in, relu=True,
-                                               want_bits=bwd and w_in.shape[0] == 256)
-        x0_bits = None
+        # is written, kept or re-read: the weight gradient regenerates the mask) where that form exists; CB_TRUNK_INDROP=0 keeps the pass.
+        # Round 4: the dropout in front of layer 0 (GCN.py:110) is applied to X0 the same way by layer 0's GEMM, so X0's dropped copy
+        # (10 GB at the headline size: one more output stream of the input Linear, one more tensor kept for the backward) does not exist
+        # either; `cur` stays None until a path that has no such form asks for the copy (dropped_x0()).
+        fused_in = x0_bits = cur = None
+        indrop = p > 0 and os.environ.get('CB_TRUNK_INDROP', '1') != '0'
+        if indrop:
+            wb = bwd and w_in.shape[0] == 256
+            r = None if os.environ.get('CB_TRUNK_X0_COPY', '0') == '1' else gemm.mm_nn_indrop(x, w_in.t().contiguous(), p, seeds[0], row0, bias=b_in,
+                                                                                              relu=True, want_bits=wb)
+            if r is not None:
+                fused_in = True
+                x0, x0_bits = r if wb else (r, None)
+            else:
+                fused_in = gemm.mm_nn_indrop_drop2(x, w_in.t().contiguous(), p, seeds[0], seeds[1], row0, bias=b_in, relu=True,
+                                                   want_bits=bwd and w_in.shape[0] == 256)
+                if fused_in is not None:
+                    x0, cur = fused_in[0], fused_in[1]
+                    x0_bits = fused_in[2] if len(fused_in) > 2 else None      # mask words of (X0 > 0): what the input stage of the backward reads instead of X0
         if fused_in is not None:
-            x0, cur = fused_in[0], fused_in[1]
-            x0_bits = fused_in[2] if len(fused_in) > 2 else None      # mask words of (X0 > 0): what the input stage of the backward reads instead of X0
             xd = x                    # saved for the backward: the UNdropped features
         else:
             xd = ops._dropout_raw(x, p, seeds[0], row0 * x.shape[1]) if p > 0 else x
@@ -282,6 +293,9 @@ class _TrunkFn(torch.autograd.Function):
                 x0, cur = gemm.mm_nn_drop2(xd, w_in.t().contiguous(), p, seeds[1], row0, bias=b_in, relu=True)
             else:
                 x0 = cur = gemm.mm_nn(xd, w_in.t().contiguous(), bias=b_in, relu=True)
+
+        def dropped_x0():
+            return ops._dropout_raw(x0, p, seeds[1], row0 * x0.shape[1])
         ctx.indrop = fused_in is not None
         h = x0.shape[1]
         saved_in, saved_bits = [cur], []
@@ -290,9 +304,15 @@ class _TrunkFn(torch.autograd.Function):
         for l in range(L):
             w, b, le = layer_params[3 * l: 3 * l + 3]
             sd_l = seeds[l + 2] if p > 0 else 0
+            if cur is None:      # layer 0 with no dropped copy of X0: its GEMM draws the mask while it stages X0
+                z0 = None if (agg_bf16 or (not ag and _chunked(graph, agg_bf16))) else gemm.mm_nn_indrop(x0, w, p, seeds[1], row0, rowscale=a, addend=le)
+                if z0 is None:
+                    cur = saved_in[0] = dropped_x0()
+            else:
+                z0 = None
             if ag:
                 from .graph import weight_image
-                z = z_ready if z_ready is not None else gemm.mm_nn(cur, w, rowscale=a, addend=le)
+                z = z_ready if z_ready is not None else z0 if z0 is not None else gemm.mm_nn(cur, w, rowscale=a, addend=le)
                 z_ready = None
                 if l + 1 < L:     # this layer's store + the next layer's transform in one kernel
                     w1, _, le1 = layer_params[3 * (l + 1): 3 * (l + 1) + 3]
@@ -308,9 +328,9 @@ class _TrunkFn(torch.autograd.Function):
                         gemm.mm_nn(cur[r0:r1], w, rowscale=a[r0:r1], addend=le[r0:r1] if le is not None else None, out=z[r0:r1])
                 bits, cur, _ = _fused_spmm(graph, z, b, x0, 1 - alpha, alpha, p, sd_l, produce=produce, want_bits=bwd)
             else:
-                z = gemm.mm_nn(cur, w, rowscale=a, addend=le, out_bf16=agg_bf16)
+                z = z0 if z0 is not None else gemm.mm_nn(cur, w, rowscale=a, addend=le, out_bf16=agg_bf16)
                 bits, cur, _ = _fused_spmm(graph, z, b, x0, 1 - alpha, alpha, p, sd_l, want_bits=bwd)
-            del z
+            del z, z0
             if bwd:
                 saved_bits.append(bits)
                 saved_in.append(cur)
@@ -361,6 +381,15 @@ class _TrunkFn(torch.autograd.Function):
         ag_bwd = agg_gemm_eligible(graph, h, agg_bf16)
         tail_tb = ag_bwd and gather and tail_trunk_bwd(graph)      # (the accumulate-in-place form needs the pass: it also adds into gx0)
 
+        def dw_layer(l, x_in, gz):
+            """X_l^T (a * dZ_l).  Layer 0 without a dropped copy of X0 (x_in is None): the mask of the dropout in front of layer 0 is
+            regenerated from X0 while the GEMM stages it (cb_gemm_tn_adrop_f32)."""
+            if x_in is not None:
+                return gemm.mm_tn(x_in, gz, rowscale=a)
+            sd0 = seeds[1] if p > 0 else 0
+            dw = gemm.mm_tn_adrop(x0, gz, p, sd0, row0, rowscale=a)
+            return dw if dw is not None else gemm.mm_tn(ops._dropout_raw(x0, p, sd0, row0 * x0.shape[1]), gz, rowscale=a)
+
         def dx_gemm(src, wt, rowscale, below, g_ready=None):
             """dL/dx of the stage above layer `below` and that layer's trunk backward: (g, gr, dbias, handle); handle = the already started
             exchange of gr (row-chunked producers of the node-sharded pull pipeline), else None."""
@@ -400,7 +429,7 @@ class _TrunkFn(torch.autograd.Function):
             if sharded and handle is None:
                 handle = graph.aggregate_start(gr, True)                        # node-sharded: the exchange is in flight from here
             if deferred is not None:
-                grads_layers[3 * deferred[0]] = gemm.mm_tn(deferred[1], deferred[2], rowscale=a)
+                grads_layers[3 * deferred[0]] = dw_layer(*deferred)
                 deferred = None
             g_fused = tb_fused = None
             if ag_bwd:
@@ -433,7 +462,7 @@ class _TrunkFn(torch.autograd.Function):
                 if sharded:
                     deferred = (l, saved_in[l], gz)
                 else:
-                    grads_layers[3 * l] = gemm.mm_tn(saved_in[l], gz, rowscale=a)
+                    grads_layers[3 * l] = dw_layer(l, saved_in[l], gz)
             grads_layers[3 * l + 1] = dbias
             if l > 0 and tb_fused is not None:
                 g, (gr, dbias) = g_fused, tb_fused
@@ -446,7 +475,7 @@ class _TrunkFn(torch.autograd.Function):
             else:
                 del gz
         if deferred is not None:
-            grads_layers[3 * deferred[0]] = gemm.mm_tn(deferred[1], deferred[2], rowscale=a)
+            grads_layers[3 * deferred[0]] = dw_layer(*deferred)
             deferred = None
         # input stage: X0 feeds layer 0 (through its dropout) and every mix
         if gather:

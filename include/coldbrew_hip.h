@@ -426,6 +426,17 @@ int cb_gemm_nn_indrop_supported(const float* A, int64_t lda, const float* B, int
 int cb_gemm_nn_indrop_drop2_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, float* C2, int64_t ldc2,
                                 int64_t M, int64_t N, int64_t K, const float* bias, int relu, float a_drop_p, uint64_t a_seed, float drop_p,
                                 uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, void* stream);
+/* Single-output forms of the same (no dropped copy of the OUTPUT either): the input Linear writes X0 (+ its mask words) only, and the first
+ * GCNConv's transform applies the dropout in front of layer 0 (GCN.py:110) to X0 while IT stages it; its weight gradient regenerates that mask:
+ *     C = act(rowscale * (dropout(A) @ B) + addend + bias)             cb_gemm_nn_indrop_f32   (cb_gemm_nn_indrop_supported with C2 = C)
+ *     C = dropout(A)^T @ (rowscale * G)                                cb_gemm_tn_adrop_f32    (cb_gemm_tn_adrop_supported)
+ * X0's dropped copy (10 GB at the headline size) is then never written, kept or read.  Bit-identical to the forms with the copy. */
+int cb_gemm_nn_indrop_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                          const float* rowscale, const float* addend, int64_t ld_add, const float* bias, int relu, float a_drop_p, uint64_t a_seed,
+                          const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, void* stream);
+int cb_gemm_tn_adrop_supported(const float* A, int64_t lda, const float* G, int64_t ldg, int64_t K1, int64_t K2);
+int cb_gemm_tn_adrop_f32(const float* A, int64_t lda, const float* G, int64_t ldg, const float* rowscale, float* C, int64_t M, int64_t K1, int64_t K2,
+                         float a_drop_p, uint64_t a_seed, const uint64_t* seed_dev, int64_t row0, void* ws, size_t ws_bytes, void* stream);
 int cb_gemm_tn_gdrop_supported(const float* A, int64_t lda, const float* G, int64_t ldg, int64_t K1, int64_t K2);
 int cb_gemm_tn_gdrop_f32(const float* A, int64_t lda, const float* G, int64_t ldg, float* C, int64_t M, int64_t K1, int64_t K2, float g_drop_p,
                          uint64_t g_seed, const uint64_t* seed_dev, int64_t row0, void* ws, size_t ws_bytes, void* stream);

@@ -430,3 +430,19 @@ def test_operand_dropout_gemms_equal_dropout_then_gemm(M, K, N, row0):
         o_a, c_a = trunk._input_bwd_multi(g, 5, [g1], [6], 0.1, y, p, row0)
         o_b, c_b = trunk._input_bwd_multi(g, 5, [g1], [6], 0.1, y, p, row0, act_bits=bits)
         assert torch.equal(o_a, o_b) and torch.equal(c_a, c_b)
+        # round 4: the single-output form (no dropped copy of the OUTPUT either) + mask words
+        y4, bits4 = gemm.mm_nn_indrop(x, w, p, s_in, row0, bias=b, relu=True, want_bits=True)
+        assert torch.equal(y4, y) and torch.equal(bits4, bits)
+        # ... and the next GEMM that applies the dropout of y while IT stages y (layer 0's transform: row scale + addend epilogue),
+        # with the weight gradient that regenerates that mask from y
+        w2 = torch.randn(N, 256, device=DEV, generator=gen) * 0.1
+        rs = torch.rand(M, device=DEV, generator=gen) + 0.5
+        le = torch.randn(M, 256, device=DEV, generator=gen)
+        z = gemm.mm_nn_indrop(y, w2, p, s_out, row0, rowscale=rs, addend=le)
+        assert z is not None and torch.equal(z, gemm.mm_nn(yd, w2, rowscale=rs, addend=le))
+        gz = torch.randn(M, 256, device=DEV, generator=gen)
+        dw2 = gemm.mm_tn_adrop(y, gz, p, s_out, row0, rowscale=rs)
+        assert dw2 is not None and torch.equal(dw2, gemm.mm_tn(yd, gz, rowscale=rs))
+        dw3 = gemm.mm_tn_adrop(y, gz, p, s_out, row0)
+        assert torch.equal(dw3, gemm.mm_tn(yd, gz))
+        assert gemm.mm_nn_indrop(y[:100], w2, p, s_out, 0, rowscale=rs[:100]) is None                # too few tiles: the caller materialises the copy
