@@ -100,6 +100,10 @@ SIGNATURES = {
                                              ctypes.c_uint64, _P, _I64, _P, _P]),
     'cb_gemm_tn_adrop_supported': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I64]),
     'cb_gemm_tn_adrop_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _SZ, _P]),
+    'cb_front_image_bytes': (_SZ, [_I64]),
+    'cb_front_image_f32': (ctypes.c_int, [_P, _I64, _I64, ctypes.c_int, _P, _SZ, _P]),
+    'cb_trunk_front_f32': (ctypes.c_int, [_P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, ctypes.c_float,
+                                          ctypes.c_uint64, ctypes.c_uint64, _P, _I64, _P]),
     'cb_gemm_tn_gdrop_supported': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I64]),
     'cb_gemm_tn_gdrop_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _SZ, _P]),
     'cb_spmm_gemm_trunkbwd_workspace_bytes': (_SZ, []),

@@ -16,7 +16,7 @@
 // bit-identical to cb_gemm_nn_f32 on the same inputs (tests/test_gpu_agg_gemm.py, tests/test_gpu_fullsize.py at 10^7 rows).
 //   A operand: the LDS tile; a fragment (8 consecutive k of one row) = two ds_read_b128, split into limbs in registers
 //              (1040-byte tile rows: the 16 lanes of a b128 group hit 16 distinct 16-byte bank columns);
-//   B operand: the weight, split ONCE per launch by k_agg_gemm_image into MFMA fragment order (384 KB, L2 resident): a fragment is
+//   B operand: the weight, split ONCE per launch by k_weight_image into MFMA fragment order (384 KB, L2 resident): a fragment is
 //              one coalesced global_load_dwordx4 per limb, no LDS, no conversion in the K loop;
 //   C: accumulators -> wave-private LDS strips -> row-major float4 -> epilogue -> 256-byte streaming row segments.
 // Hub rows (more edges than the hub threshold) are reduced by the hub kernels, which run BEFORE this kernel; their finished rows are
@@ -29,17 +29,12 @@
 #include "cb_common.h"
 #include "cb_limb_core.h"
 #include "cb_spmm_core.h"
+#include "cb_tile_gemm.h"
 
 namespace cb {
 
-constexpr int kTM = 64;      // rows per tile
-constexpr int kTLD = 260;    // floats per LDS tile row
-constexpr int kKD = 256;     // width of the aggregated rows = K of the dense part
-constexpr int kND = 256;     // output width of the dense part
-constexpr int kNT = kND / 32, kNS = kKD / 16;
-
 struct GemmTail {
-  const uint4* image;      // weight limbs in fragment order (k_agg_gemm_image)
+  const uint4* image;      // weight limbs in fragment order (k_weight_image)
   const float* rowscale;   // [rows] or null
   const float* addend;     // [rows, ld_add] or null
   int64_t ld_add;
@@ -62,11 +57,11 @@ struct GemmTail {
   int* err;                // device-visible error word (cb_error.hip): a tile hand-over that timed out is recorded here, never silent
 };
 
-// image[((s * kNT + j) * 3 + p) * 64 + lane] = limb p of B[16 s + 8 (lane >> 5) + e][32 j + (lane & 31)], e = 0..7 (B[k][n] = W[k * sk + n * sn])
-__global__ void __launch_bounds__(256) k_agg_gemm_image(const float* __restrict__ W, int64_t sk, int64_t sn, uint4* __restrict__ image) {
+// (declared in cb_tile_gemm.h)
+__global__ void __launch_bounds__(256) k_weight_image(const float* __restrict__ W, int64_t sk, int64_t sn, uint4* __restrict__ image, int n_steps) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const int lane = idx & 63, sj = idx >> 6, j = sj % kNT, s = sj / kNT;
-  if (s >= kNS) return;
+  if (s >= n_steps) return;
   const int k0 = 16 * s + 8 * (lane >> 5), n = 32 * j + (lane & 31);
   uint32_t h[4], m[4], l[4];
 #pragma unroll
@@ -77,8 +72,6 @@ __global__ void __launch_bounds__(256) k_agg_gemm_image(const float* __restrict_
   o[64] = make_uint4(m[0], m[1], m[2], m[3]);
   o[128] = make_uint4(l[0], l[1], l[2], l[3]);
 }
-
-__device__ __forceinline__ bf16x8 as_bf16x8(const uint4& v) { return __builtin_bit_cast(bf16x8, v); }
 
 // Hand-over of the LDS tile buffers WITHOUT a block barrier: two counters per buffer in LDS.
 //   ready[b]: +1 by every gathering wavefront that has written its rows of the tile in buffer b   (tile complete at kNG * (use + 1))
@@ -168,8 +161,6 @@ __device__ __forceinline__ void ag2_gather_tile(int t, float* __restrict__ tile,
   }
 }
 
-constexpr int kCLD = 68;     // floats per row of a multiplying wavefront's private C strip (8 rows x 64 columns)
-
 // One K step of B fragments in flight per multiplying wavefront (two register buffers, K loop unrolled by two): next to wavefronts that
 // keep dozens of gathers outstanding, a load of this CU — L2 hit or not — comes back after microseconds.
 template <bool TB>
@@ -177,56 +168,7 @@ __device__ __forceinline__ void ag2_mfma_tile(int t, const float* __restrict__ t
                                               const GemmTail& gt, float (&colsum)[4], uint64_t seed_eff, int* freed) {
   const int l31 = lane & 31, lh = lane >> 5;
   f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  const float* a_row[2] = {tile + l31 * kTLD + 8 * lh, tile + (32 + l31) * kTLD + 8 * lh};
-  // B fragments: a RUNNING pointer, advanced every K step (fixed per-step addresses would all be loop invariants of the persistent
-  // tile loop: the compiler hoists them — 96 address pairs — and spills)
-  const uint4* bp = gt.image + ((int64_t)(2 * w) * 3) * 64 + lane;
-  uint4 bq[2][2][3];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int p = 0; p < 3; ++p) bq[0][j][p] = bp[j * 192 + p * 64];
-  bp += kNT * 192;
-#pragma unroll(2)
-  for (int s = 0; s < kNS; ++s) {
-    const int cur = s & 1, nx = cur ^ 1;
-    if (s + 1 < kNS) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) bq[nx][j][p] = bp[j * 192 + p * 64];
-    }
-    bp += kNT * 192;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {      // one 32-row block of A at a time: its limbs live only across its twelve MFMAs
-      const float4 x0 = *reinterpret_cast<const float4*>(a_row[i] + 16 * s);
-      const float4 x1 = *reinterpret_cast<const float4*>(a_row[i] + 16 * s + 4);
-      uint32_t hh[4], mm[4], ll[4];
-      split3x2(x0.x, x0.y, hh[0], mm[0], ll[0]);
-      split3x2(x0.z, x0.w, hh[1], mm[1], ll[1]);
-      split3x2(x1.x, x1.y, hh[2], mm[2], ll[2]);
-      split3x2(x1.z, x1.w, hh[3], mm[3], ll[3]);
-      const bf16x8 a_hi = as_bf16x8(make_uint4(hh[0], hh[1], hh[2], hh[3]));
-      const bf16x8 a_mid = as_bf16x8(make_uint4(mm[0], mm[1], mm[2], mm[3]));
-      const bf16x8 a_lo = as_bf16x8(make_uint4(ll[0], ll[1], ll[2], ll[3]));
-      // limb products in increasing magnitude, the order of limb_tile_step (cb_limb_core.h)
-#define CB_AG_MFMA2(A_, P_) \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, as_bf16x8(bq[cur][j][P_]), acc[i][j], 0, 0, 0);
-      CB_AG_MFMA2(a_lo, 0)
-      CB_AG_MFMA2(a_hi, 2)
-      CB_AG_MFMA2(a_mid, 1)
-      CB_AG_MFMA2(a_mid, 0)
-      CB_AG_MFMA2(a_hi, 1)
-      CB_AG_MFMA2(a_hi, 0)
-#undef CB_AG_MFMA2
-    }
-  }
+  tile_times_image<kNS, kTLD>(tile, gt.image, w, lane, acc);
   ag_signal(freed, lane);      // the tile has been read for the last time
   // epilogue through a WAVE-PRIVATE staging strip (the tile itself is still being read by the other three multiplying wavefronts
   // and there is no barrier among four of twelve wavefronts): 8 rows x 64 columns per pass, transposed so that a lane applies
@@ -430,7 +372,7 @@ extern "C" int cb_agg_gemm_image_f32(const float* W, int64_t ld, int64_t K, int6
   CB_CHECK_ARG(image_bytes >= cb_agg_gemm_image_bytes(K, N) && ag_al16(image), CB_E_WORKSPACE, "cb_agg_gemm_image_f32: image buffer too small or misaligned");
   // B[k][n] = W[k][n] (transpose = 0) or W[n][k] (transpose = 1: the dX contraction multiplies by W^T)
   const int64_t sk = transpose ? 1 : ld, sn = transpose ? ld : 1;
-  hipLaunchKernelGGL(k_agg_gemm_image, dim3(kNS * kNT * 64 / 256), dim3(256), 0, (hipStream_t)stream, W, sk, sn, (uint4*)image);
+  hipLaunchKernelGGL(k_weight_image, dim3(kNS * kNT * 64 / 256), dim3(256), 0, (hipStream_t)stream, W, sk, sn, (uint4*)image, kNS);
   CB_LAUNCH_CHECK();
   return CB_OK;
 }

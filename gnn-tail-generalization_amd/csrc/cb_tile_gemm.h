@@ -1,0 +1,115 @@
+// "An fp32 tile in LDS times a 256-column weight on the matrix cores": the dense part shared by the aggregation + GEMM kernels
+// (cb_agg_gemm.hip: the tile is the block's 64 aggregated rows) and the forward front (cb_front.hip: the tile is 64 rows of x, then of X0).
+// Arithmetic = cb_gemm_limb.hip's, product by product (three exact bf16 limbs per fp32 operand, the six leading limb products per K step
+// in limb_tile_step's order, fp32 MFMA accumulators), so results are bit-identical to cb_gemm_nn_f32 on the same operands.
+//   A operand: the LDS tile; a fragment (8 consecutive k of one row) = two ds_read_b128, split into limbs in registers (tile rows of
+//              TLD floats, TLD * 4 = 16 mod 256 bytes: the 16 lanes of a b128 group hit 16 distinct 16-byte bank columns);
+//   B operand: the weight, split ONCE per launch by k_weight_image into MFMA fragment order (K x 256 x 6 bytes, L2 resident): a fragment
+//              is one coalesced global_load_dwordx4 per limb, no LDS, no conversion in the K loop.
+#pragma once
+#include "cb_common.h"
+#include "cb_limb_core.h"
+
+namespace cb {
+
+constexpr int kTM = 64;      // rows per tile
+constexpr int kTLD = 260;    // floats per LDS tile row (256-wide tiles)
+constexpr int kKD = 256;     // width of the aggregated rows = K of the dense part of cb_agg_gemm.hip
+constexpr int kND = 256;     // output width of the dense part
+constexpr int kNT = kND / 32, kNS = kKD / 16;
+
+// image[((s * kNT + j) * 3 + p) * 64 + lane] = limb p of B[16 s + 8 (lane >> 5) + e][32 j + (lane & 31)], e = 0..7 (B[k][n] = W[k * sk + n * sn]),
+// s < n_steps (K = 16 n_steps rows of B)
+__global__ void __launch_bounds__(256) k_weight_image(const float* __restrict__ W, int64_t sk, int64_t sn, uint4* __restrict__ image, int n_steps);
+
+__device__ __forceinline__ bf16x8 as_bf16x8(const uint4& v) { return __builtin_bit_cast(bf16x8, v); }
+
+// 16-byte store of a value that is written once and read by a later kernel: streaming (nt) policy
+__device__ __forceinline__ void store_stream4(float* __restrict__ p, const float (&v)[4]) {
+  typedef float f4_t __attribute__((ext_vector_type(4)));
+  const f4_t q = {v[0], v[1], v[2], v[3]};
+  __builtin_nontemporal_store(q, reinterpret_cast<f4_t*>(p));
+}
+
+// acc[i][j] (+)= rows 32 i .. 32 i + 31 of the tile  x  columns 64 w + 32 j .. + 31 of B, over NSTEPS K steps of 16.
+// One K step of B fragments in flight per wavefront (two register buffers, K loop unrolled by two).
+template <int NSTEPS, int TLD>
+__device__ __forceinline__ void tile_times_image(const float* __restrict__ tile, const uint4* __restrict__ image, int w, int lane, f32x16 (&acc)[2][2]) {
+  const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const float* a_row[2] = {tile + l31 * TLD + 8 * lh, tile + (32 + l31) * TLD + 8 * lh};
+  // B fragments: a RUNNING pointer, advanced every K step (fixed per-step addresses would all be loop invariants of the persistent
+  // tile loop: the compiler hoists them — 96 address pairs — and spills)
+  const uint4* bp = image + ((int64_t)(2 * w) * 3) * 64 + lane;
+  uint4 bq[2][2][3];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bq[0][j][p] = bp[j * 192 + p * 64];
+  bp += kNT * 192;
+#pragma unroll(2)
+  for (int s = 0; s < NSTEPS; ++s) {
+    const int cur = s & 1, nx = cur ^ 1;
+    if (s + 1 < NSTEPS) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[nx][j][p] = bp[j * 192 + p * 64];
+    }
+    bp += kNT * 192;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {      // one 32-row block of A at a time: its limbs live only across its twelve MFMAs
+      const float4 x0 = *reinterpret_cast<const float4*>(a_row[i] + 16 * s);
+      const float4 x1 = *reinterpret_cast<const float4*>(a_row[i] + 16 * s + 4);
+      uint32_t hh[4], mm[4], ll[4];
+      split3x2(x0.x, x0.y, hh[0], mm[0], ll[0]);
+      split3x2(x0.z, x0.w, hh[1], mm[1], ll[1]);
+      split3x2(x1.x, x1.y, hh[2], mm[2], ll[2]);
+      split3x2(x1.z, x1.w, hh[3], mm[3], ll[3]);
+      const bf16x8 a_hi = as_bf16x8(make_uint4(hh[0], hh[1], hh[2], hh[3]));
+      const bf16x8 a_mid = as_bf16x8(make_uint4(mm[0], mm[1], mm[2], mm[3]));
+      const bf16x8 a_lo = as_bf16x8(make_uint4(ll[0], ll[1], ll[2], ll[3]));
+      // limb products in increasing magnitude, the order of limb_tile_step (cb_limb_core.h)
+#define CB_TG_MFMA2(A_, P_) \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, as_bf16x8(bq[cur][j][P_]), acc[i][j], 0, 0, 0);
+      CB_TG_MFMA2(a_lo, 0)
+      CB_TG_MFMA2(a_hi, 2)
+      CB_TG_MFMA2(a_mid, 1)
+      CB_TG_MFMA2(a_mid, 0)
+      CB_TG_MFMA2(a_hi, 1)
+      CB_TG_MFMA2(a_hi, 0)
+#undef CB_TG_MFMA2
+    }
+  }
+}
+
+constexpr int kCLD = 68;     // floats per row of a wavefront's private C strip (8 rows x 64 columns)
+
+// Epilogue of a wavefront's 64 x 64 block of accumulators through a WAVE-PRIVATE staging strip: 8 rows x 64 columns per pass, transposed so
+// that a lane holds a float4 of one row; fn(m, n, v) receives tile row m (0 .. 63), column n (64 w + 4 (idx & 15)) and the four values.
+template <class F>
+__device__ __forceinline__ void acc_rows_through_strip(const f32x16 (&acc)[2][2], float* __restrict__ cs, int w, int lane, F&& fn) {
+  const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cs[(r4 + 4 * lh) * kCLD + 32 * j + l31] = acc[i][j][4 * q + r4];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int idx = lane + 64 * half, row = idx >> 4, c4 = (idx & 15) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(cs + row * kCLD + c4);
+        fn(32 * i + 8 * q + row, 64 * w + c4, v);
+      }
+    }
+}
+
+}  // namespace cb

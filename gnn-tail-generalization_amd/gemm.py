@@ -137,6 +137,44 @@ def mm_nn_indrop(a, b, p, a_seed, row0=0, rowscale=None, addend=None, bias=None,
     return (y, bits) if want_bits else y
 
 
+def trunk_front(x, w_in, b_in, w0, rowscale, addend, p, seed_x, seed_x0, row0=0, want_bits=False, want_drop=False):
+    """The forward front of the residual trunk in one kernel (cb_trunk_front_f32): X0 = relu(dropout_{seed_x}(x) @ w_in^T + b_in) and
+    Z0 = rowscale * (dropout_{seed_x0}(X0) @ w0) + addend; dropout(X0) stays on chip unless want_drop.  Returns (x0, bits | None,
+    x0_drop | None, z0), or None where the kernel does not exist for the shape (input width not 64 / 128, hidden width not 256,
+    misaligned operands).  w_in: nn.Linear layout [256, K]; w0: [256, 256]."""
+    import ctypes
+    from . import ops
+    lib = _lib.load()
+    _lib.require_device(x, w_in, b_in, w0, rowscale, addend)
+    if x.dim() != 2 or x.dtype != torch.float32 or tuple(w_in.shape) != (256, x.shape[1]) or tuple(w0.shape) != (256, 256):
+        return None
+    M, K = x.shape
+    nb_in = lib.cb_front_image_bytes(K)
+    if not nb_in or w_in.dtype != torch.float32 or w0.dtype != torch.float32:
+        return None
+    x, w_in, w0 = _rowmajor(x), _rowmajor(w_in), _rowmajor(w0)
+    if addend is not None:
+        addend = _rowmajor(addend)
+    if x.data_ptr() % 16 or _ld(x) % 4 or (addend is not None and (addend.data_ptr() % 16 or _ld(addend) % 4)):
+        return None
+    dev = x.device
+    img_in = torch.empty(nb_in, dtype=torch.uint8, device=dev)
+    nb0 = lib.cb_agg_gemm_image_bytes(256, 256)
+    img0 = torch.empty(nb0, dtype=torch.uint8, device=dev)
+    x0 = torch.empty((M, 256), dtype=torch.float32, device=dev)
+    z0 = torch.empty((M, 256), dtype=torch.float32, device=dev)
+    bits = torch.empty((M, 1, 4), dtype=torch.int64, device=dev) if want_bits else None
+    xd = torch.empty((M, 256), dtype=torch.float32, device=dev) if want_drop else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.cb_front_image_f32(_lib.ptr(w_in), _ld(w_in), K, 1, _lib.ptr(img_in), nb_in, _lib.stream_ptr()), 'cb_front_image_f32')
+        _lib.check(lib.cb_agg_gemm_image_f32(_lib.ptr(w0), _ld(w0), 256, 256, 0, _lib.ptr(img0), nb0, _lib.stream_ptr()), 'cb_agg_gemm_image_f32')
+        _lib.check(lib.cb_trunk_front_f32(_lib.ptr(x), _ld(x), M, K, _lib.ptr(img_in), _lib.ptr(b_in), _lib.ptr(img0), _lib.ptr(rowscale),
+                                          _lib.ptr(addend), _ld(addend) if addend is not None else 0, _lib.ptr(x0), 256, _lib.ptr(bits),
+                                          _lib.ptr(xd), 256, _lib.ptr(z0), 256, float(p), ctypes.c_uint64(seed_x), ctypes.c_uint64(seed_x0),
+                                          ops.seed_dev_ptr(), int(row0), _lib.stream_ptr()), 'cb_trunk_front_f32')
+    return x0, bits, xd, z0
+
+
 def mm_tn_adrop(a, g, p, a_seed, row0=0, rowscale=None):
     """dropout_{a_seed}(a)^T @ (rowscale * g) with the keep-mask regenerated while a is staged (cb_gemm_tn_adrop_f32); None where unsupported."""
     import ctypes

@@ -206,13 +206,12 @@ def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0, act_bits=No
 
 
 # The trunk backward of the layer below (dropout / mix / ReLU backward, row scale, bias column sums: cb_trunk_layer_bwd_f32's pass over dL/dx)
-# in the epilogue of the reverse aggregation + dX kernel (cb_spmm_gemm_trunkbwd_f32).  One GPU: measured neutral on S-pl10M (202.0-203.2 vs
-# 201.8-202.2 ms per step, profiles/r03_fused_agg_gemm.md), so the pass stays a kernel of its own there; node-sharded: on — the next reverse
-# aggregation's input is then complete when the kernel ends, and its first slice can be packed and sent at once.  CB_AGG_GEMM_TRUNKBWD=0/1
-# overrides.  Bias gradients are summed in another order than by the pass (block partials): equal to rounding, not bit for bit.
+# in the epilogue of the reverse aggregation + dX kernel (cb_spmm_gemm_trunkbwd_f32): opt-in, CB_AGG_GEMM_TRUNKBWD=1.  Measured neutral on one
+# GPU (202.0-203.2 vs 201.8-202.2 ms per step on S-pl10M, profiles/r03_fused_agg_gemm.md) and slower as the last halo pass of a sharded
+# aggregation (2.40 vs 1.62 + 0.48 ms at P = 8, profiles/r04_shard_probe_S-pl10M.txt): whatever leaves through the multiplying wavefronts'
+# epilogue is paid at their store rate.  Bias gradients are summed in another order than by the pass: equal to rounding, not bit for bit.
 def tail_trunk_bwd(graph):
-    env = os.environ.get('CB_AGG_GEMM_TRUNKBWD')
-    return env == '1' if env in ('0', '1') else hasattr(graph, 'part')
+    return os.environ.get('CB_AGG_GEMM_TRUNKBWD', '0') == '1'
 
 
 # The input Linear's GEMM writes the mask words of (X0 > 0) from its epilogue (a wavefront holds a whole 256-column row there: four ballots),
@@ -270,9 +269,21 @@ class _TrunkFn(torch.autograd.Function):
         # Round 4: the dropout in front of layer 0 (GCN.py:110) is applied to X0 the same way by layer 0's GEMM, so X0's dropped copy
         # (10 GB at the headline size: one more output stream of the input Linear, one more tensor kept for the backward) does not exist
         # either; `cur` stays None until a path that has no such form asks for the copy (dropped_x0()).
-        fused_in = x0_bits = cur = None
+        fused_in = x0_bits = cur = z_front = None
         indrop = p > 0 and os.environ.get('CB_TRUNK_INDROP', '1') != '0'
-        if indrop:
+        # Round 4: the whole forward front — dropout(x), input Linear, ReLU, dropout(X0), layer 0's transform — in ONE kernel
+        # (cb_trunk_front_f32): a block keeps its 64 rows of dropout(X0) in LDS and multiplies them by W_0 at once.  The dropped copy is
+        # stored only on request (CB_TRUNK_X0_COPY=1: the layer-0 weight gradient then reads it instead of regenerating the mask).
+        if (indrop or p == 0) and not agg_bf16 and L >= 1 and w_in.shape[0] == 256 and os.environ.get('CB_TRUNK_FRONT', '1') != '0':
+            w0_, _b0, le0_ = layer_params[0:3]
+            want_copy = bwd and p > 0 and os.environ.get('CB_TRUNK_X0_COPY', '0') == '1'
+            fr = gemm.trunk_front(x, w_in, b_in, w0_, a, le0_, p, seeds[0], seeds[1], row0, want_bits=bwd, want_drop=want_copy)
+            if fr is not None:
+                x0, x0_bits, cur, z_front = fr
+                fused_in = True
+                if p == 0:
+                    cur = x0
+        if fused_in is None and indrop:
             wb = bwd and w_in.shape[0] == 256
             r = None if os.environ.get('CB_TRUNK_X0_COPY', '0') == '1' else gemm.mm_nn_indrop(x, w_in.t().contiguous(), p, seeds[0], row0, bias=b_in,
                                                                                               relu=True, want_bits=wb)
@@ -304,12 +315,13 @@ class _TrunkFn(torch.autograd.Function):
         for l in range(L):
             w, b, le = layer_params[3 * l: 3 * l + 3]
             sd_l = seeds[l + 2] if p > 0 else 0
-            if cur is None:      # layer 0 with no dropped copy of X0: its GEMM draws the mask while it stages X0
+            z0 = None
+            if l == 0 and z_front is not None:      # left the forward-front kernel
+                z0 = z_front
+            elif cur is None:      # layer 0 with no dropped copy of X0: its GEMM draws the mask while it stages X0
                 z0 = None if (agg_bf16 or (not ag and _chunked(graph, agg_bf16))) else gemm.mm_nn_indrop(x0, w, p, seeds[1], row0, rowscale=a, addend=le)
                 if z0 is None:
                     cur = saved_in[0] = dropped_x0()
-            else:
-                z0 = None
             if ag:
                 from .graph import weight_image
                 z = z_ready if z_ready is not None else z0 if z0 is not None else gemm.mm_nn(cur, w, rowscale=a, addend=le)
@@ -319,7 +331,7 @@ class _TrunkFn(torch.autograd.Function):
                     bits, cur, z_ready = _fused_gemm(graph, z, b, x0, 1 - alpha, alpha, p, sd_l, weight_image(w1), a, le1, want_bits=bwd)
                 else:
                     bits, cur, _ = _fused_spmm(graph, z, b, x0, 1 - alpha, alpha, p, sd_l, want_bits=bwd)
-            elif _chunked(graph, agg_bf16):
+            elif z0 is None and _chunked(graph, agg_bf16):
                 # node-sharded pipeline: row chunk k of Z leaves the GEMM, is packed and put on the links while chunk k+1 multiplies
                 z = torch.empty((cur.shape[0], w.shape[1]), dtype=torch.float32, device=cur.device)
 
@@ -331,6 +343,7 @@ class _TrunkFn(torch.autograd.Function):
                 z = z0 if z0 is not None else gemm.mm_nn(cur, w, rowscale=a, addend=le, out_bf16=agg_bf16)
                 bits, cur, _ = _fused_spmm(graph, z, b, x0, 1 - alpha, alpha, p, sd_l, want_bits=bwd)
             del z, z0
+            z_front = None
             if bwd:
                 saved_bits.append(bits)
                 saved_in.append(cur)

@@ -405,6 +405,23 @@ int cb_spmm_gemm_fused_f32(const float* acc_init, int64_t ld_init, const int32_t
  * cb_device_status() must then report CB_E_DEVICE. */
 int cb_agg_gemm_handover_selftest(void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * The forward front of the residual trunk in one kernel (csrc/cb_front.hip): GNN_model/GCN.py:104-107 (dropout of x, input Linear, ReLU),
+ * :110 (dropout in front of layer 0) and :213,225,230-235 (first GCNConv's transform):
+ *     X0 = relu(dropout_{seed_x}(x) @ W_in^T + bias_in)                  -> x0 [M, 256] (+ relu_bits [M][4]: mask words of X0 > 0, may be NULL)
+ *     Z0 = rowscale * (dropout_{seed_x0}(X0) @ W_0) + addend             -> z0 [M, 256]
+ * dropout(X0) never leaves the chip unless x0_drop is given (then it is also stored: the backward's weight gradient can read it instead of
+ * regenerating the mask, cb_gemm_tn_adrop_f32).  drop_p = 0: no dropout.  Bit-identical to cb_gemm_nn_indrop_drop2_f32 + cb_gemm_nn_f32.
+ * image_in / image_0: cb_front_image_f32 of W_in (nn.Linear layout [256, K], transpose = 1) and of W_0 ([256, 256], transpose = 0);
+ * K (input features) in {64, 128} — cb_front_image_bytes(K) == 0 says "no forward-front kernel for this K" — and hidden width 256.
+ * ---------------------------------------------------------------------------------- */
+size_t cb_front_image_bytes(int64_t K);
+int cb_front_image_f32(const float* W, int64_t ld, int64_t K, int transpose, void* image, size_t image_bytes, void* stream);
+int cb_trunk_front_f32(const float* x, int64_t ld_x, int64_t M, int64_t K, const void* image_in, const float* bias_in, const void* image_0,
+                       const float* rowscale, const float* addend, int64_t ld_add, float* x0, int64_t ld_x0, uint64_t* relu_bits, float* x0_drop,
+                       int64_t ld_drop, float* z0, int64_t ld_z, float drop_p, uint64_t seed_x, uint64_t seed_x0, const uint64_t* seed_dev,
+                       int64_t row0, void* stream);
+
 /* Edge-weighted aggregation — the `edge_weight` argument of GCNConv.forward (GNN_model/GCN.py:199-202: fn.u_mul_e + fn.sum):
  *     out[v, :] = act( row_scale[v] * sum_{j in row v} w[j] * h[col[j], :] + bias[:] ),   w in CSR order ([E], fp32)
  * and the gradient of the weights, dw[j] = <h[col[j], :], g[row of j, :]>.  The reference asserts len(edge_weight) == E (:200);

@@ -244,10 +244,11 @@ def test_fused_step_equals_modular_step_s_pl1m():
     assert model.model.model.type_trick == 'InitialBatchNorm' and data.x.shape[0] == 1_000_000
     res = {}
     import os
-    for mode in ('fused', 'tailtb', 'x0copy', 'modular'):
+    for mode in ('fused', 'tailtb', 'x0copy', 'nofront', 'nofront_copy', 'modular'):
         TricksComb.use_fused_trunk = mode != 'modular'
         os.environ['CB_AGG_GEMM_TRUNKBWD'] = '1' if mode == 'tailtb' else '0'
-        os.environ['CB_TRUNK_X0_COPY'] = '1' if mode == 'x0copy' else '0'      # round 3's forward front: the input Linear also writes dropout(X0)
+        os.environ['CB_TRUNK_X0_COPY'] = '1' if mode in ('x0copy', 'nofront_copy') else '0'      # dropout(X0) is also stored (round 3 always did)
+        os.environ['CB_TRUNK_FRONT'] = '0' if mode.startswith('nofront') else '1'                 # 0: input Linear and layer-0 GEMM as two kernels
         try:
             model.train()
             model.zero_grad()
@@ -262,10 +263,13 @@ def test_fused_step_equals_modular_step_s_pl1m():
             TricksComb.use_fused_trunk = True
             os.environ.pop('CB_AGG_GEMM_TRUNKBWD', None)
             os.environ.pop('CB_TRUNK_X0_COPY', None)
-    # no dropped copy of X0 (layer 0's GEMM and its weight gradient draw the mask while they stage X0) == the form with the copy, bit for bit
-    assert torch.equal(res['fused'][0], res['x0copy'][0]) and torch.equal(res['fused'][1], res['x0copy'][1])
-    for k in res['fused'][2]:
-        assert torch.equal(res['fused'][2][k], res['x0copy'][2][k]), k
+            os.environ.pop('CB_TRUNK_FRONT', None)
+    # the forward-front kernel (dropout(X0) on chip only; or also stored) == the two-GEMM forms (layer 0's GEMM and its weight gradient draw
+    # the mask while they stage X0; or round 3's form with the dropped copy), bit for bit
+    for other in ('x0copy', 'nofront', 'nofront_copy'):
+        assert torch.equal(res['fused'][0], res[other][0]) and torch.equal(res['fused'][1], res[other][1]), other
+        for k in res['fused'][2]:
+            assert torch.equal(res['fused'][2][k], res[other][2][k]), (other, k)
     for mode, tol in (('fused', 1e-4), ('tailtb', 1e-4)):
         torch.testing.assert_close(res[mode][0], res['modular'][0], atol=5e-5, rtol=1e-5)
         torch.testing.assert_close(res[mode][1], res['modular'][1], atol=1e-6, rtol=1e-6)

@@ -446,3 +446,35 @@ def test_operand_dropout_gemms_equal_dropout_then_gemm(M, K, N, row0):
         dw3 = gemm.mm_tn_adrop(y, gz, p, s_out, row0)
         assert torch.equal(dw3, gemm.mm_tn(yd, gz))
         assert gemm.mm_nn_indrop(y[:100], w2, p, s_out, 0, rowscale=rs[:100]) is None                # too few tiles: the caller materialises the copy
+
+
+@pytest.mark.parametrize('M,K,p,row0', [(40000, 128, 0.1, 0), (33001, 128, 0.3, 77), (513, 64, 0.2, 5), (70, 128, 0.0, 0), (100003, 64, 0.0, 0)])
+def test_forward_front_kernel_equals_the_two_gemms(M, K, p, row0):
+    """cb_trunk_front_f32 — dropout(x), input Linear, ReLU, dropout(X0) and layer 0's transform in one kernel, the 64-row
+    tile of dropout(X0) never leaving the chip — is BIT-identical to dropout + cb_gemm_nn_f32 (bias, ReLU) + dropout + cb_gemm_nn_f32 (row
+    scale, addend): X0, its mask words, the optional dropped copy and Z0; ragged last tile, fewer tiles than persistent blocks, row-sharded
+    Philox offsets, p = 0 (eval forwards)."""
+    from gnn_tail_generalization_amd import gemm, ops
+    gen = torch.Generator(device=DEV).manual_seed(M)
+    x = torch.rand(M, K, device=DEV, generator=gen)
+    w_in = torch.randn(256, K, device=DEV, generator=gen) * 0.1
+    b_in = torch.randn(256, device=DEV, generator=gen) * 0.1
+    w0 = torch.randn(256, 256, device=DEV, generator=gen) * 0.07
+    a = torch.rand(M, device=DEV, generator=gen) + 0.5
+    le = torch.randn(M, 256, device=DEV, generator=gen)
+    sx, s0 = 0x1234ABCD5, 0x77
+    xd = ops._dropout_raw(x, p, sx, row0 * K) if p > 0 else x
+    x0_ref = gemm.mm_nn(xd, w_in.t().contiguous(), bias=b_in, relu=True)
+    x0d_ref = ops._dropout_raw(x0_ref, p, s0, row0 * 256) if p > 0 else x0_ref
+    for addend, rs, want_drop in ((le, a, True), (None, None, False)):
+        fr = gemm.trunk_front(x, w_in, b_in, w0, rs, addend, p, sx, s0, row0, want_bits=True, want_drop=want_drop)
+        assert fr is not None
+        x0, bits, x0d, z0 = fr
+        assert torch.equal(x0, x0_ref)
+        assert torch.equal(z0, gemm.mm_nn(x0d_ref, w0, rowscale=rs, addend=addend))
+        assert (x0d is None) == (not want_drop) and (x0d is None or torch.equal(x0d, x0d_ref))
+        pos = x0_ref > 0
+        for kk in range(4):
+            ref_w = (pos[:, kk::4].to(torch.int64) << torch.arange(64, device=DEV, dtype=torch.int64)).sum(dim=1)
+            assert torch.equal(bits[:, 0, kk], ref_w), kk
+    assert gemm.trunk_front(x[:, :60].contiguous(), w_in[:, :60].contiguous(), b_in, w0, a, le, p, sx, s0) is None      # no kernel for this input width
