@@ -8,13 +8,15 @@
 // 64 rows of X0d in LDS and multiplies them by W_0 before anything else is read: 10 GB of writes and 10 GB of reads per step disappear.
 //
 // One persistent block of 4 wavefronts per slot (two slots per CU: 75 KB of LDS each), tiles of 64 rows, per tile
-//   P0  the tile of x (prefetched into registers during the previous tile) -> dropout -> fp32 LDS tile [64][K1 + 4]
+//   P0  the tile of x -> dropout -> fp32 LDS tile [64][K1 + 4]
 //   P1  tile x W_in^T on the matrix cores (tile_times_image: three-limb bf16 products, B fragments from the L2-resident image)
 //   P2  accumulators -> the SAME LDS region as a [64][260] tile (the x tile is dead)
 //   P3  row pass: a wavefront owns 16 rows, a lane 4 columns: + bias, ReLU -> X0 row store (1 KiB, streaming), four ballots = the row's mask
 //       words, Philox keep-mask of the dropout in front of layer 0 -> X0d back into the tile (-> out_drop row store if requested)
 //   P4  tile x W_0 on the matrix cores -> rowscale . acc + addend -> Z0 through wave-private strips
-// Two co-resident blocks per CU run these phases out of step, so one block's MFMA phases cover the other's loads and stores.
+// Two blocks share a CU.  Measured (profiles/r04_front_kernel.md): 14.4 ms at the headline shape against 15.3 ms for the two kernels; the
+// co-resident blocks fall into lock step (the phases' times add up: 8.9 ms of K loops at 52 % of the bf16 MFMA peak + 5.4 ms of loads, row
+// pass and stores), so what the kernel buys is the 20 GB of traffic, not yet an overlap of its own phases.
 // Bit-identical to the two-kernel form: same operand values (dropout products rounded to fp32 before the limb split), same limb products
 // in the same order, same epilogue expressions (tests/test_gpu_kernels.py::test_forward_front_*).
 #include "cb_common.h"
@@ -55,6 +57,8 @@ __global__ void __launch_bounds__(256, 2) k_front(FrontArgs fa) {
   static_assert(NV >= 1 && kTM * LDX <= kTM * kTLD, "x tile must fit the region of the X0 tile");
   __shared__ __attribute__((aligned(16))) float tile[kTM * kTLD];
   __shared__ __attribute__((aligned(16))) float cstrip[4][8 * kCLD];
+  __shared__ float rs_tile[2][kTM];   // (two buffers by tile parity: a wavefront may start the next tile's P0 while others still run this tile's epilogue)
+                                      // row scales of the tile's rows: a global load per (pass, row) in the Z0 epilogue would expose its latency 16 times
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
   const uint64_t sx = fa.seed_dev ? fa.seed_x + *fa.seed_dev : fa.seed_x, s0 = fa.seed_dev ? fa.seed_x0 + *fa.seed_dev : fa.seed_x0;
   float4 xr[NV];
@@ -72,10 +76,11 @@ __global__ void __launch_bounds__(256, 2) k_front(FrontArgs fa) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) bvec[i] = fa.bias_in[4 * lane + i];
   }
-  int tile_id = blockIdx.x;
-  load_x(tile_id);
-  for (; tile_id < fa.n_tiles; tile_id += gridDim.x) {
+  int par = 0;
+  for (int tile_id = blockIdx.x; tile_id < fa.n_tiles; tile_id += gridDim.x, par ^= 1) {
     const int64_t m0 = (int64_t)tile_id * kTM;
+    load_x(tile_id);      // (not prefetched across the GEMMs: those registers hold a third ring buffer of B fragments instead; the block that
+                          //  shares the CU multiplies while this one waits)
     // ---- P0: dropout of x (the product cb_dropout_f32 forms, rounded to fp32 as a value of its own) -> LDS
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -89,11 +94,11 @@ __global__ void __launch_bounds__(256, 2) k_front(FrontArgs fa) {
       }
       *reinterpret_cast<float4*>(tile + row * LDX + 4 * c4) = make_float4(v[0], v[1], v[2], v[3]);
     }
-    load_x(tile_id + gridDim.x);      // next tile's x: in flight until the next P0
+    if (t < kTM) rs_tile[par][t] = (fa.rowscale && m0 + t < fa.M) ? fa.rowscale[m0 + t] : 1.f;      // (read in P4's epilogue: four barriers later)
     __syncthreads();
     // ---- P1: X0 pre-activation = tile(x) @ W_in^T
     f32x16 acc[2][2];
-    tile_times_image<NS1, LDX>(tile, fa.image_in, w, lane, acc);
+    tile_times_image<NS1, LDX, 2>(tile, fa.image_in, w, lane, acc);
     __syncthreads();                  // every wavefront has read its last fragment of the x tile
     // ---- P2: accumulators -> [64][260] tile (C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))
     {
@@ -141,12 +146,12 @@ __global__ void __launch_bounds__(256, 2) k_front(FrontArgs fa) {
     }
     __syncthreads();
     // ---- P4: Z0 = rowscale . (tile(X0d) @ W_0) + addend
-    tile_times_image<kNS, kTLD>(tile, fa.image_0, w, lane, acc);
+    tile_times_image<kNS, kTLD, 2>(tile, fa.image_0, w, lane, acc);
     __syncthreads();                  // the tile may be overwritten by the next P0 (the strips below are wave-private)
     acc_rows_through_strip(acc, cstrip[w], w, lane, [&](int row, int n, const float4& v) {
       const int64_t m = m0 + row;
       if (m < fa.M) {
-        const float rs = fa.rowscale ? fa.rowscale[m] : 1.f;
+        const float rs = rs_tile[par][row];
         float ad[4] = {0.f, 0.f, 0.f, 0.f};
         if (fa.addend) {
           const float4 a4 = *reinterpret_cast<const float4*>(fa.addend + m * fa.ld_add + n);

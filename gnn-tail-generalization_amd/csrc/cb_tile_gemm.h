@@ -31,10 +31,13 @@ __device__ __forceinline__ void store_stream4(float* __restrict__ p, const float
   __builtin_nontemporal_store(q, reinterpret_cast<f4_t*>(p));
 }
 
-// acc[i][j] (+)= rows 32 i .. 32 i + 31 of the tile  x  columns 64 w + 32 j .. + 31 of B, over NSTEPS K steps of 16.
-// One K step of B fragments in flight per wavefront (two register buffers, K loop unrolled by two).
-template <int NSTEPS, int TLD>
+// acc[i][j] = rows 32 i .. 32 i + 31 of the tile  x  columns 64 w + 32 j .. + 31 of B, over NSTEPS K steps of 16.
+// PF = K steps of B fragments in flight per wavefront (ring of PF + 1 register buffers of 24 registers each).  PF = 1 (K loop unrolled by
+// two) where the wavefront's B latency is covered by others (cb_agg_gemm.hip: the gathering wavefronts bound the kernel); PF = 2 where the multiplying wavefronts ARE the kernel (cb_front.hip): an L2 hit comes back after ~1 us, a K step's 24 MFMAs
+// take 0.4 us.
+template <int NSTEPS, int TLD, int PF = 1>
 __device__ __forceinline__ void tile_times_image(const float* __restrict__ tile, const uint4* __restrict__ image, int w, int lane, f32x16 (&acc)[2][2]) {
+  static_assert(PF >= 1 && PF <= 3 && PF < NSTEPS, "prefetch distance");
   const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -46,16 +49,17 @@ __device__ __forceinline__ void tile_times_image(const float* __restrict__ tile,
   // B fragments: a RUNNING pointer, advanced every K step (fixed per-step addresses would all be loop invariants of the persistent
   // tile loop: the compiler hoists them — 96 address pairs — and spills)
   const uint4* bp = image + ((int64_t)(2 * w) * 3) * 64 + lane;
-  uint4 bq[2][2][3];
+  uint4 bq[PF + 1][2][3];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int d = 0; d < PF; ++d) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) bq[0][j][p] = bp[j * 192 + p * 64];
-  bp += kNT * 192;
-#pragma unroll(2)
-  for (int s = 0; s < NSTEPS; ++s) {
-    const int cur = s & 1, nx = cur ^ 1;
-    if (s + 1 < NSTEPS) {
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bq[d][j][p] = bp[j * 192 + p * 64];
+    bp += kNT * 192;
+  }
+  auto step = [&](int s, int cur, int nx) {
+    if (s + PF < NSTEPS) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -85,7 +89,17 @@ __device__ __forceinline__ void tile_times_image(const float* __restrict__ tile,
       CB_TG_MFMA2(a_hi, 0)
 #undef CB_TG_MFMA2
     }
+  };
+  // rolled loop, unrolled by the ring size (ring indices are compile-time constants); a FULL unroll lets the compiler hoist every B load to the
+  // top and spill (724 bytes of scratch per lane)
+  constexpr int R = PF + 1, MAIN = NSTEPS / R * R;
+#pragma unroll 1
+  for (int s0 = 0; s0 < MAIN; s0 += R) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) step(s0 + r, r, (r + PF) % R);
   }
+#pragma unroll
+  for (int r = 0; r < NSTEPS - MAIN; ++r) step(MAIN + r, r, (r + PF) % R);      // (MAIN % R == 0: step s sits in ring slot s % R)
 }
 
 constexpr int kCLD = 68;     // floats per row of a wavefront's private C strip (8 rows x 64 columns)

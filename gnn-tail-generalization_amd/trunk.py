@@ -273,10 +273,11 @@ class _TrunkFn(torch.autograd.Function):
         indrop = p > 0 and os.environ.get('CB_TRUNK_INDROP', '1') != '0'
         # Round 4: the whole forward front — dropout(x), input Linear, ReLU, dropout(X0), layer 0's transform — in ONE kernel
         # (cb_trunk_front_f32): a block keeps its 64 rows of dropout(X0) in LDS and multiplies them by W_0 at once.  The dropped copy is
-        # stored only on request (CB_TRUNK_X0_COPY=1: the layer-0 weight gradient then reads it instead of regenerating the mask).
+        # also stored when a backward follows (the layer-0 weight gradient reads it: 14.8 + 6.3 ms against 14.4 + 8.7 ms with the mask
+        # regenerated while X0 is staged, profiles/r04_front_kernel.md); CB_TRUNK_X0_COPY=0 never materialises it (-10 GB of peak memory).
         if (indrop or p == 0) and not agg_bf16 and L >= 1 and w_in.shape[0] == 256 and os.environ.get('CB_TRUNK_FRONT', '1') != '0':
             w0_, _b0, le0_ = layer_params[0:3]
-            want_copy = bwd and p > 0 and os.environ.get('CB_TRUNK_X0_COPY', '0') == '1'
+            want_copy = bwd and p > 0 and os.environ.get('CB_TRUNK_X0_COPY', '1') == '1'
             fr = gemm.trunk_front(x, w_in, b_in, w0_, a, le0_, p, seeds[0], seeds[1], row0, want_bits=bwd, want_drop=want_copy)
             if fr is not None:
                 x0, x0_bits, cur, z_front = fr
@@ -285,7 +286,7 @@ class _TrunkFn(torch.autograd.Function):
                     cur = x0
         if fused_in is None and indrop:
             wb = bwd and w_in.shape[0] == 256
-            r = None if os.environ.get('CB_TRUNK_X0_COPY', '0') == '1' else gemm.mm_nn_indrop(x, w_in.t().contiguous(), p, seeds[0], row0, bias=b_in,
+            r = None if os.environ.get('CB_TRUNK_X0_COPY', '1') == '1' else gemm.mm_nn_indrop(x, w_in.t().contiguous(), p, seeds[0], row0, bias=b_in,
                                                                                               relu=True, want_bits=wb)
             if r is not None:
                 fused_in = True
