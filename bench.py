@@ -339,6 +339,8 @@ def sharding_report(t, n1, a, dev):
            'max_rows_on_one_link_recv_send': [[int(r[5]), int(r[6])] for r in rows],
            'partition': t.part.kind, 'exchange': sg.exchange_kind, 'overlap': bool(sg.overlap), 'wire': sg.wire,
            'slices': plan.n_slices if plan is not None else 1, 'symmetric': bool(sg.symmetric),
+           'cover': bool(getattr(sg, 'cover', False)),      # push / pull vertex cover of the remote edges (dist.CoverPlan)
+           'halo_rows_pull_only_rank0': int(getattr(plan, 'n_pull_only', plan.n_halo if plan is not None else 0)) if plan is not None else 0,
            'backend': dist.get_backend() if world > 1 or dist.is_initialized() else 'none'}
     # loss_matches_n1: every rank must walk the same collectives, so the decision is broadcast
     box = [None if n1 is None else {'loss': n1['loss'], 'sd': n1['sd']}]

@@ -35,26 +35,33 @@ def _full_state(argv):
     return {k: v.detach().clone() for k, v in TeacherGNN(a).state_dict().items()}
 
 
-def _worker(rank, world, port, exchange, overlap, partition, argv, q, wire='f32', slices=''):
+def _worker(rank, world, port, exchange, overlap, partition, argv, q, wire='f32', slices='', cover='1', backend='gloo'):
     sys.path.insert(0, ROOT)
     import contextlib
     import io
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), COLDBREW_EXCHANGE=exchange, COLDBREW_OVERLAP=overlap,
-                      COLDBREW_PARTITION=partition, COLDBREW_HALO_WIRE=wire)
+                      COLDBREW_PARTITION=partition, COLDBREW_HALO_WIRE=wire, COLDBREW_HALO_COVER=cover)
     if slices:
         os.environ['COLDBREW_HALO_SLICES'] = slices
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev_id = rank if backend == 'nccl' else 0          # nccl (= RCCL): one GPU per rank; gloo: the ranks share the test box's single GPU
+    if backend == 'nccl':
+        argv = [a_ for a_ in argv if not a_.startswith('--manual_assign_GPU')] + [f'--manual_assign_GPU={dev_id}']
+        torch.cuda.set_device(dev_id)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{dev_id}'))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from gnn_tail_generalization_amd import ops
         from gnn_tail_generalization_amd.base_options import BaseOptions
         from gnn_tail_generalization_amd.dist import ShardedTrainer
-        torch.cuda.set_device(0)
+        torch.cuda.set_device(dev_id)
         with contextlib.redirect_stdout(io.StringIO()):
             args = BaseOptions().get_arguments(argv)
             t = ShardedTrainer(args, 0)
             t.setup_teacherGNN()
         t.load_full_state_dict({k: v.cuda() for k, v in _full_state(argv).items()})
+        assert t.sgraph.cover == (cover == '1' and overlap == '1' and exchange == 'halo')
         assert t.sgraph.exchange_kind == exchange and t.sgraph.overlap == (overlap == '1') and t.part.kind == partition
         assert t.sgraph.wire == wire
         if slices:
@@ -83,14 +90,30 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize('exchange,overlap,partition,argv,wire,world,slices', [
-    ('halo', '1', 'edges', ARGV, 'f32', 2, ''), ('halo', '0', 'rows', ARGV, 'f32', 2, ''), ('allgather', '0', 'rows', ARGV, 'f32', 2, ''),
-    ('halo', '1', 'edges', ARGV_BN, 'f32', 2, ''), ('halo', '1', 'edges', ARGV, 'bf16', 2, ''), ('halo', '1', 'edges', ARGV, 'f32', 3, ''),
-    ('halo', '1', 'edges', ARGV, 'f32', 2, '3'), ('halo', '1', 'edges', ARGV, 'f32', 3, '4'), ('halo', '1', 'edges', ARGV, 'bf16', 2, '2'),
-    ('halo', '1', 'edges', ARGV_BN, 'f32', 2, '2')],
-    ids=['halo-overlap-edges', 'halo-singlepass-rows', 'allgather', 'batchnorm-halo-overlap', 'halo-bf16-wire', 'three-ranks',
-         'sliced3-chunked-producers', 'three-ranks-sliced4', 'sliced2-bf16-wire', 'batchnorm-sliced2'])
-def test_two_ranks_on_one_gpu_match_single_process(exchange, overlap, partition, argv, wire, world, slices):
+@pytest.mark.parametrize('exchange,overlap,partition,argv,wire,world,slices,cover', [
+    ('halo', '1', 'edges', ARGV, 'f32', 2, '', '1'), ('halo', '0', 'rows', ARGV, 'f32', 2, '', '1'), ('allgather', '0', 'rows', ARGV, 'f32', 2, '', '1'),
+    ('halo', '1', 'edges', ARGV_BN, 'f32', 2, '', '1'), ('halo', '1', 'edges', ARGV, 'bf16', 2, '', '1'), ('halo', '1', 'edges', ARGV, 'f32', 3, '', '1'),
+    ('halo', '1', 'edges', ARGV, 'f32', 2, '3', '1'), ('halo', '1', 'edges', ARGV, 'f32', 3, '4', '1'), ('halo', '1', 'edges', ARGV, 'bf16', 2, '2', '1'),
+    ('halo', '1', 'edges', ARGV_BN, 'f32', 2, '2', '1'),
+    # the pull-only plan (COLDBREW_HALO_COVER=0: slices by owner row chunk; the aggregation + GEMM kernels still take the last halo pass)
+    ('halo', '1', 'edges', ARGV, 'f32', 2, '3', '0'), ('halo', '1', 'edges', ARGV, 'f32', 3, '', '0'), ('halo', '1', 'edges', ARGV, 'bf16', 2, '2', '0')],
+    ids=['cover-overlap-edges', 'halo-singlepass-rows', 'allgather', 'batchnorm-cover-overlap', 'cover-bf16-wire', 'three-ranks-cover',
+         'cover-sliced3', 'three-ranks-cover-sliced4', 'cover-sliced2-bf16-wire', 'batchnorm-cover-sliced2',
+         'pull-sliced3', 'pull-three-ranks', 'pull-sliced2-bf16-wire-chunked-producers'])
+def test_two_ranks_on_one_gpu_match_single_process(exchange, overlap, partition, argv, wire, world, slices, cover):
+    _ranks_match_single_process(exchange, overlap, partition, argv, wire, world, slices, cover, 'gloo')
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs: RCCL refuses two ranks on one device')
+@pytest.mark.parametrize('slices,cover', [('', '1'), ('3', '1'), ('3', '0')], ids=['cover', 'cover-sliced3', 'pull-sliced3'])
+def test_two_gpus_rccl_halo_exchange(slices, cover):
+    """the first box with two GPUs runs the halo exchange on RCCL itself — torch.distributed `nccl` with
+    all_to_all_single on uneven splits, asynchronous work handles and device_id= initialisation, one rank per GPU — and must reproduce the
+    single-GPU trainer exactly as the gloo-staged ranks on one GPU do.  Skipped on the one-GPU test boxes (the driver's 8-GPU node runs it)."""
+    _ranks_match_single_process('halo', '1', 'edges', ARGV, 'f32', 2, slices, cover, 'nccl')
+
+
+def _ranks_match_single_process(exchange, overlap, partition, argv, wire, world, slices, cover, backend):
     import contextlib
     import io
     sys.path.insert(0, ROOT)
@@ -115,7 +138,7 @@ def test_two_ranks_on_one_gpu_match_single_process(exchange, overlap, partition,
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, exchange, overlap, partition, argv, q, wire, slices)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, exchange, overlap, partition, argv, q, wire, slices, cover, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]

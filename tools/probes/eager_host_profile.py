@@ -7,7 +7,7 @@ from gnn_tail_generalization_amd.trainer_node_classification import trainer
 
 ds = sys.argv[1] if len(sys.argv) > 1 else 'S-cora'
 with contextlib.redirect_stdout(io.StringIO()):
-    args = BaseOptions().get_arguments([f'--dataset={ds}', '--manual_assign_GPU=0', '--want_headtail=0', '--use_special_split=0', '--do_deg_analyze=0'])
+    args = BaseOptions().get_arguments([f'--dataset={ds}', '--manual_assign_GPU=0', '--want_headtail=0', '--use_special_split=0', '--do_deg_analyze=0'] + sys.argv[2:])
     t = trainer(args, 0)
     t.setup_teacherGNN()
 for _ in range(20):
