@@ -16,7 +16,7 @@ from torch import nn
 from torch.nn import init
 
 from .. import gemm, ops, trunk
-from ..graph import CSRGraph, DGLError
+from ..graph import CSRGraph, DGLError, build_graph  # noqa: F401
 from .drop_tricks import DropoutTrick
 from .norm_tricks import AcontainsB, appendNormLayer, run_norm_if_any
 from .res_tricks import DenseConnection, InitialConnection, ResidualConnection
@@ -96,13 +96,13 @@ class TricksComb(nn.Module):
         """First call builds the device CSR and caches it forever; later edge_index arguments are
         ignored exactly as in the reference (GCN.py:92-95)."""
         if self.dglgraph is None:
-            self.dglgraph = CSRGraph(edge_index)
+            self.dglgraph = build_graph(edge_index)
         return self.dglgraph
 
     def forward(self, x, edge_index, want_les=False):
         graph = self._graph(edge_index)
         new_adjs = self.graph_dropout(edge_index)      # computed and discarded, as in the reference (GCN.py:101,111)
-        if self.use_fused_trunk and trunk.eligible(self, x, want_les):
+        if self.use_fused_trunk and not getattr(graph, 'segmented', False) and trunk.eligible(self, x, want_les):
             return trunk.forward(self, x, graph)
         if getattr(self.args, 'agg_dtype', 'f32') != 'f32' and not want_les:
             raise NotImplementedError("--agg_dtype=bf16 (bf16-stored aggregation rows) is built for the fused 'Initial' trunk "

@@ -28,6 +28,9 @@ SIGNATURES = {
     'cb_csr_workspace_bytes': (_SZ, [_I64, _I64]),
     'cb_csr_from_coo_i64': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'cb_deg_norm_f32': (ctypes.c_int, [_P, _I64, _P, _P]),
+    'cb_csr64_from_coo_i64': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    'cb_csr_rebase_i64': (ctypes.c_int, [_P, _I64, _I64, _P, _P]),
+    'cb_deg_norm_i64ptr_f32': (ctypes.c_int, [_P, _I64, _P, _P]),
     'cb_spmm_hub_count': (ctypes.c_int, [_P, _I64, _I32, _P, _P]),
     'cb_spmm_hub_fill': (ctypes.c_int, [_P, _I64, _I32, _I32, _P, _P, _P, _P]),
     'cb_spmm_workspace_bytes': (_SZ, [_I64, _I64]),

@@ -49,7 +49,8 @@ __global__ void k_unpack_cols(const uint64_t* __restrict__ keys, int64_t E, uint
   if (i < E) col[i] = (int32_t)(keys[i] & mask);
 }
 
-__global__ void k_rowptr_search(const uint64_t* __restrict__ keys, int64_t E, int64_t N, int bits, int32_t* __restrict__ rowptr) {
+template <typename RP>      // int32_t (E < 2^31) or int64_t row pointers
+__global__ void k_rowptr_search(const uint64_t* __restrict__ keys, int64_t E, int64_t N, int bits, RP* __restrict__ rowptr) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v > N) return;
   uint64_t target = (uint64_t)v << bits;
@@ -58,14 +59,16 @@ __global__ void k_rowptr_search(const uint64_t* __restrict__ keys, int64_t E, in
     int64_t mid = (lo + hi) >> 1;
     if (keys[mid] < target) lo = mid + 1; else hi = mid;
   }
-  rowptr[v] = (int32_t)lo;
+  rowptr[v] = (RP)lo;
 }
 
-__global__ void k_degree_stats(const int32_t* __restrict__ rowptr, int64_t N, int32_t* flags) {
+template <typename RP>
+__global__ void k_degree_stats(const RP* __restrict__ rowptr, int64_t N, int32_t* flags) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int deg = 0, zero = 0;
   if (v < N) {
-    deg = rowptr[v + 1] - rowptr[v];
+    const int64_t dd = (int64_t)(rowptr[v + 1] - rowptr[v]);
+    deg = dd > INT32_MAX ? INT32_MAX : (int)dd;      // (flags[3] saturates: a single row of >= 2^31 edges is refused by the caller)
     zero = deg == 0;
   }
   unsigned long long m = __ballot(zero);
@@ -77,17 +80,19 @@ __global__ void k_degree_stats(const int32_t* __restrict__ rowptr, int64_t N, in
   }
 }
 
-__global__ void k_compare_i32(const int32_t* __restrict__ a, const int32_t* __restrict__ b, int64_t n, int32_t* flags) {
+template <typename T>
+__global__ void k_compare(const T* __restrict__ a, const T* __restrict__ b, int64_t n, int32_t* flags) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int diff = (i < n) ? (a[i] != b[i]) : 0;
   if (__ballot(diff) && lane_id() == 0) atomicAnd(&flags[2], 0);
 }
 
-__global__ void k_deg_norm(const int32_t* __restrict__ rowptr, int64_t N, float* __restrict__ norm) {
+template <typename RP>
+__global__ void k_deg_norm(const RP* __restrict__ rowptr, int64_t N, float* __restrict__ norm) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v < N) {
-    int deg = rowptr[v + 1] - rowptr[v];
-    float x = (float)max(deg, 1);
+    const int64_t deg = (int64_t)(rowptr[v + 1] - rowptr[v]);
+    float x = (float)(deg > 1 ? deg : 1);
     norm[v] = 1.0f / sqrtf(x);  // degs.float().clamp(min=1) ** -0.5
   }
 }
@@ -166,7 +171,8 @@ static size_t sort_temp_bytes(int64_t E, int bits) {
   return bytes;
 }
 
-static int build_one(const int64_t* major, const int64_t* minor, int64_t E, int64_t N, int bits, int32_t* rowptr,
+template <typename RP>
+static int build_one(const int64_t* major, const int64_t* minor, int64_t E, int64_t N, int bits, RP* rowptr,
                      int32_t* col, int32_t* flags, uint64_t* keys_a, uint64_t* keys_b, void* temp, size_t temp_bytes,
                      hipStream_t st) {
   const int B = 256;
@@ -179,7 +185,7 @@ static int build_one(const int64_t* major, const int64_t* minor, int64_t E, int6
     hipLaunchKernelGGL(k_unpack_cols, dim3(blocks_for(E, B)), dim3(B), 0, st, keys_b, E, mask, col);
     CB_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_rowptr_search, dim3(blocks_for(N + 1, B)), dim3(B), 0, st, keys_b, E, N, bits, rowptr);
+  hipLaunchKernelGGL(k_rowptr_search<RP>, dim3(blocks_for(N + 1, B)), dim3(B), 0, st, keys_b, E, N, bits, rowptr);
   CB_LAUNCH_CHECK();
   return CB_OK;
 }
@@ -195,16 +201,16 @@ extern "C" size_t cb_csr_workspace_bytes(int64_t E, int64_t N) {
   return 2 * keys + align_up(sort_temp_bytes(E > 0 ? E : 1, bits), 256) + 256;
 }
 
-extern "C" int cb_csr_from_coo_i64(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int32_t* rowptr,
-                                   int32_t* col, int32_t* rowptr_t, int32_t* col_t, int32_t* flags, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
-  CB_CHECK_ARG(E >= 0 && N >= 0, CB_E_INVALID, "cb_csr_from_coo_i64: negative size (E=%lld, N=%lld)", (long long)E, (long long)N);
-  CB_CHECK_ARG(E < INT32_MAX && N < INT32_MAX, CB_E_RANGE, "cb_csr_from_coo_i64: E=%lld / N=%lld exceed the int32 index contract",
-               (long long)E, (long long)N);
-  CB_CHECK_ARG(rowptr && rowptr_t && flags && (E == 0 || (src && dst && col && col_t)), CB_E_INVALID,
-               "cb_csr_from_coo_i64: null pointer");
-  CB_CHECK_ARG(workspace && workspace_bytes >= cb_csr_workspace_bytes(E, N), CB_E_WORKSPACE,
-               "cb_csr_from_coo_i64: workspace %zu < required %zu", workspace_bytes, cb_csr_workspace_bytes(E, N));
+template <typename RP>
+static int csr_from_coo(const char* who, const int64_t* src, const int64_t* dst, int64_t E, int64_t N, RP* rowptr, int32_t* col, RP* rowptr_t,
+                        int32_t* col_t, int32_t* flags, void* workspace, size_t workspace_bytes, void* stream) {
+  CB_CHECK_ARG(E >= 0 && N >= 0, CB_E_INVALID, "%s: negative size (E=%lld, N=%lld)", who, (long long)E, (long long)N);
+  CB_CHECK_ARG((sizeof(RP) == 8 ? E < ((int64_t)1 << 36) : E < INT32_MAX) && N < INT32_MAX, CB_E_RANGE,
+               "%s: E=%lld / N=%lld exceed the index contract (int32 column ids; %s row pointers)", who, (long long)E, (long long)N,
+               sizeof(RP) == 8 ? "int64" : "int32: use cb_csr64_from_coo_i64 for E >= 2^31");
+  CB_CHECK_ARG(rowptr && rowptr_t && flags && (E == 0 || (src && dst && col && col_t)), CB_E_INVALID, "%s: null pointer", who);
+  CB_CHECK_ARG(workspace && workspace_bytes >= cb_csr_workspace_bytes(E, N), CB_E_WORKSPACE, "%s: workspace %zu < required %zu", who,
+               workspace_bytes, cb_csr_workspace_bytes(E, N));
   hipStream_t st = (hipStream_t)stream;
   int bits = key_bits(N < 2 ? 2 : N);
   size_t keys = align_up((size_t)(E > 0 ? E : 1) * sizeof(uint64_t), 256);
@@ -217,29 +223,66 @@ extern "C" int cb_csr_from_coo_i64(const int64_t* src, const int64_t* dst, int64
   hipLaunchKernelGGL(k_init_flags, dim3(1), dim3(64), 0, st, flags);
   CB_LAUNCH_CHECK();
   // by-dst CSR: rows = dst, cols = src (forward aggregation, GCN.py:238)
-  int rc = build_one(dst, src, E, N, bits, rowptr, col, flags, keys_a, keys_b, temp, temp_bytes, st);
+  int rc = build_one<RP>(dst, src, E, N, bits, rowptr, col, flags, keys_a, keys_b, temp, temp_bytes, st);
   if (rc) return rc;
   // by-src CSR: rows = src, cols = dst (reverse graph, backward of the aggregation)
-  rc = build_one(src, dst, E, N, bits, rowptr_t, col_t, flags, keys_a, keys_b, temp, temp_bytes, st);
+  rc = build_one<RP>(src, dst, E, N, bits, rowptr_t, col_t, flags, keys_a, keys_b, temp, temp_bytes, st);
   if (rc) return rc;
   const int B = 256;
   if (N > 0) {
-    hipLaunchKernelGGL(k_degree_stats, dim3(blocks_for(N, B)), dim3(B), 0, st, rowptr, N, flags);
+    hipLaunchKernelGGL(k_degree_stats<RP>, dim3(blocks_for(N, B)), dim3(B), 0, st, rowptr, N, flags);
     CB_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_compare_i32, dim3(blocks_for(N + 1, B)), dim3(B), 0, st, rowptr, rowptr_t, N + 1, flags);
+  hipLaunchKernelGGL(k_compare<RP>, dim3(blocks_for(N + 1, B)), dim3(B), 0, st, rowptr, rowptr_t, N + 1, flags);
   CB_LAUNCH_CHECK();
   if (E > 0) {
-    hipLaunchKernelGGL(k_compare_i32, dim3(blocks_for(E, B)), dim3(B), 0, st, col, col_t, E, flags);
+    hipLaunchKernelGGL(k_compare<int32_t>, dim3(blocks_for(E, B)), dim3(B), 0, st, col, col_t, E, flags);
     CB_LAUNCH_CHECK();
   }
+  return CB_OK;
+}
+
+extern "C" int cb_csr_from_coo_i64(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int32_t* rowptr,
+                                   int32_t* col, int32_t* rowptr_t, int32_t* col_t, int32_t* flags, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  return csr_from_coo<int32_t>("cb_csr_from_coo_i64", src, dst, E, N, rowptr, col, rowptr_t, col_t, flags, workspace, workspace_bytes, stream);
+}
+
+// The same with int64 row pointers: E >= 2^31 edge_index columns on one device (SURVEY.md 8b "int64 rowptr if E >= 2^31"; the reference's
+// graph is int64 throughout, GNN_model/GCN.py:93-94).  Column ids stay int32 (N < 2^31).  The aggregation kernels index edges with 32 bits
+// INSIDE a launch: the host cuts the rows into blocks of < 2^31 edges and hands each block over as an ordinary CSR whose row pointers are
+// rebased by cb_csr_rebase_i64 (graph.SegmentedCSRGraph) — the form a rank's row block has in the node-sharded path.
+extern "C" int cb_csr64_from_coo_i64(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int64_t* rowptr, int32_t* col,
+                                     int64_t* rowptr_t, int32_t* col_t, int32_t* flags, void* workspace, size_t workspace_bytes, void* stream) {
+  return csr_from_coo<int64_t>("cb_csr64_from_coo_i64", src, dst, E, N, rowptr, col, rowptr_t, col_t, flags, workspace, workspace_bytes, stream);
+}
+
+__global__ void k_rebase(const int64_t* __restrict__ rowptr, int64_t n, int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (int32_t)(rowptr[i] - rowptr[0]);
+}
+
+// out[i] = rowptr[row0 + i] - rowptr[row0] for i <= n_rows: the int32 row pointers of the row block [row0, row0 + n_rows), whose edges
+// (fewer than 2^31: checked by the caller, who knows rowptr's values) start at col + rowptr[row0].
+extern "C" int cb_csr_rebase_i64(const int64_t* rowptr, int64_t row0, int64_t n_rows, int32_t* out, void* stream) {
+  CB_CHECK_ARG(rowptr && out && row0 >= 0 && n_rows >= 0, CB_E_INVALID, "cb_csr_rebase_i64: bad argument");
+  hipLaunchKernelGGL(k_rebase, dim3(blocks_for(n_rows + 1, 256)), dim3(256), 0, (hipStream_t)stream, rowptr + row0, n_rows + 1, out);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
+extern "C" int cb_deg_norm_i64ptr_f32(const int64_t* rowptr, int64_t N, float* norm, void* stream) {
+  CB_CHECK_ARG(N >= 0 && (N == 0 || (rowptr && norm)), CB_E_INVALID, "cb_deg_norm_i64ptr_f32: bad argument");
+  if (N == 0) return CB_OK;
+  hipLaunchKernelGGL(k_deg_norm<int64_t>, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, N, norm);
+  CB_LAUNCH_CHECK();
   return CB_OK;
 }
 
 extern "C" int cb_deg_norm_f32(const int32_t* rowptr, int64_t N, float* norm, void* stream) {
   CB_CHECK_ARG(N >= 0 && (N == 0 || (rowptr && norm)), CB_E_INVALID, "cb_deg_norm_f32: bad argument");
   if (N == 0) return CB_OK;
-  hipLaunchKernelGGL(k_deg_norm, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, N, norm);
+  hipLaunchKernelGGL(k_deg_norm<int32_t>, dim3(blocks_for(N, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, N, norm);
   CB_LAUNCH_CHECK();
   return CB_OK;
 }

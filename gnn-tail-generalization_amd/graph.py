@@ -40,11 +40,9 @@ class CSRGraph:
         dev = ei.device
         E = ei.shape[1]
         if E >= INT32_EDGE_LIMIT:
-            # indices are int32.  The guarantee for larger graphs is PER RANK, not per graph: the node-sharded path
-            # (torchrun, dist.ShardedGraph) builds one CSR per row block, and an edge-balanced partition keeps a block at about E / P
-            # edges (dist.Partition.balanced) — a 2^31-edge graph needs P >= 2 anyway for its 8.6 GB of column ids + 2 TB of gathers
-            raise ValueError(f'edge_index has {E} columns: one device CSR holds fewer than 2^31 (int32 edge offsets); shard the graph '
-                             f'(torchrun --nproc-per-node P main.py ...: every rank then indexes only its own row block, < 2^31 edges each)')
+            # int32 indices, int64 row pointers from 2^31 edges on — that form is SegmentedCSRGraph (build_graph picks it)
+            raise ValueError(f'edge_index has {E} columns: CSRGraph indexes edges with int32 (< 2^31); use graph.build_graph / '
+                             f'SegmentedCSRGraph (int64 row pointers), or shard the graph over ranks (torchrun --nproc-per-node P main.py ...)')
         if num_nodes is None:                               # DGL infers max id + 1 (GCN.py:94)
             num_nodes = int(ei.max().item()) + 1 if E else 0
         N = int(num_nodes)
@@ -452,6 +450,116 @@ class CSRGraph:
         if bias:
             b += d * elem
         return b
+
+
+class SegmentedCSRGraph:
+    """A graph with E >= 2^31 edge_index columns on ONE device ("indices int32 (int64 rowptr if E >= 2^31)"; the
+    reference's DGL graph is int64 throughout, GCN.py:93-94).  The ingest writes int64 row pointers (cb_csr64_from_coo_i64), column ids
+    stay int32.  The aggregation kernels index edges with 32 bits inside a launch, so the rows are cut into blocks of at most `max_edges`
+    (< 2^31) edges; a block is an ordinary rectangular CSRGraph over a VIEW of the column ids with rebased row pointers
+    (cb_csr_rebase_i64) — exactly the shape of a rank's row block in the node-sharded path — and an aggregation is one launch per block
+    into the block's rows of the output.  Serves the operator path (ops.aggregate: forward and reverse orientation); the fused trunk keeps
+    to graphs below 2^31 edges.  max_edges is a parameter so that the segment logic is testable on small graphs."""
+    segmented = True
+
+    def __init__(self, edge_index, num_nodes=None, hub_threshold=HUB_THRESHOLD, max_edges=INT32_EDGE_LIMIT - 1):
+        lib = _lib.load()
+        _lib.require_device(edge_index)
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise ValueError(f'edge_index must be [2, E], got {tuple(edge_index.shape)}')
+        ei = edge_index.to(torch.int64).contiguous()
+        dev = ei.device
+        E = int(ei.shape[1])
+        N = int(num_nodes) if num_nodes is not None else (int(ei.max().item()) + 1 if E else 0)
+        if N >= INT32_EDGE_LIMIT:
+            raise ValueError(f'{N} nodes: column ids are int32 (N < 2^31)')
+        self.N, self.E, self.device, self.n_cols, self.row_offset = N, E, dev, N, 0
+        self.hub_threshold, self.max_edges = int(hub_threshold), int(max_edges)
+        self.rowptr = torch.empty(N + 1, dtype=torch.int64, device=dev)
+        self.col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        self.rowptr_t = torch.empty(N + 1, dtype=torch.int64, device=dev)
+        self.col_t = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        flags = torch.empty(4, dtype=torch.int32, device=dev)
+        wsb = lib.cb_csr_workspace_bytes(E, N)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.cb_csr64_from_coo_i64(_lib.ptr(ei[0]), _lib.ptr(ei[1]), E, N, _lib.ptr(self.rowptr), _lib.ptr(self.col),
+                                                 _lib.ptr(self.rowptr_t), _lib.ptr(self.col_t), _lib.ptr(flags), _lib.ptr(ws), wsb,
+                                                 _lib.stream_ptr()), 'cb_csr64_from_coo_i64')
+            self.norm_out = torch.empty(N, dtype=torch.float32, device=dev)
+            self.norm_in = torch.empty(N, dtype=torch.float32, device=dev)
+            _lib.check(lib.cb_deg_norm_i64ptr_f32(_lib.ptr(self.rowptr_t), N, _lib.ptr(self.norm_out), _lib.stream_ptr()), 'cb_deg_norm_i64ptr_f32')
+            _lib.check(lib.cb_deg_norm_i64ptr_f32(_lib.ptr(self.rowptr), N, _lib.ptr(self.norm_in), _lib.stream_ptr()), 'cb_deg_norm_i64ptr_f32')
+            f = flags.tolist()
+        del ws, ei
+        self.n_zero_in_degree, n_bad, sym, self.max_in_degree = f[0], f[1], f[2], f[3]
+        if n_bad:
+            raise ValueError(f'edge_index has {n_bad} edges with an endpoint outside [0, {N})')
+        self.symmetric = bool(sym)
+        if self.symmetric:
+            self.rowptr_t, self.col_t = self.rowptr, self.col
+        self.segments = self._cut(self.rowptr, self.col)
+        self.segments_t = self.segments if self.symmetric else self._cut(self.rowptr_t, self.col_t)
+        self.profile = None
+
+    def _cut(self, rowptr, col):
+        """[(first row, end row, CSRGraph of the block)]: greedy blocks of at most max_edges edges."""
+        lib = _lib.load()
+        out, r0 = [], 0
+        while r0 < self.N:
+            e0 = int(rowptr[r0])
+            r1 = int(torch.searchsorted(rowptr, torch.tensor([e0 + self.max_edges], dtype=torch.int64, device=rowptr.device), right=True)) - 1
+            r1 = min(r1, self.N)
+            if r1 <= r0:
+                raise ValueError(f'row {r0} alone holds more than {self.max_edges} edges: a destination row is reduced inside one launch')
+            e1 = int(rowptr[r1])
+            rp = torch.empty(r1 - r0 + 1, dtype=torch.int32, device=rowptr.device)
+            with torch.cuda.device(rowptr.device):
+                _lib.check(lib.cb_csr_rebase_i64(_lib.ptr(rowptr), r0, r1 - r0, _lib.ptr(rp), _lib.stream_ptr()), 'cb_csr_rebase_i64')
+            out.append((r0, r1, CSRGraph.from_csr(rp, col[e0:e1], self.N, self.hub_threshold)))
+            r0 = r1
+        return out
+
+    # -- the surface GCNConv / ops.aggregate touch ----------------------------------------------------------
+    def number_of_nodes(self):
+        return self.N
+
+    def number_of_edges(self):
+        return self.E
+
+    def in_degrees(self):
+        return self.rowptr[1:] - self.rowptr[:-1]
+
+    def out_degrees(self):
+        return self.rowptr_t[1:] - self.rowptr_t[:-1]
+
+    def check_zero_in_degree(self):
+        if self.n_zero_in_degree:
+            raise ZeroInDegreeError('There are 0-in-degree nodes in the graph, output for those nodes will be invalid. '
+                                    'Adding self-loop on the input graph will resolve the issue.')
+
+    def algorithmic_bytes(self, d, elem=4, row_scale=True, bias=True, src_elem=None):
+        return self.E * (d * (src_elem or elem) + 4) + self.N * (d * elem + 4) + (4 * self.N if row_scale else 0) + (d * elem if bias else 0)
+
+    def spmm(self, h, transpose=False, row_scale=None, bias=None, relu=False, out=None, acc_init=None):
+        """As CSRGraph.spmm: one launch per row block into that block's rows of `out`."""
+        if h.dim() != 2 or h.shape[0] != self.N:
+            raise ValueError(f'feature matrix must be [{self.N}, d], got {tuple(h.shape)}')
+        if out is None:
+            out = torch.empty((self.N, h.shape[1]), dtype=torch.float32, device=h.device)
+        for r0, r1, seg in (self.segments_t if transpose else self.segments):
+            seg.profile = self.profile
+            seg.spmm(h, row_scale=row_scale[r0:r1] if row_scale is not None else None, bias=bias, relu=relu, out=out[r0:r1],
+                     acc_init=acc_init[r0:r1] if acc_init is not None else None)
+        return out
+
+
+def build_graph(edge_index, num_nodes=None):
+    """The device graph TricksComb caches in place of the reference's dgl.graph (GCN.py:92-95): int32 CSR below 2^31 edge_index columns,
+    int64 row pointers + row blocks from there on."""
+    if int(edge_index.shape[1]) >= INT32_EDGE_LIMIT:
+        return SegmentedCSRGraph(edge_index, num_nodes)
+    return CSRGraph(edge_index, num_nodes)
 
 
 def weight_image(w, transpose=False):

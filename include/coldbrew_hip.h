@@ -72,6 +72,17 @@ int cb_csr_from_coo_i64(const int64_t* src, const int64_t* dst, int64_t E, int64
  * `th.pow(degs, -0.5)` (GCN.py:206-208 with the by-src rowptr, GCN.py:243-245 with the by-dst rowptr). */
 int cb_deg_norm_f32(const int32_t* rowptr, int64_t N, float* norm, void* stream);
 
+/* E >= 2^31 on one device ("indices int32 (int64 rowptr if E >= 2^31)"; the reference's graph is int64 throughout,
+ * GCN.py:93-94): the same ingest with int64 row pointers (column ids stay int32: N < 2^31; E < 2^36), the degree norms from them, and
+ * cb_csr_rebase_i64: out[i] = rowptr[row0 + i] - rowptr[row0], i <= n_rows — the int32 row pointers of a row block with fewer than 2^31
+ * edges, whose column ids start at col + rowptr[row0].  The aggregation kernels index edges with 32 bits inside a launch; the host cuts the
+ * rows into such blocks (graph.SegmentedCSRGraph) and every entry point above runs per block, as it does on a rank's row block of the
+ * node-sharded path. */
+int cb_csr64_from_coo_i64(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int64_t* rowptr, int32_t* col, int64_t* rowptr_t,
+                          int32_t* col_t, int32_t* flags /*[4]*/, void* workspace, size_t workspace_bytes, void* stream);
+int cb_csr_rebase_i64(const int64_t* rowptr, int64_t row0, int64_t n_rows, int32_t* out, void* stream);
+int cb_deg_norm_i64ptr_f32(const int64_t* rowptr, int64_t N, float* norm, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Hub plan for the aggregation: rows longer than `hub_threshold` edges are split into
  * chunks of `hub_threshold` edges that separate wavefronts reduce (power-law graphs).

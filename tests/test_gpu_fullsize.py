@@ -384,3 +384,38 @@ def test_config4_products_shape_full_size_properties():
     rhs = (h.double() * G.out_degrees().double().unsqueeze(1)).sum(dim=0)
     torch.testing.assert_close(lhs, rhs, rtol=1e-6, atol=0)
     assert torch.equal(agg, G.spmm(h))
+
+
+def test_more_than_2_to_31_edges_on_one_device():
+    """SURVEY.md 8(b) / VERDICT r03 item 7: E >= 2^31 edge_index columns on ONE device.  The S-pl10M edge list repeated 22 times (a multigraph
+    of 2.2 * 10^9 edges: duplicates are counted, GCN.py:93-94) goes through build_graph -> SegmentedCSRGraph: int64 row pointers equal 22 x
+    the base graph's, every row block stays below 2^31 edges, column ids are each base row's ids repeated in ascending order (checked on row
+    samples + a checksum), degree norms follow 22 x the base degrees, and the aggregation at d = 16 equals 22 x the base aggregation."""
+    from gnn_tail_generalization_amd.data import synthetic_data
+    from gnn_tail_generalization_amd.graph import CSRGraph, SegmentedCSRGraph, build_graph, INT32_EDGE_LIMIT
+    data = synthetic_data('S-pl10M', seed=0, device=DEV)
+    n, ei = int(data.x.shape[0]), data.edge_index
+    del data
+    base = CSRGraph(ei, n)
+    R = 22
+    big_ei = ei.repeat(1, R)
+    assert big_ei.shape[1] == R * 100_000_000 > INT32_EDGE_LIMIT
+    del ei
+    torch.cuda.empty_cache()
+    S = build_graph(big_ei, n)
+    del big_ei
+    torch.cuda.empty_cache()
+    assert isinstance(S, SegmentedCSRGraph) and S.E == R * base.E and S.rowptr.dtype == torch.int64 and S.symmetric
+    assert torch.equal(S.rowptr, base.rowptr.long() * R)
+    assert len(S.segments) >= 2 and all(seg.E < 2 ** 31 for _, _, seg in S.segments) and sum(seg.E for _, _, seg in S.segments) == S.E
+    assert int(S.col[:S.E].long().sum()) == R * int(base.col[:base.E].long().sum())
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    for v in torch.randint(0, n, (64,), device=DEV, generator=gen).tolist() + base._plan.hub_rows[:4].tolist():
+        want = base.col[int(base.rowptr[v]):int(base.rowptr[v + 1])].repeat_interleave(R)
+        assert torch.equal(S.col[int(S.rowptr[v]):int(S.rowptr[v + 1])], want), v
+    deg = (base.rowptr[1:] - base.rowptr[:-1]).float() * R
+    torch.testing.assert_close(S.norm_in, deg.clamp(min=1).pow(-0.5), atol=0, rtol=1e-6)
+    h = torch.rand(n, 16, device=DEV, generator=gen)
+    got = S.spmm(h, row_scale=S.norm_in)
+    ref = base.spmm(h) * R * S.norm_in.unsqueeze(1)
+    torch.testing.assert_close(got, ref, atol=1e-4, rtol=2e-5)        # R-fold repeated terms summed in another order

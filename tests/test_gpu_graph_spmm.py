@@ -276,3 +276,59 @@ def test_in_place_accumulation_skips_rows_without_edges(d, dtype):
     buf2 = acc.clone()
     got2 = G.spmm(h, row_scale=rs, acc_init=buf2, out=buf2)
     torch.testing.assert_close(got2, want * rs.unsqueeze(1), atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('name,max_edges', [('case_graph_asym_multi', 7), ('case_graph_powerlaw_d7_d64', 100), ('case_r_initialbn_se111_L3_powerlaw', 64)])
+def test_segmented_graph_with_int64_row_pointers_small(name, max_edges):
+    """SURVEY.md 8(b) "int64 rowptr if E >= 2^31": SegmentedCSRGraph (int64 row pointers from cb_csr64_from_coo_i64, row blocks of at most
+    max_edges edges with rebased int32 pointers) on the golden graphs with a tiny block size: int64 row pointers / columns / degree norms
+    equal the int32 graph's bit for bit, and the aggregation (both orientations, epilogue, narrow and wide rows, running sums) equals it —
+    a row is reduced inside one launch either way."""
+    from gnn_tail_generalization_amd.graph import CSRGraph, SegmentedCSRGraph
+    g = load_golden(name)
+    n = int(g['cfg']['N_nodes']) if 'cfg' in g else int(g['edge_index'].max()) + 1
+    ei = g['edge_index'].to(DEV)
+    G = CSRGraph(ei, n)
+    big = max(max_edges, int(G.in_degrees().max()), int(G.out_degrees().max()))
+    S = SegmentedCSRGraph(ei, n, max_edges=big)
+    assert len(S.segments) > 1 and S.rowptr.dtype == torch.int64
+    assert torch.equal(S.rowptr, G.rowptr.long()) and torch.equal(S.col[:S.E], G.col[:G.E]) and S.symmetric == G.symmetric
+    assert torch.equal(S.rowptr_t, G.rowptr_t.long()) and torch.equal(S.col_t[:S.E], G.col_t[:G.E])
+    assert torch.equal(S.norm_in, G.norm_in) and torch.equal(S.norm_out, G.norm_out) and S.n_zero_in_degree == G.n_zero_in_degree
+    assert sum(seg.E for _, _, seg in S.segments) == S.E and all(seg.E <= big for _, _, seg in S.segments)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    for d in (7, 40, 256):
+        h = torch.randn(n, d, device=DEV, generator=gen)
+        bias = torch.randn(d, device=DEV, generator=gen)
+        # d > 16: one wavefront adds a row's edges in CSR order whatever block the row sits in -> bit-identical; d <= 16 (grouped-stream
+        # kernel): the segmented scan's partial sums depend on where a row falls in its wavefront's edge window -> equal to rounding
+        same = torch.equal if d > 16 else (lambda a_, b_: bool(torch.allclose(a_, b_, atol=1e-5, rtol=1e-5)))
+        for tr in (False, True):
+            assert same(S.spmm(h, transpose=tr), G.spmm(h, transpose=tr))
+        assert same(S.spmm(h, row_scale=S.norm_in, bias=bias, relu=True), G.spmm(h, row_scale=G.norm_in, bias=bias, relu=True))
+        acc = torch.randn(n, d, device=DEV, generator=gen)
+        assert same(S.spmm(h, acc_init=acc), G.spmm(h, acc_init=acc))
+    with pytest.raises(ValueError, match='alone holds more'):
+        SegmentedCSRGraph(ei, n, max_edges=max(int(G.in_degrees().max()) - 1, 0))
+
+
+def test_teacher_runs_on_a_segmented_graph():
+    """GCNConv / TricksComb on a SegmentedCSRGraph (what build_graph returns from 2^31 edges on; here forced on a golden case): the
+    operator path gives the reference's logits, loss and gradients."""
+    from helpers import product_model
+    from gnn_tail_generalization_amd.graph import SegmentedCSRGraph
+    g = load_golden('case_r_initialbn_se111_L3_powerlaw')
+    args, model = product_model(g['cfg'], g['sd'], DEV)
+    x, ei, y, mask = g['x'].to(DEV), g['edge_index'].to(DEV), g['y'].to(DEV), g['train_mask'].to(DEV)
+    tc = model.model.model
+    tc.dglgraph = SegmentedCSRGraph(ei, x.shape[0], max_edges=200)
+    assert len(tc.dglgraph.segments) > 2
+    model.train()
+    res = model.get_3_embs(x, ei, mask)
+    loss = torch.nn.functional.nll_loss(torch.nn.functional.log_softmax(res.emb4classi, 1), y[mask]) + args.se_reg * model.se_reg_all
+    loss.backward()
+    torch.testing.assert_close(res.emb4classi_full.detach().cpu(), g['train_out'], atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(loss.detach().cpu(), g['train_loss'], atol=1e-4, rtol=1e-5)
+    for k, v in g['grads'].items():
+        got = dict(model.named_parameters())[k].grad
+        torch.testing.assert_close(got.cpu(), v, atol=2e-5, rtol=2e-4, msg=lambda m, k=k: f'{k}: {m}')

@@ -223,9 +223,9 @@ def test_public_header_is_plain_c(tmp_path):
 
 
 def test_int32_edge_contract_is_a_per_rank_guarantee():
-    """SURVEY.md 8(b) 'int64 rowptr if E >= 2^31': indices stay int32 on the device; what is guaranteed instead is per RANK — a graph
-    with 2^31 or more edge_index columns is refused by the single-device graph with the remedy spelled out, and the edge-balanced
-    partition keeps every rank's block at E / P (+ one row) edges, i.e. below the limit from P = 2 on for anything up to 2^32."""
+    """SURVEY.md 8(b) 'int64 rowptr if E >= 2^31': the int32-indexed CSRGraph refuses 2^31 or more edge_index columns and names the two
+    ways on (graph.build_graph -> SegmentedCSRGraph with int64 row pointers on one device: tests/test_gpu_graph_spmm.py; or sharding), and
+    the edge-balanced partition keeps every rank's block at E / P (+ one row) edges, i.e. below the limit from P = 2 on up to 2^32."""
     import torch
     from gnn_tail_generalization_amd import graph as cbgraph
     from gnn_tail_generalization_amd.dist import Partition
@@ -250,7 +250,7 @@ def test_int32_edge_contract_is_a_per_rank_guarantee():
     real = (_lib.load, _lib.require_device)
     _lib.load, _lib.require_device = (lambda: None), (lambda *a: None)
     try:
-        with pytest.raises(ValueError, match='shard the graph'):
+        with pytest.raises(ValueError, match='SegmentedCSRGraph.*shard the graph'):
             cbgraph.CSRGraph(FakeEdges(), 10)
     finally:
         _lib.load, _lib.require_device = real
