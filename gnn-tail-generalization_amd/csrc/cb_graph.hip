@@ -4,17 +4,15 @@
 //
 // Pipeline (all on the caller's stream, no allocation):
 //   pack    key[e] = major[e] << bits | minor[e]            (uint64, 2*bits significant)
-//   sort    rocPRIM LSD radix sort over the 2*bits key bits (one-off ingest; the only
-//           library primitive in this library — everything per-step is hand-written)
+//   sort    stable LSD radix sort over the 2*bits key bits (cb_sort.hip: 8 bits per pass, ballot-match ranks, no atomics)
 //   unpack  col[e] = key[e] & mask
 //   rowptr  rowptr[v] = lower_bound(key, v << bits)          (N+1 binary searches)
 // so each row lists its neighbours in ascending id; the result depends only on the
 // edge multiset (bit-exact contract of SURVEY.md §8 a3).
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
-
 #include "cb_common.h"
+#include "cb_sort.h"
 
 namespace cb {
 
@@ -164,12 +162,7 @@ static int key_bits(int64_t N) {
   return b;
 }
 
-static size_t sort_temp_bytes(int64_t E, int bits) {
-  size_t bytes = 0;
-  uint64_t* p = nullptr;
-  (void)rocprim::radix_sort_keys(nullptr, bytes, p, p, (size_t)E, 0u, (unsigned)(2 * bits), (hipStream_t)0);
-  return bytes;
-}
+static size_t sort_temp_bytes(int64_t E, int /*bits*/) { return sort_u64_temp_bytes(E); }
 
 template <typename RP>
 static int build_one(const int64_t* major, const int64_t* minor, int64_t E, int64_t N, int bits, RP* rowptr,
@@ -179,8 +172,8 @@ static int build_one(const int64_t* major, const int64_t* minor, int64_t E, int6
   if (E > 0) {
     hipLaunchKernelGGL(k_pack_keys, dim3(blocks_for(E, B)), dim3(B), 0, st, major, minor, E, N, bits, keys_a, flags);
     CB_LAUNCH_CHECK();
-    size_t tb = temp_bytes;
-    CB_HIP(rocprim::radix_sort_keys(temp, tb, keys_a, keys_b, (size_t)E, 0u, (unsigned)(2 * bits), st));
+    const int rc = sort_u64(temp, temp_bytes, keys_a, keys_b, E, 2 * bits, st);
+    if (rc != CB_OK) return rc;
     uint64_t mask = (((uint64_t)1) << bits) - 1;
     hipLaunchKernelGGL(k_unpack_cols, dim3(blocks_for(E, B)), dim3(B), 0, st, keys_b, E, mask, col);
     CB_LAUNCH_CHECK();

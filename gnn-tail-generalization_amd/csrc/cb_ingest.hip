@@ -11,14 +11,14 @@
 //   cb_craft_isolation_i64 edges kept in order unless src != dst and an endpoint is flagged (craft_isolation_v2)
 //   cb_symmetrize_i64      union with the transpose, duplicates removed, sorted by (row, col)  (utils.py:667-674 ensure_symmetric;
 //                          PyG to_undirected as used by load_ogbn, trainer_node_classification.py:574): both directions packed as
-//                          64-bit keys, one radix sort (rocPRIM, the same one-off ingest primitive as cb_graph.hip), first-of-run
+//                          64-bit keys, one radix sort (cb_sort.hip, as the CSR ingest of cb_graph.hip), first-of-run
 //                          compaction
 //
 // All integer work, bit-exact, HBM-bound (one or two passes over the edge list).  Order-preserving compaction in two
 // passes: per-block keep counts -> exclusive scan of the block counts (one block) -> scatter at block offset + rank inside
 // the block (wave ballots + a 4-entry LDS prefix), so the output order is the input order — what np.where and the
 // reference's append loop produce.  Integer atomics only (associative: deterministic results).
-#include <rocprim/device/device_radix_sort.hpp>
+#include "cb_sort.h"
 
 #include "cb_common.h"
 
@@ -193,12 +193,7 @@ static int ingest_key_bits(int64_t N) {
   return b;
 }
 
-static size_t ingest_sort_temp_bytes(int64_t n, int bits) {
-  size_t bytes = 0;
-  uint64_t* p = nullptr;
-  (void)rocprim::radix_sort_keys(nullptr, bytes, p, p, (size_t)n, 0u, (unsigned)(2 * bits), (hipStream_t)0);
-  return bytes;
-}
+static size_t ingest_sort_temp_bytes(int64_t n, int /*bits*/) { return sort_u64_temp_bytes(n); }
 
 static inline int64_t n_blocks(int64_t n) { return (n + kTile - 1) / kTile; }
 
@@ -304,6 +299,9 @@ extern "C" int cb_symmetrize_i64(const int64_t* src, const int64_t* dst, int64_t
   if (nb > 256 * 16) nb = 256 * 16;
   hipLaunchKernelGGL(k_pack_both, dim3((unsigned)nb), dim3(kCB), 0, st, src, dst, E, N, bits, keys_a, n_bad);
   CB_LAUNCH_CHECK();
-  CB_HIP(rocprim::radix_sort_keys(temp, temp_bytes, keys_a, keys_b, (size_t)n2, 0u, (unsigned)(2 * bits), st));
+  {
+    const int rc = sort_u64(temp, temp_bytes, keys_a, keys_b, n2, 2 * bits, st);
+    if (rc != CB_OK) return rc;
+  }
   return run_compact(FirstOfRunPred{keys_b}, KeyWriter{keys_b, bits, out_row, out_col}, n2, count, cws, ws_bytes - (2 * kb + temp_bytes), st);
 }
