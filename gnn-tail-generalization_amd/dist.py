@@ -313,13 +313,18 @@ def cover_slices_enabled():
     return os.environ.get('COLDBREW_HALO_COVER', '1') != '0'
 
 
-def choose_cover(u_idx, v_idx, q_u, q_v, n_u, n_v, P):
+COVER_MIN_GAIN = 0.10      # a rank pair leaves the plain pull only for >= 10 % fewer rows: pushed rows cost the owner an aggregation over their edges
+
+
+def choose_cover(u_idx, v_idx, q_u, q_v, n_u, n_v, P, min_gain=COVER_MIN_GAIN):
     """Push / pull assignment of the remote edges of one requester.  u_idx / v_idx: per edge, index of its source among the n_u distinct
     remote sources / of its (owner, destination) pair among the n_v distinct pairs; q_u / q_v: owner of each distinct source / pair.
     Returns pull [E] bool (True: the source row is shipped; False: the edge is summed by the owner into the destination's partial row).
     Heuristic vertex cover per owner: each edge goes to its higher-degree endpoint (ties: pull), sources that are shipped anyway absorb
     all their edges, then destinations that are pushed anyway absorb theirs; per owner the result competes with all-pull and all-push and
-    the smallest row count wins (within 1 - 3 % of the Hopcroft-Karp optimum on the power-law graphs, profiles/r04_halo_cover_study.md)."""
+    the smallest row count wins — but the pull is kept unless it is beaten by min_gain (a pushed row costs its owner an aggregation over the
+    edges it sums; on the ogbn-products shape a 0.4 % smaller all-push cover would double the local work).  Within 1 - 3 % of the
+    Hopcroft-Karp optimum on the power-law graphs (profiles/r04_halo_cover_study.md)."""
     dev = u_idx.device
     du = torch.bincount(u_idx, minlength=n_u)
     dv = torch.bincount(v_idx, minlength=n_v)
@@ -335,7 +340,8 @@ def choose_cover(u_idx, v_idx, q_u, q_v, n_u, n_v, P):
     c_pull = torch.bincount(q_u, minlength=P)
     c_push = torch.bincount(q_v, minlength=P)
     c_mix = torch.bincount(q_u[S], minlength=P) + torch.bincount(q_v[T], minlength=P)
-    all_pull = (c_pull <= c_mix) & (c_pull <= c_push)
+    best = torch.minimum(c_mix, c_push)
+    all_pull = best.double() > (1.0 - float(min_gain)) * c_pull.double()      # not worth it (dense graphs: every source is referenced anyway)
     all_push = ~all_pull & (c_push <= c_mix)
     q_e = q_u[u_idx]
     return (pull | all_pull[q_e]) & ~all_push[q_e]
@@ -351,22 +357,33 @@ class CoverPlan:
     per pulled row, the summed sources per pushed row), send_counts[k][p]; pack() is an aggregation over it."""
     cover = True
 
-    def __init__(self, rows, cols, part, group, n_slices, compute):
-        """rows / cols: local destination / global source of this rank's REMOTE edges (this orientation)."""
-        P, K, me = part.world, max(1, int(n_slices)), part.rank
-        dev = cols.device
+    @staticmethod
+    def assign(rows, cols, part):
+        """The push / pull assignment of this rank's remote edges (requester side, no communication): what __init__ builds the plan from.
+        ['rows_pull'] / ['rows_cover'] = rows this rank would receive with the plain pull / with the cover."""
         nl = max(part.n_local, 1)
-        self.n_slices, self.n_local = K, part.n_local
+        dev = cols.device
         q_e = part.owner(cols)
         uu, ui = torch.unique(cols, return_inverse=True)                         # distinct remote sources (ascending: grouped by owner)
         vv, vi = torch.unique(q_e * nl + rows, return_inverse=True)              # distinct (owner, destination) pairs (owner-major)
         q_u, q_v = part.owner(uu), vv // nl
-        pull = choose_cover(ui, vi, q_u, q_v, int(uu.numel()), int(vv.numel()), P)
-        self.n_pull_only = int(uu.numel())                                       # rows the plain pull would move (diagnostics)
+        pull = choose_cover(ui, vi, q_u, q_v, int(uu.numel()), int(vv.numel()), part.world)
         S = torch.zeros(uu.numel(), dtype=torch.bool, device=dev)
         S[ui[pull]] = True
         T = torch.zeros(vv.numel(), dtype=torch.bool, device=dev)
         T[vi[~pull]] = True
+        return dict(q_e=q_e, uu=uu, ui=ui, vv=vv, vi=vi, q_u=q_u, q_v=q_v, pull=pull, S=S, T=T, rows_pull=int(uu.numel()),
+                    rows_cover=int(S.sum()) + int(T.sum()))
+
+    def __init__(self, rows, cols, part, group, n_slices, compute, assignment=None):
+        """rows / cols: local destination / global source of this rank's REMOTE edges (this orientation)."""
+        P, K = part.world, max(1, int(n_slices))
+        dev = cols.device
+        nl = max(part.n_local, 1)
+        self.n_slices, self.n_local = K, part.n_local
+        a = assignment if assignment is not None else CoverPlan.assign(rows, cols, part)
+        q_e, uu, ui, vv, vi, q_u, q_v, pull, S, T = (a[k] for k in ('q_e', 'uu', 'ui', 'vv', 'vi', 'q_u', 'q_v', 'pull', 'S', 'T'))
+        self.n_pull_only = a['rows_pull']                                        # rows the plain pull would move (diagnostics)
         su, tv = torch.nonzero(S).reshape(-1), torch.nonzero(T).reshape(-1)      # shipped sources / pushed pairs, owner-major ascending
         n_pull = torch.bincount(q_u[su], minlength=P)
         n_push = torch.bincount(q_v[tv], minlength=P)
@@ -496,6 +513,7 @@ class ShardedGraph:
         self.overlap = bool(overlap) and exchange == 'halo' and part.world > 1
         # push / pull cover of the remote edges (module docstring): overlapped halo form only; None = COLDBREW_HALO_COVER (default on)
         self.cover = self.overlap and (cover_slices_enabled() if cover is None else bool(cover))
+        self._cover_forced = cover == 'force' or os.environ.get('COLDBREW_HALO_COVER') == 'force'      # tests: the cover plan whatever it saves
         self._n_slices_req = n_slices
         if local_edges is None:
             src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
@@ -566,7 +584,17 @@ class ShardedGraph:
                 if part.world > 1:
                     _all_reduce(nh, op=dist.ReduceOp.MAX, group=self.group)
                 K = default_slices(int(nh.item()))
-        o.plan = CoverPlan(rows[remote], cols[remote], part, self.group, K, self.compute) if self.cover else HaloPlan(uniq, part, self.group, K)
+        use_cover = False
+        if self.cover:
+            # one decision for the group (every rank must build the same kind of plan): the cover is taken when it spares the busiest
+            # requester at least COVER_MIN_GAIN of its rows (power-law graphs: 25 - 32 %; the ogbn-products shape: < 6 % -> plain pull,
+            # whose pack is a row gather and whose slices follow the owners' row chunks)
+            asg = CoverPlan.assign(rows[remote], cols[remote], part)
+            gain = torch.tensor([int(1000 * (1.0 - asg['rows_cover'] / max(asg['rows_pull'], 1)))], dtype=torch.int64, device=rows.device)
+            if part.world > 1:
+                _all_reduce(gain, op=dist.ReduceOp.MAX, group=self.group)
+            use_cover = int(gain.item()) >= int(1000 * COVER_MIN_GAIN) or self._cover_forced
+        o.plan = CoverPlan(rows[remote], cols[remote], part, self.group, K, self.compute, asg) if use_cover else HaloPlan(uniq, part, self.group, K)
         if self.overlap:
             o.interior = self.compute.csr(rows[~remote], cols[~remote] - lo, self.N, self.N)
             rr, sl, slot = o.plan.halo_edges(rows[remote], inv)

@@ -197,7 +197,45 @@ def test_push_pull_cover_exchange_matches_unsharded_oracle(name, world, n_slices
     and which destination rows arrive as owner-side partial sums (push); the send buffer is an aggregation over a send CSR, the time
     slices cut a pair's list by position.  Forward, backward (own reverse plan on the directed multigraph) and every gradient equal the
     unsharded oracle's within the fp32 contract; never more rows on a link than the pull; every remote edge served exactly once."""
-    _run(_worker, world, name, 'halo', True, kind, wire, n_slices, True, True)
+    _run(_worker, world, name, 'halo', True, kind, wire, n_slices, True, 'force')
+
+
+def _decision_worker(rank, world, port, _unused, q):
+    _setup(rank, world, port)
+    try:
+        from dist_cpu_compute import OracleCompute
+        from gnn_tail_generalization_amd import dist as cbdist
+        gen = torch.Generator().manual_seed(0)
+        n = 120
+        # dense: every node has ~30 neighbours on the other rank -> every source row is referenced anyway: the cover cannot beat the pull by 10 %
+        a = (torch.rand(n, n, generator=gen) < 0.5)
+        a = a | a.t() | torch.eye(n, dtype=torch.bool)
+        dense = a.nonzero().t().contiguous()
+        # star-like: rank 0 holds two hubs that all of rank 1's nodes point to and are pointed to by -> push / pull covers save most rows
+        hub = torch.tensor([0, 1])
+        leaves = torch.arange(n // 2, n)
+        src = torch.cat([hub.repeat_interleave(leaves.numel()), leaves.repeat(2), torch.arange(n)])
+        dst = torch.cat([leaves.repeat(2), hub.repeat_interleave(leaves.numel()), torch.arange(n)])
+        star = torch.stack([src, dst])
+        part = cbdist.Partition(n, world, rank)
+        kinds = []
+        for ei in (dense, star):
+            sg = cbdist.ShardedGraph(ei, n, part, compute=OracleCompute(), n_slices=2)      # cover allowed (default), not forced
+            assert sg.cover
+            kinds.append(bool(sg.f.plan.cover))
+        assert kinds == [False, True], kinds
+        q.put((rank, 'ok'))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, 'FAIL ' + traceback.format_exc()[-1500:]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cover_is_taken_only_where_it_saves_rows():
+    """One decision per orientation for the whole group (all-reduce): the push / pull cover where it spares the busiest requester >= 10 % of
+    its rows (hubs), the plain pull plan (row-gather pack, slices by owner row chunk) on a dense graph where every source is referenced anyway."""
+    _run(_decision_worker, 2, None)
 
 
 def test_cover_heuristic_never_worse_than_pull_or_push():
@@ -218,6 +256,8 @@ def test_cover_heuristic_never_worse_than_pull_or_push():
     u = v = torch.arange(5)                                               # matching
     pull = choose_cover(u, v, z(5), z(5), 5, 5, 2)
     assert rows_moved(u, v, pull) == 5 and pull.all()
+    u, v = torch.arange(20), torch.arange(20) % 19                        # 20 sources -> 19 destinations: 5 % fewer rows are not worth a push
+    assert choose_cover(u, v, z(20), z(19), 20, 19, 2).all() and not choose_cover(u, v, z(20), z(19), 20, 19, 2, min_gain=0.0).any()
     gen = torch.Generator().manual_seed(0)
     u, v = torch.randint(0, 40, (2000,), generator=gen), torch.randint(0, 50, (2000,), generator=gen)       # dense 40 x 50 block
     pull = choose_cover(u, v, z(40), z(50), 40, 50, 2)

@@ -41,7 +41,8 @@ def _worker(rank, world, port, exchange, overlap, partition, argv, q, wire='f32'
     import io
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), COLDBREW_EXCHANGE=exchange, COLDBREW_OVERLAP=overlap,
-                      COLDBREW_PARTITION=partition, COLDBREW_HALO_WIRE=wire, COLDBREW_HALO_COVER=cover)
+                      COLDBREW_PARTITION=partition, COLDBREW_HALO_WIRE=wire,
+                      COLDBREW_HALO_COVER='force' if cover == '1' else cover)      # force: the cover plan whatever it saves on this small graph
     if slices:
         os.environ['COLDBREW_HALO_SLICES'] = slices
     dev_id = rank if backend == 'nccl' else 0          # nccl (= RCCL): one GPU per rank; gloo: the ranks share the test box's single GPU
@@ -62,6 +63,7 @@ def _worker(rank, world, port, exchange, overlap, partition, argv, q, wire='f32'
             t.setup_teacherGNN()
         t.load_full_state_dict({k: v.cuda() for k, v in _full_state(argv).items()})
         assert t.sgraph.cover == (cover == '1' and overlap == '1' and exchange == 'halo')
+        assert t.sgraph.f.plan is None or bool(t.sgraph.f.plan.cover) == t.sgraph.cover
         assert t.sgraph.exchange_kind == exchange and t.sgraph.overlap == (overlap == '1') and t.part.kind == partition
         assert t.sgraph.wire == wire
         if slices:
