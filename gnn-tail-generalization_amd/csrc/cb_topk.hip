@@ -380,15 +380,13 @@ extern "C" int cb_topk_replace_f32(const float* q, int64_t ldq, const float* t, 
   hipStream_t st = (hipStream_t)stream;
   const int aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)t % 16 == 0) && ldq % 4 == 0 && ldt % 4 == 0;
   static const bool plain = getenv("CB_GEMM_PLAIN_F32") != nullptr;
-  static const bool nofold = getenv("CB_TOPK_NOFOLD") != nullptr;      // measurement hook: the score sweep alone (results are garbage)
   if (aligned && !plain && D % 4 == 0 && ldq < (1 << 22) && ldt < (1 << 22))
-    hipLaunchKernelGGL(k_topk_scores_l3, dim3((unsigned)rb, (unsigned)ns), dim3(256), 0, st, q, ldq, t, ldt, B, (int)N, (int)D, nofold ? -1 : (int)K,
+    hipLaunchKernelGGL(k_topk_scores_l3, dim3((unsigned)rb, (unsigned)ns), dim3(256), 0, st, q, ldq, t, ldt, B, (int)N, (int)D, (int)K,
                        tps, ctl, (Cand*)ws);
   else
     hipLaunchKernelGGL(k_topk_scores, dim3((unsigned)rb, (unsigned)ns), dim3(256), 0, st, q, ldq, t, ldt, B, (int)N, (int)D, (int)K,
                        tps, ctl, (Cand*)ws, aligned);
   CB_LAUNCH_CHECK();
-  if (nofold) return CB_OK;
   hipLaunchKernelGGL(k_topk_finish, dim3((unsigned)((B * 64 + 255) / 256)), dim3(256), 0, st, (const Cand*)ws, ns, B, (int)K, t, ldt,
                      (int)D, out, out_idx, out_w);
   CB_LAUNCH_CHECK();

@@ -111,8 +111,8 @@ def main():
     ap.add_argument('--link-eff', type=float, default=0.8)
     ap.add_argument('--n1-ms', type=float, default=195.7, help="the DRIVER's 1-GPU ms/step (BENCH_r03.json: 195.7): efficiency = n1 / (P * step)")
     ap.add_argument('--dense-pull-ms', type=float, default=113.0, help='1-GPU step outside the six plain aggregations (pull pipeline: GEMMs stay kernels of their own)')
-    ap.add_argument('--dense-cover-ms', type=float, default=62.0,
-                    help='1-GPU step outside the aggregation (+ GEMM, + trunk backward) launches: 191 ms - 5 x 20.8 (fused) - 17.3 (plain) - 2 x 3.8 (trunk backward passes that move into the tails)')
+    ap.add_argument('--dense-cover-ms', type=float, default=72.0,
+                    help='1-GPU step outside the aggregation (+ GEMM) launches: 193.5 ms - 5 x 20.8 (fused, incl. hub kernels) - 17.3 (plain)')
     ap.add_argument('--layers', type=int, default=3)
     ap.add_argument('--mode', default='both', choices=['both', 'pull', 'cover'])
     ap.add_argument('--halo-only', type=int, default=0, help='1: only count rows per link (pull vs cover), no kernel timing')
@@ -308,24 +308,30 @@ def main():
 
                 def exposed(last_ms):
                     return pipeline(zero, t_pack, t_link, t_int, t_pass + [last_ms - last['clone_only']])
-                # forward: layers 0 .. L-2 store + next GEMM, layer L-1 store only; backward: layers L-1 .. 1 with the trunk backward in the tail,
-                # layer 0 with the plain dX tail
-                per = ([exposed(last['fused_store_gemm'])] * (L - 1) + [exposed(last['fused_store'])]
-                       + [exposed(last['reverse_gemm_trunkbwd'])] * (L - 1) + [exposed(last['reverse_gemm'])])
+                # forward: layers 0 .. L-2 store + next GEMM, layer L-1 store only; backward: every layer the dX tail; the trunk backward of the
+                # layer below stays a pass of its own (its time is part of --dense-cover-ms; in the tail's epilogue it measures slower:
+                # 'reverse_gemm_trunkbwd' against 'reverse_gemm' + t_trunk_bwd)
+                gb = torch.rand(n_local, d, device=dev)
+                t_tb = timed(lambda: trunk._layer_bwd(gb, bits, scale, None, False, 0.1, 7, 0, 0.9, 0.1, True))
+                last['trunk_bwd_pass'] = t_tb
+                per = ([exposed(last['fused_store_gemm'])] * (L - 1) + [exposed(last['fused_store'])] + [exposed(last['reverse_gemm'])] * L)
                 step = a.dense_cover_ms / P + sum(per)
                 row['cover'].update({'pack_ms': t_pack, 'halo_pass_ms': t_pass, 'last_pass_ms': last, 'link_ms': t_link, 'exposed_ms_per_aggregation': per,
                                      'step_ms': step, 'steps_per_s': 1e3 / step, 'efficiency_vs_driver_n1': a.n1_ms / (P * step),
                                      'link_bound_step_ms': a.dense_cover_ms / P + 2 * L * sum(t_link)})
                 del g_halo, g_send, halos, acc
             torch.cuda.empty_cache()
+        if 'cover' in row and 'pull' in row:      # the plan dist.ShardedGraph adopts: the cover where it spares >= COVER_MIN_GAIN of the rows
+            row['adopted'] = 'cover' if row['cover']['halo_rows'] <= (1.0 - cbdist.COVER_MIN_GAIN) * row['cover']['rows_pull_only'] else 'pull'
         out_rows.append(row)
         print(json.dumps(row), flush=True)
         del g_int, h, rr, cc, remote
         torch.cuda.empty_cache()
     print(f'\n{a.name} (N={n}, E={E}), d={d}, rank {a.rank} of each world, {K} slices, link {a.link_gbs} GB/s x {a.link_eff}, driver 1-GPU step {a.n1_ms} ms')
     print('| P | rows / rank | remote edges | pull: rows on the busiest link | cover: rows on the busiest link (pulled + pushed of all peers) | cover / pull |'
-          + ('' if a.halo_only else ' pull: exposed / step / steps/s / eff. | cover: exposed (fwd+GEMM, fwd last, bwd+TB, bwd last) / step / steps/s / eff. | link-bound step (cover) |'))
+          + ('' if a.halo_only else ' pull: exposed / step / steps/s / eff. | cover: exposed (fwd+GEMM, fwd last, bwd+dX) / step / steps/s / eff. | link-bound step (cover) |'))
     print('|---|---|---|---|---|---|' + ('' if a.halo_only else '---|---|---|'))
+    print('(adopted plan per world: ' + ', '.join(f"P={w_['P']}: {w_.get('adopted', '-')}" for w_ in out_rows if w_['P'] > 1) + ')')
     for w_ in out_rows:
         if w_['P'] == 1:
             print(f"| 1 | {w_['rows_local']} | 0 | - | - | - |" + ('' if a.halo_only else f" aggregation {w_['aggregation_ms']:.2f} ms, + GEMM {w_['aggregation_plus_gemm_ms']:.2f} ms | step {a.n1_ms} ms = {1e3 / a.n1_ms:.2f} steps/s (driver) | - |"))
@@ -337,7 +343,7 @@ def main():
             line += (f" {pl['exposed_ms']:.2f} / {pl['step_ms']:.1f} / {pl['steps_per_s']:.2f} / {pl['efficiency_vs_driver_n1']:.2f} |" if pl else ' - |')
             if cv:
                 e = cv['exposed_ms_per_aggregation']
-                line += (f" {e[0]:.2f}, {e[L - 1]:.2f}, {e[L]:.2f}, {e[-1]:.2f} / {cv['step_ms']:.1f} / {cv['steps_per_s']:.2f} / {cv['efficiency_vs_driver_n1']:.2f} | "
+                line += (f" {e[0]:.2f}, {e[L - 1]:.2f}, {e[L]:.2f} / {cv['step_ms']:.1f} / {cv['steps_per_s']:.2f} / {cv['efficiency_vs_driver_n1']:.2f} | "
                          f"{cv['link_bound_step_ms']:.1f} |")
             else:
                 line += ' - | - |'
