@@ -105,7 +105,12 @@ class CSRGraph:
             return hit
 
         def flag(col):
-            refs = torch.bincount(col[:self.E].long(), minlength=self.n_cols)          # how often each source row is gathered per launch
+            # how often each source row is gathered per launch: the library's own histogram kernel (cb_value_hist_i32; no int64 copy of the ids)
+            lib = _lib.load()
+            refs = torch.empty(self.n_cols, dtype=torch.int32, device=self.device)
+            bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(lib.cb_value_hist_i32(_lib.ptr(col), self.E, self.n_cols, _lib.ptr(refs), _lib.ptr(bad), _lib.stream_ptr()), 'cb_value_hist_i32')
             thr = torch.clamp(torch.topk(refs, k).values[-1], min=2)
             hot = (refs >= thr)[col.long()]
             return torch.where(hot, col | (-2 ** 31), col).to(torch.int32)

@@ -105,12 +105,16 @@ def _fused_gemm(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowscale, g_
 
 def agg_gemm_eligible(graph, hidden, agg_bf16):
     """The aggregation + next-dense-transform kernels (cb_agg_gemm.hip): hidden = 256, fp32 rows; one GPU, or node-sharded with the
-    overlapped halo exchange on the fp32 wire (the last halo pass is then the fused kernel on top of the running sums).  CB_AGG_GEMM=0
+    overlapped halo exchange on the fp32 wire under a push / pull cover plan or an unsliced pull plan (the last halo pass is then the
+    fused kernel on top of the running sums).  CB_AGG_GEMM=0
     keeps the two-kernel form (aggregation, then GEMM)."""
     if os.environ.get('CB_AGG_GEMM', '1') == '0' or hidden != 256 or agg_bf16:
         return False
     if hasattr(graph, 'part'):
-        return bool(graph.overlap) and graph.wire == 'f32'
+        # with the pull plan cut by owner row chunks the row-chunked producers win instead (the GEMM chunks run under the link time of a
+        # link-bound exchange: 12.8 vs 11.4 predicted steps/s on the ogbn-products shape at P = 2, profiles/r04_shard_probe_S-products.txt)
+        plan = graph.f.plan
+        return bool(graph.overlap) and graph.wire == 'f32' and plan is not None and (plan.cover or plan.n_slices == 1)
     return hasattr(graph, 'spmm_gemm')
 
 

@@ -97,7 +97,8 @@ def _free_port():
     ('halo', '1', 'edges', ARGV_BN, 'f32', 2, '', '1'), ('halo', '1', 'edges', ARGV, 'bf16', 2, '', '1'), ('halo', '1', 'edges', ARGV, 'f32', 3, '', '1'),
     ('halo', '1', 'edges', ARGV, 'f32', 2, '3', '1'), ('halo', '1', 'edges', ARGV, 'f32', 3, '4', '1'), ('halo', '1', 'edges', ARGV, 'bf16', 2, '2', '1'),
     ('halo', '1', 'edges', ARGV_BN, 'f32', 2, '2', '1'),
-    # the pull-only plan (COLDBREW_HALO_COVER=0: slices by owner row chunk; the aggregation + GEMM kernels still take the last halo pass)
+    # the pull-only plan (COLDBREW_HALO_COVER=0): sliced by owner row chunk with row-chunked producers; unsliced with the aggregation + GEMM
+    # kernel as its last halo pass
     ('halo', '1', 'edges', ARGV, 'f32', 2, '3', '0'), ('halo', '1', 'edges', ARGV, 'f32', 3, '', '0'), ('halo', '1', 'edges', ARGV, 'bf16', 2, '2', '0')],
     ids=['cover-overlap-edges', 'halo-singlepass-rows', 'allgather', 'batchnorm-cover-overlap', 'cover-bf16-wire', 'three-ranks-cover',
          'cover-sliced3', 'three-ranks-cover-sliced4', 'cover-sliced2-bf16-wire', 'batchnorm-cover-sliced2',
