@@ -198,7 +198,7 @@ template <typename RP>
 static int csr_from_coo(const char* who, const int64_t* src, const int64_t* dst, int64_t E, int64_t N, RP* rowptr, int32_t* col, RP* rowptr_t,
                         int32_t* col_t, int32_t* flags, void* workspace, size_t workspace_bytes, void* stream) {
   CB_CHECK_ARG(E >= 0 && N >= 0, CB_E_INVALID, "%s: negative size (E=%lld, N=%lld)", who, (long long)E, (long long)N);
-  CB_CHECK_ARG((sizeof(RP) == 8 ? E < ((int64_t)1 << 36) : E < INT32_MAX) && N < INT32_MAX, CB_E_RANGE,
+  CB_CHECK_ARG((sizeof(RP) == 8 ? E < ((int64_t)1 << 32) : E < INT32_MAX) && N < INT32_MAX, CB_E_RANGE,
                "%s: E=%lld / N=%lld exceed the index contract (int32 column ids; %s row pointers)", who, (long long)E, (long long)N,
                sizeof(RP) == 8 ? "int64" : "int32: use cb_csr64_from_coo_i64 for E >= 2^31");
   CB_CHECK_ARG(rowptr && rowptr_t && flags && (E == 0 || (src && dst && col && col_t)), CB_E_INVALID, "%s: null pointer", who);

@@ -9,7 +9,7 @@ namespace cb {
 // bytes of scratch sort_u64 needs for n keys
 size_t sort_u64_temp_bytes(int64_t n);
 
-// keys_out = keys_in sorted ascending by bits [0, end_bit) (stable); keys_in is used as the second buffer and destroyed.  n < 2^40.
+// keys_out = keys_in sorted ascending by bits [0, end_bit) (stable); keys_in is used as the second buffer and destroyed.  n < 2^32.
 int sort_u64(void* temp, size_t temp_bytes, uint64_t* keys_in, uint64_t* keys_out, int64_t n, int end_bit, hipStream_t st);
 
 }  // namespace cb

@@ -84,8 +84,7 @@ __global__ void __launch_bounds__(1024) k_sort_scan(const uint32_t* __restrict__
     uint32_t wave_off = 0;
     for (int j = 0; j < w; ++j) wave_off += s_wave[j];
     const uint64_t carry = s_carry;
-    // (a digit's exclusive prefix over the blocks stays below n: 32 bits suffice for n < 2^32; beyond, the digit bases carry the high part —
-    //  the scatter adds base (64 bit) + this 32-bit prefix, which is exact as long as ONE digit of one pass holds < 2^32 keys)
+    // (a digit's exclusive prefix over the blocks stays below n < 2^32: 32 bits; the digit bases are 64 bit)
     if (i < n_blocks) o[i] = (uint32_t)(carry + wave_off + x - v);
     __syncthreads();
     if (t == 1023) s_carry = carry + wave_off + x;
@@ -166,7 +165,7 @@ size_t sort_u64_temp_bytes(int64_t n) {
 }
 
 int sort_u64(void* temp, size_t temp_bytes, uint64_t* keys_in, uint64_t* keys_out, int64_t n, int end_bit, hipStream_t st) {
-  CB_CHECK_ARG(n >= 0 && n < ((int64_t)1 << 40) && end_bit > 0 && end_bit <= 64, CB_E_RANGE, "sort_u64: bad size / bit range");
+  CB_CHECK_ARG(n >= 0 && n < ((int64_t)1 << 32) && end_bit > 0 && end_bit <= 64, CB_E_RANGE, "sort_u64: bad size / bit range (n < 2^32: per-digit prefixes are 32 bit)");
   if (n == 0) return CB_OK;
   CB_CHECK_ARG(temp && keys_in && keys_out && temp_bytes >= sort_u64_temp_bytes(n), CB_E_WORKSPACE, "sort_u64: scratch too small");
   const int64_t nb = sort_blocks(n);

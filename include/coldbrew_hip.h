@@ -73,7 +73,7 @@ int cb_csr_from_coo_i64(const int64_t* src, const int64_t* dst, int64_t E, int64
 int cb_deg_norm_f32(const int32_t* rowptr, int64_t N, float* norm, void* stream);
 
 /* E >= 2^31 on one device ("indices int32 (int64 rowptr if E >= 2^31)"; the reference's graph is int64 throughout,
- * GCN.py:93-94): the same ingest with int64 row pointers (column ids stay int32: N < 2^31; E < 2^36), the degree norms from them, and
+ * GCN.py:93-94): the same ingest with int64 row pointers (column ids stay int32: N < 2^31; E < 2^32), the degree norms from them, and
  * cb_csr_rebase_i64: out[i] = rowptr[row0 + i] - rowptr[row0], i <= n_rows — the int32 row pointers of a row block with fewer than 2^31
  * edges, whose column ids start at col + rowptr[row0].  The aggregation kernels index edges with 32 bits inside a launch; the host cuts the
  * rows into such blocks (graph.SegmentedCSRGraph) and every entry point above runs per block, as it does on a rank's row block of the
