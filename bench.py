@@ -386,7 +386,8 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29511')
         backend = os.environ.get('COLDBREW_DIST_BACKEND', 'nccl')      # 'gloo': dry run of this file's N>1 path on a 1-GPU box
         if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+            from gnn_tail_generalization_amd.dist import init_rccl
+            init_rccl(rank, world, dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     if a.gpus != world and rank == 0:

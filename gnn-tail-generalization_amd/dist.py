@@ -84,6 +84,21 @@ class _Done:
         return True
 
 
+def init_rccl(rank, world_size, device, **kw):
+    """init_process_group('nccl' = RCCL) bound to `device`, with the collectives on HIGH-PRIORITY streams: the halo all-to-all of a
+    slice is issued beside an aggregation pass that fills every CU, and its workgroups must be dispatched ahead of that pass's
+    (tens of thousands of) pending ones, not behind them."""
+    opts = None
+    try:
+        opts = dist.ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = True
+    except (AttributeError, TypeError):        # a build without the option: default-priority streams
+        opts = None
+    if opts is not None:
+        kw.setdefault('pg_options', opts)
+    dist.init_process_group('nccl', rank=rank, world_size=world_size, device_id=torch.device(device), **kw)
+
+
 def _all_to_all_single(out, inp, out_splits=None, in_splits=None, group=None, async_op=False):
     """Returns a work handle when async_op (already finished for the staged / gloo-CPU forms)."""
     if _staged(inp, group) or _staged(out, group):

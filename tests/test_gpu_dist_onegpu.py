@@ -49,7 +49,8 @@ def _worker(rank, world, port, exchange, overlap, partition, argv, q, wire='f32'
     if backend == 'nccl':
         argv = [a_ for a_ in argv if not a_.startswith('--manual_assign_GPU')] + [f'--manual_assign_GPU={dev_id}']
         torch.cuda.set_device(dev_id)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{dev_id}'))
+        from gnn_tail_generalization_amd.dist import init_rccl
+        init_rccl(rank, world, f'cuda:{dev_id}')
     else:
         dist.init_process_group('gloo', rank=rank, world_size=world)
     try:

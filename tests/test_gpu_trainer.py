@@ -162,7 +162,8 @@ def test_sharded_trainer_world1_matches_plain_trainer():
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29533')
     if not dist.is_initialized():
-        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))
+        from gnn_tail_generalization_amd.dist import init_rccl
+        init_rccl(0, 1, DEV)
     try:
         losses, sd0 = [], None
         for cls in (trainer, ShardedTrainer):
@@ -181,6 +182,53 @@ def test_sharded_trainer_world1_matches_plain_trainer():
             losses.append([float(t.train_step()) for _ in range(4)])
             ops._seed_override[:] = []
         np.testing.assert_allclose(losses[0], losses[1], rtol=1e-5)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_carries_the_exchange_calls_in_the_forms_the_halo_plan_issues():
+    """The multi-process tests on a one-GPU box stage the exchange through gloo; the collectives themselves — `all_to_all_single` on
+    2-D device tensors with uneven (and zero) split lists, asynchronous work handles waited on later, bf16 rows moved as bytes, the
+    small all-reduces / all-gathers — run here on RCCL (world size 1: every rank-pair list has one entry, the rows loop back)."""
+    import os
+    import torch.distributed as dist
+    from gnn_tail_generalization_amd import dist as cbdist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    assert not dist.is_initialized()
+    cbdist.init_rccl(0, 1, DEV)
+    try:
+        assert dist.get_backend() == 'nccl'
+        g = torch.Generator(device='cpu').manual_seed(5)
+        flights = []
+        for n in (0, 1, 777, 40_001):                                   # several slices in flight, as start_halo leaves them
+            send = torch.randn(n, 256, generator=g).to(DEV)
+            recv = torch.empty((max(n, 1), 256), dtype=torch.float32, device=DEV)
+            work = cbdist._all_to_all_single(recv[:n], send, [n], [n], async_op=True)
+            flights.append((send, recv, n, work))
+            torch.mm(torch.ones(512, 512, device=DEV), torch.ones(512, 512, device=DEV))      # compute issued under the exchange
+        for send, recv, n, work in flights:
+            work.wait()
+            assert torch.equal(recv[:n], send)
+        send = torch.randn(333, 256, generator=g).to(DEV).to(torch.bfloat16)                    # bf16 wire: moves as bytes
+        recv = torch.empty_like(send)
+        cbdist._all_to_all_single(recv.view(torch.uint8), send.view(torch.uint8), [333], [333], async_op=True).wait()
+        assert torch.equal(recv, send)
+        cnt = torch.tensor([[3, 1, 4]], dtype=torch.int64, device=DEV)                          # plan building: counts, then index lists
+        got = torch.empty_like(cnt)
+        cbdist._all_to_all_single(got.view(-1), cnt.view(-1))
+        assert torch.equal(got, cnt)
+        t = torch.arange(6, dtype=torch.float32, device=DEV)
+        cbdist._all_reduce(t)
+        assert torch.equal(t.cpu(), torch.arange(6, dtype=torch.float32))
+        m = torch.tensor([7], dtype=torch.int64, device=DEV)
+        cbdist._all_reduce(m, op=dist.ReduceOp.MAX)
+        assert int(m) == 7
+        out = torch.empty(6, dtype=torch.float32, device=DEV)
+        cbdist._all_gather_into_tensor(out, t)
+        assert torch.equal(out, t)
+        cbdist._broadcast(t, src=0)
+        torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
 
