@@ -5,7 +5,8 @@ the seeded synthetic stand-ins of SURVEY.md §8(d) for the datasets that cannot 
 
 A real PyG `Data` object works wherever this `Data` does (duck typing).  If
 `data/<dataset>.pt` exists (a dict with x, y, edge_index, train_mask[, test_mask]) it is
-loaded instead of the synthetic stand-in.
+loaded instead of the synthetic stand-in; so are the RAW files of the reference's own loaders
+(Planetoid pickles, OGB csv files) when they lie under `data/` (datasets.py).
 """
 import os
 
@@ -140,16 +141,44 @@ def load_file(path, device):
     return d.to(device)
 
 
-def load_data(dataset, which_run, trainer_self):
-    """Counterpart of trainer_node_classification.load_data (:616-670) + load_ogbn (:570-577)."""
+def _post_planetoid(data, num_nodes):
+    """trainer_node_classification.py:655-662: symmetric, no self-loops, then one self-loop per node appended last."""
+    ei = ensure_symmetric(data.edge_index)
+    ei = remove_self_loops(ei)
+    data.edge_index = add_self_loops(ei, num_nodes)
+    return data
+
+
+def load_data(dataset, which_run, trainer_self, root='data'):
+    """Counterpart of trainer_node_classification.load_data (:616-670) + load_ogbn (:570-577) and the ogbn branch of trainer.__init__
+    (:258-271).  Sources, in this order: `<root>/<dataset>.pt` (a dict of tensors), the RAW files the reference's own loaders keep under
+    `<root>/` (Planetoid pickles, OGB csv files: datasets.py), else the seeded synthetic stand-in of the dataset's shape."""
+    from . import datasets
     device = trainer_self.device
-    path = os.path.join('data', f'{dataset}.pt')
+    path = os.path.join(root, f'{dataset}.pt')
+    raw_pl = datasets.planetoid_raw_dir(root, dataset) if dataset in ('Cora', 'Citeseer', 'Pubmed') else None
+    raw_ogb = datasets.ogb_dir(root, dataset) if dataset.startswith('ogbn') else None
     if os.path.isfile(path):
         data = load_file(path, device)
         if not dataset.startswith('ogbn'):
-            ei = ensure_symmetric(data.edge_index)
-            ei = remove_self_loops(ei)
-            data.edge_index = add_self_loops(ei, data.x.shape[0])
+            data = _post_planetoid(data, data.x.shape[0])
+    elif raw_pl is not None:
+        print(f'[data] {dataset}: Planetoid raw files in {raw_pl}')
+        data = Data(**datasets.read_planetoid(raw_pl, dataset)).to(device)
+        if dataset == 'Cora':      # trainer_node_classification.py:637-640: the first 600 nodes train, all others test
+            n = data.x.shape[0]
+            data.train_mask = torch.arange(n, device=device) < 600
+            data.test_mask = ~data.train_mask
+        data = _post_planetoid(data, data.x.shape[0])
+    elif raw_ogb is not None:
+        print(f'[data] {dataset}: OGB raw files in {raw_ogb}')
+        blob, split = datasets.read_ogbn(raw_ogb, device=device)
+        data = Data(**blob).to(device)
+        n = data.x.shape[0]
+        data.train_mask = torch.zeros(n, dtype=torch.bool, device=device).index_fill_(0, split['train'].to(device), True)
+        data.test_mask = torch.zeros(n, dtype=torch.bool, device=device).index_fill_(0, split['test'].to(device), True)
+        data.val_mask = torch.zeros(n, dtype=torch.bool, device=device).index_fill_(0, split['valid'].to(device), True)
+        data.train_idx = split['train'].to(device)      # (:261; test_idx = where(test_mask) below)
     else:
         print(f'[data] {dataset}: real files unavailable offline -> seeded synthetic stand-in '
               f'{ALIASES.get(dataset, dataset)} (SURVEY.md §8d)')
