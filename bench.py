@@ -477,8 +477,13 @@ def main():
                 'fused_epilogue_bytes_per_launch': store_b, 'achieved': (agg_b + tail_b) / (avg * 1e-3) / 1e9,
                 'achieved_incl_fused_epilogue': (agg_b + tail_b + store_b) / (avg * 1e-3) / 1e9,
                 'achieved_on_aggregation_bytes_only': agg_b / (avg * 1e-3) / 1e9}
-    fam_plain = family(lambda r: r[3] == 0)
-    fam_tail = family(lambda r: r[3] > 0)
+    # the row-sparse launch of the backward (the last layer's reverse aggregation over the loss rows only, trunk.py) is kept apart: its
+    # SURVEY 8(d) bytes are those of the filtered orientation, a tenth of the full graph's at the stand-in's 10 % train mask
+    full_b = max((r[1] for r in recs), default=0)
+    sparse = lambda r: r[1] < 0.6 * full_b      # noqa: E731
+    fam_plain = family(lambda r: r[3] == 0 and not sparse(r))
+    fam_tail = family(lambda r: r[3] > 0 and not sparse(r))
+    fam_sparse = family(sparse) if not sharded else None
     fam_main = fam_tail if (fam_tail and (not fam_plain or fam_tail['total_ms_per_step'] >= fam_plain['total_ms_per_step'])) else fam_plain
     fam_main = fam_main or {'launches_timed': 0, 'avg_launch_ms': 0.0, 'algorithmic_bytes_per_launch': 0.0, 'fused_epilogue_bytes_per_launch': 0.0,
                             'achieved': 0.0, 'achieved_incl_fused_epilogue': 0.0}
@@ -543,11 +548,15 @@ def main():
                      'launches_timed': fam_main['launches_timed'], 'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': avg_bytes,
                      'fused_epilogue_bytes_per_launch': avg_extra, 'achieved_incl_fused_epilogue': achieved_incl,
                      'plain_aggregation_launches': fam_plain, 'aggregation_plus_gemm_launches': fam_tail,
+                     'row_sparse_aggregation_launches': fam_sparse,
                      'note': ('dominant kernel = aggregation + next GEMM fused (cb_agg_gemm.hip): algorithmic bytes = SURVEY 8(d) aggregation bytes + the dense '
                               "tail's compulsory output (+ addend) — its 10 GB input never leaves the chip, and 7.9 TF-bf16 of MFMA work (3.2 ms at peak) "
                               'run under the gathers; the launches of the plain aggregation kernel in the same steps are listed beside it'
                               if fam_main is fam_tail else 'dominant kernel = the plain aggregation')},
     }
+    if fam_sparse is not None:
+        out['config']['backward'] = ('the reverse aggregation of the last layer gathers the loss (train) rows only: the gradient rows of all other nodes are exact '
+                                     'zeros under the masked loss (verified on the device every step); aggregated_edges_per_sec counts the nominal E per aggregation')
     out['peak_mem_gb'] = peak_mem / 2 ** 30
     if sharding is not None:
         out['sharding'] = sharding

@@ -25,6 +25,7 @@ SIGNATURES = {
     'cb_last_error': (ctypes.c_char_p, []),
     'cb_device_status': (ctypes.c_int, []),
     'cb_agg_gemm_handover_selftest': (ctypes.c_int, [_P]),
+    'cb_rows_zero_outside_mask_f32': (ctypes.c_int, [_P, _I64, _I64, _I64, _P, _P]),
     'cb_csr_workspace_bytes': (_SZ, [_I64, _I64]),
     'cb_csr_from_coo_i64': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'cb_deg_norm_f32': (ctypes.c_int, [_P, _I64, _P, _P]),

@@ -682,6 +682,34 @@ extern "C" int cb_act_bwd_f32(const float* g, const float* act, const float* row
   return CB_OK;
 }
 
+// Rows of g outside `mask` must be exactly zero (the claim a row-sparse backward rests on: ops.take_grad_rows / trunk.py).  Grid-stride over
+// the rows, one thread per row; a violation is recorded in the device error word (never silent: cb_device_status reports it).
+__global__ void __launch_bounds__(kBlock) k_rows_zero_check(const float* __restrict__ g, int64_t ld, int64_t rows, int d, const uint8_t* __restrict__ mask,
+                                                            int* __restrict__ err) {
+  for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < rows; r += (int64_t)gridDim.x * kBlock) {
+    if (mask[r]) continue;
+    const float* p = g + r * ld;
+    bool bad = false;
+    for (int c = 0; c < d; ++c) bad |= p[c] != 0.f;
+    if (bad) {
+      __hip_atomic_store(err + 1, (int)(r & 0x7fffffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(err + 2, (int)(r >> 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(err, CB_DEVERR_GRADROWS, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+extern "C" int cb_rows_zero_outside_mask_f32(const float* g, int64_t ld, int64_t rows, int64_t d, const uint8_t* mask, void* stream) {
+  CB_CHECK_ARG(rows >= 0 && d >= 0 && d < (1 << 20) && ld >= d, CB_E_INVALID, "cb_rows_zero_outside_mask_f32: bad size");
+  if (rows == 0 || d == 0) return CB_OK;
+  CB_CHECK_ARG(g && mask, CB_E_INVALID, "cb_rows_zero_outside_mask_f32: null pointer");
+  int* err = device_error_word();
+  CB_CHECK_ARG(err != nullptr, CB_E_HIP, "cb_rows_zero_outside_mask_f32: the device error word could not be allocated (%s)", cb_last_error());
+  hipLaunchKernelGGL(k_rows_zero_check, dim3((unsigned)grid_for(rows)), dim3(kBlock), 0, (hipStream_t)stream, g, ld, rows, (int)d, mask, err);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
 extern "C" size_t cb_reduce_workspace_bytes(void) { return (size_t)kMaxBlocks * sizeof(float); }
 
 extern "C" int cb_frobenius_norm_f32(const float* x, int64_t n, float* out2, void* ws, size_t ws_bytes, void* stream) {

@@ -38,6 +38,9 @@ const char* device_error_text() {
   if (!w || w[0] == 0) return "none";
   if (w[0] == CB_DEVERR_HANDOVER)
     snprintf(buf, sizeof(buf), "LDS tile hand-over timed out in the aggregation + GEMM kernel (block %d, counter target %d)", w[1], w[2]);
+  else if (w[0] == CB_DEVERR_GRADROWS)
+    snprintf(buf, sizeof(buf), "a gradient row outside the loss rows is not zero (row %lld): the row-sparse backward does not apply to this objective",
+             (long long)w[1] + ((long long)w[2] << 31));
   else
     snprintf(buf, sizeof(buf), "device error code %d (%d, %d)", w[0], w[1], w[2]);
   return buf;

@@ -122,6 +122,30 @@ class CSRGraph:
         self._hot_cache[k] = (ck, ctk)
         return ck, ctk
 
+    def filtered_t(self, keep):
+        """The reverse (by-source) orientation restricted to the gathered rows with keep[row] set, as a graph of its own (same N destination
+        rows, global column ids; own hub plan and hot-source flags): what the first reverse aggregation of a backward needs when the
+        gradient rows of all other nodes are exact zeros (the masked loss, ops.take_grad_rows).  Sums over it equal the sums over the
+        full orientation up to the order in which a hub row's chunks are added.  Built once per mask (torch ops on the device) and cached."""
+        key = (keep.data_ptr(), keep._version, int(keep.shape[0]))
+        if getattr(self, '_filtered_key', None) == key:
+            return self._filtered
+        if self.rowptr_t is None:
+            raise ValueError('this graph holds the forward orientation only')
+        if keep.dtype != torch.bool or keep.shape[0] != self.n_cols:
+            raise ValueError(f'filtered_t: bool mask over the {self.n_cols} source rows expected')
+        rp, col = self.rowptr_t, self.col_t[:self.E]
+        kept = torch.index_select(keep, 0, col)
+        csum = torch.cumsum(kept, 0, dtype=torch.int32)
+        csum = torch.cat([csum.new_zeros(1), csum])
+        rp_new = torch.index_select(csum, 0, rp)
+        col_new = col[kept]
+        del kept, csum
+        sub = CSRGraph.from_csr(rp_new, col_new, self.n_cols, hub_threshold=self.hub_threshold)
+        sub.norm_in, sub.norm_out = getattr(self, 'norm_in', None), getattr(self, 'norm_out', None)
+        self._filtered_key, self._filtered = key, sub
+        return sub
+
     def flagged_cols(self, transpose, row_bytes):
         """Flagged column ids for source rows of `row_bytes` bytes (None: flags off / small graph)."""
         if self.col_k is None:

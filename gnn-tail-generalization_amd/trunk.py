@@ -223,6 +223,7 @@ def tail_trunk_bwd(graph):
 
 # The input Linear's GEMM writes the mask words of (X0 > 0) from its epilogue (a wavefront holds a whole 256-column row there: four ballots),
 # and the input stage of the backward reads those 32 bytes per row instead of X0's 1 KiB (one of its six 10 GB streams).
+ROWSPARSE_MIN_NODES = 1 << 16      # below this a step is launch-bound and the extra check kernel costs more than the gather saves
 MIX_MAX = 7      # mixed-in gradients one cb_trunk_input_bwd_multi_f32 launch gathers (deeper trunks accumulate layer by layer)
 
 
@@ -439,6 +440,15 @@ class _TrunkFn(torch.autograd.Function):
             gr_, db_ = _layer_bwd(g_, saved_bits[below], bnorm, gx0, below != L - 1, p, sd, row0, 1 - alpha, alpha, want_b, out_bf16=agg_bf16)
             return g_, gr_, db_, None
 
+        # Row-sparse first aggregation: when the upstream gradient is the masked loss's own buffer, every row of gout outside the loss rows is
+        # zero — and so are those rows of dL/dX_L and of b * dY'_{L-1} (the head and the trunk store are row-wise).  The reverse aggregation
+        # of layer L-1 then gathers the loss rows only (CSRGraph.filtered_t: 10 % of the edges at the bench's 10 % train mask).  The claim is
+        # checked on the device (ops.check_rows_zero: a violation ends in the device error word).  One GPU, loss rows <= 40 % of the nodes.
+        rows_hint = ops.take_grad_rows(gout) if (not sharded and hasattr(graph, 'filtered_t') and graph.rowptr_t is not None) else None
+        sub_last = None
+        if rows_hint is not None and rows_hint[1] <= 0.4 * gout.shape[0] and gout.shape[0] >= ROWSPARSE_MIN_NODES:
+            ops.check_rows_zero(gout, rows_hint[0])
+            sub_last = graph.filtered_t(rows_hint[0])
         # dL/d(dropped X_L) and the backward of layer L-1's store
         g, gr, dbias, handle = dx_gemm(gout, w_out, None, L - 1)
         deferred = None        # (layer, X_l, dZ_l): weight gradient of the layer above, computed under this layer's halo exchange
@@ -469,14 +479,15 @@ class _TrunkFn(torch.autograd.Function):
                                                       transpose=tr, acc_init=acc)
                     return csr.spmm_gemm(src, img, transpose=tr, g_rowscale=a, acc_init=acc)
                 res = (graph.aggregate_finish(handle, True, last_pass=lambda csr, recv, acc: tail(csr, recv, acc, False)) if sharded
-                       else tail(graph, gr, None, True))
+                       else tail(sub_last, gr, None, False) if (l == L - 1 and sub_last is not None) else tail(graph, gr, None, True))
                 if use_tb:
                     gz, g_fused, gr_n, db_n = res
                     tb_fused = (gr_n, db_n)
                 else:
                     gz, g_fused = res
             else:
-                gz = graph.aggregate_finish(handle, True) if sharded else _spmm_t(graph, gr)  # dL/dZ_l = A (b * dY')
+                gz = (graph.aggregate_finish(handle, True) if sharded else sub_last.spmm(gr) if (l == L - 1 and sub_last is not None)
+                      else _spmm_t(graph, gr))  # dL/dZ_l = A (b * dY')
             del g, gr
             handle = None
             if need[7 + 3 * l]:

@@ -38,6 +38,7 @@ extern "C" {
 
 /* device-side error codes (first int of the device error word) */
 #define CB_DEVERR_HANDOVER 1 /* the LDS tile hand-over of the aggregation + GEMM kernel gave up its bounded wait */
+#define CB_DEVERR_GRADROWS 2 /* cb_rows_zero_outside_mask_f32 found a non-zero gradient row outside the loss rows */
 
 int cb_version(void);
 const char* cb_last_error(void);
@@ -48,6 +49,13 @@ const char* cb_last_error(void);
  * the word.  It does not synchronise — call it after the synchronisation that ends a step.  New relative to the reference (torch raises
  * on device faults by itself; GNN_model/GCN.py:238 + :225 are the work of those kernels). */
 int cb_device_status(void);
+
+/* Row-sparse backward (new; autograd of trainer_node_classification.py:390-391 `nll_loss(log_softmax(out[train_mask]))`): the gradient that
+ * enters the model is zero in every row outside the loss rows, and so is everything the head and the last trunk store make of it — the
+ * first reverse aggregation of the backward (autograd of GCN.py:238) then only has to gather the loss rows (graph.CSRGraph.filtered_t).
+ * This call verifies the claim on the device: any non-zero element of g [rows, d] in a row with mask[row] == 0 records
+ * CB_DEVERR_GRADROWS in the device error word (cb_device_status). */
+int cb_rows_zero_outside_mask_f32(const float* g, int64_t ld, int64_t rows, int64_t d, const uint8_t* mask, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Graph ingest — replaces `dgl.graph((src_list, dst_list))` built through Python lists
