@@ -150,7 +150,9 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
                                                       void* __restrict__ outv, float* __restrict__ gx0, int accumulate,
                                                       int64_t rows, int d, uint32_t thresh, float keep_scale, uint64_t seed,
                                                       const uint64_t* __restrict__ seed_dev, int64_t row0, float c_act, float c_mix,
-                                                      float* __restrict__ partial) {
+                                                      float* __restrict__ partial, const int64_t* __restrict__ ridx) {
+  // ridx (MODE 0, gx0 == NULL): g / out hold only the rows ridx[0 .. rows) of the matrix (the loss rows of a row-sparse backward); mask words,
+  // row scale and the dropout mask are those of row ridx[r]
   extern __shared__ float s_red[];  // [4 waves][256 cols] per tile pass
   if (seed_dev) seed += *seed_dev;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -163,12 +165,13 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (int64_t r = r_begin + w; r < r_end; r += kBlock / kWave) {
       const int64_t off = r * d + c;
+      const int64_t rr = ridx ? ridx[r] : r;      // the row of the full matrix this row is
       // g is read once (streaming)
       float gm[4] = {__builtin_nontemporal_load(g + off), __builtin_nontemporal_load(g + off + 1), __builtin_nontemporal_load(g + off + 2),
                      __builtin_nontemporal_load(g + off + 3)};
       if (thresh) {
         float m[4];
-        keep4(seed, ((row0 + r) * d + c) >> 2, thresh, keep_scale, m);
+        keep4(seed, ((row0 + rr) * d + c) >> 2, thresh, keep_scale, m);
 #pragma unroll
         for (int k = 0; k < 4; ++k) gm[k] *= m[k];
       }
@@ -179,7 +182,7 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
           a.x += c_mix * gm[0]; a.y += c_mix * gm[1]; a.z += c_mix * gm[2]; a.w += c_mix * gm[3];
           *reinterpret_cast<float4*>(gx0 + off) = a;
         }
-        const unsigned long long* bw = bits + (r * tiles + tile) * 4;
+        const unsigned long long* bw = bits + (rr * tiles + tile) * 4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) gy[k] = ((bw[k] >> lane) & 1ull) ? c_act * gm[k] : 0.f;
       } else {
@@ -190,7 +193,7 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
         gy[2] = x.z > 0.f ? a.z + gm[2] : 0.f;
         gy[3] = x.w > 0.f ? a.w + gm[3] : 0.f;
       }
-      const float sc = row_scale ? row_scale[r] : 1.f;
+      const float sc = row_scale ? row_scale[rr] : 1.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) s[k] += gy[k];
       if constexpr (!STORE) continue;
@@ -226,6 +229,7 @@ struct MixTable {
   const float* g[kMixMax];
   uint64_t seed[kMixMax];
   int n;
+  const int* pos0;      // null, or [rows]: g[0] holds only some rows (a row-sparse backward's loss rows) — row r sits at pos0[r], absent (zero) if < 0
 };
 
 template <int NMIX>   // number of mixed-in gradients, compile-time so that all row loads are issued before the first Philox round
@@ -250,11 +254,17 @@ __global__ void __launch_bounds__(kBlock) k_trunk_input_bwd_multi(const float* _
       float t[4] = {__builtin_nontemporal_load(g + off), __builtin_nontemporal_load(g + off + 1), __builtin_nontemporal_load(g + off + 2),
                     __builtin_nontemporal_load(g + off + 3)};
       float u[NMIX > 0 ? NMIX : 1][4];
+      int p0 = 0;      // (wave-uniform) position of row r in the compact operand 0, or < 0
+      if (NMIX > 0 && mt.pos0) p0 = __builtin_amdgcn_readfirstlane(mt.pos0[r]);
 #pragma unroll
       for (int l = 0; l < NMIX; ++l) {
-        const float* gl = mt.g[l] + off;
+        const float* gl = (l == 0 && mt.pos0) ? mt.g[0] + ((int64_t)max(p0, 0) * d + c) : mt.g[l] + off;
 #pragma unroll
         for (int k = 0; k < 4; ++k) u[l][k] = __builtin_nontemporal_load(gl + k);
+      }
+      if (NMIX > 0 && p0 < 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[0][k] = 0.f;
       }
       if (thresh) {
         float m[4];
@@ -264,7 +274,7 @@ __global__ void __launch_bounds__(kBlock) k_trunk_input_bwd_multi(const float* _
       }
 #pragma unroll
       for (int l = 0; l < NMIX; ++l) {
-        if (thresh) {
+        if (thresh && !(l == 0 && p0 < 0)) {      // (an absent row of the compact operand is zero whatever its mask)
           float m[4];
           keep4(mt.seed[l] + sd, quad, thresh, keep_scale, m);
 #pragma unroll
@@ -795,13 +805,13 @@ extern "C" int cb_adam_multi_f32(int32_t n_tensors, float* const* p, const float
 static int launch_trunk_bwd(int mode, int out_bf16, const float* g, const uint64_t* bits, const float* act, const float* row_scale,
                             void* out, float* gx0, int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed,
                             const uint64_t* seed_dev, int64_t row0, float c_act, float c_mix, float* colsum, void* ws, size_t ws_bytes,
-                            hipStream_t st) {
+                            hipStream_t st, const int64_t* ridx = nullptr) {
   int64_t nb = (rows + 63) / 64;
   if (nb > kMaxBlocks) nb = kMaxBlocks;
   const uint32_t thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
   const float ks = 1.f / (1.f - drop_p);
   float* partial = colsum ? (float*)ws : nullptr;
-#define CB_TB_ARGS g, (const unsigned long long*)bits, act, row_scale, out, gx0, accumulate, rows, (int)d, thresh, ks, seed, seed_dev, row0, c_act, c_mix, partial
+#define CB_TB_ARGS g, (const unsigned long long*)bits, act, row_scale, out, gx0, accumulate, rows, (int)d, thresh, ks, seed, seed_dev, row0, c_act, c_mix, partial, ridx
   const dim3 grid((unsigned)nb), blk(kBlock);
   const size_t sh = kBlock * 4 * sizeof(float);
   if (mode == 0 && !out) hipLaunchKernelGGL((k_trunk_bwd<0, false, false>), grid, blk, sh, st, CB_TB_ARGS);
@@ -831,6 +841,24 @@ extern "C" int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits,
                           colsum, ws, ws_bytes, (hipStream_t)stream);
 }
 
+// cb_trunk_layer_bwd_f32 over a SUBSET of the rows: g and out are compact [n_rows, d] matrices holding rows row_index[0 .. n_rows) of the full
+// ones (ascending global row ids); relu_bits / row_scale are the full arrays, the dropout mask is drawn at the global row.  colsum = the
+// column sums over the subset (all other rows of a row-sparse backward are zero).
+extern "C" int cb_trunk_layer_bwd_rows_f32(const float* g, const int64_t* row_index, int64_t n_rows, const uint64_t* relu_bits, const float* row_scale,
+                                           float* out, int64_t d, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, float c_act,
+                                           float* colsum, void* ws, size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(n_rows >= 0 && d > 0 && d % 256 == 0 && d < (1 << 20), CB_E_INVALID, "cb_trunk_layer_bwd_rows_f32: d must be a multiple of 256");
+  if (n_rows == 0) {
+    if (colsum) CB_HIP(hipMemsetAsync(colsum, 0, (size_t)d * sizeof(float), (hipStream_t)stream));
+    return CB_OK;
+  }
+  CB_CHECK_ARG(g && row_index && relu_bits && out && aligned16(g) && aligned16(out), CB_E_INVALID, "cb_trunk_layer_bwd_rows_f32: null or misaligned pointer");
+  CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, CB_E_INVALID, "cb_trunk_layer_bwd_rows_f32: dropout p out of range");
+  CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_colsum_workspace_bytes(n_rows, d)), CB_E_WORKSPACE, "cb_trunk_layer_bwd_rows_f32: workspace too small");
+  return launch_trunk_bwd(0, 0, g, relu_bits, nullptr, row_scale, out, nullptr, 0, n_rows, d, drop_p, seed, seed_dev, row0, c_act, 0.f, colsum, ws, ws_bytes,
+                          (hipStream_t)stream, row_index);
+}
+
 extern "C" int cb_trunk_input_bwd_f32(const float* g, const float* add, const float* act, float* out, int64_t rows, int64_t d,
                                       float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws,
                                       size_t ws_bytes, void* stream) {
@@ -847,7 +875,7 @@ extern "C" int cb_trunk_input_bwd_f32(const float* g, const float* add, const fl
 extern "C" int cb_trunk_input_bwd_multi_f32(const float* g, uint64_t seed, int32_t n_mix, const float* const* g_mix, const uint64_t* seeds_mix,
                                             float c_mix, const float* act, float* out, int64_t rows, int64_t d, float drop_p,
                                             const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes,
-                                            const uint64_t* act_bits, void* stream) {
+                                            const uint64_t* act_bits, const int32_t* g_mix0_pos, void* stream) {
   CB_CHECK_ARG(rows >= 0 && d > 0 && d % 256 == 0 && d < (1 << 20), CB_E_INVALID, "cb_trunk_input_bwd_multi_f32: d must be a multiple of 256");
   CB_CHECK_ARG(n_mix >= 0 && n_mix <= kMixMax && (n_mix == 0 || (g_mix && seeds_mix)), CB_E_INVALID,
                "cb_trunk_input_bwd_multi_f32: 0..%d mixed-in gradients", kMixMax);
@@ -856,8 +884,10 @@ extern "C" int cb_trunk_input_bwd_multi_f32(const float* g, uint64_t seed, int32
                CB_E_INVALID, "cb_trunk_input_bwd_multi_f32: null or misaligned pointer");
   CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, CB_E_INVALID, "cb_trunk_input_bwd_multi_f32: dropout p out of range");
   CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_colsum_workspace_bytes(rows, d)), CB_E_WORKSPACE, "cb_trunk_input_bwd_multi_f32: workspace too small");
+  CB_CHECK_ARG(!g_mix0_pos || n_mix >= 1, CB_E_INVALID, "cb_trunk_input_bwd_multi_f32: g_mix0_pos without a mixed-in gradient");
   MixTable mt{};
   mt.n = n_mix;
+  mt.pos0 = g_mix0_pos;
   for (int i = 0; i < n_mix; ++i) {
     CB_CHECK_ARG(g_mix[i] && aligned16(g_mix[i]), CB_E_INVALID, "cb_trunk_input_bwd_multi_f32: null or misaligned mixed-in gradient %d", i);
     mt.g[i] = g_mix[i];

@@ -143,6 +143,13 @@ class CSRGraph:
         del kept, csum
         sub = CSRGraph.from_csr(rp_new, col_new, self.n_cols, hub_threshold=self.hub_threshold)
         sub.norm_in, sub.norm_out = getattr(self, 'norm_in', None), getattr(self, 'norm_out', None)
+        # the kept rows as a COMPACT matrix: their ids (ascending), every row's position among them (-1: not kept), and the same orientation
+        # with the column ids renumbered to those positions — a backward that carries only the kept rows gathers from [n_kept, d] matrices
+        sub.rows_idx = torch.nonzero(keep).flatten()
+        pos = torch.cumsum(keep, 0, dtype=torch.int32) - 1
+        sub.row_pos = torch.where(keep, pos, torch.full_like(pos, -1))
+        sub.compact = CSRGraph.from_csr(rp_new, torch.index_select(pos, 0, col_new), int(sub.rows_idx.numel()), hub_threshold=self.hub_threshold)
+        sub.compact.norm_in, sub.compact.norm_out = sub.norm_in, sub.norm_out
         self._filtered_key, self._filtered = key, sub
         return sub
 

@@ -179,6 +179,21 @@ def _layer_bwd(g, bits, row_scale, gx0, accumulate, p, seed, row0, c_act, c_mix,
     return out, colsum
 
 
+def _layer_bwd_rows(g_c, rows_idx, bits, row_scale, p, seed, row0, c_act, want_colsum):
+    """_layer_bwd over the compact rows rows_idx of a row-sparse backward (cb_trunk_layer_bwd_rows_f32): (b * dY' of those rows, dbias)."""
+    lib = _lib.load()
+    n_c, d = g_c.shape
+    out = torch.empty_like(g_c)
+    colsum = torch.empty(d, dtype=torch.float32, device=g_c.device) if want_colsum else None
+    wsb = lib.cb_colsum_workspace_bytes(n_c, d) if want_colsum else 0
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=g_c.device)
+    with torch.cuda.device(g_c.device):
+        _lib.check(lib.cb_trunk_layer_bwd_rows_f32(_lib.ptr(g_c), _lib.ptr(rows_idx), n_c, _lib.ptr(bits), _lib.ptr(row_scale), _lib.ptr(out), d, float(p),
+                                                   ctypes.c_uint64(seed), ops.seed_dev_ptr(), int(row0), float(c_act), _lib.ptr(colsum), _lib.ptr(ws), wsb,
+                                                   _lib.stream_ptr()), 'cb_trunk_layer_bwd_rows_f32')
+    return out, colsum
+
+
 def _input_bwd(g, add, act, p, seed, row0):
     lib = _lib.load()
     rows, d = g.shape
@@ -193,9 +208,10 @@ def _input_bwd(g, add, act, p, seed, row0):
     return out, colsum
 
 
-def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0, act_bits=None):
+def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0, act_bits=None, mix0_pos=None):
     """cb_trunk_input_bwd_multi_f32: (dropout_bwd(g) + c_mix * sum_l dropout_bwd_l(g_mix[l])) * (act > 0) and its column sums.
-    act_bits: int64 [rows, d/256, 4] mask words of (act > 0), read instead of act."""
+    act_bits: int64 [rows, d/256, 4] mask words of (act > 0), read instead of act.  mix0_pos (int32 [rows]): g_mix[0] is a compact matrix
+    of the rows with mix0_pos >= 0 (the loss rows of a row-sparse backward), all its other rows are zero."""
     lib = _lib.load()
     rows, d = g.shape
     out = torch.empty_like(g)
@@ -208,7 +224,7 @@ def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0, act_bits=No
     with torch.cuda.device(g.device):
         _lib.check(lib.cb_trunk_input_bwd_multi_f32(_lib.ptr(g), ctypes.c_uint64(seed), n, ptrs, seeds, float(c_mix), _lib.ptr(None if act_bits is not None else act), _lib.ptr(out),
                                                     rows, d, float(p), ops.seed_dev_ptr(), int(row0), _lib.ptr(colsum), _lib.ptr(ws), wsb,
-                                                    _lib.ptr(act_bits), _lib.stream_ptr()), 'cb_trunk_input_bwd_multi_f32')
+                                                    _lib.ptr(act_bits), _lib.ptr(mix0_pos), _lib.stream_ptr()), 'cb_trunk_input_bwd_multi_f32')
     return out, colsum
 
 
@@ -388,10 +404,7 @@ class _TrunkFn(torch.autograd.Function):
         need = ctx.needs_input_grad       # (graph, cfg, x, w_in, b_in, w_out, b_out, *layer_params)
         gout = gemm._rowmajor(gout)
         h = x0.shape[1]
-        # output Linear (GCN.py:138)
         xl = saved_in[L]
-        d_w_out = gemm.mm_tn(gout, xl) if need[5] else None
-        d_b_out = ops.act_bwd(gout, None, None, want_out=False, want_colsum=True)[1] if need[6] else None
         # the gradient reaching X0 through the L mixes: gathered in one pass by the input stage (the per-layer gradients stay
         # alive until then) when L <= MIX_MAX, else accumulated in place layer by layer
         gather = L <= MIX_MAX and _gather_fits(L, x0, graph)
@@ -445,12 +458,30 @@ class _TrunkFn(torch.autograd.Function):
         # of layer L-1 then gathers the loss rows only (CSRGraph.filtered_t: 10 % of the edges at the bench's 10 % train mask).  The claim is
         # checked on the device (ops.check_rows_zero: a violation ends in the device error word).  One GPU, loss rows <= 40 % of the nodes.
         rows_hint = ops.take_grad_rows(gout) if (not sharded and hasattr(graph, 'filtered_t') and graph.rowptr_t is not None) else None
+        # With the per-layer gradients gathered by the input stage (`gather`) the head and layer L-1's store backward run on the loss rows
+        # alone too: compact [n_loss, .] matrices, the aggregation gathers from them through the renumbered orientation, and the input stage
+        # takes dL/dX_L as a compact operand — nothing of the other 90 % of the rows is computed, written or read.
         sub_last = None
         if rows_hint is not None and rows_hint[1] <= 0.4 * gout.shape[0] and gout.shape[0] >= ROWSPARSE_MIN_NODES:
             ops.check_rows_zero(gout, rows_hint[0])
             sub_last = graph.filtered_t(rows_hint[0])
-        # dL/d(dropped X_L) and the backward of layer L-1's store
-        g, gr, dbias, handle = dx_gemm(gout, w_out, None, L - 1)
+        compact = sub_last is not None and gather and ag_bwd and not tail_tb and not agg_bf16 and os.environ.get('CB_LOSS_ROWS_COMPACT', '1') != '0'
+        mix0_pos = None
+        if compact:
+            idx = sub_last.rows_idx
+            gout_c, xl_c = ops.gather_rows_by_index(gout, idx), ops.gather_rows_by_index(xl, idx)
+            d_w_out = gemm.mm_tn(gout_c, xl_c) if need[5] else None              # output Linear (GCN.py:138)
+            d_b_out = ops.act_bwd(gout_c, None, None, want_out=False, want_colsum=True)[1] if need[6] else None
+            g = gemm.mm_nn(gout_c, w_out)                                        # dL/d(dropped X_L), loss rows only
+            gr, dbias = _layer_bwd_rows(g, idx, saved_bits[L - 1], bnorm, p, seeds[L + 1] if p > 0 else 0, row0, 1 - alpha, need[7 + 3 * (L - 1) + 1])
+            handle, mix0_pos = None, sub_last.row_pos
+            sub_last = sub_last.compact
+            del gout_c, xl_c
+        else:
+            d_w_out = gemm.mm_tn(gout, xl) if need[5] else None                  # output Linear (GCN.py:138)
+            d_b_out = ops.act_bwd(gout, None, None, want_out=False, want_colsum=True)[1] if need[6] else None
+            # dL/d(dropped X_L) and the backward of layer L-1's store
+            g, gr, dbias, handle = dx_gemm(gout, w_out, None, L - 1)
         deferred = None        # (layer, X_l, dZ_l): weight gradient of the layer above, computed under this layer's halo exchange
         for l in range(L - 1, -1, -1):
             w, b, le = lp[l]
@@ -511,7 +542,7 @@ class _TrunkFn(torch.autograd.Function):
             deferred = None
         # input stage: X0 feeds layer 0 (through its dropout) and every mix
         if gather:
-            gpre, d_b_in = _input_bwd_multi(g, seeds[1] if p > 0 else 0, g_mix, seeds_mix, alpha, x0, p, row0, act_bits=x0_bits)
+            gpre, d_b_in = _input_bwd_multi(g, seeds[1] if p > 0 else 0, g_mix, seeds_mix, alpha, x0, p, row0, act_bits=x0_bits, mix0_pos=mix0_pos)
         else:
             gpre, d_b_in = _input_bwd(g, gx0, x0, p, seeds[1] if p > 0 else 0, row0)
         del g, gx0, g_mix

@@ -250,6 +250,11 @@ int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits, const floa
                            int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed, const uint64_t* seed_dev,
                            int64_t row0, float c_act, float c_mix, float* colsum, void* ws, size_t ws_bytes, void* stream);
 /* (out_bf16 != 0: `out` is a bf16 [rows, d] matrix — gradient rows stored in bf16 for the bf16 aggregation variant.) */
+/* The same over a SUBSET of the rows (row-sparse backward: the loss rows): g / out are compact [n_rows, d] matrices holding rows
+ * row_index[0 .. n_rows) (ascending) of the full ones; relu_bits / row_scale are the full arrays; the dropout mask is the global row's. */
+int cb_trunk_layer_bwd_rows_f32(const float* g, const int64_t* row_index, int64_t n_rows, const uint64_t* relu_bits, const float* row_scale, float* out,
+                                int64_t d, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, float c_act, float* colsum, void* ws,
+                                size_t ws_bytes, void* stream);
 
 /* Backward into the trunk's input stage X0 = relu(Linear(dropout(x))) (GCN.py:104-107,110):
  *     out = (add + dropout_bwd(g)) * (act > 0);  colsum = sum_rows out  (bias gradient of the input Linear). */
@@ -261,11 +266,13 @@ int cb_trunk_input_bwd_f32(const float* g, const float* add, const float* act, f
  *     out = ( dropout_bwd_seed(g) + c_mix * sum_{l < n_mix} dropout_bwd_seeds_mix[l](g_mix[l]) ) * (act > 0)
  * g_mix[l] = gradient w.r.t. the output of layer l's fused store (host array of n_mix <= 7 device pointers); used with
  * cb_trunk_layer_bwd_f32(gx0 = NULL).  Autograd of GCN.py:104-110 + res_tricks.py:23 for every layer at once.
- * act_bits (may be NULL): [rows][d / 256][4] mask words of (act > 0) used instead of act (act may then be NULL). */
+ * act_bits (may be NULL): [rows][d / 256][4] mask words of (act > 0) used instead of act (act may then be NULL).
+ * g_mix0_pos (may be NULL): int32 [rows]; g_mix[0] is then a COMPACT matrix that holds only some rows (the loss rows of a row-sparse
+ * backward) — row r at position g_mix0_pos[r], absent (= zero) where that is negative. */
 int cb_trunk_input_bwd_multi_f32(const float* g, uint64_t seed, int32_t n_mix, const float* const* g_mix, const uint64_t* seeds_mix,
                                  float c_mix, const float* act, float* out, int64_t rows, int64_t d, float drop_p,
                                  const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes,
-                                 const uint64_t* act_bits, void* stream);
+                                 const uint64_t* act_bits, const int32_t* g_mix0_pos, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * bf16-storage variant of the aggregation (build extension = BASELINE config 2; the reference is fp32-only):

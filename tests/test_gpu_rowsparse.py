@@ -42,7 +42,11 @@ def _step_grads(flag, dataset='S-pl1M'):
             os.environ['CB_LOSS_ROWS'] = old
 
 
-def test_row_sparse_backward_equals_the_dense_backward():
+@pytest.mark.parametrize('compact', ['1', '0'])
+def test_row_sparse_backward_equals_the_dense_backward(compact, monkeypatch):
+    """compact = 1: head, store backward, aggregation source and the input stage's operand on the loss rows alone ([n_loss, .] matrices);
+    compact = 0: dense rows, only the aggregation's gather is restricted."""
+    monkeypatch.setenv('CB_LOSS_ROWS_COMPACT', compact)
     loss_s, g_s, used_s = _step_grads('1')
     loss_d, g_d, used_d = _step_grads('0')
     assert used_s and not used_d                       # the 10 % train mask of the stand-in: the filtered orientation was built and used
