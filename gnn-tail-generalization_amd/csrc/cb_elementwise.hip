@@ -229,7 +229,8 @@ struct MixTable {
   const float* g[kMixMax];
   uint64_t seed[kMixMax];
   int n;
-  const int* pos0;      // null, or [rows]: g[0] holds only some rows (a row-sparse backward's loss rows) — row r sits at pos0[r], absent (zero) if < 0
+  const int* pos[kMixMax];      // null, or [rows]: g[l] is a COMPACT matrix that holds only some rows (a row-sparse backward's support rows) — row r
+                                // sits at pos[l][r], absent (zero) where that is negative
 };
 
 template <int NMIX>   // number of mixed-in gradients, compile-time so that all row loads are issued before the first Philox round
@@ -254,17 +255,21 @@ __global__ void __launch_bounds__(kBlock) k_trunk_input_bwd_multi(const float* _
       float t[4] = {__builtin_nontemporal_load(g + off), __builtin_nontemporal_load(g + off + 1), __builtin_nontemporal_load(g + off + 2),
                     __builtin_nontemporal_load(g + off + 3)};
       float u[NMIX > 0 ? NMIX : 1][4];
-      int p0 = 0;      // (wave-uniform) position of row r in the compact operand 0, or < 0
-      if (NMIX > 0 && mt.pos0) p0 = __builtin_amdgcn_readfirstlane(mt.pos0[r]);
+      int pl[NMIX > 0 ? NMIX : 1];      // (wave-uniform) position of row r in a compact operand, or < 0; 0 for a dense operand
+#pragma unroll
+      for (int l = 0; l < NMIX; ++l) pl[l] = mt.pos[l] ? __builtin_amdgcn_readfirstlane(mt.pos[l][r]) : 0;
 #pragma unroll
       for (int l = 0; l < NMIX; ++l) {
-        const float* gl = (l == 0 && mt.pos0) ? mt.g[0] + ((int64_t)max(p0, 0) * d + c) : mt.g[l] + off;
+        const float* gl = mt.pos[l] ? mt.g[l] + ((int64_t)max(pl[l], 0) * d + c) : mt.g[l] + off;
 #pragma unroll
         for (int k = 0; k < 4; ++k) u[l][k] = __builtin_nontemporal_load(gl + k);
       }
-      if (NMIX > 0 && p0 < 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) u[0][k] = 0.f;
+      for (int l = 0; l < NMIX; ++l) {
+        if (pl[l] < 0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) u[l][k] = 0.f;
+        }
       }
       if (thresh) {
         float m[4];
@@ -274,7 +279,7 @@ __global__ void __launch_bounds__(kBlock) k_trunk_input_bwd_multi(const float* _
       }
 #pragma unroll
       for (int l = 0; l < NMIX; ++l) {
-        if (thresh && !(l == 0 && p0 < 0)) {      // (an absent row of the compact operand is zero whatever its mask)
+        if (thresh && pl[l] >= 0) {      // (an absent row of a compact operand is zero whatever its mask)
           float m[4];
           keep4(mt.seed[l] + sd, quad, thresh, keep_scale, m);
 #pragma unroll
@@ -692,16 +697,24 @@ extern "C" int cb_act_bwd_f32(const float* g, const float* act, const float* row
   return CB_OK;
 }
 
-// Rows of g outside `mask` must be exactly zero (the claim a row-sparse backward rests on: ops.take_grad_rows / trunk.py).  Grid-stride over
-// the rows, one thread per row; a violation is recorded in the device error word (never silent: cb_device_status reports it).
+// Rows of g outside `mask` must be exactly zero (the claim a row-sparse backward rests on: ops.take_grad_rows / trunk.py).  A streaming pass
+// over the matrix (contiguous rows: float4 per thread, the row of an element by one division); a violation is recorded in the device error
+// word (never silent: cb_device_status reports it).
+template <bool VEC4>
 __global__ void __launch_bounds__(kBlock) k_rows_zero_check(const float* __restrict__ g, int64_t ld, int64_t rows, int d, const uint8_t* __restrict__ mask,
                                                             int* __restrict__ err) {
-  for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < rows; r += (int64_t)gridDim.x * kBlock) {
-    if (mask[r]) continue;
-    const float* p = g + r * ld;
-    bool bad = false;
-    for (int c = 0; c < d; ++c) bad |= p[c] != 0.f;
-    if (bad) {
+  const int64_t per_row = VEC4 ? d / 4 : d;
+  const int64_t n = rows * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t r = i / per_row, c = (i - r * per_row) * (VEC4 ? 4 : 1);
+    bool bad;
+    if constexpr (VEC4) {
+      const float4 v = *reinterpret_cast<const float4*>(g + r * ld + c);
+      bad = v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f;
+    } else {
+      bad = g[r * ld + c] != 0.f;
+    }
+    if (bad && !mask[r]) {
       __hip_atomic_store(err + 1, (int)(r & 0x7fffffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(err + 2, (int)(r >> 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(err, CB_DEVERR_GRADROWS, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -715,7 +728,10 @@ extern "C" int cb_rows_zero_outside_mask_f32(const float* g, int64_t ld, int64_t
   CB_CHECK_ARG(g && mask, CB_E_INVALID, "cb_rows_zero_outside_mask_f32: null pointer");
   int* err = device_error_word();
   CB_CHECK_ARG(err != nullptr, CB_E_HIP, "cb_rows_zero_outside_mask_f32: the device error word could not be allocated (%s)", cb_last_error());
-  hipLaunchKernelGGL(k_rows_zero_check, dim3((unsigned)grid_for(rows)), dim3(kBlock), 0, (hipStream_t)stream, g, ld, rows, (int)d, mask, err);
+  if (d % 4 == 0 && ld % 4 == 0 && aligned16(g))
+    hipLaunchKernelGGL((k_rows_zero_check<true>), dim3((unsigned)grid_for(rows * (d / 4))), dim3(kBlock), 0, (hipStream_t)stream, g, ld, rows, (int)d, mask, err);
+  else
+    hipLaunchKernelGGL((k_rows_zero_check<false>), dim3((unsigned)grid_for(rows * d)), dim3(kBlock), 0, (hipStream_t)stream, g, ld, rows, (int)d, mask, err);
   CB_LAUNCH_CHECK();
   return CB_OK;
 }
@@ -875,7 +891,7 @@ extern "C" int cb_trunk_input_bwd_f32(const float* g, const float* add, const fl
 extern "C" int cb_trunk_input_bwd_multi_f32(const float* g, uint64_t seed, int32_t n_mix, const float* const* g_mix, const uint64_t* seeds_mix,
                                             float c_mix, const float* act, float* out, int64_t rows, int64_t d, float drop_p,
                                             const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes,
-                                            const uint64_t* act_bits, const int32_t* g_mix0_pos, void* stream) {
+                                            const uint64_t* act_bits, const int32_t* const* g_mix_pos, void* stream) {
   CB_CHECK_ARG(rows >= 0 && d > 0 && d % 256 == 0 && d < (1 << 20), CB_E_INVALID, "cb_trunk_input_bwd_multi_f32: d must be a multiple of 256");
   CB_CHECK_ARG(n_mix >= 0 && n_mix <= kMixMax && (n_mix == 0 || (g_mix && seeds_mix)), CB_E_INVALID,
                "cb_trunk_input_bwd_multi_f32: 0..%d mixed-in gradients", kMixMax);
@@ -884,10 +900,9 @@ extern "C" int cb_trunk_input_bwd_multi_f32(const float* g, uint64_t seed, int32
                CB_E_INVALID, "cb_trunk_input_bwd_multi_f32: null or misaligned pointer");
   CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, CB_E_INVALID, "cb_trunk_input_bwd_multi_f32: dropout p out of range");
   CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_colsum_workspace_bytes(rows, d)), CB_E_WORKSPACE, "cb_trunk_input_bwd_multi_f32: workspace too small");
-  CB_CHECK_ARG(!g_mix0_pos || n_mix >= 1, CB_E_INVALID, "cb_trunk_input_bwd_multi_f32: g_mix0_pos without a mixed-in gradient");
   MixTable mt{};
   mt.n = n_mix;
-  mt.pos0 = g_mix0_pos;
+  for (int i = 0; i < n_mix; ++i) mt.pos[i] = g_mix_pos ? g_mix_pos[i] : nullptr;
   for (int i = 0; i < n_mix; ++i) {
     CB_CHECK_ARG(g_mix[i] && aligned16(g_mix[i]), CB_E_INVALID, "cb_trunk_input_bwd_multi_f32: null or misaligned mixed-in gradient %d", i);
     mt.g[i] = g_mix[i];

@@ -122,36 +122,54 @@ class CSRGraph:
         self._hot_cache[k] = (ck, ctk)
         return ck, ctk
 
-    def filtered_t(self, keep):
-        """The reverse (by-source) orientation restricted to the gathered rows with keep[row] set, as a graph of its own (same N destination
-        rows, global column ids; own hub plan and hot-source flags): what the first reverse aggregation of a backward needs when the
-        gradient rows of all other nodes are exact zeros (the masked loss, ops.take_grad_rows).  Sums over it equal the sums over the
-        full orientation up to the order in which a hub row's chunks are added.  Built once per mask (torch ops on the device) and cached."""
-        key = (keep.data_ptr(), keep._version, int(keep.shape[0]))
-        if getattr(self, '_filtered_key', None) == key:
-            return self._filtered
+    def grad_support_plan(self, keep, n_aggr, max_frac=0.6):
+        """Row supports of a backward whose incoming gradient is non-zero on the rows `keep` only (the masked loss: ops.take_grad_rows).
+        Reverse aggregation j (j = 0 for the last layer) gathers rows of the support S_j and produces non-zero rows exactly on
+        S_{j+1} = the rows with a (reverse-orientation) neighbour in S_j; supports are properties of the graph and the mask, not of the
+        values, so they are built once (torch ops on the device) and cached.  Returns RowSupportPlan with
+          .space0            the rows of S_0 as a compact space (ids ascending, position of every row or -1, row scale a restricted)
+          .levels[j]         (csr, dst): csr = the reverse orientation restricted to gathered rows in S_j with its column ids renumbered to
+                             positions in S_j; dst = the compact space of S_{j+1} when |S_{j+1}| <= max_frac * N (csr then has one row per
+                             member of S_{j+1}), else None (csr has all N rows, the output is an ordinary dense matrix and the plan ends).
+        At most n_aggr levels, and the last of them always has a dense destination (the stage below the first layer needs all rows).
+        max_frac = 0: one level, S_0 -> all rows.  Sums equal the full orientation's up to the order in which a hub row's chunks are added."""
+        key = (keep.data_ptr(), keep._version, int(keep.shape[0]), int(n_aggr), float(max_frac))
+        if getattr(self, '_support_key', None) == key:
+            return self._support_plan
         if self.rowptr_t is None:
             raise ValueError('this graph holds the forward orientation only')
-        if keep.dtype != torch.bool or keep.shape[0] != self.n_cols:
-            raise ValueError(f'filtered_t: bool mask over the {self.n_cols} source rows expected')
+        if keep.dtype != torch.bool or keep.shape[0] != self.n_cols or self.N != self.n_cols:
+            raise ValueError(f'grad_support_plan: bool mask over the {self.n_cols} rows of a square graph expected')
         rp, col = self.rowptr_t, self.col_t[:self.E]
-        kept = torch.index_select(keep, 0, col)
-        csum = torch.cumsum(kept, 0, dtype=torch.int32)
-        csum = torch.cat([csum.new_zeros(1), csum])
-        rp_new = torch.index_select(csum, 0, rp)
-        col_new = col[kept]
-        del kept, csum
-        sub = CSRGraph.from_csr(rp_new, col_new, self.n_cols, hub_threshold=self.hub_threshold)
-        sub.norm_in, sub.norm_out = getattr(self, 'norm_in', None), getattr(self, 'norm_out', None)
-        # the kept rows as a COMPACT matrix: their ids (ascending), every row's position among them (-1: not kept), and the same orientation
-        # with the column ids renumbered to those positions — a backward that carries only the kept rows gathers from [n_kept, d] matrices
-        sub.rows_idx = torch.nonzero(keep).flatten()
-        pos = torch.cumsum(keep, 0, dtype=torch.int32) - 1
-        sub.row_pos = torch.where(keep, pos, torch.full_like(pos, -1))
-        sub.compact = CSRGraph.from_csr(rp_new, torch.index_select(pos, 0, col_new), int(sub.rows_idx.numel()), hub_threshold=self.hub_threshold)
-        sub.compact.norm_in, sub.compact.norm_out = sub.norm_in, sub.norm_out
-        self._filtered_key, self._filtered = key, sub
-        return sub
+        a = getattr(self, 'norm_out', None)
+
+        def space_of(mask):
+            pos = torch.cumsum(mask, 0, dtype=torch.int32) - 1
+            idx = torch.nonzero(mask).flatten()
+            return RowSpace(idx, torch.where(mask, pos, torch.full_like(pos, -1)), a[idx].contiguous() if a is not None else None)
+        src_mask, src = keep, space_of(keep)
+        plan = RowSupportPlan(src, [])
+        while len(plan.levels) < n_aggr:
+            kept = torch.index_select(src_mask, 0, col)                   # edges whose gathered row is in the current support
+            csum = torch.cumsum(kept, 0, dtype=torch.int32)
+            csum = torch.cat([csum.new_zeros(1), csum])
+            rp_new = torch.index_select(csum, 0, rp)
+            col_new = torch.index_select(src.pos, 0, col[kept])
+            del kept, csum
+            cnt = rp_new[1:] - rp_new[:-1]
+            dst_mask = cnt > 0
+            n_dst = int(dst_mask.sum())
+            last = len(plan.levels) + 1 == n_aggr
+            if not last and n_dst <= max_frac * self.N:
+                dst = space_of(dst_mask)
+                rp_c = torch.cat([cnt.new_zeros(1), torch.cumsum(cnt[dst.idx], 0, dtype=torch.int32)])
+                plan.levels.append((CSRGraph.from_csr(rp_c, col_new, src.n, hub_threshold=self.hub_threshold), dst))
+                src_mask, src = dst_mask, dst
+            else:
+                plan.levels.append((CSRGraph.from_csr(rp_new, col_new, src.n, hub_threshold=self.hub_threshold), None))
+                break
+        self._support_key, self._support_plan = key, plan
+        return plan
 
     def flagged_cols(self, transpose, row_bytes):
         """Flagged column ids for source rows of `row_bytes` bytes (None: flags off / small graph)."""
@@ -588,6 +606,19 @@ class SegmentedCSRGraph:
             seg.spmm(h, row_scale=row_scale[r0:r1] if row_scale is not None else None, bias=bias, relu=relu, out=out[r0:r1],
                      acc_init=acc_init[r0:r1] if acc_init is not None else None)
         return out
+
+
+class RowSpace:
+    """A subset of the node rows as a compact index space: idx int64 [n] (ascending global row ids), pos int32 [N] (position of every row
+    in idx, -1 outside), a = norm_out restricted to the subset.  Matrices "over" the space are [n, d] and hold the rows idx."""
+
+    def __init__(self, idx, pos, a):
+        self.idx, self.pos, self.a, self.n = idx, pos, a, int(idx.numel())
+
+
+class RowSupportPlan:
+    def __init__(self, space0, levels):
+        self.space0, self.levels = space0, levels
 
 
 def build_graph(edge_index, num_nodes=None):

@@ -208,10 +208,10 @@ def _input_bwd(g, add, act, p, seed, row0):
     return out, colsum
 
 
-def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0, act_bits=None, mix0_pos=None):
+def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0, act_bits=None, mix_pos=None):
     """cb_trunk_input_bwd_multi_f32: (dropout_bwd(g) + c_mix * sum_l dropout_bwd_l(g_mix[l])) * (act > 0) and its column sums.
-    act_bits: int64 [rows, d/256, 4] mask words of (act > 0), read instead of act.  mix0_pos (int32 [rows]): g_mix[0] is a compact matrix
-    of the rows with mix0_pos >= 0 (the loss rows of a row-sparse backward), all its other rows are zero."""
+    act_bits: int64 [rows, d/256, 4] mask words of (act > 0), read instead of act.  mix_pos (list, entries None or int32 [rows]): where set,
+    g_mix[l] is a compact matrix of the rows with mix_pos[l] >= 0 (support rows of a row-sparse backward); its other rows are zero."""
     lib = _lib.load()
     rows, d = g.shape
     out = torch.empty_like(g)
@@ -221,10 +221,13 @@ def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0, act_bits=No
     n = len(g_mix)
     ptrs = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in g_mix])
     seeds = (ctypes.c_uint64 * max(n, 1))(*[int(s) for s in seeds_mix])
+    pos = None
+    if mix_pos is not None and any(q is not None for q in mix_pos):
+        pos = (ctypes.c_void_p * max(n, 1))(*[(q.data_ptr() if q is not None else None) for q in mix_pos])
     with torch.cuda.device(g.device):
         _lib.check(lib.cb_trunk_input_bwd_multi_f32(_lib.ptr(g), ctypes.c_uint64(seed), n, ptrs, seeds, float(c_mix), _lib.ptr(None if act_bits is not None else act), _lib.ptr(out),
                                                     rows, d, float(p), ops.seed_dev_ptr(), int(row0), _lib.ptr(colsum), _lib.ptr(ws), wsb,
-                                                    _lib.ptr(act_bits), _lib.ptr(mix0_pos), _lib.stream_ptr()), 'cb_trunk_input_bwd_multi_f32')
+                                                    _lib.ptr(act_bits), pos, _lib.stream_ptr()), 'cb_trunk_input_bwd_multi_f32')
     return out, colsum
 
 
@@ -240,6 +243,7 @@ def tail_trunk_bwd(graph):
 # The input Linear's GEMM writes the mask words of (X0 > 0) from its epilogue (a wavefront holds a whole 256-column row there: four ballots),
 # and the input stage of the backward reads those 32 bytes per row instead of X0's 1 KiB (one of its six 10 GB streams).
 ROWSPARSE_MIN_NODES = 1 << 16      # below this a step is launch-bound and the extra check kernel costs more than the gather saves
+ROWSPARSE_MAX_FRAC = 0.6           # a level's output stays compact while its support is at most this share of the rows
 MIX_MAX = 7      # mixed-in gradients one cb_trunk_input_bwd_multi_f32 launch gathers (deeper trunks accumulate layer by layer)
 
 
@@ -453,29 +457,31 @@ class _TrunkFn(torch.autograd.Function):
             gr_, db_ = _layer_bwd(g_, saved_bits[below], bnorm, gx0, below != L - 1, p, sd, row0, 1 - alpha, alpha, want_b, out_bf16=agg_bf16)
             return g_, gr_, db_, None
 
-        # Row-sparse first aggregation: when the upstream gradient is the masked loss's own buffer, every row of gout outside the loss rows is
-        # zero — and so are those rows of dL/dX_L and of b * dY'_{L-1} (the head and the trunk store are row-wise).  The reverse aggregation
-        # of layer L-1 then gathers the loss rows only (CSRGraph.filtered_t: 10 % of the edges at the bench's 10 % train mask).  The claim is
-        # checked on the device (ops.check_rows_zero: a violation ends in the device error word).  One GPU, loss rows <= 40 % of the nodes.
-        rows_hint = ops.take_grad_rows(gout) if (not sharded and hasattr(graph, 'filtered_t') and graph.rowptr_t is not None) else None
-        # With the per-layer gradients gathered by the input stage (`gather`) the head and layer L-1's store backward run on the loss rows
-        # alone too: compact [n_loss, .] matrices, the aggregation gathers from them through the renumbered orientation, and the input stage
-        # takes dL/dX_L as a compact operand — nothing of the other 90 % of the rows is computed, written or read.
-        sub_last = None
-        if rows_hint is not None and rows_hint[1] <= 0.4 * gout.shape[0] and gout.shape[0] >= ROWSPARSE_MIN_NODES:
+        # Row-sparse backward: when the upstream gradient is the masked loss's own buffer, every row of gout outside the loss rows is zero,
+        # and what the backward makes of it stays zero outside the rows the loss rows can reach: after the j-th reverse aggregation only the
+        # rows with a neighbour in the previous support carry gradient (CSRGraph.grad_support_plan: S_0 = loss rows, S_1, ... — 10 % / 45 % /
+        # 94 % of the rows on the bench's graph with its 10 % train mask).  The head, the store backward, the aggregation + dX kernels and
+        # the weight gradients of those levels run on compact [|S_j|, .] matrices (the aggregation through an orientation whose rows and
+        # columns are renumbered to positions in S_{j+1} and S_j), and the input stage takes the per-layer gradients as compact operands.
+        # The claim "rows outside the loss rows are zero" is checked on the device (ops.check_rows_zero: a violation ends in the device error
+        # word, never in silent wrong gradients).  One GPU, hidden 256, gathered per-layer gradients, loss rows <= 40 % of the nodes.
+        rows_hint = ops.take_grad_rows(gout) if (not sharded and hasattr(graph, 'grad_support_plan') and graph.rowptr_t is not None) else None
+        plan = None
+        if (rows_hint is not None and rows_hint[1] <= 0.4 * gout.shape[0] and gout.shape[0] >= ROWSPARSE_MIN_NODES and gather and ag_bwd
+                and not tail_tb and not agg_bf16):
             ops.check_rows_zero(gout, rows_hint[0])
-            sub_last = graph.filtered_t(rows_hint[0])
-        compact = sub_last is not None and gather and ag_bwd and not tail_tb and not agg_bf16 and os.environ.get('CB_LOSS_ROWS_COMPACT', '1') != '0'
-        mix0_pos = None
-        if compact:
-            idx = sub_last.rows_idx
-            gout_c, xl_c = ops.gather_rows_by_index(gout, idx), ops.gather_rows_by_index(xl, idx)
+            # (structural-embedding tables take dL/dZ_l as their gradient: all rows, so only the gathered side is compact then)
+            plan = graph.grad_support_plan(rows_hint[0], L, max_frac=0.0 if any(ctx.le_present) else ROWSPARSE_MAX_FRAC)
+        space = None                                                             # row space of g / gr (None: all rows)
+        mix_pos = []
+        if plan is not None:
+            space = plan.space0
+            gout_c, xl_c = ops.gather_rows_by_index(gout, space.idx), ops.gather_rows_by_index(xl, space.idx)
             d_w_out = gemm.mm_tn(gout_c, xl_c) if need[5] else None              # output Linear (GCN.py:138)
             d_b_out = ops.act_bwd(gout_c, None, None, want_out=False, want_colsum=True)[1] if need[6] else None
             g = gemm.mm_nn(gout_c, w_out)                                        # dL/d(dropped X_L), loss rows only
-            gr, dbias = _layer_bwd_rows(g, idx, saved_bits[L - 1], bnorm, p, seeds[L + 1] if p > 0 else 0, row0, 1 - alpha, need[7 + 3 * (L - 1) + 1])
-            handle, mix0_pos = None, sub_last.row_pos
-            sub_last = sub_last.compact
+            gr, dbias = _layer_bwd_rows(g, space.idx, saved_bits[L - 1], bnorm, p, seeds[L + 1] if p > 0 else 0, row0, 1 - alpha, need[7 + 3 * (L - 1) + 1])
+            handle = None
             del gout_c, xl_c
         else:
             d_w_out = gemm.mm_tn(gout, xl) if need[5] else None                  # output Linear (GCN.py:138)
@@ -487,7 +493,10 @@ class _TrunkFn(torch.autograd.Function):
             w, b, le = lp[l]
             if gather:
                 g_mix.append(g)
+                mix_pos.append(space.pos if space is not None else None)
                 seeds_mix.append(seeds[l + 2] if p > 0 else 0)
+            level = plan.levels[L - 1 - l] if (plan is not None and L - 1 - l < len(plan.levels)) else None
+            dst = level[1] if level is not None else None
             if sharded and handle is None:
                 handle = graph.aggregate_start(gr, True)                        # node-sharded: the exchange is in flight from here
             if deferred is not None:
@@ -509,25 +518,34 @@ class _TrunkFn(torch.autograd.Function):
                         return csr.spmm_gemm_trunkbwd(src, img, a, saved_bits[l - 1], 1 - alpha, p, sd_b, row0, bnorm, need[7 + 3 * (l - 1) + 1],
                                                       transpose=tr, acc_init=acc)
                     return csr.spmm_gemm(src, img, transpose=tr, g_rowscale=a, acc_init=acc)
-                res = (graph.aggregate_finish(handle, True, last_pass=lambda csr, recv, acc: tail(csr, recv, acc, False)) if sharded
-                       else tail(sub_last, gr, None, False) if (l == L - 1 and sub_last is not None) else tail(graph, gr, None, True))
+                if level is not None:      # compact source (and destination): the level's own orientation, row scale restricted to its rows
+                    level[0].profile = getattr(graph, 'profile', None)
+                    res = level[0].spmm_gemm(gr, img, transpose=False, g_rowscale=dst.a if dst is not None else a)
+                else:
+                    res = (graph.aggregate_finish(handle, True, last_pass=lambda csr, recv, acc: tail(csr, recv, acc, False)) if sharded
+                           else tail(graph, gr, None, True))
                 if use_tb:
                     gz, g_fused, gr_n, db_n = res
                     tb_fused = (gr_n, db_n)
                 else:
                     gz, g_fused = res
             else:
-                gz = (graph.aggregate_finish(handle, True) if sharded else sub_last.spmm(gr) if (l == L - 1 and sub_last is not None)
-                      else _spmm_t(graph, gr))  # dL/dZ_l = A (b * dY')
+                gz = graph.aggregate_finish(handle, True) if sharded else _spmm_t(graph, gr)  # dL/dZ_l = A (b * dY')
             del g, gr
             handle = None
             if need[7 + 3 * l]:
                 if sharded:
                     deferred = (l, saved_in[l], gz)
+                elif dst is not None:      # dL/dZ_l lives on S_{j+1}: X_l^T (a * dZ_l) over those rows (all others contribute zeros)
+                    grads_layers[3 * l] = gemm.mm_tn(ops.gather_rows_by_index(saved_in[l], dst.idx), gz, rowscale=dst.a)
                 else:
                     grads_layers[3 * l] = dw_layer(l, saved_in[l], gz)
             grads_layers[3 * l + 1] = dbias
-            if l > 0 and tb_fused is not None:
+            space = dst
+            if l > 0 and dst is not None:      # the store backward of layer l-1 on the rows of S_{j+1}
+                g = g_fused
+                gr, dbias = _layer_bwd_rows(g, dst.idx, saved_bits[l - 1], bnorm, p, seeds[l + 1] if p > 0 else 0, row0, 1 - alpha, need[7 + 3 * (l - 1) + 1])
+            elif l > 0 and tb_fused is not None:
                 g, (gr, dbias) = g_fused, tb_fused
             elif l > 0:
                 g, gr, dbias, handle = dx_gemm(gz, w.t().contiguous(), a, l - 1, g_fused)   # dL/d(dropped X_l) and the backward of layer l-1's store
@@ -542,7 +560,7 @@ class _TrunkFn(torch.autograd.Function):
             deferred = None
         # input stage: X0 feeds layer 0 (through its dropout) and every mix
         if gather:
-            gpre, d_b_in = _input_bwd_multi(g, seeds[1] if p > 0 else 0, g_mix, seeds_mix, alpha, x0, p, row0, act_bits=x0_bits, mix0_pos=mix0_pos)
+            gpre, d_b_in = _input_bwd_multi(g, seeds[1] if p > 0 else 0, g_mix, seeds_mix, alpha, x0, p, row0, act_bits=x0_bits, mix_pos=mix_pos)
         else:
             gpre, d_b_in = _input_bwd(g, gx0, x0, p, seeds[1] if p > 0 else 0, row0)
         del g, gx0, g_mix

@@ -267,12 +267,13 @@ int cb_trunk_input_bwd_f32(const float* g, const float* add, const float* act, f
  * g_mix[l] = gradient w.r.t. the output of layer l's fused store (host array of n_mix <= 7 device pointers); used with
  * cb_trunk_layer_bwd_f32(gx0 = NULL).  Autograd of GCN.py:104-110 + res_tricks.py:23 for every layer at once.
  * act_bits (may be NULL): [rows][d / 256][4] mask words of (act > 0) used instead of act (act may then be NULL).
- * g_mix0_pos (may be NULL): int32 [rows]; g_mix[0] is then a COMPACT matrix that holds only some rows (the loss rows of a row-sparse
- * backward) — row r at position g_mix0_pos[r], absent (= zero) where that is negative. */
+ * g_mix_pos (may be NULL): host array of n_mix device pointers (entries may be NULL); where g_mix_pos[l] is set (int32 [rows]), g_mix[l] is a
+ * COMPACT matrix that holds only some rows (the support rows of a row-sparse backward) — row r at position g_mix_pos[l][r], absent (= zero)
+ * where that is negative. */
 int cb_trunk_input_bwd_multi_f32(const float* g, uint64_t seed, int32_t n_mix, const float* const* g_mix, const uint64_t* seeds_mix,
                                  float c_mix, const float* act, float* out, int64_t rows, int64_t d, float drop_p,
                                  const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes,
-                                 const uint64_t* act_bits, const int32_t* g_mix0_pos, void* stream);
+                                 const uint64_t* act_bits, const int32_t* const* g_mix_pos, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * bf16-storage variant of the aggregation (build extension = BASELINE config 2; the reference is fp32-only):

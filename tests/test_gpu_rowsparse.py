@@ -1,7 +1,8 @@
-"""GPU: the row-sparse first reverse aggregation of the backward (trunk.py, CSRGraph.filtered_t, ops.take_grad_rows / check_rows_zero).
-The masked loss of trainer_node_classification.py:390-391 has a gradient that is zero in every row outside the train rows; the backward
-of the last trunk layer gathers the train rows only.  Gradients equal the dense backward's up to the order in which a hub row's chunks are
-summed, the claim is verified on the device, and a violation is reported instead of training on."""
+"""GPU: the row-sparse backward (trunk.py, CSRGraph.grad_support_plan, ops.take_grad_rows / check_rows_zero).
+The masked loss of trainer_node_classification.py:390-391 has a gradient that is zero in every row outside the train rows, and the
+backward keeps it zero outside the rows those can reach; the levels of the backward whose support is small run on compact matrices.
+Gradients equal the dense backward's up to the order in which sums are associated, the claim is verified on the device, and a violation
+is reported instead of training on."""
 import contextlib
 import io
 import os
@@ -32,7 +33,7 @@ def _step_grads(flag, dataset='S-pl1M'):
         ops._seed_override[:] = []
         torch.cuda.synchronize()
         assert _lib.load().cb_device_status() == 0
-        used = getattr(t.graph(), '_filtered', None) is not None
+        used = getattr(t.graph(), '_support_plan', None) is not None
         return float(loss.detach()), {k: p.grad.detach().clone() for k, p in t.teacherGNN.named_parameters() if p.grad is not None}, used
     finally:
         ops._seed_override[:] = []
@@ -42,43 +43,59 @@ def _step_grads(flag, dataset='S-pl1M'):
             os.environ['CB_LOSS_ROWS'] = old
 
 
-@pytest.mark.parametrize('compact', ['1', '0'])
-def test_row_sparse_backward_equals_the_dense_backward(compact, monkeypatch):
-    """compact = 1: head, store backward, aggregation source and the input stage's operand on the loss rows alone ([n_loss, .] matrices);
-    compact = 0: dense rows, only the aggregation's gather is restricted."""
-    monkeypatch.setenv('CB_LOSS_ROWS_COMPACT', compact)
+@pytest.mark.parametrize('max_frac', [0.6, 0.0])
+def test_row_sparse_backward_equals_the_dense_backward(max_frac, monkeypatch):
+    """max_frac 0.6: the supports S_0 (10 % of the rows) and S_1 (45 %) compact, from S_2 (94 %) on dense; 0: only the gathered side of the
+    first aggregation compact."""
+    from gnn_tail_generalization_amd import trunk
+    monkeypatch.setattr(trunk, 'ROWSPARSE_MAX_FRAC', max_frac)
     loss_s, g_s, used_s = _step_grads('1')
     loss_d, g_d, used_d = _step_grads('0')
-    assert used_s and not used_d                       # the 10 % train mask of the stand-in: the filtered orientation was built and used
+    assert used_s and not used_d                       # the 10 % train mask of the stand-in: the plan was built and used
     assert loss_s == loss_d
     assert set(g_s) == set(g_d)
     for k in g_d:
         scale = float(g_d[k].abs().max())
-        # same addends; only the association of a hub row's chunk sums differs (fp32 rounding of 10^2-term sums)
-        assert float((g_s[k] - g_d[k]).abs().max()) <= 2e-6 * scale, k
+        # same addends; the association of sums differs (hub chunks, the slabs of the weight-gradient reductions)
+        assert float((g_s[k] - g_d[k]).abs().max()) <= 5e-6 * scale, k
 
 
-def test_filtered_orientation_is_the_reverse_graph_restricted_to_the_kept_rows():
+def test_support_plan_levels_are_the_reverse_graph_restricted_and_renumbered():
     from gnn_tail_generalization_amd.data import synthetic_data
     from gnn_tail_generalization_amd.graph import CSRGraph
     data = synthetic_data('S-pl1M', seed=0, device=DEV, n_override=70000)
     G = CSRGraph(data.edge_index, data.x.shape[0])
     keep = data.train_mask
-    sub = G.filtered_t(keep)
-    assert sub is G.filtered_t(keep)                    # cached per mask
+    plan = G.grad_support_plan(keep, 3, max_frac=0.6)
+    assert plan is G.grad_support_plan(keep, 3, max_frac=0.6)                    # cached per mask
     rp, col = G.rowptr_t.long(), G.col_t[:G.E].long()
     rows = torch.repeat_interleave(torch.arange(G.N, device=DEV), rp[1:] - rp[:-1])
-    m = keep[col]
-    assert torch.equal(sub.col[:sub.E].long(), col[m])
-    assert torch.equal(sub.rowptr.long(), torch.cat([rows.new_zeros(1), torch.cumsum(torch.bincount(rows[m], minlength=G.N), 0)]))
-    # sums over it == sums of the full orientation over a matrix that is zero outside the kept rows: bit for bit where no hub chunking
-    # is involved, to fp32 rounding of the chunk sums on hub rows
-    h = torch.randn(G.N, 256, device=DEV) * keep.float().unsqueeze(1)
-    full, part = G.spmm(h, transpose=True), sub.spmm(h)
-    deg = (rp[1:] - rp[:-1])
-    small = deg <= G.hub_threshold
-    assert torch.equal(part[small], full[small])
-    assert float((part - full).abs().max()) <= 2e-6 * float(full.abs().max())
+    assert torch.equal(plan.space0.idx, keep.nonzero().flatten())
+    assert plan.levels[-1][1] is None and len(plan.levels) <= 3                   # the plan ends with a dense destination
+    src_mask, src, h_full = keep, plan.space0, None
+    h_full = torch.randn(G.N, 256, device=DEV) * keep.float().unsqueeze(1)       # a matrix supported on S_0
+    h_c = h_full[src.idx].contiguous()
+    for csr, dst in plan.levels:
+        m = src_mask[col]
+        want_mask = torch.zeros(G.N, dtype=torch.bool, device=DEV)
+        want_mask[rows[m]] = True
+        full = G.spmm(h_full, transpose=True)                                     # the dense orientation on the zero-padded matrix
+        part = csr.spmm(h_c)
+        if dst is None:
+            assert csr.N == G.N
+            got = part
+        else:
+            assert torch.equal(dst.idx, want_mask.nonzero().flatten()) and csr.N == dst.n
+            assert bool((dst.pos[dst.idx] == torch.arange(dst.n, device=DEV, dtype=torch.int32)).all()) and int((dst.pos < 0).sum()) == G.N - dst.n
+            assert bool((full[~want_mask] == 0).all())                            # nothing outside the support
+            got = torch.zeros_like(full)
+            got[dst.idx] = part
+        assert float((got - full).abs().max()) <= 2e-6 * float(full.abs().max())
+        if dst is None:
+            break
+        src_mask, src = want_mask, dst
+        h_full = full
+        h_c = part
 
 
 def test_violated_claim_is_reported_not_silent():
