@@ -555,8 +555,10 @@ def main():
                               if fam_main is fam_tail else 'dominant kernel = the plain aggregation')},
     }
     if fam_sparse is not None:
-        out['config']['backward'] = ('the reverse aggregation of the last layer gathers the loss (train) rows only: the gradient rows of all other nodes are exact '
-                                     'zeros under the masked loss (verified on the device every step); aggregated_edges_per_sec counts the nominal E per aggregation')
+        out['config']['backward'] = ('row-sparse: under the masked loss the gradient is exactly zero outside the rows the train rows reach after j hops; the levels '
+                                     'of the backward whose support is <= 60 % of the rows (train rows, their neighbours) run on compact matrices and gather only '
+                                     'those rows (the claim is verified on the device every step; CB_LOSS_ROWS=0: dense backward); aggregated_edges_per_sec counts '
+                                     'the nominal E per aggregation')
     out['peak_mem_gb'] = peak_mem / 2 ** 30
     if sharding is not None:
         out['sharding'] = sharding
