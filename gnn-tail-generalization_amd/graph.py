@@ -133,15 +133,17 @@ class CSRGraph:
                              member of S_{j+1}), else None (csr has all N rows, the output is an ordinary dense matrix and the plan ends).
         At most n_aggr levels, and the last of them always has a dense destination (the stage below the first layer needs all rows).
         max_frac = 0: one level, S_0 -> all rows.  Sums equal the full orientation's up to the order in which a hub row's chunks are added."""
+        # (the cache keeps the mask tensor itself alive: its address cannot be handed to another tensor while the plan is cached, and an
+        # in-place change bumps its version)
         key = (keep.data_ptr(), keep._version, int(keep.shape[0]), int(n_aggr), float(max_frac))
-        if getattr(self, '_support_key', None) == key:
+        if getattr(self, '_support_key', None) == key and getattr(self, '_support_mask', None) is keep:
             return self._support_plan
         if self.rowptr_t is None:
             raise ValueError('this graph holds the forward orientation only')
         if keep.dtype != torch.bool or keep.shape[0] != self.n_cols or self.N != self.n_cols:
             raise ValueError(f'grad_support_plan: bool mask over the {self.n_cols} rows of a square graph expected')
         rp, col = self.rowptr_t, self.col_t[:self.E]
-        a = getattr(self, 'norm_out', None)
+        a = self.norm_out
 
         def space_of(mask):
             pos = torch.cumsum(mask, 0, dtype=torch.int32) - 1
@@ -168,7 +170,7 @@ class CSRGraph:
             else:
                 plan.levels.append((CSRGraph.from_csr(rp_new, col_new, src.n, hub_threshold=self.hub_threshold), None))
                 break
-        self._support_key, self._support_plan = key, plan
+        self._support_key, self._support_plan, self._support_mask = key, plan, keep
         return plan
 
     def flagged_cols(self, transpose, row_bytes):
