@@ -470,8 +470,7 @@ class _TrunkFn(torch.autograd.Function):
         if (rows_hint is not None and rows_hint[1] <= 0.4 * gout.shape[0] and gout.shape[0] >= ROWSPARSE_MIN_NODES and gather and ag_bwd
                 and not tail_tb and not agg_bf16):
             ops.check_rows_zero(gout, rows_hint[0])
-            # (structural-embedding tables take dL/dZ_l as their gradient: all rows, so only the gathered side is compact then)
-            plan = graph.grad_support_plan(rows_hint[0], L, max_frac=0.0 if any(ctx.le_present) else ROWSPARSE_MAX_FRAC)
+            plan = graph.grad_support_plan(rows_hint[0], L, max_frac=ROWSPARSE_MAX_FRAC)
         space = None                                                             # row space of g / gr (None: all rows)
         mix_pos = []
         if plan is not None:
@@ -552,6 +551,10 @@ class _TrunkFn(torch.autograd.Function):
             else:
                 g = g_fused if g_fused is not None else gemm.mm_nn(gz, w.t().contiguous(), rowscale=a)   # dL/d(dropped X_0): consumed by the input stage
             if le is not None and need[7 + 3 * l + 2]:
+                if dst is not None:      # the table's gradient is dL/dZ_l on ALL rows: the support's rows, zeros elsewhere
+                    gz_all = torch.zeros((x0.shape[0], gz.shape[1]), dtype=gz.dtype, device=gz.device)
+                    gz_all.index_copy_(0, dst.idx, gz)
+                    gz = gz_all
                 grads_layers[3 * l + 2] = gz
             else:
                 del gz

@@ -14,14 +14,14 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def _step_grads(flag, dataset='S-pl1M'):
+def _step_grads(flag, dataset='S-pl1M', se='000'):
     import bench
     from gnn_tail_generalization_amd import _lib, ops
     from gnn_tail_generalization_amd import trainer_node_classification as tnc
     old = os.environ.get('CB_LOSS_ROWS')
     os.environ['CB_LOSS_ROWS'] = flag
     try:
-        args = bench.make_args(dataset, ['--manual_assign_GPU=0'])
+        args = bench.make_args(dataset, ['--manual_assign_GPU=0'], se=se)
         torch.manual_seed(0)
         with contextlib.redirect_stdout(io.StringIO()):
             t = tnc.trainer(args, 0)
@@ -43,14 +43,14 @@ def _step_grads(flag, dataset='S-pl1M'):
             os.environ['CB_LOSS_ROWS'] = old
 
 
-@pytest.mark.parametrize('max_frac', [0.6, 0.0])
-def test_row_sparse_backward_equals_the_dense_backward(max_frac, monkeypatch):
+@pytest.mark.parametrize('max_frac,se', [(0.6, '000'), (0.0, '000'), (0.6, '111')])
+def test_row_sparse_backward_equals_the_dense_backward(max_frac, se, monkeypatch):
     """max_frac 0.6: the supports S_0 (10 % of the rows) and S_1 (45 %) compact, from S_2 (94 %) on dense; 0: only the gathered side of the
-    first aggregation compact."""
+    first aggregation compact.  se 111: structural-embedding tables, whose gradient dL/dZ_l is scattered from the compact level to all rows."""
     from gnn_tail_generalization_amd import trunk
     monkeypatch.setattr(trunk, 'ROWSPARSE_MAX_FRAC', max_frac)
-    loss_s, g_s, used_s = _step_grads('1')
-    loss_d, g_d, used_d = _step_grads('0')
+    loss_s, g_s, used_s = _step_grads('1', se=se)
+    loss_d, g_d, used_d = _step_grads('0', se=se)
     assert used_s and not used_d                       # the 10 % train mask of the stand-in: the plan was built and used
     assert loss_s == loss_d
     assert set(g_s) == set(g_d)
