@@ -332,6 +332,8 @@ def test_config3_arxiv_shape_full_size_vs_oracle():
     args, model, data = _teacher(['--num_layers=3', '--use_special_split=0'], 'S-arxiv')
     assert data.x.shape == (169343, 128) and data.edge_index.shape[1] == 2 * 1157799
     _product_vs_oracle(args, model, data)
+    # at this size the backward just compared with the oracle was the row-sparse one (10 % train rows: compact levels, trunk.py)
+    assert getattr(model.model.model._graph(data.edge_index), '_support_plan', None) is not None
 
 
 def test_config4_products_shape_subsample_vs_oracle():
