@@ -577,9 +577,14 @@ class ShardedGraph:
         self.symmetric = bool(flag.item())
         self.f = self._orient(rf, cf)
         self.b = self.f if self.symmetric else self._orient(rb, cb)
+        # the reverse orientation's edge list (local row, global column) stays: the row-sparse backward builds its level orientations from it
+        self._rev_edges = (rf, cf) if self.symmetric else (rb, cb)
+        self._support_cache = None
 
     # -- build one orientation ---------------------------------------------------------------------------
-    def _orient(self, rows, cols):
+    def _orient(self, rows, cols, like=None):
+        """like: an existing orientation whose KIND of plan (pull / cover) and slice count this one takes over — the callers' control flow is
+        keyed to those (row-chunked producers, fused last pass), so a level orientation of the row-sparse backward mirrors the full one."""
         part, lo, hi = self.part, self.part.lo(), self.part.hi()
         o = _Orientation()
         o.E = int(rows.numel())
@@ -590,7 +595,9 @@ class ShardedGraph:
         remote = (cols < lo) | (cols >= hi)
         uniq, inv = torch.unique(cols[remote], return_inverse=True)       # ascending ids = grouped by owner
         K = 1
-        if self.overlap:
+        if like is not None and like.plan is not None:
+            K = like.plan.n_slices
+        elif self.overlap:
             # every rank must cut its plans into the same number of slices: decide on the largest halo of the group
             if self._n_slices_req is not None:
                 K = max(1, int(self._n_slices_req))
@@ -600,7 +607,10 @@ class ShardedGraph:
                     _all_reduce(nh, op=dist.ReduceOp.MAX, group=self.group)
                 K = default_slices(int(nh.item()))
         use_cover = False
-        if self.cover:
+        if like is not None and like.plan is not None:
+            use_cover = bool(like.plan.cover)
+            asg = CoverPlan.assign(rows[remote], cols[remote], part) if use_cover else None
+        elif self.cover:
             # one decision for the group (every rank must build the same kind of plan): the cover is taken when it spares the busiest
             # requester at least COVER_MIN_GAIN of its rows (power-law graphs: 25 - 32 %; the ogbn-products shape: < 6 % -> plain pull,
             # whose pack is a row gather and whose slices follow the owners' row chunks)
@@ -623,6 +633,44 @@ class ShardedGraph:
             o.whole = self.compute.csr(rows, new_col, self.N, self.N + o.plan.n_halo)
         return o
 
+    def support_orients(self, mask_local, n_aggr, max_edge_frac=0.9):
+        """Level orientations of a row-sparse backward (trunk.py; graph.CSRGraph.grad_support_plan is the one-GPU form): reverse aggregation
+        j gathers only rows of the support S_j (S_0 = the loss rows `mask_local` of this rank, S_{j+1} = rows with a reverse-orientation
+        neighbour in S_j) — all other rows of the gathered matrix are exact zeros.  Level j = the reverse orientation restricted to the edges
+        whose gathered row is in S_j: its halo plan asks the peers for the support's rows only (the first backward exchange of the bench's
+        graph ships a tenth of the rows, the second 45 %), its interior / halo passes read fewer edges; matrices keep all local rows.
+        Levels are built while they keep at most max_edge_frac of the edges (one decision for the group); the supports travel as byte
+        maps (all-gather of N bytes per level, once per mask).  Returns a list of orientations, possibly empty."""
+        key = (mask_local.data_ptr(), mask_local._version, int(n_aggr))
+        if self._support_cache is not None and self._support_cache[0] == key and self._support_cache[1] is mask_local:
+            return self._support_cache[2]
+        part, P = self.part, self.part.world
+        rows, cols = self._rev_edges
+        dev = rows.device
+        owner = part.owner(cols)
+        lo_t = torch.tensor(part.bounds[:-1], dtype=torch.int64, device=dev)
+        slot = owner * part.R + (cols - lo_t[owner])          # position of a column's row in the all-gathered [P * R] map
+        levels, s_local = [], mask_local.to(torch.bool)
+        for _ in range(int(n_aggr)):
+            m = torch.zeros(part.R, dtype=torch.uint8, device=dev)
+            m[:self.N] = s_local.to(torch.uint8)
+            allm = torch.empty(part.padded, dtype=torch.uint8, device=dev)
+            if P > 1:
+                _all_gather_into_tensor(allm, m, group=self.group)
+            else:
+                allm.copy_(m)
+            keep = allm[slot] != 0
+            cnt = torch.tensor([int(keep.sum())], dtype=torch.int64, device=dev)
+            if P > 1:
+                _all_reduce(cnt, group=self.group)
+            if int(cnt.item()) > max_edge_frac * self.E_global:
+                break
+            r_k, c_k = rows[keep], cols[keep]
+            levels.append(self._orient(r_k, c_k, like=self.b))
+            s_local = torch.bincount(r_k, minlength=self.N)[:self.N] > 0
+        self._support_cache = (key, mask_local, levels)
+        return levels
+
     # -- CSRGraph-like surface ---------------------------------------------------------------------------
     def check_zero_in_degree(self):
         from .graph import ZeroInDegreeError
@@ -641,9 +689,9 @@ class ShardedGraph:
         return b + (4 * self.N if row_scale else 0) + (d * elem if bias else 0)
 
     # -- exchange + aggregation --------------------------------------------------------------------------
-    def exchange(self, x_local, transpose=False):
+    def exchange(self, x_local, transpose=False, orient=None):
         """Blocking form: [n_local, d] -> the matrix the single-pass CSR reads ([local | halo] or the gathered [P*R, d])."""
-        o = self.b if transpose else self.f
+        o = orient if orient is not None else (self.b if transpose else self.f)
         if self.exchange_kind == 'allgather':
             return gather_rows(x_local, self.part, self.group)
         if self.part.world == 1:
@@ -674,11 +722,11 @@ class ShardedGraph:
             work = _all_to_all_single(recv[:n_k], send, plan.recv_counts[k], plan.send_counts[k], group=self.group, async_op=True)
         return recv, work, send
 
-    def start_halo(self, x_local, transpose=False, produce=None):
+    def start_halo(self, x_local, transpose=False, produce=None, orient=None):
         """Overlapped form, first half: for every slice k — produce(k, r0, r1) fills local rows [r0, r1) of x_local (if given: the
         layer GEMM / the trunk backward of row chunk k), then pack + asynchronous all-to-all of slice k, whose rows all lie in
         that chunk.  Returns the list of (receive buffer, work handle, send buffer) per slice."""
-        plan = (self.b if transpose else self.f).plan
+        plan = (orient if orient is not None else (self.b if transpose else self.f)).plan
         flights = []
         if self.exchange_log is not None:
             ev = torch.cuda.Event(enable_timing=True)
@@ -690,15 +738,16 @@ class ShardedGraph:
             flights.append(self._send_slice(x_local, plan, k))
         return flights
 
-    def aggregate_start(self, h_local, transpose=False, produce=None):
+    def aggregate_start(self, h_local, transpose=False, produce=None, orient=None):
         """First half of aggregate(): starts the exchange (overlapped form) and returns a handle for aggregate_finish().  Work
         issued between the two calls (e.g. the previous layer's weight-gradient GEMM in the trunk backward) runs under the
-        exchange.  produce: see start_halo (h_local is then an allocated, not yet filled matrix)."""
+        exchange.  produce: see start_halo (h_local is then an allocated, not yet filled matrix).  orient: a level orientation of
+        support_orients — the handle carries it to aggregate_finish."""
         if not self.overlap or h_local.dtype != torch.float32:
             if produce is not None:
                 produce(0, 0, h_local.shape[0])
-            return (h_local, None)
-        return (h_local, self.start_halo(h_local, transpose, produce))
+            return (h_local, None, orient)
+        return (h_local, self.start_halo(h_local, transpose, produce, orient), orient)
 
     def finish_halo(self, flights, o, part_sums, last_pass):
         """Second half: halo pass k (raw sums, in place) as slice k arrives; last_pass(csr, recv, acc) is the caller's final pass
@@ -721,13 +770,13 @@ class ShardedGraph:
     def aggregate_finish(self, handle, transpose=False, row_scale=None, bias=None, relu=False, last_pass=None):
         """last_pass(csr, recv, acc) (overlapped form only): the caller's own final pass over the last slice on top of the running sums
         (the fused trunk: aggregation + GEMM kernel, cb_spmm_gemm_f32 with acc_init) instead of the plain epilogue pass."""
-        h_local, flights = handle
-        o = self.b if transpose else self.f
+        h_local, flights, orient = handle if len(handle) == 3 else (*handle, None)
+        o = orient if orient is not None else (self.b if transpose else self.f)
         c = self.compute
         if flights is None:
             if last_pass is not None:
                 raise ValueError('aggregate_finish: last_pass needs the overlapped exchange')
-            return c.spmm(o.whole if o.whole is not None else self._whole(o), self.exchange(h_local, transpose), row_scale, bias, relu,
+            return c.spmm(o.whole if o.whole is not None else self._whole(o), self.exchange(h_local, transpose, orient), row_scale, bias, relu,
                           profile=self.profile)
         part = c.spmm(o.interior, h_local, profile=self.profile)             # raw sums over the local columns, overlaps the exchange
         if last_pass is None:

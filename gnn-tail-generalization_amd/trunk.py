@@ -429,6 +429,19 @@ class _TrunkFn(torch.autograd.Function):
             dw = gemm.mm_tn_adrop(x0, gz, p, sd0, row0, rowscale=a)
             return dw if dw is not None else gemm.mm_tn(ops._dropout_raw(x0, p, sd0, row0 * x0.shape[1]), gz, rowscale=a)
 
+        # Node-sharded: the row-sparse backward as LEVEL ORIENTATIONS of the reverse exchange (dist.ShardedGraph.support_orients) — level j
+        # ships and gathers only the rows of the support S_j; matrices keep all local rows, every other branch of this function is unchanged.
+        sh_levels = []
+        if sharded and hasattr(graph, 'support_orients'):
+            hint = ops.take_grad_rows(gout)
+            if hint is not None:
+                ops.check_rows_zero(gout, hint[0])
+                sh_levels = graph.support_orients(hint[0], L)
+
+        def orient_of(layer):
+            j = L - 1 - layer
+            return sh_levels[j] if j < len(sh_levels) else None
+
         def dx_gemm(src, wt, rowscale, below, g_ready=None):
             """dL/dx of the stage above layer `below` and that layer's trunk backward: (g, gr, dbias, handle); handle = the already started
             exchange of gr (row-chunked producers of the node-sharded pull pipeline), else None."""
@@ -447,7 +460,7 @@ class _TrunkFn(torch.autograd.Function):
                                        want_b, out=gr_[r0:r1])
                     if want_b:
                         colsums.append(cs)
-                h_ = graph.aggregate_start(gr_, True, produce=produce)
+                h_ = graph.aggregate_start(gr_, True, produce=produce, orient=orient_of(below))
                 db_ = None
                 if want_b:      # (a rank that owns no rows produces no chunk: its share of the bias gradient is zero)
                     db_ = (torch.zeros(wt.shape[1], dtype=torch.float32, device=src.device) if not colsums
@@ -497,7 +510,7 @@ class _TrunkFn(torch.autograd.Function):
             level = plan.levels[L - 1 - l] if (plan is not None and L - 1 - l < len(plan.levels)) else None
             dst = level[1] if level is not None else None
             if sharded and handle is None:
-                handle = graph.aggregate_start(gr, True)                        # node-sharded: the exchange is in flight from here
+                handle = graph.aggregate_start(gr, True, orient=orient_of(l))   # node-sharded: the exchange is in flight from here
             if deferred is not None:
                 grads_layers[3 * deferred[0]] = dw_layer(*deferred)
                 deferred = None

@@ -200,6 +200,53 @@ def test_push_pull_cover_exchange_matches_unsharded_oracle(name, world, n_slices
     _run(_worker, world, name, 'halo', True, kind, wire, n_slices, True, 'force')
 
 
+def _support_worker(rank, world, port, name, q, cover, n_slices):
+    """Level orientations of the row-sparse backward (ShardedGraph.support_orients): aggregating a matrix that is zero outside the support
+    S_j through level j equals the full reverse aggregation, level j + 1's support is what that aggregation can reach, and the level ships
+    fewer rows than the full plan."""
+    _setup(rank, world, port)
+    try:
+        import coldbrew_oracle as orc
+        from dist_cpu_compute import OracleCompute
+        from gnn_tail_generalization_amd import dist as cbdist
+        g = load_golden(name)
+        n, ei = g['cfg']['N_nodes'], g['edge_index']
+        csr = orc.build_csr(ei, n)
+        part = cbdist.Partition.balanced(torch.from_numpy(csr.in_deg), world, rank, node_weight=2)
+        sg = cbdist.ShardedGraph(ei, n, part, exchange='halo', overlap=True, compute=OracleCompute(), n_slices=n_slices, cover=cover)
+        gen = torch.Generator().manual_seed(3)
+        mask = torch.rand(n, generator=gen) < 0.08
+        mask[0] = True
+        levels = sg.support_orients(part.slice_rows(mask).contiguous(), 3, max_edge_frac=0.97)
+        assert len(levels) >= 1
+        src, dst = ei[0], ei[1]
+        S = mask.clone()
+        for o in levels:
+            assert o.plan.n_slices == sg.b.plan.n_slices and bool(o.plan.cover) == bool(sg.b.plan.cover)
+            assert o.plan.n_halo <= sg.b.plan.n_halo and o.E <= sg.b.E
+            h = torch.randn(n, 5, generator=gen) * S.float().unsqueeze(1)          # supported on S_j
+            hl = part.slice_rows(h).contiguous()
+            full = sg.aggregate(hl, True)
+            lvl = sg.aggregate_finish(sg.aggregate_start(hl, True, orient=o), True)
+            torch.testing.assert_close(lvl, full, atol=1e-5, rtol=1e-5)
+            nxt = torch.zeros(n, dtype=torch.bool)
+            nxt[src[S[dst]]] = True          # reverse aggregation: row u sums the rows dst(e) of its out-edges
+            assert bool((full[~part.slice_rows(nxt)] == 0).all())
+            S = nxt
+        q.put((rank, 'ok'))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, 'FAIL ' + traceback.format_exc()[-1500:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name,world,cover,n_slices', [('case_graph_powerlaw_d7_d64', 2, False, 2), ('case_graph_powerlaw_d7_d64', 3, 'force', 2),
+                                                        ('case_graph_asym_multi', 2, False, 1)])
+def test_row_sparse_level_orientations_match_the_full_reverse_exchange(name, world, cover, n_slices):
+    _run(_support_worker, world, name, cover, n_slices)
+
+
 def _decision_worker(rank, world, port, _unused, q):
     _setup(rank, world, port)
     try:

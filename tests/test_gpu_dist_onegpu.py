@@ -73,6 +73,10 @@ def _worker(rank, world, port, exchange, overlap, partition, argv, q, wire='f32'
         assert (not conv0.whetherHasSE) or conv0.le.shape[0] == t.part.n_local
         ops._seed_override[:] = list(SEEDS)
         losses = [float(t.train_step()) for _ in range(STEPS)]
+        if argv is ARGV or '--whetherHasSE=111' in argv:
+            # the fused trunk (S-pubmed: hidden 256, 'Initial'): its backward went through the level orientations of the row-sparse backward
+            # (dist.ShardedGraph.support_orients: 10 % train rows -> level 0 keeps a tenth of the reverse edges)
+            assert t.sgraph._support_cache is not None and len(t.sgraph._support_cache[2]) >= 1, 'row-sparse level orientations not used'
         accs = t.run_testSet()
         w = t.teacherGNN.model.model.layers_GCN[1].weight.detach().cpu()
         le = conv0.le.detach().cpu() if conv0.whetherHasSE else torch.zeros(1)
