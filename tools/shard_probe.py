@@ -116,13 +116,27 @@ def main():
     ap.add_argument('--layers', type=int, default=3)
     ap.add_argument('--mode', default='both', choices=['both', 'pull', 'cover'])
     ap.add_argument('--halo-only', type=int, default=0, help='1: only count rows per link (pull vs cover), no kernel timing')
+    ap.add_argument('--support-level', type=int, default=-1,
+                    help='j >= 0: probe level j of the row-sparse backward (dist.ShardedGraph.support_orients): only the edges whose gathered row lies in the '
+                         'support S_j of the stand-in\'s train mask (S_0 = train rows, S_{j+1} = rows with a neighbour in S_j); the partition stays the full graph\'s')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     data = synthetic_data(a.name, seed=0, device=dev)
     n, E = int(data.x.shape[0]), int(data.edge_index.shape[1])
     src, dst = data.edge_index[0], data.edge_index[1]
-    del data
     in_deg = torch.bincount(dst, minlength=n)
+    if a.support_level >= 0:
+        S = data.train_mask.clone()
+        for _ in range(a.support_level):
+            nxt = torch.zeros_like(S)
+            nxt[dst[S[src]]] = True
+            S = nxt
+        keep = S[src]
+        print(f'support level {a.support_level}: |S| = {float(S.float().mean()):.3f} N, {float(keep.float().mean()):.3f} of the edges kept', flush=True)
+        src, dst = src[keep], dst[keep]
+        E = int(src.numel())
+        del S, keep
+    del data
     comp = cbdist.HipCompute()
     K, d, L = max(1, a.slices), 256, a.layers
     link = a.link_gbs * a.link_eff * 1e6        # bytes per ms
