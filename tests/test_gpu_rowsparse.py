@@ -60,6 +60,20 @@ def test_row_sparse_backward_equals_the_dense_backward(max_frac, se, monkeypatch
         assert float((g_s[k] - g_d[k]).abs().max()) <= 5e-6 * scale, k
 
 
+def test_row_sparse_backward_at_the_headline_size():
+    """S-pl10M (10^7 nodes, 10^8 edges): one training step's gradients, row-sparse (supports 10 % / 45 % compact, then dense) against dense."""
+    import gc
+    loss_s, g_s, used_s = _step_grads('1', dataset='S-pl10M')
+    gc.collect()
+    torch.cuda.empty_cache()
+    loss_d, g_d, used_d = _step_grads('0', dataset='S-pl10M')
+    gc.collect()
+    torch.cuda.empty_cache()
+    assert used_s and not used_d and loss_s == loss_d
+    for k in g_d:
+        assert float((g_s[k] - g_d[k]).abs().max()) <= 5e-6 * float(g_d[k].abs().max()), k
+
+
 def test_support_plan_levels_are_the_reverse_graph_restricted_and_renumbered():
     from gnn_tail_generalization_amd.data import synthetic_data
     from gnn_tail_generalization_amd.graph import CSRGraph
