@@ -60,6 +60,37 @@ def test_row_sparse_backward_equals_the_dense_backward(max_frac, se, monkeypatch
         assert float((g_s[k] - g_d[k]).abs().max()) <= 5e-6 * scale, k
 
 
+def test_row_sparse_backward_matches_the_unmodified_reference(monkeypatch):
+    """The reference's own gradients (golden case_r_initialbn_h256_L3_train10: hidden 256, 3 layers, 8 % train rows, generated from the
+    unmodified reference by tests/golden/make_golden.py) against the product's fused trunk with the row-sparse backward switched on at this
+    small size: supports S_0 (8 %) and S_1 compact, then dense."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    from conftest import load_golden
+    from helpers import product_model
+    from gnn_tail_generalization_amd import _lib, ops, trunk
+    monkeypatch.setattr(trunk, 'ROWSPARSE_MIN_NODES', 0)
+    monkeypatch.setenv('CB_LOSS_ROWS', '1')
+    g = load_golden('case_r_initialbn_h256_L3_train10')
+    args, model = product_model(g['cfg'], g['sd'], DEV)
+    x, ei, y, mask = g['x'].to(DEV), g['edge_index'].to(DEV), g['y'].to(DEV), g['train_mask'].to(DEV)
+    model.train()
+    out = model.get_3_embs(x, ei, mask).emb4classi_full
+    loss = ops.nll_logsoftmax(out, y, mask)
+    model.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert _lib.load().cb_device_status() == 0
+    plan = getattr(model.model.model._graph(ei), '_support_plan', None)
+    assert plan is not None and plan.levels[0][1] is not None       # the backward ran on the plan, S_1 compact
+    torch.testing.assert_close(out.detach().cpu(), g['train_out'], atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(loss.detach().cpu(), g['train_loss'], atol=1e-4, rtol=1e-5)
+    got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == set(g['grads'])
+    for k, ref in g['grads'].items():
+        torch.testing.assert_close(got[k].cpu(), ref, atol=2e-5, rtol=2e-4, msg=lambda m, k=k: f'{k}: {m}')
+
+
 def test_row_sparse_backward_at_the_headline_size():
     """S-pl10M (10^7 nodes, 10^8 edges): one training step's gradients, row-sparse (supports 10 % / 45 % compact, then dense) against dense."""
     import gc
