@@ -489,6 +489,23 @@ def main():
                             'achieved': 0.0, 'achieved_incl_fused_epilogue': 0.0}
     avg_ms, avg_bytes, avg_extra = fam_main['avg_launch_ms'], fam_main['algorithmic_bytes_per_launch'], fam_main['fused_epilogue_bytes_per_launch']
     achieved, achieved_incl = fam_main['achieved'], fam_main['achieved_incl_fused_epilogue']
+    # the same K steps once more with the DENSE backward (CB_LOSS_ROWS=0), after the timed region: both numbers from one run on one box
+    dense_bwd = None
+    if fam_sparse is not None and not use_graph and os.environ.get('CB_LOSS_ROWS', '1') != '0':
+        os.environ['CB_LOSS_ROWS'] = '0'
+        try:
+            graph_obj.profile = None
+            t.train_step()
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                t.train_step()
+            sync()
+            dms = (time.perf_counter() - t1) / a.steps * 1e3
+            dense_bwd = {'ms_per_step': dms, 'value': 1e3 / dms, 'unit': 'steps/s', 'steps': a.steps,
+                         'note': 'the same trainer continued for K more steps with CB_LOSS_ROWS=0 (every backward aggregation over all rows), outside the timed region'}
+        finally:
+            os.environ['CB_LOSS_ROWS'] = '1'
     ref_epoch = None
     if a.ref_epochs > 0 and not sharded and not use_graph:
         ref_epoch = reference_epoch_rate(t, args, a.ref_epochs, sync)
@@ -554,6 +571,8 @@ def main():
                               'run under the gathers; the launches of the plain aggregation kernel in the same steps are listed beside it'
                               if fam_main is fam_tail else 'dominant kernel = the plain aggregation')},
     }
+    if dense_bwd is not None:
+        out['dense_backward'] = dense_bwd
     if fam_sparse is not None:
         out['config']['backward'] = ('row-sparse: under the masked loss the gradient is exactly zero outside the rows the train rows reach after j hops; the levels '
                                      'of the backward whose support is <= 60 % of the rows (train rows, their neighbours) run on compact matrices and gather only '
