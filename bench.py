@@ -575,7 +575,7 @@ def main():
         out['dense_backward'] = dense_bwd
     if fam_sparse is not None:
         out['config']['backward'] = ('row-sparse: under the masked loss the gradient is exactly zero outside the rows the train rows reach after j hops; the levels '
-                                     'of the backward whose support is <= 60 % of the rows (train rows, their neighbours) run on compact matrices and gather only '
+                                     'of the backward whose support is <= 70 % of the rows (train rows, their neighbours) run on compact matrices and gather only '
                                      'those rows (the claim is verified on the device every step; CB_LOSS_ROWS=0: dense backward); aggregated_edges_per_sec counts '
                                      'the nominal E per aggregation')
     out['peak_mem_gb'] = peak_mem / 2 ** 30
