@@ -281,6 +281,8 @@ class trainer:
         build, workspaces, optimizer state); restore=True puts parameters, buffers and optimizer moments / step counts back to
         their values from before the warm-up (in place), so that the replays continue exactly where the caller was."""
         import torch.cuda
+        from . import trunk
+        trunk.ROWSPARSE_SMALL_OK = True      # (set before the warm-up steps: they build the row-support plan the captured step replays)
         if restore:
             snap_model = {k: v.detach().clone() for k, v in self.teacherGNN.state_dict().items()}
             snap_opt = {p: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}

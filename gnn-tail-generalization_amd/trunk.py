@@ -243,6 +243,7 @@ def tail_trunk_bwd(graph):
 # The input Linear's GEMM writes the mask words of (X0 > 0) from its epilogue (a wavefront holds a whole 256-column row there: four ballots),
 # and the input stage of the backward reads those 32 bytes per row instead of X0's 1 KiB (one of its six 10 GB streams).
 ROWSPARSE_MIN_NODES = 1 << 16      # below this a step is launch-bound and the extra check kernel costs more than the gather saves
+ROWSPARSE_SMALL_OK = False         # set by trainer.enable_hip_graph: under hipGraph replay the extra launches cost nothing, so small graphs take the plan too (S-pubmed config 2: 0.787 -> 0.751 ms/step)
 ROWSPARSE_S0_LIMIT = 0.7           # the plan is used while the loss rows are at most this share of the rows (S-pl10M with 50 % / 70 % loss rows: 187.9 / 193.2 ms against 195.4 / 196.3 dense)
 ROWSPARSE_MAX_FRAC = 0.7           # a level's output stays compact while its support is at most this share of the rows (S-arxiv, support 61 %: 3.53 -> 3.40 ms/step against 0.6)
 MIX_MAX = 7      # mixed-in gradients one cb_trunk_input_bwd_multi_f32 launch gathers (deeper trunks accumulate layer by layer)
@@ -481,7 +482,7 @@ class _TrunkFn(torch.autograd.Function):
         # word, never in silent wrong gradients).  One GPU, hidden 256, gathered per-layer gradients, loss rows <= 70 % of the nodes.
         rows_hint = ops.take_grad_rows(gout) if (not sharded and hasattr(graph, 'grad_support_plan') and graph.rowptr_t is not None) else None
         plan = None
-        if (rows_hint is not None and rows_hint[1] <= ROWSPARSE_S0_LIMIT * gout.shape[0] and gout.shape[0] >= ROWSPARSE_MIN_NODES and gather and ag_bwd
+        if (rows_hint is not None and rows_hint[1] <= ROWSPARSE_S0_LIMIT * gout.shape[0] and (gout.shape[0] >= ROWSPARSE_MIN_NODES or ROWSPARSE_SMALL_OK) and gather and ag_bwd
                 and not tail_tb and not agg_bf16):
             ops.check_rows_zero(gout, rows_hint[0])
             plan = graph.grad_support_plan(rows_hint[0], L, max_frac=ROWSPARSE_MAX_FRAC)
