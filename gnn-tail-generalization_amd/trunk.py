@@ -482,7 +482,7 @@ class _TrunkFn(torch.autograd.Function):
         # word, never in silent wrong gradients).  One GPU, hidden 256, gathered per-layer gradients, loss rows <= 70 % of the nodes.
         rows_hint = ops.take_grad_rows(gout) if (not sharded and hasattr(graph, 'grad_support_plan') and graph.rowptr_t is not None) else None
         plan = None
-        if (rows_hint is not None and rows_hint[1] <= ROWSPARSE_S0_LIMIT * gout.shape[0] and (gout.shape[0] >= ROWSPARSE_MIN_NODES or ROWSPARSE_SMALL_OK) and gather and ag_bwd
+        if (rows_hint is not None and 1 <= rows_hint[1] <= ROWSPARSE_S0_LIMIT * gout.shape[0] and (gout.shape[0] >= ROWSPARSE_MIN_NODES or ROWSPARSE_SMALL_OK) and gather and ag_bwd
                 and not tail_tb and not agg_bf16):
             ops.check_rows_zero(gout, rows_hint[0])
             plan = graph.grad_support_plan(rows_hint[0], L, max_frac=ROWSPARSE_MAX_FRAC)

@@ -14,14 +14,14 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def _step_grads(flag, dataset='S-pl1M', se='000'):
+def _step_grads(flag, dataset='S-pl1M', se='000', layers=3):
     import bench
     from gnn_tail_generalization_amd import _lib, ops
     from gnn_tail_generalization_amd import trainer_node_classification as tnc
     old = os.environ.get('CB_LOSS_ROWS')
     os.environ['CB_LOSS_ROWS'] = flag
     try:
-        args = bench.make_args(dataset, ['--manual_assign_GPU=0'], se=se)
+        args = bench.make_args(dataset, ['--manual_assign_GPU=0'], se=se, layers=layers)
         torch.manual_seed(0)
         with contextlib.redirect_stdout(io.StringIO()):
             t = tnc.trainer(args, 0)
@@ -58,6 +58,18 @@ def test_row_sparse_backward_equals_the_dense_backward(max_frac, se, monkeypatch
         scale = float(g_d[k].abs().max())
         # same addends; the association of sums differs (hub chunks, the slabs of the weight-gradient reductions)
         assert float((g_s[k] - g_d[k]).abs().max()) <= 5e-6 * scale, k
+
+
+def test_row_sparse_backward_two_layers_small_graph(monkeypatch):
+    """BASELINE config 2's shape (S-pubmed: 19 717 nodes, 2 layers, structural embeddings): the plan has two levels, the second one dense by
+    construction (the stage below the first layer needs all rows); taken at this size only under hipGraph replay, forced here."""
+    from gnn_tail_generalization_amd import trunk
+    monkeypatch.setattr(trunk, 'ROWSPARSE_MIN_NODES', 0)
+    loss_s, g_s, used_s = _step_grads('1', dataset='S-pubmed', se='111', layers=2)
+    loss_d, g_d, used_d = _step_grads('0', dataset='S-pubmed', se='111', layers=2)
+    assert used_s and not used_d and loss_s == loss_d
+    for k in g_d:
+        assert float((g_s[k] - g_d[k]).abs().max()) <= 5e-6 * float(g_d[k].abs().max()), k
 
 
 def test_row_sparse_backward_matches_the_unmodified_reference(monkeypatch):
