@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(kBlock) k_act_bwd(const float* __restrict__ g,
 // One wavefront per row per iteration, lane l owns columns 4l..4l+3 of each 256-wide tile (same mapping as
 // the forward epilogue, so mask word k is tested at bit l).
 // MODE 0: the layer kernel above.  MODE 1: trunk input stage  gy = (add + gm) * (act > 0); out = gy; colsum(gy).
-template <int MODE, bool OUT_BF16, bool STORE = true>      // STORE = false: column sums only (no output row is written)
+template <int MODE, bool OUT_BF16, bool STORE = true, bool RIDX = false>      // STORE = false: column sums only (no output row is written); RIDX: compact rows (ridx)
 __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ g, const unsigned long long* __restrict__ bits,
                                                       const float* __restrict__ act, const float* __restrict__ row_scale,
                                                       void* __restrict__ outv, float* __restrict__ gx0, int accumulate,
@@ -165,7 +165,8 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (int64_t r = r_begin + w; r < r_end; r += kBlock / kWave) {
       const int64_t off = r * d + c;
-      const int64_t rr = ridx ? ridx[r] : r;      // the row of the full matrix this row is
+      int64_t rr = r;      // the row of the full matrix this row is
+      if constexpr (RIDX) rr = ridx[r];
       // g is read once (streaming)
       float gm[4] = {__builtin_nontemporal_load(g + off), __builtin_nontemporal_load(g + off + 1), __builtin_nontemporal_load(g + off + 2),
                      __builtin_nontemporal_load(g + off + 3)};
@@ -830,7 +831,8 @@ static int launch_trunk_bwd(int mode, int out_bf16, const float* g, const uint64
 #define CB_TB_ARGS g, (const unsigned long long*)bits, act, row_scale, out, gx0, accumulate, rows, (int)d, thresh, ks, seed, seed_dev, row0, c_act, c_mix, partial, ridx
   const dim3 grid((unsigned)nb), blk(kBlock);
   const size_t sh = kBlock * 4 * sizeof(float);
-  if (mode == 0 && !out) hipLaunchKernelGGL((k_trunk_bwd<0, false, false>), grid, blk, sh, st, CB_TB_ARGS);
+  if (mode == 0 && ridx) hipLaunchKernelGGL((k_trunk_bwd<0, false, true, true>), grid, blk, sh, st, CB_TB_ARGS);
+  else if (mode == 0 && !out) hipLaunchKernelGGL((k_trunk_bwd<0, false, false>), grid, blk, sh, st, CB_TB_ARGS);
   else if (mode == 0 && out_bf16) hipLaunchKernelGGL((k_trunk_bwd<0, true>), grid, blk, sh, st, CB_TB_ARGS);
   else if (mode == 0) hipLaunchKernelGGL((k_trunk_bwd<0, false>), grid, blk, sh, st, CB_TB_ARGS);
   else hipLaunchKernelGGL((k_trunk_bwd<1, false>), grid, blk, sh, st, CB_TB_ARGS);
