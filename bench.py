@@ -50,6 +50,7 @@ def parse():
     ap.add_argument('--extra', default='', help='further reference CLI flags, space separated (e.g. "--force_set_to_best_config=0 --type_trick=Residual")')
     ap.add_argument('--layers', type=int, default=3, help='num_layers (BASELINE config 2 = Pubmed, 2 layers)')
     ap.add_argument('--agg-dtype', default='f32', choices=['f32', 'bf16'], help='bf16 = build-extension storage of the gathered rows')
+    ap.add_argument('--dense-backward', type=int, default=1, help='also time K steps with the dense backward (CB_LOSS_ROWS=0) after the timed region (N=1, eager)')
     ap.add_argument('--check-n1', type=int, default=1, help='N > 1: rank 0 first computes the single-GPU training loss of the same model / seeds; '
                                                              'the sharded forward must reproduce it (sharding.loss_matches_n1)')
     return ap.parse_args()
@@ -491,7 +492,7 @@ def main():
     achieved, achieved_incl = fam_main['achieved'], fam_main['achieved_incl_fused_epilogue']
     # the same K steps once more with the DENSE backward (CB_LOSS_ROWS=0), after the timed region: both numbers from one run on one box
     dense_bwd = None
-    if fam_sparse is not None and not use_graph and os.environ.get('CB_LOSS_ROWS', '1') != '0':
+    if a.dense_backward and fam_sparse is not None and not use_graph and os.environ.get('CB_LOSS_ROWS', '1') != '0':
         os.environ['CB_LOSS_ROWS'] = '0'
         try:
             graph_obj.profile = None
