@@ -37,6 +37,8 @@ SIGNATURES = {
     'cb_spmm_workspace_bytes': (_SZ, [_I64, _I64]),
     'cb_spmm_csr_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_int, _P, _I64,
                                        _I32, _I32, _I32, _P, _P, _P, _SZ, _P]),
+    'cb_spmm_csr_colscale_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64,
+                                                _I32, _I32, _I32, _P, _P, _P, _SZ, _P]),
     'cb_dropout_f32': (ctypes.c_int, [_P, _P, _I64, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P]),
     'cb_axpby_f32': (ctypes.c_int, [ctypes.c_float, _P, ctypes.c_float, _P, _P, _I64, _P]),
     'cb_colsum_workspace_bytes': (_SZ, [_I64, _I64]),

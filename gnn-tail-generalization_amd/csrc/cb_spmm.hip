@@ -56,7 +56,21 @@ static int launch_spmm_cfg(const int32_t* rowptr, const int32_t* col, int64_t N,
     constexpr bool kGP = VEC == 4 && RPW == 16 && U == 8;   // gather-policy variants: the d % 256 == 0 kernels (fp32 and bf16-stored rows)
     const int gp = kGP && d % tile == 0 ? (acc ? (ep.col_flags ? 2 : 0) : gather_policy(ep.col_flags)) : 0;
     CB_CHECK_ARG(!ep.col_flags || gp == 2, CB_E_INVALID, "flagged column ids are only understood by the d %% 256 == 0 kernels");
-    if constexpr (FUSED) {
+    bool cs_done = false;      // source-row factor (ep.col_scale): the d % 256 == 0 fp32 kernels with the plain store
+    if constexpr (kGP && !FUSED && sizeof(HT) == 4) {
+      if (ep.col_scale) {
+        CB_CHECK_ARG(!acc && d % tile == 0, CB_E_INVALID, "a source-row factor needs d %% 256 == 0 and no running sums");
+        if (gp == 2)
+          hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, true, false, HT, false, 2, true>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h,
+                             ld_h, out, ld_out, (int)N, (int)d, ep, hub_T, fe);
+        else
+          hipLaunchKernelGGL((k_spmm_rows<VEC, RPW, U, true, false, HT, false, 0, true>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h,
+                             ld_h, out, ld_out, (int)N, (int)d, ep, hub_T, fe);
+        cs_done = true;
+      }
+    }
+    if (cs_done) {
+    } else if constexpr (FUSED) {
       if (acc) { if constexpr (kGP) { if (gp == 2) CB_ROWS_LAUNCH_GP(true, true, true, 2); else CB_ROWS_LAUNCH(true, true, true); } else CB_ROWS_LAUNCH(true, true, true); }
       else if constexpr (kGP) { if (gp == 2) CB_ROWS_LAUNCH_GP(true, true, false, 2); else CB_ROWS_LAUNCH(true, true, false); }
       else CB_ROWS_LAUNCH(true, true, false);
@@ -79,7 +93,20 @@ static int launch_spmm_cfg(const int32_t* rowptr, const int32_t* col, int64_t N,
 #define CB_HUB_LAUNCH(GP_)                                                                                                       \
   hipLaunchKernelGGL((k_spmm_hub_chunks<VEC, 8, HT, GP_>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h, (int)d, \
                      hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, ld_p, ep)
-    if constexpr (kGPh) { if (gph == 2) CB_HUB_LAUNCH(2); else CB_HUB_LAUNCH(0); }
+    bool cs_hub = false;
+    if constexpr (kGPh && !FUSED && sizeof(HT) == 4) {
+      if (ep.col_scale) {
+        if (gph == 2)
+          hipLaunchKernelGGL((k_spmm_hub_chunks<VEC, 8, HT, 2, true>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h, (int)d, hub_T,
+                             n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, ld_p, ep);
+        else
+          hipLaunchKernelGGL((k_spmm_hub_chunks<VEC, 8, HT, 0, true>), grid, dim3(kWave * waves_per_block), 0, st, rowptr, col, h, ld_h, (int)d, hub_T,
+                             n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, ld_p, ep);
+        cs_hub = true;
+      }
+    }
+    if (cs_hub) {
+    } else if constexpr (kGPh) { if (gph == 2) CB_HUB_LAUNCH(2); else CB_HUB_LAUNCH(0); }
     else CB_HUB_LAUNCH(0);
 #undef CB_HUB_LAUNCH
     CB_LAUNCH_CHECK();
@@ -112,7 +139,7 @@ extern "C" size_t cb_spmm_workspace_bytes(int64_t n_chunks, int64_t d) {
 static int spmm_plain_impl(const char* who, const int32_t* rowptr, const int32_t* col, int col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h,
                            int64_t d, const float* row_scale, const float* bias, int relu, const float* acc_init, int64_t ld_init,
                            float* out, int64_t ld_out, int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
-                           const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
+                           const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream, const float* col_scale = nullptr) {
   CB_CHECK_ARG(N >= 0 && E >= 0 && d >= 0, CB_E_INVALID, "%s: negative size", who);
   CB_CHECK_ARG(N < INT32_MAX && E < INT32_MAX && d < (1 << 20), CB_E_RANGE, "%s: size exceeds the int32 contract", who);
   if (N == 0 || d == 0) return CB_OK;
@@ -123,6 +150,7 @@ static int spmm_plain_impl(const char* who, const int32_t* rowptr, const int32_t
                CB_E_WORKSPACE, "%s: hub plan given but workspace missing/too small (%zu < %zu)", who, ws_bytes,
                cb_spmm_workspace_bytes(n_chunks, d));
   Epilogue ep{row_scale, bias, relu, acc_init, ld_init, col_flags};
+  ep.col_scale = col_scale;
   ep.acc_skip_empty = acc_init && acc_init == out && ld_init == ld_out && !row_scale && !bias && !relu;      // raw in-place pass: rows without edges stay untouched
   CB_CHECK_ARG(!col_flags || d % 256 == 0, CB_E_INVALID, "%s: flagged column ids need d %% 256 == 0", who);
   hipStream_t st = (hipStream_t)stream;
@@ -133,6 +161,11 @@ static int spmm_plain_impl(const char* who, const int32_t* rowptr, const int32_t
   const bool al8 = ((uintptr_t)h % 8 == 0) && ((uintptr_t)out % 8 == 0) && (ld_h % 2 == 0) && (ld_out % 2 == 0) && (d % 2 == 0) && ini8;
   float* partial = (float*)ws;
   CB_CHECK_ARG(!col_flags || al16, CB_E_INVALID, "%s: flagged column ids need 16-byte aligned rows", who);
+  if (col_scale) {
+    CB_CHECK_ARG(al16 && d % 256 == 0 && !acc_init && !bias && !relu, CB_E_INVALID,
+                 "%s: a source-row factor needs 16-byte aligned rows with d %% 256 == 0, no bias / ReLU / running sums", who);
+    return launch_spmm<4>(rowptr, col, N, h, ld_h, d, ep, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, partial, st);
+  }
   if (!acc_init && spmm_small_eligible(d, al16))
     return launch_spmm_small(rowptr, col, N, h, ld_h, d, row_scale, bias, relu, out, ld_out, hub_T, n_hubs, n_chunks, hub_rows,
                              hub_chunk_ptr, partial, partial_ld(d), al16, st);
@@ -149,6 +182,18 @@ extern "C" int cb_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, int32_
                                const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
   return spmm_plain_impl("cb_spmm_csr_f32", rowptr, col, col_flags, N, E, h, ld_h, d, row_scale, bias, relu, nullptr, 0, out, ld_out, hub_T, n_hubs,
                          n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, stream);
+}
+
+// out[v, :] = row_scale[v] * sum_{u in row v} col_scale[u] * h[u, :]: the aggregation with a factor per SOURCE row applied as the row is
+// gathered (d % 256 == 0).  The row-sparse backward takes A (a * X_l) on the loss rows with it — the weight gradient of the level
+// contracted over the loss rows (trunk.py; autograd of GCN.py:213,238 re-associated) — without a scaled copy of X_l.
+extern "C" int cb_spmm_csr_colscale_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h,
+                                        int64_t ld_h, int64_t d, const float* col_scale, const float* row_scale, float* out, int64_t ld_out,
+                                        int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
+                                        const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(col_scale != nullptr || N == 0 || d == 0, CB_E_INVALID, "cb_spmm_csr_colscale_f32: col_scale is null");
+  return spmm_plain_impl("cb_spmm_csr_colscale_f32", rowptr, col, col_flags, N, E, h, ld_h, d, row_scale, nullptr, 0, nullptr, 0, out, ld_out, hub_T,
+                         n_hubs, n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, stream, col_scale);
 }
 
 // One label-propagation step with its two elementwise passes folded into the store (Label_propagation_model/outcome_correlation.py:137-143,

@@ -123,6 +123,9 @@ struct Epilogue {
   // aggregation): a row without edges in THIS CSR keeps its running sums as they are — neither read nor written (a halo slice touches only a
   // fraction of the rows; the passes are otherwise bound by reading and re-writing all of them)
   int acc_skip_empty;
+  // CS kernels (d % 256 == 0, fp32 rows, plain store): out[v] = row_scale[v] * sum_u col_scale[u] * h[u] — the factor of a SOURCE row applied
+  // as the row is gathered (the row-sparse backward's A (a * X) on the loss rows: no scaled copy of X, trunk.py)
+  const float* col_scale;   // [n_cols] or null
 };
 
 template <int VEC>
@@ -224,13 +227,14 @@ __device__ __forceinline__ void gather_pol(float (&v)[VEC], const HT* __restrict
 // TLD > 0 (cb_agg_gemm.hip): every finished row is also written to an LDS tile — tile_lane = this lane's 4 columns of the
 // wavefront's local row 0, TLD floats per tile row.
 // P65 (64-row blocks, cb_agg_gemm.hip): lane i holds rowptr[r0 + i] for i < 64 and ptr_hi = rowptr[r0 + 64].
-template <int VEC, int U, bool FULL, bool FUSED, bool ACC, typename HT, int GP = 0, int TLD = 0, bool P65 = false>
+template <int VEC, int U, bool FULL, bool FUSED, bool ACC, typename HT, int GP = 0, int TLD = 0, bool P65 = false, bool CS = false>
 __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr_v, float my_scale, int r0, const int* __restrict__ col,
                                             const HT* __restrict__ h_lane, int64_t ld_h, float* __restrict__ out_lane,
                                             int64_t ld_out, bool active_in, int relu, const float (&bvec)[VEC], const FusedEpi& fe,
                                             int c0, const float* __restrict__ init_lane, int64_t ld_init, const Epilogue& ep,
                                             float* tile_lane = nullptr, int ptr_hi = 0) {
   static_assert(TLD == 0 || (VEC == 4 && FULL), "on-chip row tile: d == 256, float4 lanes");
+  static_assert(!CS || (!P65 && !FUSED && !ACC && sizeof(HT) == 4), "source-row factor: plain fp32 aggregation only");
   struct PtrAt {      // rowptr of local row i (wave-uniform i)
     int v, hi;
     __device__ __forceinline__ int operator()(int i) const {
@@ -331,6 +335,10 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
     } else {
       if (lane < cnt) my_col = __builtin_nontemporal_load(col + base + lane);
     }
+    float my_cs = 0.f;                         // CS: lane i holds the factor of the window's i-th source row
+    if constexpr (CS) {
+      if (lane < cnt) my_cs = ep.col_scale[my_col & kColMask];
+    }
     int k = 0;
     for (; k + U <= cnt; k += U) {
       float v[U][VEC];
@@ -344,8 +352,14 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
       for (int u = 0; u < U; ++u) {
         const int e = base + k + u;
         while (e == cur_end) flush();
+        if constexpr (CS) {
+          const float cs = __int_as_float(bcast_lane(__float_as_int(my_cs), k + u));
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
+          for (int i = 0; i < VEC; ++i) acc[i] += cs * v[u][i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
+        }
       }
     }
     if constexpr (P65) {
@@ -375,14 +389,20 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
       else zero<VEC>(v);
       const int e = base + k;
       while (e == cur_end) flush();
+      if constexpr (CS) {
+        const float cs = __int_as_float(bcast_lane(__float_as_int(my_cs), k));
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] += v[i];
+        for (int i = 0; i < VEC; ++i) acc[i] += cs * v[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += v[i];
+      }
     }
   }
   while (cur < rhi) flush();  // last row + trailing empty rows
 }
 
-template <int VEC, int RPW, int U, bool FULL, bool FUSED, typename HT, bool ACC = false, int GP = 0>
+template <int VEC, int RPW, int U, bool FULL, bool FUSED, typename HT, bool ACC = false, int GP = 0, bool CS = false>
 __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                    const HT* __restrict__ h, int64_t ld_h, float* __restrict__ out,
                                                    int64_t ld_out, int n_rows, int d, Epilogue ep, int hub_T, FusedEpi fe) {
@@ -413,7 +433,7 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
   const float* init_lane = ACC ? ep.acc_init + c0 : nullptr;
 
   if (hubmask == 0) {
-    stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP>(0, nr, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0,
+    stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP, 0, false, CS>(0, nr, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0,
                                                     init_lane, ep.ld_init, ep);
   } else {
     int r = 0;
@@ -421,7 +441,7 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
       unsigned long long m = hubmask >> r;
       int nh = m ? r + (__ffsll((long long)m) - 1) : nr;
       if (nh > r)
-        stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP>(r, nh, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe,
+        stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP, 0, false, CS>(r, nh, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe,
                                                         c0, init_lane, ep.ld_init, ep);
       r = nh + 1;
     }
@@ -429,7 +449,7 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
 }
 
 // One wavefront per chunk of T edges of a hub row -> one partial row in `partial`.
-template <int VEC, int U, typename HT, int GP = 0>
+template <int VEC, int U, typename HT, int GP = 0, bool CS = false>
 __global__ void __launch_bounds__(256) k_spmm_hub_chunks(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                          const HT* __restrict__ h, int64_t ld_h, int d, int hub_T,
                                                          int n_hubs, int n_chunks, const int* __restrict__ hub_rows,
@@ -457,6 +477,10 @@ __global__ void __launch_bounds__(256) k_spmm_hub_chunks(const int* __restrict__
     const int cnt = min(kWave, e_end - base);
     int my_col = 0;
     if (lane < cnt) my_col = __builtin_nontemporal_load(col + base + lane);
+    float my_cs = 0.f;
+    if constexpr (CS) {
+      if (lane < cnt) my_cs = ep.col_scale[my_col & kColMask];
+    }
     int k = 0;
     for (; k + U <= cnt; k += U) {
       float v[U][VEC];
@@ -468,8 +492,14 @@ __global__ void __launch_bounds__(256) k_spmm_hub_chunks(const int* __restrict__
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
+        if constexpr (CS) {
+          const float cs = __int_as_float(bcast_lane(__float_as_int(my_cs), k + u));
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
+          for (int i = 0; i < VEC; ++i) acc[i] += cs * v[u][i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
+        }
       }
     }
     for (; k < cnt; ++k) {
@@ -477,8 +507,14 @@ __global__ void __launch_bounds__(256) k_spmm_hub_chunks(const int* __restrict__
       float v[VEC];
       if (active) gather_pol<VEC, HT, GP>(v, h_lane, ld_h, c);
       else zero<VEC>(v);
+      if constexpr (CS) {
+        const float cs = __int_as_float(bcast_lane(__float_as_int(my_cs), k));
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] += v[i];
+        for (int i = 0; i < VEC; ++i) acc[i] += cs * v[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += v[i];
+      }
     }
   }
   if (active) {

@@ -11,6 +11,7 @@ import torch
 from . import _lib
 
 HUB_THRESHOLD = 256      # rows with more edges are reduced in chunks of this size by the hub kernels (64 / 128 / 512 / 1024 measured equal or slower)
+FWD0_ROWS_PER_EDGE = 0.25 # grad_support_plan keeps the forward orientation on the loss rows when S_1 has at least this many more rows than S_0 per edge between them (S-pl10M: 0.35)
 INT32_EDGE_LIMIT = 2 ** 31 - 1   # edge offsets (rowptr) and column ids are int32 on the device (include/coldbrew_hip.h); see CSRGraph.__init__
 HOT_BYTES = 256 << 20      # the hot source rows of an aggregation should fill the 256 MiB Infinity Cache: count = HOT_BYTES / row bytes
 HOT_ROWS = HOT_BYTES // 1024   # 262 144 rows at d = 256 fp32 (1 KiB rows): the measured optimum on S-pl10M (profiles/r02_spmm_gather_policy.md)
@@ -166,12 +167,30 @@ class CSRGraph:
                 dst = space_of(dst_mask)
                 rp_c = torch.cat([cnt.new_zeros(1), torch.cumsum(cnt[dst.idx], 0, dtype=torch.int32)])
                 plan.levels.append((CSRGraph.from_csr(rp_c, col_new, src.n, hub_threshold=self.hub_threshold), dst))
+                if len(plan.levels) == 1:
+                    plan.fwd0 = self._support_fwd0(src, dst)
                 src_mask, src = dst_mask, dst
             else:
                 plan.levels.append((CSRGraph.from_csr(rp_new, col_new, src.n, hub_threshold=self.hub_threshold), None))
                 break
         self._support_key, self._support_plan, self._support_mask = key, plan, keep
         return plan
+
+    def _support_fwd0(self, s0, s1):
+        """The FORWARD orientation restricted to the rows of S_0 (one row per member; its in-neighbours — all of them members of S_1 — keep
+        their global ids): (A (a * X))[S_0] = fwd0.spmm(X, col_scale=a).  With it the weight gradient of the level
+        X^T (a * A^T dY) is taken as ((A (a * X))[S_0])^T dY[S_0] — a contraction over |S_0| rows instead of |S_1| — and
+        a * (A^T dY) W^T as a * A^T (dY W^T): the GEMM on |S_0| rows in front of the aggregation (trunk.py).  Built when the rows spared
+        (|S_1| - |S_0|) outweigh the second pass over the level's edges (FWD0_ROWS_PER_EDGE), else None."""
+        rpf, colf = self.rowptr, self.col[:self.E]
+        deg0 = torch.index_select(rpf[1:] - rpf[:-1], 0, s0.idx)
+        rp_c = torch.cat([deg0.new_zeros(1), torch.cumsum(deg0, 0, dtype=torch.int32)])
+        e0 = int(rp_c[-1])
+        if (s1.n - s0.n) < FWD0_ROWS_PER_EDGE * e0 or e0 == 0:
+            return None
+        shift = torch.index_select(rpf, 0, s0.idx).long() - rp_c[:-1].long()          # CSR position minus packed position, per S_0 row
+        epos = torch.arange(e0, device=rpf.device) + torch.repeat_interleave(shift, deg0.long())
+        return CSRGraph.from_csr(rp_c, torch.index_select(colf, 0, epos), self.n_cols, hub_threshold=self.hub_threshold)
 
     def flagged_cols(self, transpose, row_bytes):
         """Flagged column ids for source rows of `row_bytes` bytes (None: flags off / small graph)."""
@@ -276,11 +295,16 @@ class CSRGraph:
         return self._ws
 
     # -- the aggregation ----------------------------------------------------------------
-    def spmm(self, h, transpose=False, row_scale=None, bias=None, relu=False, out=None, acc_init=None):
+    def spmm(self, h, transpose=False, row_scale=None, bias=None, relu=False, out=None, acc_init=None, col_scale=None):
         """out[v] = act(row_scale[v] * (acc_init[v] + sum_{u in row v} h[u]) + bias); by-dst CSR unless transpose.
-        acc_init (optional, fp32 [N, d]): partial sums of an earlier pass over other columns (node-sharded path)."""
+        acc_init (optional, fp32 [N, d]): partial sums of an earlier pass over other columns (node-sharded path).
+        col_scale (optional, fp32 [n_cols]; fp32 rows with d % 256 == 0, no bias / ReLU / acc_init): sum_u col_scale[u] * h[u]
+        (cb_spmm_csr_colscale_f32)."""
         lib = _lib.load()
-        _lib.require_device(h, row_scale, bias, out, acc_init)
+        _lib.require_device(h, row_scale, bias, out, acc_init, col_scale)
+        if col_scale is not None and (h.dtype != torch.float32 or h.shape[1] % 256 or bias is not None or relu or acc_init is not None
+                                      or col_scale.dtype != torch.float32 or col_scale.numel() != self.n_cols):
+            raise ValueError('spmm(col_scale=...): float32 rows with d % 256 == 0, one float32 factor per column, no bias / ReLU / acc_init')
         if h.dtype not in (torch.float32, torch.bfloat16):
             raise TypeError(f'aggregation expects float32 (or bf16-stored) features, got {h.dtype}')
         bf16 = h.dtype == torch.bfloat16
@@ -318,6 +342,12 @@ class CSRGraph:
                                                    self.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows),
                                                    _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
                            'cb_spmm_csr_acc_f32')
+            elif col_scale is not None:
+                _lib.check(lib.cb_spmm_csr_colscale_f32(_lib.ptr(rowptr), _lib.ptr(col), flags, self.N, self.E, _lib.ptr(h), ld_h, d,
+                                                        _lib.ptr(col_scale.contiguous()), _lib.ptr(row_scale), _lib.ptr(out), ld_o,
+                                                        self.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows),
+                                                        _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
+                           'cb_spmm_csr_colscale_f32')
             else:
                 _lib.check(fn(_lib.ptr(rowptr), _lib.ptr(col), flags, self.N, self.E, _lib.ptr(h), ld_h, d,
                               _lib.ptr(row_scale), _lib.ptr(bias), int(bool(relu)), _lib.ptr(out), ld_o,
@@ -620,7 +650,7 @@ class RowSpace:
 
 class RowSupportPlan:
     def __init__(self, space0, levels):
-        self.space0, self.levels = space0, levels
+        self.space0, self.levels, self.fwd0 = space0, levels, None
 
 
 def build_graph(edge_index, num_nodes=None):

@@ -245,6 +245,7 @@ def tail_trunk_bwd(graph):
 ROWSPARSE_MIN_NODES = 1 << 16      # below this a step is launch-bound and the extra check kernel costs more than the gather saves
 ROWSPARSE_SMALL_OK = False         # set by trainer.enable_hip_graph: under hipGraph replay the extra launches cost nothing, so small graphs take the plan too (S-pubmed config 2: 0.787 -> 0.751 ms/step)
 ROWSPARSE_S0_LIMIT = 0.7           # the plan is used while the loss rows are at most this share of the rows (S-pl10M with 50 % / 70 % loss rows: 187.9 / 193.2 ms against 195.4 / 196.3 dense)
+ROWSPARSE_LOSS_SIDE = True         # level 0 of the plan through the loss rows' side when the plan holds the orientation for it (graph.FWD0_ROWS_PER_EDGE)
 ROWSPARSE_MAX_FRAC = 0.7           # a level's output stays compact while its support is at most this share of the rows (S-arxiv, support 61 %: 3.53 -> 3.40 ms/step against 0.6)
 MIX_MAX = 7      # mixed-in gradients one cb_trunk_input_bwd_multi_f32 launch gathers (deeper trunks accumulate layer by layer)
 
@@ -517,7 +518,18 @@ class _TrunkFn(torch.autograd.Function):
                 grads_layers[3 * deferred[0]] = dw_layer(*deferred)
                 deferred = None
             g_fused = tb_fused = None
-            if ag_bwd:
+            # Level 0 through the loss rows' side (CSRGraph._support_fwd0): a * (A^T dY) W^T = a * A^T (dY W^T) and
+            # X^T (a * A^T dY) = ((A (a * X))[S_0])^T dY[S_0] — the GEMM and the weight gradient contract over |S_0| rows instead of |S_1|,
+            # dL/dZ_l itself is never formed (so not with a table gradient, which IS dL/dZ_l).  Same sums, associated differently.
+            loss_side = (ROWSPARSE_LOSS_SIDE and ag_bwd and dst is not None and L - 1 - l == 0 and plan.fwd0 is not None
+                         and not (le is not None and need[7 + 3 * l + 2]))
+            if loss_side:
+                level[0].profile = plan.fwd0.profile = getattr(graph, 'profile', None)
+                g_fused = level[0].spmm(gemm.mm_nn(gr, w.t().contiguous()), row_scale=dst.a)
+                if need[7 + 3 * l]:
+                    grads_layers[3 * l] = gemm.mm_tn(plan.fwd0.spmm(saved_in[l], col_scale=a), gr)
+                gz = None
+            elif ag_bwd:
                 # dL/dZ_l = A (b * dY') and a * (dL/dZ_l @ W_l^T) from one kernel (cb_spmm_gemm_f32); for l > 0 and tail_tb the trunk backward of
                 # layer l-1's store leaves the same epilogue (cb_spmm_gemm_trunkbwd_f32: no pass of its own over dL/dx_l).  Node-sharded: the
                 # kernel is the LAST halo pass of the reverse aggregation, on top of the running sums of the earlier passes.
@@ -547,7 +559,7 @@ class _TrunkFn(torch.autograd.Function):
                 gz = graph.aggregate_finish(handle, True) if sharded else _spmm_t(graph, gr)  # dL/dZ_l = A (b * dY')
             del g, gr
             handle = None
-            if need[7 + 3 * l]:
+            if need[7 + 3 * l] and not loss_side:
                 if sharded:
                     deferred = (l, saved_in[l], gz)
                 elif dst is not None:      # dL/dZ_l lives on S_{j+1}: X_l^T (a * dZ_l) over those rows (all others contribute zeros)

@@ -128,6 +128,14 @@ int cb_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags
                     int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
                     const int32_t* hub_rows, const int32_t* hub_chunk_ptr,
                     void* ws, size_t ws_bytes, void* stream);
+/* out[v, :] = row_scale[v] * sum_{u in row v} col_scale[u] * h[u, :] — a factor per SOURCE row, applied as the row is gathered
+ * (fp32 rows, d % 256 == 0, 16-byte aligned; col_scale: [number of columns]).  New: the row-sparse backward takes A (a * X_l) on the
+ * loss rows with it, i.e. the weight gradient X_l^T (a * A^T dY) of GCN.py:213,238 contracted over the loss rows as
+ * ((A (a * X_l))[S_0])^T dY[S_0] — without a scaled copy of X_l (trunk.py). */
+int cb_spmm_csr_colscale_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E,
+                             const float* h, int64_t ld_h, int64_t d, const float* col_scale, const float* row_scale,
+                             float* out, int64_t ld_out, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
+                             const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream);
 
 
 /* ------------------------------------------------------------------------------------

@@ -43,13 +43,21 @@ def _step_grads(flag, dataset='S-pl1M', se='000', layers=3):
             os.environ['CB_LOSS_ROWS'] = old
 
 
-@pytest.mark.parametrize('max_frac,se', [(0.6, '000'), (0.0, '000'), (0.6, '111')])
-def test_row_sparse_backward_equals_the_dense_backward(max_frac, se, monkeypatch):
+@pytest.mark.parametrize('max_frac,se,loss_side', [(0.6, '000', True), (0.6, '000', False), (0.0, '000', True), (0.6, '111', True)])
+def test_row_sparse_backward_equals_the_dense_backward(max_frac, se, loss_side, monkeypatch):
     """max_frac 0.6: the supports S_0 (10 % of the rows) and S_1 (45 %) compact, from S_2 (94 %) on dense; 0: only the gathered side of the
-    first aggregation compact.  se 111: structural-embedding tables, whose gradient dL/dZ_l is scattered from the compact level to all rows."""
+    first aggregation compact.  se 111: structural-embedding tables, whose gradient dL/dZ_l is scattered from the compact level to all rows.
+    loss_side: level 0's GEMM and weight gradient contracted over the loss rows (plan.fwd0) — not with a table gradient, not at max_frac 0."""
     from gnn_tail_generalization_amd import trunk
     monkeypatch.setattr(trunk, 'ROWSPARSE_MAX_FRAC', max_frac)
+    monkeypatch.setattr(trunk, 'ROWSPARSE_LOSS_SIDE', loss_side)
+    spmm_rows = []
+    from gnn_tail_generalization_amd.graph import CSRGraph
+    real = CSRGraph.spmm
+    monkeypatch.setattr(CSRGraph, 'spmm', lambda self, h, *a, **k: (spmm_rows.append((self.N, self.n_cols)), real(self, h, *a, **k))[1])
     loss_s, g_s, used_s = _step_grads('1', se=se)
+    took_loss_side = any(n < c for n, c in spmm_rows)  # fwd0: one row per loss row, all columns
+    assert took_loss_side == (loss_side and max_frac > 0 and se == '000')
     loss_d, g_d, used_d = _step_grads('0', se=se)
     assert used_s and not used_d                       # the 10 % train mask of the stand-in: the plan was built and used
     assert loss_s == loss_d
@@ -129,6 +137,16 @@ def test_support_plan_levels_are_the_reverse_graph_restricted_and_renumbered():
     rows = torch.repeat_interleave(torch.arange(G.N, device=DEV), rp[1:] - rp[:-1])
     assert torch.equal(plan.space0.idx, keep.nonzero().flatten())
     assert plan.levels[-1][1] is None and len(plan.levels) <= 3                   # the plan ends with a dense destination
+    # the forward orientation on the loss rows: (A (a * X))[S_0] with the factor of a source row applied as it is gathered
+    assert plan.fwd0 is not None and plan.fwd0.N == plan.space0.n and plan.fwd0.n_cols == G.N
+    xf = torch.randn(G.N, 256, device=DEV)
+    want = G.spmm(xf * G.norm_out.unsqueeze(1))[plan.space0.idx]
+    got = plan.fwd0.spmm(xf, col_scale=G.norm_out)
+    assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    got_rs = plan.fwd0.spmm(xf, col_scale=G.norm_out, row_scale=plan.space0.a)
+    assert float((got_rs - want * plan.space0.a.unsqueeze(1)).abs().max()) <= 2e-6 * float(want.abs().max())
+    with pytest.raises(ValueError):
+        plan.fwd0.spmm(xf[:, :64].contiguous(), col_scale=G.norm_out)
     src_mask, src, h_full = keep, plan.space0, None
     h_full = torch.randn(G.N, 256, device=DEV) * keep.float().unsqueeze(1)       # a matrix supported on S_0
     h_c = h_full[src.idx].contiguous()
