@@ -111,6 +111,56 @@ def test_row_sparse_backward_matches_the_unmodified_reference(monkeypatch):
         torch.testing.assert_close(got[k].cpu(), ref, atol=2e-5, rtol=2e-4, msg=lambda m, k=k: f'{k}: {m}')
 
 
+@pytest.mark.parametrize('loss_side', [True, False])
+def test_row_sparse_backward_on_a_directed_multigraph(loss_side, monkeypatch):
+    """A DIRECTED graph with repeated edges (the reverse orientation is a CSR of its own, plan.fwd0 is cut from the forward one): the
+    row-sparse backward — both forms of level 0 — against the dense backward of the same model, dropout on."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    from conftest import load_golden
+    from helpers import product_model
+    from gnn_tail_generalization_amd import _lib, ops, trunk
+    monkeypatch.setattr(trunk, 'ROWSPARSE_MIN_NODES', 0)
+    monkeypatch.setattr(trunk, 'ROWSPARSE_LOSS_SIDE', loss_side)
+    g = load_golden('case_r_initialbn_h256_L3_train10')
+    cfg = dict(g['cfg'], dropout=0.3)
+    n = cfg['N_nodes']
+    gen = torch.Generator().manual_seed(5)
+    src = torch.randint(0, n, (6 * n,), generator=gen)
+    dst = (torch.rand(6 * n, generator=gen) ** 3 * n).long()                       # skewed in-degrees
+    ei = torch.cat([torch.stack([src, dst]), torch.stack([src[:200], dst[:200]]),    # + repeated edges
+                    torch.arange(n).repeat(2, 1)], 1).to(DEV)                        # + self-loops: no zero in-degree
+    x, y = g['x'].to(DEV), g['y'].to(DEV)
+    mask = torch.zeros(n, dtype=torch.bool, device=DEV)
+    perm = torch.randperm(n, generator=gen)
+    mask[perm[perm >= 40][:24]] = True                                              # (no top hub among the loss rows: supports 24 / 94 / 256 of 400 rows)
+    grads, losses, used = {}, {}, {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('CB_LOSS_ROWS', flag)
+        args, model = product_model(cfg, g['sd'], DEV)
+        model.train()
+        ops._seed_override[:] = [21, 22, 23, 24, 25]
+        try:
+            out = model.get_3_embs(x, ei, mask).emb4classi_full
+            loss = ops.nll_logsoftmax(out, y, mask)
+            loss.backward()
+        finally:
+            ops._seed_override[:] = []
+        torch.cuda.synchronize()
+        assert _lib.load().cb_device_status() == 0
+        graph = model.model.model._graph(ei)
+        assert not graph.symmetric
+        plan = getattr(graph, '_support_plan', None)
+        used[flag] = plan is not None
+        if flag == '1':
+            assert plan is not None and plan.levels[0][1] is not None and plan.fwd0 is not None
+        losses[flag] = float(loss.detach())
+        grads[flag] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    assert used == {'1': True, '0': False} and losses['1'] == losses['0'] and set(grads['1']) == set(grads['0'])
+    for k, ref in grads['0'].items():
+        assert float((grads['1'][k] - ref).abs().max()) <= 5e-6 * float(ref.abs().max()), k
+
+
 def test_row_sparse_backward_at_the_headline_size():
     """S-pl10M (10^7 nodes, 10^8 edges): one training step's gradients, row-sparse (supports 10 % / 45 % compact, then dense) against dense."""
     import gc
