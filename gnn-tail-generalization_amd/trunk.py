@@ -483,8 +483,10 @@ class _TrunkFn(torch.autograd.Function):
         # word, never in silent wrong gradients).  One GPU, hidden 256, gathered per-layer gradients, loss rows <= 70 % of the nodes.
         rows_hint = ops.take_grad_rows(gout) if (not sharded and hasattr(graph, 'grad_support_plan') and graph.rowptr_t is not None) else None
         plan = None
-        if (rows_hint is not None and 1 <= rows_hint[1] <= ROWSPARSE_S0_LIMIT * gout.shape[0] and (gout.shape[0] >= ROWSPARSE_MIN_NODES or ROWSPARSE_SMALL_OK) and gather and ag_bwd
-                and not tail_tb and not agg_bf16):
+        # (with bf16-stored rows the compact levels still run on fp32 matrices through the aggregation + GEMM kernel; the dense levels below
+        # them go on as the bf16 path does)
+        if (rows_hint is not None and 1 <= rows_hint[1] <= ROWSPARSE_S0_LIMIT * gout.shape[0] and (gout.shape[0] >= ROWSPARSE_MIN_NODES or ROWSPARSE_SMALL_OK) and gather
+                and agg_gemm_eligible(graph, h, False) and not tail_tb):
             ops.check_rows_zero(gout, rows_hint[0])
             plan = graph.grad_support_plan(rows_hint[0], L, max_frac=ROWSPARSE_MAX_FRAC)
         space = None                                                             # row space of g / gr (None: all rows)
@@ -521,7 +523,7 @@ class _TrunkFn(torch.autograd.Function):
             # Level 0 through the loss rows' side (CSRGraph._support_fwd0): a * (A^T dY) W^T = a * A^T (dY W^T) and
             # X^T (a * A^T dY) = ((A (a * X))[S_0])^T dY[S_0] — the GEMM and the weight gradient contract over |S_0| rows instead of |S_1|,
             # dL/dZ_l itself is never formed (so not with a table gradient, which IS dL/dZ_l).  Same sums, associated differently.
-            loss_side = (ROWSPARSE_LOSS_SIDE and ag_bwd and dst is not None and L - 1 - l == 0 and plan.fwd0 is not None
+            loss_side = (ROWSPARSE_LOSS_SIDE and dst is not None and L - 1 - l == 0 and plan.fwd0 is not None
                          and not (le is not None and need[7 + 3 * l + 2]))
             if loss_side:
                 level[0].profile = plan.fwd0.profile = getattr(graph, 'profile', None)
@@ -529,7 +531,7 @@ class _TrunkFn(torch.autograd.Function):
                 if need[7 + 3 * l]:
                     grads_layers[3 * l] = gemm.mm_tn(plan.fwd0.spmm(saved_in[l], col_scale=a), gr)
                 gz = None
-            elif ag_bwd:
+            elif ag_bwd or level is not None:
                 # dL/dZ_l = A (b * dY') and a * (dL/dZ_l @ W_l^T) from one kernel (cb_spmm_gemm_f32); for l > 0 and tail_tb the trunk backward of
                 # layer l-1's store leaves the same epilogue (cb_spmm_gemm_trunkbwd_f32: no pass of its own over dL/dx_l).  Node-sharded: the
                 # kernel is the LAST halo pass of the reverse aggregation, on top of the running sums of the earlier passes.
