@@ -100,6 +100,9 @@ case('r_initialbn_se111_L3_powerlaw', dataset='Pubmed', se='111', h=32, layers=3
 # the benchmark's shape in small: hidden 256 (the fused trunk and its aggregation + GEMM kernels), 3 layers, a 10 % train mask on a power-law graph —
 # the masked loss's gradient is zero outside the train rows, which the product's row-sparse backward exploits (tests/test_gpu_rowsparse.py)
 case('r_initialbn_h256_L3_train10', dataset='Pubmed', se='000', f=32, h=256, layers=3, graph='powerlaw', n=400, train_frac=0.1)
+# the same with structural-embedding tables on every layer (the reference's own mode): a compact level of the row-sparse backward scatters the
+# table gradient dL/dZ_l into all rows and keeps the first form of its level 0
+case('r_initialbn_h256_L3_train10_se111', dataset='Pubmed', se='111', f=32, h=256, layers=3, graph='powerlaw', n=300, train_frac=0.1)
 for _t in ['Residual', 'Initial']:
     case(f'r_{_t.lower()}_L3', force_best=0, type_trick=_t, layers=3, se='111')
 for _agg in ['concat', 'maxpool', 'attention']:
