@@ -339,6 +339,25 @@ __global__ void __launch_bounds__(kBlock) k_gather_rows(const float* __restrict_
   }
 }
 
+// out[r, :] = pos[r] >= 0 ? src[pos[r], :] : 0 — the inverse of the row pack: a compact [n, d] matrix over a row subset written back to all
+// N rows in one pass (the table gradient dL/dZ_l of a compact level of the row-sparse backward, trunk.py).  float4 rows.
+__global__ void __launch_bounds__(kBlock) k_expand_rows(const float* __restrict__ src, const int* __restrict__ pos, int64_t n_rows, int d,
+                                                        float* __restrict__ out) {
+  const int q = d >> 2;
+  const int64_t total = n_rows * q;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / q;
+    const int c = (int)(i - r * q) * 4;
+    const int p = pos[r];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p >= 0) v = *reinterpret_cast<const float4*>(src + (int64_t)p * d + c);
+    __builtin_nontemporal_store(v.x, out + r * d + c);
+    __builtin_nontemporal_store(v.y, out + r * d + c + 1);
+    __builtin_nontemporal_store(v.z, out + r * d + c + 2);
+    __builtin_nontemporal_store(v.w, out + r * d + c + 3);
+  }
+}
+
 // The same row pack with the rows narrowed to bf16 (round-to-nearest-even) on their way out: the bf16 halo wire of the node-sharded
 // exchange leaves the pack kernel ready to send (no separate conversion pass over the packed rows).
 __global__ void __launch_bounds__(kBlock) k_gather_rows_bf16(const float* __restrict__ src, int64_t ld, const int64_t* __restrict__ idx,
@@ -583,6 +602,7 @@ struct AdamTable {
   float* v[kAdamMax];
   int64_t n[kAdamMax];
   const float* c[kAdamMax];   // per-tensor extra L2 coefficient read from device memory (null: none), added to weight_decay
+  float* sq[kAdamMax];        // per-tensor partial sums of squares of the UPDATED parameter, one float per block of the launch (null: not wanted)
 };
 
 __global__ void __launch_bounds__(kBlock) k_adam_multi(AdamTable t, float lr, float b1, float b2, float eps, float wd, float bc1,
@@ -605,6 +625,7 @@ __global__ void __launch_bounds__(kBlock) k_adam_multi(AdamTable t, float lr, fl
   }
   const bool vec_ok = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) == 0;
   const int64_t nq = (n + 3) / 4;
+  float ssq = 0.f;      // sum of squares of the updated values this thread wrote: k_sumsq's thread-to-element map and summation order
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = q * 4;
     float pv[4], gv[4], mv[4], vv[4];
@@ -634,9 +655,21 @@ __global__ void __launch_bounds__(kBlock) k_adam_multi(AdamTable t, float lr, fl
       *reinterpret_cast<float4*>(p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
       *reinterpret_cast<float4*>(m + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
       *reinterpret_cast<float4*>(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      ssq += pv[0] * pv[0] + pv[1] * pv[1] + pv[2] * pv[2] + pv[3] * pv[3];
     } else {
       for (int k = 0; k < 4; ++k)
-        if (i + k < n) { p[i + k] = pv[k]; m[i + k] = mv[k]; v[i + k] = vv[k]; }
+        if (i + k < n) { p[i + k] = pv[k]; m[i + k] = mv[k]; v[i + k] = vv[k]; ssq += pv[k] * pv[k]; }
+    }
+  }
+  if (t.sq[ti]) {      // (uniform over the block) ||p||_F^2 of the updated tensor as k_sumsq would leave it: the next forward's th.norm(le) for free
+    __shared__ float s_w[kBlock / kWave];
+    for (int off = 32; off > 0; off >>= 1) ssq += __shfl_xor(ssq, off);
+    if (lane_id() == 0) s_w[threadIdx.x >> 6] = ssq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tt = 0.f;
+      for (int w = 0; w < kBlock / kWave; ++w) tt += s_w[w];
+      t.sq[ti][blockIdx.x] = tt;
     }
   }
 }
@@ -792,11 +825,20 @@ extern "C" int cb_adam_step_f32(float* p, const float* g, float* m, float* v, in
   return CB_OK;
 }
 
-extern "C" int cb_adam_multi_f32(int32_t n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
-                                 const int64_t* numel, const float* const* extra_decay, float lr, float beta1, float beta2, float eps,
-                                 float weight_decay, int64_t step, const int64_t* step_dev, void* stream) {
+extern "C" size_t cb_adam_norm_workspace_bytes(int32_t n_norms) { return (size_t)(n_norms > 0 ? n_norms : 0) * cb_reduce_workspace_bytes(); }
+
+extern "C" int cb_adam_multi_norm_f32(int32_t n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                                      const int64_t* numel, const float* const* extra_decay, float* const* norm_out, float lr, float beta1,
+                                      float beta2, float eps, float weight_decay, int64_t step, const int64_t* step_dev, void* ws,
+                                      size_t ws_bytes, void* stream) {
   CB_CHECK_ARG(n_tensors >= 0 && (step >= 1 || step_dev) && (n_tensors == 0 || (p && g && m && v && numel)), CB_E_INVALID,
                "cb_adam_multi_f32: bad argument");
+  int n_norms = 0;
+  if (norm_out)
+    for (int i = 0; i < n_tensors; ++i) n_norms += norm_out[i] != nullptr;
+  CB_CHECK_ARG(n_norms == 0 || (ws && ws_bytes >= cb_adam_norm_workspace_bytes(n_norms)), CB_E_WORKSPACE,
+               "cb_adam_multi_norm_f32: workspace too small for %d norms", n_norms);
+  int norm_slot = 0;
   if (step < 1) step = 1;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -809,14 +851,29 @@ extern "C" int cb_adam_multi_f32(int32_t n_tensors, float* const* p, const float
                    "cb_adam_multi_f32: null tensor %d", base + i);
       t.p[i] = p[base + i]; t.g[i] = g[base + i]; t.m[i] = m[base + i]; t.v[i] = v[base + i]; t.n[i] = numel[base + i];
       t.c[i] = extra_decay ? extra_decay[base + i] : nullptr;
+      if (norm_out && norm_out[base + i]) t.sq[i] = (float*)ws + (size_t)(norm_slot++) * kMaxBlocks;
       if (t.n[i] > nmax) nmax = t.n[i];
     }
-    if (nmax == 0) continue;
-    hipLaunchKernelGGL(k_adam_multi, dim3((unsigned)grid_for((nmax + 3) / 4), (unsigned)cnt), dim3(kBlock), 0, (hipStream_t)stream, t, lr,
-                       beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), step_dev);
-    CB_LAUNCH_CHECK();
+    const int nb = nmax ? grid_for((nmax + 3) / 4) : 0;
+    if (nb) {
+      hipLaunchKernelGGL(k_adam_multi, dim3((unsigned)nb, (unsigned)cnt), dim3(kBlock), 0, (hipStream_t)stream, t, lr,
+                         beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), step_dev);
+      CB_LAUNCH_CHECK();
+    }
+    for (int i = 0; i < cnt; ++i)      // out[0] = ||p||_F, out[1] = ||p||_F^2 (cb_frobenius_norm_f32's pair) of every tensor that asked
+      if (t.sq[i]) {
+        hipLaunchKernelGGL(k_norm_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)t.sq[i], nb, norm_out[base + i]);
+        CB_LAUNCH_CHECK();
+      }
   }
   return CB_OK;
+}
+
+extern "C" int cb_adam_multi_f32(int32_t n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                                 const int64_t* numel, const float* const* extra_decay, float lr, float beta1, float beta2, float eps,
+                                 float weight_decay, int64_t step, const int64_t* step_dev, void* stream) {
+  return cb_adam_multi_norm_f32(n_tensors, p, g, m, v, numel, extra_decay, nullptr, lr, beta1, beta2, eps, weight_decay, step, step_dev, nullptr, 0,
+                                stream);
 }
 
 static int launch_trunk_bwd(int mode, int out_bf16, const float* g, const uint64_t* bits, const float* act, const float* row_scale,
@@ -944,6 +1001,16 @@ extern "C" int cb_gather_rows_f32(const float* src, int64_t ld, const int64_t* i
   const int vec_ok = aligned16(src) && aligned16(out) && d % 4 == 0 && ld % 4 == 0;
   const int64_t work = vec_ok ? n_idx * (d / 4) : n_idx * d;
   hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(work)), dim3(kBlock), 0, (hipStream_t)stream, src, ld, idx, n_idx, (int)d, out, vec_ok);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
+extern "C" int cb_expand_rows_f32(const float* src, const int32_t* pos, int64_t n_rows, int64_t d, float* out, void* stream) {
+  CB_CHECK_ARG(n_rows >= 0 && d >= 0 && d < (1 << 24), CB_E_INVALID, "cb_expand_rows_f32: bad size");
+  if (n_rows == 0 || d == 0) return CB_OK;
+  CB_CHECK_ARG(pos && out, CB_E_INVALID, "cb_expand_rows_f32: null pointer");
+  CB_CHECK_ARG(d % 4 == 0 && aligned16(out) && (!src || aligned16(src)), CB_E_INVALID, "cb_expand_rows_f32: 16-byte aligned rows with d %% 4 == 0 expected");
+  hipLaunchKernelGGL(k_expand_rows, dim3(grid_for(n_rows * (d / 4))), dim3(kBlock), 0, (hipStream_t)stream, src, pos, n_rows, (int)d, out);
   CB_LAUNCH_CHECK();
   return CB_OK;
 }

@@ -194,16 +194,19 @@ def aggregate(graph, h, row_scale=None, bias=None, relu=False, edge_weight=None)
 # ---------------------------------------------------------------------------------------------
 class _FrobeniusFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
-        lib = _lib.load()
-        xc = _c(x)
-        out2 = torch.empty(2, dtype=torch.float32, device=x.device)
-        wsb = lib.cb_reduce_workspace_bytes()
-        ws = _ws(wsb, x.device)
-        with torch.cuda.device(x.device):
-            _lib.check(lib.cb_frobenius_norm_f32(_lib.ptr(xc), xc.numel(), _lib.ptr(out2), _lib.ptr(ws), wsb,
-                                                 _lib.stream_ptr()), 'cb_frobenius_norm_f32')
-        norm = out2[0]
+    def forward(ctx, x, known):
+        if known is not None:      # left by the fused Adam when it wrote x (optim.Adam.step): no pass over the table
+            norm = known[0].clone()
+        else:
+            lib = _lib.load()
+            xc = _c(x)
+            out2 = torch.empty(2, dtype=torch.float32, device=x.device)
+            wsb = lib.cb_reduce_workspace_bytes()
+            ws = _ws(wsb, x.device)
+            with torch.cuda.device(x.device):
+                _lib.check(lib.cb_frobenius_norm_f32(_lib.ptr(xc), xc.numel(), _lib.ptr(out2), _lib.ptr(ws), wsb,
+                                                     _lib.stream_ptr()), 'cb_frobenius_norm_f32')
+            norm = out2[0]
         ctx.save_for_backward(x, norm)
         return norm.clone()
 
@@ -211,12 +214,39 @@ class _FrobeniusFn(torch.autograd.Function):
     def backward(ctx, g):
         x, norm = ctx.saved_tensors
         # d||x||/dx = x / ||x||; 0 at x = 0 (the subgradient torch.norm's backward picks), not NaN
-        return x * torch.where(norm > 0, g / norm, torch.zeros_like(norm))
+        return x * torch.where(norm > 0, g / norm, torch.zeros_like(norm)), None
+
+
+# Norms the fused Adam left behind: parameter._cb_norm = (parameter._version at that time, [2] device tensor {||p||_F, ||p||_F^2}).  The Adam kernel
+# computes the sum of squares of the values it writes (cb_adam_multi_norm_f32) for every parameter whose norm a forward has asked for
+# (`_cb_want_norm`), so the next forward's th.norm(le) (GCN.py:232) reads two floats instead of the table.  An entry is trusted only while
+# the parameter's version counter is the one recorded — every torch in-place write (load_state_dict, copy_, another optimiser) bumps it —,
+# never during a hipGraph capture, and never for a parameter a captured graph updates behind Python's back (`_cb_norm_off`).
+# (A write through `p.data` has a version counter of its own and is not seen: code that edits a table that way calls forget_norms.)
+ADAM_NORMS = True
+
+
+def forget_norms(module_or_params):
+    """Drops the norms the fused Adam left for these parameters (after writing them through a path that does not bump their version)."""
+    params = module_or_params.parameters() if hasattr(module_or_params, 'parameters') else module_or_params
+    for p in params:
+        p._cb_norm = None
+
+
+def known_norm(x):
+    if not ADAM_NORMS or getattr(x, '_cb_norm_off', False) or torch.cuda.is_current_stream_capturing():
+        return None
+    hit = getattr(x, '_cb_norm', None)
+    return hit[1] if hit is not None and hit[0] == x._version else None
 
 
 def frobenius_norm(x):
     _lib.require_device(x)
-    return _FrobeniusFn.apply(x)
+    known = None
+    if isinstance(x, torch.nn.Parameter) and x.is_leaf:
+        x._cb_want_norm = True
+        known = known_norm(x)
+    return _FrobeniusFn.apply(x, known)
 
 
 def fold_se_reg(model, optimizer, coef, se_reg_all):
@@ -391,6 +421,21 @@ def gather_rows_by_index(x, idx, out_bf16=False):
     with torch.cuda.device(x.device):
         _lib.check(fn(_lib.ptr(x), x.stride(0) if x.shape[0] > 1 else x.shape[1], _lib.ptr(idx), idx.numel(),
                       x.shape[1], _lib.ptr(out), _lib.stream_ptr()), 'cb_gather_rows_f32')
+    return out
+
+
+def expand_rows(src, pos):
+    """[len(pos), d] matrix whose row r is src[pos[r]] where pos[r] >= 0 and zero elsewhere (cb_expand_rows_f32): a compact matrix over a
+    row subset (graph.RowSpace: pos int32 [N]) written back to all rows."""
+    lib = _lib.load()
+    _lib.require_device(src, pos)
+    if src.dtype != torch.float32 or src.dim() != 2 or src.shape[1] % 4 or pos.dtype != torch.int32:
+        raise ValueError('expand_rows: float32 [n, d] matrix with d % 4 == 0 and an int32 position vector expected')
+    src = src.contiguous()
+    out = torch.empty((pos.numel(), src.shape[1]), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        _lib.check(lib.cb_expand_rows_f32(_lib.ptr(src), _lib.ptr(pos.contiguous()), pos.numel(), src.shape[1], _lib.ptr(out), _lib.stream_ptr()),
+                   'cb_expand_rows_f32')
     return out
 
 

@@ -55,9 +55,12 @@ class Adam(torch.optim.Optimizer):
         if self._step_dev is not None:
             self._step_dev.add_(1)         # captured: every replay advances the device-resident count
         import ctypes
+        from . import ops
+        capturing = torch.cuda.is_current_stream_capturing()
         for group in self.param_groups:
             b1, b2 = group['betas']
             ps, gs, ms, vs, ns, cs, keep, step = [], [], [], [], [], [], [], None
+            qs, wanted = [], []        # per tensor: the [2] device buffer that receives ||p||_F of the updated tensor (None: not asked for)
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -74,6 +77,9 @@ class Adam(torch.optim.Optimizer):
                 if step is None:
                     step = st['step']
                 extra = self._extra_decay.get(p)
+                p._cb_norm = None                      # p changes below: whatever norm was known is of the old values
+                if capturing:
+                    p._cb_norm_off = True              # replays of this graph will update p without Python seeing it
                 if st['step'] != step or p.device != group['params'][0].device:
                     # tensors that joined later (own bias correction) or live elsewhere: one launch of their own
                     one = lambda t, ty=ctypes.c_void_p: (ty * 1)(t)       # noqa: E731
@@ -87,17 +93,27 @@ class Adam(torch.optim.Optimizer):
                 ps.append(p.data_ptr()); gs.append(g.data_ptr()); ms.append(st['exp_avg'].data_ptr())
                 vs.append(st['exp_avg_sq'].data_ptr()); ns.append(p.numel())
                 cs.append(extra.data_ptr() if extra is not None else None)
+                norm = None
+                if getattr(p, '_cb_want_norm', False) and not capturing and not getattr(p, '_cb_norm_off', False):
+                    norm = torch.empty(2, dtype=torch.float32, device=p.device)
+                    wanted.append((p, norm))
+                qs.append(norm.data_ptr() if norm is not None else None)
                 keep.append(g)                               # contiguous copies stay alive until the launch below
             if ps:
                 n = len(ps)
                 arr = lambda vals, ty: (ty * n)(*vals)       # noqa: E731
+                wsb = lib.cb_adam_norm_workspace_bytes(len(wanted))
+                ws = ops._ws(wsb, group['params'][0].device) if wsb else None
                 with torch.cuda.device(group['params'][0].device):
-                    _lib.check(lib.cb_adam_multi_f32(n, arr(ps, ctypes.c_void_p), arr(gs, ctypes.c_void_p), arr(ms, ctypes.c_void_p),
-                                                     arr(vs, ctypes.c_void_p), arr(ns, ctypes.c_int64),
-                                                     arr(cs, ctypes.c_void_p) if any(c is not None for c in cs) else None,
-                                                     group['lr'], b1, b2, group['eps'],
-                                                     group['weight_decay'], step, _lib.ptr(self._step_dev), _lib.stream_ptr()),
-                               'cb_adam_multi_f32')
+                    _lib.check(lib.cb_adam_multi_norm_f32(n, arr(ps, ctypes.c_void_p), arr(gs, ctypes.c_void_p), arr(ms, ctypes.c_void_p),
+                                                          arr(vs, ctypes.c_void_p), arr(ns, ctypes.c_int64),
+                                                          arr(cs, ctypes.c_void_p) if any(c is not None for c in cs) else None,
+                                                          arr(qs, ctypes.c_void_p) if wanted else None,
+                                                          group['lr'], b1, b2, group['eps'],
+                                                          group['weight_decay'], step, _lib.ptr(self._step_dev), _lib.ptr(ws), wsb, _lib.stream_ptr()),
+                               'cb_adam_multi_norm_f32')
+                for p, norm in wanted:
+                    p._cb_norm = (p._version, norm)
                 del keep
         # one-shot: a coefficient belongs to the step whose forward wrote it (ops.fold_se_reg rewrites it every step); a later step()
         # after a different loss must not apply a stale one

@@ -581,9 +581,7 @@ class _TrunkFn(torch.autograd.Function):
                 g = g_fused if g_fused is not None else gemm.mm_nn(gz, w.t().contiguous(), rowscale=a)   # dL/d(dropped X_0): consumed by the input stage
             if le is not None and need[7 + 3 * l + 2]:
                 if dst is not None:      # the table's gradient is dL/dZ_l on ALL rows: the support's rows, zeros elsewhere
-                    gz_all = torch.zeros((x0.shape[0], gz.shape[1]), dtype=gz.dtype, device=gz.device)
-                    gz_all.index_copy_(0, dst.idx, gz)
-                    gz = gz_all
+                    gz = ops.expand_rows(gz, dst.pos)
                 grads_layers[3 * l + 2] = gz
             else:
                 del gz

@@ -190,6 +190,14 @@ int cb_adam_multi_f32(int32_t n_tensors, float* const* p, const float* const* g,
                       const float* const* extra_decay, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                       const int64_t* step_dev, void* stream);
 /* step_dev (may be NULL): the step count read from device memory instead of `step` (hipGraph replay). */
+/* The same, and for every tensor with norm_out[i] != NULL also norm_out[i][0] = ||p_i||_F, [1] = ||p_i||_F^2 of the UPDATED tensor
+ * (cb_frobenius_norm_f32's pair, same thread-to-element map and summation order when the tensor is the largest of its launch): the
+ * next forward's `th.norm(self.le)` (GCN.py:232) costs no pass of its own over the table.  ws: cb_adam_norm_workspace_bytes(number of
+ * non-NULL entries). */
+size_t cb_adam_norm_workspace_bytes(int32_t n_norms);
+int cb_adam_multi_norm_f32(int32_t n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* numel,
+                           const float* const* extra_decay, float* const* norm_out, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, int64_t step, const int64_t* step_dev, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Dense fp32 contractions on the matrix cores.  Default: every fp32 operand is decomposed exactly into three
@@ -517,6 +525,10 @@ int cb_spmm_csr_lp_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int
 
 /* The same pack with the rows narrowed to bf16 (round-to-nearest-even) as they are written: the send buffer of the bf16 halo wire. */
 int cb_gather_rows_bf16_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, uint16_t* out, void* stream);
+/* out[r, :] = pos[r] >= 0 ? src[pos[r], :] : 0 for r < n_rows (contiguous [n, d] src and [n_rows, d] out, d % 4 == 0): a matrix over a
+ * row subset written back to all rows in one pass — the gradient of a structural-embedding table (dL/dZ_l, GCN.py:230-232) when the level
+ * of the row-sparse backward that produces it is compact (trunk.py). */
+int cb_expand_rows_f32(const float* src, const int32_t* pos, int64_t n_rows, int64_t d, float* out, void* stream);
 
 #ifdef __cplusplus
 }

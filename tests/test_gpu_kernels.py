@@ -217,6 +217,57 @@ def test_fused_adam_extra_decay_is_the_frobenius_regulariser_gradient():
         torch.testing.assert_close(m.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-6)
 
 
+def test_fused_adam_leaves_the_norm_of_what_it_wrote():
+    """A parameter whose Frobenius norm a forward has asked for (ops.frobenius_norm on a leaf Parameter: GCN.py:232's th.norm(self.le)) gets the
+    norm of its UPDATED values from the Adam kernel itself (cb_adam_multi_norm_f32); the next ops.frobenius_norm reads it instead of the table:
+    the same bits as the stand-alone reduction for the largest tensor of the launch, the same update as without it, and it is not
+    trusted once torch has written the parameter."""
+    from gnn_tail_generalization_amd import ops
+    from gnn_tail_generalization_amd.optim import Adam
+    shapes = [(3000, 256), (77,), (3000, 256), (513, 256)]
+    mk = lambda: [torch.nn.Parameter(_rand(*s, seed=70 + i).to(DEV)) for i, s in enumerate(shapes)]      # noqa: E731
+    with_norm, without = mk(), mk()
+    opt_a, opt_b = Adam(with_norm, lr=0.01, weight_decay=5e-4), Adam(without, lr=0.01, weight_decay=5e-4)
+    for p in (with_norm[0], with_norm[2], with_norm[3]):
+        first = ops.frobenius_norm(p)                                   # computed: nothing known yet
+        torch.testing.assert_close(first, p.detach().norm(), rtol=1e-6, atol=0)
+    calls = []
+    lib_norm = ops._lib.load().cb_frobenius_norm_f32
+    for step in range(1, 4):
+        for i, s in enumerate(shapes):
+            g = _rand(*s, seed=500 * step + i).to(DEV)
+            with_norm[i].grad, without[i].grad = g, g.clone()
+        opt_a.step()
+        opt_b.step()
+        for a, b in zip(with_norm, without):
+            assert torch.equal(a.detach(), b.detach())                   # the update does not depend on the by-product
+        assert getattr(with_norm[1], '_cb_norm', None) is None          # never asked for
+        for i in (0, 2, 3):
+            p = with_norm[i]
+            known = ops.known_norm(p)
+            assert known is not None
+            alone = torch.empty(2, device=DEV)
+            ws = ops._ws(ops._lib.load().cb_reduce_workspace_bytes(), p.device)
+            ops._lib.check(lib_norm(ops._lib.ptr(p.detach()), p.numel(), ops._lib.ptr(alone), ops._lib.ptr(ws), ws.numel(), ops._lib.stream_ptr()), 'norm')
+            if i != 3:                                                   # largest tensors of the launch: k_sumsq's own thread map, bit for bit
+                assert torch.equal(known, alone)
+            torch.testing.assert_close(known, alone, rtol=1e-6, atol=0)
+            assert torch.equal(ops.frobenius_norm(p).detach(), known[0])
+    p = with_norm[0]
+    with torch.no_grad():
+        p.mul_(2.0)                                                      # torch wrote it: the known norm is of other values
+    assert ops.known_norm(p) is None
+    torch.testing.assert_close(ops.frobenius_norm(p).detach(), p.detach().norm(), rtol=1e-6, atol=0)
+    # autograd through the known norm: d||p||/dp = p / ||p||
+    q = with_norm[2]
+    assert ops.known_norm(q) is not None
+    q.grad = None
+    ops.frobenius_norm(q).backward()
+    torch.testing.assert_close(q.grad, q.detach() / q.detach().norm(), rtol=1e-5, atol=1e-7)
+    ops.forget_norms([q])
+    assert ops.known_norm(q) is None
+
+
 def test_gather_rows_by_index():
     from gnn_tail_generalization_amd import ops
     for shape in [(100, 256), (57, 40), (9, 7)]:

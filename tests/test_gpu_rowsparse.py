@@ -240,6 +240,19 @@ def test_support_plan_levels_are_the_reverse_graph_restricted_and_renumbered():
         h_c = part
 
 
+def test_expand_rows_is_the_inverse_of_the_row_pack():
+    from gnn_tail_generalization_amd import ops
+    n = 10007
+    mask = torch.rand(n, device=DEV) < 0.3
+    pos = torch.where(mask, torch.cumsum(mask, 0, dtype=torch.int32) - 1, torch.full((n,), -1, dtype=torch.int32, device=DEV))
+    src = torch.randn(int(mask.sum()), 256, device=DEV)
+    out = ops.expand_rows(src, pos)
+    want = torch.zeros(n, 256, device=DEV)
+    want[mask] = src
+    assert torch.equal(out, want)
+    assert torch.equal(ops.expand_rows(src[:0], torch.full((5,), -1, dtype=torch.int32, device=DEV)), torch.zeros(5, 256, device=DEV))
+
+
 def test_violated_claim_is_reported_not_silent():
     from gnn_tail_generalization_amd import _lib, ops
     lib = _lib.load()
