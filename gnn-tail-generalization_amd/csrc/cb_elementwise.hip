@@ -163,10 +163,17 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
   for (int tile = 0; tile < tiles; ++tile) {
     const int c = tile * 256 + lane * 4;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
+    int64_t rr_next = 0;      // RIDX: the index of the NEXT row is requested one iteration ahead (mask words and row scale hang on it)
+    if constexpr (RIDX) {
+      if (r_begin + w < r_end) rr_next = ridx[r_begin + w];
+    }
     for (int64_t r = r_begin + w; r < r_end; r += kBlock / kWave) {
       const int64_t off = r * d + c;
       int64_t rr = r;      // the row of the full matrix this row is
-      if constexpr (RIDX) rr = ridx[r];
+      if constexpr (RIDX) {
+        rr = rr_next;
+        if (r + kBlock / kWave < r_end) rr_next = ridx[r + kBlock / kWave];
+      }
       // g is read once (streaming)
       float gm[4] = {__builtin_nontemporal_load(g + off), __builtin_nontemporal_load(g + off + 1), __builtin_nontemporal_load(g + off + 2),
                      __builtin_nontemporal_load(g + off + 3)};
