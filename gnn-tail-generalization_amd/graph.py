@@ -168,25 +168,28 @@ class CSRGraph:
                 rp_c = torch.cat([cnt.new_zeros(1), torch.cumsum(cnt[dst.idx], 0, dtype=torch.int32)])
                 plan.levels.append((CSRGraph.from_csr(rp_c, col_new, src.n, hub_threshold=self.hub_threshold), dst))
                 if len(plan.levels) == 1:
-                    plan.fwd0 = self._support_fwd0(src, dst)
+                    plan.fwd0 = self._support_fwd0(src, dst.n)
                 src_mask, src = dst_mask, dst
             else:
                 plan.levels.append((CSRGraph.from_csr(rp_new, col_new, src.n, hub_threshold=self.hub_threshold), None))
+                if len(plan.levels) == 1:      # few loss rows that reach most of the graph (sparse labels): level 0's contractions still run on S_0
+                    plan.fwd0 = self._support_fwd0(src, self.N)
                 break
         self._support_key, self._support_plan, self._support_mask = key, plan, keep
         return plan
 
-    def _support_fwd0(self, s0, s1):
+    def _support_fwd0(self, s0, n_out):
         """The FORWARD orientation restricted to the rows of S_0 (one row per member; its in-neighbours — all of them members of S_1 — keep
         their global ids): (A (a * X))[S_0] = fwd0.spmm(X, col_scale=a).  With it the weight gradient of the level
         X^T (a * A^T dY) is taken as ((A (a * X))[S_0])^T dY[S_0] — a contraction over |S_0| rows instead of |S_1| — and
-        a * (A^T dY) W^T as a * A^T (dY W^T): the GEMM on |S_0| rows in front of the aggregation (trunk.py).  Built when the rows spared
-        (|S_1| - |S_0|) outweigh the second pass over the level's edges (FWD0_ROWS_PER_EDGE), else None."""
+        a * (A^T dY) W^T as a * A^T (dY W^T): the GEMM on |S_0| rows in front of the aggregation (trunk.py).  n_out = the rows level 0
+        writes (|S_1|, or all rows when its destination is dense).  Built when the rows spared (n_out - |S_0|) outweigh the second pass
+        over the level's edges (FWD0_ROWS_PER_EDGE), else None."""
         rpf, colf = self.rowptr, self.col[:self.E]
         deg0 = torch.index_select(rpf[1:] - rpf[:-1], 0, s0.idx)
         rp_c = torch.cat([deg0.new_zeros(1), torch.cumsum(deg0, 0, dtype=torch.int32)])
         e0 = int(rp_c[-1])
-        if (s1.n - s0.n) < FWD0_ROWS_PER_EDGE * e0 or e0 == 0:
+        if (n_out - s0.n) < FWD0_ROWS_PER_EDGE * e0 or e0 == 0:
             return None
         shift = torch.index_select(rpf, 0, s0.idx).long() - rp_c[:-1].long()          # CSR position minus packed position, per S_0 row
         epos = torch.arange(e0, device=rpf.device) + torch.repeat_interleave(shift, deg0.long())

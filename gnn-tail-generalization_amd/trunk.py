@@ -523,11 +523,11 @@ class _TrunkFn(torch.autograd.Function):
             # Level 0 through the loss rows' side (CSRGraph._support_fwd0): a * (A^T dY) W^T = a * A^T (dY W^T) and
             # X^T (a * A^T dY) = ((A (a * X))[S_0])^T dY[S_0] — the GEMM and the weight gradient contract over |S_0| rows instead of |S_1|,
             # dL/dZ_l itself is never formed (so not with a table gradient, which IS dL/dZ_l).  Same sums, associated differently.
-            loss_side = (ROWSPARSE_LOSS_SIDE and dst is not None and L - 1 - l == 0 and plan.fwd0 is not None
+            loss_side = (ROWSPARSE_LOSS_SIDE and level is not None and L - 1 - l == 0 and plan.fwd0 is not None
                          and not (le is not None and need[7 + 3 * l + 2]))
             if loss_side:
                 level[0].profile = plan.fwd0.profile = getattr(graph, 'profile', None)
-                g_fused = level[0].spmm(gemm.mm_nn(gr, w.t().contiguous()), row_scale=dst.a)
+                g_fused = level[0].spmm(gemm.mm_nn(gr, w.t().contiguous()), row_scale=dst.a if dst is not None else a)
                 if need[7 + 3 * l]:
                     grads_layers[3 * l] = gemm.mm_tn(plan.fwd0.spmm(saved_in[l], col_scale=a), gr)
                 gz = None

@@ -47,7 +47,8 @@ def _step_grads(flag, dataset='S-pl1M', se='000', layers=3, extra=()):
 def test_row_sparse_backward_equals_the_dense_backward(max_frac, se, loss_side, monkeypatch):
     """max_frac 0.6: the supports S_0 (10 % of the rows) and S_1 (45 %) compact, from S_2 (94 %) on dense; 0: only the gathered side of the
     first aggregation compact.  se 111: structural-embedding tables, whose gradient dL/dZ_l is scattered from the compact level to all rows.
-    loss_side: level 0's GEMM and weight gradient contracted over the loss rows (plan.fwd0) — not with a table gradient, not at max_frac 0."""
+    loss_side: level 0's GEMM and weight gradient contracted over the loss rows (plan.fwd0), whether its destination is compact or dense —
+    not with a table gradient."""
     from gnn_tail_generalization_amd import trunk
     monkeypatch.setattr(trunk, 'ROWSPARSE_MAX_FRAC', max_frac)
     monkeypatch.setattr(trunk, 'ROWSPARSE_LOSS_SIDE', loss_side)
@@ -57,7 +58,7 @@ def test_row_sparse_backward_equals_the_dense_backward(max_frac, se, loss_side, 
     monkeypatch.setattr(CSRGraph, 'spmm', lambda self, h, *a, **k: (spmm_rows.append((self.N, self.n_cols)), real(self, h, *a, **k))[1])
     loss_s, g_s, used_s = _step_grads('1', se=se)
     took_loss_side = any(n < c for n, c in spmm_rows)  # fwd0: one row per loss row, all columns
-    assert took_loss_side == (loss_side and max_frac > 0 and se == '000')
+    assert took_loss_side == (loss_side and se == '000')
     loss_d, g_d, used_d = _step_grads('0', se=se)
     assert used_s and not used_d                       # the 10 % train mask of the stand-in: the plan was built and used
     assert loss_s == loss_d
