@@ -129,6 +129,7 @@ class CSRGraph:
         S_{j+1} = the rows with a (reverse-orientation) neighbour in S_j; supports are properties of the graph and the mask, not of the
         values, so they are built once (torch ops on the device) and cached.  Returns RowSupportPlan with
           .space0            the rows of S_0 as a compact space (ids ascending, position of every row or -1, row scale a restricted)
+          .fwd[j]            the forward orientation restricted to the rows of S_j where the level pays to contract on that side (_support_fwd), else None
           .levels[j]         (csr, dst): csr = the reverse orientation restricted to gathered rows in S_j with its column ids renumbered to
                              positions in S_j; dst = the compact space of S_{j+1} when |S_{j+1}| <= max_frac * N (csr then has one row per
                              member of S_{j+1}), else None (csr has all N rows, the output is an ordinary dense matrix and the plan ends).
@@ -167,23 +168,21 @@ class CSRGraph:
                 dst = space_of(dst_mask)
                 rp_c = torch.cat([cnt.new_zeros(1), torch.cumsum(cnt[dst.idx], 0, dtype=torch.int32)])
                 plan.levels.append((CSRGraph.from_csr(rp_c, col_new, src.n, hub_threshold=self.hub_threshold), dst))
-                if len(plan.levels) == 1:
-                    plan.fwd0 = self._support_fwd0(src, dst.n)
+                plan.fwd.append(self._support_fwd(src, dst.n))
                 src_mask, src = dst_mask, dst
             else:
                 plan.levels.append((CSRGraph.from_csr(rp_new, col_new, src.n, hub_threshold=self.hub_threshold), None))
-                if len(plan.levels) == 1:      # few loss rows that reach most of the graph (sparse labels): level 0's contractions still run on S_0
-                    plan.fwd0 = self._support_fwd0(src, self.N)
+                plan.fwd.append(self._support_fwd(src, self.N))      # (few rows that reach most of the graph — sparse labels — still contract on their side)
                 break
         self._support_key, self._support_plan, self._support_mask = key, plan, keep
         return plan
 
-    def _support_fwd0(self, s0, n_out):
-        """The FORWARD orientation restricted to the rows of S_0 (one row per member; its in-neighbours — all of them members of S_1 — keep
-        their global ids): (A (a * X))[S_0] = fwd0.spmm(X, col_scale=a).  With it the weight gradient of the level
-        X^T (a * A^T dY) is taken as ((A (a * X))[S_0])^T dY[S_0] — a contraction over |S_0| rows instead of |S_1| — and
-        a * (A^T dY) W^T as a * A^T (dY W^T): the GEMM on |S_0| rows in front of the aggregation (trunk.py).  n_out = the rows level 0
-        writes (|S_1|, or all rows when its destination is dense).  Built when the rows spared (n_out - |S_0|) outweigh the second pass
+    def _support_fwd(self, s0, n_out):
+        """The FORWARD orientation restricted to the rows of a support S_j (one row per member; its in-neighbours — all of them members of
+        S_{j+1} — keep their global ids): (A (a * X))[S_j] = fwd.spmm(X, col_scale=a).  With it the weight gradient of the level
+        X^T (a * A^T dY) is taken as ((A (a * X))[S_j])^T dY[S_j] — a contraction over |S_j| rows instead of |S_{j+1}| — and
+        a * (A^T dY) W^T as a * A^T (dY W^T): the GEMM on |S_j| rows in front of the aggregation (trunk.py).  n_out = the rows the level
+        writes (|S_{j+1}|, or all rows when its destination is dense).  Built when the rows spared (n_out - |S_j|) outweigh the second pass
         over the level's edges (FWD0_ROWS_PER_EDGE), else None."""
         rpf, colf = self.rowptr, self.col[:self.E]
         deg0 = torch.index_select(rpf[1:] - rpf[:-1], 0, s0.idx)
@@ -653,7 +652,12 @@ class RowSpace:
 
 class RowSupportPlan:
     def __init__(self, space0, levels):
-        self.space0, self.levels, self.fwd0 = space0, levels, None
+        self.space0, self.levels = space0, levels
+        self.fwd = []      # per level: the forward orientation on the level's source rows (CSRGraph._support_fwd) or None
+
+    @property
+    def fwd0(self):
+        return self.fwd[0] if self.fwd else None
 
 
 def build_graph(edge_index, num_nodes=None):

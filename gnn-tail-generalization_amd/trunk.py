@@ -520,16 +520,17 @@ class _TrunkFn(torch.autograd.Function):
                 grads_layers[3 * deferred[0]] = dw_layer(*deferred)
                 deferred = None
             g_fused = tb_fused = None
-            # Level 0 through the loss rows' side (CSRGraph._support_fwd0): a * (A^T dY) W^T = a * A^T (dY W^T) and
-            # X^T (a * A^T dY) = ((A (a * X))[S_0])^T dY[S_0] — the GEMM and the weight gradient contract over |S_0| rows instead of |S_1|,
+            # A level through its SOURCE rows' side (CSRGraph._support_fwd; level 0: the loss rows): a * (A^T dY) W^T = a * A^T (dY W^T) and
+            # X^T (a * A^T dY) = ((A (a * X))[S_j])^T dY[S_j] — the GEMM and the weight gradient contract over |S_j| rows instead of |S_{j+1}|,
             # dL/dZ_l itself is never formed (so not with a table gradient, which IS dL/dZ_l).  Same sums, associated differently.
-            loss_side = (ROWSPARSE_LOSS_SIDE and level is not None and L - 1 - l == 0 and plan.fwd0 is not None
-                         and not (le is not None and need[7 + 3 * l + 2]))
+            fwd_j = plan.fwd[L - 1 - l] if (level is not None and L - 1 - l < len(plan.fwd)) else None
+            loss_side = (ROWSPARSE_LOSS_SIDE and fwd_j is not None and not (le is not None and need[7 + 3 * l + 2])
+                         and not (need[7 + 3 * l] and saved_in[l] is None))      # (layer 0 without a stored dropped copy of X0)
             if loss_side:
-                level[0].profile = plan.fwd0.profile = getattr(graph, 'profile', None)
+                level[0].profile = fwd_j.profile = getattr(graph, 'profile', None)
                 g_fused = level[0].spmm(gemm.mm_nn(gr, w.t().contiguous()), row_scale=dst.a if dst is not None else a)
                 if need[7 + 3 * l]:
-                    grads_layers[3 * l] = gemm.mm_tn(plan.fwd0.spmm(saved_in[l], col_scale=a), gr)
+                    grads_layers[3 * l] = gemm.mm_tn(fwd_j.spmm(saved_in[l], col_scale=a), gr)
                 gz = None
             elif ag_bwd or level is not None:
                 # dL/dZ_l = A (b * dY') and a * (dL/dZ_l @ W_l^T) from one kernel (cb_spmm_gemm_f32); for l > 0 and tail_tb the trunk backward of

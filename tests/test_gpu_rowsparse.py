@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def _step_grads(flag, dataset='S-pl1M', se='000', layers=3, extra=()):
+def _step_grads(flag, dataset='S-pl1M', se='000', layers=3, extra=(), n_loss_rows=None):
     import bench
     from gnn_tail_generalization_amd import _lib, ops
     from gnn_tail_generalization_amd import trainer_node_classification as tnc
@@ -25,6 +25,10 @@ def _step_grads(flag, dataset='S-pl1M', se='000', layers=3, extra=()):
         torch.manual_seed(0)
         with contextlib.redirect_stdout(io.StringIO()):
             t = tnc.trainer(args, 0)
+            if n_loss_rows is not None:      # sparse labels: every 7919-th row
+                m = torch.zeros_like(t.data.train_mask)
+                m[(torch.arange(n_loss_rows, device=m.device) * 7919) % m.numel()] = True
+                t.data.train_mask, t.data.test_mask = m, ~m
             t.setup_teacherGNN()
         t.teacherGNN.train()
         ops._seed_override[:] = [11, 12, 13, 14, 15]
@@ -67,6 +71,17 @@ def test_row_sparse_backward_equals_the_dense_backward(max_frac, se, loss_side, 
         scale = float(g_d[k].abs().max())
         # same addends; the association of sums differs (hub chunks, the slabs of the weight-gradient reductions)
         assert float((g_s[k] - g_d[k]).abs().max()) <= 5e-6 * scale, k
+
+
+@pytest.mark.parametrize('n_loss_rows', [3, 200, 20000])
+def test_row_sparse_backward_with_sparse_labels(n_loss_rows):
+    """Few loss rows (the public Planetoid splits label 0.3 - 5 % of the nodes): supports of 3 / 200 / 20 000 rows that grow by orders of
+    magnitude per level — deeper levels than the first take the source-side form too (plan.fwd[j]) — against the dense backward."""
+    loss_s, g_s, used_s = _step_grads('1', n_loss_rows=n_loss_rows)
+    loss_d, g_d, used_d = _step_grads('0', n_loss_rows=n_loss_rows)
+    assert used_s and not used_d and loss_s == loss_d
+    for k in g_d:
+        assert float((g_s[k] - g_d[k]).abs().max()) <= 5e-6 * float(g_d[k].abs().max()), k
 
 
 def test_row_sparse_backward_with_bf16_stored_rows():
