@@ -12,6 +12,7 @@ from . import _lib
 
 HUB_THRESHOLD = 256      # rows with more edges are reduced in chunks of this size by the hub kernels (64 / 128 / 512 / 1024 measured equal or slower)
 FWD0_ROWS_PER_EDGE = 0.25 # grad_support_plan keeps the forward orientation on the loss rows when S_1 has at least this many more rows than S_0 per edge between them (S-pl10M: 0.35)
+FWD0_MIN_EDGES = 1 << 19  # ... and the level moves at least this many edges: below, its kernels are latency-bound and two more launches cost more than the rows save (S-arxiv, 2.3 * 10^5 edges at level 0: 3.35 -> 3.41 ms/step with the form; S-pubmed under hipGraph 0.600 -> 0.627; S-pl1M, 10^6 edges: 16.15 -> 16.0)
 INT32_EDGE_LIMIT = 2 ** 31 - 1   # edge offsets (rowptr) and column ids are int32 on the device (include/coldbrew_hip.h); see CSRGraph.__init__
 HOT_BYTES = 256 << 20      # the hot source rows of an aggregation should fill the 256 MiB Infinity Cache: count = HOT_BYTES / row bytes
 HOT_ROWS = HOT_BYTES // 1024   # 262 144 rows at d = 256 fp32 (1 KiB rows): the measured optimum on S-pl10M (profiles/r02_spmm_gather_policy.md)
@@ -183,12 +184,12 @@ class CSRGraph:
         X^T (a * A^T dY) is taken as ((A (a * X))[S_j])^T dY[S_j] — a contraction over |S_j| rows instead of |S_{j+1}| — and
         a * (A^T dY) W^T as a * A^T (dY W^T): the GEMM on |S_j| rows in front of the aggregation (trunk.py).  n_out = the rows the level
         writes (|S_{j+1}|, or all rows when its destination is dense).  Built when the rows spared (n_out - |S_j|) outweigh the second pass
-        over the level's edges (FWD0_ROWS_PER_EDGE), else None."""
+        over the level's edges (FWD0_ROWS_PER_EDGE) and the level is large enough to be bound by bandwidth (FWD0_MIN_EDGES), else None."""
         rpf, colf = self.rowptr, self.col[:self.E]
         deg0 = torch.index_select(rpf[1:] - rpf[:-1], 0, s0.idx)
         rp_c = torch.cat([deg0.new_zeros(1), torch.cumsum(deg0, 0, dtype=torch.int32)])
         e0 = int(rp_c[-1])
-        if (n_out - s0.n) < FWD0_ROWS_PER_EDGE * e0 or e0 == 0:
+        if (n_out - s0.n) < FWD0_ROWS_PER_EDGE * e0 or e0 < FWD0_MIN_EDGES:
             return None
         shift = torch.index_select(rpf, 0, s0.idx).long() - rp_c[:-1].long()          # CSR position minus packed position, per S_0 row
         epos = torch.arange(e0, device=rpf.device) + torch.repeat_interleave(shift, deg0.long())

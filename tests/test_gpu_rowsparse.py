@@ -74,9 +74,11 @@ def test_row_sparse_backward_equals_the_dense_backward(max_frac, se, loss_side, 
 
 
 @pytest.mark.parametrize('n_loss_rows', [3, 200, 20000])
-def test_row_sparse_backward_with_sparse_labels(n_loss_rows):
+def test_row_sparse_backward_with_sparse_labels(n_loss_rows, monkeypatch):
     """Few loss rows (the public Planetoid splits label 0.3 - 5 % of the nodes): supports of 3 / 200 / 20 000 rows that grow by orders of
     magnitude per level — deeper levels than the first take the source-side form too (plan.fwd[j]) — against the dense backward."""
+    from gnn_tail_generalization_amd import graph
+    monkeypatch.setattr(graph, 'FWD0_MIN_EDGES', 0)
     loss_s, g_s, used_s = _step_grads('1', n_loss_rows=n_loss_rows)
     loss_d, g_d, used_d = _step_grads('0', n_loss_rows=n_loss_rows)
     assert used_s and not used_d and loss_s == loss_d
@@ -119,8 +121,9 @@ def test_row_sparse_backward_matches_the_unmodified_reference(case, monkeypatch)
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
     from conftest import load_golden
     from helpers import product_model
-    from gnn_tail_generalization_amd import _lib, ops, trunk
+    from gnn_tail_generalization_amd import _lib, graph, ops, trunk
     monkeypatch.setattr(trunk, 'ROWSPARSE_MIN_NODES', 0)
+    monkeypatch.setattr(graph, 'FWD0_MIN_EDGES', 0)                  # (the source-side form at this small size too)
     monkeypatch.setenv('CB_LOSS_ROWS', '1')
     g = load_golden(case)
     args, model = product_model(g['cfg'], g['sd'], DEV)
@@ -152,8 +155,9 @@ def test_row_sparse_backward_on_a_directed_multigraph(loss_side, monkeypatch):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
     from conftest import load_golden
     from helpers import product_model
-    from gnn_tail_generalization_amd import _lib, ops, trunk
+    from gnn_tail_generalization_amd import _lib, graph, ops, trunk
     monkeypatch.setattr(trunk, 'ROWSPARSE_MIN_NODES', 0)
+    monkeypatch.setattr(graph, 'FWD0_MIN_EDGES', 0)
     monkeypatch.setattr(trunk, 'ROWSPARSE_LOSS_SIDE', loss_side)
     g = load_golden('case_r_initialbn_h256_L3_train10')
     cfg = dict(g['cfg'], dropout=0.3)
@@ -208,7 +212,9 @@ def test_row_sparse_backward_at_the_headline_size():
         assert float((g_s[k] - g_d[k]).abs().max()) <= 5e-6 * float(g_d[k].abs().max()), k
 
 
-def test_support_plan_levels_are_the_reverse_graph_restricted_and_renumbered():
+def test_support_plan_levels_are_the_reverse_graph_restricted_and_renumbered(monkeypatch):
+    from gnn_tail_generalization_amd import graph
+    monkeypatch.setattr(graph, 'FWD0_MIN_EDGES', 0)
     from gnn_tail_generalization_amd.data import synthetic_data
     from gnn_tail_generalization_amd.graph import CSRGraph
     data = synthetic_data('S-pl1M', seed=0, device=DEV, n_override=70000)
