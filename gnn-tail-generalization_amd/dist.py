@@ -181,7 +181,7 @@ class Partition:
         key = node_ids.device
         if key not in self._bt:
             self._bt[key] = torch.tensor(self.bounds[1:], dtype=torch.int64, device=key)
-        return torch.bucketize(node_ids.to(torch.int64), self._bt[key], right=True)
+        return torch.bucketize(node_ids.to(torch.int64).contiguous(), self._bt[key], right=True)
 
 
 # ---------------------------------------------------------------------------------------------------------
