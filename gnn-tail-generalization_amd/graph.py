@@ -140,7 +140,9 @@ class CSRGraph:
         # in-place change bumps its version)
         key = (keep.data_ptr(), keep._version, int(keep.shape[0]), int(n_aggr), float(max_frac))
         if getattr(self, '_support_key', None) == key and getattr(self, '_support_mask', None) is keep:
+            self._support_hits = getattr(self, '_support_hits', 0) + 1
             return self._support_plan
+        self._support_builds = getattr(self, '_support_builds', 0) + 1
         if self.rowptr_t is None:
             raise ValueError('this graph holds the forward orientation only')
         if keep.dtype != torch.bool or keep.shape[0] != self.n_cols or self.N != self.n_cols:
@@ -177,6 +179,16 @@ class CSRGraph:
                 break
         self._support_key, self._support_plan, self._support_mask = key, plan, keep
         return plan
+
+    def support_plan_pays(self):
+        """False once the plans of a SMALL graph keep being rebuilt instead of re-used (a caller that hands a new loss mask to every step):
+        after four builds, fewer than three uses per build — the caller then takes the dense backward.  Building the supports is a few
+        dozen torch ops and two host syncs: on a launch-bound graph that is more than one step's row-sparse backward saves, on a large
+        one it is not (S-pl10M: 14 ms per build against 35 ms saved per step), so from 2^24 edges on a plan always pays."""
+        if self.E >= (1 << 24):
+            return True
+        builds, hits = getattr(self, '_support_builds', 0), getattr(self, '_support_hits', 0)
+        return builds < 4 or hits >= 3 * builds
 
     def _support_fwd(self, s0, n_out):
         """The FORWARD orientation restricted to the rows of a support S_j (one row per member; its in-neighbours — all of them members of

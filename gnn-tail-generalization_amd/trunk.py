@@ -486,7 +486,7 @@ class _TrunkFn(torch.autograd.Function):
         # (with bf16-stored rows the compact levels still run on fp32 matrices through the aggregation + GEMM kernel; the dense levels below
         # them go on as the bf16 path does)
         if (rows_hint is not None and 1 <= rows_hint[1] <= ROWSPARSE_S0_LIMIT * gout.shape[0] and (gout.shape[0] >= ROWSPARSE_MIN_NODES or ROWSPARSE_SMALL_OK) and gather
-                and agg_gemm_eligible(graph, h, False) and not tail_tb):
+                and agg_gemm_eligible(graph, h, False) and not tail_tb and graph.support_plan_pays()):
             ops.check_rows_zero(gout, rows_hint[0])
             plan = graph.grad_support_plan(rows_hint[0], L, max_frac=ROWSPARSE_MAX_FRAC)
         space = None                                                             # row space of g / gr (None: all rows)

@@ -275,6 +275,24 @@ def test_expand_rows_is_the_inverse_of_the_row_pack():
     assert torch.equal(ops.expand_rows(src[:0], torch.full((5,), -1, dtype=torch.int32, device=DEV)), torch.zeros(5, 256, device=DEV))
 
 
+def test_a_new_mask_every_step_falls_back_to_the_dense_backward():
+    """The supports are built once per (graph, mask): a caller that changes the loss rows every step would pay the build every step, so
+    after four builds without re-use the graph reports that planning does not pay and the trunk takes the dense backward."""
+    from gnn_tail_generalization_amd.data import synthetic_data
+    from gnn_tail_generalization_amd.graph import CSRGraph
+    data = synthetic_data('S-pl1M', seed=0, device=DEV, n_override=70000)
+    G = CSRGraph(data.edge_index, data.x.shape[0])
+    same = data.train_mask
+    for _ in range(20):                                    # one mask, re-used: pays
+        G.grad_support_plan(same, 3)
+    assert G.support_plan_pays() and G._support_builds == 1
+    G2 = CSRGraph(data.edge_index, data.x.shape[0])
+    for i in range(4):                                     # a new mask each time
+        assert G2.support_plan_pays()
+        G2.grad_support_plan(torch.rand(G2.N, device=DEV) < 0.1, 3)
+    assert not G2.support_plan_pays()
+
+
 def test_violated_claim_is_reported_not_silent():
     from gnn_tail_generalization_amd import _lib, ops
     lib = _lib.load()
