@@ -327,7 +327,9 @@ static int launch_agg_gemm(const int32_t* rowptr, const int32_t* col, int64_t N,
                          hub_chunk_ptr, partial, ld_p, ep);
     CB_LAUNCH_CHECK();
     const dim3 grid2((unsigned)((n_hubs + 3) / 4), 1);
-    hipLaunchKernelGGL((k_spmm_hub_finish<4, FUSED>), grid2, blk, 0, st, d, n_hubs, hub_rows, hub_chunk_ptr, partial, ld_p, out, ld_out, ep, fe);
+    FusedEpi fe_hub = fe;
+    fe_hub.skip_next = 0;      // hub rows always go through memory: the persistent kernel reads them back into its tile
+    hipLaunchKernelGGL((k_spmm_hub_finish<4, FUSED>), grid2, blk, 0, st, d, n_hubs, hub_rows, hub_chunk_ptr, partial, ld_p, out, ld_out, ep, fe_hub);
     CB_LAUNCH_CHECK();
   }
   const int n_tiles = (int)((N + kTM - 1) / kTM);
@@ -464,13 +466,13 @@ extern "C" int cb_spmm_gemm_trunkbwd_f32(const int32_t* rowptr, const int32_t* c
 
 // Fused trunk store (cb_spmm_csr_fused_f32 / cb_spmm_csr_fused_acc_f32: ReLU / mix / dropout, mask words, out_next) + g_out = g_rowscale *
 // (out_next @ B) + g_addend.
-extern "C" int cb_spmm_gemm_fused_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N,
-                                      int64_t E, const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias,
-                                      const float* mix_src, int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed,
-                                      const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, float* out_next, int64_t ld_next, int32_t hub_T,
-                                      int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,
-                                      size_t ws_bytes, const void* image, const float* g_rowscale, const float* g_addend, int64_t ld_add,
-                                      float* g_out, int64_t ld_gout, void* stream) {
+static int spmm_gemm_fused_impl(int skip_next, const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N,
+                                int64_t E, const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias,
+                                const float* mix_src, int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed,
+                                const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, float* out_next, int64_t ld_next, int32_t hub_T,
+                                int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,
+                                size_t ws_bytes, const void* image, const float* g_rowscale, const float* g_addend, int64_t ld_add,
+                                float* g_out, int64_t ld_gout, void* stream) {
   const int rc = agg_gemm_common_checks("cb_spmm_gemm_fused_f32", N, E, d, rowptr, col, h, ld_h, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr,
                                         ws, ws_bytes, image, g_addend, ld_add, g_out, ld_gout, acc_init, ld_init);
   if (rc != CB_OK || N == 0) return rc;
@@ -485,6 +487,7 @@ extern "C" int cb_spmm_gemm_fused_f32(const float* acc_init, int64_t ld_init, co
   fe.keep_scale = 1.f / (1.f - drop_p);
   fe.seed = seed; fe.seed_dev = seed_dev; fe.row0 = row0; fe.bits = (unsigned long long*)relu_bits;
   fe.out_act = nullptr; fe.ld_act = 0; fe.out_next = out_next; fe.ld_next = ld_next; fe.d = (int)d;
+  fe.skip_next = skip_next;
   GemmTail gt{(const uint4*)image, g_rowscale, g_addend, ld_add, g_out, ld_gout};
   if (acc_init)
     return launch_agg_gemm<true, true>(rowptr, col, N, h, ld_h, ep, out_next, ld_next, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, (float*)ws,
@@ -492,3 +495,21 @@ extern "C" int cb_spmm_gemm_fused_f32(const float* acc_init, int64_t ld_init, co
   return launch_agg_gemm<true, false>(rowptr, col, N, h, ld_h, ep, out_next, ld_next, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, (float*)ws,
                                       (hipStream_t)stream, fe, gt);
 }
+
+#define CB_SGF_PARAMS                                                                                                                              \
+  const float *acc_init, int64_t ld_init, const int32_t *rowptr, const int32_t *col, int32_t col_flags, int64_t N, int64_t E, const float *h,      \
+      int64_t ld_h, int64_t d, const float *row_scale, const float *bias, const float *mix_src, int64_t ld_mix, float c_act, float c_mix,          \
+      float drop_p, uint64_t seed, const uint64_t *seed_dev, int64_t row0, uint64_t *relu_bits, float *out_next, int64_t ld_next, int32_t hub_T,  \
+      int32_t n_hubs, int32_t n_chunks, const int32_t *hub_rows, const int32_t *hub_chunk_ptr, void *ws, size_t ws_bytes, const void *image,       \
+      const float *g_rowscale, const float *g_addend, int64_t ld_add, float *g_out, int64_t ld_gout, void *stream
+#define CB_SGF_ARGS                                                                                                                                \
+  acc_init, ld_init, rowptr, col, col_flags, N, E, h, ld_h, d, row_scale, bias, mix_src, ld_mix, c_act, c_mix, drop_p, seed, seed_dev, row0,      \
+      relu_bits, out_next, ld_next, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, image, g_rowscale, g_addend, ld_add, g_out,    \
+      ld_gout, stream
+extern "C" int cb_spmm_gemm_fused_f32(CB_SGF_PARAMS) { return spmm_gemm_fused_impl(0, CB_SGF_ARGS); }
+// The same for a forward that no backward follows (evaluation / metrics passes): the stored activations X_{l+1} have no reader — the next
+// layer's Z leaves this kernel —, so the rows the persistent kernel finishes stay on chip (out_next: still the hub rows' way into the
+// tile, contents otherwise undefined).  10 GB less written per launch at the headline size.
+extern "C" int cb_spmm_gemm_fused_eval_f32(CB_SGF_PARAMS) { return spmm_gemm_fused_impl(1, CB_SGF_ARGS); }
+#undef CB_SGF_PARAMS
+#undef CB_SGF_ARGS

@@ -164,6 +164,7 @@ struct FusedEpi {
   float* out_next;        // [N, ld_next]
   int64_t ld_next;
   int d;
+  int skip_next;          // cb_agg_gemm.hip, forwards without a backward: the finished row only goes to the on-chip tile, not to out_next
 };
 
 // x: the values stored to out_next (also handed to the caller: cb_agg_gemm.hip keeps the finished row on chip)
@@ -192,7 +193,7 @@ __device__ __forceinline__ void fused_store(const FusedEpi& fe, int64_t row, int
 #pragma unroll
     for (int i = 0; i < 4; ++i) x[i] *= m[i];
   }
-  store_stream<4>(fe.out_next + row * fe.ld_next + c0, x);
+  if (!fe.skip_next) store_stream<4>(fe.out_next + row * fe.ld_next + c0, x);
 }
 
 template <int VEC>

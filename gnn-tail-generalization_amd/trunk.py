@@ -56,9 +56,11 @@ def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False, produ
 def _fused_gemm_launch(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowscale, g_addend, want_bits=True, g=None, acc=None):
     """(bits, out_next, z_next) of cb_spmm_gemm_fused_f32: the fused trunk store of layer l and Z_{l+1} = g_rowscale * (out_next @ W_{l+1})
     + g_addend from one kernel (d = 256, fp32 rows).  g: the CSR to run on (default: the graph itself; node-sharded: the last halo slice,
-    z = its receive buffer) with acc = the running sums of the earlier passes."""
+    z = its receive buffer) with acc = the running sums of the earlier passes.  want_bits=False (a forward that no backward follows):
+    cb_spmm_gemm_fused_eval_f32 — no mask words, and out_next is not written either (it has no reader: returned as None)."""
     lib = _lib.load()
     g = graph if g is None else g
+    fn = lib.cb_spmm_gemm_fused_f32 if want_bits else lib.cb_spmm_gemm_fused_eval_f32
     n, d = g.N, z.shape[1]
     dev = z.device
     bits = torch.empty((n, d // 256, 4), dtype=torch.int64, device=dev) if want_bits else None
@@ -75,20 +77,20 @@ def _fused_gemm_launch(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowsc
     if g_addend is not None and g_addend.stride(1) != 1:
         g_addend = g_addend.contiguous()
     with torch.cuda.device(dev):
-        _lib.check(lib.cb_spmm_gemm_fused_f32(_lib.ptr(acc), acc.stride(0) if acc is not None else 0, _lib.ptr(g.rowptr),
-                                              _lib.ptr(col_k if col_k is not None else g.col), int(col_k is not None), n, g.E,
-                                              _lib.ptr(z), z.stride(0), d, _lib.ptr(graph.norm_in), _lib.ptr(bias), _lib.ptr(x0),
-                                              x0.stride(0) if x0 is not None else 0, float(c_act), float(c_mix), float(p), ctypes.c_uint64(seed),
-                                              ops.seed_dev_ptr(), int(getattr(graph, 'row_offset', 0)), _lib.ptr(bits), _lib.ptr(out_next), d,
-                                              g.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr),
-                                              _lib.ptr(ws), wsb, _lib.ptr(image), _lib.ptr(g_rowscale), _lib.ptr(g_addend),
-                                              g_addend.stride(0) if g_addend is not None else 0, _lib.ptr(z_next), 256, _lib.stream_ptr()),
+        _lib.check(fn(_lib.ptr(acc), acc.stride(0) if acc is not None else 0, _lib.ptr(g.rowptr),
+                      _lib.ptr(col_k if col_k is not None else g.col), int(col_k is not None), n, g.E,
+                      _lib.ptr(z), z.stride(0), d, _lib.ptr(graph.norm_in), _lib.ptr(bias), _lib.ptr(x0),
+                      x0.stride(0) if x0 is not None else 0, float(c_act), float(c_mix), float(p), ctypes.c_uint64(seed),
+                      ops.seed_dev_ptr(), int(getattr(graph, 'row_offset', 0)), _lib.ptr(bits), _lib.ptr(out_next), d,
+                      g.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr),
+                      _lib.ptr(ws), wsb, _lib.ptr(image), _lib.ptr(g_rowscale), _lib.ptr(g_addend),
+                      g_addend.stride(0) if g_addend is not None else 0, _lib.ptr(z_next), 256, _lib.stream_ptr()),
                    'cb_spmm_gemm_fused_f32')
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1, g.algorithmic_bytes(d), n * d * 4 + n * d // 8,
                      n * 256 * 4 * (2 if g_addend is not None else 1) + (4 * n if g_rowscale is not None else 0)))
-    return bits, out_next, z_next
+    return bits, out_next if want_bits else None, z_next
 
 
 def _fused_gemm(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowscale, g_addend, want_bits=True):

@@ -444,6 +444,15 @@ int cb_spmm_gemm_fused_f32(const float* acc_init, int64_t ld_init, const int32_t
                            uint64_t* relu_bits, float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
                            const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, const void* image,
                            const float* g_rowscale, const float* g_addend, int64_t ld_add, float* g_out, int64_t ld_gout, void* stream);
+/* cb_spmm_gemm_fused_f32 for a forward that no backward follows (evaluation / metrics passes, GCN.py:100-140 under no_grad): the stored
+ * activations have no reader — the next layer's Z leaves this kernel — so the rows the persistent kernel finishes are NOT written to
+ * out_next (which must still be given: the hub rows pass through it; its other contents are undefined afterwards).  g_out as above. */
+int cb_spmm_gemm_fused_eval_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N,
+                                int64_t E, const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias, const float* mix_src,
+                                int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0,
+                                uint64_t* relu_bits, float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
+                                const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, const void* image,
+                                const float* g_rowscale, const float* g_addend, int64_t ld_add, float* g_out, int64_t ld_gout, void* stream);
 /* Fault injection for the failure path above (tests): one wavefront waits with a short spin bound for a hand-over that never comes;
  * cb_device_status() must then report CB_E_DEVICE. */
 int cb_agg_gemm_handover_selftest(void* stream);
