@@ -365,8 +365,61 @@ def sharding_report(t, n1, a, dev):
     return rep
 
 
+def self_launch_argv(a, argv, env, n_devices):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): the command line that runs this file as N
+    ranks under torch.distributed.run (one process per GPU, 127.0.0.1 rendezvous), or None when nothing has to be re-launched.  A driver that
+    launches the ranks itself (WORLD_SIZE set) is left alone.  Fewer visible devices than ranks is an error unless the gloo dry run of the
+    N > 1 code path is asked for (COLDBREW_DIST_BACKEND=gloo: ranks share the devices there are)."""
+    if a.gpus <= 1 or 'WORLD_SIZE' in env:
+        return None
+    if env.get('COLDBREW_DIST_BACKEND', 'nccl') != 'gloo' and n_devices < a.gpus:
+        raise SystemExit(f'bench.py --gpus {a.gpus}: only {n_devices} device(s) visible (one rank per GPU over RCCL; '
+                         'COLDBREW_DIST_BACKEND=gloo runs the N > 1 code path on fewer devices as a dry run)')
+    import socket
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}', '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def roofline_families(recs, steps):
+    """Per-family table of the timed aggregation launches.  A family = launches of one kernel form on one CSR (same kind, edges, rows).
+    `achieved` / `frac` are on SURVEY.md 8(d)'s bytes ONLY (E (d s + 4) + N (d s + 4) [+ 4 N] [+ d s]) / the average launch time / 8 TB/s;
+    the streams a fused store (mixed-in row, mask words) and a dense tail (its output, addend, row scale) add are compulsory traffic of
+    those kernels but not 8(d) bytes: they only enter `frac_incl_fused_streams`."""
+    fams = {}
+    for r in recs:
+        fams.setdefault((r['kind'], r['edges'], r['rows']), []).append(r)
+    out = []
+    for (kind, edges, rows), rs in fams.items():
+        n = len(rs)
+        avg = sum(r['ms'] for r in rs) / n
+        agg, store, tail = (sum(r[k] for r in rs) / n for k in ('agg', 'store', 'tail'))
+        ach = agg / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+        ach_all = (agg + store + tail) / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+        out.append({'kind': kind, 'edges_per_launch': edges, 'rows': rows, 'launches_timed': n, 'launches_per_step': n / max(steps, 1),
+                    'avg_launch_ms': avg, 'total_ms_per_step': sum(r['ms'] for r in rs) / max(steps, 1), 'survey_8d_bytes_per_launch': agg,
+                    'fused_store_bytes_per_launch': store, 'dense_tail_bytes_per_launch': tail, 'achieved': ach, 'frac': ach / HBM_PEAK_GBS,
+                    'achieved_incl_fused_streams': ach_all, 'frac_incl_fused_streams': ach_all / HBM_PEAK_GBS})
+    out.sort(key=lambda f: -f['total_ms_per_step'])
+    return out
+
+
+KERNEL_OF = {'plain': 'k_spmm_rows (+hub kernels)', 'colscale': 'k_spmm_rows<colscale> (+hub kernels)', 'fused_store': 'k_spmm_rows<fused store> (+hub kernels)',
+             'agg_gemm': 'k_agg_gemm2<false> (+hub kernels): aggregation + the dX 256x256 contraction on the matrix cores in one kernel',
+             'agg_gemm_fused': 'k_agg_gemm2<true> (+hub kernels): aggregation with the trunk store + the next 256x256 dense transform on the matrix cores in one kernel',
+             'agg_gemm_fused_eval': 'k_agg_gemm2<true> evaluation form (+hub kernels)',
+             'agg_gemm_trunkbwd': 'k_agg_gemm2<TB> (+hub kernels)'}
+
+
 def main():
     a = parse()
+    relaunch = self_launch_argv(a, sys.argv[1:], os.environ, torch.cuda.device_count() if torch.cuda.is_available() else 0)
+    if relaunch is not None:
+        sys.stdout.flush()
+        os.execv(relaunch[0], relaunch)
     # Libraries (RCCL banner, rocm notices) write to the C stdout and flush it at exit, i.e. AFTER Python's
     # prints; keep a private copy of fd 1 for the JSON line and route everything else to stderr.
     sys.stdout.flush()
@@ -391,7 +444,7 @@ def main():
             init_rccl(rank, world, dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if a.gpus != world and rank == 0:
+    if a.gpus != world and rank == 0:      # (a launcher set WORLD_SIZE: its word counts; without one, --gpus N re-launches itself above)
         print(f'[bench] --gpus {a.gpus} but WORLD_SIZE={world}: using WORLD_SIZE', file=sys.stderr)
 
     from gnn_tail_generalization_amd import trainer_node_classification as tnc
@@ -422,6 +475,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    rng0 = torch.get_rng_state()           # (the dense-backward leg restarts from here: same weights, same dropout seeds)
     for _ in range(a.warmup):
         t.train_step()
     sync()
@@ -458,53 +512,47 @@ def main():
         pm = torch.tensor([peak_mem], device=dev, dtype=torch.float64)
         cbdist._all_reduce(pm, op=dist.ReduceOp.MAX)
         peak_mem = float(pm.item())
-    # every aggregation launch of the timed steps: (start, end, SURVEY 8(d) bytes, fused-store bytes[, dense-tail bytes]); a launch with a
-    # dense tail is the aggregation + next-GEMM kernel (cb_agg_gemm.hip), whose compulsory traffic also holds the tail's output
-    # (+ addend / row scale) — its input never leaves the chip
-    recs = [(r[0].elapsed_time(r[1]), r[2], r[3], r[4] if len(r) > 4 else 0) for r in prof]
-    spmm_ms = [r[0] for r in recs]
-
-    def family(sel):
-        ms = [r[0] for r in recs if sel(r)]
-        if not ms:
-            return None
-        n = len(ms)
-        agg_b = sum(r[1] for r in recs if sel(r)) / n
-        store_b = sum(r[2] for r in recs if sel(r)) / n
-        tail_b = sum(r[3] for r in recs if sel(r)) / n
-        avg = sum(ms) / n
-        return {'launches_timed': n, 'avg_launch_ms': avg, 'total_ms_per_step': sum(ms) / max(a.steps, 1),
-                'algorithmic_bytes_per_launch': agg_b + tail_b, 'aggregation_bytes_per_launch': agg_b, 'dense_tail_bytes_per_launch': tail_b,
-                'fused_epilogue_bytes_per_launch': store_b, 'achieved': (agg_b + tail_b) / (avg * 1e-3) / 1e9,
-                'achieved_incl_fused_epilogue': (agg_b + tail_b + store_b) / (avg * 1e-3) / 1e9,
-                'achieved_on_aggregation_bytes_only': agg_b / (avg * 1e-3) / 1e9}
-    # the row-sparse launch of the backward (the last layer's reverse aggregation over the loss rows only, trunk.py) is kept apart: its
-    # SURVEY 8(d) bytes are those of the filtered orientation, a tenth of the full graph's at the stand-in's 10 % train mask
-    full_b = max((r[1] for r in recs), default=0)
-    sparse = lambda r: r[1] < 0.6 * full_b      # noqa: E731
-    fam_plain = family(lambda r: r[3] == 0 and not sparse(r))
-    fam_tail = family(lambda r: r[3] > 0 and not sparse(r))
-    fam_sparse = family(sparse) if not sharded else None
-    fam_main = fam_tail if (fam_tail and (not fam_plain or fam_tail['total_ms_per_step'] >= fam_plain['total_ms_per_step'])) else fam_plain
-    fam_main = fam_main or {'launches_timed': 0, 'avg_launch_ms': 0.0, 'algorithmic_bytes_per_launch': 0.0, 'fused_epilogue_bytes_per_launch': 0.0,
-                            'achieved': 0.0, 'achieved_incl_fused_epilogue': 0.0}
-    avg_ms, avg_bytes, avg_extra = fam_main['avg_launch_ms'], fam_main['algorithmic_bytes_per_launch'], fam_main['fused_epilogue_bytes_per_launch']
-    achieved, achieved_incl = fam_main['achieved'], fam_main['achieved_incl_fused_epilogue']
-    # the same K steps once more with the DENSE backward (CB_LOSS_ROWS=0), after the timed region: both numbers from one run on one box
+    # every aggregation launch of the timed steps (graph.prof_rec): HIP events on the launch stream, SURVEY 8(d) bytes, the fused streams' bytes
+    # apart, the edges the launch walked
+    recs = [dict(r, ms=r['ev'][0].elapsed_time(r['ev'][1])) for r in prof]
+    for r in recs:
+        del r['ev']
+    spmm_ms = [r['ms'] for r in recs]
+    families = roofline_families(recs, a.steps)
+    fam_main = families[0] if families else {'kind': 'plain', 'launches_timed': 0, 'avg_launch_ms': 0.0, 'survey_8d_bytes_per_launch': 0.0, 'achieved': 0.0,
+                                             'frac': 0.0, 'achieved_incl_fused_streams': 0.0, 'frac_incl_fused_streams': 0.0, 'edges_per_launch': 0}
+    edges_walked = float(sum(r['edges'] for r in recs))          # this rank's launches; node-sharded: summed over the ranks below
+    if world > 1:
+        ew = torch.tensor([edges_walked], device=dev, dtype=torch.float64)
+        cbdist._all_reduce(ew)
+        edges_walked = float(ew.item())
+    row_sparse = (not sharded) and getattr(graph_obj, '_support_plan', None) is not None
+    # the DENSE backward of the same run (CB_LOSS_ROWS=0), after the timed region: the trainer is put back to the initial weights, moments and
+    # RNG state and runs warm-up + K steps again, so its final_loss is the bit-for-bit regression witness of rounds 2 - 4 (same steps, same
+    # dropout seeds, every backward aggregation over all rows) and its ms_per_step the like-for-like figure beside `value`
     dense_bwd = None
-    if a.dense_backward and fam_sparse is not None and not use_graph and os.environ.get('CB_LOSS_ROWS', '1') != '0':
+    if a.dense_backward and row_sparse and not use_graph and os.environ.get('CB_LOSS_ROWS', '1') != '0':
         os.environ['CB_LOSS_ROWS'] = '0'
         try:
             graph_obj.profile = None
-            t.train_step()
+            with torch.no_grad():
+                t.teacherGNN.load_state_dict({k: v.to(dev) for k, v in sd0.items()})
+            t.optimizer.state.clear()
+            t.optimizer.zero_grad(set_to_none=True)
+            torch.set_rng_state(rng0)
+            for _ in range(a.warmup):
+                t.train_step()
             sync()
             t1 = time.perf_counter()
             for _ in range(a.steps):
-                t.train_step()
+                dloss = t.train_step()
             sync()
             dms = (time.perf_counter() - t1) / a.steps * 1e3
-            dense_bwd = {'ms_per_step': dms, 'value': 1e3 / dms, 'unit': 'steps/s', 'steps': a.steps,
-                         'note': 'the same trainer continued for K more steps with CB_LOSS_ROWS=0 (every backward aggregation over all rows), outside the timed region'}
+            dense_bwd = {'ms_per_step': dms, 'value': 1e3 / dms, 'unit': 'steps/s', 'steps': a.steps, 'warmup': a.warmup, 'final_loss': float(dloss),
+                         'aggregated_edges_per_sec': n_edges * 2 * L * 1e3 / dms,
+                         'note': 'the same trainer restarted from the initial weights / moments / RNG state with CB_LOSS_ROWS=0 (every backward '
+                                 'aggregation over all rows: the reference\'s amount of work), warm-up + K steps, outside the timed region; '
+                                 'final_loss is bit-comparable with the final_loss of rounds 2 - 4'}
         finally:
             os.environ['CB_LOSS_ROWS'] = '1'
     ref_epoch = None
@@ -548,7 +596,11 @@ def main():
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
         'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32' if a.agg_dtype == 'f32' else 'f32 (bf16-stored aggregation rows)',
         'data': 'synthetic',
-        'aggregated_edges_per_sec': n_edges * 2 * L * a.steps / dt,
+        'aggregated_edges_per_sec': edges_walked / dt,
+        'nominal_edges_per_sec': n_edges * 2 * L * a.steps / dt,
+        'edges_note': ('aggregated_edges_per_sec = the edges the timed aggregation launches actually walked (sum of the E of the CSR each launch ran on, '
+                       f'{edges_walked / max(a.steps, 1) / max(n_edges, 1):.3f} x E per step) / time; nominal_edges_per_sec = 2L x E per step, the '
+                       "reference's amount (every forward and backward aggregation over all edges)"),
         'final_loss': float(loss),
         'config': {'workload': f'{a.dataset}: N={n_nodes} nodes, E={n_edges} edge_index columns ({graph_desc(a.dataset)}), '
                                f'F={args.num_feats} H={args.dim_hidden} '
@@ -559,26 +611,25 @@ def main():
                             'fp32 operands as three exact bf16 limbs, 6 bf16 MFMA products, fp32 accumulate (error <= fp32 GEMM)'),
                    'parallelism': par},
         'roofline': {'bound': 'hbm',
-                     'kernel': (f'k_agg_gemm2 (+hub kernels): aggregation d=256 {a.agg_dtype} rows + the next 256x256 dense transform on the matrix cores in one kernel'
-                                if fam_main is fam_tail else f'k_spmm_rows (+hub kernels) d=256 {a.agg_dtype} source rows, f32 accumulate'),
-                     'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                     'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'traffic_from_profile': traffic_profile,
-                     'launches_timed': fam_main['launches_timed'], 'avg_launch_ms': avg_ms, 'algorithmic_bytes_per_launch': avg_bytes,
-                     'fused_epilogue_bytes_per_launch': avg_extra, 'achieved_incl_fused_epilogue': achieved_incl,
-                     'plain_aggregation_launches': fam_plain, 'aggregation_plus_gemm_launches': fam_tail,
-                     'row_sparse_aggregation_launches': fam_sparse,
-                     'note': ('dominant kernel = aggregation + next GEMM fused (cb_agg_gemm.hip): algorithmic bytes = SURVEY 8(d) aggregation bytes + the dense '
-                              "tail's compulsory output (+ addend) — its 10 GB input never leaves the chip, and 7.9 TF-bf16 of MFMA work (3.2 ms at peak) "
-                              'run under the gathers; the launches of the plain aggregation kernel in the same steps are listed beside it'
-                              if fam_main is fam_tail else 'dominant kernel = the plain aggregation')},
+                     'kernel': f"{KERNEL_OF.get(fam_main['kind'], fam_main['kind'])}; d=256 {a.agg_dtype} source rows, f32 accumulate, "
+                               f"{fam_main['edges_per_launch']} edges per launch",
+                     'achieved': fam_main['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': fam_main['frac'], 'traffic': None,
+                     'traffic_from_profile': traffic_profile,
+                     'launches_timed': fam_main['launches_timed'], 'avg_launch_ms': fam_main['avg_launch_ms'],
+                     'algorithmic_bytes_per_launch': fam_main['survey_8d_bytes_per_launch'],
+                     'achieved_incl_fused_streams': fam_main['achieved_incl_fused_streams'], 'frac_incl_fused_streams': fam_main['frac_incl_fused_streams'],
+                     'per_family': families,
+                     'note': ('achieved / frac = SURVEY 8(d) bytes of the aggregation ONLY / average launch time (HIP events on the launch stream inside the '
+                              'timed steps) / 8 TB/s, for the family with the largest time per step; per_family lists every kernel form x CSR of the step the '
+                              "same way.  *_incl_fused_streams add the kernel's other compulsory streams (a fused store's mixed-in row + mask words, a dense "
+                              "tail's output / addend / row scale) — traffic those kernels must move, not 8(d) bytes")},
     }
     if dense_bwd is not None:
         out['dense_backward'] = dense_bwd
-    if fam_sparse is not None:
+    if row_sparse:
         out['config']['backward'] = ('row-sparse: under the masked loss the gradient is exactly zero outside the rows the train rows reach after j hops; the levels '
                                      'of the backward whose support is <= 70 % of the rows (train rows, their neighbours) run on compact matrices and gather only '
-                                     'those rows (the claim is verified on the device every step; CB_LOSS_ROWS=0: dense backward); aggregated_edges_per_sec counts '
-                                     'the nominal E per aggregation')
+                                     'those rows (the claim is verified on the device every step; CB_LOSS_ROWS=0: dense backward, timed beside it as `dense_backward`)')
     out['peak_mem_gb'] = peak_mem / 2 ** 30
     if sharding is not None:
         out['sharding'] = sharding
@@ -589,7 +640,7 @@ def main():
     if a.pmc_traffic and world == 1 and not sharded:
         del t, graph_obj                     # the PMC passes build their own copy of the graph in a child process
         torch.cuda.empty_cache()
-        traffic, note = pmc_traffic(a.dataset, fused=fam_main is fam_tail)
+        traffic, note = pmc_traffic(a.dataset, fused=fam_main['kind'].startswith('agg_gemm'))
         out['roofline']['traffic'] = traffic
         out['roofline']['traffic_note'] = note
     os.write(json_fd, (json.dumps(out) + '\n').encode())

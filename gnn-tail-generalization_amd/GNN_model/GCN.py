@@ -99,11 +99,12 @@ class TricksComb(nn.Module):
             self.dglgraph = build_graph(edge_index)
         return self.dglgraph
 
-    def forward(self, x, edge_index, want_les=False):
+    def forward(self, x, edge_index, want_les=False, loss_rows=None):
+        """loss_rows: see TeacherGNN.forward (an extension of the reference's signature; the general path below ignores it)."""
         graph = self._graph(edge_index)
         new_adjs = self.graph_dropout(edge_index)      # computed and discarded, as in the reference (GCN.py:101,111)
         if self.use_fused_trunk and not getattr(graph, 'segmented', False) and trunk.eligible(self, x, want_les):
-            return trunk.forward(self, x, graph)
+            return trunk.forward(self, x, graph, loss_rows=loss_rows)
         if getattr(self.args, 'agg_dtype', 'f32') != 'f32' and not want_les:
             raise NotImplementedError("--agg_dtype=bf16 (bf16-stored aggregation rows) is built for the fused 'Initial' trunk "
                                       '(hidden width a multiple of 256); this configuration runs the fp32 operator path')

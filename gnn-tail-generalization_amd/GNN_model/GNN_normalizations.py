@@ -17,8 +17,8 @@ class GNN_norm(nn.Module):
         super().__init__()
         self.model = TricksComb(args)
 
-    def forward(self, x, edge_index):
-        return self.model.forward(x, edge_index)
+    def forward(self, x, edge_index, loss_rows=None):
+        return self.model.forward(x, edge_index, loss_rows=loss_rows)
 
 
 class TeacherGNN(nn.Module):
@@ -47,13 +47,17 @@ class TeacherGNN(nn.Module):
             x = x * 0
         return self.embs if self.args.dim_learnable_input > 0 else x
 
-    def forward(self, x, edge_index):
-        self.out, self.se_reg_all = self.model(self._input(x), edge_index)
+    def forward(self, x, edge_index, loss_rows=None):
+        """loss_rows (extension, default None = the reference's call): (bool mask [N], count) — the caller's promise that the objective it
+        builds on this forward's output puts gradient into the rows of the mask only (the masked loss of trainer…:390-391; any head between
+        the output and the loss must be row-wise, as proj2class is).  The fused trunk's backward then skips the rows that stay zero; the
+        promise is verified on the device every step (ops.check_rows_zero), a broken one raises and leaves the weights untouched."""
+        self.out, self.se_reg_all = self.model(self._input(x), edge_index, loss_rows=loss_rows)
         return self.out
 
-    def get_3_embs(self, x, edge_index, mask=None, want_heads=True):
+    def get_3_embs(self, x, edge_index, mask=None, want_heads=True, loss_rows=None):
         res = D()
-        res.commonEmb = self.forward(x, edge_index)
+        res.commonEmb = self.forward(x, edge_index, loss_rows=loss_rows)
         res.emb4classi_full = self.proj2class(res.commonEmb)
         res.emb4classi = res.emb4linkp = None
         if want_heads:

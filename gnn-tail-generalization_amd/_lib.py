@@ -25,7 +25,7 @@ SIGNATURES = {
     'cb_last_error': (ctypes.c_char_p, []),
     'cb_device_status': (ctypes.c_int, []),
     'cb_agg_gemm_handover_selftest': (ctypes.c_int, [_P]),
-    'cb_rows_zero_outside_mask_f32': (ctypes.c_int, [_P, _I64, _I64, _I64, _P, _P]),
+    'cb_rows_zero_outside_mask_f32': (ctypes.c_int, [_P, _I64, _I64, _I64, _P, _P, _P]),
     'cb_csr_workspace_bytes': (_SZ, [_I64, _I64]),
     'cb_csr_from_coo_i64': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'cb_deg_norm_f32': (ctypes.c_int, [_P, _I64, _P, _P]),
@@ -49,7 +49,7 @@ SIGNATURES = {
     'cb_adam_step_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_float, ctypes.c_float, _I64, _P, _P]),
     'cb_adam_multi_f32': (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
-                                         ctypes.c_float, _I64, _P, _P]),
+                                         ctypes.c_float, _I64, _P, _P, _P]),
     'cb_gemm_nn_workspace_bytes': (_SZ, [_I64, _I64]),
     'cb_gemm_nn_splitk_workspace_bytes': (_SZ, [_I64, _I64, _I64]),
     'cb_gemm_nn_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int, _P, _SZ, _P]),
@@ -90,7 +90,7 @@ SIGNATURES = {
     'cb_gather_rows_bf16_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _P, _P]),
     'cb_adam_norm_workspace_bytes': (ctypes.c_size_t, [_I32]),
     'cb_adam_multi_norm_f32': (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
-                                              ctypes.c_float, _I64, _P, _P, _SZ, _P]),
+                                              ctypes.c_float, _I64, _P, _P, _P, _SZ, _P]),
     'cb_expand_rows_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P]),
     'cb_agg_gemm_image_bytes': (_SZ, [_I64, _I64]),
     'cb_agg_gemm_image_f32': (ctypes.c_int, [_P, _I64, _I64, _I64, ctypes.c_int, _P, _SZ, _P]),
@@ -167,15 +167,42 @@ def check(rc, what):
         raise HipExtensionError(f'{what} failed (rc={rc}): {msg.decode() if msg else ""}')
 
 
+_guards = {}      # device index -> int32 [1] device tensor (grad_guard)
+
+
+def grad_guard(device, create=True):
+    """The device word a failed gradient check sets (cb_rows_zero_outside_mask_f32, `guard`) and the fused Adam reads
+    (cb_adam_multi_norm_f32, `guard`): while it is non-zero the optimiser launch writes nothing, so the truncated gradients of a
+    row-sparse backward whose claim did not hold never reach the parameters or the moments — without a host synchronisation between
+    backward() and step().  One word per device, allocated at the first check; cleared by device_status() when it reports the error."""
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    g = _guards.get(idx)
+    if g is None and create:
+        g = _guards[idx] = torch.zeros(1, dtype=torch.int32, device=f'cuda:{idx}')
+    return g
+
+
 def device_status():
     """Raises HipExtensionError if a kernel recorded a device-side error since the last call (a tile hand-over of the aggregation + GEMM
-    kernel that timed out: the results of that launch are invalid).  Does not synchronise: the trainer calls it after the
+    kernel that timed out: the results of that launch are invalid; a gradient row outside the loss rows that was not zero: the optimiser
+    step of that backward was skipped on the device, see grad_guard).  Does not synchronise: the trainer calls it after the
     synchronisation that ends a step (where it reads the loss)."""
     lib = load()
     rc = lib.cb_device_status()
     if rc != 0:
         msg = lib.cb_last_error()
+        for g in _guards.values():      # the error is in the caller's hands now: the next step may update again
+            g.zero_()
         raise HipExtensionError(f'device-side error (rc={rc}): {msg.decode() if msg else ""}')
+    for g in _guards.values():
+        # node-sharded: the guard word is all-reduced with the gradients (dist.allreduce_grads), so a check that failed on ANOTHER rank
+        # shows here — every rank raises, none trains on alone
+        if int(g.item()) != 0:
+            g.zero_()
+            raise HipExtensionError('device-side error: the guard word of the gradient-row check is set but this process holds no error report '
+                                    '(the check failed on another rank, or the report was taken through cb_device_status() directly); '
+                                    'the optimiser step of that backward was skipped')
 
 
 def stream_ptr():

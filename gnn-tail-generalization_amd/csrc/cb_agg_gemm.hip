@@ -476,8 +476,10 @@ static int spmm_gemm_fused_impl(int skip_next, const float* acc_init, int64_t ld
   const int rc = agg_gemm_common_checks("cb_spmm_gemm_fused_f32", N, E, d, rowptr, col, h, ld_h, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr,
                                         ws, ws_bytes, image, g_addend, ld_add, g_out, ld_gout, acc_init, ld_init);
   if (rc != CB_OK || N == 0) return rc;
-  CB_CHECK_ARG(out_next && ag_al16(out_next) && ld_next % 4 == 0 && ld_next >= d && (!mix_src || (ag_al16(mix_src) && ld_mix % 4 == 0)), CB_E_INVALID,
-               "cb_spmm_gemm_fused_f32: 16-byte aligned rows required");
+  // (the evaluation form writes out_next for hub rows only: without a hub plan it may be NULL)
+  CB_CHECK_ARG((out_next || (skip_next && n_hubs == 0)) && ag_al16(out_next) && ld_next % 4 == 0 && ld_next >= d &&
+                   (!mix_src || (ag_al16(mix_src) && ld_mix % 4 == 0)),
+               CB_E_INVALID, "cb_spmm_gemm_fused_f32: 16-byte aligned rows required");
   CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, CB_E_INVALID, "cb_spmm_gemm_fused_f32: dropout p out of range");
   if (n_hubs == 0) hub_T = INT32_MAX;
   Epilogue ep{row_scale, bias, 1, acc_init, ld_init, col_flags};
@@ -509,7 +511,7 @@ static int spmm_gemm_fused_impl(int skip_next, const float* acc_init, int64_t ld
 extern "C" int cb_spmm_gemm_fused_f32(CB_SGF_PARAMS) { return spmm_gemm_fused_impl(0, CB_SGF_ARGS); }
 // The same for a forward that no backward follows (evaluation / metrics passes): the stored activations X_{l+1} have no reader — the next
 // layer's Z leaves this kernel —, so the rows the persistent kernel finishes stay on chip (out_next: still the hub rows' way into the
-// tile, contents otherwise undefined).  10 GB less written per launch at the headline size.
+// tile, contents otherwise undefined; may be NULL when the plan has no hub rows).  10 GB less written per launch at the headline size.
 extern "C" int cb_spmm_gemm_fused_eval_f32(CB_SGF_PARAMS) { return spmm_gemm_fused_impl(1, CB_SGF_ARGS); }
 #undef CB_SGF_PARAMS
 #undef CB_SGF_ARGS

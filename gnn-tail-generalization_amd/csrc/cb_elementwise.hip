@@ -613,7 +613,9 @@ struct AdamTable {
 };
 
 __global__ void __launch_bounds__(kBlock) k_adam_multi(AdamTable t, float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                       float bc2_sqrt, const int64_t* __restrict__ step_dev) {
+                                                       float bc2_sqrt, const int64_t* __restrict__ step_dev, const int32_t* __restrict__ guard) {
+  // a gradient check of this step failed (cb_rows_zero_outside_mask_f32 set the word): parameters and moments stay as they are
+  if (guard && *guard != 0) return;
   const int ti = blockIdx.y;
   float* __restrict__ p = t.p[ti];
   const float* __restrict__ g = t.g[ti];
@@ -740,10 +742,11 @@ extern "C" int cb_act_bwd_f32(const float* g, const float* act, const float* row
 
 // Rows of g outside `mask` must be exactly zero (the claim a row-sparse backward rests on: ops.take_grad_rows / trunk.py).  A streaming pass
 // over the matrix (contiguous rows: float4 per thread, the row of an element by one division); a violation is recorded in the device error
-// word (never silent: cb_device_status reports it).
+// word (never silent: cb_device_status reports it) and, if given, in the caller's `guard` word in device memory: an optimiser launch that
+// follows on the same stream and is handed the same word leaves parameters and moments untouched (the truncated gradients never reach them).
 template <bool VEC4>
 __global__ void __launch_bounds__(kBlock) k_rows_zero_check(const float* __restrict__ g, int64_t ld, int64_t rows, int d, const uint8_t* __restrict__ mask,
-                                                            int* __restrict__ err) {
+                                                            int* __restrict__ err, int32_t* __restrict__ guard) {
   const int64_t per_row = VEC4 ? d / 4 : d;
   const int64_t n = rows * per_row;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
@@ -759,20 +762,21 @@ __global__ void __launch_bounds__(kBlock) k_rows_zero_check(const float* __restr
       __hip_atomic_store(err + 1, (int)(r & 0x7fffffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(err + 2, (int)(r >> 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(err, CB_DEVERR_GRADROWS, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (guard) *guard = 1;      // device memory: read by the Adam launch that follows on the stream (cb_adam_multi_norm_f32, `guard`)
     }
   }
 }
 
-extern "C" int cb_rows_zero_outside_mask_f32(const float* g, int64_t ld, int64_t rows, int64_t d, const uint8_t* mask, void* stream) {
+extern "C" int cb_rows_zero_outside_mask_f32(const float* g, int64_t ld, int64_t rows, int64_t d, const uint8_t* mask, int32_t* guard, void* stream) {
   CB_CHECK_ARG(rows >= 0 && d >= 0 && d < (1 << 20) && ld >= d, CB_E_INVALID, "cb_rows_zero_outside_mask_f32: bad size");
   if (rows == 0 || d == 0) return CB_OK;
   CB_CHECK_ARG(g && mask, CB_E_INVALID, "cb_rows_zero_outside_mask_f32: null pointer");
   int* err = device_error_word();
   CB_CHECK_ARG(err != nullptr, CB_E_HIP, "cb_rows_zero_outside_mask_f32: the device error word could not be allocated (%s)", cb_last_error());
   if (d % 4 == 0 && ld % 4 == 0 && aligned16(g))
-    hipLaunchKernelGGL((k_rows_zero_check<true>), dim3((unsigned)grid_for(rows * (d / 4))), dim3(kBlock), 0, (hipStream_t)stream, g, ld, rows, (int)d, mask, err);
+    hipLaunchKernelGGL((k_rows_zero_check<true>), dim3((unsigned)grid_for(rows * (d / 4))), dim3(kBlock), 0, (hipStream_t)stream, g, ld, rows, (int)d, mask, err, guard);
   else
-    hipLaunchKernelGGL((k_rows_zero_check<false>), dim3((unsigned)grid_for(rows * d)), dim3(kBlock), 0, (hipStream_t)stream, g, ld, rows, (int)d, mask, err);
+    hipLaunchKernelGGL((k_rows_zero_check<false>), dim3((unsigned)grid_for(rows * d)), dim3(kBlock), 0, (hipStream_t)stream, g, ld, rows, (int)d, mask, err, guard);
   CB_LAUNCH_CHECK();
   return CB_OK;
 }
@@ -836,8 +840,8 @@ extern "C" size_t cb_adam_norm_workspace_bytes(int32_t n_norms) { return (size_t
 
 extern "C" int cb_adam_multi_norm_f32(int32_t n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
                                       const int64_t* numel, const float* const* extra_decay, float* const* norm_out, float lr, float beta1,
-                                      float beta2, float eps, float weight_decay, int64_t step, const int64_t* step_dev, void* ws,
-                                      size_t ws_bytes, void* stream) {
+                                      float beta2, float eps, float weight_decay, int64_t step, const int64_t* step_dev, const int32_t* guard,
+                                      void* ws, size_t ws_bytes, void* stream) {
   CB_CHECK_ARG(n_tensors >= 0 && (step >= 1 || step_dev) && (n_tensors == 0 || (p && g && m && v && numel)), CB_E_INVALID,
                "cb_adam_multi_f32: bad argument");
   int n_norms = 0;
@@ -864,7 +868,7 @@ extern "C" int cb_adam_multi_norm_f32(int32_t n_tensors, float* const* p, const 
     const int nb = nmax ? grid_for((nmax + 3) / 4) : 0;
     if (nb) {
       hipLaunchKernelGGL(k_adam_multi, dim3((unsigned)nb, (unsigned)cnt), dim3(kBlock), 0, (hipStream_t)stream, t, lr,
-                         beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), step_dev);
+                         beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), step_dev, guard);
       CB_LAUNCH_CHECK();
     }
     for (int i = 0; i < cnt; ++i)      // out[0] = ||p||_F, out[1] = ||p||_F^2 (cb_frobenius_norm_f32's pair) of every tensor that asked
@@ -878,9 +882,9 @@ extern "C" int cb_adam_multi_norm_f32(int32_t n_tensors, float* const* p, const 
 
 extern "C" int cb_adam_multi_f32(int32_t n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
                                  const int64_t* numel, const float* const* extra_decay, float lr, float beta1, float beta2, float eps,
-                                 float weight_decay, int64_t step, const int64_t* step_dev, void* stream) {
-  return cb_adam_multi_norm_f32(n_tensors, p, g, m, v, numel, extra_decay, nullptr, lr, beta1, beta2, eps, weight_decay, step, step_dev, nullptr, 0,
-                                stream);
+                                 float weight_decay, int64_t step, const int64_t* step_dev, const int32_t* guard, void* stream) {
+  return cb_adam_multi_norm_f32(n_tensors, p, g, m, v, numel, extra_decay, nullptr, lr, beta1, beta2, eps, weight_decay, step, step_dev, guard, nullptr,
+                                0, stream);
 }
 
 static int launch_trunk_bwd(int mode, int out_bf16, const float* g, const uint64_t* bits, const float* act, const float* row_scale,

@@ -615,10 +615,13 @@ class ShardedGraph:
             # requester at least COVER_MIN_GAIN of its rows (power-law graphs: 25 - 32 %; the ogbn-products shape: < 6 % -> plain pull,
             # whose pack is a row gather and whose slices follow the owners' row chunks)
             asg = CoverPlan.assign(rows[remote], cols[remote], part)
-            gain = torch.tensor([int(1000 * (1.0 - asg['rows_cover'] / max(asg['rows_pull'], 1)))], dtype=torch.int64, device=rows.device)
+            # (the busiest requester under either plan — MAX of each count over the ranks —, not the best ratio of any one rank: a rank with
+            # nothing to pull in this orientation has no say)
+            busiest = torch.tensor([int(asg['rows_pull']), int(asg['rows_cover'])], dtype=torch.int64, device=rows.device)
             if part.world > 1:
-                _all_reduce(gain, op=dist.ReduceOp.MAX, group=self.group)
-            use_cover = int(gain.item()) >= int(1000 * COVER_MIN_GAIN) or self._cover_forced
+                _all_reduce(busiest, op=dist.ReduceOp.MAX, group=self.group)
+            n_pull, n_cover = (int(v) for v in busiest.tolist())
+            use_cover = (n_pull > 0 and 1.0 - n_cover / n_pull >= COVER_MIN_GAIN) or self._cover_forced
         o.plan = CoverPlan(rows[remote], cols[remote], part, self.group, K, self.compute, asg) if use_cover else HaloPlan(uniq, part, self.group, K)
         if self.overlap:
             o.interior = self.compute.csr(rows[~remote], cols[~remote] - lo, self.N, self.N)
@@ -828,18 +831,21 @@ def sharded_aggregate(graph, h_local, row_scale=None, bias=None, relu=False):
     return _ShardedAggregateFn.apply(graph, h_local, row_scale, bias, bool(relu))
 
 
-def allreduce_grads(params, group=None):
-    """Sum the gradients of the replicated parameters in one flat bucket (weights are a few hundred KB)."""
+def allreduce_grads(params, group=None, guard=None):
+    """Sum the gradients of the replicated parameters in one flat bucket (weights are a few hundred KB).  guard (int32 [1] device word,
+    _lib.grad_guard): rides in the same bucket, so that a failed gradient check on ONE rank stops the optimiser launch on EVERY rank."""
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    flat = torch.cat([g.reshape(-1) for g in grads] + ([guard.to(grads[0].dtype)] if guard is not None else []))
     _all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     off = 0
     for g in grads:
         n = g.numel()
         g.copy_(flat[off:off + n].view_as(g))
         off += n
+    if guard is not None:
+        guard.copy_((flat[off:off + 1] != 0).to(guard.dtype))
 
 
 class _AllReduceSumFn(torch.autograd.Function):
@@ -1142,7 +1148,8 @@ class ShardedTrainer:
     def training_loss(self):
         from . import ops
         m = self.teacherGNN
-        out = m.get_3_embs(self.x, self.edge_index).emb4classi_full
+        # (loss_rows: this rank's rows of the train mask — the objective touches the logits there only, trainer_node_classification.training_loss)
+        out = m.get_3_embs(self.x, self.edge_index, loss_rows=(self.train_mask, self.n_train)).emb4classi_full
         # local numerator / global count; the global loss is the sum over ranks
         unit = float(self.args.TeacherGNN.lossa_semantic) == 1.0
         loss = ops.nll_logsoftmax(out, self.y, self.train_mask, self.n_train, unit_grad=unit)
@@ -1164,7 +1171,7 @@ class ShardedTrainer:
                 self._headtail_metrics()
             self.optimizer.zero_grad()
             loss.backward()
-        allreduce_grads(self.replicated, self.group)
+        allreduce_grads(self.replicated, self.group, guard=_lib.grad_guard(self.device))
         self.optimizer.step()
         total = loss.detach().clone()
         _all_reduce(total, group=self.group)

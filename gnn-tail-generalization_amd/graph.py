@@ -18,6 +18,12 @@ HOT_BYTES = 256 << 20      # the hot source rows of an aggregation should fill t
 HOT_ROWS = HOT_BYTES // 1024   # 262 144 rows at d = 256 fp32 (1 KiB rows): the measured optimum on S-pl10M (profiles/r02_spmm_gather_policy.md)
 
 
+def prof_rec(ev0, ev1, g, kind, agg_bytes, store_bytes=0, tail_bytes=0):
+    """One timed aggregation launch for bench.py's roofline: HIP events around it, the launch's SURVEY.md 8(d) bytes, the bytes of the
+    streams a fused store / dense tail adds (kept apart), the edges the launch walked (g.E of the CSR it ran on) and the kernel family."""
+    return {'ev': (ev0, ev1), 'agg': int(agg_bytes), 'store': int(store_bytes), 'tail': int(tail_bytes), 'edges': int(g.E), 'rows': int(g.N), 'kind': kind}
+
+
 class ZeroInDegreeError(RuntimeError):
     """Stands where the reference raises dgl.base.DGLError (GCN.py:187-197)."""
 
@@ -82,7 +88,7 @@ class CSRGraph:
         self._plan_t = self._plan if self.symmetric else self._make_plan(self.rowptr_t)
         self._ws = None
         self._hot_cols()
-        self.profile = None      # bench.py sets a list: (start_event, end_event, SURVEY §8(d) bytes, extra epilogue bytes) per aggregation
+        self.profile = None      # bench.py sets a list: one prof_rec() per aggregation launch
 
     def _hot_cols(self):
         """Kernel-side column arrays with the hot-source flag in bit 31 (include/coldbrew_hip.h, cb_spmm_csr_f32 col_flags):
@@ -371,8 +377,8 @@ class CSRGraph:
                            'cb_spmm_csr')
         if prof is not None:
             ev1.record()
-            prof.append((ev0, ev1, self.algorithmic_bytes(d, row_scale=row_scale is not None, bias=bias is not None,
-                                                          src_elem=2 if bf16 else 4), 0))
+            prof.append(prof_rec(ev0, ev1, self, 'colscale' if col_scale is not None else 'plain',
+                                 self.algorithmic_bytes(d, row_scale=row_scale is not None, bias=bias is not None, src_elem=2 if bf16 else 4)))
         return out
 
     def spmm_gemm_trunkbwd(self, h, image, g_rowscale, bits, c_act, p, seed, row0, rowscale2, want_colsum, transpose=True, acc_init=None):
@@ -416,7 +422,8 @@ class CSRGraph:
                        'cb_spmm_gemm_trunkbwd_f32')
         if prof is not None:
             ev1.record()
-            prof.append((ev0, ev1, self.algorithmic_bytes(d, row_scale=False, bias=False), 0, self.N * 256 * 4 * 2 + 4 * self.N + 32 * self.N))
+            prof.append(prof_rec(ev0, ev1, self, 'agg_gemm_trunkbwd', self.algorithmic_bytes(d, row_scale=False, bias=False), 0,
+                                 self.N * 256 * 4 * 2 + 4 * self.N + 32 * self.N))
         return out, g, gr, colsum
 
     def spmm_lp(self, h, row_scale, mix, c_mix, post_scale=None, out=None):
@@ -530,8 +537,8 @@ class CSRGraph:
         if prof is not None:
             ev1.record()
             # SURVEY §8(d) bytes of the aggregation; the dense tail's own stream (its [N, 256] output) is kept apart
-            prof.append((ev0, ev1, self.algorithmic_bytes(d, row_scale=row_scale is not None, bias=bias is not None), 0,
-                         self.N * 256 * 4 * (2 if g_addend is not None else 1) + (4 * self.N if g_rowscale is not None else 0)))
+            prof.append(prof_rec(ev0, ev1, self, 'agg_gemm', self.algorithmic_bytes(d, row_scale=row_scale is not None, bias=bias is not None), 0,
+                                 self.N * 256 * 4 * (2 if g_addend is not None else 1) + (4 * self.N if g_rowscale is not None else 0)))
         return out, g_out
 
     def _acc_out(self, acc_init, d, device):

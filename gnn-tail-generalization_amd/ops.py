@@ -331,26 +331,19 @@ def axpby(a, x, b, y):
 # loss
 # ---------------------------------------------------------------------------------------------
 # Row-sparse backward: the masked loss's gradient w.r.t. the logits is zero outside the loss rows, and so is everything row-wise stages
-# make of it.  _NllFn.backward leaves a note (the gradient buffer it returned, the mask, the row count); a consumer that receives exactly that
-# buffer as its upstream gradient picks it up with take_grad_rows() and may skip the other rows — after check_rows_zero() has put the claim
-# under the device's own eyes (violations end in the device error word, never in silent wrong gradients).  CB_LOSS_ROWS=0 switches it off.
-_GRAD_ROWS = []
-
-
-def take_grad_rows(gout):
-    """(mask, count) if `gout` is the gradient buffer the masked loss just produced, else None; the note is consumed."""
-    note = _GRAD_ROWS[0] if _GRAD_ROWS else None
-    _GRAD_ROWS[:] = []
-    if note is None or os.environ.get('CB_LOSS_ROWS', '1') == '0':
-        return None
-    ptr, shape, mask, count = note
-    if gout.data_ptr() != ptr or tuple(gout.shape) != shape or mask.shape[0] != gout.shape[0]:
-        return None
-    return mask, count
+# make of it.  The caller that builds such an objective SAYS so: `loss_rows=(mask, count)` handed to the forward (TeacherGNN.get_3_embs ->
+# TricksComb.forward -> trunk) is the promise that the logits of that forward receive gradient in the rows of `mask` only; the trunk's
+# backward then may skip the other rows — after check_rows_zero() has put the claim under the device's own eyes: a violation ends in the
+# device error word AND in the guard word that keeps the optimiser launch of that step from writing (_lib.grad_guard), never in silent wrong
+# gradients or updated weights.  CB_LOSS_ROWS=0 makes every backward dense.
+def loss_rows_enabled():
+    return os.environ.get('CB_LOSS_ROWS', '1') != '0'
 
 
 def check_rows_zero(g, mask):
-    """Device-side check that every row of g outside `mask` is exactly zero (cb_rows_zero_outside_mask_f32)."""
+    """Device-side check that every row of g outside `mask` is exactly zero (cb_rows_zero_outside_mask_f32).  A violation is recorded in
+    the device error word (the trainers raise where they read the loss) and in the device's guard word: the fused Adam launch that follows
+    on the stream then leaves parameters and moments untouched (_lib.grad_guard)."""
     lib = _lib.load()
     _lib.require_device(g, mask)
     if g.stride(1) != 1:
@@ -358,7 +351,7 @@ def check_rows_zero(g, mask):
     m8 = mask.view(torch.uint8)
     with torch.cuda.device(g.device):
         _lib.check(lib.cb_rows_zero_outside_mask_f32(_lib.ptr(g), g.stride(0) if g.shape[0] > 1 else g.shape[1], g.shape[0], g.shape[1], _lib.ptr(m8),
-                                                     _lib.stream_ptr()), 'cb_rows_zero_outside_mask_f32')
+                                                     _lib.ptr(_lib.grad_guard(g.device)), _lib.stream_ptr()), 'cb_rows_zero_outside_mask_f32')
 
 
 class _NllFn(torch.autograd.Function):
@@ -378,7 +371,6 @@ class _NllFn(torch.autograd.Function):
                                                  _lib.ptr(loss), _lib.ptr(grad), _lib.ptr(ws), wsb, _lib.stream_ptr()),
                        'cb_nll_logsoftmax_f32')
         ctx.save_for_backward(grad)
-        ctx.rows_mask, ctx.rows_count = mask, int(count)
         return loss[0].clone()
 
     @staticmethod
@@ -386,11 +378,8 @@ class _NllFn(torch.autograd.Function):
         (grad,) = ctx.saved_tensors
         # unit_grad: the caller promised that this loss enters its objective with coefficient 1 and that backward() is seeded
         # with 1 (the trainers' own step): the [N, C] pass that would multiply by that 1 is skipped
-        out = grad if ctx.unit_grad else grad * g
-        # rows outside the mask are exactly zero in `out`: whoever receives THIS tensor as its upstream gradient may run a
-        # row-sparse backward (take_grad_rows)
-        _GRAD_ROWS[:] = [(out.data_ptr(), tuple(out.shape), ctx.rows_mask, ctx.rows_count)] if ctx.rows_mask is not None else []
-        return out, None, None, None, None
+        # (rows outside the mask are exactly zero: what a forward called with loss_rows=(mask, count) relies on)
+        return (grad if ctx.unit_grad else grad * g), None, None, None, None
 
 
 def nll_logsoftmax(logits, y, mask=None, count=None, unit_grad=False):

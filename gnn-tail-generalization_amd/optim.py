@@ -88,7 +88,7 @@ class Adam(torch.optim.Optimizer):
                                                          one(st['exp_avg_sq'].data_ptr()), one(p.numel(), ctypes.c_int64),
                                                          one(extra.data_ptr() if extra is not None else None), group['lr'], b1, b2,
                                                          group['eps'], group['weight_decay'], st['step'], _lib.ptr(self._step_dev),
-                                                         _lib.stream_ptr()), 'cb_adam_multi_f32')
+                                                         _lib.ptr(_lib.grad_guard(p.device, create=False)), _lib.stream_ptr()), 'cb_adam_multi_f32')
                     continue
                 ps.append(p.data_ptr()); gs.append(g.data_ptr()); ms.append(st['exp_avg'].data_ptr())
                 vs.append(st['exp_avg_sq'].data_ptr()); ns.append(p.numel())
@@ -110,7 +110,10 @@ class Adam(torch.optim.Optimizer):
                                                           arr(cs, ctypes.c_void_p) if any(c is not None for c in cs) else None,
                                                           arr(qs, ctypes.c_void_p) if wanted else None,
                                                           group['lr'], b1, b2, group['eps'],
-                                                          group['weight_decay'], step, _lib.ptr(self._step_dev), _lib.ptr(ws), wsb, _lib.stream_ptr()),
+                                                          group['weight_decay'], step, _lib.ptr(self._step_dev),
+                                                          # (a failed gradient check of this step's backward: the launch writes nothing, _lib.grad_guard)
+                                                          _lib.ptr(_lib.grad_guard(group['params'][0].device, create=False)), _lib.ptr(ws), wsb,
+                                                          _lib.stream_ptr()),
                                'cb_adam_multi_norm_f32')
                 for p, norm in wanted:
                     p._cb_norm = (p._version, norm)

@@ -259,9 +259,11 @@ class trainer:
 
     def training_loss(self):
         """Forward + loss of run_trainSet (:386-394): nll(log_softmax(out[train])) + se_reg * sum ||E||."""
-        res = self.teacherGNN.get_3_embs(self.data.x, self.data.edge_index)
         if getattr(self, '_n_train', None) is None:
             self._n_train = int(self.data.train_mask.sum().item())      # once: keeps the step free of host syncs
+        # the objective below touches the logits in the train rows only (and nothing else of this forward's output): said to the model,
+        # whose backward may then skip the rows that stay zero (ops.py "Row-sparse backward"; verified on the device every step)
+        res = self.teacherGNN.get_3_embs(self.data.x, self.data.edge_index, loss_rows=(self.data.train_mask, self._n_train))
         # == F.nll_loss(F.log_softmax(out[train_mask], 1), y[train_mask]) (:390-391), fused, no row gather
         unit = float(self.args.TeacherGNN.lossa_semantic) == 1.0      # the step seeds backward() with 1: no [N, C] pass to multiply by it
         loss = ops.nll_logsoftmax(res.emb4classi_full, self.data.y, self.data.train_mask, self._n_train, unit_grad=unit)
@@ -281,8 +283,9 @@ class trainer:
         build, workspaces, optimizer state); restore=True puts parameters, buffers and optimizer moments / step counts back to
         their values from before the warm-up (in place), so that the replays continue exactly where the caller was."""
         import torch.cuda
-        from . import trunk
-        trunk.ROWSPARSE_SMALL_OK = True      # (set before the warm-up steps: they build the row-support plan the captured step replays)
+        # under replay the extra launches of the row-sparse backward cost nothing: this trainer's graph takes the plan at any size
+        # (set before the warm-up steps: they build the row-support plan the captured step replays)
+        self.graph().rowsparse_small_ok = True
         if restore:
             snap_model = {k: v.detach().clone() for k, v in self.teacherGNN.state_dict().items()}
             snap_opt = {p: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}

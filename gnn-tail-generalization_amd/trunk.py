@@ -64,9 +64,10 @@ def _fused_gemm_launch(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowsc
     n, d = g.N, z.shape[1]
     dev = z.device
     bits = torch.empty((n, d // 256, 4), dtype=torch.int64, device=dev) if want_bits else None
-    out_next = torch.empty((n, d), dtype=torch.float32, device=dev)
-    z_next = torch.empty((n, 256), dtype=torch.float32, device=dev)
     plan = g._plan
+    # (the evaluation form keeps the finished rows on chip: X_{l+1} goes to memory only as the hub rows' way into the tile)
+    out_next = torch.empty((n, d), dtype=torch.float32, device=dev) if (want_bits or plan.n_hubs > 0) else None
+    z_next = torch.empty((n, 256), dtype=torch.float32, device=dev)
     wsb = lib.cb_spmm_workspace_bytes(plan.n_chunks, d)
     ws = g._workspace(wsb)
     prof = getattr(graph, 'profile', None)
@@ -88,8 +89,11 @@ def _fused_gemm_launch(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowsc
                    'cb_spmm_gemm_fused_f32')
     if prof is not None:
         ev1.record()
-        prof.append((ev0, ev1, g.algorithmic_bytes(d), n * d * 4 + n * d // 8,
-                     n * 256 * 4 * (2 if g_addend is not None else 1) + (4 * n if g_rowscale is not None else 0)))
+        from .graph import prof_rec
+        # (the evaluation form writes neither the mask words nor X_{l+1}: 8(d)'s output stream is not there, its rows stay on chip)
+        prof.append(prof_rec(ev0, ev1, g, 'agg_gemm_fused' if want_bits else 'agg_gemm_fused_eval',
+                             g.algorithmic_bytes(d) - (0 if want_bits else n * d * 4), n * d * 4 + (n * d // 8 if want_bits else 0),
+                             n * 256 * 4 * (2 if g_addend is not None else 1) + (4 * n if g_rowscale is not None else 0)))
     return bits, out_next if want_bits else None, z_next
 
 
@@ -155,7 +159,8 @@ def _fused_launch(lib, graph, g, z, acc, bias, x0, c_act, c_mix, p, seed, want_a
     if prof is not None:
         ev1.record()
         # SURVEY §8(d) bytes of the aggregation; the fused store's own streams (mixed-in row read + mask bits) are kept apart
-        prof.append((ev0, ev1, g.algorithmic_bytes(d, src_elem=2 if bf16 else 4), n * d * 4 + n * d // 8))
+        from .graph import prof_rec
+        prof.append(prof_rec(ev0, ev1, g, 'fused_store', g.algorithmic_bytes(d, src_elem=2 if bf16 else 4), n * d * 4 + (n * d // 8 if want_bits else 0)))
     return bits, out_next, act
 
 
@@ -245,7 +250,7 @@ def tail_trunk_bwd(graph):
 # The input Linear's GEMM writes the mask words of (X0 > 0) from its epilogue (a wavefront holds a whole 256-column row there: four ballots),
 # and the input stage of the backward reads those 32 bytes per row instead of X0's 1 KiB (one of its six 10 GB streams).
 ROWSPARSE_MIN_NODES = 1 << 16      # below this a step is launch-bound and the extra check kernel costs more than the gather saves
-ROWSPARSE_SMALL_OK = False         # set by trainer.enable_hip_graph: under hipGraph replay the extra launches cost nothing, so small graphs take the plan too (S-pubmed config 2: 0.787 -> 0.751 ms/step)
+#                                    (graph.rowsparse_small_ok, set by trainer.enable_hip_graph on ITS graph, lifts the limit: under hipGraph replay the extra launches cost nothing — S-pubmed config 2: 0.787 -> 0.751 ms/step)
 ROWSPARSE_S0_LIMIT = 0.7           # the plan is used while the loss rows are at most this share of the rows (S-pl10M with 50 % / 70 % loss rows: 187.9 / 193.2 ms against 195.4 / 196.3 dense)
 ROWSPARSE_LOSS_SIDE = True         # level 0 of the plan through the loss rows' side when the plan holds the orientation for it (graph.FWD0_ROWS_PER_EDGE)
 ROWSPARSE_MAX_FRAC = 0.7           # a level's output stays compact while its support is at most this share of the rows (S-arxiv, support 61 %: 3.53 -> 3.40 ms/step against 0.6)
@@ -290,9 +295,10 @@ def _chunked(graph, agg_bf16):
 class _TrunkFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph, cfg, x, w_in, b_in, w_out, b_out, *layer_params):
-        """layer_params = (W_0, bias_0, le_0 | None, W_1, ...).  cfg = (L, alpha, p, seeds, agg_bf16, track): track = autograd was recording
-        when the trunk was called (inside a Function's forward it never is, and needs_input_grad does not know about no_grad)."""
-        L, alpha, p, seeds, agg_bf16, track = cfg
+        """layer_params = (W_0, bias_0, le_0 | None, W_1, ...).  cfg = (L, alpha, p, seeds, agg_bf16, track, loss_rows): track = autograd was
+        recording when the trunk was called (inside a Function's forward it never is, and needs_input_grad does not know about no_grad);
+        loss_rows = None or (bool mask [N], count): the caller's promise that the output receives gradient in those rows only (ops.py)."""
+        L, alpha, p, seeds, agg_bf16, track, _loss_rows = cfg
         row0 = int(getattr(graph, 'row_offset', 0))
         a = graph.norm_out
         x = x.contiguous()
@@ -352,7 +358,8 @@ class _TrunkFn(torch.autograd.Function):
             z0 = None
             if l == 0 and z_front is not None:      # left the forward-front kernel
                 z0 = z_front
-            elif cur is None:      # layer 0 with no dropped copy of X0: its GEMM draws the mask while it stages X0
+            elif l == 0 and cur is None:      # layer 0 with no dropped copy of X0: its GEMM draws the mask while it stages X0
+                # (l > 0 with cur None: a forward that no backward follows — the activations stayed on chip and Z_l is in z_ready)
                 z0 = None if (agg_bf16 or (not ag and _chunked(graph, agg_bf16))) else gemm.mm_nn_indrop(x0, w, p, seeds[1], row0, rowscale=a, addend=le)
                 if z0 is None:
                     cur = saved_in[0] = dropped_x0()
@@ -393,7 +400,9 @@ class _TrunkFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        graph, (L, alpha, p, seeds, agg_bf16, _track), row0 = ctx.graph, ctx.cfg, ctx.row0
+        graph, (L, alpha, p, seeds, agg_bf16, _track, loss_rows), row0 = ctx.graph, ctx.cfg, ctx.row0
+        if loss_rows is not None and (not ops.loss_rows_enabled() or loss_rows[0].shape[0] != gout.shape[0]):
+            loss_rows = None
         sv = list(ctx.saved_tensors)
         xd, x0, w_in, w_out = sv[:4]
         saved_in = sv[4: 4 + L + 1]
@@ -438,7 +447,7 @@ class _TrunkFn(torch.autograd.Function):
         # ships and gathers only the rows of the support S_j; matrices keep all local rows, every other branch of this function is unchanged.
         sh_levels = []
         if sharded and hasattr(graph, 'support_orients'):
-            hint = ops.take_grad_rows(gout)
+            hint = loss_rows
             if hint is not None:
                 ops.check_rows_zero(gout, hint[0])
                 sh_levels = graph.support_orients(hint[0], L)
@@ -483,11 +492,11 @@ class _TrunkFn(torch.autograd.Function):
         # columns are renumbered to positions in S_{j+1} and S_j), and the input stage takes the per-layer gradients as compact operands.
         # The claim "rows outside the loss rows are zero" is checked on the device (ops.check_rows_zero: a violation ends in the device error
         # word, never in silent wrong gradients).  One GPU, hidden 256, gathered per-layer gradients, loss rows <= 70 % of the nodes.
-        rows_hint = ops.take_grad_rows(gout) if (not sharded and hasattr(graph, 'grad_support_plan') and graph.rowptr_t is not None) else None
+        rows_hint = loss_rows if (not sharded and hasattr(graph, 'grad_support_plan') and graph.rowptr_t is not None) else None
         plan = None
         # (with bf16-stored rows the compact levels still run on fp32 matrices through the aggregation + GEMM kernel; the dense levels below
         # them go on as the bf16 path does)
-        if (rows_hint is not None and 1 <= rows_hint[1] <= ROWSPARSE_S0_LIMIT * gout.shape[0] and (gout.shape[0] >= ROWSPARSE_MIN_NODES or ROWSPARSE_SMALL_OK) and gather
+        if (rows_hint is not None and 1 <= rows_hint[1] <= ROWSPARSE_S0_LIMIT * gout.shape[0] and (gout.shape[0] >= ROWSPARSE_MIN_NODES or getattr(graph, 'rowsparse_small_ok', False)) and gather
                 and agg_gemm_eligible(graph, h, False) and not tail_tb and graph.support_plan_pays()):
             ops.check_rows_zero(gout, rows_hint[0])
             plan = graph.grad_support_plan(rows_hint[0], L, max_frac=ROWSPARSE_MAX_FRAC)
@@ -599,7 +608,7 @@ class _TrunkFn(torch.autograd.Function):
         del g, gx0, g_mix
         d_w_in = None
         if need[3]:
-            if ctx.indrop:      # xd holds the undropped features: the mask is regenerated while the GEMM stages them
+            if ctx.indrop and p > 0:      # xd holds the undropped features: the mask is regenerated while the GEMM stages them
                 d_w_in = gemm.mm_tn_gdrop(gpre, xd, p, seeds[0], row0)
                 if d_w_in is None:
                     d_w_in = gemm.mm_tn(gpre, ops._dropout_raw(xd, p, seeds[0], row0 * xd.shape[1]))
@@ -613,8 +622,9 @@ class _TrunkFn(torch.autograd.Function):
         return (None, None, d_x, d_w_in, d_b_in if need[4] else None, d_w_out, d_b_out, *grads_layers)
 
 
-def forward(tc, x, graph):
-    """TricksComb.forward on the fused trunk; returns (logits, se_reg_all)."""
+def forward(tc, x, graph, loss_rows=None):
+    """TricksComb.forward on the fused trunk; returns (logits, se_reg_all).  loss_rows: None, (bool mask [N], count) or the mask alone — the caller's promise
+    that the logits receive gradient in the rows of the mask only (the masked loss, trainer_node_classification.py:390-391)."""
     L = tc.num_layers
     p = float(tc.dropout) if tc.training else 0.0
     seeds = tuple(ops.next_seed() for _ in range(L + 2)) if p > 0 else (0,) * (L + 2)
@@ -632,6 +642,13 @@ def forward(tc, x, graph):
     if not all(c._allow_zero_in_degree for c in tc.layers_GCN):      # GCN.py:187-197; set_allow_zero_in_degree(True) lifts it
         graph.check_zero_in_degree()
     agg_bf16 = getattr(tc.args, 'agg_dtype', 'f32') == 'bf16'
-    out = _TrunkFn.apply(graph, (L, float(tc.alpha), p, seeds, agg_bf16, torch.is_grad_enabled()), x, tc.layers_MLP[0].weight, tc.layers_MLP[0].bias,
+    if loss_rows is not None:
+        mask, count = loss_rows if isinstance(loss_rows, (tuple, list)) else (loss_rows, None)
+        if count is None:      # (a host sync: the trainers hand the count, computed once per run)
+            count = int(mask.sum().item())
+        if mask.dtype != torch.bool or mask.dim() != 1 or mask.shape[0] != x.shape[0]:
+            raise ValueError(f'loss_rows: a bool mask over the {x.shape[0]} rows expected, got {tuple(mask.shape)} {mask.dtype}')
+        loss_rows = (mask, int(count))
+    out = _TrunkFn.apply(graph, (L, float(tc.alpha), p, seeds, agg_bf16, torch.is_grad_enabled(), loss_rows), x, tc.layers_MLP[0].weight, tc.layers_MLP[0].bias,
                          tc.layers_MLP[1].weight, tc.layers_MLP[1].bias, *params)
     return out, se_reg_all

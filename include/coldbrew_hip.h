@@ -54,8 +54,11 @@ int cb_device_status(void);
  * enters the model is zero in every row outside the loss rows, and so is everything the head and the last trunk store make of it — the
  * first reverse aggregation of the backward (autograd of GCN.py:238) then only has to gather the loss rows (graph.CSRGraph.filtered_t).
  * This call verifies the claim on the device: any non-zero element of g [rows, d] in a row with mask[row] == 0 records
- * CB_DEVERR_GRADROWS in the device error word (cb_device_status). */
-int cb_rows_zero_outside_mask_f32(const float* g, int64_t ld, int64_t rows, int64_t d, const uint8_t* mask, void* stream);
+ * CB_DEVERR_GRADROWS in the device error word (cb_device_status).  guard (may be NULL): an int32 in DEVICE memory the caller owns; a
+ * violation also sets it to 1.  Handed to the optimiser launch that follows on the same stream (cb_adam_multi_norm_f32), it keeps the
+ * truncated gradients of such a step away from the parameters and the moments without a host synchronisation in between; the caller
+ * clears it when it handles the error. */
+int cb_rows_zero_outside_mask_f32(const float* g, int64_t ld, int64_t rows, int64_t d, const uint8_t* mask, int32_t* guard, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Graph ingest — replaces `dgl.graph((src_list, dst_list))` built through Python lists
@@ -188,8 +191,9 @@ int cb_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
  * autograd accumulation into le.grad: 50 bytes / element less HBM traffic per table per step. */
 int cb_adam_multi_f32(int32_t n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* numel,
                       const float* const* extra_decay, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                      const int64_t* step_dev, void* stream);
-/* step_dev (may be NULL): the step count read from device memory instead of `step` (hipGraph replay). */
+                      const int64_t* step_dev, const int32_t* guard, void* stream);
+/* step_dev (may be NULL): the step count read from device memory instead of `step` (hipGraph replay).
+ * guard (may be NULL): int32 in device memory; while it is non-zero the launch writes nothing (see cb_rows_zero_outside_mask_f32). */
 /* The same, and for every tensor with norm_out[i] != NULL also norm_out[i][0] = ||p_i||_F, [1] = ||p_i||_F^2 of the UPDATED tensor
  * (cb_frobenius_norm_f32's pair, same thread-to-element map and summation order when the tensor is the largest of its launch): the
  * next forward's `th.norm(self.le)` (GCN.py:232) costs no pass of its own over the table.  ws: cb_adam_norm_workspace_bytes(number of
@@ -197,7 +201,8 @@ int cb_adam_multi_f32(int32_t n_tensors, float* const* p, const float* const* g,
 size_t cb_adam_norm_workspace_bytes(int32_t n_norms);
 int cb_adam_multi_norm_f32(int32_t n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* numel,
                            const float* const* extra_decay, float* const* norm_out, float lr, float beta1, float beta2, float eps,
-                           float weight_decay, int64_t step, const int64_t* step_dev, void* ws, size_t ws_bytes, void* stream);
+                           float weight_decay, int64_t step, const int64_t* step_dev, const int32_t* guard, void* ws, size_t ws_bytes,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Dense fp32 contractions on the matrix cores.  Default: every fp32 operand is decomposed exactly into three
@@ -446,7 +451,7 @@ int cb_spmm_gemm_fused_f32(const float* acc_init, int64_t ld_init, const int32_t
                            const float* g_rowscale, const float* g_addend, int64_t ld_add, float* g_out, int64_t ld_gout, void* stream);
 /* cb_spmm_gemm_fused_f32 for a forward that no backward follows (evaluation / metrics passes, GCN.py:100-140 under no_grad): the stored
  * activations have no reader — the next layer's Z leaves this kernel — so the rows the persistent kernel finishes are NOT written to
- * out_next (which must still be given: the hub rows pass through it; its other contents are undefined afterwards).  g_out as above. */
+ * out_next (the hub rows pass through it, its other contents are undefined afterwards; NULL is accepted when n_hubs == 0).  g_out as above. */
 int cb_spmm_gemm_fused_eval_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N,
                                 int64_t E, const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias, const float* mix_src,
                                 int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0,

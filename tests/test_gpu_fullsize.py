@@ -289,7 +289,7 @@ def _product_vs_oracle(args, model, data, grad_rel=5e-4):
     import oracle_c
     from gnn_tail_generalization_amd import ops
     model.train()
-    out = model(data.x, data.edge_index)
+    out = model(data.x, data.edge_index, loss_rows=data.train_mask)      # (the promise the trainer makes: the loss below touches those rows only)
     loss = nll = ops.nll_logsoftmax(out, data.y, data.train_mask)
     if model.se_reg_all is not None:
         loss = nll + args.se_reg * model.se_reg_all

@@ -1,4 +1,4 @@
-"""GPU: the row-sparse backward (trunk.py, CSRGraph.grad_support_plan, ops.take_grad_rows / check_rows_zero).
+"""GPU: the row-sparse backward (trunk.py, CSRGraph.grad_support_plan, the loss_rows promise of the forward / ops.check_rows_zero).
 The masked loss of trainer_node_classification.py:390-391 has a gradient that is zero in every row outside the train rows, and the
 backward keeps it zero outside the rows those can reach; the levels of the backward whose support is small run on compact matrices.
 Gradients equal the dense backward's up to the order in which sums are associated, the claim is verified on the device, and a violation
@@ -129,7 +129,7 @@ def test_row_sparse_backward_matches_the_unmodified_reference(case, monkeypatch)
     args, model = product_model(g['cfg'], g['sd'], DEV)
     x, ei, y, mask = g['x'].to(DEV), g['edge_index'].to(DEV), g['y'].to(DEV), g['train_mask'].to(DEV)
     model.train()
-    out = model.get_3_embs(x, ei, mask).emb4classi_full
+    out = model.get_3_embs(x, ei, mask, loss_rows=mask).emb4classi_full
     loss = ops.nll_logsoftmax(out, y, mask)
     if model.se_reg_all is not None:                                  # trainer_node_classification.py:393-394
         loss = loss + args.se_reg * model.se_reg_all
@@ -178,7 +178,7 @@ def test_row_sparse_backward_on_a_directed_multigraph(loss_side, monkeypatch):
         model.train()
         ops._seed_override[:] = [21, 22, 23, 24, 25]
         try:
-            out = model.get_3_embs(x, ei, mask).emb4classi_full
+            out = model.get_3_embs(x, ei, mask, loss_rows=mask).emb4classi_full
             loss = ops.nll_logsoftmax(out, y, mask)
             loss.backward()
         finally:
@@ -307,23 +307,81 @@ def test_violated_claim_is_reported_not_silent():
     bad[row, 3] = 1e-30
     ops.check_rows_zero(bad, mask)
     torch.cuda.synchronize()
-    assert lib.cb_device_status() != 0
-    assert f'row {row}' in lib.cb_last_error().decode()
-    assert lib.cb_device_status() == 0                  # reported once, then cleared
+    assert int(_lib.grad_guard(DEV).item()) == 1        # ... and the word the optimiser launch of such a step looks at is set
+    with pytest.raises(_lib.HipExtensionError, match=f'row {row}'):
+        _lib.device_status()
+    assert lib.cb_device_status() == 0                  # reported once, then cleared — the guard with it
+    assert int(_lib.grad_guard(DEV).item()) == 0
 
 
-def test_the_note_belongs_to_the_loss_gradient_buffer_only():
-    from gnn_tail_generalization_amd import ops
-    logits = torch.randn(3000, 7, device=DEV, requires_grad=True)
-    y = torch.randint(0, 7, (3000,), device=DEV)
-    mask = torch.rand(3000, device=DEV) < 0.3
-    seen = []
-    logits.register_hook(lambda gr: seen.append((ops.take_grad_rows(torch.empty_like(gr)), )))      # some other buffer: no hint, note consumed
-    ops.nll_logsoftmax(logits, y, mask).backward()
-    assert seen == [(None,)] and ops._GRAD_ROWS == []
-    logits2 = torch.randn(3000, 7, device=DEV, requires_grad=True)
-    got = []
-    logits2.register_hook(lambda gr: got.append(ops.take_grad_rows(gr)))
-    ops.nll_logsoftmax(logits2, y, mask).backward()
-    assert got[0] is not None and got[0][0] is not None and got[0][1] == int(mask.sum())
-    assert bool((logits2.grad[~mask] == 0).all())
+def _small_trainer(dataset='S-pl1M'):
+    import bench
+    from gnn_tail_generalization_amd import trainer_node_classification as tnc
+    args = bench.make_args(dataset, ['--manual_assign_GPU=0'])
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        t = tnc.trainer(args, 0)
+        t.setup_teacherGNN()
+    t.teacherGNN.train()
+    if getattr(t, '_n_train', None) is None:
+        t._n_train = int(t.data.train_mask.sum().item())
+    return t
+
+
+def test_without_the_promise_the_backward_is_dense(monkeypatch):
+    """The row hint is an ARGUMENT of the forward (loss_rows=...), not something the backward finds out: a caller that builds another
+    objective on the logits — here the masked loss plus a dense term — simply does not pass it and gets the dense backward, whose gradients
+    equal those of the same objective with CB_LOSS_ROWS=0 bit for bit (it IS the same code path); no plan is built, nothing is checked."""
+    from gnn_tail_generalization_amd import _lib, ops
+    monkeypatch.setenv('CB_LOSS_ROWS', '1')
+    grads = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('CB_LOSS_ROWS', flag)
+        t = _small_trainer()
+        ops._seed_override[:] = [11, 12, 13, 14, 15]
+        out = t.teacherGNN.get_3_embs(t.data.x, t.data.edge_index).emb4classi_full            # the reference's call: no loss_rows
+        loss = ops.nll_logsoftmax(out, t.data.y, t.data.train_mask, t._n_train) + 1e-3 * out.square().mean()
+        loss.backward()
+        ops._seed_override[:] = []
+        torch.cuda.synchronize()
+        _lib.device_status()
+        assert getattr(t.graph(), '_support_plan', None) is None
+        grads.append({k: p.grad.detach().clone() for k, p in t.teacherGNN.named_parameters() if p.grad is not None})
+        del t
+    assert grads[0].keys() == grads[1].keys()
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
+
+
+def test_a_broken_promise_raises_and_never_reaches_the_weights(monkeypatch):
+    """loss_rows handed to the forward, then a DENSE term added to the objective: the device-side check of the backward fails.  The error
+    word reports it (the trainers raise where they read the loss) and the guard word keeps the fused Adam launch that follows on the
+    stream from writing — parameters and moments are bit for bit what they were (the truncated gradients must never be applied)."""
+    from gnn_tail_generalization_amd import _lib, ops
+    monkeypatch.setenv('CB_LOSS_ROWS', '1')
+    t = _small_trainer()
+    t.train_step()                                               # one good step: moments exist
+    torch.cuda.synchronize()
+    _lib.device_status()
+    before = {k: v.detach().clone() for k, v in t.teacherGNN.state_dict().items()}
+    mom = [{k: v.clone() for k, v in st.items() if torch.is_tensor(v)} for st in t.optimizer.state.values()]
+    out = t.teacherGNN.get_3_embs(t.data.x, t.data.edge_index, loss_rows=(t.data.train_mask, t._n_train)).emb4classi_full
+    loss = ops.nll_logsoftmax(out, t.data.y, t.data.train_mask, t._n_train) + 1e-3 * out.square().mean()      # ... and breaks the promise
+    t.optimizer.zero_grad()
+    loss.backward()
+    t.optimizer.step()
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.HipExtensionError, match='outside the loss rows'):
+        _lib.device_status()
+    for k, v in t.teacherGNN.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    for st, old in zip(t.optimizer.state.values(), mom):
+        for k, v in old.items():
+            assert torch.equal(st[k], v), k
+    # the error is handled: the guard is clear again and the next (honest) step updates
+    assert int(_lib.grad_guard(DEV).item()) == 0
+    t.train_step()
+    torch.cuda.synchronize()
+    _lib.device_status()
+    assert any(not torch.equal(v, before[k]) for k, v in t.teacherGNN.state_dict().items())
+
