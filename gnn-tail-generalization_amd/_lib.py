@@ -58,15 +58,15 @@ SIGNATURES = {
     'cb_gemm_tn_workspace_bytes': (_SZ, [_I64, _I64, _I64]),
     'cb_gemm_tn_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _SZ, _P]),
     'cb_spmm_csr_fused_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,
-                                             ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P,
+                                             ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _I32, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P,
                                              _P, _SZ, _P]),
     'cb_trunk_layer_bwd_f32': (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, _P, ctypes.c_int, _I64, _I64, ctypes.c_float, ctypes.c_uint64,
-                                              _P, _I64, ctypes.c_float, ctypes.c_float, _P, _P, _SZ, _P]),
+                                              _P, _I64, ctypes.c_float, ctypes.c_float, _P, ctypes.c_uint64, ctypes.c_float, _P, _P, _SZ, _P]),
     'cb_gemm_nn_bf16out_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int, _P, _SZ, _P]),
     'cb_spmm_csr_bf16_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_int, _P, _I64,
                                             _I32, _I32, _I32, _P, _P, _P, _SZ, _P]),
     'cb_spmm_csr_fused_bf16_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,
-                                                  ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P,
+                                                  ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _I32, _P, _I64, _P, _I64, _I32, _I32, _I32, _P,
                                                   _P, _P, _SZ, _P]),
     'cb_node_norm_fwd_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I64, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P]),
     'cb_node_norm_bwd_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64, ctypes.c_float, ctypes.c_float, _P]),
@@ -80,12 +80,12 @@ SIGNATURES = {
     'cb_spmm_csr_acc_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_int, _P, _I64, _P, _I64,
                                            _I32, _I32, _I32, _P, _P, _P, _SZ, _P]),
     'cb_spmm_csr_fused_acc_f32': (ctypes.c_int, [_P, _I64, _P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float,
-                                                 ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _P, _I64, _P, _I64, _I32,
+                                                 ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _I32, _P, _I64, _P, _I64, _I32,
                                                  _I32, _I32, _P, _P, _P, _SZ, _P]),
     'cb_spmm_csr_acc_bf16_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_int, _P, _I64, _P, _I64,
                                                 _I32, _I32, _I32, _P, _P, _P, _SZ, _P]),
     'cb_spmm_csr_fused_acc_bf16_f32': (ctypes.c_int, [_P, _I64, _P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float,
-                                                      ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _P, _I64, _P, _I64, _I32,
+                                                      ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _I32, _P, _I64, _P, _I64, _I32,
                                                       _I32, _I32, _P, _P, _P, _SZ, _P]),
     'cb_gather_rows_bf16_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _P, _P]),
     'cb_adam_norm_workspace_bytes': (ctypes.c_size_t, [_I32]),
@@ -97,10 +97,10 @@ SIGNATURES = {
     'cb_spmm_gemm_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_int, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P,
                                         _P, _SZ, _P, _P, _P, _I64, _P, _I64, _P]),
     'cb_spmm_gemm_fused_f32': (ctypes.c_int, [_P, _I64, _P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,
-                                              ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _SZ,
+                                              ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _I32, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _SZ,
                                               _P, _P, _P, _I64, _P, _I64, _P]),
     'cb_spmm_gemm_fused_eval_f32': (ctypes.c_int, [_P, _I64, _P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,
-                                                   ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _SZ,
+                                                   ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _I32, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _SZ,
                                                    _P, _P, _P, _I64, _P, _I64, _P]),
     'cb_spmm_gemm_trunkbwd_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _SZ, _P, _P,
                                                  _P, _I64, _P, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _P, _I64, _P, _P, _SZ, _P]),

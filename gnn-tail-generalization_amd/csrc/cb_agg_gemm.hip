@@ -469,8 +469,8 @@ extern "C" int cb_spmm_gemm_trunkbwd_f32(const int32_t* rowptr, const int32_t* c
 static int spmm_gemm_fused_impl(int skip_next, const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N,
                                 int64_t E, const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias,
                                 const float* mix_src, int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed,
-                                const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, float* out_next, int64_t ld_next, int32_t hub_T,
-                                int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,
+                                const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, int32_t bits_relu_only, float* out_act, int64_t ld_act,
+                                float* out_next, int64_t ld_next, int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,
                                 size_t ws_bytes, const void* image, const float* g_rowscale, const float* g_addend, int64_t ld_add,
                                 float* g_out, int64_t ld_gout, void* stream) {
   const int rc = agg_gemm_common_checks("cb_spmm_gemm_fused_f32", N, E, d, rowptr, col, h, ld_h, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr,
@@ -478,7 +478,7 @@ static int spmm_gemm_fused_impl(int skip_next, const float* acc_init, int64_t ld
   if (rc != CB_OK || N == 0) return rc;
   // (the evaluation form writes out_next for hub rows only: without a hub plan it may be NULL)
   CB_CHECK_ARG((out_next || (skip_next && n_hubs == 0)) && ag_al16(out_next) && ld_next % 4 == 0 && ld_next >= d &&
-                   (!mix_src || (ag_al16(mix_src) && ld_mix % 4 == 0)),
+                   (!mix_src || (ag_al16(mix_src) && ld_mix % 4 == 0)) && (!out_act || (ag_al16(out_act) && ld_act % 4 == 0 && ld_act >= d)),
                CB_E_INVALID, "cb_spmm_gemm_fused_f32: 16-byte aligned rows required");
   CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, CB_E_INVALID, "cb_spmm_gemm_fused_f32: dropout p out of range");
   if (n_hubs == 0) hub_T = INT32_MAX;
@@ -487,8 +487,8 @@ static int spmm_gemm_fused_impl(int skip_next, const float* acc_init, int64_t ld
   fe.mix_src = mix_src; fe.ld_mix = ld_mix; fe.c_act = c_act; fe.c_mix = c_mix;
   fe.thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
   fe.keep_scale = 1.f / (1.f - drop_p);
-  fe.seed = seed; fe.seed_dev = seed_dev; fe.row0 = row0; fe.bits = (unsigned long long*)relu_bits;
-  fe.out_act = nullptr; fe.ld_act = 0; fe.out_next = out_next; fe.ld_next = ld_next; fe.d = (int)d;
+  fe.seed = seed; fe.seed_dev = seed_dev; fe.row0 = row0; fe.bits = (unsigned long long*)relu_bits; fe.bits_relu_only = bits_relu_only;
+  fe.out_act = out_act; fe.ld_act = ld_act; fe.out_next = out_next; fe.ld_next = ld_next; fe.d = (int)d;
   fe.skip_next = skip_next;
   GemmTail gt{(const uint4*)image, g_rowscale, g_addend, ld_add, g_out, ld_gout};
   if (acc_init)
@@ -501,12 +501,13 @@ static int spmm_gemm_fused_impl(int skip_next, const float* acc_init, int64_t ld
 #define CB_SGF_PARAMS                                                                                                                              \
   const float *acc_init, int64_t ld_init, const int32_t *rowptr, const int32_t *col, int32_t col_flags, int64_t N, int64_t E, const float *h,      \
       int64_t ld_h, int64_t d, const float *row_scale, const float *bias, const float *mix_src, int64_t ld_mix, float c_act, float c_mix,          \
-      float drop_p, uint64_t seed, const uint64_t *seed_dev, int64_t row0, uint64_t *relu_bits, float *out_next, int64_t ld_next, int32_t hub_T,  \
+      float drop_p, uint64_t seed, const uint64_t *seed_dev, int64_t row0, uint64_t *relu_bits, int32_t bits_relu_only, float *out_act,          \
+      int64_t ld_act, float *out_next, int64_t ld_next, int32_t hub_T,                                                                            \
       int32_t n_hubs, int32_t n_chunks, const int32_t *hub_rows, const int32_t *hub_chunk_ptr, void *ws, size_t ws_bytes, const void *image,       \
       const float *g_rowscale, const float *g_addend, int64_t ld_add, float *g_out, int64_t ld_gout, void *stream
 #define CB_SGF_ARGS                                                                                                                                \
   acc_init, ld_init, rowptr, col, col_flags, N, E, h, ld_h, d, row_scale, bias, mix_src, ld_mix, c_act, c_mix, drop_p, seed, seed_dev, row0,      \
-      relu_bits, out_next, ld_next, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, image, g_rowscale, g_addend, ld_add, g_out,    \
+      relu_bits, bits_relu_only, out_act, ld_act, out_next, ld_next, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, image, g_rowscale, g_addend, ld_add, g_out,    \
       ld_gout, stream
 extern "C" int cb_spmm_gemm_fused_f32(CB_SGF_PARAMS) { return spmm_gemm_fused_impl(0, CB_SGF_ARGS); }
 // The same for a forward that no backward follows (evaluation / metrics passes): the stored activations X_{l+1} have no reader — the next

@@ -150,11 +150,15 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
                                                       void* __restrict__ outv, float* __restrict__ gx0, int accumulate,
                                                       int64_t rows, int d, uint32_t thresh, float keep_scale, uint64_t seed,
                                                       const uint64_t* __restrict__ seed_dev, int64_t row0, float c_act, float c_mix,
-                                                      float* __restrict__ partial, const int64_t* __restrict__ ridx) {
+                                                      float* __restrict__ partial, const int64_t* __restrict__ ridx,
+                                                      const float* __restrict__ g2, uint64_t seed2, float c2) {
+  // g2 (MODE 0, dense rows; may be null): the 'Residual' connection (res_tricks.py:7-14) — this layer's ReLU output A_l is also the mix source
+  // of layer l+1, so dL/dA_l = c_act * dropout_bwd_seed(g) + c2 * dropout_bwd_seed2(g2), g2 = the gradient w.r.t. layer l+1's stored (dropped)
+  // output; `bits` must then be the ReLU mask alone (bits_relu_only of the forward store)
   // ridx (MODE 0, gx0 == NULL): g / out hold only the rows ridx[0 .. rows) of the matrix (the loss rows of a row-sparse backward); mask words,
   // row scale and the dropout mask are those of row ridx[r]
   extern __shared__ float s_red[];  // [4 waves][256 cols] per tile pass
-  if (seed_dev) seed += *seed_dev;
+  if (seed_dev) { seed += *seed_dev; seed2 += *seed_dev; }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int tiles = d >> 8;
   const int64_t rows_per_block = (rows + gridDim.x - 1) / gridDim.x;
@@ -191,8 +195,21 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
           *reinterpret_cast<float4*>(gx0 + off) = a;
         }
         const unsigned long long* bw = bits + (rr * tiles + tile) * 4;
+        if (g2) {      // (uniform) second gradient through the same ReLU, under the next layer's dropout mask
+          float g2m[4] = {__builtin_nontemporal_load(g2 + off), __builtin_nontemporal_load(g2 + off + 1), __builtin_nontemporal_load(g2 + off + 2),
+                          __builtin_nontemporal_load(g2 + off + 3)};
+          if (thresh) {
+            float m2[4];
+            keep4(seed2, ((row0 + rr) * d + c) >> 2, thresh, keep_scale, m2);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) gy[k] = ((bw[k] >> lane) & 1ull) ? c_act * gm[k] : 0.f;
+            for (int k = 0; k < 4; ++k) g2m[k] *= m2[k];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) gy[k] = ((bw[k] >> lane) & 1ull) ? c_act * gm[k] + c2 * g2m[k] : 0.f;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) gy[k] = ((bw[k] >> lane) & 1ull) ? c_act * gm[k] : 0.f;
+        }
       } else {
         const float4 a = *reinterpret_cast<const float4*>(gx0 + off);
         const float4 x = *reinterpret_cast<const float4*>(act + off);
@@ -890,13 +907,13 @@ extern "C" int cb_adam_multi_f32(int32_t n_tensors, float* const* p, const float
 static int launch_trunk_bwd(int mode, int out_bf16, const float* g, const uint64_t* bits, const float* act, const float* row_scale,
                             void* out, float* gx0, int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed,
                             const uint64_t* seed_dev, int64_t row0, float c_act, float c_mix, float* colsum, void* ws, size_t ws_bytes,
-                            hipStream_t st, const int64_t* ridx = nullptr) {
+                            hipStream_t st, const int64_t* ridx = nullptr, const float* g2 = nullptr, uint64_t seed2 = 0, float c2 = 0.f) {
   int64_t nb = (rows + 63) / 64;
   if (nb > kMaxBlocks) nb = kMaxBlocks;
   const uint32_t thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
   const float ks = 1.f / (1.f - drop_p);
   float* partial = colsum ? (float*)ws : nullptr;
-#define CB_TB_ARGS g, (const unsigned long long*)bits, act, row_scale, out, gx0, accumulate, rows, (int)d, thresh, ks, seed, seed_dev, row0, c_act, c_mix, partial, ridx
+#define CB_TB_ARGS g, (const unsigned long long*)bits, act, row_scale, out, gx0, accumulate, rows, (int)d, thresh, ks, seed, seed_dev, row0, c_act, c_mix, partial, ridx, g2, seed2, c2
   const dim3 grid((unsigned)nb), blk(kBlock);
   const size_t sh = kBlock * 4 * sizeof(float);
   if (mode == 0 && ridx) hipLaunchKernelGGL((k_trunk_bwd<0, false, true, true>), grid, blk, sh, st, CB_TB_ARGS);
@@ -915,16 +932,17 @@ static int launch_trunk_bwd(int mode, int out_bf16, const float* g, const uint64
 
 extern "C" int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits, const float* row_scale, void* out, int out_bf16,
                                       float* gx0, int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed,
-                                      const uint64_t* seed_dev, int64_t row0, float c_act, float c_mix, float* colsum, void* ws,
-                                      size_t ws_bytes, void* stream) {
+                                      const uint64_t* seed_dev, int64_t row0, float c_act, float c_mix, const float* g2, uint64_t seed2, float c2,
+                                      float* colsum, void* ws, size_t ws_bytes, void* stream) {
   CB_CHECK_ARG(rows >= 0 && d > 0 && d % 256 == 0 && d < (1 << 20), CB_E_INVALID, "cb_trunk_layer_bwd_f32: d must be a multiple of 256");
   if (rows == 0) return CB_OK;
+  CB_CHECK_ARG(!g2 || aligned16(g2), CB_E_INVALID, "cb_trunk_layer_bwd_f32: misaligned second gradient");
   CB_CHECK_ARG(g && relu_bits && (out || colsum) && aligned16(g) && ((uintptr_t)out % (out_bf16 ? 8 : 16) == 0) && (!gx0 || aligned16(gx0)),
                CB_E_INVALID, "cb_trunk_layer_bwd_f32: null or misaligned pointer");
   CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, CB_E_INVALID, "cb_trunk_layer_bwd_f32: dropout p out of range");
   CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_colsum_workspace_bytes(rows, d)), CB_E_WORKSPACE, "cb_trunk_layer_bwd_f32: workspace too small");
   return launch_trunk_bwd(0, out_bf16, g, relu_bits, nullptr, row_scale, out, gx0, accumulate, rows, d, drop_p, seed, seed_dev, row0, c_act, c_mix,
-                          colsum, ws, ws_bytes, (hipStream_t)stream);
+                          colsum, ws, ws_bytes, (hipStream_t)stream, nullptr, g2, seed2, c2);
 }
 
 // cb_trunk_layer_bwd_f32 over a SUBSET of the rows: g and out are compact [n_rows, d] matrices holding rows row_index[0 .. n_rows) of the full

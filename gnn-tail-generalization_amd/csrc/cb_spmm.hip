@@ -233,7 +233,7 @@ extern "C" int cb_spmm_csr_acc_f32(const int32_t* rowptr, const int32_t* col, in
 
 static int spmm_fused_impl(int h_bf16, const float* acc_init, int64_t ld_init, int col_flags, const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const void* h, int64_t ld_h,
                                      int64_t d, const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix,
-                                     float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits,
+                                     float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, int32_t bits_relu_only,
                                      float* out_act, int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_T,
                                      int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr,
                                      void* ws, size_t ws_bytes, void* stream) {
@@ -257,7 +257,7 @@ static int spmm_fused_impl(int h_bf16, const float* acc_init, int64_t ld_init, i
   fe.mix_src = mix_src; fe.ld_mix = ld_mix; fe.c_act = c_act; fe.c_mix = c_mix;
   fe.thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
   fe.keep_scale = 1.f / (1.f - drop_p);
-  fe.seed = seed; fe.seed_dev = seed_dev; fe.row0 = row0; fe.bits = (unsigned long long*)relu_bits;
+  fe.seed = seed; fe.seed_dev = seed_dev; fe.row0 = row0; fe.bits = (unsigned long long*)relu_bits; fe.bits_relu_only = bits_relu_only;
   fe.out_act = out_act; fe.ld_act = ld_act; fe.out_next = out_next; fe.ld_next = ld_next; fe.d = (int)d;
   if (h_bf16)
     return launch_spmm<4, true, bf16_t>(rowptr, col, N, (const bf16_t*)h, ld_h, d, ep, out_next, ld_next, hub_T, n_hubs, n_chunks,
@@ -270,16 +270,16 @@ static int spmm_fused_impl(int h_bf16, const float* acc_init, int64_t ld_init, i
   const int32_t *rowptr, const int32_t *col, int64_t N, int64_t E, const void *h, int64_t ld_h, int64_t d, const float *row_scale, \
       const float *bias, const float *mix_src, int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed,               \
       const uint64_t *seed_dev, int64_t row0,                                                                                      \
-      uint64_t *relu_bits, float *out_act, int64_t ld_act, float *out_next, int64_t ld_next, int32_t hub_T, int32_t n_hubs,        \
+      uint64_t *relu_bits, int32_t bits_relu_only, float *out_act, int64_t ld_act, float *out_next, int64_t ld_next, int32_t hub_T, int32_t n_hubs,        \
       int32_t n_chunks, const int32_t *hub_rows, const int32_t *hub_chunk_ptr, void *ws, size_t ws_bytes, void *stream
 #define CB_FUSED_ARGS                                                                                                            \
-  rowptr, col, N, E, h, ld_h, d, row_scale, bias, mix_src, ld_mix, c_act, c_mix, drop_p, seed, seed_dev, row0, relu_bits, out_act, ld_act,  \
+  rowptr, col, N, E, h, ld_h, d, row_scale, bias, mix_src, ld_mix, c_act, c_mix, drop_p, seed, seed_dev, row0, relu_bits, bits_relu_only, out_act, ld_act,  \
       out_next, ld_next, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, stream
 
 extern "C" int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h,
                                      int64_t ld_h, int64_t d, const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix,
                                      float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0,
-                                     uint64_t* relu_bits, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
+                                     uint64_t* relu_bits, int32_t bits_relu_only, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
                                      int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
                                      const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
   return spmm_fused_impl(0, nullptr, 0, col_flags, CB_FUSED_ARGS);
@@ -289,7 +289,7 @@ extern "C" int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, 
 extern "C" int cb_spmm_csr_fused_acc_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int32_t col_flags,
                                          int64_t N, int64_t E, const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias,
                                          const float* mix_src, int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed,
-                                         const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, float* out_act, int64_t ld_act,
+                                         const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, int32_t bits_relu_only, float* out_act, int64_t ld_act,
                                          float* out_next, int64_t ld_next, int32_t hub_T, int32_t n_hubs, int32_t n_chunks,
                                          const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
   CB_CHECK_ARG(acc_init != nullptr || N == 0, CB_E_INVALID, "cb_spmm_csr_fused_acc_f32: acc_init is null");
@@ -299,7 +299,7 @@ extern "C" int cb_spmm_csr_fused_acc_f32(const float* acc_init, int64_t ld_init,
 extern "C" int cb_spmm_csr_fused_bf16_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const uint16_t* h,
                                           int64_t ld_h, int64_t d, const float* row_scale, const float* bias, const float* mix_src,
                                           int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed,
-                                          const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
+                                          const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, int32_t bits_relu_only, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
                                           int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
                                           const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
   return spmm_fused_impl(1, nullptr, 0, col_flags, CB_FUSED_ARGS);
@@ -360,8 +360,8 @@ extern "C" int cb_spmm_csr_acc_bf16_f32(const int32_t* rowptr, const int32_t* co
 extern "C" int cb_spmm_csr_fused_acc_bf16_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int32_t col_flags,
                                               int64_t N, int64_t E, const uint16_t* h, int64_t ld_h, int64_t d, const float* row_scale,
                                               const float* bias, const float* mix_src, int64_t ld_mix, float c_act, float c_mix, float drop_p,
-                                              uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, float* out_act,
-                                              int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_T, int32_t n_hubs, int32_t n_chunks,
+                                              uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, int32_t bits_relu_only,
+                                              float* out_act, int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_T, int32_t n_hubs, int32_t n_chunks,
                                               const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
   CB_CHECK_ARG(acc_init != nullptr || N == 0, CB_E_INVALID, "cb_spmm_csr_fused_acc_bf16_f32: acc_init is null");
   return spmm_fused_impl(1, acc_init, ld_init, col_flags, CB_FUSED_ARGS);

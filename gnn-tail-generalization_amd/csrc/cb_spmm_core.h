@@ -159,6 +159,8 @@ struct FusedEpi {
   const uint64_t* seed_dev;  // hipGraph mode: per-step seed part in device memory (added to `seed`), or null
   int64_t row0;           // global index of local row 0 (node-sharded runs draw the unsharded mask)
   unsigned long long* bits;  // [N][d/256][4] or null
+  int bits_relu_only;     // mask words hold (act > 0) alone, not (act > 0 AND kept by this store's dropout): the 'Residual' trunk, whose backward
+                          // also sends the NEXT layer's mix gradient through this ReLU (under another dropout mask)
   float* out_act;         // [N, ld_act] or null
   int64_t ld_act;
   float* out_next;        // [N, ld_next]
@@ -181,7 +183,7 @@ __device__ __forceinline__ void fused_store(const FusedEpi& fe, int64_t row, int
     unsigned long long mine = 0ull;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const unsigned long long w = __ballot(a[k] > 0.f && m[k] != 0.f);
+      const unsigned long long w = __ballot(a[k] > 0.f && (fe.bits_relu_only || m[k] != 0.f));
       if (lane == k) mine = w;
     }
     if (lane < 4) fe.bits[(row * (fe.d >> 8) + (c0 >> 8)) * 4 + lane] = mine;

@@ -59,7 +59,9 @@ import torch.distributed as dist
 
 from . import _lib
 
-NODE_WEIGHT = 12      # one node's dense work (GEMMs, elementwise) ~ 12 edges' aggregation work per step (S-pl10M profile)
+from .tuning import T
+
+NODE_WEIGHT = T.node_weight      # (tuning.T: node_weight, cover_min_gain, slice_min_bytes, support_max_edge_frac)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -248,7 +250,7 @@ def default_slices(n_halo_rows, d=256):
     env = os.environ.get('COLDBREW_HALO_SLICES')
     if env:
         return max(1, int(env))
-    return 4 if int(n_halo_rows) * d * 4 >= (64 << 20) else 1
+    return 4 if int(n_halo_rows) * d * 4 >= T.slice_min_bytes else 1
 
 
 class HaloPlan:
@@ -328,7 +330,7 @@ def cover_slices_enabled():
     return os.environ.get('COLDBREW_HALO_COVER', '1') != '0'
 
 
-COVER_MIN_GAIN = 0.10      # a rank pair leaves the plain pull only for >= 10 % fewer rows: pushed rows cost the owner an aggregation over their edges
+COVER_MIN_GAIN = T.cover_min_gain
 
 
 def choose_cover(u_idx, v_idx, q_u, q_v, n_u, n_v, P, min_gain=COVER_MIN_GAIN):
@@ -636,7 +638,7 @@ class ShardedGraph:
             o.whole = self.compute.csr(rows, new_col, self.N, self.N + o.plan.n_halo)
         return o
 
-    def support_orients(self, mask_local, n_aggr, max_edge_frac=0.9):
+    def support_orients(self, mask_local, n_aggr, max_edge_frac=None):
         """Level orientations of a row-sparse backward (trunk.py; graph.CSRGraph.grad_support_plan is the one-GPU form): reverse aggregation
         j gathers only rows of the support S_j (S_0 = the loss rows `mask_local` of this rank, S_{j+1} = rows with a reverse-orientation
         neighbour in S_j) — all other rows of the gathered matrix are exact zeros.  Level j = the reverse orientation restricted to the edges
@@ -644,6 +646,7 @@ class ShardedGraph:
         graph ships a tenth of the rows, the second 45 %), its interior / halo passes read fewer edges; matrices keep all local rows.
         Levels are built while they keep at most max_edge_frac of the edges (one decision for the group); the supports travel as byte
         maps (all-gather of N bytes per level, once per mask).  Returns a list of orientations, possibly empty."""
+        max_edge_frac = T.support_max_edge_frac if max_edge_frac is None else max_edge_frac
         key = (mask_local.data_ptr(), mask_local._version, int(n_aggr))
         if self._support_cache is not None and self._support_cache[0] == key and self._support_cache[1] is mask_local:
             return self._support_cache[2]

@@ -9,13 +9,10 @@ out_degrees(), number_of_edges(), number_of_nodes().
 import torch
 
 from . import _lib
+from .tuning import T
 
-HUB_THRESHOLD = 256      # rows with more edges are reduced in chunks of this size by the hub kernels (64 / 128 / 512 / 1024 measured equal or slower)
-FWD0_ROWS_PER_EDGE = 0.25 # grad_support_plan keeps the forward orientation on the loss rows when S_1 has at least this many more rows than S_0 per edge between them (S-pl10M: 0.35)
-FWD0_MIN_EDGES = 1 << 19  # ... and the level moves at least this many edges: below, its kernels are latency-bound and two more launches cost more than the rows save (S-arxiv, 2.3 * 10^5 edges at level 0: 3.35 -> 3.41 ms/step with the form; S-pubmed under hipGraph 0.600 -> 0.627; S-pl1M, 10^6 edges: 16.15 -> 16.0)
+HUB_THRESHOLD = T.hub_threshold      # (thresholds: tuning.T — hub_threshold, hot_bytes, fwd0_rows_per_edge, fwd0_min_edges)
 INT32_EDGE_LIMIT = 2 ** 31 - 1   # edge offsets (rowptr) and column ids are int32 on the device (include/coldbrew_hip.h); see CSRGraph.__init__
-HOT_BYTES = 256 << 20      # the hot source rows of an aggregation should fill the 256 MiB Infinity Cache: count = HOT_BYTES / row bytes
-HOT_ROWS = HOT_BYTES // 1024   # 262 144 rows at d = 256 fp32 (1 KiB rows): the measured optimum on S-pl10M (profiles/r02_spmm_gather_policy.md)
 
 
 def prof_rec(ev0, ev1, g, kind, agg_bytes, store_bytes=0, tail_bytes=0):
@@ -93,19 +90,19 @@ class CSRGraph:
     def _hot_cols(self):
         """Kernel-side column arrays with the hot-source flag in bit 31 (include/coldbrew_hip.h, cb_spmm_csr_f32 col_flags):
         the most-referenced source rows of each orientation (referenced at least twice) — as many as fit the Infinity Cache at the
-        row size being gathered, HOT_BYTES / (d * element bytes) — keep the default cache policy, every other gather streams.
+        row size being gathered, tuning.T.hot_bytes / (d * element bytes) — keep the default cache policy, every other gather streams.
         self.col / self.col_t stay the plain ids (the bit-exact CSR contract).  col_k / col_t_k hold the arrays for 1 KiB rows
         (d = 256 fp32, built eagerly); other row sizes (bf16-stored rows, d = 512) are flagged on first use (flagged_cols).
         CB_SPMM_GATHER=0 switches the flags off (every gather then uses the default cache policy)."""
         import os
         self.col_k = self.col_t_k = None
         self._hot_cache = {}
-        if os.environ.get('CB_SPMM_GATHER', '2') != '2' or self.E == 0 or self.n_cols < 2 * HOT_ROWS:
+        if os.environ.get('CB_SPMM_GATHER', '2') != '2' or self.E == 0 or self.n_cols < 2 * (T.hot_bytes // 1024):
             return      # small graphs: the whole feature matrix is cache resident anyway
         self.col_k, self.col_t_k = self._flag_pair(self._hot_count(1024))
 
     def _hot_count(self, row_bytes):
-        return max(1, min(HOT_BYTES // max(int(row_bytes), 1), self.n_cols))
+        return max(1, min(T.hot_bytes // max(int(row_bytes), 1), self.n_cols))
 
     def _flag_pair(self, k):
         hit = self._hot_cache.get(k)
@@ -131,7 +128,7 @@ class CSRGraph:
         return ck, ctk
 
     def grad_support_plan(self, keep, n_aggr, max_frac=0.6):
-        """Row supports of a backward whose incoming gradient is non-zero on the rows `keep` only (the masked loss: ops.take_grad_rows).
+        """Row supports of a backward whose incoming gradient is non-zero on the rows `keep` only (the masked loss: the loss_rows promise of the forward, ops.py).
         Reverse aggregation j (j = 0 for the last layer) gathers rows of the support S_j and produces non-zero rows exactly on
         S_{j+1} = the rows with a (reverse-orientation) neighbour in S_j; supports are properties of the graph and the mask, not of the
         values, so they are built once (torch ops on the device) and cached.  Returns RowSupportPlan with
@@ -202,12 +199,12 @@ class CSRGraph:
         X^T (a * A^T dY) is taken as ((A (a * X))[S_j])^T dY[S_j] — a contraction over |S_j| rows instead of |S_{j+1}| — and
         a * (A^T dY) W^T as a * A^T (dY W^T): the GEMM on |S_j| rows in front of the aggregation (trunk.py).  n_out = the rows the level
         writes (|S_{j+1}|, or all rows when its destination is dense).  Built when the rows spared (n_out - |S_j|) outweigh the second pass
-        over the level's edges (FWD0_ROWS_PER_EDGE) and the level is large enough to be bound by bandwidth (FWD0_MIN_EDGES), else None."""
+        over the level's edges (tuning.T.fwd0_rows_per_edge) and the level is large enough to be bound by bandwidth (fwd0_min_edges), else None."""
         rpf, colf = self.rowptr, self.col[:self.E]
         deg0 = torch.index_select(rpf[1:] - rpf[:-1], 0, s0.idx)
         rp_c = torch.cat([deg0.new_zeros(1), torch.cumsum(deg0, 0, dtype=torch.int32)])
         e0 = int(rp_c[-1])
-        if (n_out - s0.n) < FWD0_ROWS_PER_EDGE * e0 or e0 < FWD0_MIN_EDGES:
+        if (n_out - s0.n) < T.fwd0_rows_per_edge * e0 or e0 < T.fwd0_min_edges:
             return None
         shift = torch.index_select(rpf, 0, s0.idx).long() - rp_c[:-1].long()          # CSR position minus packed position, per S_0 row
         epos = torch.arange(e0, device=rpf.device) + torch.repeat_interleave(shift, deg0.long())

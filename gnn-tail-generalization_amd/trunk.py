@@ -1,9 +1,10 @@
-"""Fused residual trunk of TricksComb.forward for the 'Initial' connection without a bare norm — the
-configuration the reference's best-config table selects for Pubmed / ogbn-arxiv ('InitialBatchNorm',
-base_options.py:416) and the benchmark graphs.  One autograd node for
+"""Fused residual trunk of TricksComb.forward for the 'Initial' and 'Residual' connections without a bare norm — the
+configurations the reference's best-config table selects for Pubmed / ogbn-arxiv / chameleon / squirrel ('Initial…') and WISCONSIN /
+CORNELL / TEXAS ('Residual…', base_options.py:416-421) and the benchmark graphs.  One autograd node for
 
     X0   = relu(Linear_0(dropout(x)))                                   GCN.py:103-107
-    for l: X  = dropout(X);  Y = GCNConv_l(X);  A = relu(Y);  X = (1-a) A + a X0      GCN.py:109-131
+    for l: X  = dropout(X);  Y = GCNConv_l(X);  A_l = relu(Y);  X = (1-a) A_l + a M_l      GCN.py:109-131
+           M_l = X0 ('Initial', res_tricks.py:16-23)  |  M_0 = X0, M_l = A_{l-1} ('Residual', res_tricks.py:7-14: x_list holds the ReLU outputs)
     out  = Linear_1(dropout(X))                                          GCN.py:133-138
 
 with the hand-written backward.  Forward: ONE kernel for the front (dropout(x), input Linear, ReLU, dropout(X0) and layer 0's
@@ -21,11 +22,18 @@ import os
 import torch
 
 from . import _lib, gemm, ops
+from .tuning import T
+
+
+def connection(tc):
+    """'residual' | 'initial' | None: which mix TricksComb builds for this type_trick (GCN.py:57-60: 'Residual' is tested first)."""
+    t = tc.type_trick
+    return 'residual' if 'Residual' in t else 'initial' if 'Initial' in t else None
 
 
 def eligible(tc, x, want_les):
     t = tc.type_trick
-    return (tc.has_residual_MLP and 'Initial' in t and 'Residual' not in t and 'Jumping' not in t and not want_les
+    return (tc.has_residual_MLP and connection(tc) is not None and 'Jumping' not in t and not want_les
             and tc.args.type_trick not in ('BatchNorm', 'PairNorm', 'NodeNorm', 'MeanNorm', 'GroupNorm', 'CombNorm')
             and tc.dim_hidden % 256 == 0 and x.is_cuda and x.dtype == torch.float32 and len(tc.layers_GCN) == tc.num_layers
             and len(tc.layers_MLP) == 2
@@ -33,7 +41,7 @@ def eligible(tc, x, want_les):
             and tc.embedding_dropout == tc.dropout and tc.args.dropout == tc.dropout)
 
 
-def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False, produce=None, want_bits=True):
+def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False, produce=None, want_bits=True, relu_only=False):
     """(bits, out_next[, act]) of cb_spmm_csr_fused_f32 on the (possibly node-sharded) graph.  Node-sharded + overlapped:
     the exchange runs as the sliced pipeline of dist.ShardedGraph (produce(k, r0, r1), if given, fills rows [r0, r1) of z — the
     row-chunked layer GEMM — right before slice k is packed and sent); the interior-column pass (plain kernel, raw sums) and
@@ -45,19 +53,21 @@ def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False, produ
         flights = sh.start_halo(z, False, produce)
         sh.f.interior.profile = getattr(graph, 'profile', None)
         acc = sh.f.interior.spmm(z)
-        return sh.finish_halo(flights, sh.f, acc, lambda g, recv, a_: _fused_launch(lib, graph, g, recv, a_, bias, x0, c_act, c_mix, p, seed, want_act, want_bits))
+        return sh.finish_halo(flights, sh.f, acc, lambda g, recv, a_: _fused_launch(lib, graph, g, recv, a_, bias, x0, c_act, c_mix, p, seed, want_act, want_bits, relu_only))
     if produce is not None:
         produce(0, 0, z.shape[0])
     if sh is None:
-        return _fused_launch(lib, graph, graph, z, None, bias, x0, c_act, c_mix, p, seed, want_act, want_bits)
-    return _fused_launch(lib, graph, sh.f.whole, sh.exchange(z, False), None, bias, x0, c_act, c_mix, p, seed, want_act, want_bits)
+        return _fused_launch(lib, graph, graph, z, None, bias, x0, c_act, c_mix, p, seed, want_act, want_bits, relu_only)
+    return _fused_launch(lib, graph, sh.f.whole, sh.exchange(z, False), None, bias, x0, c_act, c_mix, p, seed, want_act, want_bits, relu_only)
 
 
-def _fused_gemm_launch(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowscale, g_addend, want_bits=True, g=None, acc=None):
-    """(bits, out_next, z_next) of cb_spmm_gemm_fused_f32: the fused trunk store of layer l and Z_{l+1} = g_rowscale * (out_next @ W_{l+1})
+def _fused_gemm_launch(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowscale, g_addend, want_bits=True, g=None, acc=None, want_act=False,
+                       relu_only=False):
+    """(bits, out_next, z_next[, act]) of cb_spmm_gemm_fused_f32: the fused trunk store of layer l and Z_{l+1} = g_rowscale * (out_next @ W_{l+1})
     + g_addend from one kernel (d = 256, fp32 rows).  g: the CSR to run on (default: the graph itself; node-sharded: the last halo slice,
     z = its receive buffer) with acc = the running sums of the earlier passes.  want_bits=False (a forward that no backward follows):
-    cb_spmm_gemm_fused_eval_f32 — no mask words, and out_next is not written either (it has no reader: returned as None)."""
+    cb_spmm_gemm_fused_eval_f32 — no mask words, and out_next is not written either (it has no reader: returned as None).  want_act: a
+    fourth result, the ReLU output A_l itself (the next 'Residual' layer's mix source); relu_only: mask words of A_l > 0 alone."""
     lib = _lib.load()
     g = graph if g is None else g
     fn = lib.cb_spmm_gemm_fused_f32 if want_bits else lib.cb_spmm_gemm_fused_eval_f32
@@ -68,6 +78,7 @@ def _fused_gemm_launch(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowsc
     # (the evaluation form keeps the finished rows on chip: X_{l+1} goes to memory only as the hub rows' way into the tile)
     out_next = torch.empty((n, d), dtype=torch.float32, device=dev) if (want_bits or plan.n_hubs > 0) else None
     z_next = torch.empty((n, 256), dtype=torch.float32, device=dev)
+    act = torch.empty((n, d), dtype=torch.float32, device=dev) if want_act else None
     wsb = lib.cb_spmm_workspace_bytes(plan.n_chunks, d)
     ws = g._workspace(wsb)
     prof = getattr(graph, 'profile', None)
@@ -82,8 +93,8 @@ def _fused_gemm_launch(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowsc
                       _lib.ptr(col_k if col_k is not None else g.col), int(col_k is not None), n, g.E,
                       _lib.ptr(z), z.stride(0), d, _lib.ptr(graph.norm_in), _lib.ptr(bias), _lib.ptr(x0),
                       x0.stride(0) if x0 is not None else 0, float(c_act), float(c_mix), float(p), ctypes.c_uint64(seed),
-                      ops.seed_dev_ptr(), int(getattr(graph, 'row_offset', 0)), _lib.ptr(bits), _lib.ptr(out_next), d,
-                      g.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr),
+                      ops.seed_dev_ptr(), int(getattr(graph, 'row_offset', 0)), _lib.ptr(bits), int(bool(relu_only)), _lib.ptr(act), d,
+                      _lib.ptr(out_next), d, g.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr),
                       _lib.ptr(ws), wsb, _lib.ptr(image), _lib.ptr(g_rowscale), _lib.ptr(g_addend),
                       g_addend.stride(0) if g_addend is not None else 0, _lib.ptr(z_next), 256, _lib.stream_ptr()),
                    'cb_spmm_gemm_fused_f32')
@@ -94,22 +105,23 @@ def _fused_gemm_launch(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowsc
         prof.append(prof_rec(ev0, ev1, g, 'agg_gemm_fused' if want_bits else 'agg_gemm_fused_eval',
                              g.algorithmic_bytes(d) - (0 if want_bits else n * d * 4), n * d * 4 + (n * d // 8 if want_bits else 0),
                              n * 256 * 4 * (2 if g_addend is not None else 1) + (4 * n if g_rowscale is not None else 0)))
-    return bits, out_next if want_bits else None, z_next
+    res = (bits, out_next if want_bits else None, z_next)
+    return res + (act,) if want_act else res
 
 
-def _fused_gemm(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowscale, g_addend, want_bits=True):
+def _fused_gemm(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowscale, g_addend, want_bits=True, want_act=False, relu_only=False):
     """_fused_gemm_launch on the (possibly node-sharded) graph: sharded, the exchange of z runs as the sliced pipeline of dist.ShardedGraph
     (pack / push-sum, all-to-all, interior pass, halo passes of the earlier slices) and the LAST halo pass is the fused kernel on top of the
     running sums — the rank's last pass over its rows also yields the next layer's Z, so no GEMM stands between this aggregation and the next
     layer's first send."""
     if not hasattr(graph, 'part'):
-        return _fused_gemm_launch(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowscale, g_addend, want_bits)
+        return _fused_gemm_launch(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowscale, g_addend, want_bits, want_act=want_act, relu_only=relu_only)
     sh = graph
     flights = sh.start_halo(z, False)
     sh.f.interior.profile = getattr(graph, 'profile', None)
     acc = sh.f.interior.spmm(z)
     return sh.finish_halo(flights, sh.f, acc, lambda g, recv, a_: _fused_gemm_launch(graph, recv, bias, x0, c_act, c_mix, p, seed, image, g_rowscale,
-                                                                                      g_addend, want_bits, g=g, acc=a_))
+                                                                                      g_addend, want_bits, g=g, acc=a_, want_act=want_act, relu_only=relu_only))
 
 
 def agg_gemm_eligible(graph, hidden, agg_bf16):
@@ -127,7 +139,7 @@ def agg_gemm_eligible(graph, hidden, agg_bf16):
     return hasattr(graph, 'spmm_gemm')
 
 
-def _fused_launch(lib, graph, g, z, acc, bias, x0, c_act, c_mix, p, seed, want_act, want_bits=True):
+def _fused_launch(lib, graph, g, z, acc, bias, x0, c_act, c_mix, p, seed, want_act, want_bits=True, relu_only=False):
     """One fused-store launch over CSR g (the whole graph, a rank's single-pass block, or the last halo slice on top of acc).
     want_bits=False (forward without a backward: eval / metrics forwards): the backward's mask words are not written."""
     n, d = g.N, z.shape[1]
@@ -147,7 +159,8 @@ def _fused_launch(lib, graph, g, z, acc, bias, x0, c_act, c_mix, p, seed, want_a
     head = (_lib.ptr(g.rowptr), _lib.ptr(col_k if col_k is not None else g.col), int(col_k is not None))
     args = head + (n, g.E, _lib.ptr(z), z.stride(0), d, _lib.ptr(graph.norm_in), _lib.ptr(bias),
             _lib.ptr(x0), x0.stride(0) if x0 is not None else 0, float(c_act), float(c_mix), float(p), ctypes.c_uint64(seed),
-            ops.seed_dev_ptr(), int(getattr(graph, 'row_offset', 0)), _lib.ptr(bits), _lib.ptr(act), d, _lib.ptr(out_next), d, g.hub_threshold,
+            ops.seed_dev_ptr(), int(getattr(graph, 'row_offset', 0)), _lib.ptr(bits), int(bool(relu_only)), _lib.ptr(act), d, _lib.ptr(out_next), d,
+            g.hub_threshold,
             plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), wsb, _lib.stream_ptr())
     with torch.cuda.device(dev):
         if acc is not None:
@@ -170,7 +183,9 @@ def _spmm_t(graph, gr):
     return graph.spmm(gr, transpose=True)
 
 
-def _layer_bwd(g, bits, row_scale, gx0, accumulate, p, seed, row0, c_act, c_mix, want_colsum, out_bf16=False, out=None):
+def _layer_bwd(g, bits, row_scale, gx0, accumulate, p, seed, row0, c_act, c_mix, want_colsum, out_bf16=False, out=None, g2=None, seed2=0, c2=0.0):
+    """cb_trunk_layer_bwd_f32: (b * dY' of the layer's store, dbias).  g2 ('Residual'): the gradient w.r.t. the NEXT layer's stored output, which
+    reaches this layer's ReLU output through that layer's mix (c2 = alpha) under that layer's dropout mask (seed2)."""
     lib = _lib.load()
     rows, d = g.shape
     if out is None:
@@ -181,7 +196,8 @@ def _layer_bwd(g, bits, row_scale, gx0, accumulate, p, seed, row0, c_act, c_mix,
     with torch.cuda.device(g.device):
         _lib.check(lib.cb_trunk_layer_bwd_f32(_lib.ptr(g), _lib.ptr(bits), _lib.ptr(row_scale), _lib.ptr(out), int(out_bf16),
                                               _lib.ptr(gx0), int(accumulate), rows, d, float(p), ctypes.c_uint64(seed), ops.seed_dev_ptr(),
-                                              int(row0), float(c_act), float(c_mix), _lib.ptr(colsum), _lib.ptr(ws), wsb, _lib.stream_ptr()),
+                                              int(row0), float(c_act), float(c_mix), _lib.ptr(g2), ctypes.c_uint64(seed2), float(c2), _lib.ptr(colsum),
+                                              _lib.ptr(ws), wsb, _lib.stream_ptr()),
                    'cb_trunk_layer_bwd_f32')
     return out, colsum
 
@@ -247,14 +263,8 @@ def tail_trunk_bwd(graph):
     return os.environ.get('CB_AGG_GEMM_TRUNKBWD', '0') == '1'
 
 
-# The input Linear's GEMM writes the mask words of (X0 > 0) from its epilogue (a wavefront holds a whole 256-column row there: four ballots),
-# and the input stage of the backward reads those 32 bytes per row instead of X0's 1 KiB (one of its six 10 GB streams).
-ROWSPARSE_MIN_NODES = 1 << 16      # below this a step is launch-bound and the extra check kernel costs more than the gather saves
-#                                    (graph.rowsparse_small_ok, set by trainer.enable_hip_graph on ITS graph, lifts the limit: under hipGraph replay the extra launches cost nothing — S-pubmed config 2: 0.787 -> 0.751 ms/step)
-ROWSPARSE_S0_LIMIT = 0.7           # the plan is used while the loss rows are at most this share of the rows (S-pl10M with 50 % / 70 % loss rows: 187.9 / 193.2 ms against 195.4 / 196.3 dense)
-ROWSPARSE_LOSS_SIDE = True         # level 0 of the plan through the loss rows' side when the plan holds the orientation for it (graph.FWD0_ROWS_PER_EDGE)
-ROWSPARSE_MAX_FRAC = 0.7           # a level's output stays compact while its support is at most this share of the rows (S-arxiv, support 61 %: 3.53 -> 3.40 ms/step against 0.6)
-MIX_MAX = 7      # mixed-in gradients one cb_trunk_input_bwd_multi_f32 launch gathers (deeper trunks accumulate layer by layer)
+# Thresholds of the row-sparse backward and the gather mode: tuning.T (rowsparse_*, fwd0_*, mix_max, gather_mem_frac), each documented there with
+# the graph it was tuned on.
 
 
 _GATHER_OK = {}
@@ -273,7 +283,7 @@ def _gather_fits(L, x0, graph=None):
             ok = env == '1'
         else:
             free, _total = torch.cuda.mem_get_info(x0.device)
-            ok = (L - 1) * x0.numel() * 4 <= 0.25 * free
+            ok = (L - 1) * x0.numel() * 4 <= T.gather_mem_frac * free
         if graph is not None and hasattr(graph, 'part') and graph.part.world > 1:
             from .dist import _all_reduce
             import torch.distributed as dist
@@ -295,10 +305,11 @@ def _chunked(graph, agg_bf16):
 class _TrunkFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph, cfg, x, w_in, b_in, w_out, b_out, *layer_params):
-        """layer_params = (W_0, bias_0, le_0 | None, W_1, ...).  cfg = (L, alpha, p, seeds, agg_bf16, track, loss_rows): track = autograd was
-        recording when the trunk was called (inside a Function's forward it never is, and needs_input_grad does not know about no_grad);
-        loss_rows = None or (bool mask [N], count): the caller's promise that the output receives gradient in those rows only (ops.py)."""
-        L, alpha, p, seeds, agg_bf16, track, _loss_rows = cfg
+        """layer_params = (W_0, bias_0, le_0 | None, W_1, ...).  cfg = (L, alpha, p, seeds, agg_bf16, track, loss_rows, residual): track = autograd
+        was recording when the trunk was called (inside a Function's forward it never is, and needs_input_grad does not know about no_grad);
+        loss_rows = None or (bool mask [N], count): the caller's promise that the output receives gradient in those rows only (ops.py);
+        residual: the 'Residual' connection (mix source of layer l > 0 = the previous layer's ReLU output) instead of 'Initial' (X0)."""
+        L, alpha, p, seeds, agg_bf16, track, _loss_rows, residual = cfg
         row0 = int(getattr(graph, 'row_offset', 0))
         a = graph.norm_out
         x = x.contiguous()
@@ -352,10 +363,14 @@ class _TrunkFn(torch.autograd.Function):
         saved_in, saved_bits = [cur], []
         ag = agg_gemm_eligible(graph, h, agg_bf16)
         z_ready = None                           # Z_l already produced by layer l-1's aggregation kernel (cb_spmm_gemm_fused_f32)
+        mix = x0                                 # mix source of the layer: X0 ('Initial', and layer 0 of 'Residual'), else the previous ReLU output
         for l in range(L):
             w, b, le = layer_params[3 * l: 3 * l + 3]
             sd_l = seeds[l + 2] if p > 0 else 0
-            z0 = None
+            # 'Residual': this layer's ReLU output is the next layer's mix source (stored by the same kernel); its mask words hold the ReLU
+            # alone, because the next layer's mix sends a second gradient through it under another dropout mask (cb_trunk_layer_bwd_f32, g2)
+            keep_act = residual and l + 1 < L
+            z0 = act = None
             if l == 0 and z_front is not None:      # left the forward-front kernel
                 z0 = z_front
             elif l == 0 and cur is None:      # layer 0 with no dropped copy of X0: its GEMM draws the mask while it stages X0
@@ -369,9 +384,12 @@ class _TrunkFn(torch.autograd.Function):
                 z_ready = None
                 if l + 1 < L:     # this layer's store + the next layer's transform in one kernel
                     w1, _, le1 = layer_params[3 * (l + 1): 3 * (l + 1) + 3]
-                    bits, cur, z_ready = _fused_gemm(graph, z, b, x0, 1 - alpha, alpha, p, sd_l, weight_image(w1), a, le1, want_bits=bwd)
+                    res = _fused_gemm(graph, z, b, mix, 1 - alpha, alpha, p, sd_l, weight_image(w1), a, le1, want_bits=bwd, want_act=keep_act,
+                                      relu_only=residual)
+                    bits, cur, z_ready = res[:3]
+                    act = res[3] if keep_act else None
                 else:
-                    bits, cur, _ = _fused_spmm(graph, z, b, x0, 1 - alpha, alpha, p, sd_l, want_bits=bwd)
+                    bits, cur, act = _fused_spmm(graph, z, b, mix, 1 - alpha, alpha, p, sd_l, want_bits=bwd, relu_only=residual)
             elif z0 is None and _chunked(graph, agg_bf16):
                 # node-sharded pipeline: row chunk k of Z leaves the GEMM, is packed and put on the links while chunk k+1 multiplies
                 z = torch.empty((cur.shape[0], w.shape[1]), dtype=torch.float32, device=cur.device)
@@ -379,15 +397,19 @@ class _TrunkFn(torch.autograd.Function):
                 def produce(k, r0, r1, cur=cur, w=w, le=le, z=z):
                     if r1 > r0:
                         gemm.mm_nn(cur[r0:r1], w, rowscale=a[r0:r1], addend=le[r0:r1] if le is not None else None, out=z[r0:r1])
-                bits, cur, _ = _fused_spmm(graph, z, b, x0, 1 - alpha, alpha, p, sd_l, produce=produce, want_bits=bwd)
+                bits, cur, act = _fused_spmm(graph, z, b, mix, 1 - alpha, alpha, p, sd_l, want_act=keep_act, produce=produce, want_bits=bwd,
+                                             relu_only=residual)
             else:
                 z = z0 if z0 is not None else gemm.mm_nn(cur, w, rowscale=a, addend=le, out_bf16=agg_bf16)
-                bits, cur, _ = _fused_spmm(graph, z, b, x0, 1 - alpha, alpha, p, sd_l, want_bits=bwd)
+                bits, cur, act = _fused_spmm(graph, z, b, mix, 1 - alpha, alpha, p, sd_l, want_act=keep_act, want_bits=bwd, relu_only=residual)
             del z, z0
             z_front = None
+            if residual:
+                mix = act
             if bwd:
                 saved_bits.append(bits)
                 saved_in.append(cur)
+        del mix
         out = gemm.mm_nn(cur, w_out.t().contiguous(), bias=b_out)
         ctx.graph, ctx.cfg, ctx.row0 = graph, cfg, row0
         ctx.n_layer_params = len(layer_params)
@@ -400,16 +422,29 @@ class _TrunkFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        graph, (L, alpha, p, seeds, agg_bf16, _track, loss_rows), row0 = ctx.graph, ctx.cfg, ctx.row0
-        if loss_rows is not None and (not ops.loss_rows_enabled() or loss_rows[0].shape[0] != gout.shape[0]):
-            loss_rows = None
+        return _Backward(ctx, gout).run()
+
+
+class _Backward:
+    """The hand-written backward of the trunk, one object per call.  run() = head stage, then the layers from the last to the first, then the
+    input stage.  What a layer does depends on where its operands live:
+      * _layer_source_side / _layer_compact: a level of the row-sparse PLAN (one GPU): compact [|S_j|, .] matrices, the level's own orientation;
+      * _layer_fused: the reverse aggregation + dX contraction in one kernel (cb_spmm_gemm_f32) on all rows — one GPU, or as the last halo pass
+        of a node-sharded exchange (whose level orientations restrict the exchange to the support's rows: dist.ShardedGraph.support_orients);
+      * _layer_plain: aggregation, then the dX GEMM (+ row-chunked producers of the node-sharded pull pipeline; bf16-stored rows).
+    All share the same stage helpers (_store_bwd*, _dw, the bookkeeping of the gradients that reach X0)."""
+
+    def __init__(self, ctx, gout):
+        self.ctx = ctx
+        graph, (L, alpha, p, seeds, agg_bf16, _track, loss_rows, residual), row0 = ctx.graph, ctx.cfg, ctx.row0
+        self.graph, self.L, self.alpha, self.p, self.seeds, self.agg_bf16, self.row0, self.residual = graph, L, alpha, p, seeds, agg_bf16, row0, residual
         sv = list(ctx.saved_tensors)
-        xd, x0, w_in, w_out = sv[:4]
-        saved_in = sv[4: 4 + L + 1]
-        saved_bits = sv[4 + L + 1: 4 + 2 * L + 1]
+        self.xd, self.x0, self.w_in, self.w_out = sv[:4]
+        self.saved_in = sv[4: 4 + L + 1]
+        self.saved_bits = sv[4 + L + 1: 4 + 2 * L + 1]
         rest = sv[4 + 2 * L + 1:]
-        x0_bits = rest.pop() if ctx.has_x0_bits else None
-        lp, k = [], 0
+        self.x0_bits = rest.pop() if ctx.has_x0_bits else None
+        self.lp, k = [], 0
         for l in range(L):
             w, b = rest[k], rest[k + 1]
             k += 2
@@ -417,209 +452,277 @@ class _TrunkFn(torch.autograd.Function):
             if ctx.le_present[l]:
                 le = rest[k]
                 k += 1
-            lp.append((w, b, le))
-        a, bnorm = graph.norm_out, graph.norm_in
-        need = ctx.needs_input_grad       # (graph, cfg, x, w_in, b_in, w_out, b_out, *layer_params)
-        gout = gemm._rowmajor(gout)
-        h = x0.shape[1]
-        xl = saved_in[L]
-        # the gradient reaching X0 through the L mixes: gathered in one pass by the input stage (the per-layer gradients stay
-        # alive until then) when L <= MIX_MAX, else accumulated in place layer by layer
-        gather = L <= MIX_MAX and _gather_fits(L, x0, graph)
-        gx0 = None if gather else torch.empty_like(x0)
-        g_mix, seeds_mix = [], []
-        grads_layers = [None] * (3 * L)
-        sharded = hasattr(graph, 'part')
-        chunked = gather and _chunked(graph, agg_bf16) and graph.b.plan.n_slices > 1 and not agg_gemm_eligible(graph, h, agg_bf16)
-        ag_bwd = agg_gemm_eligible(graph, h, agg_bf16)
-        tail_tb = ag_bwd and gather and tail_trunk_bwd(graph)      # (the accumulate-in-place form needs the pass: it also adds into gx0)
+            self.lp.append((w, b, le))
+        self.a, self.bnorm = graph.norm_out, graph.norm_in
+        self.need = ctx.needs_input_grad       # (graph, cfg, x, w_in, b_in, w_out, b_out, *layer_params)
+        self.gout = gemm._rowmajor(gout)
+        self.h = self.x0.shape[1]
+        self.sharded = hasattr(graph, 'part')
+        if loss_rows is not None and (not ops.loss_rows_enabled() or loss_rows[0].shape[0] != self.gout.shape[0] or residual):
+            # ('Residual': the gradient that enters a layer's reverse aggregation lives on the UNION of two supports — the plan is not built for it)
+            loss_rows = None
+        self.loss_rows = loss_rows
+        # the gradient reaching X0 through the mixes: 'Initial' — every layer's, gathered in one pass by the input stage (the per-layer gradients
+        # stay alive until then) when L <= mix_max and they fit, else accumulated in place layer by layer; 'Residual' — layer 0's alone
+        self.gather = residual or (L <= T.mix_max and _gather_fits(L, self.x0, graph))
+        self.gx0 = None if self.gather else torch.empty_like(self.x0)
+        self.g_mix, self.seeds_mix, self.mix_pos = [], [], []
+        self.grads_layers = [None] * (3 * L)
+        self.ag = agg_gemm_eligible(graph, self.h, agg_bf16)
+        self.chunked = (self.gather and _chunked(graph, agg_bf16) and graph.b.plan.n_slices > 1 and not self.ag)
+        self.tail_tb = self.ag and self.gather and not residual and tail_trunk_bwd(graph)      # (the accumulate-in-place form needs the pass: it also adds into gx0)
 
-        def dw_layer(l, x_in, gz):
-            """X_l^T (a * dZ_l).  Layer 0 without a dropped copy of X0 (x_in is None): the mask of the dropout in front of layer 0 is
-            regenerated from X0 while the GEMM stages it (cb_gemm_tn_adrop_f32)."""
-            if x_in is not None:
-                return gemm.mm_tn(x_in, gz, rowscale=a)
-            sd0 = seeds[1] if p > 0 else 0
-            dw = gemm.mm_tn_adrop(x0, gz, p, sd0, row0, rowscale=a)
-            return dw if dw is not None else gemm.mm_tn(ops._dropout_raw(x0, p, sd0, row0 * x0.shape[1]), gz, rowscale=a)
+    # -- small helpers -------------------------------------------------------------------------------------------------------------------
+    def seed(self, i):
+        return self.seeds[i] if self.p > 0 else 0
 
-        # Node-sharded: the row-sparse backward as LEVEL ORIENTATIONS of the reverse exchange (dist.ShardedGraph.support_orients) — level j
-        # ships and gathers only the rows of the support S_j; matrices keep all local rows, every other branch of this function is unchanged.
-        sh_levels = []
-        if sharded and hasattr(graph, 'support_orients'):
-            hint = loss_rows
-            if hint is not None:
-                ops.check_rows_zero(gout, hint[0])
-                sh_levels = graph.support_orients(hint[0], L)
+    def need_w(self, l):
+        return self.need[7 + 3 * l]
 
-        def orient_of(layer):
-            j = L - 1 - layer
-            return sh_levels[j] if j < len(sh_levels) else None
+    def need_b(self, l):
+        return self.need[7 + 3 * l + 1]
 
-        def dx_gemm(src, wt, rowscale, below, g_ready=None):
-            """dL/dx of the stage above layer `below` and that layer's trunk backward: (g, gr, dbias, handle); handle = the already started
-            exchange of gr (row-chunked producers of the node-sharded pull pipeline), else None."""
-            sd = seeds[below + 2] if p > 0 else 0
-            want_b = need[7 + 3 * below + 1]
-            if chunked:
-                g_ = torch.empty((src.shape[0], wt.shape[1]), dtype=torch.float32, device=src.device)
-                gr_ = torch.empty_like(g_)
-                colsums = []
+    def need_le(self, l):
+        return self.lp[l][2] is not None and self.need[7 + 3 * l + 2]
 
-                def produce(k, r0, r1):
-                    if r1 <= r0:
-                        return
-                    gemm.mm_nn(src[r0:r1], wt, rowscale=rowscale[r0:r1] if rowscale is not None else None, out=g_[r0:r1])
-                    _, cs = _layer_bwd(g_[r0:r1], saved_bits[below][r0:r1], bnorm[r0:r1], None, False, p, sd, row0 + r0, 1 - alpha, alpha,
-                                       want_b, out=gr_[r0:r1])
-                    if want_b:
-                        colsums.append(cs)
-                h_ = graph.aggregate_start(gr_, True, produce=produce, orient=orient_of(below))
-                db_ = None
-                if want_b:      # (a rank that owns no rows produces no chunk: its share of the bias gradient is zero, ADVICE r03)
-                    db_ = (torch.zeros(wt.shape[1], dtype=torch.float32, device=src.device) if not colsums
-                           else colsums[0] if len(colsums) == 1 else torch.stack(colsums).sum(0))
-                return g_, gr_, db_, h_
-            g_ = g_ready if g_ready is not None else gemm.mm_nn(src, wt, rowscale=rowscale)     # g_ready: left the reverse aggregation's kernel
-            gr_, db_ = _layer_bwd(g_, saved_bits[below], bnorm, gx0, below != L - 1, p, sd, row0, 1 - alpha, alpha, want_b, out_bf16=agg_bf16)
-            return g_, gr_, db_, None
+    def _dw(self, l, x_in, gz):
+        """X_l^T (a * dZ_l).  Layer 0 without a dropped copy of X0 (x_in is None): the mask of the dropout in front of layer 0 is
+        regenerated from X0 while the GEMM stages it (cb_gemm_tn_adrop_f32)."""
+        if x_in is not None:
+            return gemm.mm_tn(x_in, gz, rowscale=self.a)
+        sd0 = self.seed(1)
+        dw = gemm.mm_tn_adrop(self.x0, gz, self.p, sd0, self.row0, rowscale=self.a)
+        return dw if dw is not None else gemm.mm_tn(ops._dropout_raw(self.x0, self.p, sd0, self.row0 * self.x0.shape[1]), gz, rowscale=self.a)
 
-        # Row-sparse backward: when the upstream gradient is the masked loss's own buffer, every row of gout outside the loss rows is zero,
-        # and what the backward makes of it stays zero outside the rows the loss rows can reach: after the j-th reverse aggregation only the
-        # rows with a neighbour in the previous support carry gradient (CSRGraph.grad_support_plan: S_0 = loss rows, S_1, ... — 10 % / 45 % /
-        # 94 % of the rows on the bench's graph with its 10 % train mask).  The head, the store backward, the aggregation + dX kernels and
-        # the weight gradients of those levels run on compact [|S_j|, .] matrices (the aggregation through an orientation whose rows and
-        # columns are renumbered to positions in S_{j+1} and S_j), and the input stage takes the per-layer gradients as compact operands.
-        # The claim "rows outside the loss rows are zero" is checked on the device (ops.check_rows_zero: a violation ends in the device error
-        # word, never in silent wrong gradients).  One GPU, hidden 256, gathered per-layer gradients, loss rows <= 70 % of the nodes.
-        rows_hint = loss_rows if (not sharded and hasattr(graph, 'grad_support_plan') and graph.rowptr_t is not None) else None
-        plan = None
-        # (with bf16-stored rows the compact levels still run on fp32 matrices through the aggregation + GEMM kernel; the dense levels below
-        # them go on as the bf16 path does)
-        if (rows_hint is not None and 1 <= rows_hint[1] <= ROWSPARSE_S0_LIMIT * gout.shape[0] and (gout.shape[0] >= ROWSPARSE_MIN_NODES or getattr(graph, 'rowsparse_small_ok', False)) and gather
-                and agg_gemm_eligible(graph, h, False) and not tail_tb and graph.support_plan_pays()):
-            ops.check_rows_zero(gout, rows_hint[0])
-            plan = graph.grad_support_plan(rows_hint[0], L, max_frac=ROWSPARSE_MAX_FRAC)
-        space = None                                                             # row space of g / gr (None: all rows)
-        mix_pos = []
-        if plan is not None:
+    def _second(self, below, g_above):
+        """'Residual': keyword arguments of the second gradient that reaches layer `below`'s ReLU output — through the mix of layer below + 1,
+        under that layer's dropout mask."""
+        if not self.residual or g_above is None:
+            return {}
+        return dict(g2=g_above, seed2=self.seed(below + 3), c2=self.alpha)
+
+    def _dx_and_store_bwd(self, src, wt, rowscale, below, g_ready=None, g_above=None, orient=None):
+        """dL/dx of the stage above layer `below` and that layer's store backward: (g, gr, dbias, handle); handle = the already started
+        exchange of gr (row-chunked producers of the node-sharded pull pipeline), else None.  g_ready: dL/dx left the reverse aggregation's kernel."""
+        p, alpha, row0, bnorm = self.p, self.alpha, self.row0, self.bnorm
+        sd = self.seed(below + 2)
+        want_b = self.need_b(below)
+        bits = self.saved_bits[below]
+        if self.chunked:
+            g_ = torch.empty((src.shape[0], wt.shape[1]), dtype=torch.float32, device=src.device)
+            gr_ = torch.empty_like(g_)
+            colsums = []
+            sec = self._second(below, g_above)
+
+            def produce(k, r0, r1):
+                if r1 <= r0:
+                    return
+                gemm.mm_nn(src[r0:r1], wt, rowscale=rowscale[r0:r1] if rowscale is not None else None, out=g_[r0:r1])
+                sec_k = dict(sec, g2=sec['g2'][r0:r1]) if sec else {}
+                _, cs = _layer_bwd(g_[r0:r1], bits[r0:r1], bnorm[r0:r1], None, False, p, sd, row0 + r0, 1 - alpha, alpha, want_b, out=gr_[r0:r1], **sec_k)
+                if want_b:
+                    colsums.append(cs)
+            h_ = self.graph.aggregate_start(gr_, True, produce=produce, orient=orient)
+            db_ = None
+            if want_b:      # (a rank that owns no rows produces no chunk: its share of the bias gradient is zero, ADVICE r03)
+                db_ = (torch.zeros(wt.shape[1], dtype=torch.float32, device=src.device) if not colsums
+                       else colsums[0] if len(colsums) == 1 else torch.stack(colsums).sum(0))
+            return g_, gr_, db_, h_
+        g_ = g_ready if g_ready is not None else gemm.mm_nn(src, wt, rowscale=rowscale)
+        gr_, db_ = _layer_bwd(g_, bits, bnorm, self.gx0, below != self.L - 1, p, sd, row0, 1 - alpha, alpha, want_b, out_bf16=self.agg_bf16,
+                              **self._second(below, g_above))
+        return g_, gr_, db_, None
+
+    # -- head ----------------------------------------------------------------------------------------------------------------------------
+    def _head(self, plan):
+        """Output Linear (GCN.py:133-138) and the store backward of the last layer: sets d_w_out, d_b_out and returns (g, gr, dbias, handle, space)."""
+        L, need, gout, xl, w_out = self.L, self.need, self.gout, self.saved_in[self.L], self.w_out
+        if plan is not None:      # loss rows only
             space = plan.space0
             gout_c, xl_c = ops.gather_rows_by_index(gout, space.idx), ops.gather_rows_by_index(xl, space.idx)
-            d_w_out = gemm.mm_tn(gout_c, xl_c) if need[5] else None              # output Linear (GCN.py:138)
-            d_b_out = ops.act_bwd(gout_c, None, None, want_out=False, want_colsum=True)[1] if need[6] else None
+            self.d_w_out = gemm.mm_tn(gout_c, xl_c) if need[5] else None
+            self.d_b_out = ops.act_bwd(gout_c, None, None, want_out=False, want_colsum=True)[1] if need[6] else None
             g = gemm.mm_nn(gout_c, w_out)                                        # dL/d(dropped X_L), loss rows only
-            gr, dbias = _layer_bwd_rows(g, space.idx, saved_bits[L - 1], bnorm, p, seeds[L + 1] if p > 0 else 0, row0, 1 - alpha, need[7 + 3 * (L - 1) + 1])
-            handle = None
-            del gout_c, xl_c
-        else:
-            d_w_out = gemm.mm_tn(gout, xl) if need[5] else None                  # output Linear (GCN.py:138)
-            d_b_out = ops.act_bwd(gout, None, None, want_out=False, want_colsum=True)[1] if need[6] else None
-            # dL/d(dropped X_L) and the backward of layer L-1's store
-            g, gr, dbias, handle = dx_gemm(gout, w_out, None, L - 1)
+            gr, dbias = _layer_bwd_rows(g, space.idx, self.saved_bits[L - 1], self.bnorm, self.p, self.seed(L + 1), self.row0, 1 - self.alpha, self.need_b(L - 1))
+            return g, gr, dbias, None, space
+        self.d_w_out = gemm.mm_tn(gout, xl) if need[5] else None
+        self.d_b_out = ops.act_bwd(gout, None, None, want_out=False, want_colsum=True)[1] if need[6] else None
+        g, gr, dbias, handle = self._dx_and_store_bwd(gout, w_out, None, L - 1, orient=self._orient_of(L - 1))
+        return g, gr, dbias, handle, None
+
+    def _orient_of(self, layer):
+        j = self.L - 1 - layer
+        return self.sh_levels[j] if j < len(self.sh_levels) else None
+
+    # -- the layer forms -----------------------------------------------------------------------------------------------------------------
+    def _layer_source_side(self, l, gr, level, fwd_j):
+        """A plan level through its SOURCE rows' side (CSRGraph._support_fwd; level 0: the loss rows): a * (A^T dY) W^T = a * A^T (dY W^T) and
+        X^T (a * A^T dY) = ((A (a * X))[S_j])^T dY[S_j] — the GEMM and the weight gradient contract over |S_j| rows instead of |S_{j+1}|,
+        dL/dZ_l itself is never formed (so not with a table gradient, which IS dL/dZ_l).  Same sums, associated differently."""
+        w = self.lp[l][0]
+        dst = level[1]
+        level[0].profile = fwd_j.profile = getattr(self.graph, 'profile', None)
+        g_new = level[0].spmm(gemm.mm_nn(gr, w.t().contiguous()), row_scale=dst.a if dst is not None else self.a)
+        if self.need_w(l):
+            self.grads_layers[3 * l] = gemm.mm_tn(fwd_j.spmm(self.saved_in[l], col_scale=self.a), gr)
+        return None, g_new
+
+    def _layer_compact(self, l, gr, level):
+        """A plan level on compact matrices: dL/dZ_l = A (b * dY') over the level's own orientation (rows / columns renumbered to positions in
+        S_{j+1} / S_j) and a * (dL/dZ_l @ W_l^T) from the same kernel; the weight gradient over the rows of S_{j+1}."""
+        from .graph import weight_image
+        w = self.lp[l][0]
+        dst = level[1]
+        level[0].profile = getattr(self.graph, 'profile', None)
+        gz, g_new = level[0].spmm_gemm(gr, weight_image(w, transpose=True), transpose=False, g_rowscale=dst.a if dst is not None else self.a)
+        if self.need_w(l):
+            if dst is not None:      # dL/dZ_l lives on S_{j+1}: X_l^T (a * dZ_l) over those rows (all others contribute zeros)
+                self.grads_layers[3 * l] = gemm.mm_tn(ops.gather_rows_by_index(self.saved_in[l], dst.idx), gz, rowscale=dst.a)
+            else:
+                self.grads_layers[3 * l] = self._dw(l, self.saved_in[l], gz)
+        return gz, g_new
+
+    def _layer_fused(self, l, gr, handle):
+        """dL/dZ_l = A (b * dY') and a * (dL/dZ_l @ W_l^T) from one kernel (cb_spmm_gemm_f32) on all rows; for l > 0 and tail_tb the trunk backward
+        of layer l-1's store leaves the same epilogue (cb_spmm_gemm_trunkbwd_f32).  Node-sharded: the kernel is the LAST halo pass of the reverse
+        aggregation, on top of the running sums of the earlier passes.  Returns (gz, g_new, (gr_next, dbias_next) | None)."""
+        from .graph import weight_image
+        graph, a = self.graph, self.a
+        w = self.lp[l][0]
+        img = weight_image(w, transpose=True)
+        use_tb = l > 0 and self.tail_tb
+        sd_b = self.seed(l + 1)
+
+        def tail(csr, src, acc, tr):
+            csr.profile = getattr(graph, 'profile', None)
+            if use_tb:
+                return csr.spmm_gemm_trunkbwd(src, img, a, self.saved_bits[l - 1], 1 - self.alpha, self.p, sd_b, self.row0, self.bnorm, self.need_b(l - 1),
+                                              transpose=tr, acc_init=acc)
+            return csr.spmm_gemm(src, img, transpose=tr, g_rowscale=a, acc_init=acc)
+        res = (graph.aggregate_finish(handle, True, last_pass=lambda csr, recv, acc: tail(csr, recv, acc, False)) if self.sharded
+               else tail(graph, gr, None, True))
+        if use_tb:
+            gz, g_new, gr_n, db_n = res
+            return gz, g_new, (gr_n, db_n)
+        gz, g_new = res
+        return gz, g_new, None
+
+    def _layer_plain(self, gr, handle):
+        """dL/dZ_l = A (b * dY') by the plain aggregation (the dX GEMM is a kernel of its own)."""
+        return self.graph.aggregate_finish(handle, True) if self.sharded else _spmm_t(self.graph, gr)
+
+    # -- the backward --------------------------------------------------------------------------------------------------------------------
+    def run(self):
+        ctx, graph, L, alpha, p, need = self.ctx, self.graph, self.L, self.alpha, self.p, self.need
+        a, sharded, gather = self.a, self.sharded, self.gather
+        gout = self.gout
+        # Node-sharded: the row-sparse backward as LEVEL ORIENTATIONS of the reverse exchange (dist.ShardedGraph.support_orients) — level j
+        # ships and gathers only the rows of the support S_j; matrices keep all local rows, every other branch is unchanged.
+        self.sh_levels = []
+        if sharded and hasattr(graph, 'support_orients') and self.loss_rows is not None:
+            ops.check_rows_zero(gout, self.loss_rows[0])
+            self.sh_levels = graph.support_orients(self.loss_rows[0], L)
+        # Row-sparse backward (one GPU): when the caller promised that only the loss rows of gout carry gradient, what the backward makes of it
+        # stays zero outside the rows those can reach: after the j-th reverse aggregation only the rows with a neighbour in the previous support
+        # carry gradient (CSRGraph.grad_support_plan: S_0 = loss rows, S_1, ... — 10 % / 45 % / 94 % of the rows on the bench's graph with its
+        # 10 % train mask).  The head, the store backward, the aggregation + dX kernels and the weight gradients of those levels run on compact
+        # [|S_j|, .] matrices, and the input stage takes the per-layer gradients as compact operands.  The promise is checked on the device
+        # (ops.check_rows_zero: a violation ends in the device error word and stops the optimiser launch, never in silent wrong gradients).
+        # Hidden 256, gathered per-layer gradients, loss rows <= rowsparse_s0_limit of the nodes.
+        plan = None
+        hint = self.loss_rows if (not sharded and hasattr(graph, 'grad_support_plan') and graph.rowptr_t is not None) else None
+        # (with bf16-stored rows the compact levels still run on fp32 matrices through the aggregation + GEMM kernel; the dense levels below
+        # them go on as the bf16 path does)
+        if (hint is not None and 1 <= hint[1] <= T.rowsparse_s0_limit * gout.shape[0]
+                and (gout.shape[0] >= T.rowsparse_min_nodes or getattr(graph, 'rowsparse_small_ok', False)) and gather
+                and agg_gemm_eligible(graph, self.h, False) and not self.tail_tb and graph.support_plan_pays()):
+            ops.check_rows_zero(gout, hint[0])
+            plan = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac)
+
+        g, gr, dbias, handle, space = self._head(plan)
+        g_above = None         # 'Residual': dL/d(stored output) of the layer above the one whose store backward comes next
         deferred = None        # (layer, X_l, dZ_l): weight gradient of the layer above, computed under this layer's halo exchange
         for l in range(L - 1, -1, -1):
-            w, b, le = lp[l]
-            if gather:
-                g_mix.append(g)
-                mix_pos.append(space.pos if space is not None else None)
-                seeds_mix.append(seeds[l + 2] if p > 0 else 0)
-            level = plan.levels[L - 1 - l] if (plan is not None and L - 1 - l < len(plan.levels)) else None
+            w, b, le = self.lp[l]
+            if gather and (not self.residual or l == 0):      # this layer's mix reads X0: its gradient is gathered by the input stage
+                self.g_mix.append(g)
+                self.mix_pos.append(space.pos if space is not None else None)
+                self.seeds_mix.append(self.seed(l + 2))
+            j = L - 1 - l
+            level = plan.levels[j] if (plan is not None and j < len(plan.levels)) else None
             dst = level[1] if level is not None else None
             if sharded and handle is None:
-                handle = graph.aggregate_start(gr, True, orient=orient_of(l))   # node-sharded: the exchange is in flight from here
+                handle = graph.aggregate_start(gr, True, orient=self._orient_of(l))   # node-sharded: the exchange is in flight from here
             if deferred is not None:
-                grads_layers[3 * deferred[0]] = dw_layer(*deferred)
+                self.grads_layers[3 * deferred[0]] = self._dw(*deferred)
                 deferred = None
-            g_fused = tb_fused = None
-            # A level through its SOURCE rows' side (CSRGraph._support_fwd; level 0: the loss rows): a * (A^T dY) W^T = a * A^T (dY W^T) and
-            # X^T (a * A^T dY) = ((A (a * X))[S_j])^T dY[S_j] — the GEMM and the weight gradient contract over |S_j| rows instead of |S_{j+1}|,
-            # dL/dZ_l itself is never formed (so not with a table gradient, which IS dL/dZ_l).  Same sums, associated differently.
-            fwd_j = plan.fwd[L - 1 - l] if (level is not None and L - 1 - l < len(plan.fwd)) else None
-            loss_side = (ROWSPARSE_LOSS_SIDE and fwd_j is not None and not (le is not None and need[7 + 3 * l + 2])
-                         and not (need[7 + 3 * l] and saved_in[l] is None))      # (layer 0 without a stored dropped copy of X0)
-            if loss_side:
-                level[0].profile = fwd_j.profile = getattr(graph, 'profile', None)
-                g_fused = level[0].spmm(gemm.mm_nn(gr, w.t().contiguous()), row_scale=dst.a if dst is not None else a)
-                if need[7 + 3 * l]:
-                    grads_layers[3 * l] = gemm.mm_tn(fwd_j.spmm(saved_in[l], col_scale=a), gr)
-                gz = None
-            elif ag_bwd or level is not None:
-                # dL/dZ_l = A (b * dY') and a * (dL/dZ_l @ W_l^T) from one kernel (cb_spmm_gemm_f32); for l > 0 and tail_tb the trunk backward of
-                # layer l-1's store leaves the same epilogue (cb_spmm_gemm_trunkbwd_f32: no pass of its own over dL/dx_l).  Node-sharded: the
-                # kernel is the LAST halo pass of the reverse aggregation, on top of the running sums of the earlier passes.
-                from .graph import weight_image
-                img = weight_image(w, transpose=True)
-                use_tb = l > 0 and tail_tb
-                sd_b = seeds[l + 1] if p > 0 else 0
-
-                def tail(csr, src, acc, tr, use_tb=use_tb, img=img, sd_b=sd_b, l=l):
-                    csr.profile = getattr(graph, 'profile', None)
-                    if use_tb:
-                        return csr.spmm_gemm_trunkbwd(src, img, a, saved_bits[l - 1], 1 - alpha, p, sd_b, row0, bnorm, need[7 + 3 * (l - 1) + 1],
-                                                      transpose=tr, acc_init=acc)
-                    return csr.spmm_gemm(src, img, transpose=tr, g_rowscale=a, acc_init=acc)
-                if level is not None:      # compact source (and destination): the level's own orientation, row scale restricted to its rows
-                    level[0].profile = getattr(graph, 'profile', None)
-                    res = level[0].spmm_gemm(gr, img, transpose=False, g_rowscale=dst.a if dst is not None else a)
-                else:
-                    res = (graph.aggregate_finish(handle, True, last_pass=lambda csr, recv, acc: tail(csr, recv, acc, False)) if sharded
-                           else tail(graph, gr, None, True))
-                if use_tb:
-                    gz, g_fused, gr_n, db_n = res
-                    tb_fused = (gr_n, db_n)
-                else:
-                    gz, g_fused = res
+            tb_next = None
+            fwd_j = plan.fwd[j] if (level is not None and j < len(plan.fwd)) else None
+            source_side = (T.rowsparse_loss_side and fwd_j is not None and not self.need_le(l)
+                           and not (self.need_w(l) and self.saved_in[l] is None))      # (layer 0 without a stored dropped copy of X0)
+            if source_side:
+                gz, g_new = self._layer_source_side(l, gr, level, fwd_j)
+            elif level is not None:
+                gz, g_new = self._layer_compact(l, gr, level)
+            elif self.ag:
+                gz, g_new, tb_next = self._layer_fused(l, gr, handle)
+                if self.need_w(l):
+                    if sharded:
+                        deferred = (l, self.saved_in[l], gz)
+                    else:
+                        self.grads_layers[3 * l] = self._dw(l, self.saved_in[l], gz)
             else:
-                gz = graph.aggregate_finish(handle, True) if sharded else _spmm_t(graph, gr)  # dL/dZ_l = A (b * dY')
+                gz, g_new = self._layer_plain(gr, handle), None
+                if self.need_w(l):
+                    if sharded:
+                        deferred = (l, self.saved_in[l], gz)
+                    else:
+                        self.grads_layers[3 * l] = self._dw(l, self.saved_in[l], gz)
+            g_above = g if self.residual else None
             del g, gr
             handle = None
-            if need[7 + 3 * l] and not loss_side:
-                if sharded:
-                    deferred = (l, saved_in[l], gz)
-                elif dst is not None:      # dL/dZ_l lives on S_{j+1}: X_l^T (a * dZ_l) over those rows (all others contribute zeros)
-                    grads_layers[3 * l] = gemm.mm_tn(ops.gather_rows_by_index(saved_in[l], dst.idx), gz, rowscale=dst.a)
-                else:
-                    grads_layers[3 * l] = dw_layer(l, saved_in[l], gz)
-            grads_layers[3 * l + 1] = dbias
+            self.grads_layers[3 * l + 1] = dbias
             space = dst
             if l > 0 and dst is not None:      # the store backward of layer l-1 on the rows of S_{j+1}
-                g = g_fused
-                gr, dbias = _layer_bwd_rows(g, dst.idx, saved_bits[l - 1], bnorm, p, seeds[l + 1] if p > 0 else 0, row0, 1 - alpha, need[7 + 3 * (l - 1) + 1])
-            elif l > 0 and tb_fused is not None:
-                g, (gr, dbias) = g_fused, tb_fused
-            elif l > 0:
-                g, gr, dbias, handle = dx_gemm(gz, w.t().contiguous(), a, l - 1, g_fused)   # dL/d(dropped X_l) and the backward of layer l-1's store
-            else:
-                g = g_fused if g_fused is not None else gemm.mm_nn(gz, w.t().contiguous(), rowscale=a)   # dL/d(dropped X_0): consumed by the input stage
-            if le is not None and need[7 + 3 * l + 2]:
+                g = g_new
+                gr, dbias = _layer_bwd_rows(g, dst.idx, self.saved_bits[l - 1], self.bnorm, p, self.seed(l + 1), self.row0, 1 - alpha, self.need_b(l - 1))
+            elif l > 0 and tb_next is not None:
+                g, (gr, dbias) = g_new, tb_next
+            elif l > 0:      # dL/d(dropped X_l) and the backward of layer l-1's store
+                g, gr, dbias, handle = self._dx_and_store_bwd(gz, w.t().contiguous(), a, l - 1, g_new, g_above, orient=self._orient_of(l - 1))
+            else:            # dL/d(dropped X_0): consumed by the input stage
+                g = g_new if g_new is not None else gemm.mm_nn(gz, w.t().contiguous(), rowscale=a)
+            g_above = None
+            if self.need_le(l):
                 if dst is not None:      # the table's gradient is dL/dZ_l on ALL rows: the support's rows, zeros elsewhere
                     gz = ops.expand_rows(gz, dst.pos)
-                grads_layers[3 * l + 2] = gz
-            else:
-                del gz
+                self.grads_layers[3 * l + 2] = gz
+            del gz
         if deferred is not None:
-            grads_layers[3 * deferred[0]] = dw_layer(*deferred)
-            deferred = None
-        # input stage: X0 feeds layer 0 (through its dropout) and every mix
+            self.grads_layers[3 * deferred[0]] = self._dw(*deferred)
+        # input stage: X0 feeds layer 0 (through its dropout) and the mixes
         if gather:
-            gpre, d_b_in = _input_bwd_multi(g, seeds[1] if p > 0 else 0, g_mix, seeds_mix, alpha, x0, p, row0, act_bits=x0_bits, mix_pos=mix_pos)
+            gpre, d_b_in = _input_bwd_multi(g, self.seed(1), self.g_mix, self.seeds_mix, alpha, self.x0, p, self.row0, act_bits=self.x0_bits,
+                                            mix_pos=self.mix_pos)
         else:
-            gpre, d_b_in = _input_bwd(g, gx0, x0, p, seeds[1] if p > 0 else 0, row0)
-        del g, gx0, g_mix
+            gpre, d_b_in = _input_bwd(g, self.gx0, self.x0, p, self.seed(1), self.row0)
+        del g
+        self.gx0 = self.g_mix = None
         d_w_in = None
+        xd, row0 = self.xd, self.row0
         if need[3]:
             if ctx.indrop and p > 0:      # xd holds the undropped features: the mask is regenerated while the GEMM stages them
-                d_w_in = gemm.mm_tn_gdrop(gpre, xd, p, seeds[0], row0)
+                d_w_in = gemm.mm_tn_gdrop(gpre, xd, p, self.seeds[0], row0)
                 if d_w_in is None:
-                    d_w_in = gemm.mm_tn(gpre, ops._dropout_raw(xd, p, seeds[0], row0 * xd.shape[1]))
+                    d_w_in = gemm.mm_tn(gpre, ops._dropout_raw(xd, p, self.seeds[0], row0 * xd.shape[1]))
             else:
                 d_w_in = gemm.mm_tn(gpre, xd)
         d_x = None
         if need[2]:
-            d_x = gemm.mm_nn(gpre, w_in)
+            d_x = gemm.mm_nn(gpre, self.w_in)
             if p > 0:
-                d_x = ops._dropout_raw(d_x, p, seeds[0], row0 * d_x.shape[1])
-        return (None, None, d_x, d_w_in, d_b_in if need[4] else None, d_w_out, d_b_out, *grads_layers)
+                d_x = ops._dropout_raw(d_x, p, self.seeds[0], row0 * d_x.shape[1])
+        return (None, None, d_x, d_w_in, d_b_in if need[4] else None, self.d_w_out, self.d_b_out, *self.grads_layers)
 
 
 def forward(tc, x, graph, loss_rows=None):
@@ -649,6 +752,6 @@ def forward(tc, x, graph, loss_rows=None):
         if mask.dtype != torch.bool or mask.dim() != 1 or mask.shape[0] != x.shape[0]:
             raise ValueError(f'loss_rows: a bool mask over the {x.shape[0]} rows expected, got {tuple(mask.shape)} {mask.dtype}')
         loss_rows = (mask, int(count))
-    out = _TrunkFn.apply(graph, (L, float(tc.alpha), p, seeds, agg_bf16, torch.is_grad_enabled(), loss_rows), x, tc.layers_MLP[0].weight, tc.layers_MLP[0].bias,
+    out = _TrunkFn.apply(graph, (L, float(tc.alpha), p, seeds, agg_bf16, torch.is_grad_enabled(), loss_rows, connection(tc) == 'residual'), x, tc.layers_MLP[0].weight, tc.layers_MLP[0].bias,
                          tc.layers_MLP[1].weight, tc.layers_MLP[1].bias, *params)
     return out, se_reg_all

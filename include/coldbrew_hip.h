@@ -252,15 +252,16 @@ int cb_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, con
  *     act      = relu(row_scale[v] * sum_j h[col[j]] + bias)                       (GCN.py:238-253,128)
  *     out_next = dropout_{seed,p}( c_act * act + c_mix * mix_src[v] )              (res_tricks.py:23, GCN.py:110/133)
  * relu_bits [N][d/256][4] uint64 receives the backward mask of the store (word k, bit l = column 256*tile + 4*l + k): set where
- * the element passes gradient to the pre-activation, i.e. act > 0 AND the dropout keeps it (p = 0: the ReLU mask); out_act
- * (nullable) the activation itself.  d must be a multiple of 256; rows 16-byte aligned.  row0 = global index
+ * the element passes gradient to the pre-activation, i.e. act > 0 AND the dropout keeps it (p = 0: the ReLU mask); bits_relu_only != 0: act > 0
+ * alone (the 'Residual' connection, res_tricks.py:7-14: layer l+1's mix sends a second gradient through this ReLU under ANOTHER dropout mask —
+ * the backward kernels regenerate the keep masks anyway); out_act (nullable) the activation itself (the mix source of the next 'Residual' layer).  d must be a multiple of 256; rows 16-byte aligned.  row0 = global index
  * of local row 0 (dropout mask of the unsharded tensor).  mix_src NULL: no mix; drop_p 0: no dropout.
  * ---------------------------------------------------------------------------------- */
 int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h,
                           int64_t d,
                           const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix, float c_act,
                           float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits,
-                          float* out_act, int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs,
+                          int32_t bits_relu_only, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs,
                           int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes,
                           void* stream);
 
@@ -269,7 +270,11 @@ int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, int32_t col
  *     gy = c_act * gm * relu_bit;  colsum = sum_rows gy (dbias; NULL to skip);  out = gy * row_scale[r]. */
 int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits, const float* row_scale, void* out, int out_bf16, float* gx0,
                            int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed, const uint64_t* seed_dev,
-                           int64_t row0, float c_act, float c_mix, float* colsum, void* ws, size_t ws_bytes, void* stream);
+                           int64_t row0, float c_act, float c_mix, const float* g2, uint64_t seed2, float c2, float* colsum, void* ws,
+                           size_t ws_bytes, void* stream);
+/* g2 (may be NULL): 'Residual' connection (res_tricks.py:7-14) — the layer's ReLU output also is the mix source of the NEXT layer, so
+ *     gy = (c_act * dropout_bwd_seed(g) + c2 * dropout_bwd_seed2(g2)) * relu_bit     (g2 = gradient w.r.t. the next layer's stored output;
+ * relu_bits written with bits_relu_only). */
 /* (out_bf16 != 0: `out` is a bf16 [rows, d] matrix — gradient rows stored in bf16 for the bf16 aggregation variant.) */
 /* The same over a SUBSET of the rows (row-sparse backward: the loss rows): g / out are compact [n_rows, d] matrices holding rows
  * row_index[0 .. n_rows) (ascending) of the full ones; relu_bits / row_scale are the full arrays; the dropout mask is the global row's. */
@@ -313,7 +318,7 @@ int cb_spmm_csr_bf16_f32(const int32_t* rowptr, const int32_t* col, int32_t col_
 int cb_spmm_csr_fused_bf16_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const uint16_t* h, int64_t ld_h,
                                int64_t d, const float* row_scale, const float* bias, const float* mix_src, int64_t ld_mix,
                                float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0,
-                               uint64_t* relu_bits, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
+                               uint64_t* relu_bits, int32_t bits_relu_only, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
                                int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
                                const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream);
 
@@ -370,7 +375,7 @@ int cb_spmm_csr_fused_acc_f32(const float* acc_init, int64_t ld_init, const int3
                               int64_t E,
                               const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias,
                               const float* mix_src, int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed,
-                              const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, float* out_act, int64_t ld_act,
+                              const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, int32_t bits_relu_only, float* out_act, int64_t ld_act,
                               float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
                               const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream);
 
@@ -385,7 +390,7 @@ int cb_spmm_csr_acc_bf16_f32(const int32_t* rowptr, const int32_t* col, int32_t 
 int cb_spmm_csr_fused_acc_bf16_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int32_t col_flags,
                                    int64_t N, int64_t E, const uint16_t* h, int64_t ld_h, int64_t d, const float* row_scale,
                                    const float* bias, const float* mix_src, int64_t ld_mix, float c_act, float c_mix, float drop_p,
-                                   uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, float* out_act,
+                                   uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, int32_t bits_relu_only, float* out_act,
                                    int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs,
                                    int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes,
                                    void* stream);
@@ -446,7 +451,8 @@ int cb_spmm_gemm_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flag
 int cb_spmm_gemm_fused_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N,
                            int64_t E, const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias, const float* mix_src,
                            int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0,
-                           uint64_t* relu_bits, float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
+                           uint64_t* relu_bits, int32_t bits_relu_only, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
+                           int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
                            const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, const void* image,
                            const float* g_rowscale, const float* g_addend, int64_t ld_add, float* g_out, int64_t ld_gout, void* stream);
 /* cb_spmm_gemm_fused_f32 for a forward that no backward follows (evaluation / metrics passes, GCN.py:100-140 under no_grad): the stored
@@ -455,7 +461,8 @@ int cb_spmm_gemm_fused_f32(const float* acc_init, int64_t ld_init, const int32_t
 int cb_spmm_gemm_fused_eval_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N,
                                 int64_t E, const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias, const float* mix_src,
                                 int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0,
-                                uint64_t* relu_bits, float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
+                                uint64_t* relu_bits, int32_t bits_relu_only, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
+                                int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
                                 const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, const void* image,
                                 const float* g_rowscale, const float* g_addend, int64_t ld_add, float* g_out, int64_t ld_gout, void* stream);
 /* Fault injection for the failure path above (tests): one wavefront waits with a short spin bound for a hand-over that never comes;

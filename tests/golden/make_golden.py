@@ -105,6 +105,14 @@ case('r_initialbn_h256_L3_train10', dataset='Pubmed', se='000', f=32, h=256, lay
 case('r_initialbn_h256_L3_train10_se111', dataset='Pubmed', se='111', f=32, h=256, layers=3, graph='powerlaw', n=300, train_frac=0.1)
 for _t in ['Residual', 'Initial']:
     case(f'r_{_t.lower()}_L3', force_best=0, type_trick=_t, layers=3, se='111')
+# the reference's other two default trunk shapes at the fused path's width (round 5): 'Residual' (WISCONSIN / CORNELL / TEXAS in the best-config
+# table, base_options.py:416-421; mix source = the previous layer's ReLU output, res_tricks.py:7-14) without and with structural-embedding
+# tables, and the non-residual stack (Cora / Citeseer / ACTOR: F -> H -> H -> C, dropout on the logits, GCN.py:44-50,70-71,133)
+case('r_residual_h256_L3_train10', force_best=0, type_trick='Residual', se='000', f=32, h=256, layers=3, graph='powerlaw', n=400, train_frac=0.1)
+case('r_residual_h256_L3_train10_se111', force_best=0, type_trick='Residual', se='111', f=32, h=256, layers=3, graph='powerlaw', n=300, train_frac=0.1)
+case('r_residual_h256_L2', force_best=0, type_trick='ResidualPairNorm', se='000', f=32, h=256, layers=2, graph='powerlaw', n=300, train_frac=0.3)
+case('nr_h256_L3_train10', se='000', f=32, h=256, layers=3, graph='powerlaw', n=400, train_frac=0.1)
+case('nr_h256_L3_train10_se111', se='111', f=32, h=256, layers=3, graph='powerlaw', n=300, train_frac=0.1)
 for _agg in ['concat', 'maxpool', 'attention']:
     case(f'r_dense_{_agg}_L3', force_best=0, type_trick='Dense', layer_agg=_agg, layers=3)
     case(f'r_jumping_{_agg}_L2', force_best=0, type_trick='Jumping', layer_agg=_agg, layers=2, se='111')

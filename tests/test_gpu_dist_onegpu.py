@@ -129,6 +129,7 @@ def _ranks_match_single_process(exchange, overlap, partition, argv, wire, world,
     from gnn_tail_generalization_amd.base_options import BaseOptions
     from gnn_tail_generalization_amd.trainer_node_classification import trainer
     # single-process reference on the same data, parameters and dropout seeds
+    ops.set_graph_seed(None)       # (a --hip_graph test that ran earlier in this process leaves its device seed word installed: the eager reference must not add it)
     with contextlib.redirect_stdout(io.StringIO()):
         args = BaseOptions().get_arguments(argv)
         ref = trainer(args, 0)

@@ -55,15 +55,14 @@ def test_hot_source_flags_change_no_bit_full_size(pl10m_graph, dtype, d):
     """The hot / cold gather policy (flagged column ids, bit 31) is a cache policy only: plain and fused aggregation at N = 10^7
     are bit-identical with the flagged ids and with the plain ids — fp32 rows, bf16-stored rows and d = 512; the number of
     flagged rows follows the row size (HOT_BYTES / row bytes: the hot rows together fill the Infinity Cache)."""
-    from gnn_tail_generalization_amd import graph as cbgraph
-    from gnn_tail_generalization_amd import trunk
+    from gnn_tail_generalization_amd import trunk, tuning
     G = pl10m_graph
     assert G.col_k is not None and bool((G.col_k < 0).any()) and torch.equal(G.col_k & 0x7fffffff, G.col)
     row_bytes = d * (2 if dtype == torch.bfloat16 else 4)
     ck = G.flagged_cols(False, row_bytes)
     assert torch.equal(ck & 0x7fffffff, G.col)
     n_hot = int(torch.unique(G.col[ck < 0]).numel())
-    want = cbgraph.HOT_BYTES // row_bytes
+    want = tuning.T.hot_bytes // row_bytes
     assert 0.9 * want <= n_hot <= 2.5 * want, (n_hot, want)       # every row tied with the k-th reference count is flagged too
     n = G.N
     gen = torch.Generator(device=DEV).manual_seed(11)

@@ -10,6 +10,8 @@ import os
 import pytest
 import torch
 
+from gnn_tail_generalization_amd import tuning
+
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
@@ -54,8 +56,8 @@ def test_row_sparse_backward_equals_the_dense_backward(max_frac, se, loss_side, 
     loss_side: level 0's GEMM and weight gradient contracted over the loss rows (plan.fwd0), whether its destination is compact or dense —
     not with a table gradient."""
     from gnn_tail_generalization_amd import trunk
-    monkeypatch.setattr(trunk, 'ROWSPARSE_MAX_FRAC', max_frac)
-    monkeypatch.setattr(trunk, 'ROWSPARSE_LOSS_SIDE', loss_side)
+    monkeypatch.setattr(tuning.T, 'rowsparse_max_frac', max_frac)
+    monkeypatch.setattr(tuning.T, 'rowsparse_loss_side', loss_side)
     spmm_rows = []
     from gnn_tail_generalization_amd.graph import CSRGraph
     real = CSRGraph.spmm
@@ -78,7 +80,7 @@ def test_row_sparse_backward_with_sparse_labels(n_loss_rows, monkeypatch):
     """Few loss rows (the public Planetoid splits label 0.3 - 5 % of the nodes): supports of 3 / 200 / 20 000 rows that grow by orders of
     magnitude per level — deeper levels than the first take the source-side form too (plan.fwd[j]) — against the dense backward."""
     from gnn_tail_generalization_amd import graph
-    monkeypatch.setattr(graph, 'FWD0_MIN_EDGES', 0)
+    monkeypatch.setattr(tuning.T, 'fwd0_min_edges', 0)
     loss_s, g_s, used_s = _step_grads('1', n_loss_rows=n_loss_rows)
     loss_d, g_d, used_d = _step_grads('0', n_loss_rows=n_loss_rows)
     assert used_s and not used_d and loss_s == loss_d
@@ -103,7 +105,7 @@ def test_row_sparse_backward_two_layers_small_graph(monkeypatch):
     """BASELINE config 2's shape (S-pubmed: 19 717 nodes, 2 layers, structural embeddings): the plan has two levels, the second one dense by
     construction (the stage below the first layer needs all rows); taken at this size only under hipGraph replay, forced here."""
     from gnn_tail_generalization_amd import trunk
-    monkeypatch.setattr(trunk, 'ROWSPARSE_MIN_NODES', 0)
+    monkeypatch.setattr(tuning.T, 'rowsparse_min_nodes', 0)
     loss_s, g_s, used_s = _step_grads('1', dataset='S-pubmed', se='111', layers=2)
     loss_d, g_d, used_d = _step_grads('0', dataset='S-pubmed', se='111', layers=2)
     assert used_s and not used_d and loss_s == loss_d
@@ -122,8 +124,8 @@ def test_row_sparse_backward_matches_the_unmodified_reference(case, monkeypatch)
     from conftest import load_golden
     from helpers import product_model
     from gnn_tail_generalization_amd import _lib, graph, ops, trunk
-    monkeypatch.setattr(trunk, 'ROWSPARSE_MIN_NODES', 0)
-    monkeypatch.setattr(graph, 'FWD0_MIN_EDGES', 0)                  # (the source-side form at this small size too)
+    monkeypatch.setattr(tuning.T, 'rowsparse_min_nodes', 0)
+    monkeypatch.setattr(tuning.T, 'fwd0_min_edges', 0)                  # (the source-side form at this small size too)
     monkeypatch.setenv('CB_LOSS_ROWS', '1')
     g = load_golden(case)
     args, model = product_model(g['cfg'], g['sd'], DEV)
@@ -156,9 +158,9 @@ def test_row_sparse_backward_on_a_directed_multigraph(loss_side, monkeypatch):
     from conftest import load_golden
     from helpers import product_model
     from gnn_tail_generalization_amd import _lib, graph, ops, trunk
-    monkeypatch.setattr(trunk, 'ROWSPARSE_MIN_NODES', 0)
-    monkeypatch.setattr(graph, 'FWD0_MIN_EDGES', 0)
-    monkeypatch.setattr(trunk, 'ROWSPARSE_LOSS_SIDE', loss_side)
+    monkeypatch.setattr(tuning.T, 'rowsparse_min_nodes', 0)
+    monkeypatch.setattr(tuning.T, 'fwd0_min_edges', 0)
+    monkeypatch.setattr(tuning.T, 'rowsparse_loss_side', loss_side)
     g = load_golden('case_r_initialbn_h256_L3_train10')
     cfg = dict(g['cfg'], dropout=0.3)
     n = cfg['N_nodes']
@@ -214,7 +216,7 @@ def test_row_sparse_backward_at_the_headline_size():
 
 def test_support_plan_levels_are_the_reverse_graph_restricted_and_renumbered(monkeypatch):
     from gnn_tail_generalization_amd import graph
-    monkeypatch.setattr(graph, 'FWD0_MIN_EDGES', 0)
+    monkeypatch.setattr(tuning.T, 'fwd0_min_edges', 0)
     from gnn_tail_generalization_amd.data import synthetic_data
     from gnn_tail_generalization_amd.graph import CSRGraph
     data = synthetic_data('S-pl1M', seed=0, device=DEV, n_override=70000)
