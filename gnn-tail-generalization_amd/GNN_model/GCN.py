@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn import init
 
-from .. import gemm, ops, trunk
+from .. import gemm, ops, stack, trunk
 from ..graph import CSRGraph, DGLError, build_graph  # noqa: F401
 from .drop_tricks import DropoutTrick
 from .norm_tricks import AcontainsB, appendNormLayer, run_norm_if_any
@@ -29,7 +29,7 @@ class TricksComb(nn.Module):
     """Layer stack of the teacher: non-residual mode = GCNConv(F,H), (L-2) x GCNConv(H,H), GCNConv(H,C);
     residual mode (type_trick names Jumping/Initial/Residual/Dense) = Linear(F,H), L x GCNConv(H,H), Linear(H,C)."""
 
-    use_fused_trunk = True   # 'Initial' connection without a bare norm runs as one fused autograd node (trunk.py)
+    use_fused_trunk = True   # 'Initial' / 'Residual' connections (trunk.py) and the non-residual stack (stack.py) without a bare norm run as one fused autograd node at hidden 256
 
     def __init__(self, args):
         super().__init__()
@@ -105,6 +105,8 @@ class TricksComb(nn.Module):
         new_adjs = self.graph_dropout(edge_index)      # computed and discarded, as in the reference (GCN.py:101,111)
         if self.use_fused_trunk and not getattr(graph, 'segmented', False) and trunk.eligible(self, x, want_les):
             return trunk.forward(self, x, graph, loss_rows=loss_rows)
+        if self.use_fused_trunk and not getattr(graph, 'segmented', False) and stack.eligible(self, x, graph, want_les):
+            return stack.forward(self, x, graph)      # the non-residual stack (NoRes...) at hidden 256
         if getattr(self.args, 'agg_dtype', 'f32') != 'f32' and not want_les:
             raise NotImplementedError("--agg_dtype=bf16 (bf16-stored aggregation rows) is built for the fused 'Initial' trunk "
                                       '(hidden width a multiple of 256); this configuration runs the fp32 operator path')

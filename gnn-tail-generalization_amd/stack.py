@@ -1,0 +1,150 @@
+"""Fused non-residual stack of TricksComb.forward — the configuration the reference's best-config table selects for Cora / Citeseer / ACTOR
+('NoRes…', base_options.py:416-421; no input / output Linear, no mix, GCN.py:44-50,70-71):
+
+    for l < L:  X = dropout(X);  Y = GCNConv_l(X)  (widths F -> H -> ... -> H -> C);  X = relu(Y) for l < L - 1      GCN.py:109-131
+    out = dropout(X)                                                                    (on the logits)             GCN.py:133
+
+One autograd node with the fused trunk's kernels (trunk.py): the dropout in front of layer 0 is applied by its GEMM while it stages x
+(cb_gemm_nn_indrop_f32), every hidden layer's aggregation stores ReLU mask words and the DROPPED activation in one pass (cb_spmm_csr_fused_f32
+without a mix source) and — between two hidden layers — also yields the next layer's transform (cb_spmm_gemm_fused_f32); the backward runs the
+reverse aggregation + dX contraction as one kernel (cb_spmm_gemm_f32), keeps ReLU masks as bits and regenerates dropout masks.  Hidden width
+256 (the fused store's row layout), one GPU; every other shape takes the operator path (GCN.py _forward_modular), whose arithmetic and sequence
+of dropout seeds this node reproduces (tests/test_gpu_model.py::test_fused_stack_equals_modular_path; goldens case_nr_h256_*)."""
+import torch
+
+from . import gemm, ops
+from .trunk import _fused_gemm, _fused_spmm, _layer_bwd, agg_gemm_eligible
+
+
+def eligible(tc, x, graph, want_les):
+    return (not tc.has_residual_MLP and not want_les and tc.dim_hidden == 256 and tc.num_layers >= 2 and len(tc.layers_GCN) == tc.num_layers
+            and tc.args.type_trick not in ('BatchNorm', 'PairNorm', 'NodeNorm', 'MeanNorm', 'GroupNorm', 'CombNorm')
+            and x.is_cuda and x.dtype == torch.float32 and not hasattr(graph, 'part') and getattr(tc.args, 'agg_dtype', 'f32') == 'f32'
+            and tc.args.dropout == tc.dropout and hasattr(graph, 'spmm_gemm'))
+
+
+class _StackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, graph, cfg, x, *layer_params):
+        """layer_params = (W_0, bias_0, le_0 | None, W_1, ...).  cfg = (L, p, seeds[L + 1], track)."""
+        L, p, seeds, track = cfg
+        a, b = graph.norm_out, graph.norm_in
+        x = x.contiguous()
+        bwd = bool(track) and any(ctx.needs_input_grad)
+        w0, _b0, le0 = layer_params[0:3]
+        # layer 0: Z_0 = a * (dropout(x) W_0) + E_0, the dropout applied while the GEMM stages x where that form exists
+        z = gemm.mm_nn_indrop(x, w0, p, seeds[0], 0, rowscale=a, addend=le0) if p > 0 else None
+        ctx.indrop = z is not None
+        if z is None:
+            xd0 = ops._dropout_raw(x, p, seeds[0], 0) if p > 0 else x
+            z = gemm.mm_nn(xd0, w0, rowscale=a, addend=le0)
+        else:
+            xd0 = x                       # kept for the backward: the UNdropped features (the weight gradient regenerates the mask)
+        ag = agg_gemm_eligible(graph, 256, False)
+        saved_in, saved_bits = [xd0], []
+        z_ready = None
+        for l in range(L - 1):            # hidden layers: aggregation with the ReLU / dropout store (+ the next hidden layer's transform)
+            _w, bias, _le = layer_params[3 * l: 3 * l + 3]
+            w1, _b1, le1 = layer_params[3 * (l + 1): 3 * (l + 1) + 3]
+            sd = seeds[l + 1] if p > 0 else 0
+            z = z_ready if z_ready is not None else z
+            z_ready = None
+            if ag and l + 1 < L - 1:      # the next layer is H -> H: its transform leaves this layer's aggregation kernel
+                from .graph import weight_image
+                # (a forward that no backward follows leaves cur = None: the activations stayed on chip)
+                bits, cur, z_ready = _fused_gemm(graph, z, bias, None, 1.0, 0.0, p, sd, weight_image(w1), a, le1, want_bits=bwd)[:3]
+            else:
+                bits, cur, _ = _fused_spmm(graph, z, bias, None, 1.0, 0.0, p, sd, want_bits=bwd)
+                z = gemm.mm_nn(cur, w1, rowscale=a, addend=le1)
+            if bwd:
+                saved_bits.append(bits)
+                saved_in.append(cur)
+        z = z_ready if z_ready is not None else z
+        bias_last = layer_params[3 * (L - 1) + 1]
+        y = graph.spmm(z, row_scale=b, bias=bias_last)                           # the last layer: no ReLU (GCN.py:127)
+        out = ops._dropout_raw(y, p, seeds[L], 0) if p > 0 else y                 # dropout on the logits (GCN.py:133)
+        ctx.graph, ctx.cfg = graph, cfg
+        if bwd:
+            ctx.save_for_backward(*saved_in, *saved_bits, *[t for t in layer_params if t is not None])
+        ctx.le_present = [layer_params[3 * l + 2] is not None for l in range(L)]
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        graph, (L, p, seeds, _track) = ctx.graph, ctx.cfg
+        sv = list(ctx.saved_tensors)
+        saved_in, saved_bits, rest = sv[:L], sv[L: 2 * L - 1], sv[2 * L - 1:]
+        lp, k = [], 0
+        for l in range(L):
+            w, bias = rest[k], rest[k + 1]
+            k += 2
+            le = None
+            if ctx.le_present[l]:
+                le = rest[k]
+                k += 1
+            lp.append((w, bias, le))
+        a, b = graph.norm_out, graph.norm_in
+        need = ctx.needs_input_grad          # (graph, cfg, x, *layer_params)
+        nw = lambda l: need[3 + 3 * l]       # noqa: E731
+        nb = lambda l: need[3 + 3 * l + 1]   # noqa: E731
+        nle = lambda l: lp[l][2] is not None and need[3 + 3 * l + 2]      # noqa: E731
+        grads = [None] * (3 * L)
+        ag = agg_gemm_eligible(graph, 256, False)
+        # last layer: dropout on the logits, bias, degree norm, reverse aggregation at the class width
+        gd = ops._dropout_raw(gemm._rowmajor(gout), p, seeds[L], 0) if p > 0 else gemm._rowmajor(gout)
+        gr, grads[3 * (L - 1) + 1] = ops.act_bwd(gd, None, b, want_out=True, want_colsum=nb(L - 1))
+        gz = graph.spmm(gr, transpose=True)
+        w_last = lp[L - 1][0]
+        if nw(L - 1):
+            grads[3 * (L - 1)] = gemm.mm_tn(saved_in[L - 1], gz, rowscale=a)
+        if nle(L - 1):
+            grads[3 * (L - 1) + 2] = gz
+        g = gemm.mm_nn(gz, w_last.t().contiguous(), rowscale=a)                  # dL/d(dropped X_{L-1})
+        del gd, gr, gz
+        for l in range(L - 2, -1, -1):
+            w = lp[l][0]
+            gr, grads[3 * l + 1] = _layer_bwd(g, saved_bits[l], b, None, False, p, seeds[l + 1] if p > 0 else 0, 0, 1.0, 0.0, nb(l))
+            del g
+            g = None
+            if ag and l > 0:             # dL/dZ_l = A (b * dY') and a * (dL/dZ_l W_l^T) from one kernel
+                from .graph import weight_image
+                gz, g = graph.spmm_gemm(gr, weight_image(w, transpose=True), transpose=True, g_rowscale=a)
+            else:
+                gz = graph.spmm(gr, transpose=True)
+                if l > 0 or need[2]:
+                    g = gemm.mm_nn(gz, w.t().contiguous(), rowscale=a)
+            del gr
+            if nw(l):
+                if l == 0 and ctx.indrop:      # the mask of the dropout in front of layer 0 is regenerated while the GEMM stages x
+                    dw = gemm.mm_tn_adrop(saved_in[0], gz, p, seeds[0], 0, rowscale=a)
+                    if dw is None:
+                        dw = gemm.mm_tn(ops._dropout_raw(saved_in[0], p, seeds[0], 0), gz, rowscale=a)
+                    grads[0] = dw
+                else:
+                    grads[3 * l] = gemm.mm_tn(saved_in[l], gz, rowscale=a)
+            if nle(l):
+                grads[3 * l + 2] = gz
+            del gz
+        d_x = None
+        if need[2]:
+            d_x = ops._dropout_raw(g, p, seeds[0], 0) if p > 0 else g
+        return (None, None, d_x, *grads)
+
+
+def forward(tc, x, graph):
+    """TricksComb.forward on the fused non-residual stack; returns (logits, se_reg_all)."""
+    L = tc.num_layers
+    p = float(tc.dropout) if tc.training else 0.0
+    seeds = tuple(ops.next_seed() for _ in range(L + 1)) if p > 0 else (0,) * (L + 1)
+    params, se_reg_all = [], None
+    for conv in tc.layers_GCN:
+        le = conv.le if conv.whetherHasSE else None
+        params += [conv.weight, conv.bias, le]
+        if le is not None:
+            reg = ops.frobenius_norm(le)
+            conv.se_norm = reg.detach()
+            se_reg_all = reg if se_reg_all is None else se_reg_all + reg
+    if not all(c._allow_zero_in_degree for c in tc.layers_GCN):      # GCN.py:187-197
+        graph.check_zero_in_degree()
+    out = _StackFn.apply(graph, (L, p, seeds, torch.is_grad_enabled()), x, *params)
+    return out, se_reg_all

@@ -138,6 +138,77 @@ def test_fused_trunk_equals_modular_path(se, train, conn, monkeypatch):
         torch.testing.assert_close(res[True][2][k], res[False][2][k], atol=2e-6, rtol=1e-4, msg=lambda m, k=k: f'{k}: {m}')
 
 
+@pytest.mark.parametrize('L', [2, 3, 4])
+@pytest.mark.parametrize('se', ['000', '111'])
+@pytest.mark.parametrize('train', [True, False])
+def test_fused_stack_equals_modular_path(se, train, L, monkeypatch):
+    """The fused non-residual stack (stack.py: 'NoRes...' — Cora / Citeseer / ACTOR in the best-config table, base_options.py:416-421) and the
+    modular operator path compute the same logits, loss and gradients from the same parameters and the same dropout seeds (hidden = 256,
+    F -> H -> ... -> C, dropout on the logits, hub rows present; L = 4: two hidden layers in a row, i.e. the aggregation + GEMM kernel)."""
+    from gnn_tail_generalization_amd import ops, stack
+    from gnn_tail_generalization_amd.GNN_model.GCN import TricksComb
+    args, model, data = _tiny_trunk_setup(L=L, se=se, extra=('--force_set_to_best_config=0', '--type_trick=NoResNodeNorm'))
+    assert model.model.model.type_trick == 'NoResNodeNorm' and not model.model.model.has_residual_MLP
+    calls = []
+    real = stack._StackFn.apply
+    monkeypatch.setattr(stack._StackFn, 'apply', staticmethod(lambda *a, **k: (calls.append(1), real(*a, **k))[1]))
+    res = {}
+    for fused in (True, False):
+        TricksComb.use_fused_trunk = fused
+        try:
+            model.train(train)
+            model.zero_grad()
+            ops._seed_override[:] = list(range(900, 910)) if train else []
+            out = model(data.x, data.edge_index)
+            ops._seed_override[:] = []
+            loss = ops.nll_logsoftmax(out, data.y, data.train_mask)
+            if model.se_reg_all is not None:
+                loss = loss + args.se_reg * model.se_reg_all
+            loss.backward()
+            res[fused] = (out.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        finally:
+            TricksComb.use_fused_trunk = True
+    assert calls == [1]
+    torch.testing.assert_close(res[True][0], res[False][0], atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(res[True][1], res[False][1], atol=1e-6, rtol=1e-6)
+    assert set(res[True][2]) == set(res[False][2])
+    for k in res[True][2]:
+        torch.testing.assert_close(res[True][2][k], res[False][2][k], atol=2e-6, rtol=1e-4, msg=lambda m, k=k: f'{k}: {m}')
+
+
+@pytest.mark.parametrize('name,which', [('case_r_residual_h256_L3_train10', 'trunk'), ('case_r_residual_h256_L3_train10_se111', 'trunk'),
+                                        ('case_r_residual_h256_L2', 'trunk'), ('case_r_initialbn_h256_L3_train10', 'trunk'),
+                                        ('case_nr_h256_L3_train10', 'stack'), ('case_nr_h256_L3_train10_se111', 'stack')])
+def test_default_trunk_shapes_run_fused_against_the_reference(name, which, monkeypatch):
+    """The reference's three default trunk shapes (base_options.py:416-421: Initial / Residual / NoRes) at hidden 256 go through the FUSED autograd
+    nodes (trunk._TrunkFn / stack._StackFn), and what those compute is the unmodified reference's: logits, loss and every gradient of the goldens."""
+    from gnn_tail_generalization_amd import ops, stack, trunk
+    g = load_golden(name)
+    args, model = product_model(g['cfg'], g['sd'], DEV)
+    calls = []
+    for mod, fn, tag in ((trunk, '_TrunkFn', 'trunk'), (stack, '_StackFn', 'stack')):
+        real = getattr(mod, fn).apply
+        monkeypatch.setattr(getattr(mod, fn), 'apply', staticmethod(lambda *a, _r=real, _t=tag, **k: (calls.append(_t), _r(*a, **k))[1]))
+    x, ei, y, mask = g['x'].to(DEV), g['edge_index'].to(DEV), g['y'].to(DEV), g['train_mask'].to(DEV)
+    model.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(model(x, ei).cpu(), g['eval_out'], atol=1e-4, rtol=1e-4)
+    model.train()
+    out = model.get_3_embs(x, ei, mask).emb4classi_full
+    loss = ops.nll_logsoftmax(out, y, mask)
+    if model.se_reg_all is not None:
+        loss = loss + args.se_reg * model.se_reg_all
+    model.zero_grad()
+    loss.backward()
+    assert calls == [which, which]
+    torch.testing.assert_close(out.detach().cpu(), g['train_out'], atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(loss.detach().cpu(), g['train_loss'], atol=1e-4, rtol=1e-5)
+    got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == set(g['grads'])
+    for k, ref in g['grads'].items():
+        torch.testing.assert_close(got[k].cpu(), ref, atol=2e-5, rtol=2e-4, msg=lambda m, k=k: f'{k}: {m}')
+
+
 def test_fused_trunk_matches_oracle_with_injected_masks():
     import coldbrew_oracle as orc
     from gnn_tail_generalization_amd import ops
