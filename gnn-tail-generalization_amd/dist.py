@@ -262,12 +262,14 @@ class HaloPlan:
     `uniq_remote` to (slice, row of that slice's receive buffer).  Owner side: send_idx[k] = my local rows of slice k in
     per-destination order, send_counts[k][q] of them go to peer q."""
 
-    def __init__(self, uniq_remote, part, group=None, n_slices=1):
-        """uniq_remote: ascending unique remote column ids this rank's edges reference (= grouped by owner)."""
+    def __init__(self, uniq_remote, part, group=None, n_slices=1, local_pos=None, n_src=None):
+        """uniq_remote: ascending unique remote column ids this rank's edges reference (= grouped by owner).  local_pos (int32 [n_local], a
+        compact level of the row-sparse backward): the matrix this rank SENDS from holds only the rows with local_pos >= 0, at those
+        positions (n_src of them) — the send lists index it."""
         P, K = part.world, max(1, int(n_slices))
         dev = uniq_remote.device
         self.n_slices = K
-        self.n_local, self.n_halo = part.n_local, int(uniq_remote.numel())
+        self.n_local, self.n_halo = (part.n_local if local_pos is None else int(n_src)), int(uniq_remote.numel())
         # segment (q, k) = ids in chunk k of owner q; boundaries ascending over (q major, k minor)
         bnd = [b for q in range(P) for b in chunk_bounds(part.lo(q), part.hi(q), K)[:-1]] + [part.N]
         pos = torch.searchsorted(uniq_remote, torch.tensor(bnd, dtype=torch.int64, device=dev))       # [P*K + 1] positions in uniq
@@ -286,7 +288,7 @@ class HaloPlan:
         if P > 1:
             _all_to_all_single(wanted, uniq_remote, per_peer_out, per_peer_in, group=group)            # peer-major, ascending per peer
         local = wanted - part.lo()
-        if local.numel() and (int(local.min()) < 0 or int(local.max()) >= self.n_local):
+        if local.numel() and (int(local.min()) < 0 or int(local.max()) >= part.n_local):
             raise RuntimeError('halo plan: a peer requested a row this rank does not own')
         # wanted is laid out (peer q, slice k); the send lists are (slice k, peer q)
         starts, off = {}, 0
@@ -303,7 +305,7 @@ class HaloPlan:
             r0, r1 = self.chunks[k]
             if idx.numel() and (int(idx.min()) < r0 or int(idx.max()) >= r1):
                 raise RuntimeError('halo plan: the peers cut their requests at other chunk boundaries than this rank')
-            self.send_idx.append(idx)
+            self.send_idx.append(self._to_pos(idx, local_pos))
         # requester side: position j of uniq_remote -> (slice, slot in that slice's receive buffer [peer-major, ascending])
         seg = torch.bucketize(torch.arange(self.n_halo, device=dev), pos[1:], right=True)              # segment q*K + k of position j
         roff = torch.cumsum(cnt, 0) - cnt                                                              # rows of peers < q in slice k
@@ -312,8 +314,16 @@ class HaloPlan:
         self.slot_of = torch.arange(self.n_halo, device=dev) + base[seg] if self.n_halo else seg
         # K = 1 views (the blocking / single-pass forms)
         self.recv_counts_all, self.send_counts_all = per_peer_in, per_peer_out
-        self.send_idx_all = local.contiguous()
+        self.send_idx_all = self._to_pos(local.contiguous(), local_pos)
 
+    @staticmethod
+    def _to_pos(idx, local_pos):
+        if local_pos is None:
+            return idx
+        pos = local_pos[idx].to(torch.int64)
+        if pos.numel() and int(pos.min()) < 0:
+            raise RuntimeError('halo plan: a peer requested a row outside the support this level sends from')
+        return pos.contiguous()
 
     cover = False
 
@@ -392,8 +402,9 @@ class CoverPlan:
         return dict(q_e=q_e, uu=uu, ui=ui, vv=vv, vi=vi, q_u=q_u, q_v=q_v, pull=pull, S=S, T=T, rows_pull=int(uu.numel()),
                     rows_cover=int(S.sum()) + int(T.sum()))
 
-    def __init__(self, rows, cols, part, group, n_slices, compute, assignment=None):
-        """rows / cols: local destination / global source of this rank's REMOTE edges (this orientation)."""
+    def __init__(self, rows, cols, part, group, n_slices, compute, assignment=None, local_pos=None, n_src=None):
+        """rows / cols: local destination / global source of this rank's REMOTE edges (this orientation).  local_pos / n_src: see HaloPlan
+        (the send CSRs' columns index the compact matrix this rank sends from)."""
         P, K = part.world, max(1, int(n_slices))
         dev = cols.device
         nl = max(part.n_local, 1)
@@ -471,6 +482,10 @@ class CoverPlan:
         gk, gr, gc = got[:, 0], got[:, 1], got[:, 2] - part.lo()
         if got.numel() and (int(gc.min()) < 0 or int(gc.max()) >= part.n_local or int(gk.min()) < 0 or int(gk.max()) >= K):
             raise RuntimeError('cover plan: a peer requested a row this rank does not own')
+        n_send_cols = nl
+        if local_pos is not None:
+            gc = HaloPlan._to_pos(gc, local_pos)
+            n_send_cols = max(int(n_src), 1)
         self.send_csr, self.n_send_slice = [], []
         for k in range(K):
             m = gk == k if K > 1 else slice(None)
@@ -478,7 +493,7 @@ class CoverPlan:
             srow = sbase[k][req[m]] + gr[m]
             if srow.numel() and int(srow.max()) >= n_rows_k:
                 raise RuntimeError('cover plan: a peer addressed a row beyond its segment of the send buffer')
-            self.send_csr.append(compute.csr(srow, gc[m], max(n_rows_k, 1), nl))
+            self.send_csr.append(compute.csr(srow, gc[m], max(n_rows_k, 1), n_send_cols))
             self.n_send_slice.append(n_rows_k)
         self.chunks = [(0, part.n_local)] + [(part.n_local, part.n_local)] * (K - 1)      # a producer, if any, delivers the whole matrix before slice 0
         self.recv_counts_all = [sum(self.recv_counts[k][q] for k in range(K)) for q in range(P)]
@@ -492,6 +507,15 @@ class CoverPlan:
 
     def halo_edges(self, rows=None, inv=None):
         return self._h_rows, self._h_slice, self._h_slot
+
+
+class SupportLevel:
+    """One level of the row-sparse backward on a rank: the level's orientation and the row spaces of what it reads (src) and writes (dst);
+    None = all local rows."""
+    __slots__ = ('orient', 'src', 'dst')
+
+    def __init__(self, orient, src, dst):
+        self.orient, self.src, self.dst = orient, src, dst
 
 
 class _Orientation:
@@ -584,12 +608,20 @@ class ShardedGraph:
         self._support_cache = None
 
     # -- build one orientation ---------------------------------------------------------------------------
-    def _orient(self, rows, cols, like=None):
+    def _orient(self, rows, cols, like=None, dst=None, src=None):
         """like: an existing orientation whose KIND of plan (pull / cover) and slice count this one takes over — the callers' control flow is
-        keyed to those (row-chunked producers, fused last pass), so a level orientation of the row-sparse backward mirrors the full one."""
+        keyed to those (row-chunked producers, fused last pass), so a level orientation of the row-sparse backward mirrors the full one.
+        dst / src (graph.RowSpace over this rank's rows, overlapped form only): a COMPACT level — the CSRs' rows are positions in dst, the
+        interior columns and the send lists positions in src: the level reads a [src.n, d] matrix and writes a [dst.n, d] one."""
         part, lo, hi = self.part, self.part.lo(), self.part.hi()
         o = _Orientation()
         o.E = int(rows.numel())
+        n_r = self.N if dst is None else max(dst.n, 1)
+        n_c = self.N if src is None else max(src.n, 1)
+        if dst is not None:
+            rows = dst.pos[rows].to(torch.int64)
+            if rows.numel() and int(rows.min()) < 0:
+                raise RuntimeError('level orientation: an edge writes a row outside the destination support')
         o.whole = o.interior = o.halo = o.plan = None
         if self.exchange_kind == 'allgather':       # columns index the gathered [P*R, d] matrix (equal blocks: identity)
             o.whole = self.compute.csr(rows, cols, self.N, part.padded)
@@ -624,14 +656,21 @@ class ShardedGraph:
                 _all_reduce(busiest, op=dist.ReduceOp.MAX, group=self.group)
             n_pull, n_cover = (int(v) for v in busiest.tolist())
             use_cover = (n_pull > 0 and 1.0 - n_cover / n_pull >= COVER_MIN_GAIN) or self._cover_forced
-        o.plan = CoverPlan(rows[remote], cols[remote], part, self.group, K, self.compute, asg) if use_cover else HaloPlan(uniq, part, self.group, K)
+        lp_, ns_ = (src.pos, src.n) if src is not None else (None, None)
+        o.plan = (CoverPlan(rows[remote], cols[remote], part, self.group, K, self.compute, asg, local_pos=lp_, n_src=ns_) if use_cover
+                  else HaloPlan(uniq, part, self.group, K, local_pos=lp_, n_src=ns_))
         if self.overlap:
-            o.interior = self.compute.csr(rows[~remote], cols[~remote] - lo, self.N, self.N)
+            ci = cols[~remote] - lo
+            if src is not None:
+                ci = HaloPlan._to_pos(ci, src.pos)
+            o.interior = self.compute.csr(rows[~remote], ci, n_r, n_c)
             rr, sl, slot = o.plan.halo_edges(rows[remote], inv)
             o.halo = []
             for k in range(K):
                 m = sl == k if K > 1 else slice(None)
-                o.halo.append(self.compute.csr(rr[m], slot[m], self.N, max(o.plan.n_halo_slice[k], 1)))
+                o.halo.append(self.compute.csr(rr[m], slot[m], n_r, max(o.plan.n_halo_slice[k], 1)))
+        elif dst is not None or src is not None:
+            raise ValueError('compact level orientations need the overlapped exchange')
         else:
             new_col = cols - lo
             new_col[remote] = self.N + inv
@@ -639,15 +678,26 @@ class ShardedGraph:
         return o
 
     def support_orients(self, mask_local, n_aggr, max_edge_frac=None):
-        """Level orientations of a row-sparse backward (trunk.py; graph.CSRGraph.grad_support_plan is the one-GPU form): reverse aggregation
+        """The level orientations alone (matrices keep all local rows): [lv.orient for lv in support_levels(..., compact=False)]."""
+        return [lv.orient for lv in self.support_levels(mask_local, n_aggr, max_edge_frac, compact=False)]
+
+    def support_levels(self, mask_local, n_aggr, max_edge_frac=None, compact=True, max_frac=None):
+        """Levels of a row-sparse backward on row shards (trunk.py; graph.CSRGraph.grad_support_plan is the one-GPU form): reverse aggregation
         j gathers only rows of the support S_j (S_0 = the loss rows `mask_local` of this rank, S_{j+1} = rows with a reverse-orientation
         neighbour in S_j) — all other rows of the gathered matrix are exact zeros.  Level j = the reverse orientation restricted to the edges
         whose gathered row is in S_j: its halo plan asks the peers for the support's rows only (the first backward exchange of the bench's
-        graph ships a tenth of the rows, the second 45 %), its interior / halo passes read fewer edges; matrices keep all local rows.
-        Levels are built while they keep at most max_edge_frac of the edges (one decision for the group); the supports travel as byte
-        maps (all-gather of N bytes per level, once per mask).  Returns a list of orientations, possibly empty."""
+        graph ships a tenth of the rows, the second 45 %), its interior / halo passes read fewer edges.
+        compact (round 5): while the GLOBAL support is at most max_frac (tuning.T.rowsparse_max_frac) of the nodes the level is also COMPACT
+        in this rank's rows — SupportLevel.src / .dst are graph.RowSpace objects over the rank's block (S_j / S_{j+1} restricted to it), the
+        level reads a [src.n, d] matrix and writes a [dst.n, d] one (dst None: all local rows; the last level always), so the rank's store
+        backward, weight gradient and GEMM tail run on the support's rows only, as on one GPU.  One decision per level for the group; needs
+        the overlapped exchange with a plan whose last pass can be the aggregation + GEMM kernel (cover, or one slice).
+        Levels are built while they keep at most max_edge_frac of the edges; the supports travel as byte maps (all-gather of N bytes per
+        level, once per mask).  Returns a list of SupportLevel, possibly empty."""
+        from .graph import RowSpace
         max_edge_frac = T.support_max_edge_frac if max_edge_frac is None else max_edge_frac
-        key = (mask_local.data_ptr(), mask_local._version, int(n_aggr))
+        max_frac = T.rowsparse_max_frac if max_frac is None else max_frac
+        key = (mask_local.data_ptr(), mask_local._version, int(n_aggr), bool(compact), float(max_frac), float(max_edge_frac))
         if self._support_cache is not None and self._support_cache[0] == key and self._support_cache[1] is mask_local:
             return self._support_cache[2]
         part, P = self.part, self.part.world
@@ -656,7 +706,26 @@ class ShardedGraph:
         owner = part.owner(cols)
         lo_t = torch.tensor(part.bounds[:-1], dtype=torch.int64, device=dev)
         slot = owner * part.R + (cols - lo_t[owner])          # position of a column's row in the all-gathered [P * R] map
-        levels, s_local = [], mask_local.to(torch.bool)
+        plan_b = self.b.plan
+        compact = bool(compact) and self.overlap and plan_b is not None and (plan_b.cover or plan_b.n_slices == 1) and min(
+            part.hi(q) - part.lo(q) for q in range(P)) > 0
+
+        def space_of(mask):
+            if not bool(mask.any()):      # (a superset of the support is as good: a row outside it carries exact zeros)
+                mask = mask.clone()
+                mask[0] = True
+            pos = torch.cumsum(mask, 0, dtype=torch.int32) - 1
+            idx = torch.nonzero(mask).flatten()
+            return RowSpace(idx, torch.where(mask, pos, torch.full_like(pos, -1)), self.norm_out[idx].contiguous())
+
+        def global_count(mask):
+            c = torch.tensor([int(mask.sum())], dtype=torch.int64, device=dev)
+            if P > 1:
+                _all_reduce(c, group=self.group)
+            return int(c.item())
+        # pass 1: the supports and the edges each level keeps (collectives: one all-gather + one all-reduce per level, the same on every rank)
+        found, s_local = [], mask_local.to(torch.bool)
+        n0 = global_count(s_local) if compact else 0
         for _ in range(int(n_aggr)):
             m = torch.zeros(part.R, dtype=torch.uint8, device=dev)
             m[:self.N] = s_local.to(torch.uint8)
@@ -672,8 +741,18 @@ class ShardedGraph:
             if int(cnt.item()) > max_edge_frac * self.E_global:
                 break
             r_k, c_k = rows[keep], cols[keep]
-            levels.append(self._orient(r_k, c_k, like=self.b))
-            s_local = torch.bincount(r_k, minlength=self.N)[:self.N] > 0
+            s_next = torch.bincount(r_k, minlength=self.N)[:self.N] > 0
+            found.append((r_k, c_k, s_next, global_count(s_next) if compact else 0))
+            s_local = s_next
+        # pass 2: the orientations.  A level writes a COMPACT matrix only if the next level exists to read it (and its support is small)
+        levels = []
+        src = space_of(mask_local.to(torch.bool)) if (compact and found and n0 <= T.rowsparse_s0_limit * self.N_global) else None
+        for j, (r_k, c_k, s_next, n_next) in enumerate(found):
+            dst = None
+            if src is not None and j + 1 < len(found) and j + 1 < int(n_aggr) and n_next <= max_frac * self.N_global:
+                dst = space_of(s_next)
+            levels.append(SupportLevel(self._orient(r_k, c_k, like=self.b, dst=dst, src=src), src, dst))
+            src = dst
         self._support_cache = (key, mask_local, levels)
         return levels
 

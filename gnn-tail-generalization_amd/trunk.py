@@ -534,11 +534,11 @@ class _Backward:
         return g_, gr_, db_, None
 
     # -- head ----------------------------------------------------------------------------------------------------------------------------
-    def _head(self, plan):
-        """Output Linear (GCN.py:133-138) and the store backward of the last layer: sets d_w_out, d_b_out and returns (g, gr, dbias, handle, space)."""
+    def _head(self, space):
+        """Output Linear (GCN.py:133-138) and the store backward of the last layer: sets d_w_out, d_b_out and returns (g, gr, dbias, handle, space).
+        space: the compact row space of the loss rows (a plan's space0 / a rank's share of it), or None = all rows."""
         L, need, gout, xl, w_out = self.L, self.need, self.gout, self.saved_in[self.L], self.w_out
-        if plan is not None:      # loss rows only
-            space = plan.space0
+        if space is not None:      # loss rows only
             gout_c, xl_c = ops.gather_rows_by_index(gout, space.idx), ops.gather_rows_by_index(xl, space.idx)
             self.d_w_out = gemm.mm_tn(gout_c, xl_c) if need[5] else None
             self.d_b_out = ops.act_bwd(gout_c, None, None, want_out=False, want_colsum=True)[1] if need[6] else None
@@ -550,9 +550,20 @@ class _Backward:
         g, gr, dbias, handle = self._dx_and_store_bwd(gout, w_out, None, L - 1, orient=self._orient_of(L - 1))
         return g, gr, dbias, handle, None
 
-    def _orient_of(self, layer):
+    def _sh_level(self, layer):
+        """Node-sharded: the dist.SupportLevel of the reverse aggregation of `layer` (orientation + row spaces), or None."""
         j = self.L - 1 - layer
-        return self.sh_levels[j] if j < len(self.sh_levels) else None
+        return self.sh_levels[j] if 0 <= j < len(self.sh_levels) else None
+
+    def _orient_of(self, layer):
+        lv = self._sh_level(layer)
+        return lv.orient if lv is not None else None
+
+    def _dw_rows(self, l, x_in, gz, dst):
+        """The layer's weight gradient with dL/dZ_l on the rows of `dst` (None: all rows — _dw)."""
+        if dst is None:
+            return self._dw(l, x_in, gz)
+        return gemm.mm_tn(ops.gather_rows_by_index(x_in, dst.idx), gz, rowscale=dst.a)
 
     # -- the layer forms -----------------------------------------------------------------------------------------------------------------
     def _layer_source_side(self, l, gr, level, fwd_j):
@@ -582,12 +593,14 @@ class _Backward:
                 self.grads_layers[3 * l] = self._dw(l, self.saved_in[l], gz)
         return gz, g_new
 
-    def _layer_fused(self, l, gr, handle):
+    def _layer_fused(self, l, gr, handle, dst=None):
         """dL/dZ_l = A (b * dY') and a * (dL/dZ_l @ W_l^T) from one kernel (cb_spmm_gemm_f32) on all rows; for l > 0 and tail_tb the trunk backward
         of layer l-1's store leaves the same epilogue (cb_spmm_gemm_trunkbwd_f32).  Node-sharded: the kernel is the LAST halo pass of the reverse
-        aggregation, on top of the running sums of the earlier passes.  Returns (gz, g_new, (gr_next, dbias_next) | None)."""
+        aggregation, on top of the running sums of the earlier passes; dst (a compact level of the rank, dist.SupportLevel): its rows are the
+        positions of the level's destination support.  Returns (gz, g_new, (gr_next, dbias_next) | None)."""
         from .graph import weight_image
-        graph, a = self.graph, self.a
+        graph = self.graph
+        a = dst.a if dst is not None else self.a
         w = self.lp[l][0]
         img = weight_image(w, transpose=True)
         use_tb = l > 0 and self.tail_tb
@@ -618,10 +631,12 @@ class _Backward:
         gout = self.gout
         # Node-sharded: the row-sparse backward as LEVEL ORIENTATIONS of the reverse exchange (dist.ShardedGraph.support_orients) — level j
         # ships and gathers only the rows of the support S_j; matrices keep all local rows, every other branch is unchanged.
+        # Round 5: while a support is a small share of the nodes the level is also COMPACT in the rank's rows (SupportLevel.src / .dst), so the
+        # rank's head, store backward, weight gradients and GEMM tails run on the support's rows as on one GPU.
         self.sh_levels = []
-        if sharded and hasattr(graph, 'support_orients') and self.loss_rows is not None:
+        if sharded and hasattr(graph, 'support_levels') and self.loss_rows is not None:
             ops.check_rows_zero(gout, self.loss_rows[0])
-            self.sh_levels = graph.support_orients(self.loss_rows[0], L)
+            self.sh_levels = graph.support_levels(self.loss_rows[0], L, compact=self.ag and gather and not self.tail_tb)
         # Row-sparse backward (one GPU): when the caller promised that only the loss rows of gout carry gradient, what the backward makes of it
         # stays zero outside the rows those can reach: after the j-th reverse aggregation only the rows with a neighbour in the previous support
         # carry gradient (CSRGraph.grad_support_plan: S_0 = loss rows, S_1, ... — 10 % / 45 % / 94 % of the rows on the bench's graph with its
@@ -639,7 +654,8 @@ class _Backward:
             ops.check_rows_zero(gout, hint[0])
             plan = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac)
 
-        g, gr, dbias, handle, space = self._head(plan)
+        space0 = plan.space0 if plan is not None else (self.sh_levels[0].src if self.sh_levels else None)
+        g, gr, dbias, handle, space = self._head(space0)
         g_above = None         # 'Residual': dL/d(stored output) of the layer above the one whose store backward comes next
         deferred = None        # (layer, X_l, dZ_l): weight gradient of the layer above, computed under this layer's halo exchange
         for l in range(L - 1, -1, -1):
@@ -650,11 +666,12 @@ class _Backward:
                 self.seeds_mix.append(self.seed(l + 2))
             j = L - 1 - l
             level = plan.levels[j] if (plan is not None and j < len(plan.levels)) else None
-            dst = level[1] if level is not None else None
+            lv = self._sh_level(l)
+            dst = level[1] if level is not None else lv.dst if lv is not None else None
             if sharded and handle is None:
                 handle = graph.aggregate_start(gr, True, orient=self._orient_of(l))   # node-sharded: the exchange is in flight from here
             if deferred is not None:
-                self.grads_layers[3 * deferred[0]] = self._dw(*deferred)
+                self.grads_layers[3 * deferred[0]] = self._dw_rows(*deferred)
                 deferred = None
             tb_next = None
             fwd_j = plan.fwd[j] if (level is not None and j < len(plan.fwd)) else None
@@ -665,17 +682,17 @@ class _Backward:
             elif level is not None:
                 gz, g_new = self._layer_compact(l, gr, level)
             elif self.ag:
-                gz, g_new, tb_next = self._layer_fused(l, gr, handle)
+                gz, g_new, tb_next = self._layer_fused(l, gr, handle, dst)
                 if self.need_w(l):
                     if sharded:
-                        deferred = (l, self.saved_in[l], gz)
+                        deferred = (l, self.saved_in[l], gz, dst)
                     else:
                         self.grads_layers[3 * l] = self._dw(l, self.saved_in[l], gz)
             else:
                 gz, g_new = self._layer_plain(gr, handle), None
                 if self.need_w(l):
                     if sharded:
-                        deferred = (l, self.saved_in[l], gz)
+                        deferred = (l, self.saved_in[l], gz, None)
                     else:
                         self.grads_layers[3 * l] = self._dw(l, self.saved_in[l], gz)
             g_above = g if self.residual else None
@@ -699,7 +716,7 @@ class _Backward:
                 self.grads_layers[3 * l + 2] = gz
             del gz
         if deferred is not None:
-            self.grads_layers[3 * deferred[0]] = self._dw(*deferred)
+            self.grads_layers[3 * deferred[0]] = self._dw_rows(*deferred)
         # input stage: X0 feeds layer 0 (through its dropout) and the mixes
         if gather:
             gpre, d_b_in = _input_bwd_multi(g, self.seed(1), self.g_mix, self.seeds_mix, alpha, self.x0, p, self.row0, act_bits=self.x0_bits,

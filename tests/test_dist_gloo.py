@@ -217,11 +217,17 @@ def _support_worker(rank, world, port, name, q, cover, n_slices):
         gen = torch.Generator().manual_seed(3)
         mask = torch.rand(n, generator=gen) < 0.08
         mask[0] = True
-        levels = sg.support_orients(part.slice_rows(mask).contiguous(), 3, max_edge_frac=0.97)
+        mask_l = part.slice_rows(mask).contiguous()
+        levels = sg.support_orients(mask_l, 3, max_edge_frac=0.97)
         assert len(levels) >= 1
+        # round 5: the same levels COMPACT in this rank's rows (SupportLevel.src / .dst) where the plan allows it (cover, or one slice)
+        clevels = sg.support_levels(mask_l, 3, max_edge_frac=0.97, compact=True, max_frac=0.95)
+        can_compact = bool(sg.b.plan.cover) or sg.b.plan.n_slices == 1
+        assert len(clevels) == len(levels) and (clevels[0].src is not None) == can_compact
+        assert clevels[-1].dst is None or len(clevels) < 3          # the last of n_aggr levels always writes all rows
         src, dst = ei[0], ei[1]
         S = mask.clone()
-        for o in levels:
+        for o, lv in zip(levels, clevels):
             assert o.plan.n_slices == sg.b.plan.n_slices and bool(o.plan.cover) == bool(sg.b.plan.cover)
             assert o.plan.n_halo <= sg.b.plan.n_halo and o.E <= sg.b.E
             h = torch.randn(n, 5, generator=gen) * S.float().unsqueeze(1)          # supported on S_j
@@ -232,6 +238,17 @@ def _support_worker(rank, world, port, name, q, cover, n_slices):
             nxt = torch.zeros(n, dtype=torch.bool)
             nxt[src[S[dst]]] = True          # reverse aggregation: row u sums the rows dst(e) of its out-edges
             assert bool((full[~part.slice_rows(nxt)] == 0).all())
+            # the compact level: reads the support's rows of this rank, writes the next support's (or all rows)
+            if lv.src is not None:
+                assert bool(part.slice_rows(S)[lv.src.idx].sum() == part.slice_rows(S).sum())          # src covers S_j on this rank
+                assert lv.orient.plan.n_halo == o.plan.n_halo and lv.orient.E == o.E                    # same exchange, same edges
+                inp = hl[lv.src.idx].contiguous()
+                got = sg.aggregate_finish(sg.aggregate_start(inp, True, orient=lv.orient), True)
+                if lv.dst is not None:
+                    assert got.shape[0] == lv.dst.n and bool(part.slice_rows(nxt)[lv.dst.idx].sum() == part.slice_rows(nxt).sum())
+                    torch.testing.assert_close(got, full[lv.dst.idx], atol=1e-5, rtol=1e-5)
+                else:
+                    torch.testing.assert_close(got, full, atol=1e-5, rtol=1e-5)
             S = nxt
         q.put((rank, 'ok'))
     except Exception:  # noqa: BLE001

@@ -77,6 +77,13 @@ def _worker(rank, world, port, exchange, overlap, partition, argv, q, wire='f32'
             # the fused trunk (S-pubmed: hidden 256, 'Initial'): its backward went through the level orientations of the row-sparse backward
             # (dist.ShardedGraph.support_orients: 10 % train rows -> level 0 keeps a tenth of the reverse edges)
             assert t.sgraph._support_cache is not None and len(t.sgraph._support_cache[2]) >= 1, 'row-sparse level orientations not used'
+            # round 5: where the last halo pass can be the aggregation + GEMM kernel (fp32 wire, cover plan or one slice) the levels are also COMPACT
+            # in the rank's rows: head, store backward, weight gradients and GEMM tails of those levels ran on the support's rows only
+            from gnn_tail_generalization_amd import trunk
+            lv0 = t.sgraph._support_cache[2][0]
+            assert (lv0.src is not None) == bool(trunk.agg_gemm_eligible(t.sgraph, 256, False)), 'compact levels not used where the plan allows them'
+            if lv0.src is not None:
+                assert 0 < lv0.src.n < t.part.n_local
         accs = t.run_testSet()
         w = t.teacherGNN.model.model.layers_GCN[1].weight.detach().cpu()
         le = conv0.le.detach().cpu() if conv0.whetherHasSE else torch.zeros(1)
