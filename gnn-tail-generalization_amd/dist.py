@@ -336,6 +336,24 @@ class HaloPlan:
         return rows, self.slice_of[inv], self.slot_of[inv]
 
 
+def merged_first_pass_enabled():
+    return os.environ.get('COLDBREW_MERGED_FIRST_PASS', '1') != '0'
+
+
+def alloc_exchanged(graph, n_rows, d, dtype=torch.float32, device=None):
+    """An [n_rows, d] matrix that an aggregation of `graph` will exchange, allocated with ROOM behind it for the first halo slice
+    (ShardedGraph.halo_room rows): start_halo then receives slice 0 right behind the local rows and the interior pass and the first halo pass
+    become one (o.first).  On anything but a node-sharded graph: a plain matrix."""
+    room = int(getattr(graph, 'halo_room', 0) or 0)
+    device = device if device is not None else graph.norm_in.device
+    if room <= 0:
+        return torch.empty((n_rows, d), dtype=dtype, device=device)
+    buf = torch.empty((n_rows + room, d), dtype=dtype, device=device)
+    v = buf[:n_rows]
+    v._cb_room = room          # (an attribute of THIS tensor object: a matrix that merely happens to sit in a larger allocation is never taken for one)
+    return v
+
+
 def cover_slices_enabled():
     return os.environ.get('COLDBREW_HALO_COVER', '1') != '0'
 
@@ -520,7 +538,7 @@ class SupportLevel:
 
 class _Orientation:
     """One CSR orientation of a rank's row block: the CSR(s) the local passes read and the plan that feeds them."""
-    __slots__ = ('whole', 'interior', 'halo', 'plan', 'E', 'rowptr_key', 'col_key')
+    __slots__ = ('whole', 'interior', 'halo', 'plan', 'E', 'rowptr_key', 'col_key', 'first', 'n_cols_local')
 
 
 class ShardedGraph:
@@ -606,6 +624,12 @@ class ShardedGraph:
         # the reverse orientation's edge list (local row, global column) stays: the row-sparse backward builds its level orientations from it
         self._rev_edges = (rf, cf) if self.symmetric else (rb, cb)
         self._support_cache = None
+        # rows of room behind an exchanged matrix for the first halo slice (alloc_exchanged): the largest first slice of the two orientations
+        # (the level orientations of the row-sparse backward ask for subsets of the reverse one's rows)
+        self.halo_room = 0
+        self.merged_passes = self.interior_passes = 0      # how often an aggregation took the merged first pass / the separate interior pass (tests, bench)
+        if self.overlap and self.f.first is not None:
+            self.halo_room = max(self.f.plan.n_halo_slice[0], self.b.plan.n_halo_slice[0], 1)
 
     # -- build one orientation ---------------------------------------------------------------------------
     def _orient(self, rows, cols, like=None, dst=None, src=None):
@@ -622,7 +646,8 @@ class ShardedGraph:
             rows = dst.pos[rows].to(torch.int64)
             if rows.numel() and int(rows.min()) < 0:
                 raise RuntimeError('level orientation: an edge writes a row outside the destination support')
-        o.whole = o.interior = o.halo = o.plan = None
+        o.whole = o.interior = o.halo = o.plan = o.first = None
+        o.n_cols_local = n_c
         if self.exchange_kind == 'allgather':       # columns index the gathered [P*R, d] matrix (equal blocks: identity)
             o.whole = self.compute.csr(rows, cols, self.N, part.padded)
             return o
@@ -669,6 +694,13 @@ class ShardedGraph:
             for k in range(K):
                 m = sl == k if K > 1 else slice(None)
                 o.halo.append(self.compute.csr(rr[m], slot[m], n_r, max(o.plan.n_halo_slice[k], 1)))
+            if merged_first_pass_enabled() and part.world > 1:
+                # Round 5: the interior pass and the FIRST halo slice as ONE pass over [local rows | slice-0 receive buffer] — when the exchanged
+                # matrix was allocated with room behind it (alloc_exchanged), slice 0 is received right there and one CSR with a single base
+                # pointer reads both: one pass over the running sums less per aggregation (the rank's own HBM traffic is what bounds P = 8)
+                m0 = sl == 0 if K > 1 else slice(None)
+                o.first = self.compute.csr(torch.cat([rows[~remote], rr[m0]]), torch.cat([ci, n_c + slot[m0]]), n_r,
+                                           n_c + max(o.plan.n_halo_slice[0], 1))
         elif dst is not None or src is not None:
             raise ValueError('compact level orientations need the overlapped exchange')
         else:
@@ -794,12 +826,14 @@ class ShardedGraph:
         _all_to_all_single(ext[plan.n_local:], send, plan.recv_counts_all, plan.send_counts_all, group=self.group)
         return ext
 
-    def _send_slice(self, x_local, plan, k):
-        """pack slice k -> asynchronous all-to-all.  Returns (receive buffer, work handle, send buffer kept alive)."""
+    def _send_slice(self, x_local, plan, k, recv=None):
+        """pack slice k -> asynchronous all-to-all.  Returns (receive buffer, work handle, send buffer kept alive).  recv: receive into this
+        [>= n_k, d] buffer (the room behind the exchanged matrix: merged first pass)."""
         bf16 = self.wire == 'bf16' and x_local.dtype == torch.float32
         send = plan.pack(self.compute, x_local, k, 'bf16' if bf16 else 'f32')
         n_k = plan.n_halo_slice[k]
-        recv = torch.empty((max(n_k, 1), x_local.shape[1]), dtype=send.dtype, device=x_local.device)
+        if recv is None or recv.dtype != send.dtype:
+            recv = torch.empty((max(n_k, 1), x_local.shape[1]), dtype=send.dtype, device=x_local.device)
         if send.dtype == torch.bfloat16:       # moves as bytes: not every backend knows bfloat16
             work = _all_to_all_single(recv[:n_k].view(torch.uint8), send.view(torch.uint8), plan.recv_counts[k], plan.send_counts[k],
                                       group=self.group, async_op=True)
@@ -811,16 +845,26 @@ class ShardedGraph:
         """Overlapped form, first half: for every slice k — produce(k, r0, r1) fills local rows [r0, r1) of x_local (if given: the
         layer GEMM / the trunk backward of row chunk k), then pack + asynchronous all-to-all of slice k, whose rows all lie in
         that chunk.  Returns the list of (receive buffer, work handle, send buffer) per slice."""
-        plan = (orient if orient is not None else (self.b if transpose else self.f)).plan
+        o = orient if orient is not None else (self.b if transpose else self.f)
+        plan = o.plan
         flights = []
         if self.exchange_log is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             self._xev0 = ev
+        # merged first pass: slice 0 lands in the room behind x_local (alloc_exchanged), [local rows | slice 0] is then ONE matrix for o.first
+        ext = None
+        n0 = plan.n_halo_slice[0]
+        if (o.first is not None and getattr(x_local, '_cb_room', 0) >= max(n0, 1) and x_local.dtype == torch.float32 and x_local.is_contiguous()
+                and x_local.shape[0] == o.n_cols_local and not (self.wire == 'bf16')):
+            d = x_local.shape[1]
+            ext = torch.as_strided(x_local, (x_local.shape[0] + max(n0, 1), d), (d, 1), x_local.storage_offset())
         for k in range(plan.n_slices):
             if produce is not None:
                 produce(k, *plan.chunks[k])
-            flights.append(self._send_slice(x_local, plan, k))
+            flights.append(self._send_slice(x_local, plan, k, recv=ext[x_local.shape[0]:] if (ext is not None and k == 0) else None))
+        if ext is not None:
+            flights[0] = flights[0] + (ext,)          # (recv, work, send, [local | slice 0])
         return flights
 
     def aggregate_start(self, h_local, transpose=False, produce=None, orient=None):
@@ -834,14 +878,31 @@ class ShardedGraph:
             return (h_local, None, orient)
         return (h_local, self.start_halo(h_local, transpose, produce, orient), orient)
 
-    def finish_halo(self, flights, o, part_sums, last_pass):
-        """Second half: halo pass k (raw sums, in place) as slice k arrives; last_pass(csr, recv, acc) is the caller's final pass
-        (it applies the epilogue and always runs, also over an empty last slice)."""
+    def finish_halo(self, flights, o, part_sums, last_pass, x_local=None):
+        """Second half: the interior pass (part_sums None: computed here from x_local — or, when slice 0 was received behind x_local, the
+        merged pass over [local | slice 0] once it has landed), then halo pass k (raw sums, in place) as slice k arrives;
+        last_pass(csr, recv, acc) is the caller's final pass (it applies the epilogue and always runs, also over an empty last slice; acc is
+        None when the merged pass IS the last one: a single-slice plan)."""
         c = self.compute
         K = len(flights)
         out = None
-        for k, (recv, work, _send) in enumerate(flights):
+        merged = len(flights[0]) > 3 and part_sums is None
+        if part_sums is None and not merged:
+            self.interior_passes += 1
+            part_sums = c.spmm(o.interior, x_local, profile=self.profile)       # raw sums over the local columns, overlaps the exchange
+        for k, fl in enumerate(flights):
+            recv, work = fl[0], fl[1]
             work.wait()
+            if merged and k == 0:
+                self.merged_passes += 1
+                if self.exchange_log is not None and K == 1:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    self.exchange_log.append((self._xev0, ev))
+                if K == 1:
+                    return last_pass(o.first, fl[3], None)
+                part_sums = c.spmm(o.first, fl[3], profile=self.profile)
+                continue
             if k == K - 1:
                 if self.exchange_log is not None:
                     ev = torch.cuda.Event(enable_timing=True)
@@ -863,10 +924,9 @@ class ShardedGraph:
                 raise ValueError('aggregate_finish: last_pass needs the overlapped exchange')
             return c.spmm(o.whole if o.whole is not None else self._whole(o), self.exchange(h_local, transpose, orient), row_scale, bias, relu,
                           profile=self.profile)
-        part = c.spmm(o.interior, h_local, profile=self.profile)             # raw sums over the local columns, overlaps the exchange
         if last_pass is None:
             last_pass = lambda g, recv, acc: c.spmm(g, recv, row_scale, bias, relu, acc_init=acc, profile=self.profile)      # noqa: E731
-        return self.finish_halo(flights, o, part, last_pass)
+        return self.finish_halo(flights, o, None, last_pass, x_local=h_local)
 
     def aggregate(self, h_local, transpose=False, row_scale=None, bias=None, relu=False):
         """act(row_scale * (A_block . h) + bias) for this rank's rows; h_local = this rank's rows of h."""

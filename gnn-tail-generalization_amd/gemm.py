@@ -137,7 +137,7 @@ def mm_nn_indrop(a, b, p, a_seed, row0=0, rowscale=None, addend=None, bias=None,
     return (y, bits) if want_bits else y
 
 
-def trunk_front(x, w_in, b_in, w0, rowscale, addend, p, seed_x, seed_x0, row0=0, want_bits=False, want_drop=False):
+def trunk_front(x, w_in, b_in, w0, rowscale, addend, p, seed_x, seed_x0, row0=0, want_bits=False, want_drop=False, z_out=None):
     """The forward front of the residual trunk in one kernel (cb_trunk_front_f32): X0 = relu(dropout_{seed_x}(x) @ w_in^T + b_in) and
     Z0 = rowscale * (dropout_{seed_x0}(X0) @ w0) + addend; dropout(X0) stays on chip unless want_drop.  Returns (x0, bits | None,
     x0_drop | None, z0), or None where the kernel does not exist for the shape (input width not 64 / 128, hidden width not 256,
@@ -162,7 +162,7 @@ def trunk_front(x, w_in, b_in, w0, rowscale, addend, p, seed_x, seed_x0, row0=0,
     nb0 = lib.cb_agg_gemm_image_bytes(256, 256)
     img0 = torch.empty(nb0, dtype=torch.uint8, device=dev)
     x0 = torch.empty((M, 256), dtype=torch.float32, device=dev)
-    z0 = torch.empty((M, 256), dtype=torch.float32, device=dev)
+    z0 = z_out if z_out is not None else torch.empty((M, 256), dtype=torch.float32, device=dev)      # (z_out: the caller's [M, 256] matrix, e.g. dist.alloc_exchanged)
     bits = torch.empty((M, 1, 4), dtype=torch.int64, device=dev) if want_bits else None
     xd = torch.empty((M, 256), dtype=torch.float32, device=dev) if want_drop else None
     with torch.cuda.device(dev):

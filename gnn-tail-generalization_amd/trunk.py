@@ -41,6 +41,15 @@ def eligible(tc, x, want_les):
             and tc.embedding_dropout == tc.dropout and tc.args.dropout == tc.dropout)
 
 
+def _exchanged(graph, n_rows, d=256):
+    """An [n_rows, d] fp32 matrix the next aggregation of `graph` will exchange: node-sharded, with room behind it for the first halo slice
+    (dist.alloc_exchanged: the interior pass and the first halo pass then are one); otherwise a plain matrix."""
+    if hasattr(graph, 'part'):
+        from .dist import alloc_exchanged
+        return alloc_exchanged(graph, n_rows, d)
+    return torch.empty((n_rows, d), dtype=torch.float32, device=graph.norm_in.device)
+
+
 def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False, produce=None, want_bits=True, relu_only=False):
     """(bits, out_next[, act]) of cb_spmm_csr_fused_f32 on the (possibly node-sharded) graph.  Node-sharded + overlapped:
     the exchange runs as the sliced pipeline of dist.ShardedGraph (produce(k, r0, r1), if given, fills rows [r0, r1) of z — the
@@ -51,9 +60,8 @@ def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False, produ
     sh = graph if hasattr(graph, 'part') else None
     if sh is not None and sh.overlap and z.dtype == torch.float32:
         flights = sh.start_halo(z, False, produce)
-        sh.f.interior.profile = getattr(graph, 'profile', None)
-        acc = sh.f.interior.spmm(z)
-        return sh.finish_halo(flights, sh.f, acc, lambda g, recv, a_: _fused_launch(lib, graph, g, recv, a_, bias, x0, c_act, c_mix, p, seed, want_act, want_bits, relu_only))
+        return sh.finish_halo(flights, sh.f, None, lambda g, recv, a_: _fused_launch(lib, graph, g, recv, a_, bias, x0, c_act, c_mix, p, seed, want_act, want_bits, relu_only),
+                              x_local=z)
     if produce is not None:
         produce(0, 0, z.shape[0])
     if sh is None:
@@ -77,7 +85,7 @@ def _fused_gemm_launch(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowsc
     plan = g._plan
     # (the evaluation form keeps the finished rows on chip: X_{l+1} goes to memory only as the hub rows' way into the tile)
     out_next = torch.empty((n, d), dtype=torch.float32, device=dev) if (want_bits or plan.n_hubs > 0) else None
-    z_next = torch.empty((n, 256), dtype=torch.float32, device=dev)
+    z_next = _exchanged(graph, n)          # (the next layer's aggregation exchanges it)
     act = torch.empty((n, d), dtype=torch.float32, device=dev) if want_act else None
     wsb = lib.cb_spmm_workspace_bytes(plan.n_chunks, d)
     ws = g._workspace(wsb)
@@ -118,10 +126,9 @@ def _fused_gemm(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowscale, g_
         return _fused_gemm_launch(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowscale, g_addend, want_bits, want_act=want_act, relu_only=relu_only)
     sh = graph
     flights = sh.start_halo(z, False)
-    sh.f.interior.profile = getattr(graph, 'profile', None)
-    acc = sh.f.interior.spmm(z)
-    return sh.finish_halo(flights, sh.f, acc, lambda g, recv, a_: _fused_gemm_launch(graph, recv, bias, x0, c_act, c_mix, p, seed, image, g_rowscale,
-                                                                                      g_addend, want_bits, g=g, acc=a_, want_act=want_act, relu_only=relu_only))
+    return sh.finish_halo(flights, sh.f, None, lambda g, recv, a_: _fused_gemm_launch(graph, recv, bias, x0, c_act, c_mix, p, seed, image, g_rowscale,
+                                                                                       g_addend, want_bits, g=g, acc=a_, want_act=want_act, relu_only=relu_only),
+                          x_local=z)
 
 
 def agg_gemm_eligible(graph, hidden, agg_bf16):
@@ -202,11 +209,11 @@ def _layer_bwd(g, bits, row_scale, gx0, accumulate, p, seed, row0, c_act, c_mix,
     return out, colsum
 
 
-def _layer_bwd_rows(g_c, rows_idx, bits, row_scale, p, seed, row0, c_act, want_colsum):
+def _layer_bwd_rows(g_c, rows_idx, bits, row_scale, p, seed, row0, c_act, want_colsum, out=None):
     """_layer_bwd over the compact rows rows_idx of a row-sparse backward (cb_trunk_layer_bwd_rows_f32): (b * dY' of those rows, dbias)."""
     lib = _lib.load()
     n_c, d = g_c.shape
-    out = torch.empty_like(g_c)
+    out = torch.empty_like(g_c) if out is None else out
     colsum = torch.empty(d, dtype=torch.float32, device=g_c.device) if want_colsum else None
     wsb = lib.cb_colsum_workspace_bytes(n_c, d) if want_colsum else 0
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=g_c.device)
@@ -328,7 +335,8 @@ class _TrunkFn(torch.autograd.Function):
         if (indrop or p == 0) and not agg_bf16 and L >= 1 and w_in.shape[0] == 256 and os.environ.get('CB_TRUNK_FRONT', '1') != '0':
             w0_, _b0, le0_ = layer_params[0:3]
             want_copy = bwd and p > 0 and os.environ.get('CB_TRUNK_X0_COPY', '1') == '1'
-            fr = gemm.trunk_front(x, w_in, b_in, w0_, a, le0_, p, seeds[0], seeds[1], row0, want_bits=bwd, want_drop=want_copy)
+            fr = gemm.trunk_front(x, w_in, b_in, w0_, a, le0_, p, seeds[0], seeds[1], row0, want_bits=bwd, want_drop=want_copy,
+                                  z_out=_exchanged(graph, x.shape[0]) if hasattr(graph, 'part') else None)
             if fr is not None:
                 x0, x0_bits, cur, z_front = fr
                 fused_in = True
@@ -375,12 +383,14 @@ class _TrunkFn(torch.autograd.Function):
                 z0 = z_front
             elif l == 0 and cur is None:      # layer 0 with no dropped copy of X0: its GEMM draws the mask while it stages X0
                 # (l > 0 with cur None: a forward that no backward follows — the activations stayed on chip and Z_l is in z_ready)
-                z0 = None if (agg_bf16 or (not ag and _chunked(graph, agg_bf16))) else gemm.mm_nn_indrop(x0, w, p, seeds[1], row0, rowscale=a, addend=le)
+                z0 = None if (agg_bf16 or (not ag and _chunked(graph, agg_bf16))) else gemm.mm_nn_indrop(x0, w, p, seeds[1], row0, rowscale=a, addend=le,
+                                                                                                         out=_exchanged(graph, x0.shape[0], w.shape[1]))
                 if z0 is None:
                     cur = saved_in[0] = dropped_x0()
             if ag:
                 from .graph import weight_image
-                z = z_ready if z_ready is not None else z0 if z0 is not None else gemm.mm_nn(cur, w, rowscale=a, addend=le)
+                z = (z_ready if z_ready is not None else z0 if z0 is not None
+                     else gemm.mm_nn(cur, w, rowscale=a, addend=le, out=_exchanged(graph, cur.shape[0], w.shape[1])))
                 z_ready = None
                 if l + 1 < L:     # this layer's store + the next layer's transform in one kernel
                     w1, _, le1 = layer_params[3 * (l + 1): 3 * (l + 1) + 3]
@@ -530,6 +540,7 @@ class _Backward:
             return g_, gr_, db_, h_
         g_ = g_ready if g_ready is not None else gemm.mm_nn(src, wt, rowscale=rowscale)
         gr_, db_ = _layer_bwd(g_, bits, bnorm, self.gx0, below != self.L - 1, p, sd, row0, 1 - alpha, alpha, want_b, out_bf16=self.agg_bf16,
+                              out=_exchanged(self.graph, g_.shape[0], g_.shape[1]) if (self.sharded and not self.agg_bf16) else None,
                               **self._second(below, g_above))
         return g_, gr_, db_, None
 
@@ -543,7 +554,8 @@ class _Backward:
             self.d_w_out = gemm.mm_tn(gout_c, xl_c) if need[5] else None
             self.d_b_out = ops.act_bwd(gout_c, None, None, want_out=False, want_colsum=True)[1] if need[6] else None
             g = gemm.mm_nn(gout_c, w_out)                                        # dL/d(dropped X_L), loss rows only
-            gr, dbias = _layer_bwd_rows(g, space.idx, self.saved_bits[L - 1], self.bnorm, self.p, self.seed(L + 1), self.row0, 1 - self.alpha, self.need_b(L - 1))
+            gr, dbias = _layer_bwd_rows(g, space.idx, self.saved_bits[L - 1], self.bnorm, self.p, self.seed(L + 1), self.row0, 1 - self.alpha, self.need_b(L - 1),
+                                        out=_exchanged(self.graph, g.shape[0], g.shape[1]) if self.sharded else None)
             return g, gr, dbias, None, space
         self.d_w_out = gemm.mm_tn(gout, xl) if need[5] else None
         self.d_b_out = ops.act_bwd(gout, None, None, want_out=False, want_colsum=True)[1] if need[6] else None
@@ -702,7 +714,8 @@ class _Backward:
             space = dst
             if l > 0 and dst is not None:      # the store backward of layer l-1 on the rows of S_{j+1}
                 g = g_new
-                gr, dbias = _layer_bwd_rows(g, dst.idx, self.saved_bits[l - 1], self.bnorm, p, self.seed(l + 1), self.row0, 1 - alpha, self.need_b(l - 1))
+                gr, dbias = _layer_bwd_rows(g, dst.idx, self.saved_bits[l - 1], self.bnorm, p, self.seed(l + 1), self.row0, 1 - alpha, self.need_b(l - 1),
+                                            out=_exchanged(graph, g.shape[0], g.shape[1]) if sharded else None)
             elif l > 0 and tb_next is not None:
                 g, (gr, dbias) = g_new, tb_next
             elif l > 0:      # dL/d(dropped X_l) and the backward of layer l-1's store

@@ -264,6 +264,65 @@ def test_row_sparse_level_orientations_match_the_full_reverse_exchange(name, wor
     _run(_support_worker, world, name, cover, n_slices)
 
 
+def _merged_worker(rank, world, port, name, q, cover, n_slices):
+    """Round 5: the interior pass and the first halo slice as ONE pass (dist._Orientation.first): a matrix allocated with room behind it
+    (dist.alloc_exchanged) receives slice 0 right there; forward, reverse and compact-level aggregations equal the two-pass form's — whose
+    matrix has no room — within summation order, with a fused-epilogue last pass (row scale, bias, ReLU) and when the merged pass IS the last one."""
+    _setup(rank, world, port)
+    try:
+        import coldbrew_oracle as orc
+        from dist_cpu_compute import OracleCompute
+        from gnn_tail_generalization_amd import dist as cbdist
+        g = load_golden(name)
+        n, ei = g['cfg']['N_nodes'], g['edge_index']
+        csr = orc.build_csr(ei, n)
+        part = cbdist.Partition.balanced(torch.from_numpy(csr.in_deg), world, rank, node_weight=2)
+        sg = cbdist.ShardedGraph(ei, n, part, exchange='halo', overlap=True, compute=OracleCompute(), n_slices=n_slices, cover=cover)
+        assert sg.f.first is not None and sg.halo_room >= 1
+        assert sg.f.first.E == sg.f.interior.E + sg.f.halo[0].E and sg.f.first.n_cols == part.n_local + max(sg.f.plan.n_halo_slice[0], 1)
+        gen = torch.Generator().manual_seed(5)
+        h = torch.randn(n, 6, generator=gen)
+        hl = part.slice_rows(h).contiguous()
+        bias = torch.randn(6, generator=gen)
+        for transpose in (False, True):
+            ref = sg.aggregate(hl, transpose, sg.norm_in, bias, True)                     # two passes: hl has no room behind it
+            m = cbdist.alloc_exchanged(sg, part.n_local, 6, device='cpu')
+            assert getattr(m, '_cb_room', 0) == sg.halo_room
+            m.copy_(hl)
+            flights = sg.start_halo(m, transpose)
+            assert len(flights[0]) == 4 and flights[0][0].data_ptr() == m.data_ptr() + m.numel() * 4      # slice 0 lands right behind the local rows
+            o = sg.b if transpose else sg.f
+            c = sg.compute
+            got = sg.finish_halo(flights, o, None, lambda gg, recv, acc: c.spmm(gg, recv, sg.norm_in, bias, True, acc_init=acc), x_local=m)
+            torch.testing.assert_close(got, ref, atol=1e-5, rtol=1e-5)
+            torch.testing.assert_close(m, hl, atol=0, rtol=0)                              # the local rows are untouched
+        # a compact level of the row-sparse backward through the merged pass
+        mask = torch.rand(n, generator=gen) < 0.1
+        mask[0] = True
+        mask_l = part.slice_rows(mask).contiguous()
+        levels = sg.support_levels(mask_l, 3, max_edge_frac=0.97, compact=True, max_frac=0.95)
+        if levels and levels[0].src is not None:
+            lv = levels[0]
+            hs = part.slice_rows(h * mask.float().unsqueeze(1)).contiguous()
+            full = sg.aggregate(hs, True)
+            m = cbdist.alloc_exchanged(sg, lv.src.n, 6, device='cpu')
+            m.copy_(hs[lv.src.idx])
+            got = sg.aggregate_finish(sg.aggregate_start(m, True, orient=lv.orient), True)
+            torch.testing.assert_close(got, full[lv.dst.idx] if lv.dst is not None else full, atol=1e-5, rtol=1e-5)
+        q.put((rank, 'ok'))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, 'FAIL ' + traceback.format_exc()[-1500:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name,world,cover,n_slices', [('case_graph_powerlaw_d7_d64', 2, False, 3), ('case_graph_powerlaw_d7_d64', 3, 'force', 2),
+                                                        ('case_graph_asym_multi', 2, False, 1), ('case_graph_asym_multi', 3, 'force', 1)])
+def test_interior_and_first_slice_as_one_pass(name, world, cover, n_slices):
+    _run(_merged_worker, world, name, cover, n_slices)
+
+
 def _decision_worker(rank, world, port, _unused, q):
     _setup(rank, world, port)
     try:

@@ -84,6 +84,10 @@ def _worker(rank, world, port, exchange, overlap, partition, argv, q, wire='f32'
             assert (lv0.src is not None) == bool(trunk.agg_gemm_eligible(t.sgraph, 256, False)), 'compact levels not used where the plan allows them'
             if lv0.src is not None:
                 assert 0 < lv0.src.n < t.part.n_local
+        if overlap == '1' and exchange == 'halo' and wire == 'f32' and (argv is ARGV or '--whetherHasSE=111' in argv):
+            # round 5: the trunk allocates the matrices it exchanges with room behind them (dist.alloc_exchanged), so the interior pass and the first
+            # halo slice ran as ONE pass ([local | slice 0], dist._Orientation.first) wherever a producer of the trunk wrote the matrix
+            assert t.sgraph.merged_passes > 0, (t.sgraph.merged_passes, t.sgraph.interior_passes)
         accs = t.run_testSet()
         w = t.teacherGNN.model.model.layers_GCN[1].weight.detach().cpu()
         le = conv0.le.detach().cpu() if conv0.whetherHasSE else torch.zeros(1)

@@ -119,6 +119,13 @@ def main():
     ap.add_argument('--support-level', type=int, default=-1,
                     help='j >= 0: probe level j of the row-sparse backward (dist.ShardedGraph.support_orients): only the edges whose gathered row lies in the '
                          'support S_j of the stand-in\'s train mask (S_0 = train rows, S_{j+1} = rows with a neighbour in S_j); the partition stays the full graph\'s')
+    ap.add_argument('--compact', type=int, default=0,
+                    help='with --support-level j: the level COMPACT in the rank\'s rows as dist.ShardedGraph.support_levels builds it (round 5) — the rank reads '
+                         'a [|S_j in block|, d] matrix and writes [|S_{j+1} in block|, d] (all rows when S_{j+1} exceeds 70 %% of the nodes): CSR rows / interior '
+                         'columns / send lists renumbered, last pass, store backward and packs timed at those shapes')
+    ap.add_argument('--merged', type=int, default=1,
+                    help='cover pipeline: 1 = the interior pass and the first halo slice as ONE pass over [local | slice 0] (dist._Orientation.first, round 5); '
+                         '0 = two passes (round 4)')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     data = synthetic_data(a.name, seed=0, device=dev)
@@ -135,7 +142,15 @@ def main():
         print(f'support level {a.support_level}: |S| = {float(S.float().mean()):.3f} N, {float(keep.float().mean()):.3f} of the edges kept', flush=True)
         src, dst = src[keep], dst[keep]
         E = int(src.numel())
-        del S, keep
+        S_src, S_dst = None, None
+        if a.compact:
+            S_src = S
+            nxt = torch.zeros_like(S)
+            nxt[dst] = True
+            share = float(nxt.float().mean())
+            S_dst = nxt if share <= 0.7 else None
+            print(f'compact level: reads |S_j| = {float(S.float().mean()):.3f} N rows, writes ' + (f'|S_j+1| = {share:.3f} N rows' if S_dst is not None else f'all rows (|S_j+1| = {share:.3f} N)'), flush=True)
+        del keep
     del data
     comp = cbdist.HipCompute()
     K, d, L = max(1, a.slices), 256, a.layers
@@ -152,13 +167,23 @@ def main():
         rr, cc = dst[m] - lo, src[m]
         del m
         remote = (cc < lo) | (cc >= hi)
-        row = {'P': P, 'rank': r, 'rows_local': n_local, 'edges_local': int(rr.numel()), 'edges_remote': int(remote.sum()), 'slices': K}
-        h = torch.rand(n_local, d, device=dev)
+        # compact level (--compact): rows renumbered to positions in S_{j+1} of this block, local columns to positions in S_j of this block
+        n_src_l, col_pos = n_local, None
+        if a.support_level >= 0 and a.compact:
+            col_pos = torch.cumsum(S_src[lo:hi], 0) - 1
+            n_src_l = max(int(S_src[lo:hi].sum()), 1)
+            if S_dst is not None:
+                row_pos = torch.cumsum(S_dst[lo:hi], 0) - 1
+                rr = row_pos[rr]
+                n_full, n_local = n_local, max(int(S_dst[lo:hi].sum()), 1)      # (from here on n_local = the rows this rank WRITES)
+        row = {'P': P, 'rank': r, 'rows_local': n_local, 'rows_read': n_src_l, 'edges_local': int(rr.numel()), 'edges_remote': int(remote.sum()), 'slices': K}
+        h = torch.rand(n_src_l, d, device=dev)
         scale = torch.rand(n_local, device=dev)
         bias = torch.rand(d, device=dev)
         w = torch.rand(d, d, device=dev) * 0.06
         x0 = torch.rand(n_local, d, device=dev)
-        g_int = comp.csr(rr[~remote], cc[~remote] - lo, n_local, n_local)
+        ci_ = cc[~remote] - lo
+        g_int = comp.csr(rr[~remote], col_pos[ci_] if col_pos is not None else ci_, n_local, n_src_l)
         row['edges_interior'] = g_int.E
         if P == 1:
             img = weight_image(w)
@@ -285,7 +310,7 @@ def main():
                 for k in range(K):
                     send[k][q] = int(cuts[k + 1] - cuts[k])
                 s_rows.append(it - cuts[k_of])
-                s_cols.append(u[keep])
+                s_cols.append(col_pos[u[keep]] if col_pos is not None else u[keep])
                 s_slice.append(k_of)
                 s_owner.append(torch.full_like(it, q))
             s_rows, s_cols, s_slice, s_owner = (torch.cat(t_) for t_ in (s_rows, s_cols, s_slice, s_owner))
@@ -297,12 +322,24 @@ def main():
                             'send_rows': sum(n_send), 'max_link_rows': sum(link_rows), 'halo_edges': int(e_rows.numel()), 'send_edges': int(s_rows.numel())}
             if not a.halo_only:
                 g_halo = [comp.csr(e_rows[e_slice == k], e_slot[e_slice == k], n_local, max(n_k[k], 1)) for k in range(K)]
-                g_send = [comp.csr(s_rows[s_slice == k], s_cols[s_slice == k], max(n_send[k], 1), n_local) for k in range(K)]
+                g_first = None
+                if a.merged and K > 1:
+                    m0_ = e_slice == 0
+                    g_first = comp.csr(torch.cat([rr[~remote], e_rows[m0_]]), torch.cat([col_pos[ci_] if col_pos is not None else ci_, n_src_l + e_slot[m0_]]),
+                                       n_local, n_src_l + max(n_k[0], 1))
+                g_send = [comp.csr(s_rows[s_slice == k], s_cols[s_slice == k], max(n_send[k], 1), n_src_l) for k in range(K)]
                 del e_rows, e_slot, e_slice, e_owner, s_rows, s_cols, s_slice, s_owner, e_slot_local
                 t_pack = [timed(lambda k=k: g_send[k].spmm(h)) for k in range(K)]
                 halos = [torch.rand(max(n_k[k], 1), d, device=dev) for k in range(K)]
                 acc = g_int.spmm(h)
                 t_pass = [timed(lambda k=k: g_halo[k].spmm(halos[k], acc_init=acc, out=acc)) for k in range(K - 1)]
+                t_int_cover = t_int
+                if g_first is not None:      # merged: no interior pass of its own; the first pass waits for slice 0 and covers both
+                    ext = torch.cat([h, halos[0]])
+                    t_first = timed(lambda: g_first.spmm(ext, out=acc))
+                    row['merged_first_pass_ms'], row['interior_plus_pass0_ms'] = t_first, t_int + t_pass[0]
+                    t_pass[0], t_int_cover = t_first, 0.0
+                    del ext
                 gl = g_halo[K - 1]
                 gl.norm_in, gl.row_offset = scale, 0
                 img, img_t = weight_image(w), weight_image(w, transpose=True)
@@ -321,7 +358,7 @@ def main():
                 zero = [0.0] * K
 
                 def exposed(last_ms):
-                    return pipeline(zero, t_pack, t_link, t_int, t_pass + [last_ms - last['clone_only']])
+                    return pipeline(zero, t_pack, t_link, t_int_cover, t_pass + [last_ms - last['clone_only']])
                 # forward: layers 0 .. L-2 store + next GEMM, layer L-1 store only; backward: every layer the dX tail; the trunk backward of the
                 # layer below stays a pass of its own (its time is part of --dense-cover-ms; in the tail's epilogue it measures slower:
                 # 'reverse_gemm_trunkbwd' against 'reverse_gemm' + t_trunk_bwd)
