@@ -402,7 +402,7 @@ class _TrunkFn(torch.autograd.Function):
                     bits, cur, act = _fused_spmm(graph, z, b, mix, 1 - alpha, alpha, p, sd_l, want_bits=bwd, relu_only=residual)
             elif z0 is None and _chunked(graph, agg_bf16):
                 # node-sharded pipeline: row chunk k of Z leaves the GEMM, is packed and put on the links while chunk k+1 multiplies
-                z = torch.empty((cur.shape[0], w.shape[1]), dtype=torch.float32, device=cur.device)
+                z = _exchanged(graph, cur.shape[0], w.shape[1])
 
                 def produce(k, r0, r1, cur=cur, w=w, le=le, z=z):
                     if r1 > r0:
@@ -410,7 +410,8 @@ class _TrunkFn(torch.autograd.Function):
                 bits, cur, act = _fused_spmm(graph, z, b, mix, 1 - alpha, alpha, p, sd_l, want_act=keep_act, produce=produce, want_bits=bwd,
                                              relu_only=residual)
             else:
-                z = z0 if z0 is not None else gemm.mm_nn(cur, w, rowscale=a, addend=le, out_bf16=agg_bf16)
+                z = z0 if z0 is not None else gemm.mm_nn(cur, w, rowscale=a, addend=le, out_bf16=agg_bf16,
+                                                         out=None if agg_bf16 else _exchanged(graph, cur.shape[0], w.shape[1]))
                 bits, cur, act = _fused_spmm(graph, z, b, mix, 1 - alpha, alpha, p, sd_l, want_act=keep_act, want_bits=bwd, relu_only=residual)
             del z, z0
             z_front = None
@@ -520,7 +521,7 @@ class _Backward:
         bits = self.saved_bits[below]
         if self.chunked:
             g_ = torch.empty((src.shape[0], wt.shape[1]), dtype=torch.float32, device=src.device)
-            gr_ = torch.empty_like(g_)
+            gr_ = _exchanged(self.graph, g_.shape[0], g_.shape[1])
             colsums = []
             sec = self._second(below, g_above)
 
