@@ -39,7 +39,7 @@ class Tuning:
 
     # ---- node-sharded exchange (dist.py) --------------------------------------------------------------------------------------------------
     # one node's dense work (GEMMs, elementwise) ~ this many edges' aggregation work per step: the edge-balanced partition's node weight.
-    # S-pl10M kernel profile
+    # S-pl10M kernel profile (HISTORY.md section 6)
     node_weight: int = 12
     # a rank pair leaves the plain pull for the push / pull cover only for >= this share fewer rows (a pushed row costs its owner an
     # aggregation over the edges it sums).  S-pl10M: 25 - 32 % fewer rows (cover); the ogbn-products shape: < 6 % (pull)
