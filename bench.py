@@ -411,6 +411,8 @@ KERNEL_OF = {'plain': 'k_spmm_rows (+hub kernels)', 'colscale': 'k_spmm_rows<col
              'agg_gemm': 'k_agg_gemm2<false> (+hub kernels): aggregation + the dX 256x256 contraction on the matrix cores in one kernel',
              'agg_gemm_fused': 'k_agg_gemm2<true> (+hub kernels): aggregation with the trunk store + the next 256x256 dense transform on the matrix cores in one kernel',
              'agg_gemm_fused_eval': 'k_agg_gemm2<true> evaluation form (+hub kernels)',
+             'agg_gemm_head': 'k_agg_gemm2<true, narrow> (+hub kernels): last layer store + the output Linear (256 x C) in one kernel',
+             'agg_gemm_head_eval': 'k_agg_gemm2<true, narrow> evaluation form (+hub kernels)',
              'agg_gemm_trunkbwd': 'k_agg_gemm2<TB> (+hub kernels)'}
 
 

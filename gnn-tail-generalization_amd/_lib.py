@@ -102,6 +102,14 @@ SIGNATURES = {
     'cb_spmm_gemm_fused_eval_f32': (ctypes.c_int, [_P, _I64, _P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,
                                                    ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _I32, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _SZ,
                                                    _P, _P, _P, _I64, _P, _I64, _P]),
+    'cb_agg_gemm_head_image_bytes': (_SZ, [_I64, _I64]),
+    'cb_agg_gemm_head_image_f32': (ctypes.c_int, [_P, _I64, _I64, _I64, ctypes.c_int, _P, _SZ, _P]),
+    'cb_spmm_gemm_fused_head_f32': (ctypes.c_int, [_P, _I64, _P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,
+                                                   ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _I32, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _SZ,
+                                                   _P, _P, _I64, _P, _I64, _P]),
+    'cb_spmm_gemm_fused_head_eval_f32': (ctypes.c_int, [_P, _I64, _P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,
+                                                   ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _I32, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _SZ,
+                                                   _P, _P, _I64, _P, _I64, _P]),
     'cb_spmm_gemm_trunkbwd_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _SZ, _P, _P,
                                                  _P, _I64, _P, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _P, _I64, _P, _P, _SZ, _P]),
     'cb_spmm_csr_weighted_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_int, _P, _I64, _P]),

@@ -55,6 +55,9 @@ struct GemmTail {
   int64_t ld_out2;
   float* colsum_partial;   // [gridDim.x][256] or null
   int* err;                // device-visible error word (cb_error.hip): a tile hand-over that timed out is recorded here, never silent
+  // NARROW kernels only (the output Linear as the tail of the last layer's aggregation, GCN.py:133-138): out[m][n] = acc + bias[n], n < n_out <= 64
+  const float* bias;       // [n_out] or null
+  int n_out;
 };
 
 // (declared in cb_tile_gemm.h)
@@ -68,6 +71,26 @@ __global__ void __launch_bounds__(256) k_weight_image(const float* __restrict__ 
   for (int e = 0; e < 4; ++e)
     split3x2(W[(int64_t)(k0 + 2 * e) * sk + (int64_t)n * sn], W[(int64_t)(k0 + 2 * e + 1) * sk + (int64_t)n * sn], h[e], m[e], l[e]);
   uint4* o = image + ((int64_t)(s * kNT + j) * 3) * 64 + lane;
+  o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+  o[64] = make_uint4(m[0], m[1], m[2], m[3]);
+  o[128] = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// B[k][n] = W[k * sk + n * sn] for n < n_cols, zero beyond: the narrow image (kNTn = 2 column blocks) of a 256 x C weight, C <= 64
+__global__ void __launch_bounds__(256) k_weight_image_narrow(const float* __restrict__ W, int64_t sk, int64_t sn, uint4* __restrict__ image, int n_steps,
+                                                             int n_cols) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int lane = idx & 63, sj = idx >> 6, j = sj % kNTn, s = sj / kNTn;
+  if (s >= n_steps) return;
+  const int k0 = 16 * s + 8 * (lane >> 5), n = 32 * j + (lane & 31);
+  uint32_t h[4], m[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float w0 = n < n_cols ? W[(int64_t)(k0 + 2 * e) * sk + (int64_t)n * sn] : 0.f;
+    const float w1 = n < n_cols ? W[(int64_t)(k0 + 2 * e + 1) * sk + (int64_t)n * sn] : 0.f;
+    split3x2(w0, w1, h[e], m[e], l[e]);
+  }
+  uint4* o = image + ((int64_t)(s * kNTn + j) * 3) * 64 + lane;
   o[0] = make_uint4(h[0], h[1], h[2], h[3]);
   o[64] = make_uint4(m[0], m[1], m[2], m[3]);
   o[128] = make_uint4(l[0], l[1], l[2], l[3]);
@@ -227,7 +250,41 @@ __device__ __forceinline__ void ag2_mfma_tile(int t, const float* __restrict__ t
     }
 }
 
-template <bool FUSED, int GP, bool ACC, bool TB>
+// NARROW tail: multiplying wavefront w takes the 32 x 32 block (rows 32 (w & 1), columns 32 (w >> 1)) of the tile's 64 x 64 output = the
+// logits of 64 rows (C <= 64 classes): out = acc + bias, the epilogue expression of cb_gemm_nn_f32 with a bias and neither row scale nor addend.
+__device__ __forceinline__ void ag2_mfma_tile_head(int t, const float* __restrict__ tile, float* __restrict__ cs, int w, int lane, int n_rows,
+                                                   const GemmTail& gt, int* freed) {
+  const int l31 = lane & 31, lh = lane >> 5, bi = w & 1, bj = w >> 1;
+  f32x16 acc;
+  tile_times_image_block<kNS, kTLD>(tile, gt.image, bi, bj, lane, acc);
+  ag_signal(freed, lane);      // the tile has been read for the last time
+  const int r0 = t * kTM + 32 * bi;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {      // 8 rows x 32 columns per pass through the wave-private strip
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) cs[(r4 + 4 * lh) * kCLD + l31] = acc[4 * q + r4];
+    const int row = lane >> 3, c4 = (lane & 7) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(cs + row * kCLD + c4);
+    const int64_t m = r0 + 8 * q + row;
+    const int n = 32 * bj + c4;
+    if (m < n_rows && n < gt.n_out) {
+      const float zero_add = 0.f;
+      float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = o[e] * 1.f + zero_add + ((gt.bias && n + e < gt.n_out) ? gt.bias[n + e] : 0.f);
+      float* dst = gt.out + m * gt.ld_out + n;
+      if (n + 4 <= gt.n_out && (gt.ld_out & 3) == 0) {
+        store_stream<4>(dst, o);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < gt.n_out) dst[e] = o[e];
+      }
+    }
+  }
+}
+
+template <bool FUSED, int GP, bool ACC, bool TB, bool NARROW = false>
 __global__ void __launch_bounds__(64 * (kNG + 4), (kNG + 4) / 4) k_agg_gemm2(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                                             const float* __restrict__ h, int64_t ld_h, float* __restrict__ out,
                                                                             int64_t ld_out, int n_rows, Epilogue ep, int hub_T, FusedEpi fe,
@@ -254,7 +311,8 @@ __global__ void __launch_bounds__(64 * (kNG + 4), (kNG + 4) / 4) k_agg_gemm2(con
     for (int it = 0; it < n_it; ++it) {
       const int b = it & 1, use = it >> 1;
       ag_wait(&ready[b], kNG * (use + 1), gt.err);
-      ag2_mfma_tile<TB>(blockIdx.x + it * gridDim.x, tiles[b], cstrip[w], w, lane, n_rows, gt, colsum, seed_eff, &freed[b]);
+      if constexpr (NARROW) ag2_mfma_tile_head(blockIdx.x + it * gridDim.x, tiles[b], cstrip[w], w, lane, n_rows, gt, &freed[b]);
+      else ag2_mfma_tile<TB>(blockIdx.x + it * gridDim.x, tiles[b], cstrip[w], w, lane, n_rows, gt, colsum, seed_eff, &freed[b]);
     }
   }
   if constexpr (TB) {
@@ -336,12 +394,19 @@ static int launch_agg_gemm(const int32_t* rowptr, const int32_t* col, int64_t N,
   const dim3 grid((unsigned)ag_n_blocks(n_tiles)), block(64 * (kNG + 4));
 #define CB_AG2(GP_, TB_) \
   hipLaunchKernelGGL((k_agg_gemm2<FUSED, GP_, ACC, TB_>), grid, block, 0, st, rowptr, col, h, ld_h, out, ld_out, (int)N, ep, hub_T, fe, gt, n_tiles)
-  bool tb = false;
+  bool tb = false, narrow = false;
   if constexpr (!FUSED) tb = gt.out2 != nullptr;      // + the trunk backward of the layer below in the dense tail's epilogue
   if constexpr (!FUSED) {
     if (tb) { if (ep.col_flags) CB_AG2(2, true); else CB_AG2(0, true); }
   }
-  if (!tb) { if (ep.col_flags) CB_AG2(2, false); else CB_AG2(0, false); }
+  if constexpr (FUSED) {      // the output Linear (<= 64 classes) as the tail: gt.n_out > 0
+    narrow = gt.n_out > 0;
+    if (narrow) {
+      if (ep.col_flags) hipLaunchKernelGGL((k_agg_gemm2<true, 2, ACC, false, true>), grid, block, 0, st, rowptr, col, h, ld_h, out, ld_out, (int)N, ep, hub_T, fe, gt, n_tiles);
+      else hipLaunchKernelGGL((k_agg_gemm2<true, 0, ACC, false, true>), grid, block, 0, st, rowptr, col, h, ld_h, out, ld_out, (int)N, ep, hub_T, fe, gt, n_tiles);
+    }
+  }
+  if (!tb && !narrow) { if (ep.col_flags) CB_AG2(2, false); else CB_AG2(0, false); }
 #undef CB_AG2
   CB_LAUNCH_CHECK();
   return CB_OK;
@@ -472,9 +537,10 @@ static int spmm_gemm_fused_impl(int skip_next, const float* acc_init, int64_t ld
                                 const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, int32_t bits_relu_only, float* out_act, int64_t ld_act,
                                 float* out_next, int64_t ld_next, int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,
                                 size_t ws_bytes, const void* image, const float* g_rowscale, const float* g_addend, int64_t ld_add,
-                                float* g_out, int64_t ld_gout, void* stream) {
+                                float* g_out, int64_t ld_gout, void* stream, const float* head_bias = nullptr, int n_out = 0) {
+  // (n_out > 0: the narrow tail — g_out = logits [N, ld_gout >= n_out]; the common checks see a stand-in leading dimension)
   const int rc = agg_gemm_common_checks("cb_spmm_gemm_fused_f32", N, E, d, rowptr, col, h, ld_h, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr,
-                                        ws, ws_bytes, image, g_addend, ld_add, g_out, ld_gout, acc_init, ld_init);
+                                        ws, ws_bytes, image, g_addend, ld_add, g_out, n_out > 0 ? kND : ld_gout, acc_init, ld_init);
   if (rc != CB_OK || N == 0) return rc;
   // (the evaluation form writes out_next for hub rows only: without a hub plan it may be NULL)
   CB_CHECK_ARG((out_next || (skip_next && n_hubs == 0)) && ag_al16(out_next) && ld_next % 4 == 0 && ld_next >= d &&
@@ -491,6 +557,7 @@ static int spmm_gemm_fused_impl(int skip_next, const float* acc_init, int64_t ld
   fe.out_act = out_act; fe.ld_act = ld_act; fe.out_next = out_next; fe.ld_next = ld_next; fe.d = (int)d;
   fe.skip_next = skip_next;
   GemmTail gt{(const uint4*)image, g_rowscale, g_addend, ld_add, g_out, ld_gout};
+  gt.bias = head_bias; gt.n_out = n_out;
   if (acc_init)
     return launch_agg_gemm<true, true>(rowptr, col, N, h, ld_h, ep, out_next, ld_next, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, (float*)ws,
                                        (hipStream_t)stream, fe, gt);
@@ -516,3 +583,50 @@ extern "C" int cb_spmm_gemm_fused_f32(CB_SGF_PARAMS) { return spmm_gemm_fused_im
 extern "C" int cb_spmm_gemm_fused_eval_f32(CB_SGF_PARAMS) { return spmm_gemm_fused_impl(1, CB_SGF_ARGS); }
 #undef CB_SGF_PARAMS
 #undef CB_SGF_ARGS
+
+// ---- the output Linear as the tail of the LAST layer's aggregation (round 5; GCN.py:133-138: Linear(dropout(X_L)) on the rows the store just made) ----
+extern "C" size_t cb_agg_gemm_head_image_bytes(int64_t K, int64_t C) {
+  if (K != kKD || C < 1 || C > 32 * kNTn) return 0;
+  return (size_t)kNS * kNTn * 3 * 64 * sizeof(uint4);
+}
+
+// image of B = W^T for an nn.Linear weight W [C, 256] (transpose = 1) or of B = W [256, C] (transpose = 0); columns C .. 63 are zero
+extern "C" int cb_agg_gemm_head_image_f32(const float* W, int64_t ld, int64_t K, int64_t C, int transpose, void* image, size_t image_bytes, void* stream) {
+  CB_CHECK_ARG(cb_agg_gemm_head_image_bytes(K, C) > 0, CB_E_INVALID, "cb_agg_gemm_head_image_f32: K must be 256 and 1 <= C <= 64 (got %lld x %lld)", (long long)K,
+               (long long)C);
+  CB_CHECK_ARG(W && image && ld >= (transpose ? K : C), CB_E_INVALID, "cb_agg_gemm_head_image_f32: null pointer / bad leading dimension");
+  CB_CHECK_ARG(image_bytes >= cb_agg_gemm_head_image_bytes(K, C) && ag_al16(image), CB_E_WORKSPACE, "cb_agg_gemm_head_image_f32: image buffer too small or misaligned");
+  const int64_t sk = transpose ? 1 : ld, sn = transpose ? ld : 1;
+  hipLaunchKernelGGL(k_weight_image_narrow, dim3(kNS * kNTn * 64 / 256), dim3(256), 0, (hipStream_t)stream, W, sk, sn, (uint4*)image, kNS, (int)C);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
+#define CB_SGH_PARAMS                                                                                                                              \
+  const float *acc_init, int64_t ld_init, const int32_t *rowptr, const int32_t *col, int32_t col_flags, int64_t N, int64_t E, const float *h,      \
+      int64_t ld_h, int64_t d, const float *row_scale, const float *bias, const float *mix_src, int64_t ld_mix, float c_act, float c_mix,          \
+      float drop_p, uint64_t seed, const uint64_t *seed_dev, int64_t row0, uint64_t *relu_bits, int32_t bits_relu_only, float *out_act,          \
+      int64_t ld_act, float *out_next, int64_t ld_next, int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t *hub_rows,                \
+      const int32_t *hub_chunk_ptr, void *ws, size_t ws_bytes, const void *head_image, const float *head_bias, int64_t C, float *logits,          \
+      int64_t ld_logits, void *stream
+static int spmm_gemm_head_impl(int skip_next, CB_SGH_PARAMS) {
+  CB_CHECK_ARG(C >= 1 && C <= 32 * kNTn && (N == 0 || (logits && ld_logits >= C)), CB_E_INVALID, "cb_spmm_gemm_fused_head_f32: 1 <= C <= 64 logits per row expected");
+  // (the common checks want a 256-wide 16-byte aligned tail output: the narrow tail has its own rule — any ld >= C, float4 stores where ld % 4 == 0)
+  CB_CHECK_ARG(N == 0 || ((uintptr_t)logits % 16) == 0, CB_E_INVALID, "cb_spmm_gemm_fused_head_f32: logits must be 16-byte aligned");
+  return spmm_gemm_fused_impl(skip_next, acc_init, ld_init, rowptr, col, col_flags, N, E, h, ld_h, d, row_scale, bias, mix_src, ld_mix, c_act, c_mix, drop_p, seed,
+                              seed_dev, row0, relu_bits, bits_relu_only, out_act, ld_act, out_next, ld_next, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, ws,
+                              ws_bytes, head_image, nullptr, nullptr, 0, logits, ld_logits, stream, head_bias, (int)C);
+}
+// Fused trunk store of the LAST layer (as cb_spmm_gemm_fused_f32) + logits = out_next @ B + head_bias, B = the 256 x C matrix behind head_image.
+extern "C" int cb_spmm_gemm_fused_head_f32(CB_SGH_PARAMS) {
+  return spmm_gemm_head_impl(0, acc_init, ld_init, rowptr, col, col_flags, N, E, h, ld_h, d, row_scale, bias, mix_src, ld_mix, c_act, c_mix, drop_p, seed, seed_dev, row0,
+                             relu_bits, bits_relu_only, out_act, ld_act, out_next, ld_next, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, head_image,
+                             head_bias, C, logits, ld_logits, stream);
+}
+// The same for a forward that no backward follows: the last layer's activations are not written at all (hub rows excepted), only the logits leave.
+extern "C" int cb_spmm_gemm_fused_head_eval_f32(CB_SGH_PARAMS) {
+  return spmm_gemm_head_impl(1, acc_init, ld_init, rowptr, col, col_flags, N, E, h, ld_h, d, row_scale, bias, mix_src, ld_mix, c_act, c_mix, drop_p, seed, seed_dev, row0,
+                             relu_bits, bits_relu_only, out_act, ld_act, out_next, ld_next, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, ws, ws_bytes, head_image,
+                             head_bias, C, logits, ld_logits, stream);
+}
+#undef CB_SGH_PARAMS

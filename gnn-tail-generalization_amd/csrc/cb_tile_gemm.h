@@ -102,6 +102,56 @@ __device__ __forceinline__ void tile_times_image(const float* __restrict__ tile,
   for (int r = 0; r < NSTEPS - MAIN; ++r) step(MAIN + r, r, (r + PF) % R);      // (MAIN % R == 0: step s sits in ring slot s % R)
 }
 
+// ---- narrow tail (round 5: the output Linear 256 -> C <= 64 as the tail of the LAST layer's aggregation, GCN.py:133-138) ----------------
+// image layout as above with kNTn = 2 column blocks (columns >= C are zero): image[((s * kNTn + j) * 3 + p) * 64 + lane]
+constexpr int kNTn = 2;
+__global__ void __launch_bounds__(256) k_weight_image_narrow(const float* __restrict__ W, int64_t sk, int64_t sn, uint4* __restrict__ image, int n_steps,
+                                                             int n_cols);
+
+// acc = rows 32 i .. 32 i + 31 of the tile  x  columns 32 j .. 32 j + 31 of the narrow image, over NSTEPS K steps of 16: the four multiplying
+// wavefronts of a block take the four (i, j) blocks of a 64 x 64 output.  Same limb products in the same order as tile_times_image.
+template <int NSTEPS, int TLD>
+__device__ __forceinline__ void tile_times_image_block(const float* __restrict__ tile, const uint4* __restrict__ image, int i, int j, int lane, f32x16& acc) {
+  const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const float* a_row = tile + (32 * i + l31) * TLD + 8 * lh;
+  const uint4* bp = image + ((int64_t)j * 3) * 64 + lane;
+  uint4 bq[2][3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) bq[0][p] = bp[p * 64];
+  bp += kNTn * 192;
+  auto step = [&](int s, int cur, int nx) {
+    if (s + 1 < NSTEPS) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bq[nx][p] = bp[p * 64];
+    }
+    bp += kNTn * 192;
+    const float4 x0 = *reinterpret_cast<const float4*>(a_row + 16 * s);
+    const float4 x1 = *reinterpret_cast<const float4*>(a_row + 16 * s + 4);
+    uint32_t hh[4], mm[4], ll[4];
+    split3x2(x0.x, x0.y, hh[0], mm[0], ll[0]);
+    split3x2(x0.z, x0.w, hh[1], mm[1], ll[1]);
+    split3x2(x1.x, x1.y, hh[2], mm[2], ll[2]);
+    split3x2(x1.z, x1.w, hh[3], mm[3], ll[3]);
+    const bf16x8 a_hi = as_bf16x8(make_uint4(hh[0], hh[1], hh[2], hh[3]));
+    const bf16x8 a_mid = as_bf16x8(make_uint4(mm[0], mm[1], mm[2], mm[3]));
+    const bf16x8 a_lo = as_bf16x8(make_uint4(ll[0], ll[1], ll[2], ll[3]));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, as_bf16x8(bq[cur][0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, as_bf16x8(bq[cur][2]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, as_bf16x8(bq[cur][1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, as_bf16x8(bq[cur][0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, as_bf16x8(bq[cur][1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, as_bf16x8(bq[cur][0]), acc, 0, 0, 0);
+  };
+  static_assert(NSTEPS % 2 == 0, "K loop unrolled by two");
+#pragma unroll 1
+  for (int s0 = 0; s0 < NSTEPS; s0 += 2) {
+    step(s0, 0, 1);
+    step(s0 + 1, 1, 0);
+  }
+}
+
 constexpr int kCLD = 68;     // floats per row of a wavefront's private C strip (8 rows x 64 columns)
 
 // Epilogue of a wavefront's 64 x 64 block of accumulators through a WAVE-PRIVATE staging strip: 8 rows x 64 columns per pass, transposed so

@@ -700,3 +700,24 @@ def weight_image(w, transpose=False):
         _lib.check(lib.cb_agg_gemm_image_f32(_lib.ptr(w), w.stride(0), 256, 256, int(bool(transpose)), _lib.ptr(image), nbytes,
                                              _lib.stream_ptr()), 'cb_agg_gemm_image_f32')
     return image
+
+
+def head_image(w_out):
+    """The 256 x C (C <= 64) matrix B = w_out^T of the output nn.Linear (weight [C, 256]) as bf16 limbs in MFMA fragment order, zero columns
+    beyond C (cb_agg_gemm_head_image_f32): the B operand of the narrow tail of the last layer's aggregation kernel.  None where no such tail
+    exists (C > 64 or another input width)."""
+    lib = _lib.load()
+    _lib.require_device(w_out)
+    if w_out.dtype != torch.float32 or w_out.dim() != 2 or w_out.shape[1] != 256:
+        return None
+    C = int(w_out.shape[0])
+    nbytes = lib.cb_agg_gemm_head_image_bytes(256, C)
+    if not nbytes:
+        return None
+    if w_out.stride(1) != 1:
+        w_out = w_out.contiguous()
+    image = torch.empty(nbytes, dtype=torch.uint8, device=w_out.device)
+    with torch.cuda.device(w_out.device):
+        _lib.check(lib.cb_agg_gemm_head_image_f32(_lib.ptr(w_out), w_out.stride(0), 256, C, 1, _lib.ptr(image), nbytes, _lib.stream_ptr()),
+                   'cb_agg_gemm_head_image_f32')
+    return image

@@ -70,22 +70,27 @@ def _fused_spmm(graph, z, bias, x0, c_act, c_mix, p, seed, want_act=False, produ
 
 
 def _fused_gemm_launch(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowscale, g_addend, want_bits=True, g=None, acc=None, want_act=False,
-                       relu_only=False):
+                       relu_only=False, head=None):
     """(bits, out_next, z_next[, act]) of cb_spmm_gemm_fused_f32: the fused trunk store of layer l and Z_{l+1} = g_rowscale * (out_next @ W_{l+1})
     + g_addend from one kernel (d = 256, fp32 rows).  g: the CSR to run on (default: the graph itself; node-sharded: the last halo slice,
     z = its receive buffer) with acc = the running sums of the earlier passes.  want_bits=False (a forward that no backward follows):
     cb_spmm_gemm_fused_eval_f32 — no mask words, and out_next is not written either (it has no reader: returned as None).  want_act: a
-    fourth result, the ReLU output A_l itself (the next 'Residual' layer's mix source); relu_only: mask words of A_l > 0 alone."""
+    fourth result, the ReLU output A_l itself (the next 'Residual' layer's mix source); relu_only: mask words of A_l > 0 alone.
+    head = (b_out, C) (the LAST layer; image = graph.head_image(w_out)): the tail is the output Linear — the third result is the logits [N, C]
+    (cb_spmm_gemm_fused_head_f32, GCN.py:133-138), g_rowscale / g_addend are ignored."""
     lib = _lib.load()
     g = graph if g is None else g
-    fn = lib.cb_spmm_gemm_fused_f32 if want_bits else lib.cb_spmm_gemm_fused_eval_f32
+    if head is not None:
+        fn = lib.cb_spmm_gemm_fused_head_f32 if want_bits else lib.cb_spmm_gemm_fused_head_eval_f32
+    else:
+        fn = lib.cb_spmm_gemm_fused_f32 if want_bits else lib.cb_spmm_gemm_fused_eval_f32
     n, d = g.N, z.shape[1]
     dev = z.device
     bits = torch.empty((n, d // 256, 4), dtype=torch.int64, device=dev) if want_bits else None
     plan = g._plan
     # (the evaluation form keeps the finished rows on chip: X_{l+1} goes to memory only as the hub rows' way into the tile)
     out_next = torch.empty((n, d), dtype=torch.float32, device=dev) if (want_bits or plan.n_hubs > 0) else None
-    z_next = _exchanged(graph, n)          # (the next layer's aggregation exchanges it)
+    z_next = _exchanged(graph, n) if head is None else torch.empty((n, int(head[1])), dtype=torch.float32, device=dev)     # (Z_{l+1}: the next aggregation exchanges it | the logits)
     act = torch.empty((n, d), dtype=torch.float32, device=dev) if want_act else None
     wsb = lib.cb_spmm_workspace_bytes(plan.n_chunks, d)
     ws = g._workspace(wsb)
@@ -103,32 +108,47 @@ def _fused_gemm_launch(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowsc
                       x0.stride(0) if x0 is not None else 0, float(c_act), float(c_mix), float(p), ctypes.c_uint64(seed),
                       ops.seed_dev_ptr(), int(getattr(graph, 'row_offset', 0)), _lib.ptr(bits), int(bool(relu_only)), _lib.ptr(act), d,
                       _lib.ptr(out_next), d, g.hub_threshold, plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr),
-                      _lib.ptr(ws), wsb, _lib.ptr(image), _lib.ptr(g_rowscale), _lib.ptr(g_addend),
-                      g_addend.stride(0) if g_addend is not None else 0, _lib.ptr(z_next), 256, _lib.stream_ptr()),
+                      _lib.ptr(ws), wsb, _lib.ptr(image),
+                      *((_lib.ptr(head[0]), int(head[1])) if head is not None
+                        else (_lib.ptr(g_rowscale), _lib.ptr(g_addend), g_addend.stride(0) if g_addend is not None else 0)),
+                      _lib.ptr(z_next), z_next.stride(0), _lib.stream_ptr()),
                    'cb_spmm_gemm_fused_f32')
     if prof is not None:
         ev1.record()
         from .graph import prof_rec
         # (the evaluation form writes neither the mask words nor X_{l+1}: 8(d)'s output stream is not there, its rows stay on chip)
-        prof.append(prof_rec(ev0, ev1, g, 'agg_gemm_fused' if want_bits else 'agg_gemm_fused_eval',
+        prof.append(prof_rec(ev0, ev1, g, ('agg_gemm_head' if head is not None else 'agg_gemm_fused') + ('' if want_bits else '_eval'),
                              g.algorithmic_bytes(d) - (0 if want_bits else n * d * 4), n * d * 4 + (n * d // 8 if want_bits else 0),
-                             n * 256 * 4 * (2 if g_addend is not None else 1) + (4 * n if g_rowscale is not None else 0)))
+                             (n * int(head[1]) * 4) if head is not None
+                             else n * 256 * 4 * (2 if g_addend is not None else 1) + (4 * n if g_rowscale is not None else 0)))
     res = (bits, out_next if want_bits else None, z_next)
     return res + (act,) if want_act else res
 
 
-def _fused_gemm(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowscale, g_addend, want_bits=True, want_act=False, relu_only=False):
+def _fused_gemm(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowscale, g_addend, want_bits=True, want_act=False, relu_only=False, head=None):
     """_fused_gemm_launch on the (possibly node-sharded) graph: sharded, the exchange of z runs as the sliced pipeline of dist.ShardedGraph
     (pack / push-sum, all-to-all, interior pass, halo passes of the earlier slices) and the LAST halo pass is the fused kernel on top of the
     running sums — the rank's last pass over its rows also yields the next layer's Z, so no GEMM stands between this aggregation and the next
     layer's first send."""
     if not hasattr(graph, 'part'):
-        return _fused_gemm_launch(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowscale, g_addend, want_bits, want_act=want_act, relu_only=relu_only)
+        return _fused_gemm_launch(graph, z, bias, x0, c_act, c_mix, p, seed, image, g_rowscale, g_addend, want_bits, want_act=want_act, relu_only=relu_only,
+                                  head=head)
     sh = graph
     flights = sh.start_halo(z, False)
     return sh.finish_halo(flights, sh.f, None, lambda g, recv, a_: _fused_gemm_launch(graph, recv, bias, x0, c_act, c_mix, p, seed, image, g_rowscale,
-                                                                                       g_addend, want_bits, g=g, acc=a_, want_act=want_act, relu_only=relu_only),
+                                                                                       g_addend, want_bits, g=g, acc=a_, want_act=want_act, relu_only=relu_only, head=head),
                           x_local=z)
+
+
+def head_tail_enabled(bwd):
+    """The output Linear as the tail of the last layer's aggregation (cb_spmm_gemm_fused_head_f32).  Default: in forwards that no backward follows
+    (the metrics and evaluation forwards: two of the three forwards of the reference's epoch) — there the last layer's activations are not
+    written at all and the head's 10 GB re-read disappears (reference epoch 318.2 / 315.9 -> 313.3 / 314.5 ms, A/B on one box).  In the training
+    forward the activations must be stored anyway and the persistent kernel moves its bytes slower than the plain aggregation kernel it would
+    replace (5.9 against 7.5 TB/s): 160.6 / 160.5 against 159.7 / 160.1 ms per step, so it stays two kernels there.  CB_AGG_GEMM_HEAD=0: never;
+    =2: also in the training forward."""
+    mode = os.environ.get('CB_AGG_GEMM_HEAD', '1')
+    return mode == '2' or (mode == '1' and not bwd)
 
 
 def agg_gemm_eligible(graph, hidden, agg_bf16):
@@ -371,6 +391,7 @@ class _TrunkFn(torch.autograd.Function):
         saved_in, saved_bits = [cur], []
         ag = agg_gemm_eligible(graph, h, agg_bf16)
         z_ready = None                           # Z_l already produced by layer l-1's aggregation kernel (cb_spmm_gemm_fused_f32)
+        out_head = None                          # the logits, when the output Linear left the last layer's aggregation kernel
         mix = x0                                 # mix source of the layer: X0 ('Initial', and layer 0 of 'Residual'), else the previous ReLU output
         for l in range(L):
             w, b, le = layer_params[3 * l: 3 * l + 3]
@@ -399,7 +420,14 @@ class _TrunkFn(torch.autograd.Function):
                     bits, cur, z_ready = res[:3]
                     act = res[3] if keep_act else None
                 else:
-                    bits, cur, act = _fused_spmm(graph, z, b, mix, 1 - alpha, alpha, p, sd_l, want_bits=bwd, relu_only=residual)
+                    # the last layer: the output Linear (GCN.py:133-138) is the tail of its aggregation where that form exists (<= 64 classes)
+                    from .graph import head_image
+                    himg = head_image(w_out) if head_tail_enabled(bwd) else None
+                    if himg is not None:
+                        bits, cur, out_head = _fused_gemm(graph, z, b, mix, 1 - alpha, alpha, p, sd_l, himg, None, None, want_bits=bwd, relu_only=residual,
+                                                          head=(b_out, w_out.shape[0]))[:3]
+                    else:
+                        bits, cur, act = _fused_spmm(graph, z, b, mix, 1 - alpha, alpha, p, sd_l, want_bits=bwd, relu_only=residual)
             elif z0 is None and _chunked(graph, agg_bf16):
                 # node-sharded pipeline: row chunk k of Z leaves the GEMM, is packed and put on the links while chunk k+1 multiplies
                 z = _exchanged(graph, cur.shape[0], w.shape[1])
@@ -421,7 +449,7 @@ class _TrunkFn(torch.autograd.Function):
                 saved_bits.append(bits)
                 saved_in.append(cur)
         del mix
-        out = gemm.mm_nn(cur, w_out.t().contiguous(), bias=b_out)
+        out = out_head if out_head is not None else gemm.mm_nn(cur, w_out.t().contiguous(), bias=b_out)
         ctx.graph, ctx.cfg, ctx.row0 = graph, cfg, row0
         ctx.n_layer_params = len(layer_params)
         if bwd:

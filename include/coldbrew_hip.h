@@ -465,6 +465,28 @@ int cb_spmm_gemm_fused_eval_f32(const float* acc_init, int64_t ld_init, const in
                                 int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
                                 const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, const void* image,
                                 const float* g_rowscale, const float* g_addend, int64_t ld_add, float* g_out, int64_t ld_gout, void* stream);
+/* The output Linear as the tail of the LAST layer's aggregation (round 5): GCN.py:133-138 `layers_MLP[-1](F.dropout(x))` reads exactly the rows
+ * the last trunk store has just made — logits = out_next @ W_out^T + b_out leave the aggregation kernel (C <= 64 classes; the four multiplying
+ * wavefronts of a block take the four 32 x 32 blocks of a tile's 64 x 64 output), the separate head GEMM and its re-read of the [N, 256]
+ * activations disappear.  Same limb products in the same order as cb_gemm_nn_f32.  head_image: cb_agg_gemm_head_image_f32 of the nn.Linear
+ * weight [C, 256] (transpose = 1) — 256 x 64 with zero columns beyond C; logits [N, ld_logits >= C], 16-byte aligned.  Other arguments as
+ * cb_spmm_gemm_fused_f32.  _eval: a forward that no backward follows — the last layer's activations are not written at all. */
+size_t cb_agg_gemm_head_image_bytes(int64_t K, int64_t C);
+int cb_agg_gemm_head_image_f32(const float* W, int64_t ld, int64_t K, int64_t C, int transpose, void* image, size_t image_bytes, void* stream);
+int cb_spmm_gemm_fused_head_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N,
+                                int64_t E, const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias, const float* mix_src,
+                                int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0,
+                                uint64_t* relu_bits, int32_t bits_relu_only, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
+                                int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr,
+                                void* ws, size_t ws_bytes, const void* head_image, const float* head_bias, int64_t C, float* logits,
+                                int64_t ld_logits, void* stream);
+int cb_spmm_gemm_fused_head_eval_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N,
+                                     int64_t E, const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias,
+                                     const float* mix_src, int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed,
+                                     const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, int32_t bits_relu_only, float* out_act,
+                                     int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_threshold, int32_t n_hubs, int32_t n_chunks,
+                                     const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, const void* head_image,
+                                     const float* head_bias, int64_t C, float* logits, int64_t ld_logits, void* stream);
 /* Fault injection for the failure path above (tests): one wavefront waits with a short spin bound for a hand-over that never comes;
  * cb_device_status() must then report CB_E_DEVICE. */
 int cb_agg_gemm_handover_selftest(void* stream);

@@ -113,6 +113,48 @@ def test_fused_store_gemm_equals_fused_store_then_gemm(n, T, p):
     assert b2 is None and n2 is None and torch.equal(z2, gemm.mm_nn(nxt_mix, w, rowscale=a, addend=le))
 
 
+@pytest.mark.parametrize('C', [40, 47, 3, 64, 7])
+@pytest.mark.parametrize('n,T,p', [(5003, 16, 0.1), (70001, 64, 0.2), (777, 256, 0.0)])
+def test_head_linear_as_the_tail_of_the_last_aggregation(n, T, p, C):
+    """cb_spmm_gemm_fused_head_f32 (round 5): the LAST layer's trunk store and the output Linear (GCN.py:133-138) from one
+    kernel — mask words and the stored activations bit-identical to cb_spmm_csr_fused_f32, the logits bit-identical to cb_gemm_nn_f32 on those
+    activations (same limb products in the same order), for class counts that are / are not multiples of 4, with hub rows, on top of running sums
+    (node-sharded last pass), and in the evaluation form, which writes no activations at all."""
+    from gnn_tail_generalization_amd import _lib, gemm, trunk
+    from gnn_tail_generalization_amd.graph import head_image
+    G = _powerlaw_graph(n, 9, T)
+    gen = torch.Generator(device=DEV).manual_seed(8 + C)
+    z = torch.randn(n, 256, device=DEV, generator=gen)
+    x0 = torch.randn(n, 256, device=DEV, generator=gen)
+    bias = torch.randn(256, device=DEV, generator=gen)
+    w_out = torch.randn(C, 256, device=DEV, generator=gen) * 0.07          # nn.Linear layout
+    b_out = torch.randn(C, device=DEV, generator=gen)
+    img = head_image(w_out)
+    assert img is not None and head_image(torch.randn(65, 256, device=DEV)) is None
+    bits_r, nxt_r, _ = trunk._fused_spmm(G, z, bias, x0, 0.9, 0.1, p, 4242)
+    want = gemm.mm_nn(nxt_r, w_out.t().contiguous(), bias=b_out)
+    bits, nxt, logits = trunk._fused_gemm_launch(G, z, bias, x0, 0.9, 0.1, p, 4242, img, None, None, head=(b_out, C))
+    assert logits.shape == (n, C) and torch.equal(bits, bits_r) and torch.equal(nxt, nxt_r)
+    ref64 = nxt_r.double() @ w_out.t().double() + b_out.double()
+
+    def same(got, ref):
+        # class counts that are multiples of 4: cb_gemm_nn_f32 runs the same limb kernel -> the same bits; others send it to its fp32-input fallback
+        # (rows of C floats are not 16-byte aligned), so the two agree as two fp32-grade GEMMs do — and the tail is the closer one to fp64
+        if C % 4 == 0:
+            return torch.equal(got, ref)
+        tol = 2e-5 * float(ref64.abs().max())
+        return float((got.double() - ref64).abs().max()) <= tol and float((got - ref).abs().max()) <= 2 * tol
+    assert same(logits, want), float((logits - want).abs().max())
+    b2, n2, l2 = trunk._fused_gemm_launch(G, z, bias, x0, 0.9, 0.1, p, 4242, img, None, None, want_bits=False, head=(b_out, C))
+    assert b2 is None and n2 is None and torch.equal(l2, logits)
+    # on top of the partial sums of earlier passes (the last halo pass of a node-sharded aggregation)
+    acc = torch.randn(n, 256, device=DEV, generator=gen)
+    rb, rn, _ = trunk._fused_launch(_lib.load(), G, G, z, acc.clone(), bias, x0, 0.9, 0.1, p, 4242, False)
+    b3, n3, l3 = trunk._fused_gemm_launch(G, z, bias, x0, 0.9, 0.1, p, 4242, img, None, None, g=G, acc=acc.clone(), head=(b_out, C))
+    ref64 = rn.double() @ w_out.t().double() + b_out.double()
+    assert torch.equal(b3, rb) and torch.equal(n3, rn) and same(l3, gemm.mm_nn(rn, w_out.t().contiguous(), bias=b_out))
+
+
 @pytest.mark.parametrize('n,T,p', [(5003, 16, 0.1), (20000, 256, 0.0)])
 def test_reverse_aggregation_gemm_trunk_backward_equals_three_kernels(n, T, p):
     """cb_spmm_gemm_trunkbwd_f32: dL/dZ (reverse aggregation), dL/dx = a * (dL/dZ @ W^T) and the trunk backward of the layer below
