@@ -151,7 +151,9 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
                                                       int64_t rows, int d, uint32_t thresh, float keep_scale, uint64_t seed,
                                                       const uint64_t* __restrict__ seed_dev, int64_t row0, float c_act, float c_mix,
                                                       float* __restrict__ partial, const int64_t* __restrict__ ridx,
-                                                      const float* __restrict__ g2, uint64_t seed2, float c2) {
+                                                      const float* __restrict__ g2, uint64_t seed2, float c2, const int* __restrict__ g2_pos) {
+  // g2_pos (may be null; int32 per row of the FULL matrix): g2 is a COMPACT matrix — row rr of the full matrix sits at g2_pos[rr], absent (zero)
+  // where that is negative (a row-sparse backward: g2 lives on the previous level's support)
   // g2 (MODE 0, dense rows; may be null): the 'Residual' connection (res_tricks.py:7-14) — this layer's ReLU output A_l is also the mix source
   // of layer l+1, so dL/dA_l = c_act * dropout_bwd_seed(g) + c2 * dropout_bwd_seed2(g2), g2 = the gradient w.r.t. layer l+1's stored (dropped)
   // output; `bits` must then be the ReLU mask alone (bits_relu_only of the forward store)
@@ -196,8 +198,11 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
         }
         const unsigned long long* bw = bits + (rr * tiles + tile) * 4;
         if (g2) {      // (uniform) second gradient through the same ReLU, under the next layer's dropout mask
-          float g2m[4] = {__builtin_nontemporal_load(g2 + off), __builtin_nontemporal_load(g2 + off + 1), __builtin_nontemporal_load(g2 + off + 2),
-                          __builtin_nontemporal_load(g2 + off + 3)};
+          const int64_t p2 = g2_pos ? (int64_t)__builtin_amdgcn_readfirstlane(g2_pos[rr]) : (RIDX ? rr : r);      // (wave-uniform row)
+          const int64_t off2 = (p2 < 0 ? 0 : p2) * d + c;
+          float g2m[4] = {__builtin_nontemporal_load(g2 + off2), __builtin_nontemporal_load(g2 + off2 + 1), __builtin_nontemporal_load(g2 + off2 + 2),
+                          __builtin_nontemporal_load(g2 + off2 + 3)};
+          if (p2 < 0) { g2m[0] = g2m[1] = g2m[2] = g2m[3] = 0.f; }
           if (thresh) {
             float m2[4];
             keep4(seed2, ((row0 + rr) * d + c) >> 2, thresh, keep_scale, m2);
@@ -907,13 +912,14 @@ extern "C" int cb_adam_multi_f32(int32_t n_tensors, float* const* p, const float
 static int launch_trunk_bwd(int mode, int out_bf16, const float* g, const uint64_t* bits, const float* act, const float* row_scale,
                             void* out, float* gx0, int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed,
                             const uint64_t* seed_dev, int64_t row0, float c_act, float c_mix, float* colsum, void* ws, size_t ws_bytes,
-                            hipStream_t st, const int64_t* ridx = nullptr, const float* g2 = nullptr, uint64_t seed2 = 0, float c2 = 0.f) {
+                            hipStream_t st, const int64_t* ridx = nullptr, const float* g2 = nullptr, uint64_t seed2 = 0, float c2 = 0.f,
+                            const int32_t* g2_pos = nullptr) {
   int64_t nb = (rows + 63) / 64;
   if (nb > kMaxBlocks) nb = kMaxBlocks;
   const uint32_t thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
   const float ks = 1.f / (1.f - drop_p);
   float* partial = colsum ? (float*)ws : nullptr;
-#define CB_TB_ARGS g, (const unsigned long long*)bits, act, row_scale, out, gx0, accumulate, rows, (int)d, thresh, ks, seed, seed_dev, row0, c_act, c_mix, partial, ridx, g2, seed2, c2
+#define CB_TB_ARGS g, (const unsigned long long*)bits, act, row_scale, out, gx0, accumulate, rows, (int)d, thresh, ks, seed, seed_dev, row0, c_act, c_mix, partial, ridx, g2, seed2, c2, g2_pos
   const dim3 grid((unsigned)nb), blk(kBlock);
   const size_t sh = kBlock * 4 * sizeof(float);
   if (mode == 0 && ridx) hipLaunchKernelGGL((k_trunk_bwd<0, false, true, true>), grid, blk, sh, st, CB_TB_ARGS);
@@ -933,7 +939,7 @@ static int launch_trunk_bwd(int mode, int out_bf16, const float* g, const uint64
 extern "C" int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits, const float* row_scale, void* out, int out_bf16,
                                       float* gx0, int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed,
                                       const uint64_t* seed_dev, int64_t row0, float c_act, float c_mix, const float* g2, uint64_t seed2, float c2,
-                                      float* colsum, void* ws, size_t ws_bytes, void* stream) {
+                                      const int32_t* g2_pos, float* colsum, void* ws, size_t ws_bytes, void* stream) {
   CB_CHECK_ARG(rows >= 0 && d > 0 && d % 256 == 0 && d < (1 << 20), CB_E_INVALID, "cb_trunk_layer_bwd_f32: d must be a multiple of 256");
   if (rows == 0) return CB_OK;
   CB_CHECK_ARG(!g2 || aligned16(g2), CB_E_INVALID, "cb_trunk_layer_bwd_f32: misaligned second gradient");
@@ -942,7 +948,7 @@ extern "C" int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits,
   CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, CB_E_INVALID, "cb_trunk_layer_bwd_f32: dropout p out of range");
   CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_colsum_workspace_bytes(rows, d)), CB_E_WORKSPACE, "cb_trunk_layer_bwd_f32: workspace too small");
   return launch_trunk_bwd(0, out_bf16, g, relu_bits, nullptr, row_scale, out, gx0, accumulate, rows, d, drop_p, seed, seed_dev, row0, c_act, c_mix,
-                          colsum, ws, ws_bytes, (hipStream_t)stream, nullptr, g2, seed2, c2);
+                          colsum, ws, ws_bytes, (hipStream_t)stream, nullptr, g2, seed2, c2, g2_pos);
 }
 
 // cb_trunk_layer_bwd_f32 over a SUBSET of the rows: g and out are compact [n_rows, d] matrices holding rows row_index[0 .. n_rows) of the full
@@ -950,7 +956,8 @@ extern "C" int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits,
 // column sums over the subset (all other rows of a row-sparse backward are zero).
 extern "C" int cb_trunk_layer_bwd_rows_f32(const float* g, const int64_t* row_index, int64_t n_rows, const uint64_t* relu_bits, const float* row_scale,
                                            float* out, int64_t d, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, float c_act,
-                                           float* colsum, void* ws, size_t ws_bytes, void* stream) {
+                                           const float* g2, uint64_t seed2, float c2, const int32_t* g2_pos, float* colsum, void* ws, size_t ws_bytes,
+                                           void* stream) {
   CB_CHECK_ARG(n_rows >= 0 && d > 0 && d % 256 == 0 && d < (1 << 20), CB_E_INVALID, "cb_trunk_layer_bwd_rows_f32: d must be a multiple of 256");
   if (n_rows == 0) {
     if (colsum) CB_HIP(hipMemsetAsync(colsum, 0, (size_t)d * sizeof(float), (hipStream_t)stream));
@@ -959,8 +966,9 @@ extern "C" int cb_trunk_layer_bwd_rows_f32(const float* g, const int64_t* row_in
   CB_CHECK_ARG(g && row_index && relu_bits && out && aligned16(g) && aligned16(out), CB_E_INVALID, "cb_trunk_layer_bwd_rows_f32: null or misaligned pointer");
   CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, CB_E_INVALID, "cb_trunk_layer_bwd_rows_f32: dropout p out of range");
   CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_colsum_workspace_bytes(n_rows, d)), CB_E_WORKSPACE, "cb_trunk_layer_bwd_rows_f32: workspace too small");
+  CB_CHECK_ARG(!g2 || (aligned16(g2) && g2_pos), CB_E_INVALID, "cb_trunk_layer_bwd_rows_f32: the second gradient needs 16-byte aligned rows and its position map");
   return launch_trunk_bwd(0, 0, g, relu_bits, nullptr, row_scale, out, nullptr, 0, n_rows, d, drop_p, seed, seed_dev, row0, c_act, 0.f, colsum, ws, ws_bytes,
-                          (hipStream_t)stream, row_index);
+                          (hipStream_t)stream, row_index, g2, seed2, c2, g2_pos);
 }
 
 extern "C" int cb_trunk_input_bwd_f32(const float* g, const float* add, const float* act, float* out, int64_t rows, int64_t d,

@@ -127,7 +127,7 @@ class CSRGraph:
         self._hot_cache[k] = (ck, ctk)
         return ck, ctk
 
-    def grad_support_plan(self, keep, n_aggr, max_frac=0.6):
+    def grad_support_plan(self, keep, n_aggr, max_frac=0.6, cumulative=False):
         """Row supports of a backward whose incoming gradient is non-zero on the rows `keep` only (the masked loss: the loss_rows promise of the forward, ops.py).
         Reverse aggregation j (j = 0 for the last layer) gathers rows of the support S_j and produces non-zero rows exactly on
         S_{j+1} = the rows with a (reverse-orientation) neighbour in S_j; supports are properties of the graph and the mask, not of the
@@ -138,10 +138,12 @@ class CSRGraph:
                              positions in S_j; dst = the compact space of S_{j+1} when |S_{j+1}| <= max_frac * N (csr then has one row per
                              member of S_{j+1}), else None (csr has all N rows, the output is an ordinary dense matrix and the plan ends).
         At most n_aggr levels, and the last of them always has a dense destination (the stage below the first layer needs all rows).
-        max_frac = 0: one level, S_0 -> all rows.  Sums equal the full orientation's up to the order in which a hub row's chunks are added."""
+        max_frac = 0: one level, S_0 -> all rows.  Sums equal the full orientation's up to the order in which a hub row's chunks are added.
+        cumulative (the 'Residual' trunk): S_{j+1} = N(S_j) ∪ S_j — a superset that also holds the rows the previous level's gradient lives on
+        (rows of S_j without a neighbour in S_j are rows without edges in the level's CSR)."""
         # (the cache keeps the mask tensor itself alive: its address cannot be handed to another tensor while the plan is cached, and an
         # in-place change bumps its version)
-        key = (keep.data_ptr(), keep._version, int(keep.shape[0]), int(n_aggr), float(max_frac))
+        key = (keep.data_ptr(), keep._version, int(keep.shape[0]), int(n_aggr), float(max_frac), bool(cumulative))
         if getattr(self, '_support_key', None) == key and getattr(self, '_support_mask', None) is keep:
             self._support_hits = getattr(self, '_support_hits', 0) + 1
             return self._support_plan
@@ -167,7 +169,7 @@ class CSRGraph:
             col_new = torch.index_select(src.pos, 0, col[kept])
             del kept, csum
             cnt = rp_new[1:] - rp_new[:-1]
-            dst_mask = cnt > 0
+            dst_mask = (cnt > 0) | src_mask if cumulative else cnt > 0
             n_dst = int(dst_mask.sum())
             last = len(plan.levels) + 1 == n_aggr
             if not last and n_dst <= max_frac * self.N:

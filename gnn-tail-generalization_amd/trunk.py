@@ -210,9 +210,10 @@ def _spmm_t(graph, gr):
     return graph.spmm(gr, transpose=True)
 
 
-def _layer_bwd(g, bits, row_scale, gx0, accumulate, p, seed, row0, c_act, c_mix, want_colsum, out_bf16=False, out=None, g2=None, seed2=0, c2=0.0):
+def _layer_bwd(g, bits, row_scale, gx0, accumulate, p, seed, row0, c_act, c_mix, want_colsum, out_bf16=False, out=None, g2=None, seed2=0, c2=0.0, g2_pos=None):
     """cb_trunk_layer_bwd_f32: (b * dY' of the layer's store, dbias).  g2 ('Residual'): the gradient w.r.t. the NEXT layer's stored output, which
-    reaches this layer's ReLU output through that layer's mix (c2 = alpha) under that layer's dropout mask (seed2)."""
+    reaches this layer's ReLU output through that layer's mix (c2 = alpha) under that layer's dropout mask (seed2); g2_pos (int32 [rows]): g2 is
+    a compact matrix of a row-sparse backward, row r at g2_pos[r] (absent where negative)."""
     lib = _lib.load()
     rows, d = g.shape
     if out is None:
@@ -223,13 +224,13 @@ def _layer_bwd(g, bits, row_scale, gx0, accumulate, p, seed, row0, c_act, c_mix,
     with torch.cuda.device(g.device):
         _lib.check(lib.cb_trunk_layer_bwd_f32(_lib.ptr(g), _lib.ptr(bits), _lib.ptr(row_scale), _lib.ptr(out), int(out_bf16),
                                               _lib.ptr(gx0), int(accumulate), rows, d, float(p), ctypes.c_uint64(seed), ops.seed_dev_ptr(),
-                                              int(row0), float(c_act), float(c_mix), _lib.ptr(g2), ctypes.c_uint64(seed2), float(c2), _lib.ptr(colsum),
-                                              _lib.ptr(ws), wsb, _lib.stream_ptr()),
+                                              int(row0), float(c_act), float(c_mix), _lib.ptr(g2), ctypes.c_uint64(seed2), float(c2), _lib.ptr(g2_pos),
+                                              _lib.ptr(colsum), _lib.ptr(ws), wsb, _lib.stream_ptr()),
                    'cb_trunk_layer_bwd_f32')
     return out, colsum
 
 
-def _layer_bwd_rows(g_c, rows_idx, bits, row_scale, p, seed, row0, c_act, want_colsum, out=None):
+def _layer_bwd_rows(g_c, rows_idx, bits, row_scale, p, seed, row0, c_act, want_colsum, out=None, g2=None, seed2=0, c2=0.0, g2_pos=None):
     """_layer_bwd over the compact rows rows_idx of a row-sparse backward (cb_trunk_layer_bwd_rows_f32): (b * dY' of those rows, dbias)."""
     lib = _lib.load()
     n_c, d = g_c.shape
@@ -239,8 +240,9 @@ def _layer_bwd_rows(g_c, rows_idx, bits, row_scale, p, seed, row0, c_act, want_c
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=g_c.device)
     with torch.cuda.device(g_c.device):
         _lib.check(lib.cb_trunk_layer_bwd_rows_f32(_lib.ptr(g_c), _lib.ptr(rows_idx), n_c, _lib.ptr(bits), _lib.ptr(row_scale), _lib.ptr(out), d, float(p),
-                                                   ctypes.c_uint64(seed), ops.seed_dev_ptr(), int(row0), float(c_act), _lib.ptr(colsum), _lib.ptr(ws), wsb,
-                                                   _lib.stream_ptr()), 'cb_trunk_layer_bwd_rows_f32')
+                                                   ctypes.c_uint64(seed), ops.seed_dev_ptr(), int(row0), float(c_act), _lib.ptr(g2), ctypes.c_uint64(seed2),
+                                                   float(c2), _lib.ptr(g2_pos), _lib.ptr(colsum), _lib.ptr(ws), wsb, _lib.stream_ptr()),
+                   'cb_trunk_layer_bwd_rows_f32')
     return out, colsum
 
 
@@ -497,8 +499,9 @@ class _Backward:
         self.gout = gemm._rowmajor(gout)
         self.h = self.x0.shape[1]
         self.sharded = hasattr(graph, 'part')
-        if loss_rows is not None and (not ops.loss_rows_enabled() or loss_rows[0].shape[0] != self.gout.shape[0] or residual):
-            # ('Residual': the gradient that enters a layer's reverse aggregation lives on the UNION of two supports — the plan is not built for it)
+        if loss_rows is not None and (not ops.loss_rows_enabled() or loss_rows[0].shape[0] != self.gout.shape[0] or (residual and self.sharded)):
+            # ('Residual' on row shards: the gradient that enters a layer's reverse aggregation lives on the UNION of two supports — the level
+            # orientations of dist.support_levels are not built for it; on one GPU the plan is taken with CUMULATIVE supports, see run())
             loss_rows = None
         self.loss_rows = loss_rows
         # the gradient reaching X0 through the mixes: 'Initial' — every layer's, gathered in one pass by the input stage (the per-layer gradients
@@ -533,14 +536,14 @@ class _Backward:
         dw = gemm.mm_tn_adrop(self.x0, gz, self.p, sd0, self.row0, rowscale=self.a)
         return dw if dw is not None else gemm.mm_tn(ops._dropout_raw(self.x0, self.p, sd0, self.row0 * self.x0.shape[1]), gz, rowscale=self.a)
 
-    def _second(self, below, g_above):
+    def _second(self, below, g_above, pos_above=None):
         """'Residual': keyword arguments of the second gradient that reaches layer `below`'s ReLU output — through the mix of layer below + 1,
-        under that layer's dropout mask."""
+        under that layer's dropout mask.  pos_above: the position map of g_above's row space when it is a compact matrix (row-sparse plan)."""
         if not self.residual or g_above is None:
             return {}
-        return dict(g2=g_above, seed2=self.seed(below + 3), c2=self.alpha)
+        return dict(g2=g_above, seed2=self.seed(below + 3), c2=self.alpha, **({'g2_pos': pos_above} if pos_above is not None else {}))
 
-    def _dx_and_store_bwd(self, src, wt, rowscale, below, g_ready=None, g_above=None, orient=None):
+    def _dx_and_store_bwd(self, src, wt, rowscale, below, g_ready=None, g_above=None, orient=None, pos_above=None):
         """dL/dx of the stage above layer `below` and that layer's store backward: (g, gr, dbias, handle); handle = the already started
         exchange of gr (row-chunked producers of the node-sharded pull pipeline), else None.  g_ready: dL/dx left the reverse aggregation's kernel."""
         p, alpha, row0, bnorm = self.p, self.alpha, self.row0, self.bnorm
@@ -551,7 +554,7 @@ class _Backward:
             g_ = torch.empty((src.shape[0], wt.shape[1]), dtype=torch.float32, device=src.device)
             gr_ = _exchanged(self.graph, g_.shape[0], g_.shape[1])
             colsums = []
-            sec = self._second(below, g_above)
+            sec = self._second(below, g_above, pos_above)
 
             def produce(k, r0, r1):
                 if r1 <= r0:
@@ -570,7 +573,7 @@ class _Backward:
         g_ = g_ready if g_ready is not None else gemm.mm_nn(src, wt, rowscale=rowscale)
         gr_, db_ = _layer_bwd(g_, bits, bnorm, self.gx0, below != self.L - 1, p, sd, row0, 1 - alpha, alpha, want_b, out_bf16=self.agg_bf16,
                               out=_exchanged(self.graph, g_.shape[0], g_.shape[1]) if (self.sharded and not self.agg_bf16) else None,
-                              **self._second(below, g_above))
+                              **self._second(below, g_above, pos_above))
         return g_, gr_, db_, None
 
     # -- head ----------------------------------------------------------------------------------------------------------------------------
@@ -693,7 +696,9 @@ class _Backward:
                 and (gout.shape[0] >= T.rowsparse_min_nodes or getattr(graph, 'rowsparse_small_ok', False)) and gather
                 and agg_gemm_eligible(graph, self.h, False) and not self.tail_tb and graph.support_plan_pays()):
             ops.check_rows_zero(gout, hint[0])
-            plan = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac)
+            # ('Residual': a layer's store backward also takes the gradient of the layer above, so the supports are CUMULATIVE — W_{j+1} = N(W_j) ∪ W_j,
+            # a superset of both; every matrix of level j lives on W_j)
+            plan = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac, cumulative=self.residual)
 
         space0 = plan.space0 if plan is not None else (self.sh_levels[0].src if self.sh_levels else None)
         g, gr, dbias, handle, space = self._head(space0)
@@ -737,6 +742,7 @@ class _Backward:
                     else:
                         self.grads_layers[3 * l] = self._dw(l, self.saved_in[l], gz)
             g_above = g if self.residual else None
+            pos_above = space.pos if (self.residual and space is not None) else None      # (g lives on the space of this level's source rows)
             del g, gr
             handle = None
             self.grads_layers[3 * l + 1] = dbias
@@ -744,11 +750,13 @@ class _Backward:
             if l > 0 and dst is not None:      # the store backward of layer l-1 on the rows of S_{j+1}
                 g = g_new
                 gr, dbias = _layer_bwd_rows(g, dst.idx, self.saved_bits[l - 1], self.bnorm, p, self.seed(l + 1), self.row0, 1 - alpha, self.need_b(l - 1),
-                                            out=_exchanged(graph, g.shape[0], g.shape[1]) if sharded else None)
+                                            out=_exchanged(graph, g.shape[0], g.shape[1]) if sharded else None,
+                                            **self._second(l - 1, g_above, pos_above))
             elif l > 0 and tb_next is not None:
                 g, (gr, dbias) = g_new, tb_next
             elif l > 0:      # dL/d(dropped X_l) and the backward of layer l-1's store
-                g, gr, dbias, handle = self._dx_and_store_bwd(gz, w.t().contiguous(), a, l - 1, g_new, g_above, orient=self._orient_of(l - 1))
+                g, gr, dbias, handle = self._dx_and_store_bwd(gz, w.t().contiguous(), a, l - 1, g_new, g_above, orient=self._orient_of(l - 1),
+                                                              pos_above=pos_above)
             else:            # dL/d(dropped X_0): consumed by the input stage
                 g = g_new if g_new is not None else gemm.mm_nn(gz, w.t().contiguous(), rowscale=a)
             g_above = None

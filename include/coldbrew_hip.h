@@ -270,17 +270,19 @@ int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, int32_t col
  *     gy = c_act * gm * relu_bit;  colsum = sum_rows gy (dbias; NULL to skip);  out = gy * row_scale[r]. */
 int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits, const float* row_scale, void* out, int out_bf16, float* gx0,
                            int accumulate, int64_t rows, int64_t d, float drop_p, uint64_t seed, const uint64_t* seed_dev,
-                           int64_t row0, float c_act, float c_mix, const float* g2, uint64_t seed2, float c2, float* colsum, void* ws,
-                           size_t ws_bytes, void* stream);
+                           int64_t row0, float c_act, float c_mix, const float* g2, uint64_t seed2, float c2, const int32_t* g2_pos, float* colsum,
+                           void* ws, size_t ws_bytes, void* stream);
 /* g2 (may be NULL): 'Residual' connection (res_tricks.py:7-14) — the layer's ReLU output also is the mix source of the NEXT layer, so
  *     gy = (c_act * dropout_bwd_seed(g) + c2 * dropout_bwd_seed2(g2)) * relu_bit     (g2 = gradient w.r.t. the next layer's stored output;
- * relu_bits written with bits_relu_only). */
+ * relu_bits written with bits_relu_only).  g2_pos (may be NULL; int32 [rows of the full matrix]): g2 is a COMPACT matrix of a row-sparse backward —
+ * full row r sits at g2_pos[r], absent (= zero) where that is negative. */
 /* (out_bf16 != 0: `out` is a bf16 [rows, d] matrix — gradient rows stored in bf16 for the bf16 aggregation variant.) */
 /* The same over a SUBSET of the rows (row-sparse backward: the loss rows): g / out are compact [n_rows, d] matrices holding rows
  * row_index[0 .. n_rows) (ascending) of the full ones; relu_bits / row_scale are the full arrays; the dropout mask is the global row's. */
 int cb_trunk_layer_bwd_rows_f32(const float* g, const int64_t* row_index, int64_t n_rows, const uint64_t* relu_bits, const float* row_scale, float* out,
-                                int64_t d, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, float c_act, float* colsum, void* ws,
-                                size_t ws_bytes, void* stream);
+                                int64_t d, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, float c_act, const float* g2, uint64_t seed2,
+                                float c2, const int32_t* g2_pos, float* colsum, void* ws, size_t ws_bytes, void* stream);
+/* (g2 / seed2 / c2 / g2_pos as in cb_trunk_layer_bwd_f32; g2_pos is required with g2: the two compact matrices live on different supports.) */
 
 /* Backward into the trunk's input stage X0 = relu(Linear(dropout(x))) (GCN.py:104-107,110):
  *     out = (add + dropout_bwd(g)) * (act > 0);  colsum = sum_rows out  (bias gradient of the input Linear). */

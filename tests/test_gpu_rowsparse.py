@@ -49,8 +49,9 @@ def _step_grads(flag, dataset='S-pl1M', se='000', layers=3, extra=(), n_loss_row
             os.environ['CB_LOSS_ROWS'] = old
 
 
+@pytest.mark.parametrize('conn', ['Initial', 'Residual'])
 @pytest.mark.parametrize('max_frac,se,loss_side', [(0.6, '000', True), (0.6, '000', False), (0.0, '000', True), (0.6, '111', True)])
-def test_row_sparse_backward_equals_the_dense_backward(max_frac, se, loss_side, monkeypatch):
+def test_row_sparse_backward_equals_the_dense_backward(max_frac, se, loss_side, conn, monkeypatch):
     """max_frac 0.6: the supports S_0 (10 % of the rows) and S_1 (45 %) compact, from S_2 (94 %) on dense; 0: only the gathered side of the
     first aggregation compact.  se 111: structural-embedding tables, whose gradient dL/dZ_l is scattered from the compact level to all rows.
     loss_side: level 0's GEMM and weight gradient contracted over the loss rows (plan.fwd0), whether its destination is compact or dense —
@@ -62,10 +63,11 @@ def test_row_sparse_backward_equals_the_dense_backward(max_frac, se, loss_side, 
     from gnn_tail_generalization_amd.graph import CSRGraph
     real = CSRGraph.spmm
     monkeypatch.setattr(CSRGraph, 'spmm', lambda self, h, *a, **k: (spmm_rows.append((self.N, self.n_cols)), real(self, h, *a, **k))[1])
-    loss_s, g_s, used_s = _step_grads('1', se=se)
+    extra = () if conn == 'Initial' else ('--force_set_to_best_config=0', '--type_trick=Residual')      # (Residual: cumulative supports, a second compact gradient)
+    loss_s, g_s, used_s = _step_grads('1', se=se, extra=extra)
     took_loss_side = any(n < c for n, c in spmm_rows)  # fwd0: one row per loss row, all columns
     assert took_loss_side == (loss_side and se == '000')
-    loss_d, g_d, used_d = _step_grads('0', se=se)
+    loss_d, g_d, used_d = _step_grads('0', se=se, extra=extra)
     assert used_s and not used_d                       # the 10 % train mask of the stand-in: the plan was built and used
     assert loss_s == loss_d
     assert set(g_s) == set(g_d)
@@ -113,7 +115,8 @@ def test_row_sparse_backward_two_layers_small_graph(monkeypatch):
         assert float((g_s[k] - g_d[k]).abs().max()) <= 5e-6 * float(g_d[k].abs().max()), k
 
 
-@pytest.mark.parametrize('case', ['case_r_initialbn_h256_L3_train10', 'case_r_initialbn_h256_L3_train10_se111'])
+@pytest.mark.parametrize('case', ['case_r_initialbn_h256_L3_train10', 'case_r_initialbn_h256_L3_train10_se111',
+                                  'case_r_residual_h256_L3_train10', 'case_r_residual_h256_L3_train10_se111'])      # (Residual, round 5: cumulative supports)
 def test_row_sparse_backward_matches_the_unmodified_reference(case, monkeypatch):
     """The reference's own gradients (goldens case_r_initialbn_h256_L3_train10[_se111]: hidden 256, 3 layers, 8 – 10 % train rows, without
     and with structural-embedding tables on every layer, generated from the unmodified reference by tests/golden/make_golden.py) against
