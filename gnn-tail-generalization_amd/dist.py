@@ -713,7 +713,7 @@ class ShardedGraph:
         """The level orientations alone (matrices keep all local rows): [lv.orient for lv in support_levels(..., compact=False)]."""
         return [lv.orient for lv in self.support_levels(mask_local, n_aggr, max_edge_frac, compact=False)]
 
-    def support_levels(self, mask_local, n_aggr, max_edge_frac=None, compact=True, max_frac=None):
+    def support_levels(self, mask_local, n_aggr, max_edge_frac=None, compact=True, max_frac=None, cumulative=False):
         """Levels of a row-sparse backward on row shards (trunk.py; graph.CSRGraph.grad_support_plan is the one-GPU form): reverse aggregation
         j gathers only rows of the support S_j (S_0 = the loss rows `mask_local` of this rank, S_{j+1} = rows with a reverse-orientation
         neighbour in S_j) — all other rows of the gathered matrix are exact zeros.  Level j = the reverse orientation restricted to the edges
@@ -724,12 +724,13 @@ class ShardedGraph:
         level reads a [src.n, d] matrix and writes a [dst.n, d] one (dst None: all local rows; the last level always), so the rank's store
         backward, weight gradient and GEMM tail run on the support's rows only, as on one GPU.  One decision per level for the group; needs
         the overlapped exchange with a plan whose last pass can be the aggregation + GEMM kernel (cover, or one slice).
+        cumulative (the 'Residual' trunk: a layer's store backward also takes the gradient of the layer above): S_{j+1} = N(S_j) ∪ S_j.
         Levels are built while they keep at most max_edge_frac of the edges; the supports travel as byte maps (all-gather of N bytes per
         level, once per mask).  Returns a list of SupportLevel, possibly empty."""
         from .graph import RowSpace
         max_edge_frac = T.support_max_edge_frac if max_edge_frac is None else max_edge_frac
         max_frac = T.rowsparse_max_frac if max_frac is None else max_frac
-        key = (mask_local.data_ptr(), mask_local._version, int(n_aggr), bool(compact), float(max_frac), float(max_edge_frac))
+        key = (mask_local.data_ptr(), mask_local._version, int(n_aggr), bool(compact), float(max_frac), float(max_edge_frac), bool(cumulative))
         if self._support_cache is not None and self._support_cache[0] == key and self._support_cache[1] is mask_local:
             return self._support_cache[2]
         part, P = self.part, self.part.world
@@ -774,6 +775,8 @@ class ShardedGraph:
                 break
             r_k, c_k = rows[keep], cols[keep]
             s_next = torch.bincount(r_k, minlength=self.N)[:self.N] > 0
+            if cumulative:
+                s_next = s_next | s_local
             found.append((r_k, c_k, s_next, global_count(s_next) if compact else 0))
             s_local = s_next
         # pass 2: the orientations.  A level writes a COMPACT matrix only if the next level exists to read it (and its support is small)

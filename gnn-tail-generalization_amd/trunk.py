@@ -499,9 +499,7 @@ class _Backward:
         self.gout = gemm._rowmajor(gout)
         self.h = self.x0.shape[1]
         self.sharded = hasattr(graph, 'part')
-        if loss_rows is not None and (not ops.loss_rows_enabled() or loss_rows[0].shape[0] != self.gout.shape[0] or (residual and self.sharded)):
-            # ('Residual' on row shards: the gradient that enters a layer's reverse aggregation lives on the UNION of two supports — the level
-            # orientations of dist.support_levels are not built for it; on one GPU the plan is taken with CUMULATIVE supports, see run())
+        if loss_rows is not None and (not ops.loss_rows_enabled() or loss_rows[0].shape[0] != self.gout.shape[0]):
             loss_rows = None
         self.loss_rows = loss_rows
         # the gradient reaching X0 through the mixes: 'Initial' — every layer's, gathered in one pass by the input stage (the per-layer gradients
@@ -680,7 +678,8 @@ class _Backward:
         self.sh_levels = []
         if sharded and hasattr(graph, 'support_levels') and self.loss_rows is not None:
             ops.check_rows_zero(gout, self.loss_rows[0])
-            self.sh_levels = graph.support_levels(self.loss_rows[0], L, compact=self.ag and gather and not self.tail_tb)
+            # ('Residual': CUMULATIVE supports, as on one GPU below)
+            self.sh_levels = graph.support_levels(self.loss_rows[0], L, compact=self.ag and gather and not self.tail_tb, cumulative=self.residual)
         # Row-sparse backward (one GPU): when the caller promised that only the loss rows of gout carry gradient, what the backward makes of it
         # stays zero outside the rows those can reach: after the j-th reverse aggregation only the rows with a neighbour in the previous support
         # carry gradient (CSRGraph.grad_support_plan: S_0 = loss rows, S_1, ... — 10 % / 45 % / 94 % of the rows on the bench's graph with its

@@ -18,6 +18,8 @@ ARGV = ['--dataset=S-pubmed', '--use_special_split=0', '--want_headtail=0', '--w
         '--num_layers=2', '--manual_assign_GPU=0', '--do_deg_analyze=0']
 ARGV_BN = ['--dataset=S-pubmed', '--use_special_split=0', '--want_headtail=0', '--whetherHasSE=000', '--num_layers=2',
            '--manual_assign_GPU=0', '--do_deg_analyze=0', '--force_set_to_best_config=0', '--type_trick=BatchNorm']   # norm runs (bare name)
+ARGV_RES = ['--dataset=S-pubmed', '--use_special_split=0', '--want_headtail=0', '--whetherHasSE=000', '--num_layers=3',
+            '--manual_assign_GPU=0', '--do_deg_analyze=0', '--force_set_to_best_config=0', '--type_trick=Residual']   # 'Residual' trunk (round 5)
 SEEDS = list(range(7000, 7040))
 STEPS = 3
 
@@ -73,7 +75,7 @@ def _worker(rank, world, port, exchange, overlap, partition, argv, q, wire='f32'
         assert (not conv0.whetherHasSE) or conv0.le.shape[0] == t.part.n_local
         ops._seed_override[:] = list(SEEDS)
         losses = [float(t.train_step()) for _ in range(STEPS)]
-        if argv is ARGV or '--whetherHasSE=111' in argv:
+        if argv is ARGV or '--whetherHasSE=111' in argv or '--type_trick=Residual' in argv:
             # the fused trunk (S-pubmed: hidden 256, 'Initial'): its backward went through the level orientations of the row-sparse backward
             # (dist.ShardedGraph.support_orients: 10 % train rows -> level 0 keeps a tenth of the reverse edges)
             assert t.sgraph._support_cache is not None and len(t.sgraph._support_cache[2]) >= 1, 'row-sparse level orientations not used'
@@ -84,7 +86,7 @@ def _worker(rank, world, port, exchange, overlap, partition, argv, q, wire='f32'
             assert (lv0.src is not None) == bool(trunk.agg_gemm_eligible(t.sgraph, 256, False)), 'compact levels not used where the plan allows them'
             if lv0.src is not None:
                 assert 0 < lv0.src.n < t.part.n_local
-        if overlap == '1' and exchange == 'halo' and wire == 'f32' and (argv is ARGV or '--whetherHasSE=111' in argv):
+        if overlap == '1' and exchange == 'halo' and wire == 'f32' and (argv is ARGV or '--whetherHasSE=111' in argv or '--type_trick=Residual' in argv):
             # round 5: the trunk allocates the matrices it exchanges with room behind them (dist.alloc_exchanged), so the interior pass and the first
             # halo slice ran as ONE pass ([local | slice 0], dist._Orientation.first) wherever a producer of the trunk wrote the matrix
             assert t.sgraph.merged_passes > 0, (t.sgraph.merged_passes, t.sgraph.interior_passes)
@@ -115,10 +117,12 @@ def _free_port():
     ('halo', '1', 'edges', ARGV_BN, 'f32', 2, '2', '1'),
     # the pull-only plan (COLDBREW_HALO_COVER=0): sliced by owner row chunk with row-chunked producers; unsliced with the aggregation + GEMM
     # kernel as its last halo pass
-    ('halo', '1', 'edges', ARGV, 'f32', 2, '3', '0'), ('halo', '1', 'edges', ARGV, 'f32', 3, '', '0'), ('halo', '1', 'edges', ARGV, 'bf16', 2, '2', '0')],
+    ('halo', '1', 'edges', ARGV, 'f32', 2, '3', '0'), ('halo', '1', 'edges', ARGV, 'f32', 3, '', '0'), ('halo', '1', 'edges', ARGV, 'bf16', 2, '2', '0'),
+    # the 'Residual' trunk on shards: cumulative supports, the second gradient of a store backward compact (cover) / row-chunked (pull, sliced)
+    ('halo', '1', 'edges', ARGV_RES, 'f32', 2, '', '1'), ('halo', '1', 'edges', ARGV_RES, 'f32', 3, '2', '0')],
     ids=['cover-overlap-edges', 'halo-singlepass-rows', 'allgather', 'batchnorm-cover-overlap', 'cover-bf16-wire', 'three-ranks-cover',
          'cover-sliced3', 'three-ranks-cover-sliced4', 'cover-sliced2-bf16-wire', 'batchnorm-cover-sliced2',
-         'pull-sliced3', 'pull-three-ranks', 'pull-sliced2-bf16-wire-chunked-producers'])
+         'pull-sliced3', 'pull-three-ranks', 'pull-sliced2-bf16-wire-chunked-producers', 'residual-cover', 'residual-three-ranks-pull-sliced2'])
 def test_two_ranks_on_one_gpu_match_single_process(exchange, overlap, partition, argv, wire, world, slices, cover):
     _ranks_match_single_process(exchange, overlap, partition, argv, wire, world, slices, cover, 'gloo')
 

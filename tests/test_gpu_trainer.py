@@ -109,7 +109,12 @@ def test_cli_end_to_end_tiny():
 
 
 @pytest.mark.parametrize('extra', [['--dataset=S-tiny', '--want_headtail=1', '--use_special_split=1', '--whetherHasSE=111', '--se_reg=0.5'],
-                                   ['--dataset=S-pubmed', '--want_headtail=0', '--use_special_split=0', '--do_deg_analyze=0']])
+                                   ['--dataset=S-pubmed', '--want_headtail=0', '--use_special_split=0', '--do_deg_analyze=0'],
+                                   # round 5: the other two default trunk shapes through their fused nodes (trunk 'Residual', stack.py NoRes) under replay
+                                   ['--dataset=S-pubmed', '--want_headtail=0', '--use_special_split=0', '--do_deg_analyze=0', '--force_set_to_best_config=0',
+                                    '--type_trick=Residual'],
+                                   ['--dataset=S-pubmed', '--want_headtail=0', '--use_special_split=0', '--do_deg_analyze=0', '--force_set_to_best_config=0',
+                                    '--type_trick=NoResNodeNorm']])
 def test_epoch_loop_replayed_as_hip_graphs_matches_eager(extra):
     """--hip_graph=1: run_trainSet's step and run_testSet's eval forward replayed as hipGraphs give the records of the eager epoch
     loop (dropout 0 so that both draw the same data gradients): test accuracy and head/tail/isolation rows, final weights."""
