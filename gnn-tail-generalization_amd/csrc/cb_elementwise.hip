@@ -173,6 +173,14 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
     if constexpr (RIDX) {
       if (r_begin + w < r_end) rr_next = ridx[r_begin + w];
     }
+    // g is read once (streaming); the NEXT row's 1 KiB is requested before this row is worked on: at full occupancy (8 wavefronts per SIMD) one
+    // row in flight per wavefront keeps only 32 KB per CU outstanding — 4 TB/s at the ~2 us these loads take; two rows double that
+    float gn[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r_begin + w < r_end) {
+      const int64_t o0 = (r_begin + w) * d + c;
+      gn[0] = __builtin_nontemporal_load(g + o0); gn[1] = __builtin_nontemporal_load(g + o0 + 1);
+      gn[2] = __builtin_nontemporal_load(g + o0 + 2); gn[3] = __builtin_nontemporal_load(g + o0 + 3);
+    }
     for (int64_t r = r_begin + w; r < r_end; r += kBlock / kWave) {
       const int64_t off = r * d + c;
       int64_t rr = r;      // the row of the full matrix this row is
@@ -180,9 +188,22 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
         rr = rr_next;
         if (r + kBlock / kWave < r_end) rr_next = ridx[r + kBlock / kWave];
       }
-      // g is read once (streaming)
-      float gm[4] = {__builtin_nontemporal_load(g + off), __builtin_nontemporal_load(g + off + 1), __builtin_nontemporal_load(g + off + 2),
-                     __builtin_nontemporal_load(g + off + 3)};
+      float gm[4] = {gn[0], gn[1], gn[2], gn[3]};
+      // (this row's mask words and scale are requested BEFORE the next row's gradient: loads return in order, so waiting for them must not
+      // mean waiting for the prefetch)
+      unsigned long long bwr[4] = {0ull, 0ull, 0ull, 0ull};
+      float sc_r = 1.f;
+      if (MODE == 0) {
+        const unsigned long long* bwp = bits + (rr * tiles + tile) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bwr[k] = bwp[k];
+        sc_r = row_scale ? row_scale[rr] : 1.f;
+      }
+      if (r + kBlock / kWave < r_end) {
+        const int64_t o1 = off + (int64_t)(kBlock / kWave) * d;
+        gn[0] = __builtin_nontemporal_load(g + o1); gn[1] = __builtin_nontemporal_load(g + o1 + 1);
+        gn[2] = __builtin_nontemporal_load(g + o1 + 2); gn[3] = __builtin_nontemporal_load(g + o1 + 3);
+      }
       if (thresh) {
         float m[4];
         keep4(seed, ((row0 + rr) * d + c) >> 2, thresh, keep_scale, m);
@@ -196,7 +217,7 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
           a.x += c_mix * gm[0]; a.y += c_mix * gm[1]; a.z += c_mix * gm[2]; a.w += c_mix * gm[3];
           *reinterpret_cast<float4*>(gx0 + off) = a;
         }
-        const unsigned long long* bw = bits + (rr * tiles + tile) * 4;
+        const unsigned long long* bw = bwr;
         if (g2) {      // (uniform) second gradient through the same ReLU, under the next layer's dropout mask
           const int64_t p2 = g2_pos ? (int64_t)__builtin_amdgcn_readfirstlane(g2_pos[rr]) : (RIDX ? rr : r);      // (wave-uniform row)
           const int64_t off2 = (p2 < 0 ? 0 : p2) * d + c;
@@ -223,14 +244,18 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
         gy[2] = x.z > 0.f ? a.z + gm[2] : 0.f;
         gy[3] = x.w > 0.f ? a.w + gm[3] : 0.f;
       }
-      const float sc = row_scale ? row_scale[rr] : 1.f;
+      const float sc = MODE == 0 ? sc_r : (row_scale ? row_scale[rr] : 1.f);
 #pragma unroll
       for (int k = 0; k < 4; ++k) s[k] += gy[k];
       if constexpr (!STORE) continue;
       else if constexpr (OUT_BF16)
         *reinterpret_cast<uint2*>((bf16_t*)outv + off) = pack4_bf16(gy[0] * sc, gy[1] * sc, gy[2] * sc, gy[3] * sc);
       else
-        *reinterpret_cast<float4*>((float*)outv + off) = make_float4(gy[0] * sc, gy[1] * sc, gy[2] * sc, gy[3] * sc);
+      {      // written once, gathered by the next kernel: streaming store
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        const f4_t q = {gy[0] * sc, gy[1] * sc, gy[2] * sc, gy[3] * sc};
+        __builtin_nontemporal_store(q, reinterpret_cast<f4_t*>((float*)outv + off));
+      }
     }
     if (partial) {
 #pragma unroll
@@ -329,7 +354,11 @@ __global__ void __launch_bounds__(kBlock) k_trunk_input_bwd_multi(const float* _
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) s[k] += gy[k];
-      *reinterpret_cast<float4*>(out + off) = make_float4(gy[0], gy[1], gy[2], gy[3]);
+      {      // written once, streamed by the weight-gradient GEMM that follows
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        const f4_t q = {gy[0], gy[1], gy[2], gy[3]};
+        __builtin_nontemporal_store(q, reinterpret_cast<f4_t*>(out + off));
+      }
     }
     if (partial) {
 #pragma unroll
