@@ -577,6 +577,14 @@ def main():
         sharding['exchange_span_ms_per_rank'] = [round(float(v[0]), 3) for v in allst]     # first send issued -> last slice waited for, per aggregation
         sharding['exchanges_per_step'] = [round(float(v[1]), 2) for v in allst]
         sharding['local_aggregation_kernel_ms_per_step_per_rank'] = [round(float(v[2]), 3) for v in allst]
+        # (rank 0's view) how the aggregations of the timed steps ran: merged first pass ([local | slice 0]) vs a separate interior pass, and the
+        # levels of the row-sparse backward with the rows this rank reads / writes on each (None = all local rows)
+        sg_ = t.sgraph
+        sharding['first_pass_rank0'] = {'merged': int(sg_.merged_passes), 'interior_only': int(sg_.interior_passes)}
+        cache_ = getattr(sg_, '_support_cache', None)
+        sharding['row_sparse_levels_rank0'] = ([{'edges': int(lv.orient.E), 'rows_read': (lv.src.n if lv.src is not None else None),
+                                                 'rows_written': (lv.dst.n if lv.dst is not None else None), 'halo_rows': int(lv.orient.plan.n_halo)}
+                                                for lv in cache_[2]] if cache_ is not None else [])
         dist.barrier()
         dist.destroy_process_group()
     if rank != 0:

@@ -337,3 +337,24 @@ def test_sharded_checkpoint_resume_and_model_artifact(tmp_path):
     for _, _, _, le, w, (lo, hi) in straight:
         np.testing.assert_array_equal(le_full[lo:hi], le)
         np.testing.assert_array_equal(ref.teacherGNN.model.model.layers_GCN[1].weight.detach().cpu().numpy(), w)
+
+
+def test_bench_gpus_n_without_a_launcher_runs_n_ranks():
+    """`python bench.py --gpus 2` started WITHOUT torch.distributed.run (no WORLD_SIZE) re-executes itself as two ranks (here: gloo
+    dry run, both on the box's single GPU) and prints ONE JSON line that says n_gpus = 2, with the sharding self-diagnosis: both ranks seen, the
+    sharded loss equal to the single-GPU loss of the same weights and seeds, row-sparse levels and the merged first pass in use."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['COLDBREW_DIST_BACKEND'] = 'gloo'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dataset', 'S-arxiv', '--steps', '3', '--warmup', '1',
+                        '--cpu-baseline', '0', '--pmc-traffic', '0', '--ref-epochs', '0'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['value'] > 0
+    sh = d['sharding']
+    assert sh['ranks_seen'] == [0, 1] and sh['backend'] == 'gloo' and sh['loss_matches_n1'] is True, sh
+    assert sum(sh['rows_per_rank']) == 169343
+
