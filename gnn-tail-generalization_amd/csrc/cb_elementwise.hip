@@ -791,7 +791,7 @@ extern "C" int cb_act_bwd_f32(const float* g, const float* act, const float* row
   return CB_OK;
 }
 
-// Rows of g outside `mask` must be exactly zero (the claim a row-sparse backward rests on: ops.take_grad_rows / trunk.py).  A streaming pass
+// Rows of g outside `mask` must be exactly zero (the promise a row-sparse backward rests on: the loss_rows argument of the forward, ops.py / trunk.py).  A streaming pass
 // over the matrix (contiguous rows: float4 per thread, the row of an element by one division); a violation is recorded in the device error
 // word (never silent: cb_device_status reports it) and, if given, in the caller's `guard` word in device memory: an optimiser launch that
 // follows on the same stream and is handed the same word leaves parameters and moments untouched (the truncated gradients never reach them).

@@ -10,11 +10,12 @@ CORNELL / TEXAS ('Residual…', base_options.py:416-421) and the benchmark graph
 with the hand-written backward.  Forward: ONE kernel for the front (dropout(x), input Linear, ReLU, dropout(X0) and layer 0's
 transform: cb_trunk_front_f32; hidden 256, 64 / 128 input features), then one kernel per layer — the aggregation with its
 ReLU-mask / mix / dropout store AND the next layer's transform (cb_spmm_gemm_fused_f32; the last layer: cb_spmm_csr_fused_f32) —
-and the output Linear.  Backward per layer: reverse aggregation + dX contraction in one kernel (cb_spmm_gemm_f32), the weight-gradient
+and the output Linear (in forwards without a backward: the narrow tail of the last aggregation, cb_spmm_gemm_fused_head_f32).  Backward per layer: reverse aggregation + dX contraction in one kernel (cb_spmm_gemm_f32), the weight-gradient
 GEMM, one fused elementwise pass (cb_trunk_layer_bwd_f32); ReLU masks are kept as bits, dropout masks are regenerated, the gradient
 w.r.t. X0 is gathered in one pass by the input stage.  Other widths, bf16-stored rows and node-sharded pull plans take the same node with
 one kernel per stage.  Same arithmetic and the same sequence of dropout seeds as the modular path (ops.py), which stays the general
 fallback; every fused form is bit-identical to the kernels it replaces (tests/test_gpu_agg_gemm.py, test_gpu_kernels.py, test_gpu_fullsize.py).
+The backward (_Backward) runs on the rows that carry gradient when the caller promised `loss_rows` ("Row-sparse backward").
 """
 import ctypes
 import os
