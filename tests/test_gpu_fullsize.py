@@ -156,6 +156,20 @@ def test_aggregation_gemm_kernels_full_size(pl10m_graph):
     assert torch.equal(bits, bits_r) and torch.equal(nxt, nxt_r)
     del bits, bits_r, nxt, x0
     assert torch.equal(zn, gemm.mm_nn(nxt_r, w, rowscale=a, addend=le))
+    del zn
+    # round 5: the output Linear (40 classes) as the narrow tail of the LAST layer's store, training and evaluation form
+    from gnn_tail_generalization_amd.graph import head_image
+    w_out = torch.randn(40, d, device=DEV, generator=gen) * 0.06
+    b_out = torch.randn(40, device=DEV, generator=gen)
+    want = gemm.mm_nn(nxt_r, w_out.t().contiguous(), bias=b_out)
+    x0 = torch.randn(n, d, device=DEV, generator=gen)      # (another mix source than above: only the logits of the two forms are compared here)
+    bits_r, nxt_r, _ = trunk._fused_spmm(G, h, bias, x0, 1 - alpha, alpha, p, seed)
+    want = gemm.mm_nn(nxt_r, w_out.t().contiguous(), bias=b_out)
+    bits, nxt, logits = trunk._fused_gemm_launch(G, h, bias, x0, 1 - alpha, alpha, p, seed, head_image(w_out), None, None, head=(b_out, 40))
+    assert torch.equal(bits, bits_r) and torch.equal(nxt, nxt_r) and torch.equal(logits, want)
+    del bits, bits_r, nxt, nxt_r, logits
+    _b, _n, logits = trunk._fused_gemm_launch(G, h, bias, x0, 1 - alpha, alpha, p, seed, head_image(w_out), None, None, want_bits=False, head=(b_out, 40))
+    assert _b is None and _n is None and torch.equal(logits, want)
     torch.cuda.synchronize()
     _lib.device_status()              # raises if any tile hand-over timed out
 
