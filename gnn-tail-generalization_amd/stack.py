@@ -8,19 +8,20 @@ One autograd node with the fused trunk's kernels (trunk.py): the dropout in fron
 (cb_gemm_nn_indrop_f32), every hidden layer's aggregation stores ReLU mask words and the DROPPED activation in one pass (cb_spmm_csr_fused_f32
 without a mix source) and — between two hidden layers — also yields the next layer's transform (cb_spmm_gemm_fused_f32); the backward runs the
 reverse aggregation + dX contraction as one kernel (cb_spmm_gemm_f32), keeps ReLU masks as bits and regenerates dropout masks.  Hidden width
-256 (the fused store's row layout), one GPU; every other shape takes the operator path (GCN.py _forward_modular), whose arithmetic and sequence
+256 (the fused store's row layout), one GPU or row shards (dist.ShardedGraph: the exchanges run inside the same helpers as the trunk's, the
+reverse aggregation + dX kernel as the last halo pass); every other shape takes the operator path (GCN.py _forward_modular), whose arithmetic and sequence
 of dropout seeds this node reproduces (tests/test_gpu_model.py::test_fused_stack_equals_modular_path; goldens case_nr_h256_*)."""
 import torch
 
 from . import gemm, ops
-from .trunk import _fused_gemm, _fused_spmm, _layer_bwd, agg_gemm_eligible
+from .trunk import _exchanged, _fused_gemm, _fused_spmm, _layer_bwd, _spmm_t, agg_gemm_eligible
 
 
 def eligible(tc, x, graph, want_les):
     return (not tc.has_residual_MLP and not want_les and tc.dim_hidden == 256 and tc.num_layers >= 2 and len(tc.layers_GCN) == tc.num_layers
             and tc.args.type_trick not in ('BatchNorm', 'PairNorm', 'NodeNorm', 'MeanNorm', 'GroupNorm', 'CombNorm')
-            and x.is_cuda and x.dtype == torch.float32 and not hasattr(graph, 'part') and getattr(tc.args, 'agg_dtype', 'f32') == 'f32'
-            and tc.args.dropout == tc.dropout and hasattr(graph, 'spmm_gemm'))
+            and x.is_cuda and x.dtype == torch.float32 and getattr(tc.args, 'agg_dtype', 'f32') == 'f32'
+            and tc.args.dropout == tc.dropout and (hasattr(graph, 'spmm_gemm') or hasattr(graph, 'part')))
 
 
 class _StackFn(torch.autograd.Function):
@@ -29,15 +30,16 @@ class _StackFn(torch.autograd.Function):
         """layer_params = (W_0, bias_0, le_0 | None, W_1, ...).  cfg = (L, p, seeds[L + 1], track)."""
         L, p, seeds, track = cfg
         a, b = graph.norm_out, graph.norm_in
+        row0 = int(getattr(graph, 'row_offset', 0))       # first global row of this rank's block (dropout masks are those of the unsharded tensor)
         x = x.contiguous()
         bwd = bool(track) and any(ctx.needs_input_grad)
         w0, _b0, le0 = layer_params[0:3]
         # layer 0: Z_0 = a * (dropout(x) W_0) + E_0, the dropout applied while the GEMM stages x where that form exists
-        z = gemm.mm_nn_indrop(x, w0, p, seeds[0], 0, rowscale=a, addend=le0) if p > 0 else None
+        z = gemm.mm_nn_indrop(x, w0, p, seeds[0], row0, rowscale=a, addend=le0, out=_exchanged(graph, x.shape[0], w0.shape[1])) if p > 0 else None
         ctx.indrop = z is not None
         if z is None:
-            xd0 = ops._dropout_raw(x, p, seeds[0], 0) if p > 0 else x
-            z = gemm.mm_nn(xd0, w0, rowscale=a, addend=le0)
+            xd0 = ops._dropout_raw(x, p, seeds[0], row0 * x.shape[1]) if p > 0 else x
+            z = gemm.mm_nn(xd0, w0, rowscale=a, addend=le0, out=_exchanged(graph, x.shape[0], w0.shape[1]))
         else:
             xd0 = x                       # kept for the backward: the UNdropped features (the weight gradient regenerates the mask)
         ag = agg_gemm_eligible(graph, 256, False)
@@ -55,14 +57,15 @@ class _StackFn(torch.autograd.Function):
                 bits, cur, z_ready = _fused_gemm(graph, z, bias, None, 1.0, 0.0, p, sd, weight_image(w1), a, le1, want_bits=bwd)[:3]
             else:
                 bits, cur, _ = _fused_spmm(graph, z, bias, None, 1.0, 0.0, p, sd, want_bits=bwd)
-                z = gemm.mm_nn(cur, w1, rowscale=a, addend=le1)
+                z = gemm.mm_nn(cur, w1, rowscale=a, addend=le1, out=_exchanged(graph, cur.shape[0], w1.shape[1]) if w1.shape[1] % 4 == 0 else None)
             if bwd:
                 saved_bits.append(bits)
                 saved_in.append(cur)
         z = z_ready if z_ready is not None else z
         bias_last = layer_params[3 * (L - 1) + 1]
-        y = graph.spmm(z, row_scale=b, bias=bias_last)                           # the last layer: no ReLU (GCN.py:127)
-        out = ops._dropout_raw(y, p, seeds[L], 0) if p > 0 else y                 # dropout on the logits (GCN.py:133)
+        # the last layer: no ReLU (GCN.py:127); then the dropout on the logits (GCN.py:133)
+        y = graph.aggregate(z, False, b, bias_last, False) if hasattr(graph, 'part') else graph.spmm(z, row_scale=b, bias=bias_last)
+        out = ops._dropout_raw(y, p, seeds[L], row0 * y.shape[1]) if p > 0 else y
         ctx.graph, ctx.cfg = graph, cfg
         if bwd:
             ctx.save_for_backward(*saved_in, *saved_bits, *[t for t in layer_params if t is not None])
@@ -84,6 +87,8 @@ class _StackFn(torch.autograd.Function):
                 k += 1
             lp.append((w, bias, le))
         a, b = graph.norm_out, graph.norm_in
+        row0 = int(getattr(graph, 'row_offset', 0))
+        sharded = hasattr(graph, 'part')
         need = ctx.needs_input_grad          # (graph, cfg, x, *layer_params)
         nw = lambda l: need[3 + 3 * l]       # noqa: E731
         nb = lambda l: need[3 + 3 * l + 1]   # noqa: E731
@@ -91,9 +96,9 @@ class _StackFn(torch.autograd.Function):
         grads = [None] * (3 * L)
         ag = agg_gemm_eligible(graph, 256, False)
         # last layer: dropout on the logits, bias, degree norm, reverse aggregation at the class width
-        gd = ops._dropout_raw(gemm._rowmajor(gout), p, seeds[L], 0) if p > 0 else gemm._rowmajor(gout)
+        gd = ops._dropout_raw(gemm._rowmajor(gout), p, seeds[L], row0 * gout.shape[1]) if p > 0 else gemm._rowmajor(gout)
         gr, grads[3 * (L - 1) + 1] = ops.act_bwd(gd, None, b, want_out=True, want_colsum=nb(L - 1))
-        gz = graph.spmm(gr, transpose=True)
+        gz = _spmm_t(graph, gr)
         w_last = lp[L - 1][0]
         if nw(L - 1):
             grads[3 * (L - 1)] = gemm.mm_tn(saved_in[L - 1], gz, rowscale=a)
@@ -103,22 +108,28 @@ class _StackFn(torch.autograd.Function):
         del gd, gr, gz
         for l in range(L - 2, -1, -1):
             w = lp[l][0]
-            gr, grads[3 * l + 1] = _layer_bwd(g, saved_bits[l], b, None, False, p, seeds[l + 1] if p > 0 else 0, 0, 1.0, 0.0, nb(l))
+            gr, grads[3 * l + 1] = _layer_bwd(g, saved_bits[l], b, None, False, p, seeds[l + 1] if p > 0 else 0, row0, 1.0, 0.0, nb(l),
+                                              out=_exchanged(graph, g.shape[0], g.shape[1]) if sharded else None)
             del g
             g = None
-            if ag and l > 0:             # dL/dZ_l = A (b * dY') and a * (dL/dZ_l W_l^T) from one kernel
+            if ag and l > 0:             # dL/dZ_l = A (b * dY') and a * (dL/dZ_l W_l^T) from one kernel (sharded: as the last halo pass)
                 from .graph import weight_image
-                gz, g = graph.spmm_gemm(gr, weight_image(w, transpose=True), transpose=True, g_rowscale=a)
+                img = weight_image(w, transpose=True)
+                if sharded:
+                    gz, g = graph.aggregate_finish(graph.aggregate_start(gr, True), True,
+                                                   last_pass=lambda csr, recv, acc: csr.spmm_gemm(recv, img, transpose=False, g_rowscale=a, acc_init=acc))
+                else:
+                    gz, g = graph.spmm_gemm(gr, img, transpose=True, g_rowscale=a)
             else:
-                gz = graph.spmm(gr, transpose=True)
+                gz = _spmm_t(graph, gr)
                 if l > 0 or need[2]:
                     g = gemm.mm_nn(gz, w.t().contiguous(), rowscale=a)
             del gr
             if nw(l):
                 if l == 0 and ctx.indrop:      # the mask of the dropout in front of layer 0 is regenerated while the GEMM stages x
-                    dw = gemm.mm_tn_adrop(saved_in[0], gz, p, seeds[0], 0, rowscale=a)
+                    dw = gemm.mm_tn_adrop(saved_in[0], gz, p, seeds[0], row0, rowscale=a)
                     if dw is None:
-                        dw = gemm.mm_tn(ops._dropout_raw(saved_in[0], p, seeds[0], 0), gz, rowscale=a)
+                        dw = gemm.mm_tn(ops._dropout_raw(saved_in[0], p, seeds[0], row0 * saved_in[0].shape[1]), gz, rowscale=a)
                     grads[0] = dw
                 else:
                     grads[3 * l] = gemm.mm_tn(saved_in[l], gz, rowscale=a)
@@ -127,7 +138,7 @@ class _StackFn(torch.autograd.Function):
             del gz
         d_x = None
         if need[2]:
-            d_x = ops._dropout_raw(g, p, seeds[0], 0) if p > 0 else g
+            d_x = ops._dropout_raw(g, p, seeds[0], row0 * g.shape[1]) if p > 0 else g
         return (None, None, d_x, *grads)
 
 
@@ -142,6 +153,9 @@ def forward(tc, x, graph):
         params += [conv.weight, conv.bias, le]
         if le is not None:
             reg = ops.frobenius_norm(le)
+            if hasattr(graph, 'part'):      # row shards: the norm is over all ranks' rows
+                from .dist import allreduce_sum
+                reg = allreduce_sum(reg * reg, graph.group).sqrt()
             conv.se_norm = reg.detach()
             se_reg_all = reg if se_reg_all is None else se_reg_all + reg
     if not all(c._allow_zero_in_degree for c in tc.layers_GCN):      # GCN.py:187-197

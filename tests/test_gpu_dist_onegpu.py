@@ -20,6 +20,8 @@ ARGV_BN = ['--dataset=S-pubmed', '--use_special_split=0', '--want_headtail=0', '
            '--manual_assign_GPU=0', '--do_deg_analyze=0', '--force_set_to_best_config=0', '--type_trick=BatchNorm']   # norm runs (bare name)
 ARGV_RES = ['--dataset=S-pubmed', '--use_special_split=0', '--want_headtail=0', '--whetherHasSE=000', '--num_layers=3',
             '--manual_assign_GPU=0', '--do_deg_analyze=0', '--force_set_to_best_config=0', '--type_trick=Residual']   # 'Residual' trunk (round 5)
+ARGV_NR = ['--dataset=S-pubmed', '--use_special_split=0', '--want_headtail=0', '--whetherHasSE=111', '--se_reg=0.5', '--num_layers=3',
+           '--manual_assign_GPU=0', '--do_deg_analyze=0', '--force_set_to_best_config=0', '--type_trick=NoResNodeNorm']   # non-residual stack (round 5)
 SEEDS = list(range(7000, 7040))
 STEPS = 3
 
@@ -73,9 +75,15 @@ def _worker(rank, world, port, exchange, overlap, partition, argv, q, wire='f32'
             assert t.sgraph.f.plan.n_slices == int(slices) and len(t.sgraph.f.halo) == int(slices)
         conv0 = t.teacherGNN.model.model.layers_GCN[0]
         assert (not conv0.whetherHasSE) or conv0.le.shape[0] == t.part.n_local
+        from gnn_tail_generalization_amd import stack
+        stack_calls, real_apply = [], stack._StackFn.apply
+        stack._StackFn.apply = staticmethod(lambda *a_, **k_: (stack_calls.append(1), real_apply(*a_, **k_))[1])
         ops._seed_override[:] = list(SEEDS)
         losses = [float(t.train_step()) for _ in range(STEPS)]
-        if argv is ARGV or '--whetherHasSE=111' in argv or '--type_trick=Residual' in argv:
+        nores = '--type_trick=NoResNodeNorm' in argv
+        if nores:
+            assert stack_calls, 'the non-residual stack did not run as its fused node on the shards'
+        if (argv is ARGV or '--whetherHasSE=111' in argv or '--type_trick=Residual' in argv) and not nores:
             # the fused trunk (S-pubmed: hidden 256, 'Initial'): its backward went through the level orientations of the row-sparse backward
             # (dist.ShardedGraph.support_orients: 10 % train rows -> level 0 keeps a tenth of the reverse edges)
             assert t.sgraph._support_cache is not None and len(t.sgraph._support_cache[2]) >= 1, 'row-sparse level orientations not used'
@@ -119,10 +127,13 @@ def _free_port():
     # kernel as its last halo pass
     ('halo', '1', 'edges', ARGV, 'f32', 2, '3', '0'), ('halo', '1', 'edges', ARGV, 'f32', 3, '', '0'), ('halo', '1', 'edges', ARGV, 'bf16', 2, '2', '0'),
     # the 'Residual' trunk on shards: cumulative supports, the second gradient of a store backward compact (cover) / row-chunked (pull, sliced)
-    ('halo', '1', 'edges', ARGV_RES, 'f32', 2, '', '1'), ('halo', '1', 'edges', ARGV_RES, 'f32', 3, '2', '0')],
+    ('halo', '1', 'edges', ARGV_RES, 'f32', 2, '', '1'), ('halo', '1', 'edges', ARGV_RES, 'f32', 3, '2', '0'),
+    # the non-residual stack (stack.py) on shards: widths F -> H -> H -> C, SE tables on every layer, dropout on the logits
+    ('halo', '1', 'edges', ARGV_NR, 'f32', 2, '', '1'), ('halo', '1', 'edges', ARGV_NR, 'f32', 3, '2', '0'), ('halo', '0', 'rows', ARGV_NR, 'f32', 2, '', '1')],
     ids=['cover-overlap-edges', 'halo-singlepass-rows', 'allgather', 'batchnorm-cover-overlap', 'cover-bf16-wire', 'three-ranks-cover',
          'cover-sliced3', 'three-ranks-cover-sliced4', 'cover-sliced2-bf16-wire', 'batchnorm-cover-sliced2',
-         'pull-sliced3', 'pull-three-ranks', 'pull-sliced2-bf16-wire-chunked-producers', 'residual-cover', 'residual-three-ranks-pull-sliced2'])
+         'pull-sliced3', 'pull-three-ranks', 'pull-sliced2-bf16-wire-chunked-producers', 'residual-cover', 'residual-three-ranks-pull-sliced2',
+         'nores-cover', 'nores-three-ranks-pull-sliced2', 'nores-singlepass-rows'])
 def test_two_ranks_on_one_gpu_match_single_process(exchange, overlap, partition, argv, wire, world, slices, cover):
     _ranks_match_single_process(exchange, overlap, partition, argv, wire, world, slices, cover, 'gloo')
 
