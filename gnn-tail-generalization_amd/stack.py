@@ -14,7 +14,8 @@ of dropout seeds this node reproduces (tests/test_gpu_model.py::test_fused_stack
 import torch
 
 from . import gemm, ops
-from .trunk import _exchanged, _fused_gemm, _fused_spmm, _layer_bwd, _spmm_t, agg_gemm_eligible
+from .trunk import _exchanged, _fused_gemm, _fused_spmm, _layer_bwd, _layer_bwd_rows, _spmm_t, agg_gemm_eligible
+from .tuning import T
 
 
 def eligible(tc, x, graph, want_les):
@@ -27,8 +28,9 @@ def eligible(tc, x, graph, want_les):
 class _StackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph, cfg, x, *layer_params):
-        """layer_params = (W_0, bias_0, le_0 | None, W_1, ...).  cfg = (L, p, seeds[L + 1], track)."""
-        L, p, seeds, track = cfg
+        """layer_params = (W_0, bias_0, le_0 | None, W_1, ...).  cfg = (L, p, seeds[L + 1], track, loss_rows): loss_rows = None or (bool mask [N],
+        count), the caller's promise that the output receives gradient in those rows only (ops.py "Row-sparse backward")."""
+        L, p, seeds, track, _loss_rows = cfg
         a, b = graph.norm_out, graph.norm_in
         row0 = int(getattr(graph, 'row_offset', 0))       # first global row of this rank's block (dropout masks are those of the unsharded tensor)
         x = x.contiguous()
@@ -74,7 +76,7 @@ class _StackFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        graph, (L, p, seeds, _track) = ctx.graph, ctx.cfg
+        graph, (L, p, seeds, _track, loss_rows) = ctx.graph, ctx.cfg
         sv = list(ctx.saved_tensors)
         saved_in, saved_bits, rest = sv[:L], sv[L: 2 * L - 1], sv[2 * L - 1:]
         lp, k = [], 0
@@ -95,23 +97,87 @@ class _StackFn(torch.autograd.Function):
         nle = lambda l: lp[l][2] is not None and need[3 + 3 * l + 2]      # noqa: E731
         grads = [None] * (3 * L)
         ag = agg_gemm_eligible(graph, 256, False)
+        gout = gemm._rowmajor(gout)
+        # Row-sparse backward (one GPU; trunk.py / DESIGN.md section 1): under the caller's loss_rows promise the levels of the backward whose support
+        # is small run on compact [|S_j|, .] matrices through the plan's renumbered orientations; the promise is checked on the device.
+        plan = None
+        if (loss_rows is not None and ops.loss_rows_enabled() and not sharded and loss_rows[0].shape[0] == gout.shape[0] and graph.rowptr_t is not None
+                and 1 <= loss_rows[1] <= T.rowsparse_s0_limit * gout.shape[0]
+                and (gout.shape[0] >= T.rowsparse_min_nodes or getattr(graph, 'rowsparse_small_ok', False)) and ag and graph.support_plan_pays()):
+            ops.check_rows_zero(gout, loss_rows[0])
+            plan = graph.grad_support_plan(loss_rows[0], L, max_frac=T.rowsparse_max_frac)
+        space = plan.space0 if plan is not None else None                        # row space of g / gr (None: all rows)
+
+        def level_of(j):
+            return plan.levels[j] if (plan is not None and space is not None and j < len(plan.levels)) else None
+
+        def rows_of(x_full, sp):
+            return ops.gather_rows_by_index(x_full, sp.idx) if sp is not None else x_full
+
+        def all_rows(gz_c, sp):      # a table's gradient is dL/dZ_l on ALL rows: the support's rows, zeros elsewhere
+            if sp is None:
+                return gz_c
+            if gz_c.shape[1] % 4 == 0:
+                return ops.expand_rows(gz_c, sp.pos)
+            out_ = torch.zeros((sp.pos.numel(), gz_c.shape[1]), dtype=gz_c.dtype, device=gz_c.device)
+            out_[sp.idx] = gz_c
+            return out_
         # last layer: dropout on the logits, bias, degree norm, reverse aggregation at the class width
-        gd = ops._dropout_raw(gemm._rowmajor(gout), p, seeds[L], row0 * gout.shape[1]) if p > 0 else gemm._rowmajor(gout)
+        gd = ops._dropout_raw(gout, p, seeds[L], row0 * gout.shape[1]) if p > 0 else gout
         gr, grads[3 * (L - 1) + 1] = ops.act_bwd(gd, None, b, want_out=True, want_colsum=nb(L - 1))
-        gz = _spmm_t(graph, gr)
+        level = level_of(0)
+        if level is not None:            # gathers the loss rows only; writes S_1 (or all rows)
+            csr, dst = level
+            csr.profile = getattr(graph, 'profile', None)
+            gz = csr.spmm(rows_of(gr, space))
+            space = dst
+        else:
+            gz = _spmm_t(graph, gr)
+        a_sp = space.a if space is not None else a
         w_last = lp[L - 1][0]
         if nw(L - 1):
-            grads[3 * (L - 1)] = gemm.mm_tn(saved_in[L - 1], gz, rowscale=a)
+            grads[3 * (L - 1)] = gemm.mm_tn(rows_of(saved_in[L - 1], space), gz, rowscale=a_sp)
         if nle(L - 1):
-            grads[3 * (L - 1) + 2] = gz
-        g = gemm.mm_nn(gz, w_last.t().contiguous(), rowscale=a)                  # dL/d(dropped X_{L-1})
+            grads[3 * (L - 1) + 2] = all_rows(gz, space)
+        g = gemm.mm_nn(gz, w_last.t().contiguous(), rowscale=a_sp)               # dL/d(dropped X_{L-1}), on the rows of `space`
         del gd, gr, gz
         for l in range(L - 2, -1, -1):
             w = lp[l][0]
-            gr, grads[3 * l + 1] = _layer_bwd(g, saved_bits[l], b, None, False, p, seeds[l + 1] if p > 0 else 0, row0, 1.0, 0.0, nb(l),
-                                              out=_exchanged(graph, g.shape[0], g.shape[1]) if sharded else None)
+            sd_l = seeds[l + 1] if p > 0 else 0
+            if space is not None:
+                gr, grads[3 * l + 1] = _layer_bwd_rows(g, space.idx, saved_bits[l], b, p, sd_l, row0, 1.0, nb(l))
+            else:
+                gr, grads[3 * l + 1] = _layer_bwd(g, saved_bits[l], b, None, False, p, sd_l, row0, 1.0, 0.0, nb(l),
+                                                  out=_exchanged(graph, g.shape[0], g.shape[1]) if sharded else None)
             del g
             g = None
+            level = level_of(L - 1 - l)
+            if level is not None:        # a compact level of the plan: the level's own orientation, rows of S_{j+1} (or all rows) out
+                from .graph import weight_image
+                csr, dst = level
+                csr.profile = getattr(graph, 'profile', None)
+                a_dst = dst.a if dst is not None else a
+                if l > 0:
+                    gz, g = csr.spmm_gemm(gr, weight_image(w, transpose=True), transpose=False, g_rowscale=a_dst)
+                else:
+                    gz = csr.spmm(gr)
+                    if need[2]:
+                        g = gemm.mm_nn(gz, w.t().contiguous(), rowscale=a_dst)
+                del gr
+                if nw(l):
+                    if l == 0 and ctx.indrop and dst is None:
+                        dw = gemm.mm_tn_adrop(saved_in[0], gz, p, seeds[0], row0, rowscale=a)
+                        if dw is None:
+                            dw = gemm.mm_tn(ops._dropout_raw(saved_in[0], p, seeds[0], row0 * saved_in[0].shape[1]), gz, rowscale=a)
+                        grads[0] = dw
+                    else:
+                        x_in = saved_in[l] if not (l == 0 and ctx.indrop) else ops._dropout_raw(saved_in[0], p, seeds[0], row0 * saved_in[0].shape[1])
+                        grads[3 * l] = gemm.mm_tn(rows_of(x_in, dst), gz, rowscale=a_dst)
+                if nle(l):
+                    grads[3 * l + 2] = all_rows(gz, dst)
+                del gz
+                space = dst
+                continue
             if ag and l > 0:             # dL/dZ_l = A (b * dY') and a * (dL/dZ_l W_l^T) from one kernel (sharded: as the last halo pass)
                 from .graph import weight_image
                 img = weight_image(w, transpose=True)
@@ -142,8 +208,8 @@ class _StackFn(torch.autograd.Function):
         return (None, None, d_x, *grads)
 
 
-def forward(tc, x, graph):
-    """TricksComb.forward on the fused non-residual stack; returns (logits, se_reg_all)."""
+def forward(tc, x, graph, loss_rows=None):
+    """TricksComb.forward on the fused non-residual stack; returns (logits, se_reg_all).  loss_rows: as trunk.forward."""
     L = tc.num_layers
     p = float(tc.dropout) if tc.training else 0.0
     seeds = tuple(ops.next_seed() for _ in range(L + 1)) if p > 0 else (0,) * (L + 1)
@@ -160,5 +226,10 @@ def forward(tc, x, graph):
             se_reg_all = reg if se_reg_all is None else se_reg_all + reg
     if not all(c._allow_zero_in_degree for c in tc.layers_GCN):      # GCN.py:187-197
         graph.check_zero_in_degree()
-    out = _StackFn.apply(graph, (L, p, seeds, torch.is_grad_enabled()), x, *params)
+    if loss_rows is not None:
+        mask, count = loss_rows if isinstance(loss_rows, (tuple, list)) else (loss_rows, None)
+        if mask.dtype != torch.bool or mask.dim() != 1 or mask.shape[0] != x.shape[0]:
+            raise ValueError(f'loss_rows: a bool mask over the {x.shape[0]} rows expected, got {tuple(mask.shape)} {mask.dtype}')
+        loss_rows = (mask, int(count) if count is not None else int(mask.sum().item()))
+    out = _StackFn.apply(graph, (L, p, seeds, torch.is_grad_enabled(), loss_rows), x, *params)
     return out, se_reg_all

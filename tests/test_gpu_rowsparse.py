@@ -77,6 +77,19 @@ def test_row_sparse_backward_equals_the_dense_backward(max_frac, se, loss_side, 
         assert float((g_s[k] - g_d[k]).abs().max()) <= 5e-6 * scale, k
 
 
+@pytest.mark.parametrize('se,layers', [('000', 3), ('111', 3), ('000', 2), ('100', 4)])
+def test_row_sparse_backward_of_the_non_residual_stack_equals_its_dense_backward(se, layers):
+    """stack.py (NoRes: F -> H -> ... -> C, dropout on the logits): level 0 of the plan runs at the class width on the loss rows, the hidden levels
+    on compact matrices through the aggregation + dX kernel; gradients equal the dense backward's up to the association of sums."""
+    extra = ('--force_set_to_best_config=0', '--type_trick=NoResNodeNorm')
+    loss_s, g_s, used_s = _step_grads('1', se=se, layers=layers, extra=extra)
+    loss_d, g_d, used_d = _step_grads('0', se=se, layers=layers, extra=extra)
+    assert used_s and not used_d and loss_s == loss_d and set(g_s) == set(g_d)
+    for k in g_d:
+        scale = float(g_d[k].abs().max())
+        assert float((g_s[k] - g_d[k]).abs().max()) <= 5e-6 * scale, k
+
+
 @pytest.mark.parametrize('n_loss_rows', [3, 200, 20000])
 def test_row_sparse_backward_with_sparse_labels(n_loss_rows, monkeypatch):
     """Few loss rows (the public Planetoid splits label 0.3 - 5 % of the nodes): supports of 3 / 200 / 20 000 rows that grow by orders of
@@ -116,7 +129,8 @@ def test_row_sparse_backward_two_layers_small_graph(monkeypatch):
 
 
 @pytest.mark.parametrize('case', ['case_r_initialbn_h256_L3_train10', 'case_r_initialbn_h256_L3_train10_se111',
-                                  'case_r_residual_h256_L3_train10', 'case_r_residual_h256_L3_train10_se111'])      # (Residual, round 5: cumulative supports)
+                                  'case_r_residual_h256_L3_train10', 'case_r_residual_h256_L3_train10_se111',      # (Residual, round 5: cumulative supports)
+                                  'case_nr_h256_L3_train10', 'case_nr_h256_L3_train10_se111'])                    # (the non-residual stack, stack.py)
 def test_row_sparse_backward_matches_the_unmodified_reference(case, monkeypatch):
     """The reference's own gradients (goldens case_r_initialbn_h256_L3_train10[_se111]: hidden 256, 3 layers, 8 – 10 % train rows, without
     and with structural-embedding tables on every layer, generated from the unmodified reference by tests/golden/make_golden.py) against
