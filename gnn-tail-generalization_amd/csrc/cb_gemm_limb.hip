@@ -48,7 +48,8 @@ template <int WM, int WN, int WTN = 2, int PD = 1>
 struct LTile {
   static constexpr int BM = 64 * WM, BN = 32 * WTN * WN;
   static constexpr int MINW = (WM == 2 && WTN == 2 && PD < 3 ? 3 : 2);   // wavefronts per SIMD the registers must allow
-  static_assert(WM * WN == 4, "four wavefronts per block");
+  static constexpr int NTHR = 64 * WM * WN;                                // four wavefronts per block; eight for the 256 x 256 TN tile (round 5)
+  static_assert(WM * WN == 4 || WM * WN == 8, "four or eight wavefronts per block");
 };
 
 // ---- NN ------------------------------------------------------------------------------------
@@ -95,15 +96,15 @@ __global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_nn
 // GDROP: F.dropout of the G operand while it is staged (gd): the weight gradient of the input Linear reads the undropped features
 // ADROP: the same for the A operand (ad): the weight gradient of the first GCNConv reads X0 and regenerates the mask of F.dropout(X0)
 template <int WM, int WN, bool SCALED, int WTN = 2, int PD = 1, bool GDROP = false, bool ADROP = false>
-__global__ void __launch_bounds__(256, (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_tn_l3(const float* __restrict__ A, int64_t lda,
+__global__ void __launch_bounds__((LTile<WM, WN, WTN, PD>::NTHR), (LTile<WM, WN, WTN, PD>::MINW)) k_gemm_tn_l3(const float* __restrict__ A, int64_t lda,
                                                                                  const float* __restrict__ G, int64_t ldg,
                                                                                  const float* __restrict__ rowscale,
                                                                                  float* __restrict__ partial, int64_t M, int K1, int K2,
                                                                                  int64_t rows_per_split, int tiles_j, int n_tiles,
                                                                                  int nsplit, DropSpec gd) {
   using T = LTile<WM, WN, WTN>;
-  using OA = ColOperand<T::BM, false, ADROP>;
-  using OB = ColOperand<T::BN, SCALED, GDROP>;
+  using OA = ColOperand<T::BM, false, ADROP, T::NTHR>;
+  using OB = ColOperand<T::BN, SCALED, GDROP, T::NTHR>;
   constexpr int BM = T::BM, BN = T::BN;
   __shared__ __attribute__((aligned(16))) char smem[2 * (OA::BYTES + OB::BYTES)];
   const int b = blockIdx.x;
@@ -221,7 +222,7 @@ static void launch_tn_l3_t(const float* A, int64_t lda, const float* G, int64_t 
   const int ti = (int)((K1 + T::BM - 1) / T::BM), tj = (int)((K2 + T::BN - 1) / T::BN);
   const dim3 grid((unsigned)(((nsplit + 7) / 8) * 8 * ti * tj));
 #define CB_TN_LAUNCH(SC_, GD_, AD_)                                                                                                  \
-  hipLaunchKernelGGL((k_gemm_tn_l3<WM, WN, SC_, WTN, 1, GD_, AD_>), grid, dim3(256), 0, st, A, lda, G, ldg, rowscale, partial, M, (int)K1, \
+  hipLaunchKernelGGL((k_gemm_tn_l3<WM, WN, SC_, WTN, 1, GD_, AD_>), grid, dim3(T::NTHR), 0, st, A, lda, G, ldg, rowscale, partial, M, (int)K1, \
                      (int)K2, rows_per_split, tj, ti * tj, nsplit, gd.thresh ? gd : ad)
   if (gd.thresh) CB_TN_LAUNCH(false, true, false);      // (launch_tn_limb3 admits it without a row scale only)
   else if (ad.thresh) {
@@ -245,6 +246,16 @@ int launch_tn_limb3(const float* A, int64_t lda, const float* G, int64_t ldg, co
   if (bm == 64) launch_tn_l3_t<1, 4>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd, ad);
   else if (bm == 256) launch_tn_l3_t<4, 1>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd, ad);
   else {
+    // Round 5: the whole 256 x 256 weight gradient of a hidden layer as ONE tile of eight wavefronts (wave tile 64 x 128 as before): each operand
+    // element is staged — split into limbs — once, where the 128 x 256 tile staged the gradient operand twice: 2.1 instead of 3.1 staging VALU per
+    // MFMA on a kernel whose SIMDs are issue-bound (PMC: matrix pipe 62 % + VALU 39 % of the cycles, profiles/r05_gemm_tn_pmc_raw.txt).
+    // 7.29 -> 6.55 ms at M = 10^7, bit-identical (same K order per output element).  CB_GEMM_TN_WIDE=0 keeps the 128 x 256 tile.
+    static const bool wide = !(getenv("CB_GEMM_TN_WIDE") && getenv("CB_GEMM_TN_WIDE")[0] == '0');
+    if (wide && !ad.thresh && !gd.thresh && K1 == 256 && K2 == 256 && nsplit >= 256) {      // (fewer slabs than CUs — a Pubmed-sized M —: the 128 x 256 tile has twice the blocks)
+      launch_tn_l3_t<4, 2, 4>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd, ad);
+      CB_LAUNCH_CHECK();
+      return CB_OK;
+    }
     // (operand dropout: the 128 x 128 tile — the wide one is at the register cap and the mask's Philox rounds would spill)
     if (!ad.thresh && K2 > 128 && ((K1 + 127) / 128) * ((K2 + 255) / 256) * nsplit >= 256) launch_tn_l3_t<2, 2, 4>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd, ad);
     else launch_tn_l3_t<2, 2>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd, ad);

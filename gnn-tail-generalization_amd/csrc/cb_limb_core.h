@@ -121,10 +121,11 @@ struct RowOperand {
 };
 
 // ---- "col" operand: global [k][cols] (cols contiguous) -> LDS planes [16 k][C cols] ------------------
-template <int C, bool SCALED, bool DROP = false>
+template <int C, bool SCALED, bool DROP = false, int NT = 256>      // NT: threads of the block that stage the operand
 struct ColOperand {
   static constexpr int ROWB = C * 2, PLANE = 16 * ROWB, BYTES = 3 * PLANE;
-  static constexpr int TPR = C / 4, KPP = 256 / TPR, NV = 16 / KPP;   // threads per k row, k rows per pass, float4 per thread
+  static constexpr int TPR = C / 4, KPP = NT / TPR, NV = 16 / KPP;   // threads per k row, k rows per pass, float4 per thread
+  static_assert(KPP >= 4 && KPP % 4 == 0 && NV >= 1, "staging map: whole swizzle groups of k rows per pass");
   static constexpr int NC = C / 32;                                    // 64-byte chunks per row
   static_assert(NC == 2 || NC == 4 || NC == 8, "tile widths 64 / 128 / 256");
   static __device__ __forceinline__ int swz(int k) { return NC == 2 ? ((k >> 1) & 1) : (k & 3); }
