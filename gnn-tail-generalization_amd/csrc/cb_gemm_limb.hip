@@ -256,6 +256,13 @@ int launch_tn_limb3(const float* A, int64_t lda, const float* G, int64_t ldg, co
       CB_LAUNCH_CHECK();
       return CB_OK;
     }
+    // the same for the input Linear's weight gradient (256 x F, F <= 128, the dropout mask of the features regenerated while they are staged): one
+    // 256 x 128 tile of eight wavefronts draws every mask quad once instead of once per 128-row tile
+    if (wide && gd.thresh && !ad.thresh && !rowscale && K1 == 256 && K2 <= 128 && K2 > 64 && nsplit >= 256) {
+      launch_tn_l3_t<4, 2, 2>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd, ad);
+      CB_LAUNCH_CHECK();
+      return CB_OK;
+    }
     // (operand dropout: the 128 x 128 tile — the wide one is at the register cap and the mask's Philox rounds would spill)
     if (!ad.thresh && K2 > 128 && ((K1 + 127) / 128) * ((K2 + 255) / 256) * nsplit >= 256) launch_tn_l3_t<2, 2, 4>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd, ad);
     else launch_tn_l3_t<2, 2>(A, lda, G, ldg, rowscale, partial, M, K1, K2, nsplit, rows_per_split, st, gd, ad);
