@@ -369,3 +369,26 @@ def test_bench_gpus_n_without_a_launcher_runs_n_ranks():
     assert sh['ranks_seen'] == [0, 1] and sh['backend'] == 'gloo' and sh['loss_matches_n1'] is True, sh
     assert sum(sh['rows_per_rank']) == 169343
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('extra', ['', '--force_set_to_best_config=0 --type_trick=Residual', '--force_set_to_best_config=0 --type_trick=NoResNodeNorm'])
+def test_bench_sharded_path_on_rccl_with_one_rank(extra):
+    """The N > 1 leg of bench.py (ShardedTrainer, the sharding report, the edge all-reduce, barrier-bracketed timing) on the backend the driver's SCALE runs
+    use — torch.distributed `nccl` = RCCL —, as far as one GPU allows: world size 1 (`COLDBREW_FORCE_SHARDED=1`), for the three default trunk shapes."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'COLDBREW_DIST_BACKEND')}
+    env['COLDBREW_FORCE_SHARDED'] = '1'
+    env['MASTER_PORT'] = '29547'
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--dataset', 'S-arxiv', '--steps', '3', '--warmup', '1', '--cpu-baseline', '0',
+           '--pmc-traffic', '0', '--ref-epochs', '0']
+    if extra:
+        cmd.append('--extra=' + extra)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['value'] > 0 and d['sharding']['backend'] == 'nccl', d.get('sharding')
+    assert d['roofline']['frac'] > 0 and d['final_loss'] == d['final_loss']
