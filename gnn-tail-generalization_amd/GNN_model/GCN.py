@@ -10,6 +10,8 @@ What changes is below the surface: the graph is a device CSR built once through 
 (graph.CSRGraph instead of dgl.graph from Python lists, GCN.py:92-95), and the
 transform / aggregate stages run as hand-written gfx950 kernels (ops.py).
 """
+import os
+
 import torch as th
 import torch.nn.functional as F
 from torch import nn
@@ -29,7 +31,9 @@ class TricksComb(nn.Module):
     """Layer stack of the teacher: non-residual mode = GCNConv(F,H), (L-2) x GCNConv(H,H), GCNConv(H,C);
     residual mode (type_trick names Jumping/Initial/Residual/Dense) = Linear(F,H), L x GCNConv(H,H), Linear(H,C)."""
 
-    use_fused_trunk = True   # 'Initial' / 'Residual' connections (trunk.py) and the non-residual stack (stack.py) without a bare norm run as one fused autograd node at hidden 256
+    # 'Initial' / 'Residual' connections (trunk.py) and the non-residual stack (stack.py) without a bare norm run as one fused autograd node at hidden 256
+    # (CB_FUSED_TRUNK=0: one operator per stage everywhere — the path of every other configuration, for A/B runs)
+    use_fused_trunk = os.environ.get('CB_FUSED_TRUNK', '1') != '0'
 
     def __init__(self, args):
         super().__init__()
@@ -100,7 +104,7 @@ class TricksComb(nn.Module):
         return self.dglgraph
 
     def forward(self, x, edge_index, want_les=False, loss_rows=None):
-        """loss_rows: see TeacherGNN.forward (an extension of the reference's signature; the general path below ignores it)."""
+        """loss_rows: see TeacherGNN.forward (an extension of the reference's signature; the general path uses it for its last aggregation)."""
         graph = self._graph(edge_index)
         new_adjs = self.graph_dropout(edge_index)      # computed and discarded, as in the reference (GCN.py:101,111)
         if self.use_fused_trunk and not getattr(graph, 'segmented', False) and trunk.eligible(self, x, want_les):
@@ -110,11 +114,30 @@ class TricksComb(nn.Module):
         if getattr(self.args, 'agg_dtype', 'f32') != 'f32' and not want_les:
             raise NotImplementedError("--agg_dtype=bf16 (bf16-stored aggregation rows) is built for the fused 'Initial' trunk "
                                       '(hidden width a multiple of 256); this configuration runs the fp32 operator path')
-        return self._forward_modular(x, graph, new_adjs, want_les)
+        return self._forward_modular(x, graph, new_adjs, want_les, loss_rows)
 
-    def _forward_modular(self, x, graph, new_adjs, want_les):
+    def _last_grad_rows(self, graph, want_les, loss_rows):
+        """The mask the LAST aggregation's backward may restrict itself to (ops._AggregateFn), or None.  Every stage between that aggregation and
+        the logits must act row by row: ReLU, the residual mixes, dropout and the output Linear do; of the norms only NodeNorm (per-row statistics,
+        norm_tricks.py:53-84) — the others take column statistics, whose backward reaches every row."""
+        from ..tuning import T
+        if (loss_rows is None or want_les or not self.training or not ops.loss_rows_enabled() or hasattr(graph, 'part') or getattr(graph, 'segmented', False)
+                or getattr(graph, 'rowptr_t', None) is None or (self.args.type_trick in _BARE_NORMS and self.args.type_trick != 'NodeNorm')):
+            return None
+        mask, count = loss_rows if isinstance(loss_rows, (tuple, list)) else (loss_rows, None)
+        n = int(mask.shape[0])
+        if mask.dtype != th.bool or n != graph.N or (n < T.rowsparse_min_nodes and not getattr(graph, 'rowsparse_small_ok', False)):
+            return None
+        if count is None:
+            count = int(mask.sum())
+        if not (0 < int(count) <= T.rowsparse_s0_limit * n) or not graph.support_plan_pays():
+            return None
+        return mask
+
+    def _forward_modular(self, x, graph, new_adjs, want_les, loss_rows=None):
         """General path: one HIP operator per stage, any trick combination."""
         L, train = self.num_layers, self.training
+        last_rows = self._last_grad_rows(graph, want_les, loss_rows)
         row0 = getattr(graph, 'row_offset', 0)     # first global row of this rank's shard (0 on one GPU)
         drop = lambda t, p: ops.dropout(t, p, train, offset=row0 * t.shape[1])   # noqa: E731
         x_list, les, se_reg_all = [], [], None
@@ -128,7 +151,7 @@ class TricksComb(nn.Module):
             _unused_edge_index, _ = new_adjs[i]
             act = self.has_residual_MLP or i < L - 1
             fuse_relu = act and not norms_run and not want_les   # ReLU rides in the aggregation epilogue
-            x, se_reg = self.layers_GCN[i](graph, drop(x, self.dropout), _fused_relu=fuse_relu)
+            x, se_reg = self.layers_GCN[i](graph, drop(x, self.dropout), _fused_relu=fuse_relu, _grad_rows=last_rows if i == L - 1 else None)
             if se_reg is not None:
                 # intended semantics of GCN.py:116-120 (sum of the per-layer norms); the reference's in-place `+=`
                 # on a tensor autograd saved breaks backward for >= 2 SE layers
@@ -198,7 +221,7 @@ class GCNConv(nn.Module):
             raise NotImplementedError('GCNConv without a weight is not reachable from TricksComb')
         return w
 
-    def forward(self, graph, feat, weight=None, edge_weight=None, _fused_relu=False):
+    def forward(self, graph, feat, weight=None, edge_weight=None, _fused_relu=False, _grad_rows=None):
         if not self._allow_zero_in_degree:
             graph.check_zero_in_degree()                       # GCN.py:187-197
         if edge_weight is not None:                            # GCN.py:199-202: u_mul_e instead of copy_src (TricksComb never passes one)
@@ -208,7 +231,8 @@ class GCNConv(nn.Module):
         w = self._pick_weight(weight)
         h, se_reg = ops.transform(feat, graph.norm_out, w, self.le if self.whetherHasSE else None, graph)   # :213,225,230-236
         self.se_norm = None if se_reg is None else se_reg.detach()      # last ||le||_F (ops.fold_se_reg)
-        rst = ops.aggregate(graph, h, row_scale=graph.norm_in, bias=self.bias, relu=_fused_relu, edge_weight=edge_weight)   # :238,250,253
+        rst = ops.aggregate(graph, h, row_scale=graph.norm_in, bias=self.bias, relu=_fused_relu, edge_weight=edge_weight,
+                            grad_rows=_grad_rows)                                                                         # :238,250,253
         return (rst if self._activation is None else self._activation(rst)), se_reg
 
     def extra_repr(self):

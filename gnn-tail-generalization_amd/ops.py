@@ -125,12 +125,16 @@ def act_bwd(g, act=None, row_scale=None, want_out=True, want_colsum=False):
 class _AggregateFn(torch.autograd.Function):
     """Forward: by-dst CSR SpMM with fused `* norm_in`, `+ bias`, optional ReLU.
     Backward (autograd of DGL's gspmm = SpMM on the reverse graph):
-        dY' = dY * (Y > 0) if relu;  dbias = colsum(dY');  dZ = A (b * dY')."""
+        dY' = dY * (Y > 0) if relu;  dbias = colsum(dY');  dZ = A (b * dY').
+    grad_rows (bool mask over the rows, or None): the loss_rows promise below for the gradient this node receives.  The backward then works on
+    the rows of the mask only: it checks the claim on the device (check_rows_zero), takes dY' and dbias on the compact rows and gathers over
+    the edges that leave them (CSRGraph.grad_support_plan with one level: rows S_0 -> all rows) — level 0 of the fused trunk's row-sparse
+    backward for the one-operator-per-stage path."""
 
     @staticmethod
-    def forward(ctx, graph, h, row_scale, bias, relu):
+    def forward(ctx, graph, h, row_scale, bias, relu, grad_rows=None):
         out = graph.spmm(h, transpose=False, row_scale=row_scale, bias=bias, relu=relu)
-        ctx.graph, ctx.relu = graph, relu
+        ctx.graph, ctx.relu, ctx.grad_rows = graph, relu, grad_rows
         ctx.has_bias = bias is not None
         ctx.save_for_backward(out if relu else None, row_scale)
         return out
@@ -139,12 +143,28 @@ class _AggregateFn(torch.autograd.Function):
     def backward(ctx, g):
         out, row_scale = ctx.saved_tensors
         need_h, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[3]
+        if ctx.grad_rows is not None and need_h:
+            check_rows_zero(g, ctx.grad_rows)
+            plan = ctx.graph.grad_support_plan(ctx.grad_rows, 1, max_frac=0.0)
+            idx = plan.space0.idx
+            gc = gather_rows_by_index(g, idx)
+            if ctx.relu or row_scale is not None or need_b:
+                rs = None
+                if row_scale is not None:
+                    rs = getattr(plan, '_row_scale0', None)
+                    if rs is None or rs[0] is not row_scale:
+                        rs = plan._row_scale0 = (row_scale, row_scale[idx].contiguous())
+                    rs = rs[1]
+                gc, dbias = act_bwd(gc, gather_rows_by_index(out, idx) if ctx.relu else None, rs, want_out=True, want_colsum=need_b)
+            else:
+                dbias = None
+            return None, plan.levels[0][0].spmm(gc, transpose=False), None, dbias, None, None
         if not (ctx.relu or row_scale is not None or need_b):
             gs, dbias = _c(g), None
         else:
             gs, dbias = act_bwd(g, out if ctx.relu else None, row_scale, want_out=need_h, want_colsum=need_b)
         dh = ctx.graph.spmm(gs, transpose=True) if need_h else None
-        return None, dh, None, dbias, None
+        return None, dh, None, dbias, None, None
 
 
 class _WeightedAggregateFn(torch.autograd.Function):
@@ -177,7 +197,8 @@ class _WeightedAggregateFn(torch.autograd.Function):
         return None, dh, dw, None, dbias, None
 
 
-def aggregate(graph, h, row_scale=None, bias=None, relu=False, edge_weight=None):
+def aggregate(graph, h, row_scale=None, bias=None, relu=False, edge_weight=None, grad_rows=None):
+    """grad_rows: see _AggregateFn (ignored by the weighted and the node-sharded forms: their backward is dense)."""
     _lib.require_device(h)
     if edge_weight is not None:
         if hasattr(graph, 'part'):
@@ -186,7 +207,7 @@ def aggregate(graph, h, row_scale=None, bias=None, relu=False, edge_weight=None)
     if hasattr(graph, 'part'):      # node-sharded graph: all-gather exchange + local rows (dist.py)
         from .dist import sharded_aggregate
         return sharded_aggregate(graph, h, row_scale, bias, relu)
-    return _AggregateFn.apply(graph, h, row_scale, bias, bool(relu))
+    return _AggregateFn.apply(graph, h, row_scale, bias, bool(relu), grad_rows)
 
 
 # ---------------------------------------------------------------------------------------------

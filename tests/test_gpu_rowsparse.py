@@ -90,6 +90,37 @@ def test_row_sparse_backward_of_the_non_residual_stack_equals_its_dense_backward
         assert float((g_s[k] - g_d[k]).abs().max()) <= 5e-6 * scale, k
 
 
+@pytest.mark.parametrize('extra,se', [(('--type_trick=Initial',), '000'), (('--type_trick=Residual',), '111'), (('--type_trick=NodeNorm',), '000'),
+                                      (('--type_trick=DenseNodeNorm',), '000'), (('--type_trick=NoRes',), '001'), (('--type_trick=JumpingBatchNorm',), '000')])
+def test_row_sparse_last_aggregation_of_the_operator_path_equals_the_dense_backward(extra, se, monkeypatch):
+    """configurations outside the fused nodes (other hidden widths — the dataset presets fix them, base_options.py:192-224 —, norms, 'Dense'
+    / 'Jumping' connections) run one operator per stage; the backward of their LAST aggregation (ops._AggregateFn with grad_rows) works on the loss rows: dY'
+    and the bias gradient on the compact rows, the gather over the edges that leave them.  Everything below is dense.  Forced here for the fusable
+    shapes too (use_fused_trunk = False).  Same gradients as CB_LOSS_ROWS=0 up to the association of the hub rows' sums."""
+    from gnn_tail_generalization_amd import ops
+    from gnn_tail_generalization_amd.GNN_model.GCN import TricksComb
+    monkeypatch.setattr(TricksComb, 'use_fused_trunk', False)
+    hinted = []
+    real = ops._AggregateFn.apply
+    monkeypatch.setattr(ops._AggregateFn, 'apply', lambda *a: (hinted.append(a[5] is not None), real(*a))[1])
+    extra = ('--force_set_to_best_config=0',) + extra
+    loss_s, g_s, used_s = _step_grads('1', se=se, extra=extra)
+    assert hinted == [False, False, True]              # three layers: the last aggregation alone carries the promise
+    loss_d, g_d, used_d = _step_grads('0', se=se, extra=extra)
+    assert used_s and not used_d and loss_s == loss_d and set(g_s) == set(g_d)
+    for k in g_d:
+        scale = float(g_d[k].abs().max())
+        assert float((g_s[k] - g_d[k]).abs().max()) <= 5e-6 * scale, k
+
+
+def test_column_statistic_norms_keep_the_dense_backward():
+    """BatchNorm / PairNorm / ... take column statistics after the last aggregation: their backward reaches every row, the promise about the logits says
+    nothing about the aggregation's gradient, and the operator path does not pass it on."""
+    extra = ('--force_set_to_best_config=0', '--type_trick=BatchNorm')
+    _, _, used = _step_grads('1', extra=extra)
+    assert not used
+
+
 @pytest.mark.parametrize('n_loss_rows', [3, 200, 20000])
 def test_row_sparse_backward_with_sparse_labels(n_loss_rows, monkeypatch):
     """Few loss rows (the public Planetoid splits label 0.3 - 5 % of the nodes): supports of 3 / 200 / 20 000 rows that grow by orders of
