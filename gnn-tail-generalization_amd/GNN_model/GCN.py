@@ -103,12 +103,12 @@ class TricksComb(nn.Module):
             self.dglgraph = build_graph(edge_index)
         return self.dglgraph
 
-    def forward(self, x, edge_index, want_les=False, loss_rows=None):
-        """loss_rows: see TeacherGNN.forward (an extension of the reference's signature; the general path uses it for its last aggregation)."""
+    def forward(self, x, edge_index, want_les=False, loss_rows=None, rows_only=False):
+        """loss_rows, rows_only: see TeacherGNN.forward (extensions of the reference's signature; the general path uses loss_rows for its last aggregation)."""
         graph = self._graph(edge_index)
         new_adjs = self.graph_dropout(edge_index)      # computed and discarded, as in the reference (GCN.py:101,111)
         if self.use_fused_trunk and not getattr(graph, 'segmented', False) and trunk.eligible(self, x, want_les):
-            return trunk.forward(self, x, graph, loss_rows=loss_rows)
+            return trunk.forward(self, x, graph, loss_rows=loss_rows, rows_only=rows_only)
         if self.use_fused_trunk and not getattr(graph, 'segmented', False) and stack.eligible(self, x, graph, want_les):
             return stack.forward(self, x, graph, loss_rows=loss_rows)      # the non-residual stack (NoRes...) at hidden 256
         if getattr(self.args, 'agg_dtype', 'f32') != 'f32' and not want_les:

@@ -17,8 +17,8 @@ class GNN_norm(nn.Module):
         super().__init__()
         self.model = TricksComb(args)
 
-    def forward(self, x, edge_index, loss_rows=None):
-        return self.model.forward(x, edge_index, loss_rows=loss_rows)
+    def forward(self, x, edge_index, loss_rows=None, rows_only=False):
+        return self.model.forward(x, edge_index, loss_rows=loss_rows, rows_only=rows_only)
 
 
 class TeacherGNN(nn.Module):
@@ -47,17 +47,20 @@ class TeacherGNN(nn.Module):
             x = x * 0
         return self.embs if self.args.dim_learnable_input > 0 else x
 
-    def forward(self, x, edge_index, loss_rows=None):
+    def forward(self, x, edge_index, loss_rows=None, rows_only=False):
         """loss_rows (extension, default None = the reference's call): (bool mask [N], count) — the caller's promise that the objective it
         builds on this forward's output puts gradient into the rows of the mask only (the masked loss of trainer…:390-391; any head between
         the output and the loss must be row-wise, as proj2class is).  The fused trunk's backward then skips the rows that stay zero; the
-        promise is verified on the device every step (ops.check_rows_zero), a broken one raises and leaves the weights untouched."""
-        self.out, self.se_reg_all = self.model(self._input(x), edge_index, loss_rows=loss_rows)
+        promise is verified on the device every step (ops.check_rows_zero), a broken one raises and leaves the weights untouched.
+        rows_only (extension, with loss_rows): the caller's second promise — it READS this forward's output (the return value, `self.out`) in the rows
+        of the mask only.  A training forward of the fused trunk then evaluates its last layer and the output Linear on those rows; every other row
+        of the output is returned as zeros."""
+        self.out, self.se_reg_all = self.model(self._input(x), edge_index, loss_rows=loss_rows, rows_only=rows_only)
         return self.out
 
-    def get_3_embs(self, x, edge_index, mask=None, want_heads=True, loss_rows=None):
+    def get_3_embs(self, x, edge_index, mask=None, want_heads=True, loss_rows=None, rows_only=False):
         res = D()
-        res.commonEmb = self.forward(x, edge_index, loss_rows=loss_rows)
+        res.commonEmb = self.forward(x, edge_index, loss_rows=loss_rows, rows_only=rows_only)
         res.emb4classi_full = self.proj2class(res.commonEmb)
         res.emb4classi = res.emb4linkp = None
         if want_heads:

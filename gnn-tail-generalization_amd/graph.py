@@ -195,7 +195,17 @@ class CSRGraph:
         builds, hits = getattr(self, '_support_builds', 0), getattr(self, '_support_hits', 0)
         return builds < 4 or hits >= 3 * builds
 
-    def _support_fwd(self, s0, n_out):
+    def loss_rows_fwd(self, plan):
+        """The forward orientation on the rows of S_0 of a plan (plan.fwd[0]), built now if the thresholds of _support_fwd had left it out: the rows-only
+        forward of trunk.py evaluates the last layer on those rows whatever the break-even of the backward's source-side form says."""
+        if not plan.fwd:
+            plan.fwd.append(None)
+        if plan.fwd[0] is None:
+            dst = plan.levels[0][1]
+            plan.fwd[0] = self._support_fwd(plan.space0, dst.n if dst is not None else self.N, force=True)
+        return plan.fwd[0]
+
+    def _support_fwd(self, s0, n_out, force=False):
         """The FORWARD orientation restricted to the rows of a support S_j (one row per member; its in-neighbours — all of them members of
         S_{j+1} — keep their global ids): (A (a * X))[S_j] = fwd.spmm(X, col_scale=a).  With it the weight gradient of the level
         X^T (a * A^T dY) is taken as ((A (a * X))[S_j])^T dY[S_j] — a contraction over |S_j| rows instead of |S_{j+1}| — and
@@ -206,7 +216,7 @@ class CSRGraph:
         deg0 = torch.index_select(rpf[1:] - rpf[:-1], 0, s0.idx)
         rp_c = torch.cat([deg0.new_zeros(1), torch.cumsum(deg0, 0, dtype=torch.int32)])
         e0 = int(rp_c[-1])
-        if (n_out - s0.n) < T.fwd0_rows_per_edge * e0 or e0 < T.fwd0_min_edges:
+        if not force and ((n_out - s0.n) < T.fwd0_rows_per_edge * e0 or e0 < T.fwd0_min_edges):
             return None
         shift = torch.index_select(rpf, 0, s0.idx).long() - rp_c[:-1].long()          # CSR position minus packed position, per S_0 row
         epos = torch.arange(e0, device=rpf.device) + torch.repeat_interleave(shift, deg0.long())

@@ -261,9 +261,10 @@ class trainer:
         """Forward + loss of run_trainSet (:386-394): nll(log_softmax(out[train])) + se_reg * sum ||E||."""
         if getattr(self, '_n_train', None) is None:
             self._n_train = int(self.data.train_mask.sum().item())      # once: keeps the step free of host syncs
-        # the objective below touches the logits in the train rows only (and nothing else of this forward's output): said to the model,
-        # whose backward may then skip the rows that stay zero (ops.py "Row-sparse backward"; verified on the device every step)
-        res = self.teacherGNN.get_3_embs(self.data.x, self.data.edge_index, loss_rows=(self.data.train_mask, self._n_train))
+        # the objective below touches the logits in the train rows only (loss_rows) and nothing else of this forward's output is read (rows_only): said to
+        # the model, whose backward may then skip the rows that stay zero (ops.py "Row-sparse backward"; verified on the device every step) and whose
+        # forward may evaluate its last layer on the train rows (trunk.py "Rows-only forward")
+        res = self.teacherGNN.get_3_embs(self.data.x, self.data.edge_index, loss_rows=(self.data.train_mask, self._n_train), rows_only=True)
         # == F.nll_loss(F.log_softmax(out[train_mask], 1), y[train_mask]) (:390-391), fused, no row gather
         unit = float(self.args.TeacherGNN.lossa_semantic) == 1.0      # the step seeds backward() with 1: no [N, C] pass to multiply by it
         loss = ops.nll_logsoftmax(res.emb4classi_full, self.data.y, self.data.train_mask, self._n_train, unit_grad=unit)

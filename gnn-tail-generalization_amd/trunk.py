@@ -332,14 +332,73 @@ def _chunked(graph, agg_bf16):
             and not graph.f.plan.cover and os.environ.get('COLDBREW_CHUNKED_PRODUCERS', '1') != '0')
 
 
+def _support_plan(graph, loss_rows, n_rows, L, residual, h, x0):
+    """(plan, gather, tail_tb) of a backward — and of a rows-only forward — under the caller's loss_rows promise: ONE decision for both, so that a
+    forward that evaluated its last layer on the loss rows finds the same plan in its backward.  plan: CSRGraph.grad_support_plan or None (dense)."""
+    gather = residual or (L <= T.mix_max and _gather_fits(L, x0, graph))
+    tail_tb = agg_gemm_eligible(graph, h, False) and gather and not residual and tail_trunk_bwd(graph)
+    hint = loss_rows if (not hasattr(graph, 'part') and hasattr(graph, 'grad_support_plan') and graph.rowptr_t is not None) else None
+    if hint is not None and (not ops.loss_rows_enabled() or hint[0].shape[0] != n_rows):
+        hint = None
+    if not (hint is not None and 1 <= hint[1] <= T.rowsparse_s0_limit * n_rows
+            and (n_rows >= T.rowsparse_min_nodes or getattr(graph, 'rowsparse_small_ok', False)) and gather
+            and agg_gemm_eligible(graph, h, False) and not tail_tb and graph.support_plan_pays()):
+        return None, gather, tail_tb
+    return hint, gather, tail_tb
+
+
+def rows_only_enabled():
+    """CB_ROWS_ONLY_FWD=0: the training forward evaluates every row of every layer even when the caller reads the loss rows only."""
+    return os.environ.get('CB_ROWS_ONLY_FWD', '1') != '0'
+
+
+def _store_rows(y, idx, mix, c_act, c_mix, p, seed, row0, bits, relu_only):
+    """cb_trunk_store_rows_f32: the trunk's fused store (ReLU, mask words, mix, dropout) on the compact rows idx of a dense transform's output."""
+    lib = _lib.load()
+    out = torch.empty_like(y)
+    with torch.cuda.device(y.device):
+        _lib.check(lib.cb_trunk_store_rows_f32(_lib.ptr(y), _lib.ptr(idx), y.shape[0], y.shape[1], _lib.ptr(mix), mix.stride(0) if mix is not None else 0,
+                                               float(c_act), float(c_mix), float(p), ctypes.c_uint64(seed), ops.seed_dev_ptr(), int(row0), _lib.ptr(bits),
+                                               int(bool(relu_only)), _lib.ptr(out), _lib.stream_ptr()), 'cb_trunk_store_rows_f32')
+    return out
+
+
+def _last_layer_on_loss_rows(graph, plan, cur, w, b, mix, alpha, p, seed, row0, residual, w_out, b_out):
+    """The LAST GCNConv, its store and the output Linear on the loss rows S_0 only (rows-only forward): aggregation and transform commute,
+        Y[S_0] = b * ((A (a * X))[S_0] W) + bias        (GCN.py:213-256 with the sum taken first)
+    so the layer is one aggregation over the edges that ENTER the loss rows (10 % of the edges under a 10 % mask) into a compact [|S_0|, H] matrix, a
+    GEMM on |S_0| rows, the store on those rows and the head on those rows.  Z_{L-1} — the previous layer's dense tail — is never formed.
+    Returns (mask words [N, H/256, 4] (rows of S_0 written), dropped X_L on S_0, logits [N, C] with zeros outside S_0, H = (A (a * X))[S_0]:
+    the operand of the level's weight gradient in the backward's source-side form)."""
+    sp = plan.space0
+    fwd0 = graph.loss_rows_fwd(plan)
+    fwd0.profile = getattr(graph, 'profile', None)
+    h_agg = fwd0.spmm(cur, col_scale=graph.norm_out)
+    b0 = getattr(plan, '_norm_in0', None)
+    if b0 is None:
+        b0 = plan._norm_in0 = graph.norm_in[sp.idx].contiguous()
+    y = gemm.mm_nn(h_agg, w, rowscale=b0, bias=b)
+    n, d = cur.shape[0], w.shape[1]
+    bits = torch.empty((n, d // 256, 4), dtype=torch.int64, device=cur.device)
+    x_l = _store_rows(y, sp.idx, mix, 1 - alpha, alpha, p, seed, row0, bits, residual)
+    del y
+    logits_c = gemm.mm_nn(x_l, w_out.t().contiguous(), bias=b_out)
+    if logits_c.shape[1] % 4 == 0:
+        out = ops.expand_rows(logits_c, sp.pos)
+    else:
+        out = torch.zeros((n, logits_c.shape[1]), dtype=torch.float32, device=cur.device).index_copy_(0, sp.idx, logits_c)
+    return bits, x_l, out, h_agg
+
+
 class _TrunkFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph, cfg, x, w_in, b_in, w_out, b_out, *layer_params):
         """layer_params = (W_0, bias_0, le_0 | None, W_1, ...).  cfg = (L, alpha, p, seeds, agg_bf16, track, loss_rows, residual): track = autograd
         was recording when the trunk was called (inside a Function's forward it never is, and needs_input_grad does not know about no_grad);
         loss_rows = None or (bool mask [N], count): the caller's promise that the output receives gradient in those rows only (ops.py);
-        residual: the 'Residual' connection (mix source of layer l > 0 = the previous layer's ReLU output) instead of 'Initial' (X0)."""
-        L, alpha, p, seeds, agg_bf16, track, _loss_rows, residual = cfg
+        residual: the 'Residual' connection (mix source of layer l > 0 = the previous layer's ReLU output) instead of 'Initial' (X0);
+        rows_only: the caller's second promise — it READS the output in the rows of loss_rows only (the other rows are returned as zeros)."""
+        L, alpha, p, seeds, agg_bf16, track, loss_rows_, residual, rows_only = cfg
         row0 = int(getattr(graph, 'row_offset', 0))
         a = graph.norm_out
         x = x.contiguous()
@@ -393,6 +452,14 @@ class _TrunkFn(torch.autograd.Function):
         h = x0.shape[1]
         saved_in, saved_bits = [cur], []
         ag = agg_gemm_eligible(graph, h, agg_bf16)
+        # Rows-only forward: with both promises of the caller (gradient AND reads in the loss rows only) the last layer, its store and the output
+        # Linear run on the loss rows (_last_layer_on_loss_rows) — where the backward will run its level 0 through the source rows' side.  Same
+        # decision as the backward's (_support_plan); the last layer without a structural-embedding table (its gradient is dL/dZ on ALL rows).
+        ro_plan = h_last = None
+        if rows_only and bwd and loss_rows_ is not None and L >= 2 and ag and layer_params[3 * (L - 1) + 2] is None and T.rowsparse_loss_side and rows_only_enabled():
+            hint, _gather, _tb = _support_plan(graph, loss_rows_, x.shape[0], L, residual, h, x0)
+            if hint is not None:
+                ro_plan = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac, cumulative=residual)
         z_ready = None                           # Z_l already produced by layer l-1's aggregation kernel (cb_spmm_gemm_fused_f32)
         out_head = None                          # the logits, when the output Linear left the last layer's aggregation kernel
         mix = x0                                 # mix source of the layer: X0 ('Initial', and layer 0 of 'Residual'), else the previous ReLU output
@@ -411,12 +478,18 @@ class _TrunkFn(torch.autograd.Function):
                                                                                                          out=_exchanged(graph, x0.shape[0], w.shape[1]))
                 if z0 is None:
                     cur = saved_in[0] = dropped_x0()
-            if ag:
+            if ag and ro_plan is not None and l == L - 1:
+                bits, cur, out_head, h_last = _last_layer_on_loss_rows(graph, ro_plan, cur, w, b, mix, alpha, p, sd_l, row0, residual, w_out, b_out)
+                saved_in[L - 1] = None        # X_{L-1}: read by the aggregation above only (the level's weight gradient contracts h_last)
+                z = None
+            elif ag:
                 from .graph import weight_image
                 z = (z_ready if z_ready is not None else z0 if z0 is not None
                      else gemm.mm_nn(cur, w, rowscale=a, addend=le, out=_exchanged(graph, cur.shape[0], w.shape[1])))
                 z_ready = None
-                if l + 1 < L:     # this layer's store + the next layer's transform in one kernel
+                if ro_plan is not None and l + 2 == L:     # rows-only: the last layer aggregates X_{L-1} itself — no dense tail under this store
+                    bits, cur, act = _fused_spmm(graph, z, b, mix, 1 - alpha, alpha, p, sd_l, want_act=keep_act, want_bits=bwd, relu_only=residual)
+                elif l + 1 < L:     # this layer's store + the next layer's transform in one kernel
                     w1, _, le1 = layer_params[3 * (l + 1): 3 * (l + 1) + 3]
                     res = _fused_gemm(graph, z, b, mix, 1 - alpha, alpha, p, sd_l, weight_image(w1), a, le1, want_bits=bwd, want_act=keep_act,
                                       relu_only=residual)
@@ -457,8 +530,9 @@ class _TrunkFn(torch.autograd.Function):
         ctx.n_layer_params = len(layer_params)
         if bwd:
             ctx.save_for_backward(xd, x0, w_in, w_out, *saved_in, *saved_bits, *[t for t in layer_params if t is not None],
-                                  *([x0_bits] if x0_bits is not None else []))
+                                  *([h_last] if h_last is not None else []), *([x0_bits] if x0_bits is not None else []))
         ctx.has_x0_bits = bwd and x0_bits is not None
+        ctx.rows_only = bwd and h_last is not None
         ctx.le_present = [layer_params[3 * l + 2] is not None for l in range(L)]
         return out
 
@@ -478,7 +552,7 @@ class _Backward:
 
     def __init__(self, ctx, gout):
         self.ctx = ctx
-        graph, (L, alpha, p, seeds, agg_bf16, _track, loss_rows, residual), row0 = ctx.graph, ctx.cfg, ctx.row0
+        graph, (L, alpha, p, seeds, agg_bf16, _track, loss_rows, residual, _rows_only), row0 = ctx.graph, ctx.cfg, ctx.row0
         self.graph, self.L, self.alpha, self.p, self.seeds, self.agg_bf16, self.row0, self.residual = graph, L, alpha, p, seeds, agg_bf16, row0, residual
         sv = list(ctx.saved_tensors)
         self.xd, self.x0, self.w_in, self.w_out = sv[:4]
@@ -486,6 +560,8 @@ class _Backward:
         self.saved_bits = sv[4 + L + 1: 4 + 2 * L + 1]
         rest = sv[4 + 2 * L + 1:]
         self.x0_bits = rest.pop() if ctx.has_x0_bits else None
+        self.rows_only = ctx.rows_only                      # the forward ran its last layer on the loss rows: saved_in[L] is compact, saved_in[L - 1] absent
+        self.h_last = rest.pop() if ctx.rows_only else None  # (A (a * X_{L-1}))[S_0]
         self.lp, k = [], 0
         for l in range(L):
             w, b = rest[k], rest[k + 1]
@@ -500,7 +576,7 @@ class _Backward:
         self.gout = gemm._rowmajor(gout)
         self.h = self.x0.shape[1]
         self.sharded = hasattr(graph, 'part')
-        if loss_rows is not None and (not ops.loss_rows_enabled() or loss_rows[0].shape[0] != self.gout.shape[0]):
+        if loss_rows is not None and not ctx.rows_only and (not ops.loss_rows_enabled() or loss_rows[0].shape[0] != self.gout.shape[0]):
             loss_rows = None
         self.loss_rows = loss_rows
         # the gradient reaching X0 through the mixes: 'Initial' — every layer's, gathered in one pass by the input stage (the per-layer gradients
@@ -581,7 +657,7 @@ class _Backward:
         space: the compact row space of the loss rows (a plan's space0 / a rank's share of it), or None = all rows."""
         L, need, gout, xl, w_out = self.L, self.need, self.gout, self.saved_in[self.L], self.w_out
         if space is not None:      # loss rows only
-            gout_c, xl_c = ops.gather_rows_by_index(gout, space.idx), ops.gather_rows_by_index(xl, space.idx)
+            gout_c, xl_c = ops.gather_rows_by_index(gout, space.idx), (xl if self.rows_only else ops.gather_rows_by_index(xl, space.idx))
             self.d_w_out = gemm.mm_tn(gout_c, xl_c) if need[5] else None
             self.d_b_out = ops.act_bwd(gout_c, None, None, want_out=False, want_colsum=True)[1] if need[6] else None
             g = gemm.mm_nn(gout_c, w_out)                                        # dL/d(dropped X_L), loss rows only
@@ -618,7 +694,8 @@ class _Backward:
         level[0].profile = fwd_j.profile = getattr(self.graph, 'profile', None)
         g_new = level[0].spmm(gemm.mm_nn(gr, w.t().contiguous()), row_scale=dst.a if dst is not None else self.a)
         if self.need_w(l):
-            self.grads_layers[3 * l] = gemm.mm_tn(fwd_j.spmm(self.saved_in[l], col_scale=self.a), gr)
+            x_agg = self.h_last if (self.rows_only and l == self.L - 1) else fwd_j.spmm(self.saved_in[l], col_scale=self.a)
+            self.grads_layers[3 * l] = gemm.mm_tn(x_agg, gr)
         return None, g_new
 
     def _layer_compact(self, l, gr, level):
@@ -689,16 +766,17 @@ class _Backward:
         # (ops.check_rows_zero: a violation ends in the device error word and stops the optimiser launch, never in silent wrong gradients).
         # Hidden 256, gathered per-layer gradients, loss rows <= rowsparse_s0_limit of the nodes.
         plan = None
-        hint = self.loss_rows if (not sharded and hasattr(graph, 'grad_support_plan') and graph.rowptr_t is not None) else None
+        hint = None if sharded else _support_plan(graph, self.loss_rows, gout.shape[0], L, self.residual, self.h, self.x0)[0]
         # (with bf16-stored rows the compact levels still run on fp32 matrices through the aggregation + GEMM kernel; the dense levels below
         # them go on as the bf16 path does)
-        if (hint is not None and 1 <= hint[1] <= T.rowsparse_s0_limit * gout.shape[0]
-                and (gout.shape[0] >= T.rowsparse_min_nodes or getattr(graph, 'rowsparse_small_ok', False)) and gather
-                and agg_gemm_eligible(graph, self.h, False) and not self.tail_tb and graph.support_plan_pays()):
+        if hint is not None:
             ops.check_rows_zero(gout, hint[0])
             # ('Residual': a layer's store backward also takes the gradient of the layer above, so the supports are CUMULATIVE — W_{j+1} = N(W_j) ∪ W_j,
             # a superset of both; every matrix of level j lives on W_j)
             plan = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac, cumulative=self.residual)
+        if self.rows_only and (plan is None or not plan.fwd or plan.fwd[0] is None):
+            raise RuntimeError('the forward evaluated its last layer on the loss rows (rows_only), but its backward finds no row-support plan: '
+                               'CB_LOSS_ROWS / tuning.T / the mask changed between the forward and the backward')
 
         space0 = plan.space0 if plan is not None else (self.sh_levels[0].src if self.sh_levels else None)
         g, gr, dbias, handle, space = self._head(space0)
@@ -721,8 +799,8 @@ class _Backward:
                 deferred = None
             tb_next = None
             fwd_j = plan.fwd[j] if (level is not None and j < len(plan.fwd)) else None
-            source_side = (T.rowsparse_loss_side and fwd_j is not None and not self.need_le(l)
-                           and not (self.need_w(l) and self.saved_in[l] is None))      # (layer 0 without a stored dropped copy of X0)
+            source_side = (self.rows_only and l == L - 1) or (T.rowsparse_loss_side and fwd_j is not None and not self.need_le(l)
+                                                              and not (self.need_w(l) and self.saved_in[l] is None))      # (layer 0 without a stored dropped copy of X0)
             if source_side:
                 gz, g_new = self._layer_source_side(l, gr, level, fwd_j)
             elif level is not None:
@@ -792,9 +870,10 @@ class _Backward:
         return (None, None, d_x, d_w_in, d_b_in if need[4] else None, self.d_w_out, self.d_b_out, *self.grads_layers)
 
 
-def forward(tc, x, graph, loss_rows=None):
+def forward(tc, x, graph, loss_rows=None, rows_only=False):
     """TricksComb.forward on the fused trunk; returns (logits, se_reg_all).  loss_rows: None, (bool mask [N], count) or the mask alone — the caller's promise
-    that the logits receive gradient in the rows of the mask only (the masked loss, trainer_node_classification.py:390-391)."""
+    that the logits receive gradient in the rows of the mask only (the masked loss, trainer_node_classification.py:390-391).  rows_only (with loss_rows):
+    the caller also READS the logits in those rows only — a training forward may then evaluate its last layer on them; the other rows come back as zeros."""
     L = tc.num_layers
     p = float(tc.dropout) if tc.training else 0.0
     seeds = tuple(ops.next_seed() for _ in range(L + 2)) if p > 0 else (0,) * (L + 2)
@@ -819,6 +898,6 @@ def forward(tc, x, graph, loss_rows=None):
         if mask.dtype != torch.bool or mask.dim() != 1 or mask.shape[0] != x.shape[0]:
             raise ValueError(f'loss_rows: a bool mask over the {x.shape[0]} rows expected, got {tuple(mask.shape)} {mask.dtype}')
         loss_rows = (mask, int(count))
-    out = _TrunkFn.apply(graph, (L, float(tc.alpha), p, seeds, agg_bf16, torch.is_grad_enabled(), loss_rows, connection(tc) == 'residual'), x, tc.layers_MLP[0].weight, tc.layers_MLP[0].bias,
+    out = _TrunkFn.apply(graph, (L, float(tc.alpha), p, seeds, agg_bf16, torch.is_grad_enabled(), loss_rows, connection(tc) == 'residual', bool(rows_only) and loss_rows is not None), x, tc.layers_MLP[0].weight, tc.layers_MLP[0].bias,
                          tc.layers_MLP[1].weight, tc.layers_MLP[1].bias, *params)
     return out, se_reg_all

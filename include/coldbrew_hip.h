@@ -574,6 +574,14 @@ int cb_gather_rows_bf16_f32(const float* src, int64_t ld, const int64_t* idx, in
  * row subset written back to all rows in one pass — the gradient of a structural-embedding table (dL/dZ_l, GCN.py:230-232) when the level
  * of the row-sparse backward that produces it is compact (trunk.py). */
 int cb_expand_rows_f32(const float* src, const int32_t* pos, int64_t n_rows, int64_t d, float* out, void* stream);
+/* The trunk's fused store — ReLU, mask words, residual mix, dropout (GCN.py:127-133, res_tricks.py:7-23) — on a SUBSET of the rows, applied to the
+ * output of a dense transform instead of inside an aggregation: y / out are compact [n_rows, d] matrices of the rows row_index[0 .. n_rows) (ascending
+ * global ids), mix_src (may be NULL) and relu_bits ([N][d/256][4], may be NULL) are the full arrays, the dropout mask is drawn at the global row.
+ *   act = relu(y[r]);  out[r] = dropout((c_act * act + c_mix * mix_src[row_index[r]]));  bits as cb_spmm_csr_fused_f32 writes them.
+ * The rows-only forward of the training step (trunk.py): the last GCNConv (GCN.py:205-256) evaluated on the loss rows of trainer…:390-391. */
+int cb_trunk_store_rows_f32(const float* y, const int64_t* row_index, int64_t n_rows, int64_t d, const float* mix_src, int64_t ld_mix, float c_act,
+                            float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, int bits_relu_only,
+                            float* out, void* stream);
 
 #ifdef __cplusplus
 }

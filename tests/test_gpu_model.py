@@ -112,7 +112,7 @@ def test_fused_trunk_equals_modular_path(se, train, conn, monkeypatch):
     assert model.model.model.type_trick == conn
     calls = []
     real = trunk._TrunkFn.apply
-    monkeypatch.setattr(trunk._TrunkFn, 'apply', staticmethod(lambda *a, **k: (calls.append(a[1][-1]), real(*a, **k))[1]))
+    monkeypatch.setattr(trunk._TrunkFn, 'apply', staticmethod(lambda *a, **k: (calls.append(a[1][7]), real(*a, **k))[1]))
     res = {}
     for fused in (True, False):
         TricksComb.use_fused_trunk = fused

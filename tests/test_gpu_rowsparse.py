@@ -16,12 +16,15 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def _step_grads(flag, dataset='S-pl1M', se='000', layers=3, extra=(), n_loss_rows=None):
+def _step_grads(flag, dataset='S-pl1M', se='000', layers=3, extra=(), n_loss_rows=None, rows_only=False):
+    """One training step's (loss, gradients, plan used).  flag: CB_LOSS_ROWS.  rows_only=False pins the FORWARD to all rows (CB_ROWS_ONLY_FWD=0), so
+    that the tests of the backward compare like with like (the same loss bit for bit); the rows-only forward has its own tests below."""
     import bench
     from gnn_tail_generalization_amd import _lib, ops
     from gnn_tail_generalization_amd import trainer_node_classification as tnc
-    old = os.environ.get('CB_LOSS_ROWS')
+    old, old_ro = os.environ.get('CB_LOSS_ROWS'), os.environ.get('CB_ROWS_ONLY_FWD')
     os.environ['CB_LOSS_ROWS'] = flag
+    os.environ['CB_ROWS_ONLY_FWD'] = '1' if rows_only else '0'
     try:
         args = bench.make_args(dataset, ['--manual_assign_GPU=0'] + list(extra), se=se, layers=layers)
         torch.manual_seed(0)
@@ -43,10 +46,11 @@ def _step_grads(flag, dataset='S-pl1M', se='000', layers=3, extra=(), n_loss_row
         return float(loss.detach()), {k: p.grad.detach().clone() for k, p in t.teacherGNN.named_parameters() if p.grad is not None}, used
     finally:
         ops._seed_override[:] = []
-        if old is None:
-            os.environ.pop('CB_LOSS_ROWS', None)
-        else:
-            os.environ['CB_LOSS_ROWS'] = old
+        for k, v in (('CB_LOSS_ROWS', old), ('CB_ROWS_ONLY_FWD', old_ro)):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.mark.parametrize('conn', ['Initial', 'Residual'])
@@ -121,6 +125,74 @@ def test_column_statistic_norms_keep_the_dense_backward():
     assert not used
 
 
+def _close_up_to_relu_flips(got, ref, name):
+    """(sum a X) W and sum a (X W) differ in the last bits, and a pre-activation that is zero to rounding may land on either side of the ReLU: one such
+    element among the 2.6 * 10^7 of S-pl1M's loss rows moves every gradient by ~ 1 / sqrt(2.6 * 10^7) = 2 * 10^-4 of its norm (measured:
+    tools/probes/rows_only_dbg.py — no flipped mask word: 1e-7; two: 1.8e-4).  A wrong term would show at 1e-2 and more."""
+    assert float((got - ref).norm()) <= 1e-3 * float(ref.norm()), name
+    assert float((got - ref).abs().max()) <= 5e-3 * float(ref.abs().max()), name
+
+
+@pytest.mark.parametrize('conn,se,layers,n_loss_rows', [('Initial', '000', 3, None), ('Residual', '000', 3, None), ('Initial', '100', 3, None), ('Initial', '000', 2, None),
+                                                        ('Residual', '100', 4, None), ('Initial', '000', 3, 200)])
+def test_rows_only_forward_equals_the_dense_step(conn, se, layers, n_loss_rows, monkeypatch):
+    """Rows-only forward (trunk._last_layer_on_loss_rows): the trainer promises that it reads — not only differentiates — the logits in the train rows
+    only, and the training forward evaluates its LAST layer (aggregation of the inputs over the edges that enter the loss rows, transform, store,
+    output Linear) on those rows; the backward's level 0 contracts the saved aggregate.  Against the all-rows step with the dense backward: the
+    same loss and gradients up to the association of sums — (sum a X) W against sum a (X W) — and the ReLUs that association flips at zero."""
+    from gnn_tail_generalization_amd import trunk
+    calls = []
+    real = trunk._last_layer_on_loss_rows
+    monkeypatch.setattr(trunk, '_last_layer_on_loss_rows', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    extra = () if conn == 'Initial' else ('--force_set_to_best_config=0', '--type_trick=Residual')
+    loss_s, g_s, used_s = _step_grads('1', se=se, layers=layers, extra=extra, n_loss_rows=n_loss_rows, rows_only=True)
+    assert calls == [1] and used_s
+    loss_d, g_d, used_d = _step_grads('0', se=se, layers=layers, extra=extra, n_loss_rows=n_loss_rows)
+    assert calls == [1] and not used_d
+    assert abs(loss_s - loss_d) <= 2e-6 * abs(loss_d) and set(g_s) == set(g_d)
+    for k in g_d:
+        _close_up_to_relu_flips(g_s[k], g_d[k], k)
+
+
+def test_rows_only_forward_returns_the_loss_rows_and_zeros(monkeypatch):
+    """What the caller gets under both promises: the logits of the all-rows forward (same dropout masks: they are drawn at the global row) in the rows
+    of the mask, zeros in every other row.  Without rows_only — the gradient promise alone — every row is evaluated."""
+    import bench
+    from gnn_tail_generalization_amd import ops
+    from gnn_tail_generalization_amd import trainer_node_classification as tnc
+    args = bench.make_args('S-pl1M', ['--manual_assign_GPU=0'])
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        t = tnc.trainer(args, 0)
+        t.setup_teacherGNN()
+    t.teacherGNN.train()
+    mask, n = t.data.train_mask, int(t.data.train_mask.sum())
+    outs = {}
+    for ro in (True, False):
+        ops._seed_override[:] = [21, 22, 23, 24, 25]
+        outs[ro] = t.teacherGNN.get_3_embs(t.data.x, t.data.edge_index, loss_rows=(mask, n), rows_only=ro).emb4classi_full
+        ops._seed_override[:] = []
+    assert float(outs[True].detach()[~mask].abs().max()) == 0.0 and float(outs[False].detach()[~mask].abs().max()) > 0.0
+    torch.testing.assert_close(outs[True].detach()[mask], outs[False].detach()[mask], atol=2e-5, rtol=2e-5)
+    with torch.no_grad():      # a forward that no backward follows keeps every row, whatever was promised
+        ops._seed_override[:] = [21, 22, 23, 24, 25]
+        out_ng = t.teacherGNN.get_3_embs(t.data.x, t.data.edge_index, loss_rows=(mask, n), rows_only=True).emb4classi_full
+        ops._seed_override[:] = []
+    torch.testing.assert_close(out_ng, outs[False].detach(), atol=0, rtol=0)
+
+
+def test_rows_only_forward_is_not_taken_with_a_table_on_the_last_layer(monkeypatch):
+    """A structural-embedding table on the last layer has dL/dZ on ALL rows of S_1 as its gradient: the level cannot run through the loss rows' side,
+    so the forward keeps every row (the backward is row-sparse as before)."""
+    from gnn_tail_generalization_amd import trunk
+    calls = []
+    real = trunk._last_layer_on_loss_rows
+    monkeypatch.setattr(trunk, '_last_layer_on_loss_rows', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    loss_s, g_s, used_s = _step_grads('1', se='111', rows_only=True)
+    loss_d, g_d, _ = _step_grads('0', se='111')
+    assert calls == [] and used_s and loss_s == loss_d
+
+
 @pytest.mark.parametrize('n_loss_rows', [3, 200, 20000])
 def test_row_sparse_backward_with_sparse_labels(n_loss_rows, monkeypatch):
     """Few loss rows (the public Planetoid splits label 0.3 - 5 % of the nodes): supports of 3 / 200 / 20 000 rows that grow by orders of
@@ -162,7 +234,8 @@ def test_row_sparse_backward_two_layers_small_graph(monkeypatch):
 @pytest.mark.parametrize('case', ['case_r_initialbn_h256_L3_train10', 'case_r_initialbn_h256_L3_train10_se111',
                                   'case_r_residual_h256_L3_train10', 'case_r_residual_h256_L3_train10_se111',      # (Residual, round 5: cumulative supports)
                                   'case_nr_h256_L3_train10', 'case_nr_h256_L3_train10_se111'])                    # (the non-residual stack, stack.py)
-def test_row_sparse_backward_matches_the_unmodified_reference(case, monkeypatch):
+@pytest.mark.parametrize('rows_only', [False, True])
+def test_row_sparse_backward_matches_the_unmodified_reference(case, rows_only, monkeypatch):
     """The reference's own gradients (goldens case_r_initialbn_h256_L3_train10[_se111]: hidden 256, 3 layers, 8 – 10 % train rows, without
     and with structural-embedding tables on every layer, generated from the unmodified reference by tests/golden/make_golden.py) against
     the product's fused trunk with the row-sparse backward switched on at this small size: supports S_0 and S_1 compact, then dense; without
@@ -179,7 +252,8 @@ def test_row_sparse_backward_matches_the_unmodified_reference(case, monkeypatch)
     args, model = product_model(g['cfg'], g['sd'], DEV)
     x, ei, y, mask = g['x'].to(DEV), g['edge_index'].to(DEV), g['y'].to(DEV), g['train_mask'].to(DEV)
     model.train()
-    out = model.get_3_embs(x, ei, mask, loss_rows=mask).emb4classi_full
+    # rows_only: the last layer of the residual trunks on the loss rows (tables on every layer / the non-residual stack: the forward keeps all rows)
+    out = model.get_3_embs(x, ei, mask, loss_rows=mask, rows_only=rows_only).emb4classi_full
     loss = ops.nll_logsoftmax(out, y, mask)
     if model.se_reg_all is not None:                                  # trainer_node_classification.py:393-394
         loss = loss + args.se_reg * model.se_reg_all
@@ -189,7 +263,12 @@ def test_row_sparse_backward_matches_the_unmodified_reference(case, monkeypatch)
     assert _lib.load().cb_device_status() == 0
     plan = getattr(model.model.model._graph(ei), '_support_plan', None)
     assert plan is not None and plan.levels[0][1] is not None       # the backward ran on the plan, S_1 compact
-    torch.testing.assert_close(out.detach().cpu(), g['train_out'], atol=1e-4, rtol=1e-4)
+    took_rows_only = rows_only and case in ('case_r_initialbn_h256_L3_train10', 'case_r_residual_h256_L3_train10')
+    if took_rows_only:
+        assert float(out.detach()[~mask].abs().max()) == 0.0
+        torch.testing.assert_close(out.detach()[mask].cpu(), g['train_out'][mask.cpu()], atol=1e-4, rtol=1e-4)
+    else:
+        torch.testing.assert_close(out.detach().cpu(), g['train_out'], atol=1e-4, rtol=1e-4)
     torch.testing.assert_close(loss.detach().cpu(), g['train_loss'], atol=1e-4, rtol=1e-5)
     got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
     assert set(got) == set(g['grads'])
@@ -260,6 +339,13 @@ def test_row_sparse_backward_at_the_headline_size():
     assert used_s and not used_d and loss_s == loss_d
     for k in g_d:
         assert float((g_s[k] - g_d[k]).abs().max()) <= 5e-6 * float(g_d[k].abs().max()), k
+    del g_s
+    loss_r, g_r, used_r = _step_grads('1', dataset='S-pl10M', rows_only=True)      # + the rows-only forward (the default of the trainer's step)
+    gc.collect()
+    torch.cuda.empty_cache()
+    assert used_r and abs(loss_r - loss_d) <= 2e-6 * abs(loss_d)
+    for k in g_d:
+        _close_up_to_relu_flips(g_r[k], g_d[k], k)
 
 
 def test_support_plan_levels_are_the_reverse_graph_restricted_and_renumbered(monkeypatch):

@@ -148,7 +148,10 @@ def test_epoch_loop_replayed_as_hip_graphs_matches_eager(extra):
     np.testing.assert_allclose(recs[1], recs[0], atol=1e-3)
     for k, v in sds[0].items():
         if v.dtype.is_floating_point:
-            torch.testing.assert_close(sds[1][k], v, atol=1e-5, rtol=1e-4, msg=lambda m, k=k: f'{k}: {m}')
+            # (under replay the trainer's graph takes the row-sparse plan and the rows-only forward at any size, the eager loop on these small graphs does not:
+            # a pre-activation that is zero to rounding may fall on either side of the ReLU — tests/test_gpu_rowsparse.py::_close_up_to_relu_flips — and Adam
+            # turns a gradient that moved by 1e-3 of its norm into a step that moved by about as much of lr = 0.01, six times)
+            torch.testing.assert_close(sds[1][k], v, atol=2e-4, rtol=1e-3, msg=lambda m, k=k: f'{k}: {m}')
 
 
 def test_sharded_trainer_world1_matches_plain_trainer():
