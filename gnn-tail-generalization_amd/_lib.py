@@ -60,6 +60,9 @@ SIGNATURES = {
     'cb_spmm_csr_fused_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,
                                              ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _I32, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P,
                                              _P, _SZ, _P]),
+    'cb_spmm_csr_fused_rows_f32': (ctypes.c_int, [_P, _P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float,
+                                                  ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, _I32, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P,
+                                                  _P, _SZ, _P]),
     'cb_trunk_layer_bwd_f32': (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, _P, ctypes.c_int, _I64, _I64, ctypes.c_float, ctypes.c_uint64,
                                               _P, _I64, ctypes.c_float, ctypes.c_float, _P, ctypes.c_uint64, ctypes.c_float, _P, _P, _P, _SZ, _P]),
     'cb_gemm_nn_bf16out_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, ctypes.c_int, _P, _SZ, _P]),
@@ -92,7 +95,7 @@ SIGNATURES = {
     'cb_adam_multi_norm_f32': (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                               ctypes.c_float, _I64, _P, _P, _P, _SZ, _P]),
     'cb_expand_rows_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P]),
-    'cb_trunk_store_rows_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P,
+    'cb_trunk_store_rows_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P,
                                                ctypes.c_int, _P, _P]),
     'cb_agg_gemm_image_bytes': (_SZ, [_I64, _I64]),
     'cb_agg_gemm_image_f32': (ctypes.c_int, [_P, _I64, _I64, _I64, ctypes.c_int, _P, _SZ, _P]),

@@ -1074,16 +1074,18 @@ extern "C" int cb_gather_rows_f32(const float* src, int64_t ld, const int64_t* i
 namespace cb {
 // The trunk's fused store (cb_spmm_core.h FusedEpi: ReLU, mask words, mix, dropout) on a SUBSET of the rows, after a dense transform instead of
 // inside an aggregation — the rows-only forward of trunk.py (the last layer on the loss rows):
-//   act = relu(y[r]);  out[r] = dropout_seed((c_act * act + c_mix * mix_src[row_index[r]]));  mask words at the GLOBAL row row_index[r].
-// y / out: compact [n_rows, d]; mix_src (may be null) and relu_bits: the full arrays.  One wavefront per row, lane l = columns 4l .. 4l+3 of each tile.
+//   act = relu(y[r]);  out[r] = dropout_seed((c_act * act + c_mix * mix_src[mix_index[r]]));  mask words at the GLOBAL row row_index[r].
+// y / out: compact [n_rows, d]; relu_bits: the full array; mix_src (may be null): its row mix_index[r] (mix_index null: row_index[r], i.e. the full
+// array).  One wavefront per row, lane l = columns 4l .. 4l+3 of each tile.
 __global__ void __launch_bounds__(kBlock) k_trunk_store_rows(const float* __restrict__ y, const int64_t* __restrict__ ridx, int64_t n_rows, int d,
-                                                             const float* __restrict__ mix_src, int64_t ld_mix, float c_act, float c_mix, uint32_t thresh,
+                                                             const float* __restrict__ mix_src, int64_t ld_mix, const int64_t* __restrict__ midx, float c_act,
+                                                             float c_mix, uint32_t thresh,
                                                              float keep_scale, uint64_t seed, const uint64_t* __restrict__ seed_dev, int64_t row0,
                                                              unsigned long long* __restrict__ bits, int relu_only, float* __restrict__ out) {
   if (seed_dev) seed += *seed_dev;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tiles = d >> 8;
   for (int64_t r = (int64_t)blockIdx.x * (kBlock / kWave) + w; r < n_rows; r += (int64_t)gridDim.x * (kBlock / kWave)) {
-    const int64_t rr = ridx[r];
+    const int64_t rr = ridx[r], mr = midx ? midx[r] : rr;
     for (int tile = 0; tile < tiles; ++tile) {
       const int c = tile * 256 + lane * 4;
       const float4 y4 = *reinterpret_cast<const float4*>(y + r * d + c);
@@ -1100,7 +1102,7 @@ __global__ void __launch_bounds__(kBlock) k_trunk_store_rows(const float* __rest
       }
       float x[4] = {a[0], a[1], a[2], a[3]};
       if (mix_src) {
-        const float4 q = *reinterpret_cast<const float4*>(mix_src + rr * ld_mix + c);
+        const float4 q = *reinterpret_cast<const float4*>(mix_src + mr * ld_mix + c);
         x[0] = mix2(c_act, a[0], c_mix, q.x); x[1] = mix2(c_act, a[1], c_mix, q.y); x[2] = mix2(c_act, a[2], c_mix, q.z); x[3] = mix2(c_act, a[3], c_mix, q.w);
       }
       if (thresh) {
@@ -1113,8 +1115,8 @@ __global__ void __launch_bounds__(kBlock) k_trunk_store_rows(const float* __rest
 }
 }  // namespace cb
 
-extern "C" int cb_trunk_store_rows_f32(const float* y, const int64_t* row_index, int64_t n_rows, int64_t d, const float* mix_src, int64_t ld_mix, float c_act,
-                                       float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits,
+extern "C" int cb_trunk_store_rows_f32(const float* y, const int64_t* row_index, int64_t n_rows, int64_t d, const float* mix_src, int64_t ld_mix,
+                                       const int64_t* mix_index, float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits,
                                        int bits_relu_only, float* out, void* stream) {
   CB_CHECK_ARG(n_rows >= 0 && d > 0 && d % 256 == 0 && d < (1 << 20), CB_E_INVALID, "cb_trunk_store_rows_f32: d must be a multiple of 256");
   if (n_rows == 0) return CB_OK;
@@ -1124,7 +1126,7 @@ extern "C" int cb_trunk_store_rows_f32(const float* y, const int64_t* row_index,
   CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && row0 >= 0, CB_E_INVALID, "cb_trunk_store_rows_f32: dropout p / row offset out of range");
   int64_t nb = (n_rows + kBlock / kWave - 1) / (kBlock / kWave);
   if (nb > kMaxBlocks) nb = kMaxBlocks;
-  hipLaunchKernelGGL(k_trunk_store_rows, dim3((unsigned)nb), dim3(kBlock), 0, (hipStream_t)stream, y, row_index, n_rows, (int)d, mix_src, ld_mix, c_act, c_mix,
+  hipLaunchKernelGGL(k_trunk_store_rows, dim3((unsigned)nb), dim3(kBlock), 0, (hipStream_t)stream, y, row_index, n_rows, (int)d, mix_src, ld_mix, mix_index, c_act, c_mix,
                      drop_p > 0.f ? dropout_threshold(drop_p) : 0u, 1.f / (1.f - drop_p), seed, seed_dev, row0, (unsigned long long*)relu_bits, bits_relu_only, out);
   CB_LAUNCH_CHECK();
   return CB_OK;

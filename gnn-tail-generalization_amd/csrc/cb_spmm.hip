@@ -236,7 +236,7 @@ static int spmm_fused_impl(int h_bf16, const float* acc_init, int64_t ld_init, i
                                      float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, int32_t bits_relu_only,
                                      float* out_act, int64_t ld_act, float* out_next, int64_t ld_next, int32_t hub_T,
                                      int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr,
-                                     void* ws, size_t ws_bytes, void* stream) {
+                                     void* ws, size_t ws_bytes, void* stream, const int32_t* row_ids = nullptr) {
   CB_CHECK_ARG(N >= 0 && E >= 0 && d > 0 && d % 256 == 0, CB_E_INVALID, "cb_spmm_csr_fused_f32: d must be a positive multiple of 256");
   CB_CHECK_ARG(N < INT32_MAX && E < INT32_MAX && d < (1 << 20), CB_E_RANGE, "cb_spmm_csr_fused_f32: size exceeds the int32 contract");
   if (N == 0) return CB_OK;
@@ -258,7 +258,7 @@ static int spmm_fused_impl(int h_bf16, const float* acc_init, int64_t ld_init, i
   fe.thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
   fe.keep_scale = 1.f / (1.f - drop_p);
   fe.seed = seed; fe.seed_dev = seed_dev; fe.row0 = row0; fe.bits = (unsigned long long*)relu_bits; fe.bits_relu_only = bits_relu_only;
-  fe.out_act = out_act; fe.ld_act = ld_act; fe.out_next = out_next; fe.ld_next = ld_next; fe.d = (int)d;
+  fe.out_act = out_act; fe.ld_act = ld_act; fe.out_next = out_next; fe.ld_next = ld_next; fe.d = (int)d; fe.row_ids = row_ids;
   if (h_bf16)
     return launch_spmm<4, true, bf16_t>(rowptr, col, N, (const bf16_t*)h, ld_h, d, ep, out_next, ld_next, hub_T, n_hubs, n_chunks,
                                         hub_rows, hub_chunk_ptr, (float*)ws, (hipStream_t)stream, fe);
@@ -283,6 +283,18 @@ extern "C" int cb_spmm_csr_fused_f32(const int32_t* rowptr, const int32_t* col, 
                                      int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows,
                                      const int32_t* hub_chunk_ptr, void* ws, size_t ws_bytes, void* stream) {
   return spmm_fused_impl(0, nullptr, 0, col_flags, CB_FUSED_ARGS);
+}
+
+// The same over a CSR whose rows are a SUBSET of the node rows (rows-only forward, trunk.py): row r of the CSR / of row_scale / of out_act / out_next is
+// node row row_ids[r] (ascending); mix_src, relu_bits and the dropout mask are taken at the node row.
+extern "C" int cb_spmm_csr_fused_rows_f32(const int32_t* row_ids, const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E,
+                                          const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias, const float* mix_src,
+                                          int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0,
+                                          uint64_t* relu_bits, int32_t bits_relu_only, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
+                                          int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,
+                                          size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(row_ids != nullptr || N == 0, CB_E_INVALID, "cb_spmm_csr_fused_rows_f32: row_ids is null");
+  return spmm_fused_impl(0, nullptr, 0, col_flags, CB_FUSED_ARGS, row_ids);
 }
 
 // Fused store of the residual trunk on top of the interior-column partial sums (second pass of the node-sharded aggregation)

@@ -167,15 +167,18 @@ struct FusedEpi {
   int64_t ld_next;
   int d;
   int skip_next;          // cb_agg_gemm.hip, forwards without a backward: the finished row only goes to the on-chip tile, not to out_next
+  const int32_t* row_ids; // or null.  The CSR's rows are a SUBSET of the node rows (row r = node row_ids[r]; rows-only forward, trunk.py): mix_src, the mask
+                          // words and the dropout mask are taken at the node row, out_act / out_next (and row_scale, rowptr) at the compact row
 };
 
 // x: the values stored to out_next (also handed to the caller: cb_agg_gemm.hip keeps the finished row on chip)
+// grow: the node row of `row` (== row unless fe.row_ids)
 __device__ __forceinline__ void fused_store(const FusedEpi& fe, int64_t row, int c0, const float (&acc)[4], float scale,
-                                            const float (&b)[4], const float (&rmix)[4], float (&x)[4]) {
+                                            const float (&b)[4], const float (&rmix)[4], float (&x)[4], int64_t grow) {
   float a[4], m[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
   for (int i = 0; i < 4; ++i) a[i] = fmaxf(scale_add(acc[i], scale, b[i]), 0.f);
-  if (fe.thresh) keep4(fe.seed_dev ? fe.seed + *fe.seed_dev : fe.seed, ((fe.row0 + row) * fe.d + c0) >> 2, fe.thresh, fe.keep_scale, m);
+  if (fe.thresh) keep4(fe.seed_dev ? fe.seed + *fe.seed_dev : fe.seed, ((fe.row0 + grow) * fe.d + c0) >> 2, fe.thresh, fe.keep_scale, m);
   if (fe.bits) {
     // mask word k of (row, tile), bit l: the element (column 4 l + k) passes gradient to the pre-activation — ReLU positive AND kept
     // by the dropout.  The backward kernels that also regenerate the keep-mask are unaffected (masking twice is masking once).
@@ -186,7 +189,7 @@ __device__ __forceinline__ void fused_store(const FusedEpi& fe, int64_t row, int
       const unsigned long long w = __ballot(a[k] > 0.f && (fe.bits_relu_only || m[k] != 0.f));
       if (lane == k) mine = w;
     }
-    if (lane < 4) fe.bits[(row * (fe.d >> 8) + (c0 >> 8)) * 4 + lane] = mine;
+    if (lane < 4) fe.bits[(grow * (fe.d >> 8) + (c0 >> 8)) * 4 + lane] = mine;
   }
   if (fe.out_act) store_stream<4>(fe.out_act + row * fe.ld_act + c0, a);
 #pragma unroll
@@ -235,7 +238,8 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
                                             const HT* __restrict__ h_lane, int64_t ld_h, float* __restrict__ out_lane,
                                             int64_t ld_out, bool active_in, int relu, const float (&bvec)[VEC], const FusedEpi& fe,
                                             int c0, const float* __restrict__ init_lane, int64_t ld_init, const Epilogue& ep,
-                                            float* tile_lane = nullptr, int ptr_hi = 0) {
+                                            float* tile_lane = nullptr, int ptr_hi = 0, int my_gid_v = 0) {
+  // my_gid_v (FUSED with fe.row_ids): lane i holds the node row of local row i
   static_assert(TLD == 0 || (VEC == 4 && FULL), "on-chip row tile: d == 256, float4 lanes");
   static_assert(!CS || (!P65 && !FUSED && !ACC && sizeof(HT) == 4), "source-row factor: plain fp32 aggregation only");
   struct PtrAt {      // rowptr of local row i (wave-uniform i)
@@ -254,10 +258,11 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
     if (active && !(skip_empty && my_ptr_at(rlo) == my_ptr_at(rlo + 1))) gather_stream<VEC>(ainit, init_lane + (int64_t)(r0 + rlo) * ld_init);
   }
   float rmix[4] = {0.f, 0.f, 0.f, 0.f};   // FUSED: mix_src row of local row `cur`, fetched one row ahead
+  auto gid_of = [&](int i) -> int64_t { return fe.row_ids ? (int64_t)bcast_lane(my_gid_v, i) : (int64_t)(r0 + i); };
   if constexpr (FUSED) {
     if (fe.mix_src) {
       float t[VEC];
-      gather_stream<VEC>(t, fe.mix_src + (int64_t)(r0 + rlo) * fe.ld_mix + c0);
+      gather_stream<VEC>(t, fe.mix_src + gid_of(rlo) * fe.ld_mix + c0);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) rmix[i] = t[i];
     }
@@ -292,11 +297,11 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
 #pragma unroll
       for (int i = 0; i < 4; ++i) { a4[i] = acc[i % VEC]; b4[i] = bvec[i % VEC]; }
       float x4[4];
-      fused_store(fe, (int64_t)(r0 + cur), c0, a4, s, b4, rmix, x4);
+      fused_store(fe, (int64_t)(r0 + cur), c0, a4, s, b4, rmix, x4, gid_of(cur));
       if constexpr (TLD > 0) *reinterpret_cast<float4*>(tile_lane + cur * TLD) = make_float4(x4[0], x4[1], x4[2], x4[3]);
       if (fe.mix_src && cur + 1 < nr) {
         float t[VEC];
-        gather_stream<VEC>(t, fe.mix_src + (int64_t)(r0 + cur + 1) * fe.ld_mix + c0);
+        gather_stream<VEC>(t, fe.mix_src + gid_of(cur + 1) * fe.ld_mix + c0);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) rmix[i] = t[i];
       }
@@ -424,6 +429,10 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
   if (ep.row_scale && lane < nr) my_scale = __builtin_nontemporal_load(ep.row_scale + r0 + lane);
   const int nxt = __shfl_down(my_ptr, 1);
   const unsigned long long hubmask = __ballot(lane < nr && (nxt - my_ptr) > hub_T);
+  int my_gid = 0;
+  if constexpr (FUSED) {
+    if (fe.row_ids && lane < nr) my_gid = fe.row_ids[r0 + lane];
+  }
 
   float bvec[VEC];
   zero<VEC>(bvec);
@@ -437,7 +446,7 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
 
   if (hubmask == 0) {
     stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP, 0, false, CS>(0, nr, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0,
-                                                    init_lane, ep.ld_init, ep);
+                                                    init_lane, ep.ld_init, ep, nullptr, 0, my_gid);
   } else {
     int r = 0;
     while (r < nr) {  // maximal hub-free runs; hub rows are written by the hub kernels
@@ -445,7 +454,7 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
       int nh = m ? r + (__ffsll((long long)m) - 1) : nr;
       if (nh > r)
         stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP, 0, false, CS>(r, nh, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe,
-                                                        c0, init_lane, ep.ld_init, ep);
+                                                        c0, init_lane, ep.ld_init, ep, nullptr, 0, my_gid);
       r = nh + 1;
     }
   }
@@ -564,14 +573,15 @@ __global__ void __launch_bounds__(256) k_spmm_hub_finish(int d, int n_hubs, cons
     float a4[4], b4[4], rmix[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) { a4[k] = acc[k % VEC]; b4[k] = bvec[k % VEC]; }
+    const int64_t grow = fe.row_ids ? (int64_t)fe.row_ids[row] : (int64_t)row;
     if (fe.mix_src) {
       float t[VEC];
-      gather_stream<VEC>(t, fe.mix_src + (int64_t)row * fe.ld_mix + c0);
+      gather_stream<VEC>(t, fe.mix_src + grow * fe.ld_mix + c0);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) rmix[k] = t[k];
     }
     float x4[4];
-    fused_store(fe, (int64_t)row, c0, a4, s, b4, rmix, x4);
+    fused_store(fe, (int64_t)row, c0, a4, s, b4, rmix, x4, grow);
   } else {
     {
       if (ep.lp_mix) {      // label-propagation store (narrow rows only ever set it)

@@ -205,6 +205,25 @@ class CSRGraph:
             plan.fwd[0] = self._support_fwd(plan.space0, dst.n if dst is not None else self.N, force=True)
         return plan.fwd[0]
 
+    def rows_only_fwd(self, plan):
+        """Orientations of a rows-only forward that also evaluates the layer BELOW the last one on the rows the last layer reads — S_1, when the plan keeps
+        that support compact (else None): (fwd1, fwd0c, ids1, b1, s1) with fwd1 = the forward orientation on the rows of S_1 (sources: all node rows),
+        fwd0c = the one on the rows of S_0 with its sources renumbered to positions in S_1 (every in-neighbour of a loss row is a member of S_1),
+        ids1 = int32 node ids of S_1's rows, b1 = norm_in on them, s1 = the RowSpace.  Built once per plan."""
+        hit = getattr(plan, '_rows_fwd', None)
+        if hit is not None:
+            return hit or None
+        s1 = plan.levels[0][1]
+        if s1 is None:
+            plan._rows_fwd = ()
+            return None
+        fwd0 = self.loss_rows_fwd(plan)
+        fwd1 = self._support_fwd(s1, self.N, force=True)
+        col_c = torch.index_select(s1.pos, 0, fwd0.col[:fwd0.E].long())
+        fwd0c = CSRGraph.from_csr(fwd0.rowptr, col_c, s1.n, hub_threshold=self.hub_threshold)
+        plan._rows_fwd = (fwd1, fwd0c, s1.idx.to(torch.int32).contiguous(), self.norm_in[s1.idx].contiguous(), s1)
+        return plan._rows_fwd
+
     def _support_fwd(self, s0, n_out, force=False):
         """The FORWARD orientation restricted to the rows of a support S_j (one row per member; its in-neighbours — all of them members of
         S_{j+1} — keep their global ids): (A (a * X))[S_j] = fwd.spmm(X, col_scale=a).  With it the weight gradient of the level

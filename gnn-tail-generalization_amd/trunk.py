@@ -167,12 +167,14 @@ def agg_gemm_eligible(graph, hidden, agg_bf16):
     return hasattr(graph, 'spmm_gemm')
 
 
-def _fused_launch(lib, graph, g, z, acc, bias, x0, c_act, c_mix, p, seed, want_act, want_bits=True, relu_only=False):
+def _fused_launch(lib, graph, g, z, acc, bias, x0, c_act, c_mix, p, seed, want_act, want_bits=True, relu_only=False, row_ids=None, row_scale=None):
     """One fused-store launch over CSR g (the whole graph, a rank's single-pass block, or the last halo slice on top of acc).
-    want_bits=False (forward without a backward: eval / metrics forwards): the backward's mask words are not written."""
+    want_bits=False (forward without a backward: eval / metrics forwards): the backward's mask words are not written.
+    row_ids (int32 [g.N], with row_scale = norm_in on those rows): g's rows are a subset of the node rows (cb_spmm_csr_fused_rows_f32) — out_next is
+    compact, x0 / the mask words / the dropout mask are taken at the node row (the mask words of the other rows are not written)."""
     n, d = g.N, z.shape[1]
     dev = z.device
-    bits = torch.empty((n, d // 256, 4), dtype=torch.int64, device=dev) if want_bits else None
+    bits = torch.empty((n if row_ids is None else graph.N, d // 256, 4), dtype=torch.int64, device=dev) if want_bits else None
     out_next = torch.empty((n, d), dtype=torch.float32, device=dev)
     act = torch.empty((n, d), dtype=torch.float32, device=dev) if want_act else None
     plan = g._plan
@@ -185,13 +187,15 @@ def _fused_launch(lib, graph, g, z, acc, bias, x0, c_act, c_mix, p, seed, want_a
     bf16 = z.dtype == torch.bfloat16
     col_k = g.flagged_cols(False, d * z.element_size()) if hasattr(g, 'flagged_cols') else None
     head = (_lib.ptr(g.rowptr), _lib.ptr(col_k if col_k is not None else g.col), int(col_k is not None))
-    args = head + (n, g.E, _lib.ptr(z), z.stride(0), d, _lib.ptr(graph.norm_in), _lib.ptr(bias),
+    args = head + (n, g.E, _lib.ptr(z), z.stride(0), d, _lib.ptr(graph.norm_in if row_scale is None else row_scale), _lib.ptr(bias),
             _lib.ptr(x0), x0.stride(0) if x0 is not None else 0, float(c_act), float(c_mix), float(p), ctypes.c_uint64(seed),
             ops.seed_dev_ptr(), int(getattr(graph, 'row_offset', 0)), _lib.ptr(bits), int(bool(relu_only)), _lib.ptr(act), d, _lib.ptr(out_next), d,
             g.hub_threshold,
             plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), wsb, _lib.stream_ptr())
     with torch.cuda.device(dev):
-        if acc is not None:
+        if row_ids is not None:
+            _lib.check(lib.cb_spmm_csr_fused_rows_f32(_lib.ptr(row_ids), *args), 'cb_spmm_csr_fused_rows_f32')
+        elif acc is not None:
             fn = lib.cb_spmm_csr_fused_acc_bf16_f32 if bf16 else lib.cb_spmm_csr_fused_acc_f32
             _lib.check(fn(_lib.ptr(acc), d, *args), 'cb_spmm_csr_fused_acc_f32')
         else:
@@ -352,35 +356,41 @@ def rows_only_enabled():
     return os.environ.get('CB_ROWS_ONLY_FWD', '1') != '0'
 
 
-def _store_rows(y, idx, mix, c_act, c_mix, p, seed, row0, bits, relu_only):
-    """cb_trunk_store_rows_f32: the trunk's fused store (ReLU, mask words, mix, dropout) on the compact rows idx of a dense transform's output."""
+def _store_rows(y, idx, mix, c_act, c_mix, p, seed, row0, bits, relu_only, mix_index=None):
+    """cb_trunk_store_rows_f32: the trunk's fused store (ReLU, mask words, mix, dropout) on the compact rows idx of a dense transform's output.
+    mix_index: the rows of `mix` to read when that is a compact matrix itself (default: the node rows idx)."""
     lib = _lib.load()
     out = torch.empty_like(y)
     with torch.cuda.device(y.device):
         _lib.check(lib.cb_trunk_store_rows_f32(_lib.ptr(y), _lib.ptr(idx), y.shape[0], y.shape[1], _lib.ptr(mix), mix.stride(0) if mix is not None else 0,
-                                               float(c_act), float(c_mix), float(p), ctypes.c_uint64(seed), ops.seed_dev_ptr(), int(row0), _lib.ptr(bits),
+                                               _lib.ptr(mix_index), float(c_act), float(c_mix), float(p), ctypes.c_uint64(seed), ops.seed_dev_ptr(), int(row0), _lib.ptr(bits),
                                                int(bool(relu_only)), _lib.ptr(out), _lib.stream_ptr()), 'cb_trunk_store_rows_f32')
     return out
 
 
-def _last_layer_on_loss_rows(graph, plan, cur, w, b, mix, alpha, p, seed, row0, residual, w_out, b_out):
+def _last_layer_on_loss_rows(graph, plan, cur, w, b, mix, alpha, p, seed, row0, residual, w_out, b_out, below=None):
     """The LAST GCNConv, its store and the output Linear on the loss rows S_0 only (rows-only forward): aggregation and transform commute,
         Y[S_0] = b * ((A (a * X))[S_0] W) + bias        (GCN.py:213-256 with the sum taken first)
     so the layer is one aggregation over the edges that ENTER the loss rows (10 % of the edges under a 10 % mask) into a compact [|S_0|, H] matrix, a
     GEMM on |S_0| rows, the store on those rows and the head on those rows.  Z_{L-1} — the previous layer's dense tail — is never formed.
     Returns (mask words [N, H/256, 4] (rows of S_0 written), dropped X_L on S_0, logits [N, C] with zeros outside S_0, H = (A (a * X))[S_0]:
-    the operand of the level's weight gradient in the backward's source-side form)."""
+    the operand of the level's weight gradient in the backward's source-side form).  below (CSRGraph.rows_only_fwd): `cur` holds the rows of S_1 only."""
     sp = plan.space0
-    fwd0 = graph.loss_rows_fwd(plan)
+    fwd0 = graph.loss_rows_fwd(plan) if below is None else below[1]
     fwd0.profile = getattr(graph, 'profile', None)
-    h_agg = fwd0.spmm(cur, col_scale=graph.norm_out)
+    h_agg = fwd0.spmm(cur, col_scale=graph.norm_out if below is None else below[4].a)
     b0 = getattr(plan, '_norm_in0', None)
     if b0 is None:
         b0 = plan._norm_in0 = graph.norm_in[sp.idx].contiguous()
     y = gemm.mm_nn(h_agg, w, rowscale=b0, bias=b)
-    n, d = cur.shape[0], w.shape[1]
+    n, d = graph.N, w.shape[1]
     bits = torch.empty((n, d // 256, 4), dtype=torch.int64, device=cur.device)
-    x_l = _store_rows(y, sp.idx, mix, 1 - alpha, alpha, p, seed, row0, bits, residual)
+    mix_index = None
+    if below is not None and residual:      # the mix source (the layer below's ReLU output) lives on S_1 too: the loss rows' positions in it
+        mix_index = getattr(plan, '_pos0_in_1', None)
+        if mix_index is None:
+            mix_index = plan._pos0_in_1 = below[4].pos[sp.idx].long().contiguous()
+    x_l = _store_rows(y, sp.idx, mix, 1 - alpha, alpha, p, seed, row0, bits, residual, mix_index)
     del y
     logits_c = gemm.mm_nn(x_l, w_out.t().contiguous(), bias=b_out)
     if logits_c.shape[1] % 4 == 0:
@@ -460,6 +470,9 @@ class _TrunkFn(torch.autograd.Function):
             hint, _gather, _tb = _support_plan(graph, loss_rows_, x.shape[0], L, residual, h, x0)
             if hint is not None:
                 ro_plan = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac, cumulative=residual)
+        # ... and the layer below it on the rows the last layer reads (S_1, while the plan keeps that support compact; 'Residual': its ReLU output — the
+        # last layer's mix source — lives on those rows too).  CB_ROWS_ONLY_BELOW=0: that layer on all rows.
+        ro_below = graph.rows_only_fwd(ro_plan) if (ro_plan is not None and os.environ.get('CB_ROWS_ONLY_BELOW', '1') != '0') else None
         z_ready = None                           # Z_l already produced by layer l-1's aggregation kernel (cb_spmm_gemm_fused_f32)
         out_head = None                          # the logits, when the output Linear left the last layer's aggregation kernel
         mix = x0                                 # mix source of the layer: X0 ('Initial', and layer 0 of 'Residual'), else the previous ReLU output
@@ -479,7 +492,7 @@ class _TrunkFn(torch.autograd.Function):
                 if z0 is None:
                     cur = saved_in[0] = dropped_x0()
             if ag and ro_plan is not None and l == L - 1:
-                bits, cur, out_head, h_last = _last_layer_on_loss_rows(graph, ro_plan, cur, w, b, mix, alpha, p, sd_l, row0, residual, w_out, b_out)
+                bits, cur, out_head, h_last = _last_layer_on_loss_rows(graph, ro_plan, cur, w, b, mix, alpha, p, sd_l, row0, residual, w_out, b_out, below=ro_below)
                 saved_in[L - 1] = None        # X_{L-1}: read by the aggregation above only (the level's weight gradient contracts h_last)
                 z = None
             elif ag:
@@ -487,7 +500,12 @@ class _TrunkFn(torch.autograd.Function):
                 z = (z_ready if z_ready is not None else z0 if z0 is not None
                      else gemm.mm_nn(cur, w, rowscale=a, addend=le, out=_exchanged(graph, cur.shape[0], w.shape[1])))
                 z_ready = None
-                if ro_plan is not None and l + 2 == L:     # rows-only: the last layer aggregates X_{L-1} itself — no dense tail under this store
+                if ro_plan is not None and l + 2 == L and ro_below is not None:
+                    # ... and this layer's outputs are read on S_1 only (the in-neighbours of the loss rows): its aggregation + store on those rows, compact
+                    ro_below[0].profile = getattr(graph, 'profile', None)
+                    bits, cur, act = _fused_launch(_lib.load(), graph, ro_below[0], z, None, b, mix, 1 - alpha, alpha, p, sd_l, keep_act, want_bits=bwd,
+                                                   relu_only=residual, row_ids=ro_below[2], row_scale=ro_below[3])
+                elif ro_plan is not None and l + 2 == L:     # rows-only: the last layer aggregates X_{L-1} itself — no dense tail under this store
                     bits, cur, act = _fused_spmm(graph, z, b, mix, 1 - alpha, alpha, p, sd_l, want_act=keep_act, want_bits=bwd, relu_only=residual)
                 elif l + 1 < L:     # this layer's store + the next layer's transform in one kernel
                     w1, _, le1 = layer_params[3 * (l + 1): 3 * (l + 1) + 3]

@@ -359,6 +359,16 @@ size_t cb_topk_replace_workspace_bytes(int64_t B, int64_t N, int64_t K);
 int cb_topk_replace_f32(const float* q, int64_t ldq, const float* t, int64_t ldt, int64_t B, int64_t N, int64_t D, int32_t K,
                         float* out, int32_t* out_idx, float* out_w, void* ws, size_t ws_bytes, void* stream);
 
+/* cb_spmm_csr_fused_f32 over a CSR whose rows are a SUBSET of the node rows: row r of rowptr / row_scale / out_act / out_next is node row row_ids[r]
+ * (ascending ids); mix_src, relu_bits ([all node rows][d/256][4]) and the dropout mask are taken at the node row.  The rows-only training forward
+ * (trunk.py): a GCNConv + store (GCN.py:205-256,127-133) evaluated only on the rows the layers above read. */
+int cb_spmm_csr_fused_rows_f32(const int32_t* row_ids, const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E,
+                               const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias, const float* mix_src,
+                               int64_t ld_mix, float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0,
+                               uint64_t* relu_bits, int32_t bits_relu_only, float* out_act, int64_t ld_act, float* out_next, int64_t ld_next,
+                               int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,
+                               size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Node-sharded aggregation in two passes (new; the reference is single-device).  A rank's row block of
  * the CSR is split by column owner: the interior-column pass (plain cb_spmm_csr_f32, no epilogue) runs while the halo
@@ -576,11 +586,12 @@ int cb_gather_rows_bf16_f32(const float* src, int64_t ld, const int64_t* idx, in
 int cb_expand_rows_f32(const float* src, const int32_t* pos, int64_t n_rows, int64_t d, float* out, void* stream);
 /* The trunk's fused store — ReLU, mask words, residual mix, dropout (GCN.py:127-133, res_tricks.py:7-23) — on a SUBSET of the rows, applied to the
  * output of a dense transform instead of inside an aggregation: y / out are compact [n_rows, d] matrices of the rows row_index[0 .. n_rows) (ascending
- * global ids), mix_src (may be NULL) and relu_bits ([N][d/256][4], may be NULL) are the full arrays, the dropout mask is drawn at the global row.
- *   act = relu(y[r]);  out[r] = dropout((c_act * act + c_mix * mix_src[row_index[r]]));  bits as cb_spmm_csr_fused_f32 writes them.
+ * global ids), relu_bits ([N][d/256][4], may be NULL) is the full array, the dropout mask is drawn at the global row; mix_src (may be NULL) is read at row
+ * mix_index[r] (mix_index NULL: at row_index[r], i.e. mix_src is a full array too).
+ *   act = relu(y[r]);  out[r] = dropout((c_act * act + c_mix * mix_src[mix_index[r]]));  bits as cb_spmm_csr_fused_f32 writes them.
  * The rows-only forward of the training step (trunk.py): the last GCNConv (GCN.py:205-256) evaluated on the loss rows of trainer…:390-391. */
-int cb_trunk_store_rows_f32(const float* y, const int64_t* row_index, int64_t n_rows, int64_t d, const float* mix_src, int64_t ld_mix, float c_act,
-                            float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, int bits_relu_only,
+int cb_trunk_store_rows_f32(const float* y, const int64_t* row_index, int64_t n_rows, int64_t d, const float* mix_src, int64_t ld_mix,
+                            const int64_t* mix_index, float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, int bits_relu_only,
                             float* out, void* stream);
 
 #ifdef __cplusplus

@@ -133,20 +133,26 @@ def _close_up_to_relu_flips(got, ref, name):
     assert float((got - ref).abs().max()) <= 5e-3 * float(ref.abs().max()), name
 
 
-@pytest.mark.parametrize('conn,se,layers,n_loss_rows', [('Initial', '000', 3, None), ('Residual', '000', 3, None), ('Initial', '100', 3, None), ('Initial', '000', 2, None),
-                                                        ('Residual', '100', 4, None), ('Initial', '000', 3, 200)])
-def test_rows_only_forward_equals_the_dense_step(conn, se, layers, n_loss_rows, monkeypatch):
+@pytest.mark.parametrize('conn,se,layers,n_loss_rows,below', [('Initial', '000', 3, None, True), ('Residual', '000', 3, None, True), ('Initial', '100', 3, None, True),
+                                                              ('Initial', '000', 2, None, True), ('Residual', '100', 4, None, True), ('Initial', '000', 3, 200, True),
+                                                              ('Initial', '000', 3, None, False), ('Residual', '000', 2, None, False)])
+def test_rows_only_forward_equals_the_dense_step(conn, se, layers, n_loss_rows, below, monkeypatch):
     """Rows-only forward (trunk._last_layer_on_loss_rows): the trainer promises that it reads — not only differentiates — the logits in the train rows
     only, and the training forward evaluates its LAST layer (aggregation of the inputs over the edges that enter the loss rows, transform, store,
     output Linear) on those rows; the backward's level 0 contracts the saved aggregate.  Against the all-rows step with the dense backward: the
-    same loss and gradients up to the association of sums — (sum a X) W against sum a (X W) — and the ReLUs that association flips at zero."""
+    same loss and gradients up to the association of sums — (sum a X) W against sum a (X W) — and the ReLUs that association flips at zero.
+    below: the layer under the last one runs on the rows the last layer reads (S_1, compact: cb_spmm_csr_fused_rows_f32; 'Residual': its ReLU output, the
+    last layer's mix source, lives there too) — CB_ROWS_ONLY_BELOW=0 keeps it on all rows."""
     from gnn_tail_generalization_amd import trunk
-    calls = []
+    calls, subset_launches = [], []
     real = trunk._last_layer_on_loss_rows
     monkeypatch.setattr(trunk, '_last_layer_on_loss_rows', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    real_launch = trunk._fused_launch
+    monkeypatch.setattr(trunk, '_fused_launch', lambda *a, **k: (subset_launches.append(k.get('row_ids') is not None), real_launch(*a, **k))[1])
+    monkeypatch.setenv('CB_ROWS_ONLY_BELOW', '1' if below else '0')
     extra = () if conn == 'Initial' else ('--force_set_to_best_config=0', '--type_trick=Residual')
     loss_s, g_s, used_s = _step_grads('1', se=se, layers=layers, extra=extra, n_loss_rows=n_loss_rows, rows_only=True)
-    assert calls == [1] and used_s
+    assert calls == [1] and used_s and any(subset_launches) == below
     loss_d, g_d, used_d = _step_grads('0', se=se, layers=layers, extra=extra, n_loss_rows=n_loss_rows)
     assert calls == [1] and not used_d
     assert abs(loss_s - loss_d) <= 2e-6 * abs(loss_d) and set(g_s) == set(g_d)
