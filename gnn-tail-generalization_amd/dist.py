@@ -623,7 +623,10 @@ class ShardedGraph:
         self.b = self.f if self.symmetric else self._orient(rb, cb)
         # the reverse orientation's edge list (local row, global column) stays: the row-sparse backward builds its level orientations from it
         self._rev_edges = (rf, cf) if self.symmetric else (rb, cb)
+        self._fwd_edges = (rf, cf)      # ... and the forward one's: the rows-only forward restricts it to the edges that enter the loss rows (loss_rows_forward)
         self._support_cache = None
+        self._fwd0_cache = None
+        self.rows_only_forwards = 0     # how often a training forward evaluated its last layer on the loss rows (tests, bench)
         # rows of room behind an exchanged matrix for the first halo slice (alloc_exchanged): the largest first slice of the two orientations
         # (the level orientations of the row-sparse backward ask for subsets of the reverse one's rows)
         self.halo_room = 0
@@ -790,6 +793,20 @@ class ShardedGraph:
             src = dst
         self._support_cache = (key, mask_local, levels)
         return levels
+
+    def loss_rows_forward(self, levels):
+        """Rows-only forward on row shards (trunk.py): the FORWARD orientation restricted to the edges that enter this rank's loss rows — the compact
+        row space levels[0].src of support_levels — as a level orientation: it writes a [src.n, d] matrix, reads all local rows of the gathered matrix,
+        and its halo plan asks the peers only for the rows that are in-neighbours of those loss rows (a tenth of the forward exchange under a 10 % mask).
+        Same kind of plan and slice count as the full forward orientation.  Built once per mask (every rank at the same point of the forward)."""
+        if self._fwd0_cache is not None and self._fwd0_cache[0] is levels:
+            return self._fwd0_cache[1]
+        s0 = levels[0].src
+        rf, cf = self._fwd_edges
+        keep = s0.pos[rf] >= 0
+        o = self._orient(rf[keep], cf[keep], like=self.f, dst=s0, src=None)
+        self._fwd0_cache = (levels, o)
+        return o
 
     # -- CSRGraph-like surface ---------------------------------------------------------------------------
     def check_zero_in_degree(self):
@@ -1293,8 +1310,9 @@ class ShardedTrainer:
     def training_loss(self):
         from . import ops
         m = self.teacherGNN
-        # (loss_rows: this rank's rows of the train mask — the objective touches the logits there only, trainer_node_classification.training_loss)
-        out = m.get_3_embs(self.x, self.edge_index, loss_rows=(self.train_mask, self.n_train)).emb4classi_full
+        # (loss_rows: this rank's rows of the train mask — the objective touches the logits there only; rows_only: and reads nothing else of this forward's
+        # output, trainer_node_classification.training_loss)
+        out = m.get_3_embs(self.x, self.edge_index, loss_rows=(self.train_mask, self.n_train), rows_only=True).emb4classi_full
         # local numerator / global count; the global loss is the sum over ranks
         unit = float(self.args.TeacherGNN.lossa_semantic) == 1.0
         loss = ops.nll_logsoftmax(out, self.y, self.train_mask, self.n_train, unit_grad=unit)

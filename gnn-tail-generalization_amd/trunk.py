@@ -336,11 +336,16 @@ def _chunked(graph, agg_bf16):
             and not graph.f.plan.cover and os.environ.get('COLDBREW_CHUNKED_PRODUCERS', '1') != '0')
 
 
+def _gather_and_tail(graph, L, residual, h, x0):
+    """(gather, tail_tb) of a backward: gather mode of the gradients that reach X0 through the mixes; the trunk backward in the dX kernel's epilogue."""
+    gather = residual or (L <= T.mix_max and _gather_fits(L, x0, graph))
+    return gather, agg_gemm_eligible(graph, h, False) and gather and not residual and tail_trunk_bwd(graph)
+
+
 def _support_plan(graph, loss_rows, n_rows, L, residual, h, x0):
     """(plan, gather, tail_tb) of a backward — and of a rows-only forward — under the caller's loss_rows promise: ONE decision for both, so that a
     forward that evaluated its last layer on the loss rows finds the same plan in its backward.  plan: CSRGraph.grad_support_plan or None (dense)."""
-    gather = residual or (L <= T.mix_max and _gather_fits(L, x0, graph))
-    tail_tb = agg_gemm_eligible(graph, h, False) and gather and not residual and tail_trunk_bwd(graph)
+    gather, tail_tb = _gather_and_tail(graph, L, residual, h, x0)
     hint = loss_rows if (not hasattr(graph, 'part') and hasattr(graph, 'grad_support_plan') and graph.rowptr_t is not None) else None
     if hint is not None and (not ops.loss_rows_enabled() or hint[0].shape[0] != n_rows):
         hint = None
@@ -398,6 +403,35 @@ def _last_layer_on_loss_rows(graph, plan, cur, w, b, mix, alpha, p, seed, row0, 
     else:
         out = torch.zeros((n, logits_c.shape[1]), dtype=torch.float32, device=cur.device).index_copy_(0, sp.idx, logits_c)
     return bits, x_l, out, h_agg
+
+
+def _last_layer_on_loss_rows_sharded(graph, s0, orient, cur, w, b, mix, alpha, p, seed, row0, residual, w_out, b_out):
+    """_last_layer_on_loss_rows on a rank's row block: the aggregation of a * X over the edges that enter the rank's loss rows is a level orientation
+    of the forward exchange (dist.ShardedGraph.loss_rows_forward: the peers ship only the in-neighbours of those rows).  Returns (mask words, dropped
+    X_L on the rank's loss rows, logits [n_local, C] with zeros elsewhere)."""
+    lib = _lib.load()
+    xs = _exchanged(graph, cur.shape[0], cur.shape[1])
+    with torch.cuda.device(cur.device):      # xs = a * X (the source rows' factor, applied before the rows travel)
+        _lib.check(lib.cb_act_bwd_f32(_lib.ptr(cur), None, _lib.ptr(graph.norm_out), _lib.ptr(xs), cur.shape[0], cur.shape[1], None, None, 0, _lib.stream_ptr()),
+                   'cb_act_bwd_f32')
+    h_agg = graph.aggregate_finish(graph.aggregate_start(xs, False, orient=orient), False)
+    del xs
+    b0 = getattr(s0, '_norm_in', None)
+    if b0 is None:
+        b0 = s0._norm_in = graph.norm_in[s0.idx].contiguous()
+    y = gemm.mm_nn(h_agg, w, rowscale=b0, bias=b)
+    del h_agg
+    n, d = graph.N, w.shape[1]
+    bits = torch.empty((n, d // 256, 4), dtype=torch.int64, device=cur.device)
+    x_l = _store_rows(y, s0.idx, mix, 1 - alpha, alpha, p, seed, row0, bits, residual)
+    del y
+    logits_c = gemm.mm_nn(x_l, w_out.t().contiguous(), bias=b_out)
+    if logits_c.shape[1] % 4 == 0:
+        out = ops.expand_rows(logits_c, s0.pos)
+    else:
+        out = torch.zeros((n, logits_c.shape[1]), dtype=torch.float32, device=cur.device).index_copy_(0, s0.idx, logits_c)
+    graph.rows_only_forwards += 1
+    return bits, x_l, out
 
 
 class _TrunkFn(torch.autograd.Function):
@@ -473,6 +507,16 @@ class _TrunkFn(torch.autograd.Function):
         # ... and the layer below it on the rows the last layer reads (S_1, while the plan keeps that support compact; 'Residual': its ReLU output — the
         # last layer's mix source — lives on those rows too).  CB_ROWS_ONLY_BELOW=0: that layer on all rows.
         ro_below = graph.rows_only_fwd(ro_plan) if (ro_plan is not None and os.environ.get('CB_ROWS_ONLY_BELOW', '1') != '0') else None
+        # Node-sharded: the same for the rank's loss rows, where its backward will run compact levels (dist.ShardedGraph.support_levels) — the last
+        # layer's exchange ships only the in-neighbours of the loss rows (loss_rows_forward).  The layers below keep all local rows.
+        ro_sh = None
+        if (rows_only and bwd and loss_rows_ is not None and L >= 2 and ag and layer_params[3 * (L - 1) + 2] is None and rows_only_enabled()
+                and hasattr(graph, 'part') and hasattr(graph, 'loss_rows_forward') and ops.loss_rows_enabled() and loss_rows_[0].shape[0] == x.shape[0]):
+            gather_, tb_ = _gather_and_tail(graph, L, residual, h, x0)
+            levels = graph.support_levels(loss_rows_[0], L, compact=ag and gather_ and not tb_, cumulative=residual)
+            if levels and levels[0].src is not None:
+                ro_sh = (levels[0].src, graph.loss_rows_forward(levels))
+        ro_any = ro_plan is not None or ro_sh is not None
         z_ready = None                           # Z_l already produced by layer l-1's aggregation kernel (cb_spmm_gemm_fused_f32)
         out_head = None                          # the logits, when the output Linear left the last layer's aggregation kernel
         mix = x0                                 # mix source of the layer: X0 ('Initial', and layer 0 of 'Residual'), else the previous ReLU output
@@ -491,7 +535,10 @@ class _TrunkFn(torch.autograd.Function):
                                                                                                          out=_exchanged(graph, x0.shape[0], w.shape[1]))
                 if z0 is None:
                     cur = saved_in[0] = dropped_x0()
-            if ag and ro_plan is not None and l == L - 1:
+            if ag and ro_sh is not None and l == L - 1:
+                bits, cur, out_head = _last_layer_on_loss_rows_sharded(graph, ro_sh[0], ro_sh[1], cur, w, b, mix, alpha, p, sd_l, row0, residual, w_out, b_out)
+                z = None
+            elif ag and ro_plan is not None and l == L - 1:
                 bits, cur, out_head, h_last = _last_layer_on_loss_rows(graph, ro_plan, cur, w, b, mix, alpha, p, sd_l, row0, residual, w_out, b_out, below=ro_below)
                 saved_in[L - 1] = None        # X_{L-1}: read by the aggregation above only (the level's weight gradient contracts h_last)
                 z = None
@@ -505,7 +552,7 @@ class _TrunkFn(torch.autograd.Function):
                     ro_below[0].profile = getattr(graph, 'profile', None)
                     bits, cur, act = _fused_launch(_lib.load(), graph, ro_below[0], z, None, b, mix, 1 - alpha, alpha, p, sd_l, keep_act, want_bits=bwd,
                                                    relu_only=residual, row_ids=ro_below[2], row_scale=ro_below[3])
-                elif ro_plan is not None and l + 2 == L:     # rows-only: the last layer aggregates X_{L-1} itself — no dense tail under this store
+                elif ro_any and l + 2 == L:     # rows-only: the last layer aggregates X_{L-1} itself — no dense tail under this store
                     bits, cur, act = _fused_spmm(graph, z, b, mix, 1 - alpha, alpha, p, sd_l, want_act=keep_act, want_bits=bwd, relu_only=residual)
                 elif l + 1 < L:     # this layer's store + the next layer's transform in one kernel
                     w1, _, le1 = layer_params[3 * (l + 1): 3 * (l + 1) + 3]
@@ -550,7 +597,8 @@ class _TrunkFn(torch.autograd.Function):
             ctx.save_for_backward(xd, x0, w_in, w_out, *saved_in, *saved_bits, *[t for t in layer_params if t is not None],
                                   *([h_last] if h_last is not None else []), *([x0_bits] if x0_bits is not None else []))
         ctx.has_x0_bits = bwd and x0_bits is not None
-        ctx.rows_only = bwd and h_last is not None
+        ctx.rows_only = bwd and h_last is not None       # one GPU: saved_in[L] compact, saved_in[L - 1] absent, h_last saved
+        ctx.rows_only_sharded = bwd and ro_sh is not None # row shards: saved_in[L] compact on the rank's loss rows
         ctx.le_present = [layer_params[3 * l + 2] is not None for l in range(L)]
         return out
 
@@ -580,6 +628,7 @@ class _Backward:
         self.x0_bits = rest.pop() if ctx.has_x0_bits else None
         self.rows_only = ctx.rows_only                      # the forward ran its last layer on the loss rows: saved_in[L] is compact, saved_in[L - 1] absent
         self.h_last = rest.pop() if ctx.rows_only else None  # (A (a * X_{L-1}))[S_0]
+        self.xl_compact = ctx.rows_only or ctx.rows_only_sharded
         self.lp, k = [], 0
         for l in range(L):
             w, b = rest[k], rest[k + 1]
@@ -594,7 +643,7 @@ class _Backward:
         self.gout = gemm._rowmajor(gout)
         self.h = self.x0.shape[1]
         self.sharded = hasattr(graph, 'part')
-        if loss_rows is not None and not ctx.rows_only and (not ops.loss_rows_enabled() or loss_rows[0].shape[0] != self.gout.shape[0]):
+        if loss_rows is not None and not self.xl_compact and (not ops.loss_rows_enabled() or loss_rows[0].shape[0] != self.gout.shape[0]):
             loss_rows = None
         self.loss_rows = loss_rows
         # the gradient reaching X0 through the mixes: 'Initial' — every layer's, gathered in one pass by the input stage (the per-layer gradients
@@ -675,7 +724,7 @@ class _Backward:
         space: the compact row space of the loss rows (a plan's space0 / a rank's share of it), or None = all rows."""
         L, need, gout, xl, w_out = self.L, self.need, self.gout, self.saved_in[self.L], self.w_out
         if space is not None:      # loss rows only
-            gout_c, xl_c = ops.gather_rows_by_index(gout, space.idx), (xl if self.rows_only else ops.gather_rows_by_index(xl, space.idx))
+            gout_c, xl_c = ops.gather_rows_by_index(gout, space.idx), (xl if self.xl_compact else ops.gather_rows_by_index(xl, space.idx))
             self.d_w_out = gemm.mm_tn(gout_c, xl_c) if need[5] else None
             self.d_b_out = ops.act_bwd(gout_c, None, None, want_out=False, want_colsum=True)[1] if need[6] else None
             g = gemm.mm_nn(gout_c, w_out)                                        # dL/d(dropped X_L), loss rows only
@@ -797,6 +846,8 @@ class _Backward:
                                'CB_LOSS_ROWS / tuning.T / the mask changed between the forward and the backward')
 
         space0 = plan.space0 if plan is not None else (self.sh_levels[0].src if self.sh_levels else None)
+        if self.xl_compact and space0 is None:
+            raise RuntimeError('the forward evaluated its last layer on the loss rows (rows_only), but its backward has no compact level 0')
         g, gr, dbias, handle, space = self._head(space0)
         g_above = None         # 'Residual': dL/d(stored output) of the layer above the one whose store backward comes next
         deferred = None        # (layer, X_l, dZ_l): weight gradient of the layer above, computed under this layer's halo exchange

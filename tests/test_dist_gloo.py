@@ -250,6 +250,20 @@ def _support_worker(rank, world, port, name, q, cover, n_slices):
                 else:
                     torch.testing.assert_close(got, full, atol=1e-5, rtol=1e-5)
             S = nxt
+        # rows-only forward (ShardedGraph.loss_rows_forward): the FORWARD orientation restricted to the edges that enter this rank's loss rows writes
+        # the rows of the full forward aggregation on those rows, and asks the peers for fewer rows than the full forward plan
+        if clevels[0].src is not None:
+            s0 = clevels[0].src
+            o_f = sg.loss_rows_forward(clevels)
+            assert sg.loss_rows_forward(clevels) is o_f                                             # built once per mask
+            assert o_f.plan.n_slices == sg.f.plan.n_slices and bool(o_f.plan.cover) == bool(sg.f.plan.cover)
+            assert o_f.plan.n_halo <= sg.f.plan.n_halo and o_f.E <= sg.f.E
+            h = torch.randn(n, 5, generator=gen)
+            hl = part.slice_rows(h).contiguous()
+            full = sg.aggregate(hl, False)
+            got = sg.aggregate_finish(sg.aggregate_start(hl, False, orient=o_f), False)
+            assert got.shape[0] == s0.n
+            torch.testing.assert_close(got, full[s0.idx], atol=1e-5, rtol=1e-5)
         q.put((rank, 'ok'))
     except Exception:  # noqa: BLE001
         import traceback

@@ -22,6 +22,8 @@ ARGV_RES = ['--dataset=S-pubmed', '--use_special_split=0', '--want_headtail=0', 
             '--manual_assign_GPU=0', '--do_deg_analyze=0', '--force_set_to_best_config=0', '--type_trick=Residual']   # 'Residual' trunk (round 5)
 ARGV_NR = ['--dataset=S-pubmed', '--use_special_split=0', '--want_headtail=0', '--whetherHasSE=111', '--se_reg=0.5', '--num_layers=3',
            '--manual_assign_GPU=0', '--do_deg_analyze=0', '--force_set_to_best_config=0', '--type_trick=NoResNodeNorm']   # non-residual stack (round 5)
+ARGV_I0 = ['--dataset=S-pubmed', '--use_special_split=0', '--want_headtail=0', '--whetherHasSE=000', '--num_layers=3',
+           '--manual_assign_GPU=0', '--do_deg_analyze=0']      # 'Initial' without tables: the rows-only forward on shards (round 5)
 SEEDS = list(range(7000, 7040))
 STEPS = 3
 
@@ -83,7 +85,7 @@ def _worker(rank, world, port, exchange, overlap, partition, argv, q, wire='f32'
         nores = '--type_trick=NoResNodeNorm' in argv
         if nores:
             assert stack_calls, 'the non-residual stack did not run as its fused node on the shards'
-        if (argv is ARGV or '--whetherHasSE=111' in argv or '--type_trick=Residual' in argv) and not nores:
+        if (argv is ARGV or argv is ARGV_I0 or '--whetherHasSE=111' in argv or '--type_trick=Residual' in argv) and not nores:
             # the fused trunk (S-pubmed: hidden 256, 'Initial'): its backward went through the level orientations of the row-sparse backward
             # (dist.ShardedGraph.support_orients: 10 % train rows -> level 0 keeps a tenth of the reverse edges)
             assert t.sgraph._support_cache is not None and len(t.sgraph._support_cache[2]) >= 1, 'row-sparse level orientations not used'
@@ -94,7 +96,10 @@ def _worker(rank, world, port, exchange, overlap, partition, argv, q, wire='f32'
             assert (lv0.src is not None) == bool(trunk.agg_gemm_eligible(t.sgraph, 256, False)), 'compact levels not used where the plan allows them'
             if lv0.src is not None:
                 assert 0 < lv0.src.n < t.part.n_local
-        if overlap == '1' and exchange == 'halo' and wire == 'f32' and (argv is ARGV or '--whetherHasSE=111' in argv or '--type_trick=Residual' in argv):
+                # ... and the training forward evaluated its last layer on the rank's loss rows (rows-only forward: the last exchange ships only the
+                # in-neighbours of those rows) unless that layer carries a structural-embedding table
+                assert t.sgraph.rows_only_forwards == (0 if '--whetherHasSE=111' in argv else STEPS), t.sgraph.rows_only_forwards
+        if overlap == '1' and exchange == 'halo' and wire == 'f32' and (argv is ARGV or argv is ARGV_I0 or '--whetherHasSE=111' in argv or '--type_trick=Residual' in argv):
             # round 5: the trunk allocates the matrices it exchanges with room behind them (dist.alloc_exchanged), so the interior pass and the first
             # halo slice ran as ONE pass ([local | slice 0], dist._Orientation.first) wherever a producer of the trunk wrote the matrix
             assert t.sgraph.merged_passes > 0, (t.sgraph.merged_passes, t.sgraph.interior_passes)
@@ -128,11 +133,14 @@ def _free_port():
     ('halo', '1', 'edges', ARGV, 'f32', 2, '3', '0'), ('halo', '1', 'edges', ARGV, 'f32', 3, '', '0'), ('halo', '1', 'edges', ARGV, 'bf16', 2, '2', '0'),
     # the 'Residual' trunk on shards: cumulative supports, the second gradient of a store backward compact (cover) / row-chunked (pull, sliced)
     ('halo', '1', 'edges', ARGV_RES, 'f32', 2, '', '1'), ('halo', '1', 'edges', ARGV_RES, 'f32', 3, '2', '0'),
+    # 'Initial' without tables: the rows-only forward on shards (last layer on the rank's loss rows through loss_rows_forward), cover / three ranks sliced / pull unsliced
+    ('halo', '1', 'edges', ARGV_I0, 'f32', 2, '', '1'), ('halo', '1', 'edges', ARGV_I0, 'f32', 3, '3', '1'), ('halo', '1', 'edges', ARGV_I0, 'f32', 2, '', '0'),
     # the non-residual stack (stack.py) on shards: widths F -> H -> H -> C, SE tables on every layer, dropout on the logits
     ('halo', '1', 'edges', ARGV_NR, 'f32', 2, '', '1'), ('halo', '1', 'edges', ARGV_NR, 'f32', 3, '2', '0'), ('halo', '0', 'rows', ARGV_NR, 'f32', 2, '', '1')],
     ids=['cover-overlap-edges', 'halo-singlepass-rows', 'allgather', 'batchnorm-cover-overlap', 'cover-bf16-wire', 'three-ranks-cover',
          'cover-sliced3', 'three-ranks-cover-sliced4', 'cover-sliced2-bf16-wire', 'batchnorm-cover-sliced2',
          'pull-sliced3', 'pull-three-ranks', 'pull-sliced2-bf16-wire-chunked-producers', 'residual-cover', 'residual-three-ranks-pull-sliced2',
+         'rows-only-cover', 'rows-only-three-ranks-cover-sliced3', 'rows-only-pull',
          'nores-cover', 'nores-three-ranks-pull-sliced2', 'nores-singlepass-rows'])
 def test_two_ranks_on_one_gpu_match_single_process(exchange, overlap, partition, argv, wire, world, slices, cover):
     _ranks_match_single_process(exchange, overlap, partition, argv, wire, world, slices, cover, 'gloo')
