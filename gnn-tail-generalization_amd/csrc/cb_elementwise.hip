@@ -1081,7 +1081,8 @@ __global__ void __launch_bounds__(kBlock) k_trunk_store_rows(const float* __rest
                                                              const float* __restrict__ mix_src, int64_t ld_mix, const int64_t* __restrict__ midx, float c_act,
                                                              float c_mix, uint32_t thresh,
                                                              float keep_scale, uint64_t seed, const uint64_t* __restrict__ seed_dev, int64_t row0,
-                                                             unsigned long long* __restrict__ bits, int relu_only, float* __restrict__ out) {
+                                                             unsigned long long* __restrict__ bits, int relu_only, float* __restrict__ out,
+                                                             float* __restrict__ out_act) {
   if (seed_dev) seed += *seed_dev;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tiles = d >> 8;
   for (int64_t r = (int64_t)blockIdx.x * (kBlock / kWave) + w; r < n_rows; r += (int64_t)gridDim.x * (kBlock / kWave)) {
@@ -1100,6 +1101,7 @@ __global__ void __launch_bounds__(kBlock) k_trunk_store_rows(const float* __rest
         }
         if (lane < 4) bits[(rr * tiles + tile) * 4 + lane] = mine;
       }
+      if (out_act) *reinterpret_cast<float4*>(out_act + r * d + c) = make_float4(a[0], a[1], a[2], a[3]);
       float x[4] = {a[0], a[1], a[2], a[3]};
       if (mix_src) {
         const float4 q = *reinterpret_cast<const float4*>(mix_src + mr * ld_mix + c);
@@ -1117,17 +1119,17 @@ __global__ void __launch_bounds__(kBlock) k_trunk_store_rows(const float* __rest
 
 extern "C" int cb_trunk_store_rows_f32(const float* y, const int64_t* row_index, int64_t n_rows, int64_t d, const float* mix_src, int64_t ld_mix,
                                        const int64_t* mix_index, float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits,
-                                       int bits_relu_only, float* out, void* stream) {
+                                       int bits_relu_only, float* out, float* out_act, void* stream) {
   CB_CHECK_ARG(n_rows >= 0 && d > 0 && d % 256 == 0 && d < (1 << 20), CB_E_INVALID, "cb_trunk_store_rows_f32: d must be a multiple of 256");
   if (n_rows == 0) return CB_OK;
-  CB_CHECK_ARG(y && row_index && out && aligned16(y) && aligned16(out) && (!mix_src || (aligned16(mix_src) && ld_mix % 4 == 0 && ld_mix >= d)) &&
+  CB_CHECK_ARG(y && row_index && out && aligned16(y) && aligned16(out) && (!out_act || aligned16(out_act)) && (!mix_src || (aligned16(mix_src) && ld_mix % 4 == 0 && ld_mix >= d)) &&
                    (!relu_bits || (uintptr_t)relu_bits % 8 == 0),
                CB_E_INVALID, "cb_trunk_store_rows_f32: null or misaligned pointer");
   CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && row0 >= 0, CB_E_INVALID, "cb_trunk_store_rows_f32: dropout p / row offset out of range");
   int64_t nb = (n_rows + kBlock / kWave - 1) / (kBlock / kWave);
   if (nb > kMaxBlocks) nb = kMaxBlocks;
   hipLaunchKernelGGL(k_trunk_store_rows, dim3((unsigned)nb), dim3(kBlock), 0, (hipStream_t)stream, y, row_index, n_rows, (int)d, mix_src, ld_mix, mix_index, c_act, c_mix,
-                     drop_p > 0.f ? dropout_threshold(drop_p) : 0u, 1.f / (1.f - drop_p), seed, seed_dev, row0, (unsigned long long*)relu_bits, bits_relu_only, out);
+                     drop_p > 0.f ? dropout_threshold(drop_p) : 0u, 1.f / (1.f - drop_p), seed, seed_dev, row0, (unsigned long long*)relu_bits, bits_relu_only, out, out_act);
   CB_LAUNCH_CHECK();
   return CB_OK;
 }

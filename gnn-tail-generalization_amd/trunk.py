@@ -361,16 +361,32 @@ def rows_only_enabled():
     return os.environ.get('CB_ROWS_ONLY_FWD', '1') != '0'
 
 
-def _store_rows(y, idx, mix, c_act, c_mix, p, seed, row0, bits, relu_only, mix_index=None):
+def _store_rows(y, idx, mix, c_act, c_mix, p, seed, row0, bits, relu_only, mix_index=None, want_act=False):
     """cb_trunk_store_rows_f32: the trunk's fused store (ReLU, mask words, mix, dropout) on the compact rows idx of a dense transform's output.
-    mix_index: the rows of `mix` to read when that is a compact matrix itself (default: the node rows idx)."""
+    mix_index: the rows of `mix` to read when that is a compact matrix itself (default: the node rows idx).  Returns (stored rows, ReLU output | None)."""
     lib = _lib.load()
     out = torch.empty_like(y)
+    act = torch.empty_like(y) if want_act else None
     with torch.cuda.device(y.device):
         _lib.check(lib.cb_trunk_store_rows_f32(_lib.ptr(y), _lib.ptr(idx), y.shape[0], y.shape[1], _lib.ptr(mix), mix.stride(0) if mix is not None else 0,
                                                _lib.ptr(mix_index), float(c_act), float(c_mix), float(p), ctypes.c_uint64(seed), ops.seed_dev_ptr(), int(row0), _lib.ptr(bits),
-                                               int(bool(relu_only)), _lib.ptr(out), _lib.stream_ptr()), 'cb_trunk_store_rows_f32')
-    return out
+                                               int(bool(relu_only)), _lib.ptr(out), _lib.ptr(act), _lib.stream_ptr()), 'cb_trunk_store_rows_f32')
+    return out, act
+
+
+def _layer_on_rows(graph, space, fwd, col_scale, cur, w, b, mix, mix_index, alpha, p, seed, row0, residual, want_act=False):
+    """One GCNConv + store on the rows of `space` with the sum taken FIRST: H = (A (a * X))[space] over the forward orientation `fwd` restricted to
+    those rows (col_scale = a on fwd's source space), Y = b * (H W) + bias on |space| rows, then the store on those rows.  Returns (mask words
+    [N, d/256, 4] with the rows of `space` written, stored rows, ReLU output | None, H)."""
+    fwd.profile = getattr(graph, 'profile', None)
+    h_agg = fwd.spmm(cur, col_scale=col_scale)
+    b_rows = getattr(space, '_norm_in', None)
+    if b_rows is None:
+        b_rows = space._norm_in = graph.norm_in[space.idx].contiguous()
+    y = gemm.mm_nn(h_agg, w, rowscale=b_rows, bias=b)
+    bits = torch.empty((graph.N, w.shape[1] // 256, 4), dtype=torch.int64, device=cur.device)
+    x_next, act = _store_rows(y, space.idx, mix, 1 - alpha, alpha, p, seed, row0, bits, residual, mix_index, want_act)
+    return bits, x_next, act, h_agg
 
 
 def _last_layer_on_loss_rows(graph, plan, cur, w, b, mix, alpha, p, seed, row0, residual, w_out, b_out, below=None):
@@ -382,21 +398,14 @@ def _last_layer_on_loss_rows(graph, plan, cur, w, b, mix, alpha, p, seed, row0, 
     the operand of the level's weight gradient in the backward's source-side form).  below (CSRGraph.rows_only_fwd): `cur` holds the rows of S_1 only."""
     sp = plan.space0
     fwd0 = graph.loss_rows_fwd(plan) if below is None else below[1]
-    fwd0.profile = getattr(graph, 'profile', None)
-    h_agg = fwd0.spmm(cur, col_scale=graph.norm_out if below is None else below[4].a)
-    b0 = getattr(plan, '_norm_in0', None)
-    if b0 is None:
-        b0 = plan._norm_in0 = graph.norm_in[sp.idx].contiguous()
-    y = gemm.mm_nn(h_agg, w, rowscale=b0, bias=b)
-    n, d = graph.N, w.shape[1]
-    bits = torch.empty((n, d // 256, 4), dtype=torch.int64, device=cur.device)
     mix_index = None
     if below is not None and residual:      # the mix source (the layer below's ReLU output) lives on S_1 too: the loss rows' positions in it
         mix_index = getattr(plan, '_pos0_in_1', None)
         if mix_index is None:
             mix_index = plan._pos0_in_1 = below[4].pos[sp.idx].long().contiguous()
-    x_l = _store_rows(y, sp.idx, mix, 1 - alpha, alpha, p, seed, row0, bits, residual, mix_index)
-    del y
+    bits, x_l, _act, h_agg = _layer_on_rows(graph, sp, fwd0, graph.norm_out if below is None else below[4].a, cur, w, b, mix, mix_index, alpha, p, seed, row0,
+                                           residual)
+    n = graph.N
     logits_c = gemm.mm_nn(x_l, w_out.t().contiguous(), bias=b_out)
     if logits_c.shape[1] % 4 == 0:
         out = ops.expand_rows(logits_c, sp.pos)
@@ -423,7 +432,7 @@ def _last_layer_on_loss_rows_sharded(graph, s0, orient, cur, w, b, mix, alpha, p
     del h_agg
     n, d = graph.N, w.shape[1]
     bits = torch.empty((n, d // 256, 4), dtype=torch.int64, device=cur.device)
-    x_l = _store_rows(y, s0.idx, mix, 1 - alpha, alpha, p, seed, row0, bits, residual)
+    x_l, _act = _store_rows(y, s0.idx, mix, 1 - alpha, alpha, p, seed, row0, bits, residual)
     del y
     logits_c = gemm.mm_nn(x_l, w_out.t().contiguous(), bias=b_out)
     if logits_c.shape[1] % 4 == 0:
@@ -517,6 +526,13 @@ class _TrunkFn(torch.autograd.Function):
             if levels and levels[0].src is not None:
                 ro_sh = (levels[0].src, graph.loss_rows_forward(levels))
         ro_any = ro_plan is not None or ro_sh is not None
+        # ... and with a layer under that one (L >= 3, no table on it) the layer below the last also takes its sum FIRST, on S_1: its weight gradient
+        # then contracts the saved aggregate over |S_1| rows (the backward's level 1 through the source rows' side), its dX is a GEMM on |S_1| rows
+        # in front of the plain reverse aggregation, and the layer under it loses its dense tail.  CB_ROWS_ONLY_BELOW=1: that layer Z-first on S_1
+        # (the fused store over the subset of rows) as before.
+        agg_first_below = (ro_below is not None and L >= 3 and layer_params[3 * (L - 2) + 2] is None and len(ro_plan.levels) >= 2
+                           and os.environ.get('CB_ROWS_ONLY_BELOW', '2') == '2')
+        h_below = None
         z_ready = None                           # Z_l already produced by layer l-1's aggregation kernel (cb_spmm_gemm_fused_f32)
         out_head = None                          # the logits, when the output Linear left the last layer's aggregation kernel
         mix = x0                                 # mix source of the layer: X0 ('Initial', and layer 0 of 'Residual'), else the previous ReLU output
@@ -535,7 +551,11 @@ class _TrunkFn(torch.autograd.Function):
                                                                                                          out=_exchanged(graph, x0.shape[0], w.shape[1]))
                 if z0 is None:
                     cur = saved_in[0] = dropped_x0()
-            if ag and ro_sh is not None and l == L - 1:
+            if ag and agg_first_below and l == L - 2:
+                bits, cur, act, h_below = _layer_on_rows(graph, ro_below[4], ro_below[0], a, cur, w, b, mix, None, alpha, p, sd_l, row0, residual, want_act=keep_act)
+                saved_in[L - 2] = None        # X_{L-2}: read by the aggregation above only
+                z = None
+            elif ag and ro_sh is not None and l == L - 1:
                 bits, cur, out_head = _last_layer_on_loss_rows_sharded(graph, ro_sh[0], ro_sh[1], cur, w, b, mix, alpha, p, sd_l, row0, residual, w_out, b_out)
                 z = None
             elif ag and ro_plan is not None and l == L - 1:
@@ -547,7 +567,9 @@ class _TrunkFn(torch.autograd.Function):
                 z = (z_ready if z_ready is not None else z0 if z0 is not None
                      else gemm.mm_nn(cur, w, rowscale=a, addend=le, out=_exchanged(graph, cur.shape[0], w.shape[1])))
                 z_ready = None
-                if ro_plan is not None and l + 2 == L and ro_below is not None:
+                if agg_first_below and l + 3 == L:      # the layer under the aggregate-first one: plain fused store, no dense tail
+                    bits, cur, act = _fused_spmm(graph, z, b, mix, 1 - alpha, alpha, p, sd_l, want_act=keep_act, want_bits=bwd, relu_only=residual)
+                elif ro_plan is not None and l + 2 == L and ro_below is not None:
                     # ... and this layer's outputs are read on S_1 only (the in-neighbours of the loss rows): its aggregation + store on those rows, compact
                     ro_below[0].profile = getattr(graph, 'profile', None)
                     bits, cur, act = _fused_launch(_lib.load(), graph, ro_below[0], z, None, b, mix, 1 - alpha, alpha, p, sd_l, keep_act, want_bits=bwd,
@@ -595,8 +617,10 @@ class _TrunkFn(torch.autograd.Function):
         ctx.n_layer_params = len(layer_params)
         if bwd:
             ctx.save_for_backward(xd, x0, w_in, w_out, *saved_in, *saved_bits, *[t for t in layer_params if t is not None],
-                                  *([h_last] if h_last is not None else []), *([x0_bits] if x0_bits is not None else []))
+                                  *([h_last] if h_last is not None else []), *([h_below] if h_below is not None else []),
+                                  *([x0_bits] if x0_bits is not None else []))
         ctx.has_x0_bits = bwd and x0_bits is not None
+        ctx.has_h_below = bwd and h_below is not None
         ctx.rows_only = bwd and h_last is not None       # one GPU: saved_in[L] compact, saved_in[L - 1] absent, h_last saved
         ctx.rows_only_sharded = bwd and ro_sh is not None # row shards: saved_in[L] compact on the rank's loss rows
         ctx.le_present = [layer_params[3 * l + 2] is not None for l in range(L)]
@@ -627,6 +651,7 @@ class _Backward:
         rest = sv[4 + 2 * L + 1:]
         self.x0_bits = rest.pop() if ctx.has_x0_bits else None
         self.rows_only = ctx.rows_only                      # the forward ran its last layer on the loss rows: saved_in[L] is compact, saved_in[L - 1] absent
+        self.h_below = rest.pop() if ctx.has_h_below else None  # (A (a * X_{L-2}))[S_1]: the layer below the last one took its sum first too
         self.h_last = rest.pop() if ctx.rows_only else None  # (A (a * X_{L-1}))[S_0]
         self.xl_compact = ctx.rows_only or ctx.rows_only_sharded
         self.lp, k = [], 0
@@ -758,10 +783,14 @@ class _Backward:
         dL/dZ_l itself is never formed (so not with a table gradient, which IS dL/dZ_l).  Same sums, associated differently."""
         w = self.lp[l][0]
         dst = level[1]
-        level[0].profile = fwd_j.profile = getattr(self.graph, 'profile', None)
+        level[0].profile = getattr(self.graph, 'profile', None)
+        if fwd_j is not None:
+            fwd_j.profile = level[0].profile
         g_new = level[0].spmm(gemm.mm_nn(gr, w.t().contiguous()), row_scale=dst.a if dst is not None else self.a)
         if self.need_w(l):
-            x_agg = self.h_last if (self.rows_only and l == self.L - 1) else fwd_j.spmm(self.saved_in[l], col_scale=self.a)
+            # (the aggregate the rows-only forward saved, else taken now)
+            x_agg = (self.h_last if (self.rows_only and l == self.L - 1) else self.h_below if (self.h_below is not None and l == self.L - 2)
+                     else fwd_j.spmm(self.saved_in[l], col_scale=self.a))
             self.grads_layers[3 * l] = gemm.mm_tn(x_agg, gr)
         return None, g_new
 
@@ -868,7 +897,7 @@ class _Backward:
                 deferred = None
             tb_next = None
             fwd_j = plan.fwd[j] if (level is not None and j < len(plan.fwd)) else None
-            source_side = (self.rows_only and l == L - 1) or (T.rowsparse_loss_side and fwd_j is not None and not self.need_le(l)
+            source_side = (self.rows_only and l == L - 1) or (self.h_below is not None and l == L - 2) or (T.rowsparse_loss_side and fwd_j is not None and not self.need_le(l)
                                                               and not (self.need_w(l) and self.saved_in[l] is None))      # (layer 0 without a stored dropped copy of X0)
             if source_side:
                 gz, g_new = self._layer_source_side(l, gr, level, fwd_j)

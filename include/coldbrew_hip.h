@@ -588,11 +588,12 @@ int cb_expand_rows_f32(const float* src, const int32_t* pos, int64_t n_rows, int
  * output of a dense transform instead of inside an aggregation: y / out are compact [n_rows, d] matrices of the rows row_index[0 .. n_rows) (ascending
  * global ids), relu_bits ([N][d/256][4], may be NULL) is the full array, the dropout mask is drawn at the global row; mix_src (may be NULL) is read at row
  * mix_index[r] (mix_index NULL: at row_index[r], i.e. mix_src is a full array too).
- *   act = relu(y[r]);  out[r] = dropout((c_act * act + c_mix * mix_src[mix_index[r]]));  bits as cb_spmm_csr_fused_f32 writes them.
+ *   act = relu(y[r]) (-> out_act[r] if given: the next 'Residual' layer's mix source);  out[r] = dropout((c_act * act + c_mix * mix_src[mix_index[r]]));
+ *   bits as cb_spmm_csr_fused_f32 writes them.
  * The rows-only forward of the training step (trunk.py): the last GCNConv (GCN.py:205-256) evaluated on the loss rows of trainer…:390-391. */
 int cb_trunk_store_rows_f32(const float* y, const int64_t* row_index, int64_t n_rows, int64_t d, const float* mix_src, int64_t ld_mix,
                             const int64_t* mix_index, float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, int bits_relu_only,
-                            float* out, void* stream);
+                            float* out, float* out_act, void* stream);
 
 #ifdef __cplusplus
 }

@@ -133,26 +133,33 @@ def _close_up_to_relu_flips(got, ref, name):
     assert float((got - ref).abs().max()) <= 5e-3 * float(ref.abs().max()), name
 
 
-@pytest.mark.parametrize('conn,se,layers,n_loss_rows,below', [('Initial', '000', 3, None, True), ('Residual', '000', 3, None, True), ('Initial', '100', 3, None, True),
-                                                              ('Initial', '000', 2, None, True), ('Residual', '100', 4, None, True), ('Initial', '000', 3, 200, True),
-                                                              ('Initial', '000', 3, None, False), ('Residual', '000', 2, None, False)])
+@pytest.mark.parametrize('conn,se,layers,n_loss_rows,below', [('Initial', '000', 3, None, '2'), ('Residual', '000', 3, None, '2'), ('Initial', '100', 3, None, '2'),
+                                                              ('Initial', '000', 2, None, '2'), ('Residual', '100', 4, None, '2'), ('Initial', '000', 3, 200, '2'),
+                                                              ('Initial', '000', 3, None, '1'), ('Residual', '000', 4, None, '1'),
+                                                              ('Initial', '000', 3, None, '0'), ('Residual', '000', 2, None, '0')])
 def test_rows_only_forward_equals_the_dense_step(conn, se, layers, n_loss_rows, below, monkeypatch):
     """Rows-only forward (trunk._last_layer_on_loss_rows): the trainer promises that it reads — not only differentiates — the logits in the train rows
     only, and the training forward evaluates its LAST layer (aggregation of the inputs over the edges that enter the loss rows, transform, store,
     output Linear) on those rows; the backward's level 0 contracts the saved aggregate.  Against the all-rows step with the dense backward: the
     same loss and gradients up to the association of sums — (sum a X) W against sum a (X W) — and the ReLUs that association flips at zero.
-    below: the layer under the last one runs on the rows the last layer reads (S_1, compact: cb_spmm_csr_fused_rows_f32; 'Residual': its ReLU output, the
-    last layer's mix source, lives there too) — CB_ROWS_ONLY_BELOW=0 keeps it on all rows."""
+    below = CB_ROWS_ONLY_BELOW, what the layer UNDER the last one does: '2' (default) — its sum first too, on the rows the last layer reads (S_1: aggregate,
+    GEMM on |S_1| rows, store; the backward's level 1 contracts the saved aggregate; needs a layer under it and no table on it, else as '1');
+    '1' — Z-first on S_1 (cb_spmm_csr_fused_rows_f32: the fused store over a subset of the rows; 'Residual': its ReLU output, the last layer's mix
+    source, lives there too); '0' — on all rows."""
     from gnn_tail_generalization_amd import trunk
-    calls, subset_launches = [], []
+    calls, subset_launches, on_rows = [], [], []
     real = trunk._last_layer_on_loss_rows
     monkeypatch.setattr(trunk, '_last_layer_on_loss_rows', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     real_launch = trunk._fused_launch
     monkeypatch.setattr(trunk, '_fused_launch', lambda *a, **k: (subset_launches.append(k.get('row_ids') is not None), real_launch(*a, **k))[1])
-    monkeypatch.setenv('CB_ROWS_ONLY_BELOW', '1' if below else '0')
+    real_rows = trunk._layer_on_rows
+    monkeypatch.setattr(trunk, '_layer_on_rows', lambda *a, **k: (on_rows.append(1), real_rows(*a, **k))[1])
+    monkeypatch.setenv('CB_ROWS_ONLY_BELOW', below)
+    sum_first_below = below == '2' and layers >= 3 and se[1] == '0'      # (the residual trunks' GCNConvs all take the middle flag of whetherHasSE, GCN.py:58-60)
     extra = () if conn == 'Initial' else ('--force_set_to_best_config=0', '--type_trick=Residual')
     loss_s, g_s, used_s = _step_grads('1', se=se, layers=layers, extra=extra, n_loss_rows=n_loss_rows, rows_only=True)
-    assert calls == [1] and used_s and any(subset_launches) == below
+    assert calls == [1] and used_s
+    assert len(on_rows) == (2 if sum_first_below else 1) and any(subset_launches) == (below != '0' and not sum_first_below)
     loss_d, g_d, used_d = _step_grads('0', se=se, layers=layers, extra=extra, n_loss_rows=n_loss_rows)
     assert calls == [1] and not used_d
     assert abs(loss_s - loss_d) <= 2e-6 * abs(loss_d) and set(g_s) == set(g_d)
