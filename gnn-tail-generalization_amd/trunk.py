@@ -531,7 +531,7 @@ class _TrunkFn(torch.autograd.Function):
         # in front of the plain reverse aggregation, and the layer under it loses its dense tail.  CB_ROWS_ONLY_BELOW=1: that layer Z-first on S_1
         # (the fused store over the subset of rows) as before.
         agg_first_below = (ro_below is not None and L >= 3 and layer_params[3 * (L - 2) + 2] is None and len(ro_plan.levels) >= 2
-                           and os.environ.get('CB_ROWS_ONLY_BELOW', '2') == '2')
+                           and ro_below[0].E >= T.sum_first_below_min_edges and os.environ.get('CB_ROWS_ONLY_BELOW', '2') == '2')
         h_below = None
         z_ready = None                           # Z_l already produced by layer l-1's aggregation kernel (cb_spmm_gemm_fused_f32)
         out_head = None                          # the logits, when the output Linear left the last layer's aggregation kernel

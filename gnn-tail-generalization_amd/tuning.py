@@ -32,6 +32,10 @@ class Tuning:
     # ... and the level moves at least this many edges: below, its kernels are latency-bound and two more launches cost more than the rows
     # save.  S-arxiv (2.3 * 10^5 edges at level 0): 3.35 -> 3.41 ms/step with the form; S-pubmed under hipGraph 0.600 -> 0.627; S-pl1M (10^6): 16.15 -> 16.0
     fwd0_min_edges: int = 1 << 19
+    # rows-only forward: the layer below the last one takes its sum first (aggregate on S_1, GEMM on |S_1| rows, store rows; the backward's level 1 through
+    # the source rows' side) once S_1's rows are entered by at least this many edges — below, the Z-first form on S_1 (one kernel) wins on launches.
+    # S-arxiv (1.7 * 10^6 edges into S_1): 2.94 -> 3.11 ms/step with the sum first; S-products: 90.1 -> 89.4; S-pl10M (7.4 * 10^7): 125.3 -> 120.9
+    sum_first_below_min_edges: int = 1 << 24
     # mixed-in gradients one cb_trunk_input_bwd_multi_f32 launch gathers (deeper 'Initial' trunks accumulate layer by layer): kernel limit
     mix_max: int = 7
     # gather mode keeps every layer's [N, d] gradient alive until the input stage; allowed while that is below this share of the free memory
