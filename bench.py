@@ -532,9 +532,10 @@ def main():
     # the DENSE backward of the same run (CB_LOSS_ROWS=0), after the timed region: the trainer is put back to the initial weights, moments and
     # RNG state and runs warm-up + K steps again, so its final_loss is the bit-for-bit regression witness of rounds 2 - 4 (same steps, same
     # dropout seeds, every backward aggregation over all rows) and its ms_per_step the like-for-like figure beside `value`
-    dense_bwd = None
-    if a.dense_backward and row_sparse and not use_graph and os.environ.get('CB_LOSS_ROWS', '1') != '0':
-        os.environ['CB_LOSS_ROWS'] = '0'
+    def restarted_leg(env, note, edges_per_step):
+        """warm-up + K steps of the same trainer put back to the initial weights / moments / RNG state, under the switches `env`."""
+        old_env = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
         try:
             graph_obj.profile = None
             with torch.no_grad():
@@ -550,13 +551,29 @@ def main():
                 dloss = t.train_step()
             sync()
             dms = (time.perf_counter() - t1) / a.steps * 1e3
-            dense_bwd = {'ms_per_step': dms, 'value': 1e3 / dms, 'unit': 'steps/s', 'steps': a.steps, 'warmup': a.warmup, 'final_loss': float(dloss),
-                         'aggregated_edges_per_sec': n_edges * 2 * L * 1e3 / dms,
-                         'note': 'the same trainer restarted from the initial weights / moments / RNG state with CB_LOSS_ROWS=0 (every backward '
-                                 'aggregation over all rows: the reference\'s amount of work), warm-up + K steps, outside the timed region; '
-                                 'final_loss is bit-comparable with the final_loss of rounds 2 - 4'}
+            leg = {'ms_per_step': dms, 'value': 1e3 / dms, 'unit': 'steps/s', 'steps': a.steps, 'warmup': a.warmup, 'final_loss': float(dloss), 'note': note}
+            if edges_per_step:
+                leg['aggregated_edges_per_sec'] = edges_per_step * 1e3 / dms
+            return leg
         finally:
-            os.environ['CB_LOSS_ROWS'] = '1'
+            for k, v in old_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    dense_bwd = all_rows_fwd = None
+    # (trunk._layer_on_rows leaves norm_in restricted to the loss rows on the plan's row space: the last layer ran on those rows)
+    rows_only_fwd = bool(row_sparse and getattr(graph_obj._support_plan.space0, '_norm_in', None) is not None)
+    if a.dense_backward and row_sparse and not use_graph and os.environ.get('CB_LOSS_ROWS', '1') != '0':
+        if rows_only_fwd and os.environ.get('CB_ROWS_ONLY_FWD', '1') != '0':
+            all_rows_fwd = restarted_leg({'CB_ROWS_ONLY_FWD': '0'},
+                                         'the same trainer restarted from the initial weights / moments / RNG state with CB_ROWS_ONLY_FWD=0: every row of every '
+                                         'layer is evaluated in the training forward, the backward stays row-sparse (the step of this bench before the rows-only '
+                                         'forward), warm-up + K steps, outside the timed region', 0)
+        dense_bwd = restarted_leg({'CB_LOSS_ROWS': '0'},
+                                  'the same trainer restarted from the initial weights / moments / RNG state with CB_LOSS_ROWS=0 (every row of every layer in the '
+                                  'forward, every backward aggregation over all rows: the reference\'s amount of work), warm-up + K steps, outside the timed '
+                                  'region; final_loss is bit-comparable with the final_loss of rounds 2 - 4', n_edges * 2 * L)
     ref_epoch = None
     if a.ref_epochs > 0 and not sharded and not use_graph:
         ref_epoch = reference_epoch_rate(t, args, a.ref_epochs, sync)
@@ -636,6 +653,13 @@ def main():
     }
     if dense_bwd is not None:
         out['dense_backward'] = dense_bwd
+    if all_rows_fwd is not None:
+        out['all_rows_forward'] = all_rows_fwd
+    if rows_only_fwd and os.environ.get('CB_ROWS_ONLY_FWD', '1') != '0':
+        out['config']['forward'] = ('rows-only: the trainer reads the logits in the train rows only (trainer_node_classification.py:390-391) and says so '
+                                    '(rows_only=True); the training forward then evaluates its last layer on those rows and the layer below on the rows that one '
+                                    'reads (same loss and gradients; metrics / evaluation forwards always compute every row).  CB_ROWS_ONLY_FWD=0: every row, timed '
+                                    'beside it as `all_rows_forward`; with the dense backward on top: `dense_backward`')
     if row_sparse:
         out['config']['backward'] = ('row-sparse: under the masked loss the gradient is exactly zero outside the rows the train rows reach after j hops; the levels '
                                      'of the backward whose support is <= 70 % of the rows (train rows, their neighbours) run on compact matrices and gather only '
