@@ -374,22 +374,28 @@ def _store_rows(y, idx, mix, c_act, c_mix, p, seed, row0, bits, relu_only, mix_i
     return out, act
 
 
-def _layer_on_rows(graph, space, fwd, col_scale, cur, w, b, mix, mix_index, alpha, p, seed, row0, residual, want_act=False):
+def _layer_on_rows(graph, space, fwd, col_scale, cur, w, b, mix, mix_index, alpha, p, seed, row0, residual, want_act=False, le=None, fwd_le=None):
     """One GCNConv + store on the rows of `space` with the sum taken FIRST: H = (A (a * X))[space] over the forward orientation `fwd` restricted to
-    those rows (col_scale = a on fwd's source space), Y = b * (H W) + bias on |space| rows, then the store on those rows.  Returns (mask words
-    [N, d/256, 4] with the rows of `space` written, stored rows, ReLU output | None, H)."""
+    those rows (col_scale = a on fwd's source space), Y = b * (H W) + bias on |space| rows, then the store on those rows.  le (a structural-embedding
+    table on all node rows, GCN.py:230-232: Z = a * (X W) + le): its rows are summed the same way, Y = b * (H W + (A le)[space]) + bias, over fwd_le —
+    the same orientation with node-row sources.  Returns (mask words [N, d/256, 4] with the rows of `space` written, stored rows, ReLU output | None, H)."""
     fwd.profile = getattr(graph, 'profile', None)
     h_agg = fwd.spmm(cur, col_scale=col_scale)
     b_rows = getattr(space, '_norm_in', None)
     if b_rows is None:
         b_rows = space._norm_in = graph.norm_in[space.idx].contiguous()
-    y = gemm.mm_nn(h_agg, w, rowscale=b_rows, bias=b)
+    le_sum = None
+    if le is not None:
+        fwd_le.profile = fwd.profile
+        le_sum = fwd_le.spmm(le, row_scale=b_rows)
+    y = gemm.mm_nn(h_agg, w, rowscale=b_rows, addend=le_sum, bias=b)
+    del le_sum
     bits = torch.empty((graph.N, w.shape[1] // 256, 4), dtype=torch.int64, device=cur.device)
     x_next, act = _store_rows(y, space.idx, mix, 1 - alpha, alpha, p, seed, row0, bits, residual, mix_index, want_act)
     return bits, x_next, act, h_agg
 
 
-def _last_layer_on_loss_rows(graph, plan, cur, w, b, mix, alpha, p, seed, row0, residual, w_out, b_out, below=None):
+def _last_layer_on_loss_rows(graph, plan, cur, w, b, mix, alpha, p, seed, row0, residual, w_out, b_out, below=None, le=None):
     """The LAST GCNConv, its store and the output Linear on the loss rows S_0 only (rows-only forward): aggregation and transform commute,
         Y[S_0] = b * ((A (a * X))[S_0] W) + bias        (GCN.py:213-256 with the sum taken first)
     so the layer is one aggregation over the edges that ENTER the loss rows (10 % of the edges under a 10 % mask) into a compact [|S_0|, H] matrix, a
@@ -404,7 +410,7 @@ def _last_layer_on_loss_rows(graph, plan, cur, w, b, mix, alpha, p, seed, row0, 
         if mix_index is None:
             mix_index = plan._pos0_in_1 = below[4].pos[sp.idx].long().contiguous()
     bits, x_l, _act, h_agg = _layer_on_rows(graph, sp, fwd0, graph.norm_out if below is None else below[4].a, cur, w, b, mix, mix_index, alpha, p, seed, row0,
-                                           residual)
+                                           residual, le=le, fwd_le=graph.loss_rows_fwd(plan) if le is not None else None)
     n = graph.N
     logits_c = gemm.mm_nn(x_l, w_out.t().contiguous(), bias=b_out)
     if logits_c.shape[1] % 4 == 0:
@@ -509,7 +515,8 @@ class _TrunkFn(torch.autograd.Function):
         # Linear run on the loss rows (_last_layer_on_loss_rows) — where the backward will run its level 0 through the source rows' side.  Same
         # decision as the backward's (_support_plan); the last layer without a structural-embedding table (its gradient is dL/dZ on ALL rows).
         ro_plan = h_last = None
-        if rows_only and bwd and loss_rows_ is not None and L >= 2 and ag and layer_params[3 * (L - 1) + 2] is None and T.rowsparse_loss_side and rows_only_enabled():
+        le_last = layer_params[3 * (L - 1) + 2]      # (a table on the last layer: its sum joins the layer's, its gradient keeps the backward's level 0 on the compact form)
+        if rows_only and bwd and loss_rows_ is not None and L >= 2 and ag and T.rowsparse_loss_side and rows_only_enabled():
             hint, _gather, _tb = _support_plan(graph, loss_rows_, x.shape[0], L, residual, h, x0)
             if hint is not None:
                 ro_plan = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac, cumulative=residual)
@@ -559,8 +566,12 @@ class _TrunkFn(torch.autograd.Function):
                 bits, cur, out_head = _last_layer_on_loss_rows_sharded(graph, ro_sh[0], ro_sh[1], cur, w, b, mix, alpha, p, sd_l, row0, residual, w_out, b_out)
                 z = None
             elif ag and ro_plan is not None and l == L - 1:
-                bits, cur, out_head, h_last = _last_layer_on_loss_rows(graph, ro_plan, cur, w, b, mix, alpha, p, sd_l, row0, residual, w_out, b_out, below=ro_below)
-                saved_in[L - 1] = None        # X_{L-1}: read by the aggregation above only (the level's weight gradient contracts h_last)
+                bits, cur, out_head, h_last = _last_layer_on_loss_rows(graph, ro_plan, cur, w, b, mix, alpha, p, sd_l, row0, residual, w_out, b_out, below=ro_below,
+                                                                       le=le_last)
+                if le_last is None:
+                    saved_in[L - 1] = None    # X_{L-1}: read by the aggregation above only (the level's weight gradient contracts h_last)
+                else:
+                    h_last = None             # the table's gradient is dL/dZ itself: level 0 stays on the compact form, which reads X_{L-1} on S_1
                 z = None
             elif ag:
                 from .graph import weight_image
@@ -622,7 +633,8 @@ class _TrunkFn(torch.autograd.Function):
         ctx.has_x0_bits = bwd and x0_bits is not None
         ctx.has_h_below = bwd and h_below is not None
         ctx.rows_only = bwd and h_last is not None       # one GPU: saved_in[L] compact, saved_in[L - 1] absent, h_last saved
-        ctx.rows_only_sharded = bwd and ro_sh is not None # row shards: saved_in[L] compact on the rank's loss rows
+        ctx.rows_only_sharded = bwd and (ro_sh is not None or (ro_plan is not None and h_last is None))      # row shards / a table on the last layer: saved_in[L] compact only
+        ctx.in_last_compact = bwd and ro_plan is not None and h_last is None and ro_below is not None       # ... and saved_in[L - 1] holds the rows of S_1 (= level 0's destination)
         ctx.le_present = [layer_params[3 * l + 2] is not None for l in range(L)]
         return out
 
@@ -654,6 +666,7 @@ class _Backward:
         self.h_below = rest.pop() if ctx.has_h_below else None  # (A (a * X_{L-2}))[S_1]: the layer below the last one took its sum first too
         self.h_last = rest.pop() if ctx.rows_only else None  # (A (a * X_{L-1}))[S_0]
         self.xl_compact = ctx.rows_only or ctx.rows_only_sharded
+        self.in_last_compact = ctx.in_last_compact
         self.lp, k = [], 0
         for l in range(L):
             w, b = rest[k], rest[k + 1]
@@ -804,7 +817,8 @@ class _Backward:
         gz, g_new = level[0].spmm_gemm(gr, weight_image(w, transpose=True), transpose=False, g_rowscale=dst.a if dst is not None else self.a)
         if self.need_w(l):
             if dst is not None:      # dL/dZ_l lives on S_{j+1}: X_l^T (a * dZ_l) over those rows (all others contribute zeros)
-                self.grads_layers[3 * l] = gemm.mm_tn(ops.gather_rows_by_index(self.saved_in[l], dst.idx), gz, rowscale=dst.a)
+                x_rows = self.saved_in[l] if (self.in_last_compact and l == self.L - 1) else ops.gather_rows_by_index(self.saved_in[l], dst.idx)
+                self.grads_layers[3 * l] = gemm.mm_tn(x_rows, gz, rowscale=dst.a)
             else:
                 self.grads_layers[3 * l] = self._dw(l, self.saved_in[l], gz)
         return gz, g_new
@@ -898,7 +912,8 @@ class _Backward:
             tb_next = None
             fwd_j = plan.fwd[j] if (level is not None and j < len(plan.fwd)) else None
             source_side = (self.rows_only and l == L - 1) or (self.h_below is not None and l == L - 2) or (T.rowsparse_loss_side and fwd_j is not None and not self.need_le(l)
-                                                              and not (self.need_w(l) and self.saved_in[l] is None))      # (layer 0 without a stored dropped copy of X0)
+                                                              and not (self.need_w(l) and self.saved_in[l] is None)      # (layer 0 without a stored dropped copy of X0)
+                                                              and not (self.in_last_compact and l == L - 1))
             if source_side:
                 gz, g_new = self._layer_source_side(l, gr, level, fwd_j)
             elif level is not None:
