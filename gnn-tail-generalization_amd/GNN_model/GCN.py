@@ -110,7 +110,7 @@ class TricksComb(nn.Module):
         if self.use_fused_trunk and not getattr(graph, 'segmented', False) and trunk.eligible(self, x, want_les):
             return trunk.forward(self, x, graph, loss_rows=loss_rows, rows_only=rows_only)
         if self.use_fused_trunk and not getattr(graph, 'segmented', False) and stack.eligible(self, x, graph, want_les):
-            return stack.forward(self, x, graph, loss_rows=loss_rows)      # the non-residual stack (NoRes...) at hidden 256
+            return stack.forward(self, x, graph, loss_rows=loss_rows, rows_only=rows_only)      # the non-residual stack (NoRes...) at hidden 256
         if getattr(self.args, 'agg_dtype', 'f32') != 'f32' and not want_les:
             raise NotImplementedError("--agg_dtype=bf16 (bf16-stored aggregation rows) is built for the fused 'Initial' trunk "
                                       '(hidden width a multiple of 256); this configuration runs the fp32 operator path')

@@ -13,9 +13,18 @@ reverse aggregation + dX kernel as the last halo pass); every other shape takes 
 of dropout seeds this node reproduces (tests/test_gpu_model.py::test_fused_stack_equals_modular_path; goldens case_nr_h256_*)."""
 import torch
 
-from . import gemm, ops
-from .trunk import _exchanged, _fused_gemm, _fused_spmm, _layer_bwd, _layer_bwd_rows, _spmm_t, agg_gemm_eligible
+from . import _lib, gemm, ops
+from .trunk import _exchanged, _fused_gemm, _fused_launch, _fused_spmm, _layer_bwd, _layer_bwd_rows, _spmm_t, agg_gemm_eligible, rows_only_enabled
 from .tuning import T
+
+
+def _plan_hint(graph, loss_rows, n_rows, ag):
+    """loss_rows if the backward (and a rows-only forward) may run on the row-support plan, else None — one decision for both."""
+    if (loss_rows is not None and ops.loss_rows_enabled() and not hasattr(graph, 'part') and loss_rows[0].shape[0] == n_rows
+            and getattr(graph, 'rowptr_t', None) is not None and 1 <= loss_rows[1] <= T.rowsparse_s0_limit * n_rows
+            and (n_rows >= T.rowsparse_min_nodes or getattr(graph, 'rowsparse_small_ok', False)) and ag and graph.support_plan_pays()):
+        return loss_rows
+    return None
 
 
 def eligible(tc, x, graph, want_les):
@@ -28,9 +37,10 @@ def eligible(tc, x, graph, want_les):
 class _StackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph, cfg, x, *layer_params):
-        """layer_params = (W_0, bias_0, le_0 | None, W_1, ...).  cfg = (L, p, seeds[L + 1], track, loss_rows): loss_rows = None or (bool mask [N],
-        count), the caller's promise that the output receives gradient in those rows only (ops.py "Row-sparse backward")."""
-        L, p, seeds, track, _loss_rows = cfg
+        """layer_params = (W_0, bias_0, le_0 | None, W_1, ...).  cfg = (L, p, seeds[L + 1], track, loss_rows, rows_only): loss_rows = None or (bool mask [N],
+        count), the caller's promise that the output receives gradient in those rows only (ops.py "Row-sparse backward"); rows_only: ... and that it
+        READS the output in those rows only (trunk.py "Rows-only forward")."""
+        L, p, seeds, track, loss_rows_, rows_only = cfg
         a, b = graph.norm_out, graph.norm_in
         row0 = int(getattr(graph, 'row_offset', 0))       # first global row of this rank's block (dropout masks are those of the unsharded tensor)
         x = x.contiguous()
@@ -47,13 +57,30 @@ class _StackFn(torch.autograd.Function):
         ag = agg_gemm_eligible(graph, 256, False)
         saved_in, saved_bits = [xd0], []
         z_ready = None
+        # Rows-only forward (trunk.py; one GPU, under the plan decision of the backward): the logits are read on S_0 only, so the last aggregation (class
+        # width) runs on those rows, the last layer's transform on the rows it gathers — S_1 —, and the last HIDDEN layer's aggregation + store on S_1 too
+        # (cb_spmm_csr_fused_rows_f32), wherever the plan keeps S_1 compact.
+        ro = None
+        if rows_only and bwd and L >= 2 and rows_only_enabled():
+            hint = _plan_hint(graph, loss_rows_, x.shape[0], ag)
+            if hint is not None:
+                plan_ = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac)
+                ro = graph.rows_only_fwd(plan_)      # (fwd1, fwd0c, ids1, b1, s1) or None
+                if ro is not None:
+                    ro = ro + (plan_,)
         for l in range(L - 1):            # hidden layers: aggregation with the ReLU / dropout store (+ the next hidden layer's transform)
             _w, bias, _le = layer_params[3 * l: 3 * l + 3]
             w1, _b1, le1 = layer_params[3 * (l + 1): 3 * (l + 1) + 3]
             sd = seeds[l + 1] if p > 0 else 0
             z = z_ready if z_ready is not None else z
             z_ready = None
-            if ag and l + 1 < L - 1:      # the next layer is H -> H: its transform leaves this layer's aggregation kernel
+            if ro is not None and l == L - 2:      # the last hidden layer: read by the last aggregation only, on S_1
+                ro[0].profile = getattr(graph, 'profile', None)
+                bits, cur, _ = _fused_launch(_lib.load(), graph, ro[0], z, None, bias, None, 1.0, 0.0, p, sd, False, want_bits=bwd, row_ids=ro[2], row_scale=ro[3])
+                s1 = ro[4]
+                le_c = ops.gather_rows_by_index(le1, s1.idx) if le1 is not None else None
+                z = gemm.mm_nn(cur, w1, rowscale=s1.a, addend=le_c)          # Z_{L-1} on the rows of S_1
+            elif ag and l + 1 < L - 1:      # the next layer is H -> H: its transform leaves this layer's aggregation kernel
                 from .graph import weight_image
                 # (a forward that no backward follows leaves cur = None: the activations stayed on chip)
                 bits, cur, z_ready = _fused_gemm(graph, z, bias, None, 1.0, 0.0, p, sd, weight_image(w1), a, le1, want_bits=bwd)[:3]
@@ -66,8 +93,20 @@ class _StackFn(torch.autograd.Function):
         z = z_ready if z_ready is not None else z
         bias_last = layer_params[3 * (L - 1) + 1]
         # the last layer: no ReLU (GCN.py:127); then the dropout on the logits (GCN.py:133)
-        y = graph.aggregate(z, False, b, bias_last, False) if hasattr(graph, 'part') else graph.spmm(z, row_scale=b, bias=bias_last)
+        if ro is not None:      # the logits on the loss rows (gathering the compact Z over the orientation renumbered to S_1), zeros elsewhere
+            plan_ = ro[5]
+            sp = plan_.space0
+            ro[1].profile = getattr(graph, 'profile', None)
+            b0 = getattr(sp, '_norm_in', None)
+            if b0 is None:
+                b0 = sp._norm_in = b[sp.idx].contiguous()
+            y_c = ro[1].spmm(z, row_scale=b0, bias=bias_last)
+            y = (ops.expand_rows(y_c, sp.pos) if y_c.shape[1] % 4 == 0
+                 else torch.zeros((x.shape[0], y_c.shape[1]), dtype=torch.float32, device=x.device).index_copy_(0, sp.idx, y_c))
+        else:
+            y = graph.aggregate(z, False, b, bias_last, False) if hasattr(graph, 'part') else graph.spmm(z, row_scale=b, bias=bias_last)
         out = ops._dropout_raw(y, p, seeds[L], row0 * y.shape[1]) if p > 0 else y
+        ctx.in_last_compact = bwd and ro is not None      # saved_in[L - 1] holds the rows of S_1 (= level 0's destination)
         ctx.graph, ctx.cfg = graph, cfg
         if bwd:
             ctx.save_for_backward(*saved_in, *saved_bits, *[t for t in layer_params if t is not None])
@@ -76,7 +115,7 @@ class _StackFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        graph, (L, p, seeds, _track, loss_rows) = ctx.graph, ctx.cfg
+        graph, (L, p, seeds, _track, loss_rows, _rows_only) = ctx.graph, ctx.cfg
         sv = list(ctx.saved_tensors)
         saved_in, saved_bits, rest = sv[:L], sv[L: 2 * L - 1], sv[2 * L - 1:]
         lp, k = [], 0
@@ -101,11 +140,13 @@ class _StackFn(torch.autograd.Function):
         # Row-sparse backward (one GPU; trunk.py / DESIGN.md section 1): under the caller's loss_rows promise the levels of the backward whose support
         # is small run on compact [|S_j|, .] matrices through the plan's renumbered orientations; the promise is checked on the device.
         plan = None
-        if (loss_rows is not None and ops.loss_rows_enabled() and not sharded and loss_rows[0].shape[0] == gout.shape[0] and graph.rowptr_t is not None
-                and 1 <= loss_rows[1] <= T.rowsparse_s0_limit * gout.shape[0]
-                and (gout.shape[0] >= T.rowsparse_min_nodes or getattr(graph, 'rowsparse_small_ok', False)) and ag and graph.support_plan_pays()):
-            ops.check_rows_zero(gout, loss_rows[0])
-            plan = graph.grad_support_plan(loss_rows[0], L, max_frac=T.rowsparse_max_frac)
+        hint = _plan_hint(graph, loss_rows, gout.shape[0], ag)
+        if hint is not None:
+            ops.check_rows_zero(gout, hint[0])
+            plan = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac)
+        if ctx.in_last_compact and (plan is None or plan.levels[0][1] is None):
+            raise RuntimeError('the forward ran its last layers on the loss rows\' supports (rows_only), but its backward finds no such plan: '
+                               'CB_LOSS_ROWS / tuning.T / the mask changed between the forward and the backward')
         space = plan.space0 if plan is not None else None                        # row space of g / gr (None: all rows)
 
         def level_of(j):
@@ -136,7 +177,8 @@ class _StackFn(torch.autograd.Function):
         a_sp = space.a if space is not None else a
         w_last = lp[L - 1][0]
         if nw(L - 1):
-            grads[3 * (L - 1)] = gemm.mm_tn(rows_of(saved_in[L - 1], space), gz, rowscale=a_sp)
+            x_last = saved_in[L - 1] if ctx.in_last_compact else rows_of(saved_in[L - 1], space)      # (rows-only forward: already the rows of S_1)
+            grads[3 * (L - 1)] = gemm.mm_tn(x_last, gz, rowscale=a_sp)
         if nle(L - 1):
             grads[3 * (L - 1) + 2] = all_rows(gz, space)
         g = gemm.mm_nn(gz, w_last.t().contiguous(), rowscale=a_sp)               # dL/d(dropped X_{L-1}), on the rows of `space`
@@ -208,8 +250,8 @@ class _StackFn(torch.autograd.Function):
         return (None, None, d_x, *grads)
 
 
-def forward(tc, x, graph, loss_rows=None):
-    """TricksComb.forward on the fused non-residual stack; returns (logits, se_reg_all).  loss_rows: as trunk.forward."""
+def forward(tc, x, graph, loss_rows=None, rows_only=False):
+    """TricksComb.forward on the fused non-residual stack; returns (logits, se_reg_all).  loss_rows, rows_only: as trunk.forward."""
     L = tc.num_layers
     p = float(tc.dropout) if tc.training else 0.0
     seeds = tuple(ops.next_seed() for _ in range(L + 1)) if p > 0 else (0,) * (L + 1)
@@ -231,5 +273,5 @@ def forward(tc, x, graph, loss_rows=None):
         if mask.dtype != torch.bool or mask.dim() != 1 or mask.shape[0] != x.shape[0]:
             raise ValueError(f'loss_rows: a bool mask over the {x.shape[0]} rows expected, got {tuple(mask.shape)} {mask.dtype}')
         loss_rows = (mask, int(count) if count is not None else int(mask.sum().item()))
-    out = _StackFn.apply(graph, (L, p, seeds, torch.is_grad_enabled(), loss_rows), x, *params)
+    out = _StackFn.apply(graph, (L, p, seeds, torch.is_grad_enabled(), loss_rows, bool(rows_only) and loss_rows is not None), x, *params)
     return out, se_reg_all

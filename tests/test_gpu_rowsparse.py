@@ -196,6 +196,25 @@ def test_rows_only_forward_returns_the_loss_rows_and_zeros(monkeypatch):
     torch.testing.assert_close(out_ng, outs[False].detach(), atol=0, rtol=0)
 
 
+@pytest.mark.parametrize('se,layers', [('000', 3), ('111', 3), ('000', 2), ('100', 4)])
+def test_rows_only_forward_of_the_non_residual_stack(se, layers, monkeypatch):
+    """stack.py (NoRes: F -> H -> ... -> C): the last aggregation (class width) on the loss rows, the last transform on the rows it gathers (S_1), the last
+    hidden layer's aggregation + store on S_1 (cb_spmm_csr_fused_rows_f32).  Same sums in the same order as the all-rows forward: the loss is the same to
+    the last bit, the gradients equal the dense backward's as the row-sparse backward's do."""
+    from gnn_tail_generalization_amd import stack
+    subset_launches = []
+    real_launch = stack._fused_launch
+    monkeypatch.setattr(stack, '_fused_launch', lambda *a, **k: (subset_launches.append(k.get('row_ids') is not None), real_launch(*a, **k))[1])
+    extra = ('--force_set_to_best_config=0', '--type_trick=NoResNodeNorm')
+    loss_s, g_s, used_s = _step_grads('1', se=se, layers=layers, extra=extra, rows_only=True)
+    assert subset_launches == [True] and used_s
+    loss_d, g_d, used_d = _step_grads('0', se=se, layers=layers, extra=extra)
+    assert not used_d and loss_s == loss_d and set(g_s) == set(g_d)
+    for k in g_d:
+        scale = float(g_d[k].abs().max())
+        assert float((g_s[k] - g_d[k]).abs().max()) <= 5e-6 * scale, k
+
+
 @pytest.mark.parametrize('conn,below', [('Initial', '2'), ('Residual', '2'), ('Initial', '0')])
 def test_rows_only_forward_with_structural_embedding_tables(conn, below, monkeypatch):
     """whetherHasSE=111 (a table on every GCNConv, GCN.py:230-232): the last layer's table rows are summed over the same edges as its inputs,
@@ -275,7 +294,7 @@ def test_row_sparse_backward_matches_the_unmodified_reference(case, rows_only, m
     args, model = product_model(g['cfg'], g['sd'], DEV)
     x, ei, y, mask = g['x'].to(DEV), g['edge_index'].to(DEV), g['y'].to(DEV), g['train_mask'].to(DEV)
     model.train()
-    # rows_only: the last layer of the residual trunks on the loss rows (the non-residual stack: the forward keeps all rows)
+    # rows_only: the last layer(s) on the loss rows' supports
     out = model.get_3_embs(x, ei, mask, loss_rows=mask, rows_only=rows_only).emb4classi_full
     loss = ops.nll_logsoftmax(out, y, mask)
     if model.se_reg_all is not None:                                  # trainer_node_classification.py:393-394
@@ -286,7 +305,7 @@ def test_row_sparse_backward_matches_the_unmodified_reference(case, rows_only, m
     assert _lib.load().cb_device_status() == 0
     plan = getattr(model.model.model._graph(ei), '_support_plan', None)
     assert plan is not None and plan.levels[0][1] is not None       # the backward ran on the plan, S_1 compact
-    took_rows_only = rows_only and not case.startswith('case_nr_')      # (the residual trunks, with and without tables; the non-residual stack keeps all rows)
+    took_rows_only = rows_only      # (the residual trunks, with and without tables, and the non-residual stack)
     if took_rows_only:
         assert float(out.detach()[~mask].abs().max()) == 0.0
         torch.testing.assert_close(out.detach()[mask].cpu(), g['train_out'][mask.cpu()], atol=1e-4, rtol=1e-4)
