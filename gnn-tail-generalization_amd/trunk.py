@@ -15,7 +15,9 @@ GEMM, one fused elementwise pass (cb_trunk_layer_bwd_f32); ReLU masks are kept a
 w.r.t. X0 is gathered in one pass by the input stage.  Other widths, bf16-stored rows and node-sharded pull plans take the same node with
 one kernel per stage.  Same arithmetic and the same sequence of dropout seeds as the modular path (ops.py), which stays the general
 fallback; every fused form is bit-identical to the kernels it replaces (tests/test_gpu_agg_gemm.py, test_gpu_kernels.py, test_gpu_fullsize.py).
-The backward (_Backward) runs on the rows that carry gradient when the caller promised `loss_rows` ("Row-sparse backward").
+The backward (_Backward) runs on the rows that carry gradient when the caller promised `loss_rows` ("Row-sparse backward"); with the
+second promise, `rows_only`, a training forward evaluates its last layers on the rows the loss reads (_rows_only_decision; DESIGN.md section 1,
+"Rows-only training forward").
 """
 import ctypes
 import os
@@ -361,6 +363,45 @@ def rows_only_enabled():
     return os.environ.get('CB_ROWS_ONLY_FWD', '1') != '0'
 
 
+def _rows_only_decision(graph, cfg, x, x0, h, ag, bwd, layer_params):
+    """What a training forward under both promises of the caller (gradient AND reads in the loss rows only) evaluates on fewer rows:
+    (plan, below, sharded, sum_first_below), each None / False where not taken.
+      plan    one GPU: the backward's row-support plan (the SAME decision, _support_plan) — the last layer, its store and the output Linear run on the
+              loss rows (_last_layer_on_loss_rows), where the backward runs its level 0 through the source rows' side on the saved aggregate (a
+              structural-embedding table on that layer: its rows are summed too, the level stays on the compact form);
+      below   ... and the layer below it on the rows the last layer reads (CSRGraph.rows_only_fwd: S_1, while the plan keeps that support compact;
+              'Residual': its ReLU output — the last layer's mix source — lives on those rows too).  CB_ROWS_ONLY_BELOW=0: that layer on all rows;
+      sum_first_below   ... with its sum taken FIRST as well (L >= 3, no table on it, enough edges: tuning.T.sum_first_below_min_edges): its weight
+              gradient then contracts the saved aggregate over |S_1| rows (level 1 through the source rows' side), its dX is a GEMM on |S_1| rows
+              in front of the plain reverse aggregation, the layer under it loses its dense tail.  CB_ROWS_ONLY_BELOW=1: Z-first on S_1;
+      sharded (space, orientation): row shards — the last layer on the rank's loss rows, where its backward runs compact levels; the exchange
+              ships only the in-neighbours of those rows (dist.ShardedGraph.loss_rows_forward).  The layers below keep all local rows."""
+    L, _alpha, _p, _seeds, _agg_bf16, _track, loss_rows, residual, rows_only = cfg
+    none = (None, None, None, False)
+    if not (rows_only and bwd and loss_rows is not None and L >= 2 and ag and rows_only_enabled()):
+        return none
+    le_last, sharded = layer_params[3 * (L - 1) + 2], hasattr(graph, 'part')
+    if sharded:
+        if not (le_last is None and hasattr(graph, 'loss_rows_forward') and ops.loss_rows_enabled() and loss_rows[0].shape[0] == x.shape[0]):
+            return none
+        gather, tail_tb = _gather_and_tail(graph, L, residual, h, x0)
+        levels = graph.support_levels(loss_rows[0], L, compact=ag and gather and not tail_tb, cumulative=residual)
+        if not (levels and levels[0].src is not None):
+            return none
+        return None, None, (levels[0].src, graph.loss_rows_forward(levels)), False
+    if not T.rowsparse_loss_side:
+        return none
+    hint = _support_plan(graph, loss_rows, x.shape[0], L, residual, h, x0)[0]
+    if hint is None:
+        return none
+    plan = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac, cumulative=residual)
+    mode = os.environ.get('CB_ROWS_ONLY_BELOW', '2')
+    below = graph.rows_only_fwd(plan) if mode != '0' else None
+    sum_first = (below is not None and mode == '2' and L >= 3 and layer_params[3 * (L - 2) + 2] is None and len(plan.levels) >= 2
+                 and below[0].E >= T.sum_first_below_min_edges)
+    return plan, below, None, sum_first
+
+
 def _store_rows(y, idx, mix, c_act, c_mix, p, seed, row0, bits, relu_only, mix_index=None, want_act=False):
     """cb_trunk_store_rows_f32: the trunk's fused store (ReLU, mask words, mix, dropout) on the compact rows idx of a dense transform's output.
     mix_index: the rows of `mix` to read when that is a compact matrix itself (default: the node rows idx).  Returns (stored rows, ReLU output | None)."""
@@ -457,7 +498,7 @@ class _TrunkFn(torch.autograd.Function):
         loss_rows = None or (bool mask [N], count): the caller's promise that the output receives gradient in those rows only (ops.py);
         residual: the 'Residual' connection (mix source of layer l > 0 = the previous layer's ReLU output) instead of 'Initial' (X0);
         rows_only: the caller's second promise — it READS the output in the rows of loss_rows only (the other rows are returned as zeros)."""
-        L, alpha, p, seeds, agg_bf16, track, loss_rows_, residual, rows_only = cfg
+        L, alpha, p, seeds, agg_bf16, track, _loss_rows, residual, _rows_only = cfg
         row0 = int(getattr(graph, 'row_offset', 0))
         a = graph.norm_out
         x = x.contiguous()
@@ -511,34 +552,10 @@ class _TrunkFn(torch.autograd.Function):
         h = x0.shape[1]
         saved_in, saved_bits = [cur], []
         ag = agg_gemm_eligible(graph, h, agg_bf16)
-        # Rows-only forward: with both promises of the caller (gradient AND reads in the loss rows only) the last layer, its store and the output
-        # Linear run on the loss rows (_last_layer_on_loss_rows) — where the backward will run its level 0 through the source rows' side.  Same
-        # decision as the backward's (_support_plan); the last layer without a structural-embedding table (its gradient is dL/dZ on ALL rows).
-        ro_plan = h_last = None
-        le_last = layer_params[3 * (L - 1) + 2]      # (a table on the last layer: its sum joins the layer's, its gradient keeps the backward's level 0 on the compact form)
-        if rows_only and bwd and loss_rows_ is not None and L >= 2 and ag and T.rowsparse_loss_side and rows_only_enabled():
-            hint, _gather, _tb = _support_plan(graph, loss_rows_, x.shape[0], L, residual, h, x0)
-            if hint is not None:
-                ro_plan = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac, cumulative=residual)
-        # ... and the layer below it on the rows the last layer reads (S_1, while the plan keeps that support compact; 'Residual': its ReLU output — the
-        # last layer's mix source — lives on those rows too).  CB_ROWS_ONLY_BELOW=0: that layer on all rows.
-        ro_below = graph.rows_only_fwd(ro_plan) if (ro_plan is not None and os.environ.get('CB_ROWS_ONLY_BELOW', '1') != '0') else None
-        # Node-sharded: the same for the rank's loss rows, where its backward will run compact levels (dist.ShardedGraph.support_levels) — the last
-        # layer's exchange ships only the in-neighbours of the loss rows (loss_rows_forward).  The layers below keep all local rows.
-        ro_sh = None
-        if (rows_only and bwd and loss_rows_ is not None and L >= 2 and ag and layer_params[3 * (L - 1) + 2] is None and rows_only_enabled()
-                and hasattr(graph, 'part') and hasattr(graph, 'loss_rows_forward') and ops.loss_rows_enabled() and loss_rows_[0].shape[0] == x.shape[0]):
-            gather_, tb_ = _gather_and_tail(graph, L, residual, h, x0)
-            levels = graph.support_levels(loss_rows_[0], L, compact=ag and gather_ and not tb_, cumulative=residual)
-            if levels and levels[0].src is not None:
-                ro_sh = (levels[0].src, graph.loss_rows_forward(levels))
+        ro_plan, ro_below, ro_sh, agg_first_below = _rows_only_decision(graph, cfg, x, x0, h, ag, bwd, layer_params)
         ro_any = ro_plan is not None or ro_sh is not None
-        # ... and with a layer under that one (L >= 3, no table on it) the layer below the last also takes its sum FIRST, on S_1: its weight gradient
-        # then contracts the saved aggregate over |S_1| rows (the backward's level 1 through the source rows' side), its dX is a GEMM on |S_1| rows
-        # in front of the plain reverse aggregation, and the layer under it loses its dense tail.  CB_ROWS_ONLY_BELOW=1: that layer Z-first on S_1
-        # (the fused store over the subset of rows) as before.
-        agg_first_below = (ro_below is not None and L >= 3 and layer_params[3 * (L - 2) + 2] is None and len(ro_plan.levels) >= 2
-                           and ro_below[0].E >= T.sum_first_below_min_edges and os.environ.get('CB_ROWS_ONLY_BELOW', '2') == '2')
+        le_last = layer_params[3 * (L - 1) + 2]
+        h_last = None
         h_below = None
         z_ready = None                           # Z_l already produced by layer l-1's aggregation kernel (cb_spmm_gemm_fused_f32)
         out_head = None                          # the logits, when the output Linear left the last layer's aggregation kernel
