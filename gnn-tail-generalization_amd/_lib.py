@@ -95,6 +95,9 @@ SIGNATURES = {
     'cb_adam_multi_norm_f32': (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                               ctypes.c_float, _I64, _P, _P, _P, _SZ, _P]),
     'cb_expand_rows_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P]),
+    'cb_gemm_nn_store_rows_supported': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64]),
+    'cb_gemm_nn_store_rows_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, _P, _P, _I64, _P, ctypes.c_float,
+                                                 ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, ctypes.c_int, _P, _I64, _P, _SZ, _P]),
     'cb_trunk_store_rows_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P,
                                                ctypes.c_int, _P, _P, _P]),
     'cb_agg_gemm_image_bytes': (_SZ, [_I64, _I64]),

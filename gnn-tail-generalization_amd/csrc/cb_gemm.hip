@@ -396,6 +396,40 @@ extern "C" size_t cb_gemm_tn_workspace_bytes(int64_t M, int64_t K1, int64_t K2) 
   return (size_t)tn_splits(M, tiles) * (size_t)K1 * (size_t)K2 * sizeof(float);
 }
 
+// The trunk's store on a SUBSET of the node rows as the epilogue of the dense transform in front of it (rows-only forward, trunk.py _layer_on_rows):
+//   act = relu(rowscale * (A @ B) + addend + bias)  (-> out_act if given);   C = dropout(c_act * act + c_mix * mix_src[mix_index[m] | row_index[m]])
+// A, C, out_act, rowscale, addend: compact [M, .] over the rows row_index[0 .. M) of the node rows; relu_bits ([all node rows][4]) and the dropout
+// mask are taken at the node row.  N == 256 on the three-limb wide tile only: ask cb_gemm_nn_store_rows_supported first (else cb_gemm_nn_f32 followed
+// by cb_trunk_store_rows_f32, whose results this reproduces bit for bit).
+extern "C" int cb_gemm_nn_store_rows_supported(const float* A, int64_t lda, const float* B, int64_t ldb, const float* C, int64_t ldc, int64_t M, int64_t N,
+                                               int64_t K) {
+  return use_limb3() && N == 256 && M > 0 && limb3_nn_eligible(A, lda, B, ldb, N, K) && al16(C) && ldc % 4 == 0 ? 1 : 0;
+}
+
+extern "C" int cb_gemm_nn_store_rows_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                         const float* rowscale, const float* addend, int64_t ld_add, const float* bias, const int64_t* row_index,
+                                         const float* mix_src, int64_t ld_mix, const int64_t* mix_index, float c_act, float c_mix, float drop_p,
+                                         uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, int bits_relu_only, float* out_act,
+                                         int64_t ld_act, void* ws, size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(M >= 0 && N == 256 && K > 0 && drop_p >= 0.f && drop_p < 1.f && row0 >= 0, CB_E_INVALID, "cb_gemm_nn_store_rows_f32: bad size (N must be 256) or p");
+  CB_CHECK_ARG(K < (1 << 24) && (M + 63) / 64 < (1 << 24), CB_E_RANGE, "cb_gemm_nn_store_rows_f32: size out of range");
+  if (M == 0) return CB_OK;
+  CB_CHECK_ARG(A && B && C && row_index && lda >= K && ldb >= N && ldc >= N && (!addend || ld_add >= N), CB_E_INVALID,
+               "cb_gemm_nn_store_rows_f32: null pointer or leading dimension too small");
+  CB_CHECK_ARG(cb_gemm_nn_store_rows_supported(A, lda, B, ldb, C, ldc, M, N, K) && (!addend || (al16(addend) && ld_add % 4 == 0)) &&
+                   (!mix_src || (al16(mix_src) && ld_mix % 4 == 0 && ld_mix >= N)) && (!out_act || (al16(out_act) && ld_act % 4 == 0 && ld_act >= N)) &&
+                   (!relu_bits || (uintptr_t)relu_bits % 8 == 0),
+               CB_E_INVALID, "cb_gemm_nn_store_rows_f32: shape / alignment outside the fused form (cb_gemm_nn_store_rows_supported)");
+  GemmEpilogue ep{rowscale, addend, ld_add, bias, 1, nullptr, 0, 0u, 1.f, 0ull, nullptr, 0, 0};
+  ep.thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
+  ep.keep_scale = 1.f / (1.f - drop_p);
+  ep.seed = seed; ep.seed_dev = seed_dev; ep.row0 = row0;
+  ep.relu_bits_out = (unsigned long long*)relu_bits;
+  ep.row_ids = row_index; ep.mix_src = mix_src; ep.ld_mix = ld_mix; ep.mix_index = mix_index; ep.c_act = c_act; ep.c_mix = c_mix;
+  ep.bits_relu_only = bits_relu_only; ep.out_act = out_act; ep.ld_act = ld_act;
+  return launch_nn_limb3(A, lda, B, ldb, C, ldc, M, N, K, ep, false, (hipStream_t)stream, ws, ws_bytes);
+}
+
 extern "C" int cb_gemm_tn_f32(const float* A, int64_t lda, const float* G, int64_t ldg, const float* rowscale, float* C, int64_t M,
                               int64_t K1, int64_t K2, void* ws, size_t ws_bytes, void* stream) {
   CB_CHECK_ARG(M >= 0 && K1 >= 0 && K2 >= 0, CB_E_INVALID, "cb_gemm_tn_f32: negative size");

@@ -40,6 +40,17 @@ struct GemmEpilogue {
   DropSpec adrop;                   // ADROP kernels only: dropout of the A operand (thresh = 0: off)
   unsigned long long* relu_bits_out;   // 256-column tiles only: [M][4] mask words of (C > 0) after the ReLU (word q, bit L <-> column 4 L + q:
                                     // the layout of the aggregation's fused store) — the trunk's input stage reads them instead of C itself
+  // EPI == 2 kernels only (N == 256): the trunk's fused store on the rows of a SUBSET of the node rows (cb_trunk_store_rows_f32's pass in this
+  // epilogue): act = relu(rowscale * acc + addend + bias) -> out_act (optional); C = dropout(c_act * act + c_mix * mix_src[mix_index[m] | row_ids[m]]);
+  // relu_bits_out is indexed by the NODE row row_ids[m]; the dropout mask (thresh, keep_scale, seed, seed_dev, row0 above) is drawn there too
+  const int64_t* row_ids;
+  const float* mix_src;
+  int64_t ld_mix;
+  const int64_t* mix_index;
+  float c_act, c_mix;
+  int bits_relu_only;
+  float* out_act;
+  int64_t ld_act;
 };
 
 template <int WM, int WN, int BKT = BK, int WTN = 2>
@@ -182,7 +193,7 @@ __device__ __forceinline__ void store4(float* __restrict__ p, float a, float b, 
   }
 }
 
-// EPI: 0 = plain; 1 = second output out2 = dropout(C) (+ the mask words of C > 0) (see GemmEpilogue)
+// EPI: 0 = plain; 1 = second output out2 = dropout(C) (+ the mask words of C > 0); 2 = the trunk's store on a subset of the node rows (see GemmEpilogue)
 template <int WM, int WN, int WTN, bool OUT_BF16, int EPI = 0>
 __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __restrict__ Cs, void* __restrict__ Cv, int64_t ldc,
                                             int64_t m0, int n0, int64_t M, int N, const GemmEpilogue& ep, int c_vec_ok, int t) {
@@ -254,6 +265,32 @@ __device__ __forceinline__ void nn_epilogue(f32x16 (&acc)[2][WTN], float* __rest
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (n + q < N) cp[q] = f32_to_bf16(o[q]);
           }
+        } else if constexpr (EPI == 2) {   // launch contract: N == 256 (TPR == 64: a wavefront holds one whole row), vector stores, ep.relu set
+          const int64_t gm = ep.row_ids[m];
+          float mk[4] = {1.f, 1.f, 1.f, 1.f};
+          if (ep.thresh) keep4(ep.seed_dev ? ep.seed + *ep.seed_dev : ep.seed, ((ep.row0 + gm) * N + n) >> 2, ep.thresh, ep.keep_scale, mk);
+          if (ep.relu_bits_out) {
+            unsigned long long mine = 0ull;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const unsigned long long wq = __ballot(o[q] > 0.f && (ep.bits_relu_only || mk[q] != 0.f));
+              if ((t & 63) == q) mine = wq;
+            }
+            if ((t & 63) < 4) ep.relu_bits_out[gm * 4 + (t & 63)] = mine;
+          }
+          if (ep.out_act) store4(ep.out_act + m * ep.ld_act + n, o[0], o[1], o[2], o[3], 0);
+          float x[4] = {o[0], o[1], o[2], o[3]};
+          if (ep.mix_src) {
+            const int64_t mr = ep.mix_index ? ep.mix_index[m] : gm;
+            const float4 qv = *reinterpret_cast<const float4*>(ep.mix_src + mr * ep.ld_mix + n);
+            x[0] = mix2(ep.c_act, o[0], ep.c_mix, qv.x); x[1] = mix2(ep.c_act, o[1], ep.c_mix, qv.y);
+            x[2] = mix2(ep.c_act, o[2], ep.c_mix, qv.z); x[3] = mix2(ep.c_act, o[3], ep.c_mix, qv.w);
+          }
+          if (ep.thresh) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[q] *= mk[q];
+          }
+          store4(C + m * ldc + n, x[0], x[1], x[2], x[3], 0);
         } else {
           float* cp = C + m * ldc + n;
           if (full4 && c_vec_ok) {

@@ -169,6 +169,11 @@ static int launch_nn_l3_t(const float* A, int64_t lda, const float* B, int64_t l
       CB_LAUNCH_CHECK();
       return CB_OK;
     }
+    if (ep.row_ids) {   // the trunk's store on a subset of the node rows in the epilogue (cb_gemm_nn_store_rows_f32)
+      hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, false, WTN, 1, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb, ncb, c_vec_ok);
+      CB_LAUNCH_CHECK();
+      return CB_OK;
+    }
     if (ep.adrop.thresh) {      // single output, dropout of the A operand in its staging (no dropped copy of A anywhere)
       hipLaunchKernelGGL((k_gemm_nn_l3<WM, WN, false, WTN, 1, 0, true>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, (int)N, (int)K, ep, nrb,
                          ncb, c_vec_ok);
@@ -207,7 +212,7 @@ int launch_nn_limb3(const float* A, int64_t lda, const float* B, int64_t ldb, vo
   // 128 x 256 block tile (wave tile 64 x 128) where it fills the chip, else 128 x 128:
   // fewer than one wide tile per CU (a Pubmed-sized M = 19 717: 155 tiles): the 128 x 128 tile doubles the blocks in flight (-6 % on
   // the S-pubmed step); the dual-output epilogues exist for the wide tile only
-  const bool fills = ((M + 127) / 128) * ((N + 255) / 256) >= 256 || ep.out2 || ep.adrop.thresh;
+  const bool fills = ((M + 127) / 128) * ((N + 255) / 256) >= 256 || ep.out2 || ep.adrop.thresh || ep.row_ids;
   if (N > 128 && fills)
     return out_bf16 ? launch_nn_l3_t<2, 2, true, 4>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes)
                     : launch_nn_l3_t<2, 2, false, 4>(A, lda, B, ldb, C, ldc, M, N, K, ep, st, ws, ws_bytes);

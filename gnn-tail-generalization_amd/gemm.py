@@ -59,6 +59,35 @@ def mm_nn(a, b, rowscale=None, addend=None, bias=None, relu=False, out_bf16=Fals
     return out
 
 
+def mm_nn_store_rows(a, b, rowscale, addend, bias, row_index, mix, mix_index, c_act, c_mix, p, seed, row0, bits, relu_only, want_act=False):
+    """The trunk's store on a subset of the node rows as the epilogue of the transform in front of it (cb_gemm_nn_store_rows_f32):
+    act = relu(rowscale * (a @ b) + addend + bias);  out = dropout(c_act * act + c_mix * mix[mix_index | row_index]) — mask words (bits: the full
+    [N, 1, 4] array) and dropout mask at the node rows row_index.  Returns (out, act | None), or None where the fused form does not exist for the
+    shape (the caller then runs mm_nn and the elementwise pass) or CB_GEMM_STORE_ROWS=0."""
+    import ctypes
+    import os
+    from . import ops
+    lib = _lib.load()
+    a, b = _rowmajor(a), _rowmajor(b)
+    M, K = a.shape
+    N = b.shape[1]
+    if os.environ.get('CB_GEMM_STORE_ROWS', '1') == '0' or N != 256 or M == 0:
+        return None
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if not lib.cb_gemm_nn_store_rows_supported(_lib.ptr(a), _ld(a), _lib.ptr(b), _ld(b), _lib.ptr(out), _ld(out), M, N, K):
+        return None
+    if addend is not None:
+        addend = _rowmajor(addend)
+    act = torch.empty_like(out) if want_act else None
+    with torch.cuda.device(a.device):
+        _lib.check(lib.cb_gemm_nn_store_rows_f32(_lib.ptr(a), _ld(a), _lib.ptr(b), _ld(b), _lib.ptr(out), _ld(out), M, N, K, _lib.ptr(rowscale), _lib.ptr(addend),
+                                                 _ld(addend) if addend is not None else 0, _lib.ptr(bias), _lib.ptr(row_index), _lib.ptr(mix),
+                                                 mix.stride(0) if mix is not None else 0, _lib.ptr(mix_index), float(c_act), float(c_mix), float(p),
+                                                 ctypes.c_uint64(seed), ops.seed_dev_ptr(), int(row0), _lib.ptr(bits), int(bool(relu_only)), _lib.ptr(act), N, None, 0,
+                                                 _lib.stream_ptr()), 'cb_gemm_nn_store_rows_f32')
+    return out, act
+
+
 def mm_nn_drop2(a, b, p, seed, row0=0, bias=None, relu=False):
     """(y, dropout_p(y)) with y = act(a @ b + bias), both written by one GEMM epilogue (cb_gemm_nn_drop2_f32); the dropped copy
     uses the keep-mask ops._dropout_raw(y, p, seed, row0 * N) would draw."""

@@ -429,9 +429,13 @@ def _layer_on_rows(graph, space, fwd, col_scale, cur, w, b, mix, mix_index, alph
     if le is not None:
         fwd_le.profile = fwd.profile
         le_sum = fwd_le.spmm(le, row_scale=b_rows)
+    bits = torch.empty((graph.N, w.shape[1] // 256, 4), dtype=torch.int64, device=cur.device)
+    # the store as the epilogue of the transform where that form exists (hidden 256), else the transform and then the elementwise pass: same values
+    fused = gemm.mm_nn_store_rows(h_agg, w, b_rows, le_sum, b, space.idx, mix, mix_index, 1 - alpha, alpha, p, seed, row0, bits, residual, want_act)
+    if fused is not None:
+        return bits, fused[0], fused[1], h_agg
     y = gemm.mm_nn(h_agg, w, rowscale=b_rows, addend=le_sum, bias=b)
     del le_sum
-    bits = torch.empty((graph.N, w.shape[1] // 256, 4), dtype=torch.int64, device=cur.device)
     x_next, act = _store_rows(y, space.idx, mix, 1 - alpha, alpha, p, seed, row0, bits, residual, mix_index, want_act)
     return bits, x_next, act, h_agg
 

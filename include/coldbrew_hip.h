@@ -594,6 +594,17 @@ int cb_expand_rows_f32(const float* src, const int32_t* pos, int64_t n_rows, int
 int cb_trunk_store_rows_f32(const float* y, const int64_t* row_index, int64_t n_rows, int64_t d, const float* mix_src, int64_t ld_mix,
                             const int64_t* mix_index, float c_act, float c_mix, float drop_p, uint64_t seed, const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, int bits_relu_only,
                             float* out, float* out_act, void* stream);
+/* The same store as the EPILOGUE of the dense transform in front of it:
+ *   act = relu(rowscale * (A @ B) + addend + bias) (-> out_act if given);  C = dropout(c_act * act + c_mix * mix_src[mix_index[m] | row_index[m]])
+ * with A, C, out_act, rowscale, addend compact over the rows row_index[0 .. M) — a GCNConv evaluated sum-first on a subset of the rows (GCN.py:213-256
+ * with the aggregation taken before the transform) and the trunk's ReLU / mix / dropout (:127-133) in one kernel.  N == 256; results equal
+ * cb_gemm_nn_f32 followed by cb_trunk_store_rows_f32 bit for bit.  cb_gemm_nn_store_rows_supported tells whether the fused form exists for a shape. */
+int cb_gemm_nn_store_rows_supported(const float* A, int64_t lda, const float* B, int64_t ldb, const float* C, int64_t ldc, int64_t M, int64_t N, int64_t K);
+int cb_gemm_nn_store_rows_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                              const float* rowscale, const float* addend, int64_t ld_add, const float* bias, const int64_t* row_index,
+                              const float* mix_src, int64_t ld_mix, const int64_t* mix_index, float c_act, float c_mix, float drop_p, uint64_t seed,
+                              const uint64_t* seed_dev, int64_t row0, uint64_t* relu_bits, int bits_relu_only, float* out_act, int64_t ld_act, void* ws,
+                              size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

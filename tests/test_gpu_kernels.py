@@ -529,3 +529,34 @@ def test_forward_front_kernel_equals_the_two_gemms(M, K, p, row0):
             ref_w = (pos[:, kk::4].to(torch.int64) << torch.arange(64, device=DEV, dtype=torch.int64)).sum(dim=1)
             assert torch.equal(bits[:, 0, kk], ref_w), kk
     assert gemm.trunk_front(x[:, :60].contiguous(), w_in[:, :60].contiguous(), b_in, w0, a, le, p, sx, s0) is None      # no kernel for this input width
+
+
+@pytest.mark.parametrize('M,p,relu_only,with_mix,with_index,want_act', [(40_000, 0.1, False, True, False, False), (3_001, 0.3, True, True, True, True),
+                                                                        (70_000, 0.0, False, False, False, False), (257, 0.1, False, True, False, True)])
+def test_gemm_with_the_trunk_store_on_a_subset_of_rows_equals_the_two_kernels(M, p, relu_only, with_mix, with_index, want_act):
+    """cb_gemm_nn_store_rows_f32 (the rows-only forward's sum-first layer: transform + ReLU / mask words / mix / dropout on compact rows in one kernel) against
+    cb_gemm_nn_f32 followed by cb_trunk_store_rows_f32: stored rows, ReLU output and the mask words of the written node rows, bit for bit."""
+    from gnn_tail_generalization_amd import gemm, trunk
+    dev = 'cuda:0'
+    g = torch.Generator(device='cpu').manual_seed(M)
+    n_nodes = 3 * M + 7
+    idx = torch.sort(torch.randperm(n_nodes, generator=g)[:M]).values.to(dev)
+    a = (torch.rand(M, 256, generator=g) - 0.5).to(dev)
+    w = ((torch.rand(256, 256, generator=g) - 0.5) * 0.2).to(dev)
+    rs = (torch.rand(M, generator=g) + 0.5).to(dev)
+    addend = (torch.rand(M, 256, generator=g) - 0.5).to(dev)
+    bias = (torch.rand(256, generator=g) - 0.5).to(dev)
+    mix = mix_index = None
+    if with_mix:
+        n_mix = 2 * M if with_index else n_nodes
+        mix = (torch.rand(n_mix, 256, generator=g) - 0.5).to(dev)
+        mix_index = torch.randint(0, n_mix, (M,), generator=g).to(dev) if with_index else None
+    bits_f = torch.zeros((n_nodes, 1, 4), dtype=torch.int64, device=dev)
+    bits_t = torch.zeros_like(bits_f)
+    fused = gemm.mm_nn_store_rows(a, w, rs, addend, bias, idx, mix, mix_index, 0.9, 0.1, p, 4242, 5, bits_f, relu_only, want_act)
+    assert fused is not None
+    y = gemm.mm_nn(a, w, rowscale=rs, addend=addend, bias=bias)
+    out_t, act_t = trunk._store_rows(y, idx, mix, 0.9, 0.1, p, 4242, 5, bits_t, relu_only, mix_index, want_act)
+    assert torch.equal(fused[0], out_t) and torch.equal(bits_f, bits_t)
+    assert (fused[1] is None) == (not want_act) and (not want_act or torch.equal(fused[1], act_t))
+    assert int((bits_f[idx] != 0).sum()) > 0
