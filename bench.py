@@ -602,6 +602,10 @@ def main():
         sharding['row_sparse_levels_rank0'] = ([{'edges': int(lv.orient.E), 'rows_read': (lv.src.n if lv.src is not None else None),
                                                  'rows_written': (lv.dst.n if lv.dst is not None else None), 'halo_rows': int(lv.orient.plan.n_halo)}
                                                 for lv in cache_[2]] if cache_ is not None else [])
+        f0_ = getattr(sg_, '_fwd0_cache', None)
+        sharding['rows_only_forward_rank0'] = ({'forwards': int(sg_.rows_only_forwards), 'edges': int(f0_[1].E), 'rows_written': int(f0_[0][0].src.n),
+                                                'halo_rows': int(f0_[1].plan.n_halo), 'halo_rows_full_forward': int(sg_.f.plan.n_halo)}
+                                               if f0_ is not None else {'forwards': int(getattr(sg_, 'rows_only_forwards', 0))})
         dist.barrier()
         dist.destroy_process_group()
     if rank != 0:

@@ -376,6 +376,9 @@ def test_bench_gpus_n_without_a_launcher_runs_n_ranks():
     sh = d['sharding']
     assert sh['ranks_seen'] == [0, 1] and sh['backend'] == 'gloo' and sh['loss_matches_n1'] is True, sh
     assert sum(sh['rows_per_rank']) == 169343
+    ro = sh['rows_only_forward_rank0']      # where the plan allows compact levels the training forward ran its last layer on the rank's loss rows: a fraction of the forward halo
+    compact = any(lv['rows_read'] is not None for lv in sh['row_sparse_levels_rank0'])
+    assert (ro['forwards'] >= 3 and 0 < ro['halo_rows'] < ro['halo_rows_full_forward']) if compact else ro['forwards'] == 0, (ro, sh['row_sparse_levels_rank0'])
 
 
 
