@@ -18,11 +18,12 @@ from .trunk import _exchanged, _fused_gemm, _fused_launch, _fused_spmm, _layer_b
 from .tuning import T
 
 
-def _plan_hint(graph, loss_rows, n_rows, ag):
-    """loss_rows if the backward (and a rows-only forward) may run on the row-support plan, else None — one decision for both."""
+def _plan_hint(graph, loss_rows, n_rows, ag, committed=False):
+    """loss_rows if the backward (and a rows-only forward) may run on the row-support plan, else None — one decision for both.  committed (the backward of
+    a rows-only forward): the plan's build / hit bookkeeping is not asked again."""
     if (loss_rows is not None and ops.loss_rows_enabled() and not hasattr(graph, 'part') and loss_rows[0].shape[0] == n_rows
             and getattr(graph, 'rowptr_t', None) is not None and 1 <= loss_rows[1] <= T.rowsparse_s0_limit * n_rows
-            and (n_rows >= T.rowsparse_min_nodes or getattr(graph, 'rowsparse_small_ok', False)) and ag and graph.support_plan_pays()):
+            and (n_rows >= T.rowsparse_min_nodes or getattr(graph, 'rowsparse_small_ok', False)) and ag and (committed or graph.support_plan_pays())):
         return loss_rows
     return None
 
@@ -140,7 +141,7 @@ class _StackFn(torch.autograd.Function):
         # Row-sparse backward (one GPU; trunk.py / DESIGN.md section 1): under the caller's loss_rows promise the levels of the backward whose support
         # is small run on compact [|S_j|, .] matrices through the plan's renumbered orientations; the promise is checked on the device.
         plan = None
-        hint = _plan_hint(graph, loss_rows, gout.shape[0], ag)
+        hint = _plan_hint(graph, loss_rows, gout.shape[0], ag, committed=ctx.in_last_compact)
         if hint is not None:
             ops.check_rows_zero(gout, hint[0])
             plan = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac)

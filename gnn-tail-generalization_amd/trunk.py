@@ -344,16 +344,18 @@ def _gather_and_tail(graph, L, residual, h, x0):
     return gather, agg_gemm_eligible(graph, h, False) and gather and not residual and tail_trunk_bwd(graph)
 
 
-def _support_plan(graph, loss_rows, n_rows, L, residual, h, x0):
+def _support_plan(graph, loss_rows, n_rows, L, residual, h, x0, committed=False):
     """(plan, gather, tail_tb) of a backward — and of a rows-only forward — under the caller's loss_rows promise: ONE decision for both, so that a
-    forward that evaluated its last layer on the loss rows finds the same plan in its backward.  plan: CSRGraph.grad_support_plan or None (dense)."""
+    forward that evaluated its last layer on the loss rows finds the same plan in its backward.  plan: CSRGraph.grad_support_plan or None (dense).
+    committed (the backward of a rows-only forward): the plan's build / hit bookkeeping (support_plan_pays) is not asked again — the forward's own
+    build may just have tipped it."""
     gather, tail_tb = _gather_and_tail(graph, L, residual, h, x0)
     hint = loss_rows if (not hasattr(graph, 'part') and hasattr(graph, 'grad_support_plan') and graph.rowptr_t is not None) else None
     if hint is not None and (not ops.loss_rows_enabled() or hint[0].shape[0] != n_rows):
         hint = None
     if not (hint is not None and 1 <= hint[1] <= T.rowsparse_s0_limit * n_rows
             and (n_rows >= T.rowsparse_min_nodes or getattr(graph, 'rowsparse_small_ok', False)) and gather
-            and agg_gemm_eligible(graph, h, False) and not tail_tb and graph.support_plan_pays()):
+            and agg_gemm_eligible(graph, h, False) and not tail_tb and (committed or graph.support_plan_pays())):
         return None, gather, tail_tb
     return hint, gather, tail_tb
 
@@ -897,7 +899,7 @@ class _Backward:
         # (ops.check_rows_zero: a violation ends in the device error word and stops the optimiser launch, never in silent wrong gradients).
         # Hidden 256, gathered per-layer gradients, loss rows <= rowsparse_s0_limit of the nodes.
         plan = None
-        hint = None if sharded else _support_plan(graph, self.loss_rows, gout.shape[0], L, self.residual, self.h, self.x0)[0]
+        hint = None if sharded else _support_plan(graph, self.loss_rows, gout.shape[0], L, self.residual, self.h, self.x0, committed=self.xl_compact)[0]
         # (with bf16-stored rows the compact levels still run on fp32 matrices through the aggregation + GEMM kernel; the dense levels below
         # them go on as the bf16 path does)
         if hint is not None:

@@ -471,6 +471,31 @@ def test_a_new_mask_every_step_falls_back_to_the_dense_backward():
     assert not G2.support_plan_pays()
 
 
+def test_a_trainer_whose_mask_changes_every_step_keeps_stepping(monkeypatch):
+    """The rows-only forward commits its backward to the plan it was evaluated on: the build / hit bookkeeping (support_plan_pays) is asked ONCE per step,
+    in the forward — the build it triggers may be the one that tips the balance.  Six steps with a fresh train mask each: the first four take the plan
+    (forward and backward alike), the rest run dense; no step fails, every loss is finite."""
+    from gnn_tail_generalization_amd import trunk
+    monkeypatch.setattr(tuning.T, 'rowsparse_min_nodes', 0)
+    taken = []
+    real = trunk._last_layer_on_loss_rows
+    monkeypatch.setattr(trunk, '_last_layer_on_loss_rows', lambda *a, **k: (taken.append(1), real(*a, **k))[1])
+    import bench
+    from gnn_tail_generalization_amd import trainer_node_classification as tnc
+    args = bench.make_args('S-arxiv', ['--manual_assign_GPU=0'])
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        t = tnc.trainer(args, 0)
+        t.setup_teacherGNN()
+    g = torch.Generator(device='cpu').manual_seed(1)
+    losses = []
+    for _ in range(6):
+        m = (torch.rand(t.data.train_mask.shape[0], generator=g) < 0.1).to(t.data.train_mask.device)
+        t.data.train_mask, t.data.test_mask, t._n_train = m, ~m, None
+        losses.append(float(t.train_step()))
+    assert all(l == l and abs(l) < 1e3 for l in losses) and 1 <= len(taken) <= 4, (losses, taken)
+
+
 def test_violated_claim_is_reported_not_silent():
     from gnn_tail_generalization_amd import _lib, ops
     lib = _lib.load()
