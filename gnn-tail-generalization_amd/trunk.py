@@ -378,11 +378,13 @@ def _rows_only_decision(graph, cfg, x, x0, h, ag, bwd, layer_params):
               in front of the plain reverse aggregation, the layer under it loses its dense tail.  CB_ROWS_ONLY_BELOW=1: Z-first on S_1;
       sharded (space, orientation): row shards — the last layer on the rank's loss rows, where its backward runs compact levels; the exchange
               ships only the in-neighbours of those rows (dist.ShardedGraph.loss_rows_forward).  The layers below keep all local rows."""
-    L, _alpha, _p, _seeds, _agg_bf16, _track, loss_rows, residual, rows_only = cfg
+    L, _alpha, _p, _seeds, agg_bf16, _track, loss_rows, residual, rows_only = cfg
     none = (None, None, None, False)
-    if not (rows_only and bwd and loss_rows is not None and L >= 2 and ag and rows_only_enabled()):
-        return none
     le_last, sharded = layer_params[3 * (L - 1) + 2], hasattr(graph, 'part')
+    # (bf16-stored rows, one GPU: the last layer alone — its sum is taken over the fp32 activations, the layers below keep their bf16-stored Z)
+    bf16_last_only = bool(agg_bf16) and not sharded and agg_gemm_eligible(graph, h, False)
+    if not (rows_only and bwd and loss_rows is not None and L >= 2 and (ag or bf16_last_only) and rows_only_enabled()):
+        return none
     if sharded:
         if not (le_last is None and hasattr(graph, 'loss_rows_forward') and ops.loss_rows_enabled() and loss_rows[0].shape[0] == x.shape[0]):
             return none
@@ -397,7 +399,7 @@ def _rows_only_decision(graph, cfg, x, x0, h, ag, bwd, layer_params):
     if hint is None:
         return none
     plan = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac, cumulative=residual)
-    mode = os.environ.get('CB_ROWS_ONLY_BELOW', '2')
+    mode = '0' if bf16_last_only else os.environ.get('CB_ROWS_ONLY_BELOW', '2')
     below = graph.rows_only_fwd(plan) if mode != '0' else None
     sum_first = (below is not None and mode == '2' and L >= 3 and layer_params[3 * (L - 2) + 2] is None and len(plan.levels) >= 2
                  and below[0].E >= T.sum_first_below_min_edges)
@@ -588,7 +590,7 @@ class _TrunkFn(torch.autograd.Function):
             elif ag and ro_sh is not None and l == L - 1:
                 bits, cur, out_head = _last_layer_on_loss_rows_sharded(graph, ro_sh[0], ro_sh[1], cur, w, b, mix, alpha, p, sd_l, row0, residual, w_out, b_out)
                 z = None
-            elif ag and ro_plan is not None and l == L - 1:
+            elif ro_plan is not None and l == L - 1:
                 bits, cur, out_head, h_last = _last_layer_on_loss_rows(graph, ro_plan, cur, w, b, mix, alpha, p, sd_l, row0, residual, w_out, b_out, below=ro_below,
                                                                        le=le_last)
                 if le_last is None:

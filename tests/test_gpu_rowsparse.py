@@ -261,6 +261,23 @@ def test_row_sparse_backward_with_bf16_stored_rows():
         assert float((g_s[k] - g_f[k]).abs().max()) <= 1.5 * err_dense_bf16 + 1e-5 * scale, k
 
 
+def test_rows_only_forward_with_bf16_stored_rows(monkeypatch):
+    """--agg_dtype bf16: the last layer alone runs on the loss rows — its sum over the fp32 activations (closer to the fp32 result than the bf16-stored Z it
+    replaces), the layers below as the bf16 path does.  Loss and gradients stay within what bf16 rows cost the all-rows step."""
+    from gnn_tail_generalization_amd import trunk
+    calls = []
+    real = trunk._last_layer_on_loss_rows
+    monkeypatch.setattr(trunk, '_last_layer_on_loss_rows', lambda *a, **k: (calls.append(k.get('below') is None), real(*a, **k))[1])
+    loss_s, g_s, used_s = _step_grads('1', extra=['--agg_dtype=bf16'], rows_only=True)
+    assert calls == [True] and used_s
+    loss_d, g_d, _ = _step_grads('0', extra=['--agg_dtype=bf16'])
+    loss_f, g_f, _ = _step_grads('0')                                      # fp32 rows, dense backward: the yardstick
+    assert abs(loss_s - loss_f) <= 1.5 * abs(loss_d - loss_f) + 1e-5 * abs(loss_f)
+    for k in g_d:
+        err_dense_bf16 = float((g_d[k] - g_f[k]).norm())
+        assert float((g_s[k] - g_f[k]).norm()) <= 1.5 * err_dense_bf16 + 1e-3 * float(g_f[k].norm()), k
+
+
 def test_row_sparse_backward_two_layers_small_graph(monkeypatch):
     """BASELINE config 2's shape (S-pubmed: 19 717 nodes, 2 layers, structural embeddings): the plan has two levels, the second one dense by
     construction (the stage below the first layer needs all rows); taken at this size only under hipGraph replay, forced here."""
