@@ -413,7 +413,8 @@ KERNEL_OF = {'plain': 'k_spmm_rows (+hub kernels)', 'colscale': 'k_spmm_rows<col
              'agg_gemm_fused_eval': 'k_agg_gemm2<true> evaluation form (+hub kernels)',
              'agg_gemm_head': 'k_agg_gemm2<true, narrow> (+hub kernels): last layer store + the output Linear (256 x C) in one kernel',
              'agg_gemm_head_eval': 'k_agg_gemm2<true, narrow> evaluation form (+hub kernels)',
-             'agg_gemm_trunkbwd': 'k_agg_gemm2<TB> (+hub kernels)'}
+             'agg_gemm_trunkbwd': 'k_agg_gemm2<TB> (+hub kernels)',
+             'store_bwd': 'k_spmm_rows<store backward in the epilogue> (+hub kernels)'}
 
 
 def main():

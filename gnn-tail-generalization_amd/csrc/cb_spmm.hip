@@ -297,6 +297,39 @@ extern "C" int cb_spmm_csr_fused_rows_f32(const int32_t* row_ids, const int32_t*
   return spmm_fused_impl(0, nullptr, 0, col_flags, CB_FUSED_ARGS, row_ids);
 }
 
+// A (reverse) aggregation whose epilogue is the BACKWARD of the trunk's store of the rows it writes (the row-sparse backward's dense level, trunk.py):
+//   g = row_scale * sum  -> out_g (the gradient w.r.t. the stored, dropped activation: kept for the input stage's mix gather)
+//   out_gr = bwd_rowscale * c_act * dropout_bwd_seed(g) where relu_bits (READ: written by the forward's store) has the element's bit, else 0
+// = cb_spmm_csr_f32 followed by cb_trunk_layer_bwd_f32 without the pass's read of g (bit-identical values); the bias gradient of that pass (column sums of
+// the masked gradient) is taken by cb_trunk_input_bwd_multi_cs_f32, which reads g anyway.  d % 256 == 0, fp32 rows.
+extern "C" int cb_spmm_csr_store_bwd_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h,
+                                         int64_t d, const float* row_scale, const uint64_t* relu_bits, const float* bwd_rowscale, float c_act, float drop_p,
+                                         uint64_t seed, const uint64_t* seed_dev, int64_t row0, float* out_g, int64_t ld_g, float* out_gr, int64_t ld_gr,
+                                         int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,
+                                         size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(N >= 0 && E >= 0 && d > 0 && d % 256 == 0, CB_E_INVALID, "cb_spmm_csr_store_bwd_f32: d must be a positive multiple of 256");
+  CB_CHECK_ARG(N < INT32_MAX && E < INT32_MAX && d < (1 << 20), CB_E_RANGE, "cb_spmm_csr_store_bwd_f32: size exceeds the int32 contract");
+  if (N == 0) return CB_OK;
+  CB_CHECK_ARG(rowptr && h && out_gr && relu_bits && (E == 0 || col), CB_E_INVALID, "cb_spmm_csr_store_bwd_f32: null pointer");
+  CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && row0 >= 0, CB_E_INVALID, "cb_spmm_csr_store_bwd_f32: dropout p / row offset out of range");
+  CB_CHECK_ARG(((uintptr_t)h % 16 == 0) && ((uintptr_t)out_gr % 16 == 0) && ld_h % 4 == 0 && ld_gr % 4 == 0 && ld_h >= d && ld_gr >= d &&
+                   (!out_g || ((uintptr_t)out_g % 16 == 0 && ld_g % 4 == 0 && ld_g >= d)) && ((uintptr_t)relu_bits % 8 == 0),
+               CB_E_INVALID, "cb_spmm_csr_store_bwd_f32: 16-byte aligned rows required");
+  CB_CHECK_ARG(hub_T > 0 && n_hubs >= 0 && n_chunks >= 0, CB_E_INVALID, "cb_spmm_csr_store_bwd_f32: bad hub plan");
+  CB_CHECK_ARG(n_hubs == 0 || (hub_rows && hub_chunk_ptr && ws && ws_bytes >= cb_spmm_workspace_bytes(n_chunks, d)), CB_E_WORKSPACE,
+               "cb_spmm_csr_store_bwd_f32: hub plan given but workspace missing/too small");
+  if (n_hubs == 0) hub_T = INT32_MAX;
+  Epilogue ep{row_scale, nullptr, 0, nullptr, 0, col_flags};
+  FusedEpi fe{};
+  fe.bwd = 1; fe.bwd_rowscale = bwd_rowscale; fe.c_act = c_act;
+  fe.thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
+  fe.keep_scale = 1.f / (1.f - drop_p);
+  fe.seed = seed; fe.seed_dev = seed_dev; fe.row0 = row0; fe.bits = (unsigned long long*)relu_bits;
+  fe.out_act = out_g; fe.ld_act = ld_g; fe.out_next = out_gr; fe.ld_next = ld_gr; fe.d = (int)d;
+  return launch_spmm<4, true, float>(rowptr, col, N, h, ld_h, d, ep, out_gr, ld_gr, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, (float*)ws,
+                                     (hipStream_t)stream, fe);
+}
+
 // Fused store of the residual trunk on top of the interior-column partial sums (second pass of the node-sharded aggregation)
 extern "C" int cb_spmm_csr_fused_acc_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int32_t col_flags,
                                          int64_t N, int64_t E, const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias,

@@ -167,6 +167,11 @@ struct FusedEpi {
   int64_t ld_next;
   int d;
   int skip_next;          // cb_agg_gemm.hip, forwards without a backward: the finished row only goes to the on-chip tile, not to out_next
+  int bwd;                // BACKWARD of a store applied to the row this (reverse) aggregation just summed (cb_spmm_csr_store_bwd_f32): g = scale * acc goes to
+                          // out_act (the raw gradient w.r.t. the stored activation: the input stage's mix operand), and
+                          // out_next = bwd_rowscale[row] * c_act * keep(seed, row) * g where the mask word `bits` (READ here) has the element's bit set, else 0 —
+                          // cb_trunk_layer_bwd_f32's pass without its read of g
+  const float* bwd_rowscale;
   const int32_t* row_ids; // or null.  The CSR's rows are a SUBSET of the node rows (row r = node row_ids[r]; rows-only forward, trunk.py): mix_src, the mask
                           // words and the dropout mask are taken at the node row, out_act / out_next (and row_scale, rowptr) at the compact row
 };
@@ -176,6 +181,23 @@ struct FusedEpi {
 __device__ __forceinline__ void fused_store(const FusedEpi& fe, int64_t row, int c0, const float (&acc)[4], float scale,
                                             const float (&b)[4], const float (&rmix)[4], float (&x)[4], int64_t grow) {
   float a[4], m[4] = {1.f, 1.f, 1.f, 1.f};
+  if (fe.bwd) {
+    float g4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g4[i] = scale_add(acc[i], scale, b[i]);      // (b = 0: what the plain store writes)
+    if (fe.out_act) store_stream<4>(fe.out_act + row * fe.ld_act + c0, g4);
+    if (fe.thresh) keep4(fe.seed_dev ? fe.seed + *fe.seed_dev : fe.seed, ((fe.row0 + grow) * fe.d + c0) >> 2, fe.thresh, fe.keep_scale, m);
+    const unsigned long long* bw = fe.bits + (grow * (fe.d >> 8) + (c0 >> 8)) * 4;
+    const float rs = fe.bwd_rowscale ? fe.bwd_rowscale[grow] : 1.f;
+    const int lane = lane_id();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float gm = g4[i] * m[i];
+      x[i] = ((bw[i] >> lane) & 1ull) ? (fe.c_act * gm) * rs : 0.f;      // (cb_trunk_layer_bwd_f32's expressions, in its order)
+    }
+    store_stream<4>(fe.out_next + row * fe.ld_next + c0, x);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) a[i] = fmaxf(scale_add(acc[i], scale, b[i]), 0.f);
   if (fe.thresh) keep4(fe.seed_dev ? fe.seed + *fe.seed_dev : fe.seed, ((fe.row0 + grow) * fe.d + c0) >> 2, fe.thresh, fe.keep_scale, m);

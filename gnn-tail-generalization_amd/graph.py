@@ -195,6 +195,41 @@ class CSRGraph:
         builds, hits = getattr(self, '_support_builds', 0), getattr(self, '_support_hits', 0)
         return builds < 4 or hits >= 3 * builds
 
+    def spmm_store_bwd(self, h, row_scale, bits, bwd_rowscale, c_act, p, seed, row0):
+        """(g, gr) of cb_spmm_csr_store_bwd_f32 over this (forward-orientation) CSR: g = row_scale * sum of the gathered rows, gr = the backward of the
+        trunk's store applied to g (mask words `bits` of the written rows, dropout mask of `seed`, factor c_act, row factor bwd_rowscale) — the plain
+        aggregation followed by cb_trunk_layer_bwd_f32 without the pass's read of g.  h float32 [n_cols, d], d % 256 == 0."""
+        import ctypes
+        from . import ops
+        lib = _lib.load()
+        _lib.require_device(h, row_scale, bits, bwd_rowscale)
+        if h.dtype != torch.float32 or h.dim() != 2 or h.shape[0] != self.n_cols or h.shape[1] % 256:
+            raise ValueError(f'spmm_store_bwd: float32 [{self.n_cols}, d] rows with d % 256 == 0 expected, got {tuple(h.shape)} {h.dtype}')
+        if h.stride(1) != 1:
+            h = h.contiguous()
+        d = h.shape[1]
+        g = torch.empty((self.N, d), dtype=torch.float32, device=h.device)
+        gr = torch.empty((self.N, d), dtype=torch.float32, device=h.device)
+        plan = self._plan
+        col_k = self.flagged_cols(False, d * 4)
+        flags = int(col_k is not None and h.data_ptr() % 16 == 0 and h.stride(0) % 4 == 0)
+        wsb = lib.cb_spmm_workspace_bytes(plan.n_chunks, d)
+        ws = self._workspace(wsb)
+        prof = self.profile
+        if prof is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        with torch.cuda.device(h.device):
+            _lib.check(lib.cb_spmm_csr_store_bwd_f32(_lib.ptr(self.rowptr), _lib.ptr(col_k if flags else self.col), flags, self.N, self.E, _lib.ptr(h), h.stride(0), d,
+                                                     _lib.ptr(row_scale), _lib.ptr(bits), _lib.ptr(bwd_rowscale), float(c_act), float(p), ctypes.c_uint64(seed),
+                                                     ops.seed_dev_ptr(), int(row0), _lib.ptr(g), d, _lib.ptr(gr), d, self.hub_threshold, plan.n_hubs, plan.n_chunks,
+                                                     _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), wsb, _lib.stream_ptr()),
+                       'cb_spmm_csr_store_bwd_f32')
+        if prof is not None:
+            ev1.record()
+            prof.append(prof_rec(ev0, ev1, self, 'store_bwd', self.algorithmic_bytes(d, row_scale=row_scale is not None, bias=False), self.N * d * 4 + self.N * d // 8))
+        return g, gr
+
     def loss_rows_fwd(self, plan):
         """The forward orientation on the rows of S_0 of a plan (plan.fwd[0]), built now if the thresholds of _support_fwd had left it out: the rows-only
         forward of trunk.py evaluates the last layer on those rows whatever the break-even of the backward's source-side form says."""

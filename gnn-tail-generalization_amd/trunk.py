@@ -267,10 +267,12 @@ def _input_bwd(g, add, act, p, seed, row0):
     return out, colsum
 
 
-def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0, act_bits=None, mix_pos=None):
+def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0, act_bits=None, mix_pos=None, cs=None):
     """cb_trunk_input_bwd_multi_f32: (dropout_bwd(g) + c_mix * sum_l dropout_bwd_l(g_mix[l])) * (act > 0) and its column sums.
     act_bits: int64 [rows, d/256, 4] mask words of (act > 0), read instead of act.  mix_pos (list, entries None or int32 [rows]): where set,
-    g_mix[l] is a compact matrix of the rows with mix_pos[l] >= 0 (support rows of a row-sparse backward); its other rows are zero."""
+    g_mix[l] is a compact matrix of the rows with mix_pos[l] >= 0 (support rows of a row-sparse backward); its other rows are zero.
+    cs = (index into g_mix, mask words, factor): a third result — the column sums of factor * dropout_bwd(g_mix[index]) through those mask words, the bias
+    gradient of the store whose backward left the reverse aggregation's epilogue (cb_trunk_input_bwd_multi_cs_f32)."""
     lib = _lib.load()
     rows, d = g.shape
     out = torch.empty_like(g)
@@ -284,6 +286,14 @@ def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0, act_bits=No
     if mix_pos is not None and any(q is not None for q in mix_pos):
         pos = (ctypes.c_void_p * max(n, 1))(*[(q.data_ptr() if q is not None else None) for q in mix_pos])
     with torch.cuda.device(g.device):
+        if cs is not None:
+            colsum2 = torch.empty(d, dtype=torch.float32, device=g.device)
+            ws2 = torch.empty(max(wsb, 16), dtype=torch.uint8, device=g.device)
+            _lib.check(lib.cb_trunk_input_bwd_multi_cs_f32(_lib.ptr(g), ctypes.c_uint64(seed), n, ptrs, seeds, float(c_mix), _lib.ptr(None if act_bits is not None else act),
+                                                           _lib.ptr(out), rows, d, float(p), ops.seed_dev_ptr(), int(row0), _lib.ptr(colsum), _lib.ptr(ws), wsb,
+                                                           _lib.ptr(act_bits), pos, int(cs[0]), _lib.ptr(cs[1]), float(cs[2]), _lib.ptr(colsum2), _lib.ptr(ws2), wsb,
+                                                           _lib.stream_ptr()), 'cb_trunk_input_bwd_multi_cs_f32')
+            return out, colsum, colsum2
         _lib.check(lib.cb_trunk_input_bwd_multi_f32(_lib.ptr(g), ctypes.c_uint64(seed), n, ptrs, seeds, float(c_mix), _lib.ptr(None if act_bits is not None else act), _lib.ptr(out),
                                                     rows, d, float(p), ops.seed_dev_ptr(), int(row0), _lib.ptr(colsum), _lib.ptr(ws), wsb,
                                                     _lib.ptr(act_bits), pos, _lib.stream_ptr()), 'cb_trunk_input_bwd_multi_f32')
@@ -824,7 +834,17 @@ class _Backward:
         level[0].profile = getattr(self.graph, 'profile', None)
         if fwd_j is not None:
             fwd_j.profile = level[0].profile
-        g_new = level[0].spmm(gemm.mm_nn(gr, w.t().contiguous()), row_scale=dst.a if dst is not None else self.a)
+        t = gemm.mm_nn(gr, w.t().contiguous())
+        self._fused_store_bwd = None
+        if (dst is None and l > 0 and not self.residual and self.gather and os.environ.get('CB_SPMM_STORE_BWD', '1') != '0'
+                and hasattr(level[0], 'spmm_store_bwd') and t.shape[1] % 256 == 0):
+            # the level writes all rows: the store backward of the layer below (its dropout / mix / ReLU backward and row factor) leaves this reverse
+            # aggregation's own epilogue — the separate pass's read of g disappears; its bias gradient is taken by the input stage, which reads g anyway
+            g_new, gr_below = level[0].spmm_store_bwd(t, self.a, self.saved_bits[l - 1], self.bnorm, 1 - self.alpha, self.p, self.seed(l + 1), self.row0)
+            self._fused_store_bwd = (gr_below, l - 1)
+        else:
+            g_new = level[0].spmm(t, row_scale=dst.a if dst is not None else self.a)
+        del t
         if self.need_w(l):
             # (the aggregate the rows-only forward saved, else taken now)
             x_agg = (self.h_last if (self.rows_only and l == self.L - 1) else self.h_below if (self.h_below is not None and l == self.L - 2)
@@ -968,6 +988,10 @@ class _Backward:
                 gr, dbias = _layer_bwd_rows(g, dst.idx, self.saved_bits[l - 1], self.bnorm, p, self.seed(l + 1), self.row0, 1 - alpha, self.need_b(l - 1),
                                             out=_exchanged(graph, g.shape[0], g.shape[1]) if sharded else None,
                                             **self._second(l - 1, g_above, pos_above))
+            elif l > 0 and source_side and getattr(self, '_fused_store_bwd', None) is not None:
+                g, (gr, _below), dbias = g_new, self._fused_store_bwd, None      # (dbias of layer l - 1: the input stage's second column sum)
+                self._cs = (len(self.g_mix), self.saved_bits[l - 1], 1 - alpha, l - 1) if self.need_b(l - 1) else None
+                self._fused_store_bwd = None
             elif l > 0 and tb_next is not None:
                 g, (gr, dbias) = g_new, tb_next
             elif l > 0:      # dL/d(dropped X_l) and the backward of layer l-1's store
@@ -985,8 +1009,12 @@ class _Backward:
             self.grads_layers[3 * deferred[0]] = self._dw_rows(*deferred)
         # input stage: X0 feeds layer 0 (through its dropout) and the mixes
         if gather:
-            gpre, d_b_in = _input_bwd_multi(g, self.seed(1), self.g_mix, self.seeds_mix, alpha, self.x0, p, self.row0, act_bits=self.x0_bits,
-                                            mix_pos=self.mix_pos)
+            cs = getattr(self, '_cs', None)
+            res = _input_bwd_multi(g, self.seed(1), self.g_mix, self.seeds_mix, alpha, self.x0, p, self.row0, act_bits=self.x0_bits,
+                                   mix_pos=self.mix_pos, cs=cs[:3] if cs is not None else None)
+            gpre, d_b_in = res[0], res[1]
+            if cs is not None:
+                self.grads_layers[3 * cs[3] + 1] = res[2]
         else:
             gpre, d_b_in = _input_bwd(g, self.gx0, self.x0, p, self.seed(1), self.row0)
         del g

@@ -560,3 +560,32 @@ def test_gemm_with_the_trunk_store_on_a_subset_of_rows_equals_the_two_kernels(M,
     assert torch.equal(fused[0], out_t) and torch.equal(bits_f, bits_t)
     assert (fused[1] is None) == (not want_act) and (not want_act or torch.equal(fused[1], act_t))
     assert int((bits_f[idx] != 0).sum()) > 0
+
+
+@pytest.mark.parametrize('p', [0.0, 0.2])
+def test_reverse_aggregation_with_the_store_backward_in_its_epilogue(p):
+    """cb_spmm_csr_store_bwd_f32 (+ the second column sum of cb_trunk_input_bwd_multi_cs_f32) against cb_spmm_csr_f32 followed by cb_trunk_layer_bwd_f32:
+    the raw gradient, the masked / scaled gradient and the bias gradient, bit for bit — on a power-law graph with hub rows."""
+    from gnn_tail_generalization_amd import trunk
+    from gnn_tail_generalization_amd.data import synthetic_data
+    from gnn_tail_generalization_amd.graph import CSRGraph
+    dev = 'cuda:0'
+    data = synthetic_data('S-pl1M', seed=0, device=dev, n_override=30_000)
+    G = CSRGraph(data.edge_index, data.x.shape[0])
+    assert G._plan.n_hubs > 0
+    n = G.N
+    gen = torch.Generator(device='cpu').manual_seed(7)
+    h = (torch.rand(n, 256, generator=gen) - 0.5).to(dev)
+    bits = torch.randint(-2 ** 62, 2 ** 62, (n, 1, 4), generator=gen, dtype=torch.int64).to(dev)
+    seed, row0, c_act = 991, 3, 0.9
+    g_ref = G.spmm(h, row_scale=G.norm_out)
+    gr_ref, db_ref = trunk._layer_bwd(g_ref, bits, G.norm_in, None, False, p, seed, row0, c_act, 0.1, True)
+    g, gr = G.spmm_store_bwd(h, G.norm_out, bits, G.norm_in, c_act, p, seed, row0)
+    assert torch.equal(g, g_ref) and torch.equal(gr, gr_ref)
+    # the bias gradient from the input stage's pass over g
+    main = (torch.rand(n, 256, generator=gen) - 0.5).to(dev)
+    x0_bits = torch.randint(-2 ** 62, 2 ** 62, (n, 1, 4), generator=gen, dtype=torch.int64).to(dev)
+    other = (torch.rand(n, 256, generator=gen) - 0.5).to(dev)
+    plain = trunk._input_bwd_multi(main, 5, [other, g], [17, seed], 0.1, None, p, row0, act_bits=x0_bits)
+    with_cs = trunk._input_bwd_multi(main, 5, [other, g], [17, seed], 0.1, None, p, row0, act_bits=x0_bits, cs=(1, bits, c_act))
+    assert torch.equal(with_cs[0], plain[0]) and torch.equal(with_cs[1], plain[1]) and torch.equal(with_cs[2], db_ref)
