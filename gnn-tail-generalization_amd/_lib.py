@@ -141,9 +141,9 @@ SIGNATURES = {
     'cb_trunk_input_bwd_multi_f32': (ctypes.c_int, [_P, ctypes.c_uint64, _I32, _P, _P, ctypes.c_float, _P, _P, _I64, _I64, ctypes.c_float,
                                                     _P, _I64, _P, _P, _SZ, _P, _P, _P]),
     'cb_trunk_input_bwd_multi_cs_f32': (ctypes.c_int, [_P, ctypes.c_uint64, _I32, _P, _P, ctypes.c_float, _P, _P, _I64, _I64, ctypes.c_float,
-                                                       _P, _I64, _P, _P, _SZ, _P, _P, _I32, _P, ctypes.c_float, _P, _P, _SZ, _P]),
+                                                       _P, _I64, _P, _P, _SZ, _P, _P, _I32, _P, _P, _P, _P, _P, _SZ, _P]),
     'cb_spmm_csr_store_bwd_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, _P, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _P, _I64,
-                                                 _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _SZ, _P]),
+                                                 _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _SZ, _P, _P]),
     'cb_trunk_layer_bwd_rows_f32': (ctypes.c_int, [_P, _P, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_uint64, _P, _I64, ctypes.c_float,
                                                    _P, ctypes.c_uint64, ctypes.c_float, _P, _P, _P, _SZ, _P]),
     'cb_id_count_i64': (ctypes.c_int, [_P, _I64, _I64, _P, _P, _P]),

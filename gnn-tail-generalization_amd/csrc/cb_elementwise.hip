@@ -287,11 +287,12 @@ struct MixTable {
   const int* pos[kMixMax];      // null, or [rows]: g[l] is a COMPACT matrix that holds only some rows (a row-sparse backward's support rows) — row r
                                 // sits at pos[l][r], absent (zero) where that is negative
   // second column sum (cs_partial non-null): sum over the rows of cs_c * dropout_bwd(g[cs_src]) where cs_bits has the element's bit — the bias gradient of
-  // the store whose backward left the reverse aggregation's own epilogue (cb_spmm_csr_store_bwd_f32); g[cs_src] is a dense operand
-  int cs_src;
-  const unsigned long long* cs_bits;
-  float cs_c;
-  float* cs_partial;
+  // the store whose backward left the reverse aggregation's own epilogue (cb_spmm_csr_store_bwd_f32)
+  // (up to two such sums per launch; a compact operand's mask words are still indexed by the node row)
+  int cs_src[2];
+  const unsigned long long* cs_bits[2];
+  float cs_c[2];
+  float* cs_partial[2];
 };
 
 template <int NMIX>   // number of mixed-in gradients, compile-time so that all row loads are issued before the first Philox round
@@ -309,7 +310,7 @@ __global__ void __launch_bounds__(kBlock) k_trunk_input_bwd_multi(const float* _
   const int64_t r_end = min(rows, r_begin + rows_per_block);
   for (int tile = 0; tile < tiles; ++tile) {
     const int c = tile * 256 + lane * 4;
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, s2[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     for (int64_t r = r_begin + w; r < r_end; r += kBlock / kWave) {
       const int64_t off = r * d + c;
       const int64_t quad = ((row0 + r) * d + c) >> 2;
@@ -346,10 +347,13 @@ __global__ void __launch_bounds__(kBlock) k_trunk_input_bwd_multi(const float* _
 #pragma unroll
           for (int k = 0; k < 4; ++k) u[l][k] *= m[k];
         }
-        if (mt.cs_partial && l == mt.cs_src) {      // (wave-uniform) this operand's masked gradient through the store's mask words
-          const unsigned long long* bw2 = mt.cs_bits + (r * tiles + tile) * 4;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) s2[k] += ((bw2[k] >> lane) & 1ull) ? mt.cs_c * u[l][k] : 0.f;
+        for (int q = 0; q < 2; ++q) {
+          if (mt.cs_partial[q] && l == mt.cs_src[q]) {      // (wave-uniform) this operand's masked gradient through the store's mask words
+            const unsigned long long* bw2 = mt.cs_bits[q] + (r * tiles + tile) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s2[q][k] += ((bw2[k] >> lane) & 1ull) ? mt.cs_c[q] * u[l][k] : 0.f;
+          }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) t[k] += c_mix * u[l][k];
@@ -385,9 +389,11 @@ __global__ void __launch_bounds__(kBlock) k_trunk_input_bwd_multi(const float* _
       }
       __syncthreads();
     }
-    if (mt.cs_partial) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) s_red[(w * 64 + lane) * 4 + k] = s2[k];
+    for (int q = 0; q < 2; ++q) {
+      if (!mt.cs_partial[q]) continue;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s_red[(w * 64 + lane) * 4 + k] = s2[q][k];
       __syncthreads();
       if (w == 0) {
         float t[4] = {0.f, 0.f, 0.f, 0.f};
@@ -395,7 +401,7 @@ __global__ void __launch_bounds__(kBlock) k_trunk_input_bwd_multi(const float* _
 #pragma unroll
           for (int k = 0; k < 4; ++k) t[k] += s_red[(j * 64 + lane) * 4 + k];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) mt.cs_partial[(int64_t)blockIdx.x * d + c + k] = t[k];
+        for (int k = 0; k < 4; ++k) mt.cs_partial[q][(int64_t)blockIdx.x * d + c + k] = t[k];
       }
       __syncthreads();
     }
@@ -1041,8 +1047,8 @@ extern "C" int cb_trunk_input_bwd_f32(const float* g, const float* add, const fl
 static int trunk_input_bwd_multi_impl(const float* g, uint64_t seed, int32_t n_mix, const float* const* g_mix, const uint64_t* seeds_mix,
                                       float c_mix, const float* act, float* out, int64_t rows, int64_t d, float drop_p,
                                       const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes,
-                                      const uint64_t* act_bits, const int32_t* const* g_mix_pos, void* stream, int32_t cs_src, const uint64_t* cs_bits,
-                                      float cs_c, float* colsum2, void* ws2, size_t ws2_bytes) {
+                                      const uint64_t* act_bits, const int32_t* const* g_mix_pos, void* stream, int32_t n_cs, const int32_t* cs_src,
+                                      const uint64_t* const* cs_bits, const float* cs_c, float* const* colsum2, void* ws2, size_t ws2_bytes) {
   CB_CHECK_ARG(rows >= 0 && d > 0 && d % 256 == 0 && d < (1 << 20), CB_E_INVALID, "cb_trunk_input_bwd_multi_f32: d must be a multiple of 256");
   CB_CHECK_ARG(n_mix >= 0 && n_mix <= kMixMax && (n_mix == 0 || (g_mix && seeds_mix)), CB_E_INVALID,
                "cb_trunk_input_bwd_multi_f32: 0..%d mixed-in gradients", kMixMax);
@@ -1054,11 +1060,13 @@ static int trunk_input_bwd_multi_impl(const float* g, uint64_t seed, int32_t n_m
   MixTable mt{};
   mt.n = n_mix;
   for (int i = 0; i < n_mix; ++i) mt.pos[i] = g_mix_pos ? g_mix_pos[i] : nullptr;
-  if (colsum2) {
-    CB_CHECK_ARG(cs_src >= 0 && cs_src < n_mix && cs_bits && (uintptr_t)cs_bits % 8 == 0 && !mt.pos[cs_src], CB_E_INVALID,
-                 "cb_trunk_input_bwd_multi_cs_f32: the second column sum needs a dense mixed-in operand and its mask words");
-    CB_CHECK_ARG(ws2 && ws2_bytes >= cb_colsum_workspace_bytes(rows, d), CB_E_WORKSPACE, "cb_trunk_input_bwd_multi_cs_f32: second workspace too small");
-    mt.cs_src = cs_src; mt.cs_bits = (const unsigned long long*)cs_bits; mt.cs_c = cs_c; mt.cs_partial = (float*)ws2;
+  CB_CHECK_ARG(n_cs >= 0 && n_cs <= 2 && (n_cs == 0 || (cs_src && cs_bits && cs_c && colsum2)), CB_E_INVALID, "cb_trunk_input_bwd_multi_cs_f32: 0..2 extra column sums");
+  const size_t plane = cb_colsum_workspace_bytes(rows, d);
+  CB_CHECK_ARG(n_cs == 0 || (ws2 && ws2_bytes >= (size_t)n_cs * plane), CB_E_WORKSPACE, "cb_trunk_input_bwd_multi_cs_f32: second workspace too small");
+  for (int q = 0; q < n_cs; ++q) {
+    CB_CHECK_ARG(cs_src[q] >= 0 && cs_src[q] < n_mix && cs_bits[q] && (uintptr_t)cs_bits[q] % 8 == 0 && colsum2[q], CB_E_INVALID,
+                 "cb_trunk_input_bwd_multi_cs_f32: extra column sum %d needs an operand index, its mask words and a result vector", q);
+    mt.cs_src[q] = cs_src[q]; mt.cs_bits[q] = (const unsigned long long*)cs_bits[q]; mt.cs_c[q] = cs_c[q]; mt.cs_partial[q] = (float*)((char*)ws2 + (size_t)q * plane);
   }
   for (int i = 0; i < n_mix; ++i) {
     CB_CHECK_ARG(g_mix[i] && aligned16(g_mix[i]), CB_E_INVALID, "cb_trunk_input_bwd_multi_f32: null or misaligned mixed-in gradient %d", i);
@@ -1088,8 +1096,8 @@ static int trunk_input_bwd_multi_impl(const float* g, uint64_t seed, int32_t n_m
     hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)d), dim3(kBlock), 0, st, (const float*)ws, (int)nb, (int)d, colsum);
     CB_LAUNCH_CHECK();
   }
-  if (colsum2) {
-    hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)d), dim3(kBlock), 0, st, (const float*)ws2, (int)nb, (int)d, colsum2);
+  for (int q = 0; q < n_cs; ++q) {
+    hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)d), dim3(kBlock), 0, st, (const float*)mt.cs_partial[q], (int)nb, (int)d, colsum2[q]);
     CB_LAUNCH_CHECK();
   }
   return CB_OK;
@@ -1100,19 +1108,21 @@ extern "C" int cb_trunk_input_bwd_multi_f32(const float* g, uint64_t seed, int32
                                             const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes,
                                             const uint64_t* act_bits, const int32_t* const* g_mix_pos, void* stream) {
   return trunk_input_bwd_multi_impl(g, seed, n_mix, g_mix, seeds_mix, c_mix, act, out, rows, d, drop_p, seed_dev, row0, colsum, ws, ws_bytes, act_bits, g_mix_pos,
-                                    stream, -1, nullptr, 0.f, nullptr, nullptr, 0);
+                                    stream, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
 }
 
-// The same, which also returns colsum2 = the column sums of cs_c * dropout_bwd_{seeds_mix[cs_src]}(g_mix[cs_src]) through the mask words cs_bits: the bias
-// gradient of the store whose backward was applied by cb_spmm_csr_store_bwd_f32 (same partial-sum order as cb_trunk_layer_bwd_f32's: bit-identical).
+// The same, which also returns n_cs (<= 2) extra column sums: colsum2[q] = the column sums of cs_c[q] * dropout_bwd_{seeds_mix[cs_src[q]]}(g_mix[cs_src[q]])
+// through the mask words cs_bits[q] (indexed by the node row, also for a compact operand) — the bias gradients of the stores whose backward was applied by
+// cb_spmm_csr_store_bwd_f32.  Dense operand: the partial-sum order of cb_trunk_layer_bwd_f32's column sums (bit-identical).  ws2: n_cs planes of
+// cb_colsum_workspace_bytes(rows, d).
 extern "C" int cb_trunk_input_bwd_multi_cs_f32(const float* g, uint64_t seed, int32_t n_mix, const float* const* g_mix, const uint64_t* seeds_mix,
                                                float c_mix, const float* act, float* out, int64_t rows, int64_t d, float drop_p,
                                                const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes,
-                                               const uint64_t* act_bits, const int32_t* const* g_mix_pos, int32_t cs_src, const uint64_t* cs_bits, float cs_c,
-                                               float* colsum2, void* ws2, size_t ws2_bytes, void* stream) {
-  CB_CHECK_ARG(colsum2 != nullptr, CB_E_INVALID, "cb_trunk_input_bwd_multi_cs_f32: colsum2 is null");
+                                               const uint64_t* act_bits, const int32_t* const* g_mix_pos, int32_t n_cs, const int32_t* cs_src,
+                                               const uint64_t* const* cs_bits, const float* cs_c, float* const* colsum2, void* ws2, size_t ws2_bytes,
+                                               void* stream) {
   return trunk_input_bwd_multi_impl(g, seed, n_mix, g_mix, seeds_mix, c_mix, act, out, rows, d, drop_p, seed_dev, row0, colsum, ws, ws_bytes, act_bits, g_mix_pos,
-                                    stream, cs_src, cs_bits, cs_c, colsum2, ws2, ws2_bytes);
+                                    stream, n_cs, cs_src, cs_bits, cs_c, colsum2, ws2, ws2_bytes);
 }
 
 extern "C" int cb_gather_rows_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, float* out,

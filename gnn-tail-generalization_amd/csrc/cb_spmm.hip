@@ -301,12 +301,13 @@ extern "C" int cb_spmm_csr_fused_rows_f32(const int32_t* row_ids, const int32_t*
 //   g = row_scale * sum  -> out_g (the gradient w.r.t. the stored, dropped activation: kept for the input stage's mix gather)
 //   out_gr = bwd_rowscale * c_act * dropout_bwd_seed(g) where relu_bits (READ: written by the forward's store) has the element's bit, else 0
 // = cb_spmm_csr_f32 followed by cb_trunk_layer_bwd_f32 without the pass's read of g (bit-identical values); the bias gradient of that pass (column sums of
-// the masked gradient) is taken by cb_trunk_input_bwd_multi_cs_f32, which reads g anyway.  d % 256 == 0, fp32 rows.
+// the masked gradient) is taken by cb_trunk_input_bwd_multi_cs_f32, which reads g anyway.  d % 256 == 0, fp32 rows.  row_ids (may be null): the CSR's rows are a
+// subset of the node rows (a compact level: row r = node row_ids[r]) — mask words, dropout mask and bwd_rowscale at the node row, row_scale / out_g / out_gr compact.
 extern "C" int cb_spmm_csr_store_bwd_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h,
                                          int64_t d, const float* row_scale, const uint64_t* relu_bits, const float* bwd_rowscale, float c_act, float drop_p,
                                          uint64_t seed, const uint64_t* seed_dev, int64_t row0, float* out_g, int64_t ld_g, float* out_gr, int64_t ld_gr,
                                          int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,
-                                         size_t ws_bytes, void* stream) {
+                                         size_t ws_bytes, const int32_t* row_ids, void* stream) {
   CB_CHECK_ARG(N >= 0 && E >= 0 && d > 0 && d % 256 == 0, CB_E_INVALID, "cb_spmm_csr_store_bwd_f32: d must be a positive multiple of 256");
   CB_CHECK_ARG(N < INT32_MAX && E < INT32_MAX && d < (1 << 20), CB_E_RANGE, "cb_spmm_csr_store_bwd_f32: size exceeds the int32 contract");
   if (N == 0) return CB_OK;
@@ -325,7 +326,7 @@ extern "C" int cb_spmm_csr_store_bwd_f32(const int32_t* rowptr, const int32_t* c
   fe.thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
   fe.keep_scale = 1.f / (1.f - drop_p);
   fe.seed = seed; fe.seed_dev = seed_dev; fe.row0 = row0; fe.bits = (unsigned long long*)relu_bits;
-  fe.out_act = out_g; fe.ld_act = ld_g; fe.out_next = out_gr; fe.ld_next = ld_gr; fe.d = (int)d;
+  fe.out_act = out_g; fe.ld_act = ld_g; fe.out_next = out_gr; fe.ld_next = ld_gr; fe.d = (int)d; fe.row_ids = row_ids;
   return launch_spmm<4, true, float>(rowptr, col, N, h, ld_h, d, ep, out_gr, ld_gr, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr, (float*)ws,
                                      (hipStream_t)stream, fe);
 }

@@ -195,10 +195,11 @@ class CSRGraph:
         builds, hits = getattr(self, '_support_builds', 0), getattr(self, '_support_hits', 0)
         return builds < 4 or hits >= 3 * builds
 
-    def spmm_store_bwd(self, h, row_scale, bits, bwd_rowscale, c_act, p, seed, row0):
+    def spmm_store_bwd(self, h, row_scale, bits, bwd_rowscale, c_act, p, seed, row0, row_ids=None):
         """(g, gr) of cb_spmm_csr_store_bwd_f32 over this (forward-orientation) CSR: g = row_scale * sum of the gathered rows, gr = the backward of the
         trunk's store applied to g (mask words `bits` of the written rows, dropout mask of `seed`, factor c_act, row factor bwd_rowscale) — the plain
-        aggregation followed by cb_trunk_layer_bwd_f32 without the pass's read of g.  h float32 [n_cols, d], d % 256 == 0."""
+        aggregation followed by cb_trunk_layer_bwd_f32 without the pass's read of g.  h float32 [n_cols, d], d % 256 == 0.  row_ids (int32 [N]): this CSR's rows
+        are a subset of the node rows (a compact level) — bits / bwd_rowscale / the dropout mask at the node row, row_scale and the results compact."""
         import ctypes
         from . import ops
         lib = _lib.load()
@@ -223,7 +224,7 @@ class CSRGraph:
             _lib.check(lib.cb_spmm_csr_store_bwd_f32(_lib.ptr(self.rowptr), _lib.ptr(col_k if flags else self.col), flags, self.N, self.E, _lib.ptr(h), h.stride(0), d,
                                                      _lib.ptr(row_scale), _lib.ptr(bits), _lib.ptr(bwd_rowscale), float(c_act), float(p), ctypes.c_uint64(seed),
                                                      ops.seed_dev_ptr(), int(row0), _lib.ptr(g), d, _lib.ptr(gr), d, self.hub_threshold, plan.n_hubs, plan.n_chunks,
-                                                     _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), wsb, _lib.stream_ptr()),
+                                                     _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), wsb, _lib.ptr(row_ids), _lib.stream_ptr()),
                        'cb_spmm_csr_store_bwd_f32')
         if prof is not None:
             ev1.record()

@@ -271,8 +271,8 @@ def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0, act_bits=No
     """cb_trunk_input_bwd_multi_f32: (dropout_bwd(g) + c_mix * sum_l dropout_bwd_l(g_mix[l])) * (act > 0) and its column sums.
     act_bits: int64 [rows, d/256, 4] mask words of (act > 0), read instead of act.  mix_pos (list, entries None or int32 [rows]): where set,
     g_mix[l] is a compact matrix of the rows with mix_pos[l] >= 0 (support rows of a row-sparse backward); its other rows are zero.
-    cs = (index into g_mix, mask words, factor): a third result — the column sums of factor * dropout_bwd(g_mix[index]) through those mask words, the bias
-    gradient of the store whose backward left the reverse aggregation's epilogue (cb_trunk_input_bwd_multi_cs_f32)."""
+    cs = list of up to two (index into g_mix, mask words, factor): a third result — per entry the column sums of factor * dropout_bwd(g_mix[index]) through
+    those mask words, the bias gradient of a store whose backward left the reverse aggregation's epilogue (cb_trunk_input_bwd_multi_cs_f32)."""
     lib = _lib.load()
     rows, d = g.shape
     out = torch.empty_like(g)
@@ -286,13 +286,16 @@ def _input_bwd_multi(g, seed, g_mix, seeds_mix, c_mix, act, p, row0, act_bits=No
     if mix_pos is not None and any(q is not None for q in mix_pos):
         pos = (ctypes.c_void_p * max(n, 1))(*[(q.data_ptr() if q is not None else None) for q in mix_pos])
     with torch.cuda.device(g.device):
-        if cs is not None:
-            colsum2 = torch.empty(d, dtype=torch.float32, device=g.device)
-            ws2 = torch.empty(max(wsb, 16), dtype=torch.uint8, device=g.device)
+        if cs:
+            k = len(cs)
+            colsum2 = [torch.empty(d, dtype=torch.float32, device=g.device) for _ in range(k)]
+            ws2 = torch.empty(max(k * wsb, 16), dtype=torch.uint8, device=g.device)
             _lib.check(lib.cb_trunk_input_bwd_multi_cs_f32(_lib.ptr(g), ctypes.c_uint64(seed), n, ptrs, seeds, float(c_mix), _lib.ptr(None if act_bits is not None else act),
                                                            _lib.ptr(out), rows, d, float(p), ops.seed_dev_ptr(), int(row0), _lib.ptr(colsum), _lib.ptr(ws), wsb,
-                                                           _lib.ptr(act_bits), pos, int(cs[0]), _lib.ptr(cs[1]), float(cs[2]), _lib.ptr(colsum2), _lib.ptr(ws2), wsb,
-                                                           _lib.stream_ptr()), 'cb_trunk_input_bwd_multi_cs_f32')
+                                                           _lib.ptr(act_bits), pos, k, (ctypes.c_int32 * k)(*[int(c[0]) for c in cs]),
+                                                           (ctypes.c_void_p * k)(*[c[1].data_ptr() for c in cs]), (ctypes.c_float * k)(*[float(c[2]) for c in cs]),
+                                                           (ctypes.c_void_p * k)(*[t.data_ptr() for t in colsum2]), _lib.ptr(ws2), k * wsb, _lib.stream_ptr()),
+                       'cb_trunk_input_bwd_multi_cs_f32')
             return out, colsum, colsum2
         _lib.check(lib.cb_trunk_input_bwd_multi_f32(_lib.ptr(g), ctypes.c_uint64(seed), n, ptrs, seeds, float(c_mix), _lib.ptr(None if act_bits is not None else act), _lib.ptr(out),
                                                     rows, d, float(p), ops.seed_dev_ptr(), int(row0), _lib.ptr(colsum), _lib.ptr(ws), wsb,
@@ -836,11 +839,20 @@ class _Backward:
             fwd_j.profile = level[0].profile
         t = gemm.mm_nn(gr, w.t().contiguous())
         self._fused_store_bwd = None
-        if (dst is None and l > 0 and not self.residual and self.gather and os.environ.get('CB_SPMM_STORE_BWD', '1') != '0'
+        # 0: never; 1 (default): levels that write all rows; 2: compact levels too (measured equal on S-pl10M: 119.2 - 119.4 ms per step either way)
+        mode = os.environ.get('CB_SPMM_STORE_BWD', '1')
+        if (l > 0 and not self.residual and self.gather and len(getattr(self, '_cs', [])) < 2 and (mode == '2' or (mode == '1' and dst is None))
                 and hasattr(level[0], 'spmm_store_bwd') and t.shape[1] % 256 == 0):
-            # the level writes all rows: the store backward of the layer below (its dropout / mix / ReLU backward and row factor) leaves this reverse
-            # aggregation's own epilogue — the separate pass's read of g disappears; its bias gradient is taken by the input stage, which reads g anyway
-            g_new, gr_below = level[0].spmm_store_bwd(t, self.a, self.saved_bits[l - 1], self.bnorm, 1 - self.alpha, self.p, self.seed(l + 1), self.row0)
+            # the store backward of the layer below (its dropout / mix / ReLU backward and row factor) leaves this reverse aggregation's own epilogue —
+            # the separate pass's read of g disappears; its bias gradient is taken by the input stage, which reads g anyway.  A compact destination:
+            # mask words, row factor and dropout mask at the node rows dst.idx
+            ids = None
+            if dst is not None:
+                ids = getattr(dst, '_ids32', None)
+                if ids is None:
+                    ids = dst._ids32 = dst.idx.to(torch.int32).contiguous()
+            g_new, gr_below = level[0].spmm_store_bwd(t, dst.a if dst is not None else self.a, self.saved_bits[l - 1], self.bnorm, 1 - self.alpha, self.p,
+                                                      self.seed(l + 1), self.row0, row_ids=ids)
             self._fused_store_bwd = (gr_below, l - 1)
         else:
             g_new = level[0].spmm(t, row_scale=dst.a if dst is not None else self.a)
@@ -983,15 +995,16 @@ class _Backward:
             handle = None
             self.grads_layers[3 * l + 1] = dbias
             space = dst
-            if l > 0 and dst is not None:      # the store backward of layer l-1 on the rows of S_{j+1}
+            if l > 0 and source_side and getattr(self, '_fused_store_bwd', None) is not None:
+                g, (gr, _below), dbias = g_new, self._fused_store_bwd, None      # (dbias of layer l - 1: an extra column sum of the input stage)
+                if self.need_b(l - 1):
+                    self._cs = getattr(self, '_cs', []) + [(len(self.g_mix), self.saved_bits[l - 1], 1 - alpha, l - 1)]
+                self._fused_store_bwd = None
+            elif l > 0 and dst is not None:      # the store backward of layer l-1 on the rows of S_{j+1}
                 g = g_new
                 gr, dbias = _layer_bwd_rows(g, dst.idx, self.saved_bits[l - 1], self.bnorm, p, self.seed(l + 1), self.row0, 1 - alpha, self.need_b(l - 1),
                                             out=_exchanged(graph, g.shape[0], g.shape[1]) if sharded else None,
                                             **self._second(l - 1, g_above, pos_above))
-            elif l > 0 and source_side and getattr(self, '_fused_store_bwd', None) is not None:
-                g, (gr, _below), dbias = g_new, self._fused_store_bwd, None      # (dbias of layer l - 1: the input stage's second column sum)
-                self._cs = (len(self.g_mix), self.saved_bits[l - 1], 1 - alpha, l - 1) if self.need_b(l - 1) else None
-                self._fused_store_bwd = None
             elif l > 0 and tb_next is not None:
                 g, (gr, dbias) = g_new, tb_next
             elif l > 0:      # dL/d(dropped X_l) and the backward of layer l-1's store
@@ -1009,12 +1022,12 @@ class _Backward:
             self.grads_layers[3 * deferred[0]] = self._dw_rows(*deferred)
         # input stage: X0 feeds layer 0 (through its dropout) and the mixes
         if gather:
-            cs = getattr(self, '_cs', None)
+            cs = getattr(self, '_cs', [])
             res = _input_bwd_multi(g, self.seed(1), self.g_mix, self.seeds_mix, alpha, self.x0, p, self.row0, act_bits=self.x0_bits,
-                                   mix_pos=self.mix_pos, cs=cs[:3] if cs is not None else None)
+                                   mix_pos=self.mix_pos, cs=[c[:3] for c in cs])
             gpre, d_b_in = res[0], res[1]
-            if cs is not None:
-                self.grads_layers[3 * cs[3] + 1] = res[2]
+            for c, db in zip(cs, res[2] if cs else []):
+                self.grads_layers[3 * c[3] + 1] = db
         else:
             gpre, d_b_in = _input_bwd(g, self.gx0, self.x0, p, self.seed(1), self.row0)
         del g

@@ -302,26 +302,28 @@ int cb_trunk_input_bwd_multi_f32(const float* g, uint64_t seed, int32_t n_mix, c
                                  float c_mix, const float* act, float* out, int64_t rows, int64_t d, float drop_p,
                                  const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes,
                                  const uint64_t* act_bits, const int32_t* const* g_mix_pos, void* stream);
-/* The same, which also returns colsum2 = the column sums of cs_c * dropout_bwd_{seeds_mix[cs_src]}(g_mix[cs_src]) where the mask words cs_bits
- * ([rows][d / 256][4]) have the element's bit: the bias gradient (GCN.py:253) of the layer whose store backward was applied by the reverse aggregation's own
- * epilogue (cb_spmm_csr_store_bwd_f32) — this pass reads that gradient anyway.  g_mix[cs_src] must be a dense operand.  Same partial-sum order as
- * cb_trunk_layer_bwd_f32's column sums (bit-identical). */
+/* The same, which also returns n_cs (<= 2) extra column sums (host arrays of n_cs entries): colsum2[q] = the column sums of cs_c[q] *
+ * dropout_bwd_{seeds_mix[cs_src[q]]}(g_mix[cs_src[q]]) where the mask words cs_bits[q] ([rows][d / 256][4], indexed by the node row also for a compact operand)
+ * have the element's bit: the bias gradients (GCN.py:253) of the layers whose store backward was applied by the reverse aggregation's own epilogue
+ * (cb_spmm_csr_store_bwd_f32) — this pass reads those gradients anyway.  ws2: n_cs planes of cb_colsum_workspace_bytes(rows, d).  A dense operand's sum
+ * has the partial-sum order of cb_trunk_layer_bwd_f32's (bit-identical). */
 int cb_trunk_input_bwd_multi_cs_f32(const float* g, uint64_t seed, int32_t n_mix, const float* const* g_mix, const uint64_t* seeds_mix,
                                     float c_mix, const float* act, float* out, int64_t rows, int64_t d, float drop_p,
                                     const uint64_t* seed_dev, int64_t row0, float* colsum, void* ws, size_t ws_bytes,
-                                    const uint64_t* act_bits, const int32_t* const* g_mix_pos, int32_t cs_src, const uint64_t* cs_bits, float cs_c,
-                                    float* colsum2, void* ws2, size_t ws2_bytes, void* stream);
+                                    const uint64_t* act_bits, const int32_t* const* g_mix_pos, int32_t n_cs, const int32_t* cs_src,
+                                    const uint64_t* const* cs_bits, const float* cs_c, float* const* colsum2, void* ws2, size_t ws2_bytes, void* stream);
 /* A (reverse) aggregation whose epilogue is the BACKWARD of the trunk's store of the rows it writes — autograd of GCN.py:127-133 applied to the output of
  * the autograd of GCN.py:238 in one kernel:
  *   g = row_scale * sum_{u in row v} h[u]              -> out_g (may be NULL): dL/d(stored, dropped activation), the input stage's mix operand
  *   out_gr = bwd_rowscale[v] * c_act * dropout_bwd_seed(g) where relu_bits (READ: the forward store's mask words) has the element's bit, else 0
  * = cb_spmm_csr_f32 followed by cb_trunk_layer_bwd_f32 (gx0 = NULL, no second gradient) without that pass's read of g; values bit-identical.  The
- * pass's column sums (the bias gradient) come from cb_trunk_input_bwd_multi_cs_f32.  d % 256 == 0, fp32 rows, 16-byte aligned. */
+ * pass's column sums (the bias gradient) come from cb_trunk_input_bwd_multi_cs_f32.  d % 256 == 0, fp32 rows, 16-byte aligned.  row_ids (may be NULL): the
+ * CSR's rows are a subset of the node rows (row r = node row_ids[r]): relu_bits, the dropout mask and bwd_rowscale are taken at the node row. */
 int cb_spmm_csr_store_bwd_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h,
                               int64_t d, const float* row_scale, const uint64_t* relu_bits, const float* bwd_rowscale, float c_act, float drop_p,
                               uint64_t seed, const uint64_t* seed_dev, int64_t row0, float* out_g, int64_t ld_g, float* out_gr, int64_t ld_gr,
                               int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,
-                              size_t ws_bytes, void* stream);
+                              size_t ws_bytes, const int32_t* row_ids, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * bf16-storage variant of the aggregation (build extension = BASELINE config 2; the reference is fp32-only):

@@ -587,5 +587,5 @@ def test_reverse_aggregation_with_the_store_backward_in_its_epilogue(p):
     x0_bits = torch.randint(-2 ** 62, 2 ** 62, (n, 1, 4), generator=gen, dtype=torch.int64).to(dev)
     other = (torch.rand(n, 256, generator=gen) - 0.5).to(dev)
     plain = trunk._input_bwd_multi(main, 5, [other, g], [17, seed], 0.1, None, p, row0, act_bits=x0_bits)
-    with_cs = trunk._input_bwd_multi(main, 5, [other, g], [17, seed], 0.1, None, p, row0, act_bits=x0_bits, cs=(1, bits, c_act))
-    assert torch.equal(with_cs[0], plain[0]) and torch.equal(with_cs[1], plain[1]) and torch.equal(with_cs[2], db_ref)
+    with_cs = trunk._input_bwd_multi(main, 5, [other, g], [17, seed], 0.1, None, p, row0, act_bits=x0_bits, cs=[(1, bits, c_act)])
+    assert torch.equal(with_cs[0], plain[0]) and torch.equal(with_cs[1], plain[1]) and torch.equal(with_cs[2][0], db_ref)

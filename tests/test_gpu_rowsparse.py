@@ -156,6 +156,7 @@ def test_rows_only_forward_equals_the_dense_step(conn, se, layers, n_loss_rows, 
     real_rows = trunk._layer_on_rows
     monkeypatch.setattr(trunk, '_layer_on_rows', lambda *a, **k: (on_rows.append(1), real_rows(*a, **k))[1])
     monkeypatch.setenv('CB_ROWS_ONLY_BELOW', below)
+    monkeypatch.setenv('CB_SPMM_STORE_BWD', '2' if n_loss_rows is None else '1')      # (2: the store backward also in the epilogue of compact levels)
     monkeypatch.setattr(tuning.T, 'sum_first_below_min_edges', 0)      # (S-pl1M sits below the break-even of the form)
     sum_first_below = below == '2' and layers >= 3 and se[1] == '0'      # (the residual trunks' GCNConvs all take the middle flag of whetherHasSE, GCN.py:58-60)
     extra = () if conn == 'Initial' else ('--force_set_to_best_config=0', '--type_trick=Residual')
