@@ -399,7 +399,7 @@ def _rows_only_decision(graph, cfg, x, x0, h, ag, bwd, layer_params):
     if not (rows_only and bwd and loss_rows is not None and L >= 2 and (ag or bf16_last_only) and rows_only_enabled()):
         return none
     if sharded:
-        if not (le_last is None and hasattr(graph, 'loss_rows_forward') and ops.loss_rows_enabled() and loss_rows[0].shape[0] == x.shape[0]):
+        if not (hasattr(graph, 'loss_rows_forward') and ops.loss_rows_enabled() and loss_rows[0].shape[0] == x.shape[0]):
             return none
         gather, tail_tb = _gather_and_tail(graph, L, residual, h, x0)
         levels = graph.support_levels(loss_rows[0], L, compact=ag and gather and not tail_tb, cumulative=residual)
@@ -482,7 +482,7 @@ def _last_layer_on_loss_rows(graph, plan, cur, w, b, mix, alpha, p, seed, row0, 
     return bits, x_l, out, h_agg
 
 
-def _last_layer_on_loss_rows_sharded(graph, s0, orient, cur, w, b, mix, alpha, p, seed, row0, residual, w_out, b_out):
+def _last_layer_on_loss_rows_sharded(graph, s0, orient, cur, w, b, mix, alpha, p, seed, row0, residual, w_out, b_out, le=None):
     """_last_layer_on_loss_rows on a rank's row block: the aggregation of a * X over the edges that enter the rank's loss rows is a level orientation
     of the forward exchange (dist.ShardedGraph.loss_rows_forward: the peers ship only the in-neighbours of those rows).  Returns (mask words, dropped
     X_L on the rank's loss rows, logits [n_local, C] with zeros elsewhere)."""
@@ -496,8 +496,10 @@ def _last_layer_on_loss_rows_sharded(graph, s0, orient, cur, w, b, mix, alpha, p
     b0 = getattr(s0, '_norm_in', None)
     if b0 is None:
         b0 = s0._norm_in = graph.norm_in[s0.idx].contiguous()
-    y = gemm.mm_nn(h_agg, w, rowscale=b0, bias=b)
-    del h_agg
+    # (a structural-embedding table on the layer: its rows are summed over the same level orientation — a second, equally small exchange)
+    le_sum = graph.aggregate_finish(graph.aggregate_start(le, False, orient=orient), False, row_scale=b0) if le is not None else None
+    y = gemm.mm_nn(h_agg, w, rowscale=b0, addend=le_sum, bias=b)
+    del h_agg, le_sum
     n, d = graph.N, w.shape[1]
     bits = torch.empty((n, d // 256, 4), dtype=torch.int64, device=cur.device)
     x_l, _act = _store_rows(y, s0.idx, mix, 1 - alpha, alpha, p, seed, row0, bits, residual)
@@ -601,7 +603,7 @@ class _TrunkFn(torch.autograd.Function):
                 saved_in[L - 2] = None        # X_{L-2}: read by the aggregation above only
                 z = None
             elif ag and ro_sh is not None and l == L - 1:
-                bits, cur, out_head = _last_layer_on_loss_rows_sharded(graph, ro_sh[0], ro_sh[1], cur, w, b, mix, alpha, p, sd_l, row0, residual, w_out, b_out)
+                bits, cur, out_head = _last_layer_on_loss_rows_sharded(graph, ro_sh[0], ro_sh[1], cur, w, b, mix, alpha, p, sd_l, row0, residual, w_out, b_out, le=le)
                 z = None
             elif ro_plan is not None and l == L - 1:
                 bits, cur, out_head, h_last = _last_layer_on_loss_rows(graph, ro_plan, cur, w, b, mix, alpha, p, sd_l, row0, residual, w_out, b_out, below=ro_below,

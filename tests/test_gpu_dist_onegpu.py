@@ -97,8 +97,8 @@ def _worker(rank, world, port, exchange, overlap, partition, argv, q, wire='f32'
             if lv0.src is not None:
                 assert 0 < lv0.src.n < t.part.n_local
                 # ... and the training forward evaluated its last layer on the rank's loss rows (rows-only forward: the last exchange ships only the
-                # in-neighbours of those rows) unless that layer carries a structural-embedding table
-                assert t.sgraph.rows_only_forwards == (0 if '--whetherHasSE=111' in argv else STEPS), t.sgraph.rows_only_forwards
+                # in-neighbours of those rows; a structural-embedding table on that layer travels the same way)
+                assert t.sgraph.rows_only_forwards == STEPS, t.sgraph.rows_only_forwards
         if overlap == '1' and exchange == 'halo' and wire == 'f32' and (argv is ARGV or argv is ARGV_I0 or '--whetherHasSE=111' in argv or '--type_trick=Residual' in argv):
             # round 5: the trunk allocates the matrices it exchanges with room behind them (dist.alloc_exchanged), so the interior pass and the first
             # halo slice ran as ONE pass ([local | slice 0], dist._Orientation.first) wherever a producer of the trunk wrote the matrix
