@@ -563,8 +563,8 @@ def main():
                 else:
                     os.environ[k] = v
     dense_bwd = all_rows_fwd = None
-    # (trunk._layer_on_rows leaves norm_in restricted to the loss rows on the plan's row space: the last layer ran on those rows)
-    rows_only_fwd = bool(row_sparse and getattr(graph_obj._support_plan.space0, '_norm_in', None) is not None)
+    # (the graph counts the training forwards that evaluated their last layer on the loss rows: trunk._last_layer_on_loss_rows, stack.py)
+    rows_only_fwd = bool(row_sparse and getattr(graph_obj, 'rows_only_forwards', 0) > 0)
     if a.dense_backward and row_sparse and not use_graph and os.environ.get('CB_LOSS_ROWS', '1') != '0':
         if rows_only_fwd and os.environ.get('CB_ROWS_ONLY_FWD', '1') != '0':
             all_rows_fwd = restarted_leg({'CB_ROWS_ONLY_FWD': '0'},

@@ -54,7 +54,8 @@ class TeacherGNN(nn.Module):
         promise is verified on the device every step (ops.check_rows_zero), a broken one raises and leaves the weights untouched.
         rows_only (extension, with loss_rows): the caller's second promise — it READS this forward's output (the return value, `self.out`) in the rows
         of the mask only.  A training forward of the fused trunk then evaluates its last layer and the output Linear on those rows; every other row
-        of the output is returned as zeros."""
+        of the output (and so of `self.out`, `res.commonEmb`, `res.emb4classi_full`) is returned as NaN (tuning.T.rows_only_poison): a reader that
+        breaks the promise — e.g. the reference's edge-wise loss, which takes res.commonEmb of the same forward (trainer…:417-418) — fails loudly."""
         self.out, self.se_reg_all = self.model(self._input(x), edge_index, loss_rows=loss_rows, rows_only=rows_only)
         return self.out
 

@@ -94,7 +94,7 @@ SIGNATURES = {
     'cb_adam_norm_workspace_bytes': (ctypes.c_size_t, [_I32]),
     'cb_adam_multi_norm_f32': (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                               ctypes.c_float, _I64, _P, _P, _P, _SZ, _P]),
-    'cb_expand_rows_f32': (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P]),
+    'cb_expand_rows_f32': (ctypes.c_int, [_P, _P, _I64, _I64, ctypes.c_float, _P, _P]),
     'cb_gemm_nn_store_rows_supported': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64]),
     'cb_gemm_nn_store_rows_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, _P, _P, _I64, _P, ctypes.c_float,
                                                  ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _P, _I64, _P, ctypes.c_int, _P, _I64, _P, _SZ, _P]),
@@ -188,13 +188,32 @@ def check(rc, what):
 
 
 _guards = {}      # device index -> int32 [1] device tensor (grad_guard)
+_guard_listeners = None      # weak set of optimisers whose step counts follow the guard (register_guard_listener)
+
+
+def register_guard_listener(opt):
+    """An optimiser that reads grad_guard in its launch: device_status() calls its roll_back_skipped() when it reports a failed gradient check,
+    so that the skipped launches do not count as steps (optim.Adam)."""
+    global _guard_listeners
+    if _guard_listeners is None:
+        import weakref
+        _guard_listeners = weakref.WeakSet()
+    _guard_listeners.add(opt)
+
+
+def _guard_failed():
+    for opt in list(_guard_listeners or ()):
+        opt.roll_back_skipped()
+    for g in _guards.values():      # the error is in the caller's hands now: the next step may update again
+        g.zero_()
 
 
 def grad_guard(device, create=True):
     """The device word a failed gradient check sets (cb_rows_zero_outside_mask_f32, `guard`) and the fused Adam reads
     (cb_adam_multi_norm_f32, `guard`): while it is non-zero the optimiser launch writes nothing, so the truncated gradients of a
     row-sparse backward whose claim did not hold never reach the parameters or the moments — without a host synchronisation between
-    backward() and step().  One word per device, allocated at the first check; cleared by device_status() when it reports the error."""
+    backward() and step().  One word per device, allocated at the first check; cleared by device_status() when it reports the error (the skipped launches are then
+    taken back off the optimiser's step counts too: register_guard_listener)."""
     idx = torch.device(device).index
     idx = torch.cuda.current_device() if idx is None else idx
     g = _guards.get(idx)
@@ -212,14 +231,13 @@ def device_status():
     rc = lib.cb_device_status()
     if rc != 0:
         msg = lib.cb_last_error()
-        for g in _guards.values():      # the error is in the caller's hands now: the next step may update again
-            g.zero_()
+        _guard_failed()
         raise HipExtensionError(f'device-side error (rc={rc}): {msg.decode() if msg else ""}')
     for g in _guards.values():
         # node-sharded: the guard word is all-reduced with the gradients (dist.allreduce_grads), so a check that failed on ANOTHER rank
         # shows here — every rank raises, none trains on alone
         if int(g.item()) != 0:
-            g.zero_()
+            _guard_failed()
             raise HipExtensionError('device-side error: the guard word of the gradient-row check is set but this process holds no error report '
                                     '(the check failed on another rank, or the report was taken through cb_device_status() directly); '
                                     'the optimiser step of that backward was skipped')

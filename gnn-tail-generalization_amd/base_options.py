@@ -136,6 +136,7 @@ def build_parser():
     a('--ckpt_every', type=int, default=0)   # build extension: write the resumable checkpoint every k epochs (0 = only at the end)
     a('--hip_graph', type=int, default=0)    # build extension: 1 = the epoch loop replays the training step (and the eval forward) as hipGraphs
     a('--agg_dtype', type=str, default='f32', choices=['f32', 'bf16'])   # build extension: storage type of the aggregated rows
+    a('--rows_only_forward', type=int, default=1)   # build extension: 1 = the trainer promises the model that its training forward's output is read in the train rows only (trunk.py "Rows-only forward"; the other rows come back as NaN); 0 = every row of every training forward
     # link-prediction (I2-GTL) flags: accepted for CLI compatibility, unused by this path
     a('--public_data_convert_overlapped_subgraph', type=bool, default=True)
     a('--transfer_setting', type=str, default='i2t', choices=['t2t', 'u2t', 'i2t', 'u', 'i', ''])

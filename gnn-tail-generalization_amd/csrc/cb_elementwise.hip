@@ -428,17 +428,18 @@ __global__ void __launch_bounds__(kBlock) k_gather_rows(const float* __restrict_
   }
 }
 
-// out[r, :] = pos[r] >= 0 ? src[pos[r], :] : 0 — the inverse of the row pack: a compact [n, d] matrix over a row subset written back to all
-// N rows in one pass (the table gradient dL/dZ_l of a compact level of the row-sparse backward, trunk.py).  float4 rows.
+// out[r, :] = pos[r] >= 0 ? src[pos[r], :] : fill — the inverse of the row pack: a compact [n, d] matrix over a row subset written back to all
+// N rows in one pass (fill = 0: the table gradient dL/dZ_l of a compact level of the row-sparse backward; fill = NaN: the logits of a rows-only
+// training forward, whose other rows nobody may read; trunk.py).  float4 rows.
 __global__ void __launch_bounds__(kBlock) k_expand_rows(const float* __restrict__ src, const int* __restrict__ pos, int64_t n_rows, int d,
-                                                        float* __restrict__ out) {
+                                                        float fill, float* __restrict__ out) {
   const int q = d >> 2;
   const int64_t total = n_rows * q;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / q;
     const int c = (int)(i - r * q) * 4;
     const int p = pos[r];
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v = make_float4(fill, fill, fill, fill);
     if (p >= 0) v = *reinterpret_cast<const float4*>(src + (int64_t)p * d + c);
     __builtin_nontemporal_store(v.x, out + r * d + c);
     __builtin_nontemporal_store(v.y, out + r * d + c + 1);
@@ -1200,12 +1201,12 @@ extern "C" int cb_trunk_store_rows_f32(const float* y, const int64_t* row_index,
   return CB_OK;
 }
 
-extern "C" int cb_expand_rows_f32(const float* src, const int32_t* pos, int64_t n_rows, int64_t d, float* out, void* stream) {
+extern "C" int cb_expand_rows_f32(const float* src, const int32_t* pos, int64_t n_rows, int64_t d, float fill, float* out, void* stream) {
   CB_CHECK_ARG(n_rows >= 0 && d >= 0 && d < (1 << 24), CB_E_INVALID, "cb_expand_rows_f32: bad size");
   if (n_rows == 0 || d == 0) return CB_OK;
   CB_CHECK_ARG(pos && out, CB_E_INVALID, "cb_expand_rows_f32: null pointer");
   CB_CHECK_ARG(d % 4 == 0 && aligned16(out) && (!src || aligned16(src)), CB_E_INVALID, "cb_expand_rows_f32: 16-byte aligned rows with d %% 4 == 0 expected");
-  hipLaunchKernelGGL(k_expand_rows, dim3(grid_for(n_rows * (d / 4))), dim3(kBlock), 0, (hipStream_t)stream, src, pos, n_rows, (int)d, out);
+  hipLaunchKernelGGL(k_expand_rows, dim3(grid_for(n_rows * (d / 4))), dim3(kBlock), 0, (hipStream_t)stream, src, pos, n_rows, (int)d, fill, out);
   CB_LAUNCH_CHECK();
   return CB_OK;
 }

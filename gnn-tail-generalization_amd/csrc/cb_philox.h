@@ -6,10 +6,13 @@
 
 namespace cb {
 
+#ifndef CB_PHILOX_ROUNDS
+#define CB_PHILOX_ROUNDS 10
+#endif
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
   uint32_t c2 = 0x243F6A88u, c3 = 0x85A308D3u;
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < CB_PHILOX_ROUNDS; ++r) {
     // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a v_mul_lo_u32 / v_mul_hi_u32 pair: integer multiplies are
     // quarter rate, and they are what bounds the elementwise kernels that draw several masks per element (the trunk's input stage)
     const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;

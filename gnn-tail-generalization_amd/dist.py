@@ -2,8 +2,8 @@
 `nccl` = RCCL over xGMI).  New relative to the reference, which is single-device.
 
 Partition: 1-D contiguous row blocks.  'edges' (default): boundaries from the prefix sum of
-in-degree + NODE_WEIGHT per node, so every rank gets the same share of the step's work (the aggregation
-is per edge, the dense stages per node; NODE_WEIGHT = their cost ratio measured on one MI355X).  'rows':
+in-degree + tuning.T.node_weight per node, so every rank gets the same share of the step's work (the aggregation
+is per edge, the dense stages per node; node_weight = their cost ratio measured on one MI355X).  'rows':
 equal row counts.  Rank p owns rows [lo(p), hi(p)) of x / y / masks / activations / structural embeddings.
 
 Ingest: every rank keeps only the edges whose destination (forward CSR) resp. source (reverse CSR) it owns
@@ -61,7 +61,7 @@ from . import _lib
 
 from .tuning import T
 
-NODE_WEIGHT = T.node_weight      # (tuning.T: node_weight, cover_min_gain, slice_min_bytes, support_max_edge_frac)
+# (tuning.T: node_weight, cover_min_gain, slice_min_bytes, support_max_edge_frac — all read at call time)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -149,11 +149,11 @@ class Partition:
         self._bt = {}
 
     @classmethod
-    def balanced(cls, in_degree, world, rank, node_weight=NODE_WEIGHT):
+    def balanced(cls, in_degree, world, rank, node_weight=None):
         """Boundaries at equal shares of sum_v (in_degree[v] + node_weight): SURVEY.md §8e 'balance on edges-per-rank
         (prefix sum over in-degree), not nodes'.  Deterministic in the degree vector, so all ranks agree."""
         n = int(in_degree.numel())
-        cost = torch.cumsum(in_degree.to(torch.int64) + int(node_weight), 0)
+        cost = torch.cumsum(in_degree.to(torch.int64) + int(T.node_weight if node_weight is None else node_weight), 0)
         total = int(cost[-1]) if n else 0
         targets = torch.tensor([(total * p) // world for p in range(1, world)], dtype=torch.int64, device=cost.device)
         cuts = torch.searchsorted(cost, targets, right=False).tolist() if world > 1 and n else []
@@ -358,10 +358,9 @@ def cover_slices_enabled():
     return os.environ.get('COLDBREW_HALO_COVER', '1') != '0'
 
 
-COVER_MIN_GAIN = T.cover_min_gain
 
 
-def choose_cover(u_idx, v_idx, q_u, q_v, n_u, n_v, P, min_gain=COVER_MIN_GAIN):
+def choose_cover(u_idx, v_idx, q_u, q_v, n_u, n_v, P, min_gain=None):
     """Push / pull assignment of the remote edges of one requester.  u_idx / v_idx: per edge, index of its source among the n_u distinct
     remote sources / of its (owner, destination) pair among the n_v distinct pairs; q_u / q_v: owner of each distinct source / pair.
     Returns pull [E] bool (True: the source row is shipped; False: the edge is summed by the owner into the destination's partial row).
@@ -370,6 +369,8 @@ def choose_cover(u_idx, v_idx, q_u, q_v, n_u, n_v, P, min_gain=COVER_MIN_GAIN):
     the smallest row count wins — but the pull is kept unless it is beaten by min_gain (a pushed row costs its owner an aggregation over the
     edges it sums; on the ogbn-products shape a 0.4 % smaller all-push cover would double the local work).  Within 1 - 3 % of the
     Hopcroft-Karp optimum on the power-law graphs (profiles/r04_halo_cover_study.md)."""
+    from . import tuning
+    min_gain = tuning.T.cover_min_gain if min_gain is None else min_gain      # (read at call time; `T` below is a local)
     dev = u_idx.device
     du = torch.bincount(u_idx, minlength=n_u)
     dv = torch.bincount(v_idx, minlength=n_v)
@@ -674,7 +675,7 @@ class ShardedGraph:
             asg = CoverPlan.assign(rows[remote], cols[remote], part) if use_cover else None
         elif self.cover:
             # one decision for the group (every rank must build the same kind of plan): the cover is taken when it spares the busiest
-            # requester at least COVER_MIN_GAIN of its rows (power-law graphs: 25 - 32 %; the ogbn-products shape: < 6 % -> plain pull,
+            # requester at least tuning.T.cover_min_gain of its rows (power-law graphs: 25 - 32 %; the ogbn-products shape: < 6 % -> plain pull,
             # whose pack is a row gather and whose slices follow the owners' row chunks)
             asg = CoverPlan.assign(rows[remote], cols[remote], part)
             # (the busiest requester under either plan — MAX of each count over the ranks —, not the best ratio of any one rank: a rank with
@@ -683,7 +684,7 @@ class ShardedGraph:
             if part.world > 1:
                 _all_reduce(busiest, op=dist.ReduceOp.MAX, group=self.group)
             n_pull, n_cover = (int(v) for v in busiest.tolist())
-            use_cover = (n_pull > 0 and 1.0 - n_cover / n_pull >= COVER_MIN_GAIN) or self._cover_forced
+            use_cover = (n_pull > 0 and 1.0 - n_cover / n_pull >= T.cover_min_gain) or self._cover_forced
         lp_, ns_ = (src.pos, src.n) if src is not None else (None, None)
         o.plan = (CoverPlan(rows[remote], cols[remote], part, self.group, K, self.compute, asg, local_pos=lp_, n_src=ns_) if use_cover
                   else HaloPlan(uniq, part, self.group, K, local_pos=lp_, n_src=ns_))
@@ -1311,8 +1312,12 @@ class ShardedTrainer:
         from . import ops
         m = self.teacherGNN
         # (loss_rows: this rank's rows of the train mask — the objective touches the logits there only; rows_only: and reads nothing else of this forward's
-        # output, trainer_node_classification.training_loss)
-        out = m.get_3_embs(self.x, self.edge_index, loss_rows=(self.train_mask, self.n_train), rows_only=True).emb4classi_full
+        # output — the other rows come back as NaN —, trainer_node_classification.training_loss; `rows_only_forward = False` withdraws the second promise)
+        if getattr(self.args, 'has_loss_component_edgewise', False):
+            raise NotImplementedError('edge-wise (link-prediction) loss belongs to the I2_GTL mode (out of scope); training_loss() promises the model '
+                                      'that only the train rows of its output are read')
+        rows_only = bool(getattr(self, 'rows_only_forward', getattr(self.args, 'rows_only_forward', True)))
+        out = m.get_3_embs(self.x, self.edge_index, loss_rows=(self.train_mask, self.n_train), rows_only=rows_only).emb4classi_full
         # local numerator / global count; the global loss is the sum over ranks
         unit = float(self.args.TeacherGNN.lossa_semantic) == 1.0
         loss = ops.nll_logsoftmax(out, self.y, self.train_mask, self.n_train, unit_grad=unit)

@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from .tuning import T
 
-HUB_THRESHOLD = T.hub_threshold      # (thresholds: tuning.T — hub_threshold, hot_bytes, fwd0_rows_per_edge, fwd0_min_edges)
+# (thresholds: tuning.T — hub_threshold, hot_bytes, fwd0_rows_per_edge, fwd0_min_edges — read at call time: hub_threshold=None means T.hub_threshold)
 INT32_EDGE_LIMIT = 2 ** 31 - 1   # edge offsets (rowptr) and column ids are int32 on the device (include/coldbrew_hip.h); see CSRGraph.__init__
 
 
@@ -33,7 +33,7 @@ class _Plan:
 
 
 class CSRGraph:
-    def __init__(self, edge_index, num_nodes=None, hub_threshold=HUB_THRESHOLD, keep_edge_order=False):
+    def __init__(self, edge_index, num_nodes=None, hub_threshold=None, keep_edge_order=False):
         """keep_edge_order: keep the int64 edge list (16 bytes per edge) so that edge_perm() can map CSR positions back to columns of
         edge_index — needed only by the `edge_weight` form of GCNConv.forward (GCN.py:199-202), which TricksComb never uses; the cached graph
         of the training path is built without it (nothing but the CSR outlives the ingest)."""
@@ -54,7 +54,7 @@ class CSRGraph:
         self.N, self.E, self.device = N, E, dev
         self.n_cols, self.row_offset = N, 0
         self._ei, self._perm, self._perm_t = (ei.clone() if keep_edge_order and ei.data_ptr() == edge_index.data_ptr() else ei) if keep_edge_order else None, None, None
-        self.hub_threshold = int(hub_threshold)
+        self.hub_threshold = int(T.hub_threshold if hub_threshold is None else hub_threshold)
         self.rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
         self.col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
         self.rowptr_t = torch.empty(N + 1, dtype=torch.int32, device=dev)
@@ -86,6 +86,7 @@ class CSRGraph:
         self._ws = None
         self._hot_cols()
         self.profile = None      # bench.py sets a list: one prof_rec() per aggregation launch
+        self.rows_only_forwards = 0      # training forwards that evaluated their last layer on the loss rows (trunk._last_layer_on_loss_rows, stack.py; tests, bench)
 
     def _hot_cols(self):
         """Kernel-side column arrays with the hot-source flag in bit 31 (include/coldbrew_hip.h, cb_spmm_csr_f32 col_flags):
@@ -127,7 +128,7 @@ class CSRGraph:
         self._hot_cache[k] = (ck, ctk)
         return ck, ctk
 
-    def grad_support_plan(self, keep, n_aggr, max_frac=0.6, cumulative=False):
+    def grad_support_plan(self, keep, n_aggr, max_frac=0.6, cumulative=False, count=True):
         """Row supports of a backward whose incoming gradient is non-zero on the rows `keep` only (the masked loss: the loss_rows promise of the forward, ops.py).
         Reverse aggregation j (j = 0 for the last layer) gathers rows of the support S_j and produces non-zero rows exactly on
         S_{j+1} = the rows with a (reverse-orientation) neighbour in S_j; supports are properties of the graph and the mask, not of the
@@ -140,12 +141,14 @@ class CSRGraph:
         At most n_aggr levels, and the last of them always has a dense destination (the stage below the first layer needs all rows).
         max_frac = 0: one level, S_0 -> all rows.  Sums equal the full orientation's up to the order in which a hub row's chunks are added.
         cumulative (the 'Residual' trunk): S_{j+1} = N(S_j) ∪ S_j — a superset that also holds the rows the previous level's gradient lives on
-        (rows of S_j without a neighbour in S_j are rows without edges in the level's CSR)."""
+        (rows of S_j without a neighbour in S_j are rows without edges in the level's CSR).
+        count=False: a second lookup of the same step (the rows-only forward asked already) — not counted as a use for support_plan_pays()."""
         # (the cache keeps the mask tensor itself alive: its address cannot be handed to another tensor while the plan is cached, and an
         # in-place change bumps its version)
         key = (keep.data_ptr(), keep._version, int(keep.shape[0]), int(n_aggr), float(max_frac), bool(cumulative))
         if getattr(self, '_support_key', None) == key and getattr(self, '_support_mask', None) is keep:
-            self._support_hits = getattr(self, '_support_hits', 0) + 1
+            if count:
+                self._support_hits = getattr(self, '_support_hits', 0) + 1
             return self._support_plan
         self._support_builds = getattr(self, '_support_builds', 0) + 1
         if self.rowptr_t is None:
@@ -234,12 +237,14 @@ class CSRGraph:
     def loss_rows_fwd(self, plan):
         """The forward orientation on the rows of S_0 of a plan (plan.fwd[0]), built now if the thresholds of _support_fwd had left it out: the rows-only
         forward of trunk.py evaluates the last layer on those rows whatever the break-even of the backward's source-side form says."""
-        if not plan.fwd:
-            plan.fwd.append(None)
-        if plan.fwd[0] is None:
+        if plan.fwd and plan.fwd[0] is not None:
+            return plan.fwd[0]
+        # (kept apart from plan.fwd: that list is what the break-evens of _support_fwd decided for the BACKWARD's source-side form, and a later
+        # backward on this cached plan that did not follow a rows-only forward must still see their answer — ADVICE r05)
+        if plan.fwd0_forced is None:
             dst = plan.levels[0][1]
-            plan.fwd[0] = self._support_fwd(plan.space0, dst.n if dst is not None else self.N, force=True)
-        return plan.fwd[0]
+            plan.fwd0_forced = self._support_fwd(plan.space0, dst.n if dst is not None else self.N, force=True)
+        return plan.fwd0_forced
 
     def rows_only_fwd(self, plan):
         """Orientations of a rows-only forward that also evaluates the layer BELOW the last one on the rows the last layer reads — S_1, when the plan keeps
@@ -289,14 +294,14 @@ class CSRGraph:
         return pair[1] if transpose else pair[0]
 
     @classmethod
-    def from_csr(cls, rowptr, col, n_cols, hub_threshold=HUB_THRESHOLD):
+    def from_csr(cls, rowptr, col, n_cols, hub_threshold=None):
         """Wraps an existing (possibly rectangular: len(rowptr)-1 rows x n_cols columns) device CSR, e.g.
         the row block a rank owns in the node-sharded path.  Forward orientation only."""
         _lib.require_device(rowptr, col)
         g = cls.__new__(cls)
         g.device = rowptr.device
         g.N, g.E, g.n_cols = int(rowptr.numel()) - 1, int(col.numel()), int(n_cols)
-        g.hub_threshold = int(hub_threshold)
+        g.hub_threshold = int(T.hub_threshold if hub_threshold is None else hub_threshold)
         g.rowptr = rowptr.to(torch.int32).contiguous()
         g.col = col.to(torch.int32).contiguous() if col.numel() else torch.zeros(1, dtype=torch.int32, device=g.device)
         g.rowptr_t = g.col_t = None
@@ -310,7 +315,7 @@ class CSRGraph:
         return g
 
     @classmethod
-    def from_pairs(cls, rows, cols, n_rows, n_cols, hub_threshold=HUB_THRESHOLD):
+    def from_pairs(cls, rows, cols, n_rows, n_cols, hub_threshold=None):
         """Rectangular device CSR (n_rows x n_cols, ascending columns inside a row) from (row, col) pairs through the same
         C-ABI ingest as the square graph — the row block a rank owns in the node-sharded path (dist.py)."""
         lib = _lib.load()
@@ -634,7 +639,7 @@ class SegmentedCSRGraph:
     to graphs below 2^31 edges.  max_edges is a parameter so that the segment logic is testable on small graphs."""
     segmented = True
 
-    def __init__(self, edge_index, num_nodes=None, hub_threshold=HUB_THRESHOLD, max_edges=INT32_EDGE_LIMIT - 1):
+    def __init__(self, edge_index, num_nodes=None, hub_threshold=None, max_edges=INT32_EDGE_LIMIT - 1):
         lib = _lib.load()
         _lib.require_device(edge_index)
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
@@ -646,7 +651,7 @@ class SegmentedCSRGraph:
         if N >= INT32_EDGE_LIMIT:
             raise ValueError(f'{N} nodes: column ids are int32 (N < 2^31)')
         self.N, self.E, self.device, self.n_cols, self.row_offset = N, E, dev, N, 0
-        self.hub_threshold, self.max_edges = int(hub_threshold), int(max_edges)
+        self.hub_threshold, self.max_edges = int(T.hub_threshold if hub_threshold is None else hub_threshold), int(max_edges)
         self.rowptr = torch.empty(N + 1, dtype=torch.int64, device=dev)
         self.col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
         self.rowptr_t = torch.empty(N + 1, dtype=torch.int64, device=dev)
@@ -738,6 +743,7 @@ class RowSupportPlan:
     def __init__(self, space0, levels):
         self.space0, self.levels = space0, levels
         self.fwd = []      # per level: the forward orientation on the level's source rows (CSRGraph._support_fwd) or None
+        self.fwd0_forced = None      # level 0's, built for a rows-only FORWARD although the backward's break-evens left fwd[0] out (CSRGraph.loss_rows_fwd)
 
     @property
     def fwd0(self):

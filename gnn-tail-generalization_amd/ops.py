@@ -434,8 +434,8 @@ def gather_rows_by_index(x, idx, out_bf16=False):
     return out
 
 
-def expand_rows(src, pos):
-    """[len(pos), d] matrix whose row r is src[pos[r]] where pos[r] >= 0 and zero elsewhere (cb_expand_rows_f32): a compact matrix over a
+def expand_rows(src, pos, fill=0.0):
+    """[len(pos), d] matrix whose row r is src[pos[r]] where pos[r] >= 0 and `fill` elsewhere (cb_expand_rows_f32): a compact matrix over a
     row subset (graph.RowSpace: pos int32 [N]) written back to all rows."""
     lib = _lib.load()
     _lib.require_device(src, pos)
@@ -444,9 +444,24 @@ def expand_rows(src, pos):
     src = src.contiguous()
     out = torch.empty((pos.numel(), src.shape[1]), dtype=torch.float32, device=src.device)
     with torch.cuda.device(src.device):
-        _lib.check(lib.cb_expand_rows_f32(_lib.ptr(src), _lib.ptr(pos.contiguous()), pos.numel(), src.shape[1], _lib.ptr(out), _lib.stream_ptr()),
+        _lib.check(lib.cb_expand_rows_f32(_lib.ptr(src), _lib.ptr(pos.contiguous()), pos.numel(), src.shape[1], float(fill), _lib.ptr(out), _lib.stream_ptr()),
                    'cb_expand_rows_f32')
     return out
+
+
+def unread_rows_fill():
+    """What a rows-only training forward writes into the rows of its output that the caller promised not to read (trunk.py "Rows-only forward"):
+    NaN (tuning.T.rows_only_poison, the default) — a consumer that reads them after all (TeacherGNN.out, res.commonEmb, an edge-wise loss) gets NaN
+    instead of a plausible zero / bias-only row; 0.0 otherwise."""
+    from .tuning import T
+    return float('nan') if T.rows_only_poison else 0.0
+
+
+def expand_unread(rows, space, n):
+    """[n, C] output of a rows-only forward: `rows` on the loss rows (graph.RowSpace `space`), unread_rows_fill() elsewhere."""
+    if rows.shape[1] % 4 == 0:
+        return expand_rows(rows, space.pos, unread_rows_fill())
+    return torch.full((n, rows.shape[1]), unread_rows_fill(), dtype=torch.float32, device=rows.device).index_copy_(0, space.idx, rows)
 
 
 def label_propagation(graph, y0, deg_inv_sqrt, alpha, num_propagations):

@@ -12,6 +12,8 @@ class Adam(torch.optim.Optimizer):
             raise ValueError('invalid Adam hyper-parameter')
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._step_dev = None      # hipGraph mode: int64 device tensor holding the step count
+        self._skipped_dev = {}     # device index -> int64 [1]: launches the gradient-check guard kept from writing since the last roll-back (eager mode)
+        _lib.register_guard_listener(self)
         self._extra_decay = {}     # parameter -> [1] float32 device tensor added to weight_decay for that tensor (see extra_decay_buffer)
 
     def extra_decay_buffer(self, p):
@@ -52,8 +54,24 @@ class Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
+        # A launch that the gradient-check guard keeps from writing (_lib.grad_guard) is not a step: the device-resident count advances only while
+        # the guard word is clear, and in eager mode — where the bias corrections come from the host's counts, which cannot see the word — the
+        # skipped launches are counted on the device and taken back off the host's counts when _lib.device_status() reports the failure
+        # (roll_back_skipped): an update that "leaves the weights and moments untouched" leaves the step counts untouched too.
+        devs = {p.device for g_ in self.param_groups for p in g_['params'] if p.grad is not None and p.is_cuda}
+        for dev in devs:
+            guard = _lib.grad_guard(dev, create=False)
+            if self._step_dev is not None and self._step_dev.device == dev:
+                continue
+            if guard is not None:
+                sk = self._skipped_dev.get(dev.index)
+                if sk is None:
+                    sk = self._skipped_dev[dev.index] = torch.zeros(1, dtype=torch.int64, device=dev)
+                sk.add_(guard.ne(0))
         if self._step_dev is not None:
-            self._step_dev.add_(1)         # captured: every replay advances the device-resident count
+            guard = _lib.grad_guard(self._step_dev.device, create=False)
+            # captured: every replay advances the device-resident count (unless its launch is skipped)
+            self._step_dev.add_(1) if guard is None else self._step_dev.add_(guard.eq(0))
         import ctypes
         from . import ops
         capturing = torch.cuda.is_current_stream_capturing()
@@ -123,6 +141,20 @@ class Adam(torch.optim.Optimizer):
         for buf in self._extra_decay.values():
             buf.zero_()
         return loss
+
+
+    def roll_back_skipped(self):
+        """Called by _lib.device_status() when it reports a failed gradient check (a host synchronisation has just happened): the launches the
+        guard skipped since then did not update anything, so the per-tensor step counts that step() advanced for them are taken back."""
+        for idx, sk in self._skipped_dev.items():
+            n = int(sk.item())
+            if n:
+                sk.zero_()
+                for g_ in self.param_groups:
+                    for p in g_['params']:
+                        st = self.state.get(p)
+                        if st and p.is_cuda and p.device.index == idx:
+                            st['step'] = max(int(st['step']) - n, 0)
 
 
 def resolve(name):

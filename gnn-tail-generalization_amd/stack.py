@@ -94,7 +94,7 @@ class _StackFn(torch.autograd.Function):
         z = z_ready if z_ready is not None else z
         bias_last = layer_params[3 * (L - 1) + 1]
         # the last layer: no ReLU (GCN.py:127); then the dropout on the logits (GCN.py:133)
-        if ro is not None:      # the logits on the loss rows (gathering the compact Z over the orientation renumbered to S_1), zeros elsewhere
+        if ro is not None:      # the logits on the loss rows (gathering the compact Z over the orientation renumbered to S_1)
             plan_ = ro[5]
             sp = plan_.space0
             ro[1].profile = getattr(graph, 'profile', None)
@@ -102,8 +102,8 @@ class _StackFn(torch.autograd.Function):
             if b0 is None:
                 b0 = sp._norm_in = b[sp.idx].contiguous()
             y_c = ro[1].spmm(z, row_scale=b0, bias=bias_last)
-            y = (ops.expand_rows(y_c, sp.pos) if y_c.shape[1] % 4 == 0
-                 else torch.zeros((x.shape[0], y_c.shape[1]), dtype=torch.float32, device=x.device).index_copy_(0, sp.idx, y_c))
+            y = ops.expand_unread(y_c, sp, x.shape[0])      # the rows nobody may read: NaN (ops.unread_rows_fill)
+            graph.rows_only_forwards = getattr(graph, 'rows_only_forwards', 0) + 1
         else:
             y = graph.aggregate(z, False, b, bias_last, False) if hasattr(graph, 'part') else graph.spmm(z, row_scale=b, bias=bias_last)
         out = ops._dropout_raw(y, p, seeds[L], row0 * y.shape[1]) if p > 0 else y
@@ -144,7 +144,7 @@ class _StackFn(torch.autograd.Function):
         hint = _plan_hint(graph, loss_rows, gout.shape[0], ag, committed=ctx.in_last_compact)
         if hint is not None:
             ops.check_rows_zero(gout, hint[0])
-            plan = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac)
+            plan = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac, count=not ctx.in_last_compact)      # (one use per step)
         if ctx.in_last_compact and (plan is None or plan.levels[0][1] is None):
             raise RuntimeError('the forward ran its last layers on the loss rows\' supports (rows_only), but its backward finds no such plan: '
                                'CB_LOSS_ROWS / tuning.T / the mask changed between the forward and the backward')

@@ -263,8 +263,15 @@ class trainer:
             self._n_train = int(self.data.train_mask.sum().item())      # once: keeps the step free of host syncs
         # the objective below touches the logits in the train rows only (loss_rows) and nothing else of this forward's output is read (rows_only): said to
         # the model, whose backward may then skip the rows that stay zero (ops.py "Row-sparse backward"; verified on the device every step) and whose
-        # forward may evaluate its last layer on the train rows (trunk.py "Rows-only forward")
-        res = self.teacherGNN.get_3_embs(self.data.x, self.data.edge_index, loss_rows=(self.data.train_mask, self._n_train), rows_only=True)
+        # forward may evaluate its last layer on the train rows (trunk.py "Rows-only forward": the other rows of res.* / teacherGNN.out then hold NaN).
+        # The second promise is THIS function's to make — it builds the node-wise loss below and nothing else: an edge-wise term would read
+        # res.commonEmb on every row (trainer…:417-418) and is refused here, not only in run_trainSet; `rows_only_forward = False` on the trainer (or
+        # --rows_only_forward=0) withdraws it for a subclass that reads more of the forward.
+        rows_only = bool(getattr(self, 'rows_only_forward', getattr(self.args, 'rows_only_forward', True)))
+        if getattr(self.args, 'has_loss_component_edgewise', False):
+            raise NotImplementedError('edge-wise (link-prediction) loss belongs to the I2_GTL mode (out of scope); training_loss() promises the model '
+                                      'that only the train rows of its output are read')
+        res = self.teacherGNN.get_3_embs(self.data.x, self.data.edge_index, loss_rows=(self.data.train_mask, self._n_train), rows_only=rows_only)
         # == F.nll_loss(F.log_softmax(out[train_mask], 1), y[train_mask]) (:390-391), fused, no row gather
         unit = float(self.args.TeacherGNN.lossa_semantic) == 1.0      # the step seeds backward() with 1: no [N, C] pass to multiply by it
         loss = ops.nll_logsoftmax(res.emb4classi_full, self.data.y, self.data.train_mask, self._n_train, unit_grad=unit)

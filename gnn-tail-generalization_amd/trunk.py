@@ -462,7 +462,7 @@ def _last_layer_on_loss_rows(graph, plan, cur, w, b, mix, alpha, p, seed, row0, 
         Y[S_0] = b * ((A (a * X))[S_0] W) + bias        (GCN.py:213-256 with the sum taken first)
     so the layer is one aggregation over the edges that ENTER the loss rows (10 % of the edges under a 10 % mask) into a compact [|S_0|, H] matrix, a
     GEMM on |S_0| rows, the store on those rows and the head on those rows.  Z_{L-1} — the previous layer's dense tail — is never formed.
-    Returns (mask words [N, H/256, 4] (rows of S_0 written), dropped X_L on S_0, logits [N, C] with zeros outside S_0, H = (A (a * X))[S_0]:
+    Returns (mask words [N, H/256, 4] (rows of S_0 written), dropped X_L on S_0, logits [N, C] with ops.unread_rows_fill() (NaN) outside S_0, H = (A (a * X))[S_0]:
     the operand of the level's weight gradient in the backward's source-side form).  below (CSRGraph.rows_only_fwd): `cur` holds the rows of S_1 only."""
     sp = plan.space0
     fwd0 = graph.loss_rows_fwd(plan) if below is None else below[1]
@@ -475,17 +475,15 @@ def _last_layer_on_loss_rows(graph, plan, cur, w, b, mix, alpha, p, seed, row0, 
                                            residual, le=le, fwd_le=graph.loss_rows_fwd(plan) if le is not None else None)
     n = graph.N
     logits_c = gemm.mm_nn(x_l, w_out.t().contiguous(), bias=b_out)
-    if logits_c.shape[1] % 4 == 0:
-        out = ops.expand_rows(logits_c, sp.pos)
-    else:
-        out = torch.zeros((n, logits_c.shape[1]), dtype=torch.float32, device=cur.device).index_copy_(0, sp.idx, logits_c)
+    out = ops.expand_unread(logits_c, sp, n)      # the rows nobody may read: NaN (ops.unread_rows_fill)
+    graph.rows_only_forwards = getattr(graph, 'rows_only_forwards', 0) + 1
     return bits, x_l, out, h_agg
 
 
 def _last_layer_on_loss_rows_sharded(graph, s0, orient, cur, w, b, mix, alpha, p, seed, row0, residual, w_out, b_out, le=None):
     """_last_layer_on_loss_rows on a rank's row block: the aggregation of a * X over the edges that enter the rank's loss rows is a level orientation
     of the forward exchange (dist.ShardedGraph.loss_rows_forward: the peers ship only the in-neighbours of those rows).  Returns (mask words, dropped
-    X_L on the rank's loss rows, logits [n_local, C] with zeros elsewhere)."""
+    X_L on the rank's loss rows, logits [n_local, C] with ops.unread_rows_fill() (NaN) elsewhere)."""
     lib = _lib.load()
     xs = _exchanged(graph, cur.shape[0], cur.shape[1])
     with torch.cuda.device(cur.device):      # xs = a * X (the source rows' factor, applied before the rows travel)
@@ -505,10 +503,7 @@ def _last_layer_on_loss_rows_sharded(graph, s0, orient, cur, w, b, mix, alpha, p
     x_l, _act = _store_rows(y, s0.idx, mix, 1 - alpha, alpha, p, seed, row0, bits, residual)
     del y
     logits_c = gemm.mm_nn(x_l, w_out.t().contiguous(), bias=b_out)
-    if logits_c.shape[1] % 4 == 0:
-        out = ops.expand_rows(logits_c, s0.pos)
-    else:
-        out = torch.zeros((n, logits_c.shape[1]), dtype=torch.float32, device=cur.device).index_copy_(0, s0.idx, logits_c)
+    out = ops.expand_unread(logits_c, s0, n)
     graph.rows_only_forwards += 1
     return bits, x_l, out
 
@@ -520,7 +515,7 @@ class _TrunkFn(torch.autograd.Function):
         was recording when the trunk was called (inside a Function's forward it never is, and needs_input_grad does not know about no_grad);
         loss_rows = None or (bool mask [N], count): the caller's promise that the output receives gradient in those rows only (ops.py);
         residual: the 'Residual' connection (mix source of layer l > 0 = the previous layer's ReLU output) instead of 'Initial' (X0);
-        rows_only: the caller's second promise — it READS the output in the rows of loss_rows only (the other rows are returned as zeros)."""
+        rows_only: the caller's second promise — it READS the output in the rows of loss_rows only (the other rows are returned as NaN: ops.unread_rows_fill)."""
         L, alpha, p, seeds, agg_bf16, track, _loss_rows, residual, _rows_only = cfg
         row0 = int(getattr(graph, 'row_offset', 0))
         a = graph.norm_out
@@ -942,8 +937,9 @@ class _Backward:
             ops.check_rows_zero(gout, hint[0])
             # ('Residual': a layer's store backward also takes the gradient of the layer above, so the supports are CUMULATIVE — W_{j+1} = N(W_j) ∪ W_j,
             # a superset of both; every matrix of level j lives on W_j)
-            plan = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac, cumulative=self.residual)
-        if self.rows_only and (plan is None or not plan.fwd or plan.fwd[0] is None):
+            # (count: one use per step — the forward of a rows-only step has looked the plan up already)
+            plan = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac, cumulative=self.residual, count=not self.xl_compact)
+        if self.rows_only and plan is None:
             raise RuntimeError('the forward evaluated its last layer on the loss rows (rows_only), but its backward finds no row-support plan: '
                                'CB_LOSS_ROWS / tuning.T / the mask changed between the forward and the backward')
 
@@ -1054,7 +1050,7 @@ class _Backward:
 def forward(tc, x, graph, loss_rows=None, rows_only=False):
     """TricksComb.forward on the fused trunk; returns (logits, se_reg_all).  loss_rows: None, (bool mask [N], count) or the mask alone — the caller's promise
     that the logits receive gradient in the rows of the mask only (the masked loss, trainer_node_classification.py:390-391).  rows_only (with loss_rows):
-    the caller also READS the logits in those rows only — a training forward may then evaluate its last layer on them; the other rows come back as zeros."""
+    the caller also READS the logits in those rows only — a training forward may then evaluate its last layer on them; the other rows come back as NaN (ops.unread_rows_fill)."""
     L = tc.num_layers
     p = float(tc.dropout) if tc.training else 0.0
     seeds = tuple(ops.next_seed() for _ in range(L + 2)) if p > 0 else (0,) * (L + 2)

@@ -1,6 +1,6 @@
 """The measured thresholds of the path in ONE place: each is a break-even between two forms that compute the same thing, tuned on the graph
 named beside it (one MI355X; profiles/ holds the tables).  Read at call time (`tuning.T.<name>`), so a test or a host with another graph family
-can set them on the instance; nothing here changes results beyond the order in which sums are associated."""
+can set them on the instance (every user reads T at its call sites; a graph / partition / cover that was BUILT keeps the value it was built with); nothing here changes results beyond the order in which sums are associated."""
 from dataclasses import dataclass
 
 
@@ -36,6 +36,9 @@ class Tuning:
     # the source rows' side) once S_1's rows are entered by at least this many edges — below, the Z-first form on S_1 (one kernel) wins on launches.
     # S-arxiv (1.7 * 10^6 edges into S_1): 2.94 -> 3.11 ms/step with the sum first; S-products: 90.1 -> 89.4; S-pl10M (7.4 * 10^7): 125.3 -> 120.9
     sum_first_below_min_edges: int = 1 << 24
+    # rows-only forward: the rows of the output that the caller promised not to read come back as NaN (True) or as zeros (False).  Costs nothing (the
+    # rows are written either way); makes a broken `rows_only` promise loud: whoever reads TeacherGNN.out / res.commonEmb outside the loss rows sees NaN
+    rows_only_poison: bool = True
     # mixed-in gradients one cb_trunk_input_bwd_multi_f32 launch gathers (deeper 'Initial' trunks accumulate layer by layer): kernel limit
     mix_max: int = 7
     # gather mode keeps every layer's [N, d] gradient alive until the input stage; allowed while that is below this share of the free memory

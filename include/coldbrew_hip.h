@@ -602,10 +602,11 @@ int cb_spmm_csr_lp_f32(const int32_t* rowptr, const int32_t* col, int64_t N, int
 
 /* The same pack with the rows narrowed to bf16 (round-to-nearest-even) as they are written: the send buffer of the bf16 halo wire. */
 int cb_gather_rows_bf16_f32(const float* src, int64_t ld, const int64_t* idx, int64_t n_idx, int64_t d, uint16_t* out, void* stream);
-/* out[r, :] = pos[r] >= 0 ? src[pos[r], :] : 0 for r < n_rows (contiguous [n, d] src and [n_rows, d] out, d % 4 == 0): a matrix over a
- * row subset written back to all rows in one pass — the gradient of a structural-embedding table (dL/dZ_l, GCN.py:230-232) when the level
- * of the row-sparse backward that produces it is compact (trunk.py). */
-int cb_expand_rows_f32(const float* src, const int32_t* pos, int64_t n_rows, int64_t d, float* out, void* stream);
+/* out[r, :] = pos[r] >= 0 ? src[pos[r], :] : fill for r < n_rows (contiguous [n, d] src and [n_rows, d] out, d % 4 == 0): a matrix over a
+ * row subset written back to all rows in one pass — fill = 0: the gradient of a structural-embedding table (dL/dZ_l, GCN.py:230-232) when the level
+ * of the row-sparse backward that produces it is compact; fill = NaN: the logits (GCN.py:138) of a rows-only training forward, evaluated on the loss
+ * rows of trainer_node_classification.py:390-391 only — a reader of any other row gets NaN, not a plausible number (trunk.py). */
+int cb_expand_rows_f32(const float* src, const int32_t* pos, int64_t n_rows, int64_t d, float fill, float* out, void* stream);
 /* The trunk's fused store — ReLU, mask words, residual mix, dropout (GCN.py:127-133, res_tricks.py:7-23) — on a SUBSET of the rows, applied to the
  * output of a dense transform instead of inside an aggregation: y / out are compact [n_rows, d] matrices of the rows row_index[0 .. n_rows) (ascending
  * global ids), relu_bits ([N][d/256][4], may be NULL) is the full array, the dropout mask is drawn at the global row; mix_src (may be NULL) is read at row

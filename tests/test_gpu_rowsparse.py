@@ -170,9 +170,10 @@ def test_rows_only_forward_equals_the_dense_step(conn, se, layers, n_loss_rows, 
         _close_up_to_relu_flips(g_s[k], g_d[k], k)
 
 
-def test_rows_only_forward_returns_the_loss_rows_and_zeros(monkeypatch):
+def test_rows_only_forward_returns_the_loss_rows_and_poison(monkeypatch):
     """What the caller gets under both promises: the logits of the all-rows forward (same dropout masks: they are drawn at the global row) in the rows
-    of the mask, zeros in every other row.  Without rows_only — the gradient promise alone — every row is evaluated."""
+    of the mask, NaN in every other row (a reader that breaks the promise — TeacherGNN.out, res.commonEmb, an edge-wise loss — must not get
+    plausible numbers; tuning.T.rows_only_poison = False: zeros).  Without rows_only — the gradient promise alone — every row is evaluated."""
     import bench
     from gnn_tail_generalization_amd import ops
     from gnn_tail_generalization_amd import trainer_node_classification as tnc
@@ -188,8 +189,27 @@ def test_rows_only_forward_returns_the_loss_rows_and_zeros(monkeypatch):
         ops._seed_override[:] = [21, 22, 23, 24, 25]
         outs[ro] = t.teacherGNN.get_3_embs(t.data.x, t.data.edge_index, loss_rows=(mask, n), rows_only=ro).emb4classi_full
         ops._seed_override[:] = []
-    assert float(outs[True].detach()[~mask].abs().max()) == 0.0 and float(outs[False].detach()[~mask].abs().max()) > 0.0
+    assert bool(torch.isnan(outs[True].detach()[~mask]).all()) and bool(torch.isfinite(outs[False].detach()).all())
+    assert bool(torch.isfinite(t.teacherGNN.out.detach()).all())      # (.out is the LAST forward's: the all-rows one)
     torch.testing.assert_close(outs[True].detach()[mask], outs[False].detach()[mask], atol=2e-5, rtol=2e-5)
+    monkeypatch.setattr(tuning.T, 'rows_only_poison', False)
+    ops._seed_override[:] = [21, 22, 23, 24, 25]
+    res = t.teacherGNN.get_3_embs(t.data.x, t.data.edge_index, loss_rows=(mask, n), rows_only=True)
+    ops._seed_override[:] = []
+    assert float(res.emb4classi_full.detach()[~mask].abs().max()) == 0.0 and t.teacherGNN.out is res.commonEmb
+    monkeypatch.setattr(tuning.T, 'rows_only_poison', True)
+    # the trainer's own step makes the promise (and a loss that stays finite shows that nothing of it reads the poisoned rows) ...
+    assert bool(torch.isfinite(t.training_loss().detach()))
+    assert bool(torch.isnan(t.teacherGNN.out.detach()[~mask]).all())
+    # ... withdraws it on request ...
+    t.rows_only_forward = False
+    assert bool(torch.isfinite(t.training_loss().detach())) and bool(torch.isfinite(t.teacherGNN.out.detach()).all())
+    del t.rows_only_forward
+    # ... and refuses the objective that would read every row of the same forward (trainer…:417-418), inside training_loss itself
+    t.args.has_loss_component_edgewise = True
+    with pytest.raises(NotImplementedError, match='only the train rows'):
+        t.training_loss()
+    t.args.has_loss_component_edgewise = False
     with torch.no_grad():      # a forward that no backward follows keeps every row, whatever was promised
         ops._seed_override[:] = [21, 22, 23, 24, 25]
         out_ng = t.teacherGNN.get_3_embs(t.data.x, t.data.edge_index, loss_rows=(mask, n), rows_only=True).emb4classi_full
@@ -325,7 +345,7 @@ def test_row_sparse_backward_matches_the_unmodified_reference(case, rows_only, m
     assert plan is not None and plan.levels[0][1] is not None       # the backward ran on the plan, S_1 compact
     took_rows_only = rows_only      # (the residual trunks, with and without tables, and the non-residual stack)
     if took_rows_only:
-        assert float(out.detach()[~mask].abs().max()) == 0.0
+        assert bool(torch.isnan(out.detach()[~mask]).any(dim=1).all())      # the rows nobody may read are poisoned (ops.unread_rows_fill)
         torch.testing.assert_close(out.detach()[mask].cpu(), g['train_out'][mask.cpu()], atol=1e-4, rtol=1e-4)
     else:
         torch.testing.assert_close(out.detach().cpu(), g['train_out'], atol=1e-4, rtol=1e-4)
@@ -469,6 +489,8 @@ def test_expand_rows_is_the_inverse_of_the_row_pack():
     want[mask] = src
     assert torch.equal(out, want)
     assert torch.equal(ops.expand_rows(src[:0], torch.full((5,), -1, dtype=torch.int32, device=DEV)), torch.zeros(5, 256, device=DEV))
+    poisoned = ops.expand_rows(src, pos, fill=float('nan'))      # the logits of a rows-only forward: NaN where nobody may read
+    assert torch.equal(poisoned[mask], src) and bool(torch.isnan(poisoned[~mask]).all())
 
 
 def test_a_new_mask_every_step_falls_back_to_the_dense_backward():
@@ -588,12 +610,15 @@ def test_a_broken_promise_raises_and_never_reaches_the_weights(monkeypatch):
     mom = [{k: v.clone() for k, v in st.items() if torch.is_tensor(v)} for st in t.optimizer.state.values()]
     out = t.teacherGNN.get_3_embs(t.data.x, t.data.edge_index, loss_rows=(t.data.train_mask, t._n_train)).emb4classi_full
     loss = ops.nll_logsoftmax(out, t.data.y, t.data.train_mask, t._n_train) + 1e-3 * out.square().mean()      # ... and breaks the promise
+    steps_before = {id(p): st['step'] for p, st in t.optimizer.state.items()}
     t.optimizer.zero_grad()
     loss.backward()
     t.optimizer.step()
     torch.cuda.synchronize()
     with pytest.raises(_lib.HipExtensionError, match='outside the loss rows'):
         _lib.device_status()
+    # ... and the skipped launch is not a step: the counts behind the bias corrections are what they were
+    assert {id(p): st['step'] for p, st in t.optimizer.state.items()} == steps_before
     for k, v in t.teacherGNN.state_dict().items():
         assert torch.equal(v, before[k]), k
     for st, old in zip(t.optimizer.state.values(), mom):

@@ -372,8 +372,8 @@ def main():
                                      'link_bound_step_ms': a.dense_cover_ms / P + 2 * L * sum(t_link)})
                 del g_halo, g_send, halos, acc
             torch.cuda.empty_cache()
-        if 'cover' in row and 'pull' in row:      # the plan dist.ShardedGraph adopts: the cover where it spares >= COVER_MIN_GAIN of the rows
-            row['adopted'] = 'cover' if row['cover']['halo_rows'] <= (1.0 - cbdist.COVER_MIN_GAIN) * row['cover']['rows_pull_only'] else 'pull'
+        if 'cover' in row and 'pull' in row:      # the plan dist.ShardedGraph adopts: the cover where it spares >= tuning.T.cover_min_gain of the rows
+            row['adopted'] = 'cover' if row['cover']['halo_rows'] <= (1.0 - cbdist.T.cover_min_gain) * row['cover']['rows_pull_only'] else 'pull'
         out_rows.append(row)
         print(json.dumps(row), flush=True)
         del g_int, h, rr, cc, remote
