@@ -477,6 +477,54 @@ extern "C" int cb_gemm_tn_gdrop_f32(const float* A, int64_t lda, const float* G,
   return launch_tn<2, 2>(A, lda, G, ldg, nullptr, C, M, K1, K2, (float*)ws, st, &gd);
 }
 
+// The input stage of the fused trunk's backward INSIDE the input Linear's weight gradient (autograd of GCN.py:104-110 and of the mixes res_tricks.py:23):
+//   gy = (X0 > 0) * ( dropout_bwd_{g_seed}(g) + mfold )          [M, 256], never written
+//   C  = gy^T @ dropout_{x_seed}(X)                               [256, K2]   (= layers_MLP[0].weight.grad)
+//   colsum = column sums of gy                                    [256]       (= layers_MLP[0].bias.grad)
+// g = dL/d dropout(X0) (the dX of the first GCNConv), mfold = the folded mix gradients (cb_spmm_csr_store_bwd_mix_f32), x0_bits = mask words of (X0 > 0)
+// ([M][4] words), X = the UNdropped input features.  Replaces cb_trunk_input_bwd_multi_f32 + cb_gemm_tn_gdrop_f32: gy's 4 * 256 * M bytes are neither
+// written nor re-read.  One 256 x 128 tile of eight wavefronts per row slab: 64 < K2 <= 128, K2 % 4 == 0, both dropouts with p > 0, M large enough for
+// >= 256 slabs — cb_gemm_tn_instage_supported first.
+static inline int instage_splits(int64_t M) { return tn_splits(M, 2); }
+
+extern "C" int cb_gemm_tn_instage_supported(const float* g, const float* mfold, const float* X, int64_t ldx, int64_t M, int64_t K2) {
+  return use_limb3() && K2 > 64 && K2 <= 128 && K2 % 4 == 0 && ldx % 4 == 0 && ldx >= K2 && ldx < (1 << 22) && al16(g) && al16(mfold) && al16(X) && M > 0 &&
+                 instage_splits(M) >= 256
+             ? 1
+             : 0;
+}
+
+extern "C" size_t cb_gemm_tn_instage_workspace_bytes(int64_t M, int64_t K2) {
+  if (M <= 0 || K2 <= 0) return 0;
+  return (size_t)instage_splits(M) * (size_t)256 * (size_t)(K2 + 1) * sizeof(float);
+}
+
+extern "C" int cb_gemm_tn_instage_f32(const float* g, const float* mfold, const uint64_t* x0_bits, const float* X, int64_t ldx, float* C, float* colsum, int64_t M,
+                                      int64_t K2, float g_drop_p, uint64_t g_seed, float x_drop_p, uint64_t x_seed, const uint64_t* seed_dev, int64_t row0, void* ws,
+                                      size_t ws_bytes, void* stream) {
+  CB_CHECK_ARG(M > 0 && K2 > 0 && g_drop_p > 0.f && g_drop_p < 1.f && x_drop_p > 0.f && x_drop_p < 1.f && row0 >= 0, CB_E_INVALID,
+               "cb_gemm_tn_instage_f32: bad size or p (both dropouts must be active)");
+  CB_CHECK_ARG(g && mfold && x0_bits && X && C && colsum && (uintptr_t)x0_bits % 8 == 0, CB_E_INVALID, "cb_gemm_tn_instage_f32: null or misaligned pointer");
+  CB_CHECK_ARG(cb_gemm_tn_instage_supported(g, mfold, X, ldx, M, K2), CB_E_INVALID, "cb_gemm_tn_instage_f32: shape / alignment outside the fused form (cb_gemm_tn_instage_supported)");
+  CB_CHECK_ARG(ws && ws_bytes >= cb_gemm_tn_instage_workspace_bytes(M, K2), CB_E_WORKSPACE, "cb_gemm_tn_instage_f32: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nsplit = instage_splits(M);
+  int64_t rows_per_split = (M + nsplit - 1) / nsplit;
+  rows_per_split = (rows_per_split + 31) / 32 * 32;
+  const DropSpec xd{dropout_threshold(x_drop_p), 1.f / (1.f - x_drop_p), x_seed, seed_dev, row0, K2};
+  const DropSpec gd{dropout_threshold(g_drop_p), 1.f / (1.f - g_drop_p), g_seed, seed_dev, row0, 256};
+  float* partial = (float*)ws;
+  float* cs_partial = partial + (size_t)nsplit * 256 * K2;
+  const int rc = launch_tn_instage(g, mfold, x0_bits, X, ldx, partial, cs_partial, M, K2, nsplit, rows_per_split, st, xd, gd);
+  if (rc != CB_OK) return rc;
+  const int64_t n = 256 * K2;
+  hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)partial, nsplit, n, C);
+  CB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, (const float*)cs_partial, nsplit, (int64_t)256, colsum);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
 // C = act(rowscale * (dropout_{a_seed}(A) @ B) + addend + bias) with the dropout applied to A while it is staged (no dropped copy of A is
 // written, kept or re-read) — the input Linear of the residual trunk (GCN.py:104-107: A = x) and the first GCNConv's transform
 // (GCN.py:110 then :213,225,230-235: A = X0, the dropout in front of layer 0).  relu_bits (may be NULL; N == 256 and relu): [M][4] mask words

@@ -17,4 +17,9 @@ int launch_tn_limb3(const float* A, int64_t lda, const float* G, int64_t ldg, co
                     int64_t K1, int64_t K2, int bm, int nsplit, int64_t rows_per_split, hipStream_t st, const DropSpec* gdrop = nullptr,
                     const DropSpec* adrop = nullptr);
 
+// the input Linear's weight gradient with the trunk's input stage computed in its A operand's staging (k_gemm_tn_instage): partial [nsplit][256][K2],
+// cs_partial [nsplit][256]
+int launch_tn_instage(const float* g, const float* mfold, const uint64_t* x0_bits, const float* X, int64_t ldx, float* partial, float* cs_partial, int64_t M, int64_t K2,
+                      int nsplit, int64_t rows_per_split, hipStream_t st, const DropSpec& xd, const DropSpec& gd);
+
 }  // namespace cb

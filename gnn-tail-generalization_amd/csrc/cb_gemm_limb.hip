@@ -145,6 +145,74 @@ __global__ void __launch_bounds__((LTile<WM, WN, WTN, PD>::NTHR), (LTile<WM, WN,
     }
 }
 
+// ---- TN with the trunk's input stage as its A operand (cb_gemm_tn_instage_f32) ----------------------------------------------------------------
+// dW_in^T = gy^T @ dropout(x) with gy = (X0 > 0) * (dropout_bwd(g) + mfold) COMPUTED while it is staged (ColOperandInStage) — the [M, 256] matrix gy is
+// never written nor re-read; cs_partial[split][256] receives each slab's column sums of gy (the input Linear's bias gradient).  One 256 x 128 tile of
+// eight wavefronts per slab (the round-5 wide tile: each element staged once).
+__global__ void __launch_bounds__(512, 2) k_gemm_tn_instage(const float* __restrict__ g, const float* __restrict__ mfold,
+                                                            const unsigned long long* __restrict__ x0_bits, const float* __restrict__ X, int64_t ldx,
+                                                            float* __restrict__ partial, float* __restrict__ cs_partial, int64_t M, int K2,
+                                                            int64_t rows_per_split, int nsplit, DropSpec xd, DropSpec gd) {
+  using T = LTile<4, 2, 2>;
+  using OA = ColOperandInStage<T::NTHR>;
+  using OB = ColOperand<T::BN, false, true, T::NTHR>;
+  constexpr int K1 = 256;
+  __shared__ __attribute__((aligned(16))) char smem[2 * (OA::BYTES + OB::BYTES)];
+  const int split = blockIdx.x;
+  if (split >= nsplit) return;
+  const int64_t r_begin = (int64_t)split * rows_per_split;
+  const int64_t r_end = min(M, r_begin + rows_per_split);
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w / 2, wc = w % 2;
+
+  f32x16 acc[2][2];
+  zero_acc_n<2>(acc);
+  OA oa;
+  OB ob;
+  oa.init(K1, K1, t);
+  ob.init(ldx, K2, t);
+  oa.set_stage(g, mfold, x0_bits + r_begin * 4, gd, r_begin, r_end - r_begin, t);
+  ob.set_drop(xd, r_begin, r_end - r_begin, 0, t);
+  const uint32_t aaddr[2] = {OA::frag_addr(wr * 64, lane), OA::frag_addr(wr * 64 + 32, lane)};
+  uint32_t baddr[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) baddr[j] = OB::frag_addr(wc * 64 + 32 * j, lane);
+  limb_k_loop<2, 1, OA, OB>(oa, ob, smem, g + r_begin * K1, (int64_t)KS * K1, K1, X + r_begin * ldx, (int64_t)KS * ldx, ldx, nullptr, r_end - r_begin, aaddr, baddr,
+                            acc, t);
+  const int l31 = lane & 31, lh = lane >> 5;
+  float* P = partial + (int64_t)split * K1 * K2;
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const int n = wc * 64 + tj * 32 + l31;
+      if (n >= K2) continue;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int m = wr * 64 + ti * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        P[(int64_t)m * K2 + n] = acc[ti][tj][reg];
+      }
+    }
+  // the slab's column sums: wavefront w staged the k rows w, w + 8 of every K step; fixed order (the K loop ended with a block barrier: smem is free)
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[w * 256 + lane * 4 + i] = oa.cs[i];
+  __syncthreads();
+  if (t < 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += red[j * 256 + t];
+    cs_partial[(int64_t)split * 256 + t] = s;
+  }
+}
+
+int launch_tn_instage(const float* g, const float* mfold, const uint64_t* x0_bits, const float* X, int64_t ldx, float* partial, float* cs_partial, int64_t M, int64_t K2,
+                      int nsplit, int64_t rows_per_split, hipStream_t st, const DropSpec& xd, const DropSpec& gd) {
+  hipLaunchKernelGGL(k_gemm_tn_instage, dim3((unsigned)nsplit), dim3(512), 0, st, g, mfold, (const unsigned long long*)x0_bits, X, ldx, partial, cs_partial, M, (int)K2,
+                     rows_per_split, nsplit, xd, gd);
+  CB_LAUNCH_CHECK();
+  return CB_OK;
+}
+
 static inline bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
 // Register prefetch depth 1 everywhere (2 / 3 measured no gain: profiles/r01_*); the weight operand split once per launch and staged by

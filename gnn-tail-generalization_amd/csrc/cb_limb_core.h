@@ -200,6 +200,102 @@ struct ColOperand {
   }
 };
 
+// ---- "col" operand that is COMPUTED while it is staged: the trunk's input stage (cb_trunk_input_bwd_multi_f32 with the mix gradients folded,
+// cb_spmm_csr_store_bwd_mix_f32) as the A operand of the input Linear's weight gradient ----------------------------------------------------------
+//   value[r][c] = (x0_bits[r] has bit c) ? keep(seed, r, c) * g[r][c] + mfold[r][c] : 0        (autograd of GCN.py:104-110 + res_tricks.py:23)
+// g = dL/d dropout(X0) (the dX of the first GCNConv), mfold = the folded mix gradients, x0_bits = mask words of (X0 > 0): [rows][4] 64-bit words, word k
+// bit l <-> column 4 l + k.  256 columns, NT = 512 staging threads: one wavefront per k row (TPR = 64), so the row's four mask words are wave-uniform
+// (scalar loads) and bit `lane` of word i is this lane's column 4 lane + i.  The second stream's registers live in the operand (register prefetch depth 1).
+// cs[i]: running column sums of the staged values (the input Linear's bias gradient), columns 4 (t % 64) + i over the rows this thread stages.
+template <int NT = 512>
+struct ColOperandInStage {
+  static constexpr int C = 256;
+  static constexpr int ROWB = C * 2, PLANE = 16 * ROWB, BYTES = 3 * PLANE;
+  static constexpr int TPR = C / 4, KPP = NT / TPR, NV = 16 / KPP;
+  static_assert(TPR == 64 && KPP >= 4 && KPP % 4 == 0 && NV >= 1, "one wavefront per k row");
+  static constexpr int NC = C / 32;
+  static __device__ __forceinline__ int swz(int k) { return k & 3; }
+  uint32_t voff[NV];
+  uint32_t woff;
+  bool cok;
+  static constexpr bool HAS_SC = false;
+  float sc[1];
+  int64_t mdelta;                       // (mfold - g) in elements: the second stream is read at the first one's offsets
+  const unsigned long long* bits;       // mask words of this block's first row
+  float4 fm[NV];
+  unsigned long long bw[NV][4];
+  uint64_t dseed;
+  uint32_t dthresh;
+  float dscale;
+  int64_t drow, dtot, dwidth;
+  int dcol, kw;
+  float cs[4];
+  __device__ __forceinline__ void set_stage(const float* g, const float* mfold, const unsigned long long* bits_block, const DropSpec& d, int64_t r_begin, int64_t total,
+                                            int t) {
+    mdelta = mfold - g;
+    bits = bits_block;
+    dseed = d.seed_dev ? d.seed + *d.seed_dev : d.seed;
+    dthresh = d.thresh;
+    dscale = d.scale;
+    kw = __builtin_amdgcn_readfirstlane(t / TPR);
+    drow = d.row0 + r_begin + kw;
+    dtot = total;
+    dwidth = d.width;
+    dcol = (t % TPR) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cs[i] = 0.f;
+  }
+  __device__ __forceinline__ void init(int64_t ld, int cols_left, int t) {
+    const int k = t / TPR, nq = t % TPR;
+    cok = nq * 4 < cols_left;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) voff[j] = (uint32_t)((k + KPP * j) * ld + (cok ? nq * 4 : 0));
+    woff = k * ROWB + ((((nq >> 3) ^ swz(k)) & (NC - 1)) << 6) + ((nq & 7) << 3);
+  }
+  template <int J>
+  __device__ __forceinline__ void load(float4 (&f)[NV], const float* __restrict__ base, int64_t /*ld*/, int64_t k_left, const float* __restrict__, int /*t*/) {
+    const int k = kw + KPP * J;
+    const bool kin = k < k_left;
+    const float* p = base + (kin ? voff[J] : 0u);
+    f[J] = *reinterpret_cast<const float4*>(p);
+    fm[J] = *reinterpret_cast<const float4*>(p + mdelta);
+    const unsigned long long* b = bits + ((dtot - k_left) + (kin ? k : 0)) * 4;      // (wave-uniform address)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bw[J][i] = b[i];
+  }
+  template <int J>
+  __device__ __forceinline__ void stage(const float4 (&f)[NV], char* __restrict__ S, int64_t k_left, int t) {
+    const bool live = cok && kw + KPP * J < k_left;
+    const int lane = t & 63;
+    float mk[4];      // (no p == 0 branch: the K loop body stays one basic block; the entry point asks for p > 0)
+    keep4(dseed, ((drow + KPP * J + (dtot - k_left)) * dwidth + dcol) >> 2, dthresh, dscale, mk);
+    const float gv[4] = {f[J].x, f[J].y, f[J].z, f[J].w}, mv[4] = {fm[J].x, fm[J].y, fm[J].z, fm[J].w};
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float tsum = mul_rounded(gv[i], mk[i]) + mv[i];
+      v[i] = (live && ((bw[J][i] >> lane) & 1ull)) ? tsum : 0.f;
+      cs[i] += v[i];
+    }
+    uint2 pl[3];
+    split4(v, pl);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(S + p * PLANE + woff + J * (KPP * ROWB)) = pl[p];
+  }
+  static __device__ __forceinline__ uint32_t frag_addr(int c0, int lane) {
+    const int L = lane & 15, k = 8 * (lane >> 5) + (L >> 2);
+    return k * ROWB + ((((c0 >> 5) ^ swz(k)) & (NC - 1)) << 6) + (((lane >> 4) & 1) << 5) + ((L & 3) << 3);
+  }
+  static __device__ __forceinline__ bf16x8 frag(const char* __restrict__ S, uint32_t addr, int plane) {
+    const char* q = S + plane * PLANE + addr;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q + 4 * ROWB));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  }
+};
+
 // The producer side of the software pipeline: registers fa / fb hold K step s+1 on entry to the MFMAs of step s; piece p
 // stages its float4 into the LDS stage `dst` (if step s+1 exists) and re-fills it with step s+2 (if that exists).
 template <class OPA, class OPB>

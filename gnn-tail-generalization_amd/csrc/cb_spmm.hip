@@ -331,6 +331,128 @@ extern "C" int cb_spmm_csr_store_bwd_f32(const int32_t* rowptr, const int32_t* c
                                      (hipStream_t)stream, fe);
 }
 
+namespace cb {
+// partial[p][c], p < nparts, summed in groups of `per` consecutive rows: thread = column (coalesced), fixed order -> folded[g][c]
+__global__ void __launch_bounds__(256) k_colsum_fold(const float* __restrict__ partial, int nparts, int d, int per, float* __restrict__ folded) {
+  const int g = blockIdx.x;
+  const int p0 = g * per, p1 = min(nparts, p0 + per);
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = p0;
+    for (; p + 4 <= p1; p += 4) {
+      s0 += partial[(int64_t)p * d + c]; s1 += partial[(int64_t)(p + 1) * d + c];
+      s2 += partial[(int64_t)(p + 2) * d + c]; s3 += partial[(int64_t)(p + 3) * d + c];
+    }
+    for (; p < p1; ++p) s0 += partial[(int64_t)p * d + c];
+    folded[(int64_t)g * d + c] = (s0 + s1) + (s2 + s3);
+  }
+}
+// out[c] = sum_g folded[g][c]: 32 columns x 8 strided group lanes per block, fixed order
+__global__ void __launch_bounds__(256) k_colsum_last(const float* __restrict__ folded, int ngroups, int d, float* __restrict__ out) {
+  __shared__ float s_t[8][32];
+  const int cl = threadIdx.x & 31, gl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float s = 0.f;
+  if (c < d) {
+#pragma unroll 4
+    for (int g = gl; g < ngroups; g += 8) s += folded[(int64_t)g * d + c];
+  }
+  s_t[gl][cl] = s;
+  __syncthreads();
+  if (gl == 0 && c < d)
+    out[c] = ((s_t[0][cl] + s_t[1][cl]) + (s_t[2][cl] + s_t[3][cl])) + ((s_t[4][cl] + s_t[5][cl]) + (s_t[6][cl] + s_t[7][cl]));
+}
+constexpr int kFoldGroups = 1024;
+static inline int64_t mix_row_blocks(int64_t N) { return ((N + 15) / 16 + 3) / 4; }
+static inline int64_t mix_hub_blocks(int64_t n_hubs) { return (n_hubs + 3) / 4; }
+}  // namespace cb
+
+extern "C" size_t cb_spmm_store_bwd_mix_workspace_bytes(int64_t N, int64_t n_hubs, int64_t d) {
+  if (N <= 0 || d <= 0) return 0;
+  return (size_t)(mix_row_blocks(N) + mix_hub_blocks(n_hubs > 0 ? n_hubs : 0) + kFoldGroups) * (size_t)d * sizeof(float);
+}
+
+// cb_spmm_csr_store_bwd_f32 on ALL node rows whose first output is not the raw gradient g but the FOLDED mix gradient
+//   out_m = c_mix * ( dropout_bwd_seed(g) + sum_q dropout_bwd_{mix_seeds[q]}(mix_g[q][mix_pos[q][row]]) )        (n_mix <= 2 compact operands; pos < 0: absent)
+// — everything the layers above and this store send to X0 through their residual mixes (res_tricks.py:23, under each store's own dropout GCN.py:110,133),
+// so that the input stage (cb_gemm_tn_instage_f32) reads ONE [N, d] matrix beside dL/d dropout(X0) — and colsum (may be null) = the column sums of
+// out_gr / bwd_rowscale: the bias gradient of the store whose backward this is (autograd of GCN.py:253).  ws2: cb_spmm_store_bwd_mix_workspace_bytes.
+extern "C" int cb_spmm_csr_store_bwd_mix_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h,
+                                             int64_t d, const float* row_scale, const uint64_t* relu_bits, const float* bwd_rowscale, float c_act, float drop_p,
+                                             uint64_t seed, const uint64_t* seed_dev, int64_t row0, float* out_m, int64_t ld_m, float* out_gr, int64_t ld_gr,
+                                             int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,
+                                             size_t ws_bytes, int32_t n_mix, const float* const* mix_g, const int32_t* const* mix_pos, const uint64_t* mix_seeds,
+                                             float c_mix, float* colsum, void* ws2, size_t ws2_bytes, void* stream) {
+  CB_CHECK_ARG(N >= 0 && E >= 0 && d > 0 && d % 256 == 0, CB_E_INVALID, "cb_spmm_csr_store_bwd_mix_f32: d must be a positive multiple of 256");
+  CB_CHECK_ARG(N < INT32_MAX && E < INT32_MAX && d < (1 << 20), CB_E_RANGE, "cb_spmm_csr_store_bwd_mix_f32: size exceeds the int32 contract");
+  if (N == 0) return CB_OK;
+  CB_CHECK_ARG(rowptr && h && out_gr && out_m && relu_bits && (E == 0 || col), CB_E_INVALID, "cb_spmm_csr_store_bwd_mix_f32: null pointer");
+  CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && row0 >= 0, CB_E_INVALID, "cb_spmm_csr_store_bwd_mix_f32: dropout p / row offset out of range");
+  CB_CHECK_ARG(((uintptr_t)h % 16 == 0) && ((uintptr_t)out_gr % 16 == 0) && ((uintptr_t)out_m % 16 == 0) && ld_h % 4 == 0 && ld_gr % 4 == 0 && ld_m % 4 == 0 &&
+                   ld_h >= d && ld_gr >= d && ld_m >= d && ((uintptr_t)relu_bits % 8 == 0),
+               CB_E_INVALID, "cb_spmm_csr_store_bwd_mix_f32: 16-byte aligned rows required");
+  CB_CHECK_ARG(n_mix >= 0 && n_mix <= 2 && (n_mix == 0 || (mix_g && mix_pos && mix_seeds)), CB_E_INVALID, "cb_spmm_csr_store_bwd_mix_f32: 0..2 compact mix operands");
+  CB_CHECK_ARG(hub_T > 0 && n_hubs >= 0 && n_chunks >= 0, CB_E_INVALID, "cb_spmm_csr_store_bwd_mix_f32: bad hub plan");
+  CB_CHECK_ARG(n_hubs == 0 || (hub_rows && hub_chunk_ptr && ws && ws_bytes >= cb_spmm_workspace_bytes(n_chunks, d)), CB_E_WORKSPACE,
+               "cb_spmm_csr_store_bwd_mix_f32: hub plan given but workspace missing/too small");
+  CB_CHECK_ARG(!colsum || (ws2 && ws2_bytes >= cb_spmm_store_bwd_mix_workspace_bytes(N, n_hubs, d)), CB_E_WORKSPACE,
+               "cb_spmm_csr_store_bwd_mix_f32: column-sum workspace missing/too small");
+  if (n_hubs == 0) hub_T = INT32_MAX;
+  Epilogue ep{row_scale, nullptr, 0, nullptr, 0, col_flags};
+  FusedEpi fe{};
+  fe.bwd = 1; fe.bwd_rowscale = bwd_rowscale; fe.c_act = c_act;
+  fe.thresh = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
+  fe.keep_scale = 1.f / (1.f - drop_p);
+  fe.seed = seed; fe.seed_dev = seed_dev; fe.row0 = row0; fe.bits = (unsigned long long*)relu_bits;
+  fe.out_act = out_m; fe.ld_act = ld_m; fe.out_next = out_gr; fe.ld_next = ld_gr; fe.d = (int)d;
+  fe.mx_n = n_mix; fe.mx_c = c_mix;
+  for (int q = 0; q < n_mix; ++q) {
+    CB_CHECK_ARG(mix_g[q] && mix_pos[q] && (uintptr_t)mix_g[q] % 16 == 0, CB_E_INVALID, "cb_spmm_csr_store_bwd_mix_f32: null or misaligned mix operand %d", q);
+    fe.mx_g[q] = mix_g[q]; fe.mx_pos[q] = mix_pos[q]; fe.mx_seed[q] = mix_seeds[q];
+  }
+  fe.cs_partial = colsum ? (float*)ws2 : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  const int ny = (int)(d / 256);
+  const int64_t nb_rows = mix_row_blocks(N), nb_hub = n_hubs > 0 ? mix_hub_blocks(n_hubs) : 0;
+  {
+    dim3 grid((unsigned)nb_rows, ny);
+    fe.cs_block0 = 0;
+    if (col_flags)
+      hipLaunchKernelGGL((k_spmm_rows<4, 16, 8, true, true, float, false, 2, false, true>), grid, dim3(256), 0, st, rowptr, col, h, ld_h, out_gr, ld_gr, (int)N, (int)d, ep,
+                         hub_T, fe);
+    else
+      hipLaunchKernelGGL((k_spmm_rows<4, 16, 8, true, true, float, false, 0, false, true>), grid, dim3(256), 0, st, rowptr, col, h, ld_h, out_gr, ld_gr, (int)N, (int)d, ep,
+                         hub_T, fe);
+    CB_LAUNCH_CHECK();
+  }
+  if (n_hubs > 0) {
+    const int64_t ld_p = partial_ld(d);
+    dim3 grid((unsigned)((n_chunks + 3) / 4), ny);
+    if (col_flags)
+      hipLaunchKernelGGL((k_spmm_hub_chunks<4, 8, float, 2>), grid, dim3(256), 0, st, rowptr, col, h, ld_h, (int)d, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr,
+                         (float*)ws, ld_p, ep);
+    else
+      hipLaunchKernelGGL((k_spmm_hub_chunks<4, 8, float, 0>), grid, dim3(256), 0, st, rowptr, col, h, ld_h, (int)d, hub_T, n_hubs, n_chunks, hub_rows, hub_chunk_ptr,
+                         (float*)ws, ld_p, ep);
+    CB_LAUNCH_CHECK();
+    fe.cs_block0 = (int)nb_rows;
+    hipLaunchKernelGGL((k_spmm_hub_finish<4, true, true>), dim3((unsigned)nb_hub, ny), dim3(256), 0, st, (int)d, n_hubs, hub_rows, hub_chunk_ptr, (const float*)ws, ld_p,
+                       out_gr, ld_gr, ep, fe);
+    CB_LAUNCH_CHECK();
+  }
+  if (colsum) {
+    const int nparts = (int)(nb_rows + nb_hub);
+    const int per = (nparts + kFoldGroups - 1) / kFoldGroups;
+    const int ngroups = (nparts + per - 1) / per;
+    float* folded = (float*)ws2 + (size_t)nparts * d;
+    hipLaunchKernelGGL(k_colsum_fold, dim3((unsigned)ngroups), dim3(256), 0, st, (const float*)ws2, nparts, (int)d, per, folded);
+    CB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_colsum_last, dim3((unsigned)((d + 31) / 32)), dim3(256), 0, st, (const float*)folded, ngroups, (int)d, colsum);
+    CB_LAUNCH_CHECK();
+  }
+  return CB_OK;
+}
+
 // Fused store of the residual trunk on top of the interior-column partial sums (second pass of the node-sharded aggregation)
 extern "C" int cb_spmm_csr_fused_acc_f32(const float* acc_init, int64_t ld_init, const int32_t* rowptr, const int32_t* col, int32_t col_flags,
                                          int64_t N, int64_t E, const float* h, int64_t ld_h, int64_t d, const float* row_scale, const float* bias,

@@ -174,7 +174,51 @@ struct FusedEpi {
   const float* bwd_rowscale;
   const int32_t* row_ids; // or null.  The CSR's rows are a SUBSET of the node rows (row r = node row_ids[r]; rows-only forward, trunk.py): mix_src, the mask
                           // words and the dropout mask are taken at the node row, out_act / out_next (and row_scale, rowptr) at the compact row
+  // MIXB kernels (cb_spmm_csr_store_bwd_mix_f32: bwd, all node rows): the gradients that reach X0 through the residual mixes are FOLDED into one stream —
+  //   out_act = mx_c * ( keep(seed, row) * g  +  sum_q keep(mx_seed[q], row) * mx_g[q][mx_pos[q][row]] )        (a row with mx_pos < 0 is absent: zero)
+  // instead of the raw g: what the input stage adds to the gradient of dropout(X0) (the compact operands mx_g are the mix gradients of the layers above,
+  // each under its own store's dropout mask), so that the input stage reads ONE matrix instead of n + 1 — and cs_partial ([blocks][d]) receives the
+  // column sums of out_next / bwd_rowscale per block: the bias gradient of the store whose backward this epilogue applies
+  int mx_n;
+  const float* mx_g[2];
+  const int* mx_pos[2];
+  uint64_t mx_seed[2];
+  float mx_c;
+  float* cs_partial;
+  int cs_block0;          // (hub-finish launch: its blocks' partial rows follow the row kernel's)
 };
+
+// The MIXB form of fused_store's bwd branch (see FusedEpi).  xm[q] / xp[q]: operand q's row of this node row and its position (< 0: absent), fetched one
+// row ahead by the caller; cs: the wavefront's running column sums of c_act * keep * g under the mask word.
+__device__ __forceinline__ void fused_store_bwd_mix(const FusedEpi& fe, int64_t row, int c0, const float (&acc)[4], float scale, float (&x)[4],
+                                                    const float (&xm)[2][4], const int (&xp)[2], float (&cs)[4]) {
+  const uint64_t sd = fe.seed_dev ? *fe.seed_dev : 0ull;
+  const int64_t quad = ((fe.row0 + row) * fe.d + c0) >> 2;
+  float m[4] = {1.f, 1.f, 1.f, 1.f}, mm[4] = {0.f, 0.f, 0.f, 0.f};
+  if (fe.thresh) keep4(fe.seed + sd, quad, fe.thresh, fe.keep_scale, m);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (q < fe.mx_n && xp[q] >= 0) {      // (wave-uniform)
+      float mq[4] = {1.f, 1.f, 1.f, 1.f};
+      if (fe.thresh) keep4(fe.mx_seed[q] + sd, quad, fe.thresh, fe.keep_scale, mq);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mm[i] += fe.mx_c * (xm[q][i] * mq[i]);
+    }
+  }
+  const unsigned long long* bw = fe.bits + (row * (fe.d >> 8) + (c0 >> 8)) * 4;
+  const float rs = fe.bwd_rowscale ? fe.bwd_rowscale[row] : 1.f;
+  const int lane = lane_id();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float gm = scale_add(acc[i], scale, 0.f) * m[i];
+    mm[i] += fe.mx_c * gm;
+    const float t = ((bw[i] >> lane) & 1ull) ? fe.c_act * gm : 0.f;
+    cs[i] += t;
+    x[i] = t * rs;                       // (cb_trunk_layer_bwd_f32's expressions, in its order)
+  }
+  store_stream<4>(fe.out_act + row * fe.ld_act + c0, mm);
+  store_stream<4>(fe.out_next + row * fe.ld_next + c0, x);
+}
 
 // x: the values stored to out_next (also handed to the caller: cb_agg_gemm.hip keeps the finished row on chip)
 // grow: the node row of `row` (== row unless fe.row_ids)
@@ -255,13 +299,16 @@ __device__ __forceinline__ void gather_pol(float (&v)[VEC], const HT* __restrict
 // TLD > 0 (cb_agg_gemm.hip): every finished row is also written to an LDS tile — tile_lane = this lane's 4 columns of the
 // wavefront's local row 0, TLD floats per tile row.
 // P65 (64-row blocks, cb_agg_gemm.hip): lane i holds rowptr[r0 + i] for i < 64 and ptr_hi = rowptr[r0 + 64].
-template <int VEC, int U, bool FULL, bool FUSED, bool ACC, typename HT, int GP = 0, int TLD = 0, bool P65 = false, bool CS = false>
+template <int VEC, int U, bool FULL, bool FUSED, bool ACC, typename HT, int GP = 0, int TLD = 0, bool P65 = false, bool CS = false, bool MIXB = false>
 __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr_v, float my_scale, int r0, const int* __restrict__ col,
                                             const HT* __restrict__ h_lane, int64_t ld_h, float* __restrict__ out_lane,
                                             int64_t ld_out, bool active_in, int relu, const float (&bvec)[VEC], const FusedEpi& fe,
                                             int c0, const float* __restrict__ init_lane, int64_t ld_init, const Epilogue& ep,
-                                            float* tile_lane = nullptr, int ptr_hi = 0, int my_gid_v = 0) {
+                                            float* tile_lane = nullptr, int ptr_hi = 0, int my_gid_v = 0, int my_xp0 = 0, int my_xp1 = 0,
+                                            float* cs_acc = nullptr) {
   // my_gid_v (FUSED with fe.row_ids): lane i holds the node row of local row i
+  // MIXB (FusedEpi): my_xp0 / my_xp1: lane i holds the position of local row i in the compact operands; cs_acc: the wavefront's 4 running column sums
+  static_assert(!MIXB || (FUSED && VEC == 4 && FULL && !ACC && TLD == 0 && !P65), "folded mix gradients: the fused d % 256 == 0 kernel on all node rows");
   static_assert(TLD == 0 || (VEC == 4 && FULL), "on-chip row tile: d == 256, float4 lanes");
   static_assert(!CS || (!P65 && !FUSED && !ACC && sizeof(HT) == 4), "source-row factor: plain fp32 aggregation only");
   struct PtrAt {      // rowptr of local row i (wave-uniform i)
@@ -289,6 +336,18 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
       for (int i = 0; i < VEC; ++i) rmix[i] = t[i];
     }
   }
+  float xm[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // MIXB: the compact operands' rows of local row `cur`, fetched one row ahead
+  int xp[2] = {-1, -1};
+  auto fetch_mix = [&](int i) {
+    if constexpr (MIXB) {
+      xp[0] = fe.mx_n > 0 ? bcast_lane(my_xp0, i) : -1;
+      xp[1] = fe.mx_n > 1 ? bcast_lane(my_xp1, i) : -1;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (xp[q] >= 0) gather_stream<4>(xm[q], fe.mx_g[q] + (int64_t)xp[q] * fe.d + c0);
+    }
+  };
+  if constexpr (MIXB) fetch_mix(rlo);
   const int lane = lane_id();
   const int e_begin = my_ptr_at(rlo);
   const int e_end = my_ptr_at(rhi);
@@ -319,7 +378,13 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
 #pragma unroll
       for (int i = 0; i < 4; ++i) { a4[i] = acc[i % VEC]; b4[i] = bvec[i % VEC]; }
       float x4[4];
-      fused_store(fe, (int64_t)(r0 + cur), c0, a4, s, b4, rmix, x4, gid_of(cur));
+      if constexpr (MIXB) {
+        float (&csr)[4] = *reinterpret_cast<float (*)[4]>(cs_acc);
+        fused_store_bwd_mix(fe, (int64_t)(r0 + cur), c0, a4, s, x4, xm, xp, csr);
+        if (cur + 1 < rhi) fetch_mix(cur + 1);
+      } else {
+        fused_store(fe, (int64_t)(r0 + cur), c0, a4, s, b4, rmix, x4, gid_of(cur));
+      }
       if constexpr (TLD > 0) *reinterpret_cast<float4*>(tile_lane + cur * TLD) = make_float4(x4[0], x4[1], x4[2], x4[3]);
       if (fe.mix_src && cur + 1 < nr) {
         float t[VEC];
@@ -432,7 +497,21 @@ __device__ __forceinline__ void stream_rows(int rlo, int rhi, int nr, int my_ptr
   while (cur < rhi) flush();  // last row + trailing empty rows
 }
 
-template <int VEC, int RPW, int U, bool FULL, bool FUSED, typename HT, bool ACC = false, int GP = 0, bool CS = false>
+// The wavefronts' running column sums (MIXB: FusedEpi::cs_partial) -> one partial row per block: fixed order, no atomics.  All threads of the block call it.
+__device__ __forceinline__ void block_colsum_store(const float (&cs)[4], float* __restrict__ partial_row, int c0, bool live) {
+  __shared__ float s_cs[4][256 + 4];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s_cs[w][lane * 4 + i] = live ? cs[i] : 0.f;
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      partial_row[c0 + i] = ((s_cs[0][lane * 4 + i] + s_cs[1][lane * 4 + i]) + s_cs[2][lane * 4 + i]) + s_cs[3][lane * 4 + i];
+  }
+}
+
+template <int VEC, int RPW, int U, bool FULL, bool FUSED, typename HT, bool ACC = false, int GP = 0, bool CS = false, bool MIXB = false>
 __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                    const HT* __restrict__ h, int64_t ld_h, float* __restrict__ out,
                                                    int64_t ld_out, int n_rows, int d, Epilogue ep, int hub_T, FusedEpi fe) {
@@ -441,7 +520,15 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
   const int lane = lane_id();
   const int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int r0 = wave * RPW;
-  if (r0 >= n_rows) return;
+  float cs_acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (MIXB) {      // (no early exit: every wavefront of the block takes part in the column sums' hand-over)
+    if (r0 >= n_rows) {
+      if (fe.cs_partial) block_colsum_store(cs_acc, fe.cs_partial + (int64_t)(fe.cs_block0 + blockIdx.x) * d + blockIdx.y * 256, lane * 4, false);
+      return;
+    }
+  } else {
+    if (r0 >= n_rows) return;
+  }
   const int nr = min(RPW, n_rows - r0);
   const int c0 = (blockIdx.y * kWave + lane) * VEC;  // this lane's first column
   const bool active = c0 < d;
@@ -455,6 +542,11 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
   if constexpr (FUSED) {
     if (fe.row_ids && lane < nr) my_gid = fe.row_ids[r0 + lane];
   }
+  int my_xp0 = -1, my_xp1 = -1;      // MIXB: lane i holds the position of local row i in the compact operands
+  if constexpr (MIXB) {
+    if (fe.mx_n > 0 && lane < nr) my_xp0 = __builtin_nontemporal_load(fe.mx_pos[0] + r0 + lane);
+    if (fe.mx_n > 1 && lane < nr) my_xp1 = __builtin_nontemporal_load(fe.mx_pos[1] + r0 + lane);
+  }
 
   float bvec[VEC];
   zero<VEC>(bvec);
@@ -467,18 +559,21 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const int* __restrict__ rowpt
   const float* init_lane = ACC ? ep.acc_init + c0 : nullptr;
 
   if (hubmask == 0) {
-    stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP, 0, false, CS>(0, nr, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0,
-                                                    init_lane, ep.ld_init, ep, nullptr, 0, my_gid);
+    stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP, 0, false, CS, MIXB>(0, nr, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe, c0,
+                                                    init_lane, ep.ld_init, ep, nullptr, 0, my_gid, my_xp0, my_xp1, cs_acc);
   } else {
     int r = 0;
     while (r < nr) {  // maximal hub-free runs; hub rows are written by the hub kernels
       unsigned long long m = hubmask >> r;
       int nh = m ? r + (__ffsll((long long)m) - 1) : nr;
       if (nh > r)
-        stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP, 0, false, CS>(r, nh, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe,
-                                                        c0, init_lane, ep.ld_init, ep, nullptr, 0, my_gid);
+        stream_rows<VEC, U, FULL, FUSED, ACC, HT, GP, 0, false, CS, MIXB>(r, nh, nr, my_ptr, my_scale, r0, col, h_lane, ld_h, out_lane, ld_out, active, ep.relu, bvec, fe,
+                                                        c0, init_lane, ep.ld_init, ep, nullptr, 0, my_gid, my_xp0, my_xp1, cs_acc);
       r = nh + 1;
     }
+  }
+  if constexpr (MIXB) {
+    if (fe.cs_partial) block_colsum_store(cs_acc, fe.cs_partial + (int64_t)(fe.cs_block0 + blockIdx.x) * d + blockIdx.y * 256, lane * 4, true);
   }
 }
 
@@ -559,14 +654,22 @@ __global__ void __launch_bounds__(256) k_spmm_hub_chunks(const int* __restrict__
 }
 
 // One wavefront per hub row: partials summed in chunk order, then the epilogue.
-template <int VEC, bool FUSED>
+template <int VEC, bool FUSED, bool MIXB = false>
 __global__ void __launch_bounds__(256) k_spmm_hub_finish(int d, int n_hubs, const int* __restrict__ hub_rows,
                                                          const int* __restrict__ hub_chunk_ptr,
                                                          const float* __restrict__ partial, int64_t ld_p,
                                                          float* __restrict__ out, int64_t ld_out, Epilogue ep, FusedEpi fe) {
   const int lane = lane_id();
   const int i = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  if (i >= n_hubs) return;
+  float cs_acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (MIXB) {      // (d % 256 == 0: every lane has columns; every wavefront of the block hands its column sums over)
+    if (i >= n_hubs) {
+      if (fe.cs_partial) block_colsum_store(cs_acc, fe.cs_partial + (int64_t)(fe.cs_block0 + blockIdx.x) * d + blockIdx.y * 256, lane * 4, false);
+      return;
+    }
+  } else {
+    if (i >= n_hubs) return;
+  }
   const int c0 = (blockIdx.y * kWave + lane) * VEC;
   if (c0 >= d) return;
   const int row = hub_rows[i];
@@ -603,7 +706,19 @@ __global__ void __launch_bounds__(256) k_spmm_hub_finish(int d, int n_hubs, cons
       for (int k = 0; k < VEC; ++k) rmix[k] = t[k];
     }
     float x4[4];
-    fused_store(fe, (int64_t)row, c0, a4, s, b4, rmix, x4, grow);
+    if constexpr (MIXB) {
+      float xm[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      int xp[2] = {-1, -1};
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (q < fe.mx_n) xp[q] = fe.mx_pos[q][row];
+        if (xp[q] >= 0) gather_stream<4>(xm[q], fe.mx_g[q] + (int64_t)xp[q] * fe.d + c0);
+      }
+      fused_store_bwd_mix(fe, (int64_t)row, c0, a4, s, x4, xm, xp, cs_acc);
+      if (fe.cs_partial) block_colsum_store(cs_acc, fe.cs_partial + (int64_t)(fe.cs_block0 + blockIdx.x) * d + blockIdx.y * 256, lane * 4, true);
+    } else {
+      fused_store(fe, (int64_t)row, c0, a4, s, b4, rmix, x4, grow);
+    }
   } else {
     {
       if (ep.lp_mix) {      // label-propagation store (narrow rows only ever set it)

@@ -245,6 +245,36 @@ def mm_tn_gdrop(a, g, p, g_seed, row0=0):
     return out
 
 
+def mm_tn_instage_supported(g_like, x, M):
+    """The input stage inside the input Linear's weight gradient exists for this shape (cb_gemm_tn_instage_supported): hidden 256, 64 < F <= 128, enough rows."""
+    lib = _lib.load()
+    return (g_like.dim() == 2 and g_like.shape[1] == 256 and g_like.is_contiguous() and x.dim() == 2 and x.stride(1) == 1
+            and bool(lib.cb_gemm_tn_instage_supported(_lib.ptr(g_like), _lib.ptr(g_like), _lib.ptr(x), _ld(x), int(M), int(x.shape[1]))))
+
+
+def mm_tn_instage(g, mfold, x0_bits, x, p_g, g_seed, p_x, x_seed, row0=0):
+    """(layers_MLP[0].weight.grad [256, F], layers_MLP[0].bias.grad [256]) of the fused trunk with its input stage computed while the GEMM stages it
+    (cb_gemm_tn_instage_f32): gy = (X0 > 0) * (dropout_bwd_{g_seed}(g) + mfold) is never written; the results are gy^T @ dropout_{x_seed}(x) and gy's
+    column sums.  g: dL/d dropout(X0) [M, 256]; mfold: the folded mix gradients (graph.CSRGraph.spmm_store_bwd(mix=...)); x0_bits: int64 [M, 1, 4]."""
+    import ctypes
+    from . import ops
+    lib = _lib.load()
+    _lib.require_device(g, mfold, x0_bits, x)
+    M, K2 = x.shape
+    if (tuple(g.shape) != (M, 256) or tuple(mfold.shape) != (M, 256) or not g.is_contiguous() or not mfold.is_contiguous() or x0_bits.numel() != 4 * M
+            or not x0_bits.is_contiguous() or x0_bits.dtype != torch.int64):
+        raise ValueError('mm_tn_instage: contiguous [M, 256] gradients, [M, 1, 4] int64 mask words and [M, F] features expected')
+    out = torch.empty((256, K2), dtype=torch.float32, device=g.device)
+    colsum = torch.empty(256, dtype=torch.float32, device=g.device)
+    wsb = lib.cb_gemm_tn_instage_workspace_bytes(M, K2)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=g.device)
+    with torch.cuda.device(g.device):
+        _lib.check(lib.cb_gemm_tn_instage_f32(_lib.ptr(g), _lib.ptr(mfold), _lib.ptr(x0_bits), _lib.ptr(x), _ld(x), _lib.ptr(out), _lib.ptr(colsum), M, K2,
+                                              float(p_g), ctypes.c_uint64(g_seed), float(p_x), ctypes.c_uint64(x_seed), ops.seed_dev_ptr(), int(row0),
+                                              _lib.ptr(ws), wsb, _lib.stream_ptr()), 'cb_gemm_tn_instage_f32')
+    return out, colsum
+
+
 def mm_tn(a, g, rowscale=None):
     """a^T @ (rowscale[:,None] * g): a [M,K1], g [M,K2] -> [K1,K2]; deterministic split reduction over M."""
     lib = _lib.load()

@@ -198,11 +198,14 @@ class CSRGraph:
         builds, hits = getattr(self, '_support_builds', 0), getattr(self, '_support_hits', 0)
         return builds < 4 or hits >= 3 * builds
 
-    def spmm_store_bwd(self, h, row_scale, bits, bwd_rowscale, c_act, p, seed, row0, row_ids=None):
+    def spmm_store_bwd(self, h, row_scale, bits, bwd_rowscale, c_act, p, seed, row0, row_ids=None, mix=None):
         """(g, gr) of cb_spmm_csr_store_bwd_f32 over this (forward-orientation) CSR: g = row_scale * sum of the gathered rows, gr = the backward of the
         trunk's store applied to g (mask words `bits` of the written rows, dropout mask of `seed`, factor c_act, row factor bwd_rowscale) — the plain
         aggregation followed by cb_trunk_layer_bwd_f32 without the pass's read of g.  h float32 [n_cols, d], d % 256 == 0.  row_ids (int32 [N]): this CSR's rows
-        are a subset of the node rows (a compact level) — bits / bwd_rowscale / the dropout mask at the node row, row_scale and the results compact."""
+        are a subset of the node rows (a compact level) — bits / bwd_rowscale / the dropout mask at the node row, row_scale and the results compact.
+        mix = (operands, positions, seeds, c_mix, want_colsum) (all node rows only; <= 2 compact operands [n_q, d] with int32 position maps [N]): the first
+        result is the FOLDED mix gradient c_mix * (dropout_bwd(g) + sum_q dropout_bwd_q(operand_q)) instead of g, and a third result = the column sums of
+        gr / bwd_rowscale (the store's bias gradient) or None (cb_spmm_csr_store_bwd_mix_f32)."""
         import ctypes
         from . import ops
         lib = _lib.load()
@@ -223,6 +226,27 @@ class CSRGraph:
         if prof is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
+        if mix is not None:
+            ops_, pos_, seeds_, c_mix, want_cs = mix
+            if row_ids is not None or len(ops_) > 2 or any(q is None for q in pos_):
+                raise ValueError('spmm_store_bwd(mix=...): all node rows, at most two compact operands with position maps')
+            k = len(ops_)
+            colsum = torch.empty(d, dtype=torch.float32, device=h.device) if want_cs else None
+            ws2b = lib.cb_spmm_store_bwd_mix_workspace_bytes(self.N, plan.n_hubs, d) if want_cs else 0
+            ws2 = torch.empty(max(ws2b, 16), dtype=torch.uint8, device=h.device) if want_cs else None
+            with torch.cuda.device(h.device):
+                _lib.check(lib.cb_spmm_csr_store_bwd_mix_f32(
+                    _lib.ptr(self.rowptr), _lib.ptr(col_k if flags else self.col), flags, self.N, self.E, _lib.ptr(h), h.stride(0), d, _lib.ptr(row_scale), _lib.ptr(bits),
+                    _lib.ptr(bwd_rowscale), float(c_act), float(p), ctypes.c_uint64(seed), ops.seed_dev_ptr(), int(row0), _lib.ptr(g), d, _lib.ptr(gr), d, self.hub_threshold,
+                    plan.n_hubs, plan.n_chunks, _lib.ptr(plan.hub_rows), _lib.ptr(plan.hub_chunk_ptr), _lib.ptr(ws), wsb, k,
+                    (ctypes.c_void_p * max(k, 1))(*[t.data_ptr() for t in ops_]), (ctypes.c_void_p * max(k, 1))(*[q.data_ptr() for q in pos_]),
+                    (ctypes.c_uint64 * max(k, 1))(*[int(s_) for s_ in seeds_]), float(c_mix), _lib.ptr(colsum), _lib.ptr(ws2), ws2b, _lib.stream_ptr()),
+                    'cb_spmm_csr_store_bwd_mix_f32')
+            if prof is not None:
+                ev1.record()
+                extra = sum(int(t.numel()) * 4 for t in ops_)
+                prof.append(prof_rec(ev0, ev1, self, 'store_bwd', self.algorithmic_bytes(d, row_scale=row_scale is not None, bias=False), self.N * d * 4 + self.N * d // 8 + extra))
+            return g, gr, colsum
         with torch.cuda.device(h.device):
             _lib.check(lib.cb_spmm_csr_store_bwd_f32(_lib.ptr(self.rowptr), _lib.ptr(col_k if flags else self.col), flags, self.N, self.E, _lib.ptr(h), h.stride(0), d,
                                                      _lib.ptr(row_scale), _lib.ptr(bits), _lib.ptr(bwd_rowscale), float(c_act), float(p), ctypes.c_uint64(seed),

@@ -728,6 +728,16 @@ class _Backward:
         self.ag = agg_gemm_eligible(graph, self.h, agg_bf16)
         self.chunked = (self.gather and _chunked(graph, agg_bf16) and graph.b.plan.n_slices > 1 and not self.ag)
         self.tail_tb = self.ag and self.gather and not residual and tail_trunk_bwd(graph)      # (the accumulate-in-place form needs the pass: it also adds into gx0)
+        # Round 6 — the input stage without a pass of its own: the reverse aggregation that writes all rows and applies layer 0's store backward in its epilogue
+        # (_layer_source_side) FOLDS every mix gradient known by then into one matrix (cb_spmm_csr_store_bwd_mix_f32: it holds layer 0's in registers, the
+        # compact ones of the layers above are gathered per row) and takes layer 0's bias gradient; the input Linear's weight gradient then computes
+        # gy = (X0 > 0) * (dropout_bwd(dL/d dropout(X0)) + fold) while it stages it (cb_gemm_tn_instage_f32).  gy's [N, 256] write + read and the n + 1
+        # operand reads of cb_trunk_input_bwd_multi_f32 disappear (S-pl10M: 20 GB per step).  'Initial', one GPU, gathered mix gradients, dropout active,
+        # features staged undropped, no gradient w.r.t. the features.  CB_INSTAGE_FOLD=0: the separate pass.
+        self.fold_ok = (os.environ.get('CB_INSTAGE_FOLD', '1') != '0' and self.gather and not residual and not self.sharded and not agg_bf16 and p > 0
+                        and ctx.indrop and self.need[3] and not self.need[2] and self.x0_bits is not None and self.h == 256
+                        and gemm.mm_tn_instage_supported(self.x0, self.xd, self.x0.shape[0]))
+        self.mfold = None      # the folded mix gradients, once a level produced them
 
     # -- small helpers -------------------------------------------------------------------------------------------------------------------
     def seed(self, i):
@@ -848,8 +858,17 @@ class _Backward:
                 ids = getattr(dst, '_ids32', None)
                 if ids is None:
                     ids = dst._ids32 = dst.idx.to(torch.int32).contiguous()
-            g_new, gr_below = level[0].spmm_store_bwd(t, dst.a if dst is not None else self.a, self.saved_bits[l - 1], self.bnorm, 1 - self.alpha, self.p,
-                                                      self.seed(l + 1), self.row0, row_ids=ids)
+            fold = (self.fold_ok and l == 1 and dst is None and len(self.g_mix) <= 2 and all(q is not None for q in self.mix_pos)
+                    and not getattr(self, '_cs', []))
+            if fold:      # (g_mix holds the mix gradients of the layers above, compact on their supports; layer 0's own is this aggregation's sum)
+                self.mfold, gr_below, db0 = level[0].spmm_store_bwd(t, self.a, self.saved_bits[0], self.bnorm, 1 - self.alpha, self.p, self.seed(2), self.row0,
+                                                                    mix=(self.g_mix, self.mix_pos, self.seeds_mix, self.alpha, self.need_b(0)))
+                self.grads_layers[1] = db0
+                self.g_mix, self.mix_pos, self.seeds_mix = [], [], []      # folded: the input stage reads self.mfold instead
+                g_new = None
+            else:
+                g_new, gr_below = level[0].spmm_store_bwd(t, dst.a if dst is not None else self.a, self.saved_bits[l - 1], self.bnorm, 1 - self.alpha, self.p,
+                                                          self.seed(l + 1), self.row0, row_ids=ids)
             self._fused_store_bwd = (gr_below, l - 1)
         else:
             g_new = level[0].spmm(t, row_scale=dst.a if dst is not None else self.a)
@@ -951,7 +970,7 @@ class _Backward:
         deferred = None        # (layer, X_l, dZ_l): weight gradient of the layer above, computed under this layer's halo exchange
         for l in range(L - 1, -1, -1):
             w, b, le = self.lp[l]
-            if gather and (not self.residual or l == 0):      # this layer's mix reads X0: its gradient is gathered by the input stage
+            if gather and (not self.residual or l == 0) and self.mfold is None:      # this layer's mix reads X0: its gradient is gathered by the input stage
                 self.g_mix.append(g)
                 self.mix_pos.append(space.pos if space is not None else None)
                 self.seeds_mix.append(self.seed(l + 2))
@@ -995,7 +1014,9 @@ class _Backward:
             space = dst
             if l > 0 and source_side and getattr(self, '_fused_store_bwd', None) is not None:
                 g, (gr, _below), dbias = g_new, self._fused_store_bwd, None      # (dbias of layer l - 1: an extra column sum of the input stage)
-                if self.need_b(l - 1):
+                if self.mfold is not None:      # (folded: the epilogue took that bias gradient itself)
+                    dbias = self.grads_layers[3 * (l - 1) + 1]
+                elif self.need_b(l - 1):
                     self._cs = getattr(self, '_cs', []) + [(len(self.g_mix), self.saved_bits[l - 1], 1 - alpha, l - 1)]
                 self._fused_store_bwd = None
             elif l > 0 and dst is not None:      # the store backward of layer l-1 on the rows of S_{j+1}
@@ -1019,6 +1040,12 @@ class _Backward:
         if deferred is not None:
             self.grads_layers[3 * deferred[0]] = self._dw_rows(*deferred)
         # input stage: X0 feeds layer 0 (through its dropout) and the mixes
+        if self.mfold is not None:      # folded mix gradients (see __init__): the stage is computed inside the input Linear's weight gradient — no pass, no gpre
+            d_w_in, d_b_in = gemm.mm_tn_instage(g, self.mfold, self.x0_bits, self.xd, p, self.seed(1), p, self.seeds[0], self.row0)
+            del g
+            self.gx0 = self.g_mix = self.mfold = None
+            graph.instage_folds = getattr(graph, 'instage_folds', 0) + 1      # (tests, bench)
+            return (None, None, None, d_w_in, d_b_in if need[4] else None, self.d_w_out, self.d_b_out, *self.grads_layers)
         if gather:
             cs = getattr(self, '_cs', [])
             res = _input_bwd_multi(g, self.seed(1), self.g_mix, self.seeds_mix, alpha, self.x0, p, self.row0, act_bits=self.x0_bits,

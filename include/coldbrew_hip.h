@@ -324,6 +324,20 @@ int cb_spmm_csr_store_bwd_f32(const int32_t* rowptr, const int32_t* col, int32_t
                               uint64_t seed, const uint64_t* seed_dev, int64_t row0, float* out_g, int64_t ld_g, float* out_gr, int64_t ld_gr,
                               int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,
                               size_t ws_bytes, const int32_t* row_ids, void* stream);
+/* The same on ALL node rows, with the mix gradients FOLDED (round 6): the first output is not the raw g but everything this store and the layers above
+ * send to X0 through their residual mixes (InitialConnection, res_tricks.py:19-23: X = (1 - alpha) X_l + alpha X_0, each under its own store's dropout
+ * GCN.py:110,133):
+ *   out_m = c_mix * ( dropout_bwd_seed(g) + sum_q dropout_bwd_{mix_seeds[q]}(mix_g[q][mix_pos[q][v]]) )          n_mix <= 2 compact operands (host arrays);
+ * mix_pos[q] (int32 [N]): position of node row v in operand q, < 0 where it holds no such row.  out_gr as above (bit-identical).  colsum (may be NULL; [d]) =
+ * column sums of out_gr / bwd_rowscale: the bias gradient (GCN.py:253) of the store whose backward this is; ws2 = cb_spmm_store_bwd_mix_workspace_bytes.
+ * The input stage then reads ONE [N, d] matrix beside dL/d dropout(X0): cb_gemm_tn_instage_f32. */
+size_t cb_spmm_store_bwd_mix_workspace_bytes(int64_t N, int64_t n_hubs, int64_t d);
+int cb_spmm_csr_store_bwd_mix_f32(const int32_t* rowptr, const int32_t* col, int32_t col_flags, int64_t N, int64_t E, const float* h, int64_t ld_h,
+                                  int64_t d, const float* row_scale, const uint64_t* relu_bits, const float* bwd_rowscale, float c_act, float drop_p,
+                                  uint64_t seed, const uint64_t* seed_dev, int64_t row0, float* out_m, int64_t ld_m, float* out_gr, int64_t ld_gr,
+                                  int32_t hub_T, int32_t n_hubs, int32_t n_chunks, const int32_t* hub_rows, const int32_t* hub_chunk_ptr, void* ws,
+                                  size_t ws_bytes, int32_t n_mix, const float* const* mix_g, const int32_t* const* mix_pos, const uint64_t* mix_seeds,
+                                  float c_mix, float* colsum, void* ws2, size_t ws2_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * bf16-storage variant of the aggregation (build extension = BASELINE config 2; the reference is fp32-only):
@@ -577,6 +591,19 @@ int cb_gemm_tn_adrop_f32(const float* A, int64_t lda, const float* G, int64_t ld
 int cb_gemm_tn_gdrop_supported(const float* A, int64_t lda, const float* G, int64_t ldg, int64_t K1, int64_t K2);
 int cb_gemm_tn_gdrop_f32(const float* A, int64_t lda, const float* G, int64_t ldg, float* C, int64_t M, int64_t K1, int64_t K2, float g_drop_p,
                          uint64_t g_seed, const uint64_t* seed_dev, int64_t row0, void* ws, size_t ws_bytes, void* stream);
+/* The input stage of the fused trunk's backward INSIDE the input Linear's weight gradient (round 6; autograd of GCN.py:104-110 — F.dropout(x),
+ * layers_MLP[0], F.relu, F.dropout — and of the mixes res_tricks.py:23):
+ *     gy = (X0 > 0) * ( dropout_bwd_{g_seed}(g) + mfold )          [M, 256], computed while it is staged as the A operand: never written, never re-read
+ *     C  = gy^T @ dropout_{x_seed}(X)                               [256, K2] = layers_MLP[0].weight.grad
+ *     colsum = column sums of gy                                    [256]     = layers_MLP[0].bias.grad
+ * g = dL/d dropout(X0) (the dX of the first GCNConv), mfold = the folded mix gradients (cb_spmm_csr_store_bwd_mix_f32), x0_bits = [M][4] mask words of
+ * (X0 > 0) (cb_gemm_nn_indrop_*'s relu_bits), X = the undropped features.  Replaces cb_trunk_input_bwd_multi_f32 + cb_gemm_tn_gdrop_f32 (2 * 4 * 256 * M bytes
+ * less traffic).  64 < K2 <= 128, K2 % 4 == 0, both dropouts active, >= 256 row slabs: cb_gemm_tn_instage_supported first. */
+int cb_gemm_tn_instage_supported(const float* g, const float* mfold, const float* X, int64_t ldx, int64_t M, int64_t K2);
+size_t cb_gemm_tn_instage_workspace_bytes(int64_t M, int64_t K2);
+int cb_gemm_tn_instage_f32(const float* g, const float* mfold, const uint64_t* x0_bits, const float* X, int64_t ldx, float* C, float* colsum, int64_t M, int64_t K2,
+                           float g_drop_p, uint64_t g_seed, float x_drop_p, uint64_t x_seed, const uint64_t* seed_dev, int64_t row0, void* ws, size_t ws_bytes,
+                           void* stream);
 
 /* cb_spmm_gemm_f32 (reverse aggregation + dX contraction) + the trunk backward of the layer below from the same epilogue: g_out is
  * dL/dx of the stage above layer l-1; gr_out = c_act * dropout_bwd_{seed}(g_out) * relu_bits * rowscale2 (input of the next reverse

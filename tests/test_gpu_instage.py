@@ -1,0 +1,118 @@
+"""GPU: the trunk's input stage without a pass of its own (round 6).  The reverse aggregation that applies layer 0's store backward folds every mix
+gradient into one matrix (cb_spmm_csr_store_bwd_mix_f32) and the input Linear's weight gradient computes (X0 > 0) * (dropout_bwd(g) + fold) while it
+stages it (cb_gemm_tn_instage_f32) — autograd of GCN.py:104-110 and res_tricks.py:19-23.  Both kernels against plain torch formulas built from the
+product's own keep-masks (cb_dropout_f32 of ones), and the fused step against the step with the separate pass (CB_INSTAGE_FOLD=0)."""
+import os
+
+import pytest
+import torch
+
+from gnn_tail_generalization_amd import tuning
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _mask_words(active):
+    """[rows, 256] bool -> int64 [rows, 1, 4]: word k, bit l <-> column 4 l + k (the layout of the fused stores' mask words)."""
+    rows = active.shape[0]
+    a = active.view(rows, 64, 4).permute(0, 2, 1).to(torch.int64)                    # [rows, k, l]
+    w = (a << torch.arange(64, device=active.device, dtype=torch.int64)).sum(-1)     # bit 63 wraps into the sign: the same 64 bits
+    return w.view(rows, 1, 4).contiguous()
+
+
+def _keep(shape, p, seed, offset=0):
+    from gnn_tail_generalization_amd import ops
+    return ops._dropout_raw(torch.ones(shape, device=DEV), p, seed, offset)         # keep ? 1 / (1 - p) : 0
+
+
+@pytest.mark.parametrize('rows,feats', [(300000, 128), (262144 + 77, 100)])
+def test_weight_gradient_with_the_input_stage_in_its_staging(rows, feats):
+    from gnn_tail_generalization_amd import gemm
+    torch.manual_seed(3)
+    g = torch.randn(rows, 256, device=DEV)
+    mfold = torch.randn(rows, 256, device=DEV) * 0.3
+    x = torch.rand(rows, feats, device=DEV)
+    active = torch.rand(rows, 256, device=DEV) < 0.55
+    bits = _mask_words(active)
+    p, sg, sx, row0 = 0.1, 1234567, 7654321, 5
+    assert gemm.mm_tn_instage_supported(g, x, rows)
+    dw, db = gemm.mm_tn_instage(g, mfold, bits, x, p, sg, p, sx, row0)
+    gy = torch.where(active, g * _keep((rows, 256), p, sg, row0 * 256) + mfold, torch.zeros((), device=DEV))
+    xd = x * _keep((rows, feats), p, sx, row0 * feats)
+    want_dw = (gy.double().t() @ xd.double())
+    want_db = gy.double().sum(0)
+    # (fp32 accumulation over 3 * 10^5 rows: relative to the size of the sums' terms)
+    scale_w = float((gy.abs().double().t() @ xd.abs().double()).max())
+    assert float((dw.double() - want_dw).abs().max()) <= 2e-6 * scale_w
+    assert float((db.double() - want_db).abs().max()) <= 2e-6 * float(gy.abs().double().sum(0).max())
+    # the separate pass + the plain weight gradient give the same numbers up to the order of the sums
+    ref = gemm.mm_tn_gdrop(gy, x, p, sx, row0)
+    assert float((dw - ref).abs().max()) <= 2e-6 * scale_w
+    assert not gemm.mm_tn_instage_supported(g, x[:, :64].contiguous(), rows)         # (the wide tile exists for 64 < F <= 128)
+    assert not gemm.mm_tn_instage_supported(g[:1000], x[:1000], 1000)                # (and for >= 256 row slabs)
+
+
+@pytest.mark.parametrize('n_mix', [0, 1, 2])
+def test_reverse_aggregation_folds_the_mix_gradients(n_mix):
+    from gnn_tail_generalization_amd import graph as G
+    from gnn_tail_generalization_amd.data import synthetic_data
+    data = synthetic_data('S-pl1M', seed=0, device=DEV, n_override=60000)
+    g = G.build_graph(data.edge_index, 60000)
+    n = g.N
+    assert g._plan.n_hubs > 0                                                       # (the hub rows' epilogue runs in k_spmm_hub_finish)
+    torch.manual_seed(5)
+    h = torch.randn(n, 256, device=DEV)
+    active = torch.rand(n, 256, device=DEV) < 0.5
+    bits = _mask_words(active)
+    p, seed, row0, alpha = 0.1, 424242, 3, 0.1
+    ops_, pos_, seeds_ = [], [], []
+    for q in range(n_mix):
+        member = torch.rand(n, device=DEV) < (0.1 if q == 0 else 0.45)
+        pos = torch.where(member, torch.cumsum(member, 0, dtype=torch.int32) - 1, torch.full((n,), -1, dtype=torch.int32, device=DEV))
+        ops_.append(torch.randn(int(member.sum()), 256, device=DEV))
+        pos_.append(pos.contiguous())
+        seeds_.append(1000 + q)
+    g_raw, gr = g.spmm_store_bwd(h, g.norm_out, bits, g.norm_in, 1 - alpha, p, seed, row0)
+    m, gr2, db = g.spmm_store_bwd(h, g.norm_out, bits, g.norm_in, 1 - alpha, p, seed, row0, mix=(ops_, pos_, seeds_, alpha, True))
+    assert torch.equal(gr, gr2)                                                     # the store backward itself is untouched
+    want = g_raw * _keep((n, 256), p, seed, row0 * 256)
+    for t, pos, sd in zip(ops_, pos_, seeds_):
+        full = torch.zeros(n, 256, device=DEV)
+        full[pos >= 0] = t
+        want = want + full * _keep((n, 256), p, sd, row0 * 256)
+    want = alpha * want
+    assert float((m - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    want_db = (gr.double() / g.norm_in.double().unsqueeze(1)).sum(0)
+    assert float((db.double() - want_db).abs().max()) <= 2e-5 * float((gr.abs().double() / g.norm_in.double().unsqueeze(1)).sum(0).max())
+    m3, _, none = g.spmm_store_bwd(h, g.norm_out, bits, g.norm_in, 1 - alpha, p, seed, row0, mix=(ops_, pos_, seeds_, alpha, False))
+    assert none is None and torch.equal(m3, m)
+
+
+@pytest.mark.parametrize('n_loss_rows', [None, 30000])
+def test_training_step_with_the_folded_input_stage(n_loss_rows, monkeypatch):
+    """The trainer's step (rows-only forward, row-sparse backward, L = 3: level 1 writes all rows and carries layer 0's store backward) with the fold
+    against the same step with the separate input-stage pass: the same loss bit for bit, every gradient above the input stage bit for bit, the three
+    the fold touches (layer 0's bias, the input Linear's weight and bias) up to the order of their sums."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_rowsparse import _step_grads
+    from gnn_tail_generalization_amd import gemm
+    monkeypatch.setattr(tuning.T, 'sum_first_below_min_edges', 0)      # (S-pl1M sits below the break-even of the sum-first layer)
+    monkeypatch.setenv('CB_SPMM_STORE_BWD', '1')
+    calls = []
+    real = gemm.mm_tn_instage
+    monkeypatch.setattr(gemm, 'mm_tn_instage', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    monkeypatch.setenv('CB_INSTAGE_FOLD', '1')
+    loss_f, g_f, used_f = _step_grads('1', n_loss_rows=n_loss_rows, rows_only=True)
+    assert calls == [1] and used_f
+    monkeypatch.setenv('CB_INSTAGE_FOLD', '0')
+    loss_p, g_p, used_p = _step_grads('1', n_loss_rows=n_loss_rows, rows_only=True)
+    assert calls == [1] and used_p
+    assert loss_f == loss_p and set(g_f) == set(g_p)
+    touched = ('layers_MLP.0.weight', 'layers_MLP.0.bias', 'layers_GCN.0.bias')
+    for k in g_p:
+        if k.endswith(touched):
+            assert float((g_f[k] - g_p[k]).abs().max()) <= 1e-5 * float(g_p[k].abs().max()) + 1e-9, k
+        else:
+            assert torch.equal(g_f[k], g_p[k]), k
