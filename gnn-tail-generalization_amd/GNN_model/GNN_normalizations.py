@@ -64,8 +64,18 @@ class TeacherGNN(nn.Module):
         res.commonEmb = self.forward(x, edge_index, loss_rows=loss_rows, rows_only=rows_only)
         res.emb4classi_full = self.proj2class(res.commonEmb)
         res.emb4classi = res.emb4linkp = None
+        # (extension) a rows-only forward of the fused trunk also hands back the logits of the loss rows as the compact matrix they were computed as,
+        # with the mask they belong to: (== emb4classi_full[mask], mask).  A loss built on it (trainer_node_classification.training_loss) sends its
+        # gradient back compact — no [N, C] loss pass, no row gather.  None otherwise.
+        rows = getattr(res.commonEmb, '_cb_rows', None)
+        res.emb4classi_rows = (self.proj2class(rows[0]), rows[1]) if rows is not None else None
         if want_heads:
-            res.emb4classi = res.emb4classi_full if mask is None else res.emb4classi_full[mask]
+            if mask is None:
+                res.emb4classi = res.emb4classi_full
+            elif rows is not None and mask is rows[1]:
+                res.emb4classi = res.emb4classi_rows[0]      # the reference's raw_logits = emb4classi_full[mask] (:45-47), never gathered
+            else:
+                res.emb4classi = res.emb4classi_full[mask]
             res.emb4linkp = self.proj2linkp(res.commonEmb)
         return res
 

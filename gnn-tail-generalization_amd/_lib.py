@@ -33,6 +33,7 @@ SIGNATURES = {
     'cb_csr_rebase_i64': (ctypes.c_int, [_P, _I64, _I64, _P, _P]),
     'cb_deg_norm_i64ptr_f32': (ctypes.c_int, [_P, _I64, _P, _P]),
     'cb_spmm_hub_count': (ctypes.c_int, [_P, _I64, _I32, _P, _P]),
+    'cb_spmm_hub_fill_scratch_ints': (_I64, [_I64]),
     'cb_spmm_hub_fill': (ctypes.c_int, [_P, _I64, _I32, _I32, _P, _P, _P, _P]),
     'cb_spmm_workspace_bytes': (_SZ, [_I64, _I64]),
     'cb_spmm_csr_f32': (ctypes.c_int, [_P, _P, _I32, _I64, _I64, _P, _I64, _I64, _P, _P, ctypes.c_int, _P, _I64,

@@ -115,16 +115,59 @@ __global__ void k_hub_count(const int32_t* __restrict__ rowptr, int64_t N, int T
   }
 }
 
-__global__ void k_hub_collect(const int32_t* __restrict__ rowptr, int64_t N, int T, int cap, int32_t* hub_rows, int32_t* cursor) {
-  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v < N && rowptr[v + 1] - rowptr[v] > T) {
-    int slot = atomicAdd(cursor, 1);
-    if (slot < cap) hub_rows[slot] = (int32_t)v;
+// Hub rows in ASCENDING row order, without atomics: per-block counts, a single-block exclusive scan of them, an ordered write.  (Round 6: the order
+// of hub_rows decides which rows share a block of k_spmm_hub_finish — and with it the order in which that kernel's column sums are added
+// (cb_spmm_csr_store_bwd_mix_f32); a cursor handed out by atomicAdd made that order differ from process to process.)
+__global__ void __launch_bounds__(256) k_hub_block_count(const int32_t* __restrict__ rowptr, int64_t N, int T, int32_t* __restrict__ block_count) {
+  __shared__ int s_w[4];
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool hub = v < N && rowptr[v + 1] - rowptr[v] > T;
+  const unsigned long long m = __ballot(hub);
+  if (lane_id() == 0) s_w[threadIdx.x >> 6] = (int)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) block_count[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+__global__ void __launch_bounds__(1024) k_hub_block_scan(int32_t* __restrict__ block_count, int nb) {      // in place: counts -> exclusive prefix
+  __shared__ int s_part[1024];
+  __shared__ int s_base;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (int start = 0; start < nb; start += blockDim.x) {
+    const int i = start + threadIdx.x;
+    const int c = i < nb ? block_count[i] : 0;
+    s_part[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 1; off < (int)blockDim.x; off <<= 1) {
+      const int add = (threadIdx.x >= (unsigned)off) ? s_part[threadIdx.x - off] : 0;
+      __syncthreads();
+      s_part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    const int incl = s_part[threadIdx.x], base = s_base;
+    if (i < nb) block_count[i] = base + incl - c;
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) s_base = base + incl;
+    __syncthreads();
   }
 }
 
-// Single block: sorts nothing — the order of hub_rows only decides which wavefront takes
-// which chunk; results are reduced per hub in chunk order, so they do not depend on it.
+__global__ void __launch_bounds__(256) k_hub_collect(const int32_t* __restrict__ rowptr, int64_t N, int T, int cap, int32_t* __restrict__ hub_rows,
+                                                     const int32_t* __restrict__ block_base) {
+  __shared__ int s_w[4];
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool hub = v < N && rowptr[v + 1] - rowptr[v] > T;
+  const unsigned long long m = __ballot(hub);
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  if (lane == 0) s_w[w] = (int)__popcll(m);
+  __syncthreads();
+  int before = 0;
+  for (int j = 0; j < w; ++j) before += s_w[j];
+  const int slot = block_base[blockIdx.x] + before + (int)__popcll(m & ((1ull << lane) - 1ull));
+  if (hub && slot < cap) hub_rows[slot] = (int32_t)v;
+}
+
+// Single block: chunk pointers of the hub rows in the order of hub_rows (ascending row ids, k_hub_collect); results are reduced per hub in chunk order.
 __global__ void k_hub_scan(const int32_t* __restrict__ rowptr, int T, int n_hubs, const int32_t* __restrict__ hub_rows,
                            int32_t* __restrict__ hub_chunk_ptr) {
   __shared__ int s_part[1024];
@@ -291,14 +334,20 @@ extern "C" int cb_spmm_hub_count(const int32_t* rowptr, int64_t N, int32_t T, in
   return CB_OK;
 }
 
+extern "C" int64_t cb_spmm_hub_fill_scratch_ints(int64_t N) { return N > 0 ? (int64_t)blocks_for(N, 256) : 1; }
+
 extern "C" int cb_spmm_hub_fill(const int32_t* rowptr, int64_t N, int32_t T, int32_t n_hubs, int32_t* hub_rows,
                                 int32_t* hub_chunk_ptr, int32_t* cursor, void* stream) {
   CB_CHECK_ARG(rowptr && hub_chunk_ptr && cursor && N >= 0 && T > 0 && n_hubs >= 0 && (n_hubs == 0 || hub_rows), CB_E_INVALID,
                "cb_spmm_hub_fill: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  CB_HIP(hipMemsetAsync(cursor, 0, sizeof(int32_t), st));
-  if (n_hubs > 0) {
-    hipLaunchKernelGGL(k_hub_collect, dim3(blocks_for(N, 256)), dim3(256), 0, st, rowptr, N, T, n_hubs, hub_rows, cursor);
+  if (n_hubs > 0) {      // cursor: scratch of cb_spmm_hub_fill_scratch_ints(N) int32 (per-block hub counts -> their exclusive prefix)
+    const int nb = blocks_for(N, 256);
+    hipLaunchKernelGGL(k_hub_block_count, dim3(nb), dim3(256), 0, st, rowptr, N, T, cursor);
+    CB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_hub_block_scan, dim3(1), dim3(1024), 0, st, cursor, nb);
+    CB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_hub_collect, dim3(nb), dim3(256), 0, st, rowptr, N, T, n_hubs, hub_rows, (const int32_t*)cursor);
     CB_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(k_hub_scan, dim3(1), dim3(1024), 0, st, rowptr, T, n_hubs, hub_rows, hub_chunk_ptr);

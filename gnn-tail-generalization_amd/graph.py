@@ -395,7 +395,7 @@ class CSRGraph:
             p.n_hubs, p.n_chunks = counts.tolist()
             p.hub_rows = torch.empty(max(p.n_hubs, 1), dtype=torch.int32, device=self.device)
             p.hub_chunk_ptr = torch.empty(p.n_hubs + 1, dtype=torch.int32, device=self.device)
-            cursor = torch.empty(1, dtype=torch.int32, device=self.device)
+            cursor = torch.empty(int(lib.cb_spmm_hub_fill_scratch_ints(self.N)), dtype=torch.int32, device=self.device)      # (scratch of the ordered compaction)
             _lib.check(lib.cb_spmm_hub_fill(_lib.ptr(rowptr), self.N, self.hub_threshold, p.n_hubs, _lib.ptr(p.hub_rows),
                                             _lib.ptr(p.hub_chunk_ptr), _lib.ptr(cursor), _lib.stream_ptr()),
                        'cb_spmm_hub_fill')

@@ -274,7 +274,15 @@ class trainer:
         res = self.teacherGNN.get_3_embs(self.data.x, self.data.edge_index, loss_rows=(self.data.train_mask, self._n_train), rows_only=rows_only)
         # == F.nll_loss(F.log_softmax(out[train_mask], 1), y[train_mask]) (:390-391), fused, no row gather
         unit = float(self.args.TeacherGNN.lossa_semantic) == 1.0      # the step seeds backward() with 1: no [N, C] pass to multiply by it
-        loss = ops.nll_logsoftmax(res.emb4classi_full, self.data.y, self.data.train_mask, self._n_train, unit_grad=unit)
+        rows = getattr(res, 'emb4classi_rows', None) if os.environ.get('CB_COMPACT_LOSS', '1') != '0' else None      # (0: the masked loss over [N, C])
+        if rows is not None and rows[1] is self.data.train_mask:
+            # the rows-only forward handed the train rows' logits over as a compact matrix (== emb4classi_full[train_mask], the reference's raw_logits):
+            # the loss reads 4 C bytes per TRAIN row instead of scanning [N, C], and its gradient reaches the trunk's backward compact
+            if getattr(self, '_y_train', None) is None or self._y_train_of is not self.data.train_mask:
+                self._y_train, self._y_train_of = self.data.y[self.data.train_mask].contiguous(), self.data.train_mask
+            loss = ops.nll_logsoftmax(rows[0], self._y_train, None, self._n_train, unit_grad=unit)
+        else:
+            loss = ops.nll_logsoftmax(res.emb4classi_full, self.data.y, self.data.train_mask, self._n_train, unit_grad=unit)
         if not unit:
             loss = loss * self.args.TeacherGNN.lossa_semantic
         if self.teacherGNN.se_reg_all is not None:

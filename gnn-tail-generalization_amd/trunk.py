@@ -477,7 +477,7 @@ def _last_layer_on_loss_rows(graph, plan, cur, w, b, mix, alpha, p, seed, row0, 
     logits_c = gemm.mm_nn(x_l, w_out.t().contiguous(), bias=b_out)
     out = ops.expand_unread(logits_c, sp, n)      # the rows nobody may read: NaN (ops.unread_rows_fill)
     graph.rows_only_forwards = getattr(graph, 'rows_only_forwards', 0) + 1
-    return bits, x_l, out, h_agg
+    return bits, x_l, (out, logits_c), h_agg
 
 
 def _last_layer_on_loss_rows_sharded(graph, s0, orient, cur, w, b, mix, alpha, p, seed, row0, residual, w_out, b_out, le=None):
@@ -526,7 +526,7 @@ class _TrunkFn(torch.autograd.Function):
         # Round 4: the dropout in front of layer 0 (GCN.py:110) is applied to X0 the same way by layer 0's GEMM, so X0's dropped copy
         # (10 GB at the headline size: one more output stream of the input Linear, one more tensor kept for the backward) does not exist
         # either; `cur` stays None until a path that has no such form asks for the copy (dropped_x0()).
-        fused_in = x0_bits = cur = z_front = None
+        fused_in = x0_bits = cur = z_front = out_rows = None
         indrop = p > 0 and os.environ.get('CB_TRUNK_INDROP', '1') != '0'
         # Round 4: the whole forward front — dropout(x), input Linear, ReLU, dropout(X0), layer 0's transform — in ONE kernel
         # (cb_trunk_front_f32): a block keeps its 64 rows of dropout(X0) in LDS and multiplies them by W_0 at once.  The dropped copy is
@@ -601,8 +601,8 @@ class _TrunkFn(torch.autograd.Function):
                 bits, cur, out_head = _last_layer_on_loss_rows_sharded(graph, ro_sh[0], ro_sh[1], cur, w, b, mix, alpha, p, sd_l, row0, residual, w_out, b_out, le=le)
                 z = None
             elif ro_plan is not None and l == L - 1:
-                bits, cur, out_head, h_last = _last_layer_on_loss_rows(graph, ro_plan, cur, w, b, mix, alpha, p, sd_l, row0, residual, w_out, b_out, below=ro_below,
-                                                                       le=le_last)
+                bits, cur, (out_head, out_rows), h_last = _last_layer_on_loss_rows(graph, ro_plan, cur, w, b, mix, alpha, p, sd_l, row0, residual, w_out, b_out,
+                                                                                   below=ro_below, le=le_last)
                 if le_last is None:
                     saved_in[L - 1] = None    # X_{L-1}: read by the aggregation above only (the level's weight gradient contracts h_last)
                 else:
@@ -671,11 +671,17 @@ class _TrunkFn(torch.autograd.Function):
         ctx.rows_only_sharded = bwd and (ro_sh is not None or (ro_plan is not None and h_last is None))      # row shards / a table on the last layer: saved_in[L] compact only
         ctx.in_last_compact = bwd and ro_plan is not None and h_last is None and ro_below is not None       # ... and saved_in[L - 1] holds the rows of S_1 (= level 0's destination)
         ctx.le_present = [layer_params[3 * l + 2] is not None for l in range(L)]
-        return out
+        # Second output (rows-only forward on one GPU, else None): the logits of the loss rows as the compact [|S_0|, C] matrix they were computed as — what
+        # the reference calls res.emb4classi = emb4classi_full[mask] (GNN_normalizations.py:45-47).  A loss built on it hands its gradient back compact:
+        # no [N, C] loss pass, no zero-row check, no row gather in the backward's head.
+        ctx.set_materialize_grads(False)
+        return out, out_rows
 
     @staticmethod
-    def backward(ctx, gout):
-        return _Backward(ctx, gout).run()
+    def backward(ctx, gout, gout_rows=None):
+        if gout is None and gout_rows is None:
+            return (None,) * (7 + ctx.n_layer_params)
+        return _Backward(ctx, gout, gout_rows).run()
 
 
 class _Backward:
@@ -687,8 +693,9 @@ class _Backward:
       * _layer_plain: aggregation, then the dX GEMM (+ row-chunked producers of the node-sharded pull pipeline; bf16-stored rows).
     All share the same stage helpers (_store_bwd*, _dw, the bookkeeping of the gradients that reach X0)."""
 
-    def __init__(self, ctx, gout):
+    def __init__(self, ctx, gout, gout_rows=None):
         self.ctx = ctx
+        self.gout_rows = gemm._rowmajor(gout_rows) if gout_rows is not None else None      # gradient of the compact loss-row logits (forward's second output)
         graph, (L, alpha, p, seeds, agg_bf16, _track, loss_rows, residual, _rows_only), row0 = ctx.graph, ctx.cfg, ctx.row0
         self.graph, self.L, self.alpha, self.p, self.seeds, self.agg_bf16, self.row0, self.residual = graph, L, alpha, p, seeds, agg_bf16, row0, residual
         sv = list(ctx.saved_tensors)
@@ -713,10 +720,11 @@ class _Backward:
             self.lp.append((w, b, le))
         self.a, self.bnorm = graph.norm_out, graph.norm_in
         self.need = ctx.needs_input_grad       # (graph, cfg, x, w_in, b_in, w_out, b_out, *layer_params)
-        self.gout = gemm._rowmajor(gout)
+        self.gout = gemm._rowmajor(gout) if gout is not None else None
+        self.n_rows = self.x0.shape[0]
         self.h = self.x0.shape[1]
         self.sharded = hasattr(graph, 'part')
-        if loss_rows is not None and not self.xl_compact and (not ops.loss_rows_enabled() or loss_rows[0].shape[0] != self.gout.shape[0]):
+        if loss_rows is not None and not self.xl_compact and (not ops.loss_rows_enabled() or loss_rows[0].shape[0] != self.x0.shape[0]):
             loss_rows = None
         self.loss_rows = loss_rows
         # the gradient reaching X0 through the mixes: 'Initial' — every layer's, gathered in one pass by the input stage (the per-layer gradients
@@ -807,7 +815,10 @@ class _Backward:
         space: the compact row space of the loss rows (a plan's space0 / a rank's share of it), or None = all rows."""
         L, need, gout, xl, w_out = self.L, self.need, self.gout, self.saved_in[self.L], self.w_out
         if space is not None:      # loss rows only
-            gout_c, xl_c = ops.gather_rows_by_index(gout, space.idx), (xl if self.xl_compact else ops.gather_rows_by_index(xl, space.idx))
+            gout_c = ops.gather_rows_by_index(gout, space.idx) if gout is not None else None
+            if self.gout_rows is not None:      # (the compact output's gradient arrives on those rows already)
+                gout_c = self.gout_rows if gout_c is None else gout_c + self.gout_rows
+            xl_c = xl if self.xl_compact else ops.gather_rows_by_index(xl, space.idx)
             self.d_w_out = gemm.mm_tn(gout_c, xl_c) if need[5] else None
             self.d_b_out = ops.act_bwd(gout_c, None, None, want_out=False, want_colsum=True)[1] if need[6] else None
             g = gemm.mm_nn(gout_c, w_out)                                        # dL/d(dropped X_L), loss rows only
@@ -937,6 +948,8 @@ class _Backward:
         # Round 5: while a support is a small share of the nodes the level is also COMPACT in the rank's rows (SupportLevel.src / .dst), so the
         # rank's head, store backward, weight gradients and GEMM tails run on the support's rows as on one GPU.
         self.sh_levels = []
+        if self.gout_rows is not None and not self.rows_only and not ctx.rows_only_sharded:
+            raise RuntimeError('gradient for the compact loss-row logits, but the forward did not run rows-only')
         if sharded and hasattr(graph, 'support_levels') and self.loss_rows is not None:
             ops.check_rows_zero(gout, self.loss_rows[0])
             # ('Residual': CUMULATIVE supports, as on one GPU below)
@@ -949,11 +962,12 @@ class _Backward:
         # (ops.check_rows_zero: a violation ends in the device error word and stops the optimiser launch, never in silent wrong gradients).
         # Hidden 256, gathered per-layer gradients, loss rows <= rowsparse_s0_limit of the nodes.
         plan = None
-        hint = None if sharded else _support_plan(graph, self.loss_rows, gout.shape[0], L, self.residual, self.h, self.x0, committed=self.xl_compact)[0]
+        hint = None if sharded else _support_plan(graph, self.loss_rows, self.n_rows, L, self.residual, self.h, self.x0, committed=self.xl_compact)[0]
         # (with bf16-stored rows the compact levels still run on fp32 matrices through the aggregation + GEMM kernel; the dense levels below
         # them go on as the bf16 path does)
         if hint is not None:
-            ops.check_rows_zero(gout, hint[0])
+            if gout is not None:      # (no gradient for the [N, C] output at all: the loss was built on the compact output — nothing to check)
+                ops.check_rows_zero(gout, hint[0])
             # ('Residual': a layer's store backward also takes the gradient of the layer above, so the supports are CUMULATIVE — W_{j+1} = N(W_j) ∪ W_j,
             # a superset of both; every matrix of level j lives on W_j)
             # (count: one use per step — the forward of a rows-only step has looked the plan up already)
@@ -1102,6 +1116,9 @@ def forward(tc, x, graph, loss_rows=None, rows_only=False):
         if mask.dtype != torch.bool or mask.dim() != 1 or mask.shape[0] != x.shape[0]:
             raise ValueError(f'loss_rows: a bool mask over the {x.shape[0]} rows expected, got {tuple(mask.shape)} {mask.dtype}')
         loss_rows = (mask, int(count))
-    out = _TrunkFn.apply(graph, (L, float(tc.alpha), p, seeds, agg_bf16, torch.is_grad_enabled(), loss_rows, connection(tc) == 'residual', bool(rows_only) and loss_rows is not None), x, tc.layers_MLP[0].weight, tc.layers_MLP[0].bias,
-                         tc.layers_MLP[1].weight, tc.layers_MLP[1].bias, *params)
+    out, out_rows = _TrunkFn.apply(graph, (L, float(tc.alpha), p, seeds, agg_bf16, torch.is_grad_enabled(), loss_rows, connection(tc) == 'residual',
+                                           bool(rows_only) and loss_rows is not None), x, tc.layers_MLP[0].weight, tc.layers_MLP[0].bias,
+                                   tc.layers_MLP[1].weight, tc.layers_MLP[1].bias, *params)
+    if out_rows is not None:      # (rows-only forward: the logits of the loss rows as they were computed, == out[mask]; TeacherGNN.get_3_embs hands them on)
+        out._cb_rows = (out_rows, loss_rows[0])
     return out, se_reg_all

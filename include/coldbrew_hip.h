@@ -99,10 +99,14 @@ int cb_deg_norm_i64ptr_f32(const int64_t* rowptr, int64_t N, float* norm, void* 
  * chunks of `hub_threshold` edges that separate wavefronts reduce (power-law graphs).
  * counts[0] = #hub rows, counts[1] = #chunks.  Call cb_spmm_hub_count, read counts on the
  * host, allocate hub_rows[counts[0]] and hub_chunk_ptr[counts[0]+1], call cb_spmm_hub_fill.
+ * hub_rows comes back in ASCENDING row order (no atomics: the plan — and with it the order of every
+ * sum a kernel takes over the hub rows — is the same in every process); scratch: int32
+ * [cb_spmm_hub_fill_scratch_ints(N)].
  * ---------------------------------------------------------------------------------- */
 int cb_spmm_hub_count(const int32_t* rowptr, int64_t N, int32_t hub_threshold, int32_t* counts /*[2]*/, void* stream);
+int64_t cb_spmm_hub_fill_scratch_ints(int64_t N);
 int cb_spmm_hub_fill(const int32_t* rowptr, int64_t N, int32_t hub_threshold, int32_t n_hubs,
-                     int32_t* hub_rows, int32_t* hub_chunk_ptr, int32_t* cursor /*[1] scratch*/, void* stream);
+                     int32_t* hub_rows, int32_t* hub_chunk_ptr, int32_t* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Sum aggregation — replaces `graph.update_all(fn.copy_src('h','m'), fn.sum('m','h'))`

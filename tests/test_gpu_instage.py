@@ -116,3 +116,68 @@ def test_training_step_with_the_folded_input_stage(n_loss_rows, monkeypatch):
             assert float((g_f[k] - g_p[k]).abs().max()) <= 1e-5 * float(g_p[k].abs().max()) + 1e-9, k
         else:
             assert torch.equal(g_f[k], g_p[k]), k
+
+
+def test_loss_on_the_compact_logits_of_the_rows_only_forward(monkeypatch):
+    """The rows-only forward hands the train rows' logits over as the compact matrix they were computed as (res.emb4classi_rows == emb4classi_full[mask]:
+    the reference's raw_logits, GNN_normalizations.py:45-47); the trainer's loss on it equals the masked loss over [N, C] and every gradient is the same
+    bit for bit (the gradient reaches the backward's head compact instead of being gathered from an [N, C] matrix)."""
+    import contextlib
+    import io
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bench
+    from test_gpu_rowsparse import _step_grads
+    from gnn_tail_generalization_amd import ops
+    from gnn_tail_generalization_amd import trainer_node_classification as tnc
+    monkeypatch.setenv('CB_COMPACT_LOSS', '1')
+    loss_c, g_c, used_c = _step_grads('1', rows_only=True)
+    monkeypatch.setenv('CB_COMPACT_LOSS', '0')
+    loss_f, g_f, used_f = _step_grads('1', rows_only=True)
+    assert used_c and used_f and abs(loss_c - loss_f) <= 1e-6 * abs(loss_f) and set(g_c) == set(g_f)
+    for k in g_f:
+        assert torch.equal(g_c[k], g_f[k]), k
+    # what the caller sees: the compact logits are the rows of the full output, and a mask= argument that IS the loss mask gets them without a gather
+    args = bench.make_args('S-pl1M', ['--manual_assign_GPU=0'])
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        t = tnc.trainer(args, 0)
+        t.setup_teacherGNN()
+    t.teacherGNN.train()
+    mask, n = t.data.train_mask, int(t.data.train_mask.sum())
+    y_rows = t.data.y[mask].contiguous()
+    grads = {}
+    for both in (True, False):
+        ops._seed_override[:] = [31, 32, 33, 34, 35]
+        res = t.teacherGNN.get_3_embs(t.data.x, t.data.edge_index, mask, loss_rows=(mask, n), rows_only=True)
+        ops._seed_override[:] = []
+        assert res.emb4classi_rows is not None and res.emb4classi_rows[1] is mask and res.emb4classi is res.emb4classi_rows[0]
+        assert torch.equal(res.emb4classi.detach(), res.emb4classi_full.detach()[mask])
+        # a loss that uses BOTH outputs of the forward: the two gradients add up on the loss rows (== twice the compact one alone)
+        loss = ops.nll_logsoftmax(res.emb4classi, y_rows, None, n)
+        loss = loss + (ops.nll_logsoftmax(res.emb4classi_full, t.data.y, mask, n) if both else loss)
+        t.teacherGNN.zero_grad()
+        loss.backward()
+        grads[both] = {k: p.grad.detach().clone() for k, p in t.teacherGNN.named_parameters() if p.grad is not None}
+    for k in grads[True]:
+        assert float((grads[True][k] - grads[False][k]).abs().max()) <= 2e-6 * float(grads[False][k].abs().max()) + 1e-10, k
+    res = t.teacherGNN.get_3_embs(t.data.x, t.data.edge_index, loss_rows=(mask, n), rows_only=False)
+    assert res.emb4classi_rows is None      # (every row evaluated: nothing compact to hand over)
+
+
+def test_hub_rows_come_back_in_ascending_order():
+    """The hub plan lists its rows in ascending order (ordered compaction, no atomic cursor): which rows share a block of the hub-finish kernel — and with
+    it the order of the column sums cb_spmm_csr_store_bwd_mix_f32 takes there — is the same in every process (found as a last-bit flicker of layer 0's
+    bias gradient between runs)."""
+    from gnn_tail_generalization_amd import graph as G
+    from gnn_tail_generalization_amd.data import synthetic_data
+    data = synthetic_data('S-pl1M', seed=0, device=DEV, n_override=200000)
+    g = G.build_graph(data.edge_index, 200000)
+    p = g._plan
+    assert p.n_hubs > 1
+    rows = p.hub_rows[:p.n_hubs].long()
+    assert bool((rows[1:] > rows[:-1]).all())
+    deg = g.rowptr[1:] - g.rowptr[:-1]
+    assert torch.equal(rows, torch.nonzero(deg > g.hub_threshold).flatten())
+    chunks = (deg[rows] + g.hub_threshold - 1) // g.hub_threshold
+    assert torch.equal(p.hub_chunk_ptr.long(), torch.cat([chunks.new_zeros(1), torch.cumsum(chunks, 0)]).long()) and int(p.hub_chunk_ptr[-1]) == p.n_chunks
