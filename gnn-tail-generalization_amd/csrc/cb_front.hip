@@ -9,7 +9,8 @@
 //
 // One persistent block of 4 wavefronts per slot (two slots per CU: 75 KB of LDS each), tiles of 64 rows, per tile
 //   P0  the tile of x -> dropout -> fp32 LDS tile [64][K1 + 4]
-//   P1  tile x W_in^T on the matrix cores (tile_times_image: three-limb bf16 products, B fragments from the L2-resident image)
+//   P1  tile x W_in^T on the matrix cores (tile_times_image_coop: three-limb bf16 products, A limbs split once per K step into LDS planes, B fragments
+//       from the L2-resident image)
 //   P2  accumulators -> the SAME LDS region as a [64][260] tile (the x tile is dead)
 //   P3  row pass: a wavefront owns 16 rows, a lane 4 columns: + bias, ReLU -> X0 row store (1 KiB, streaming), four ballots = the row's mask
 //       words, Philox keep-mask of the dropout in front of layer 0 -> X0d back into the tile (-> out_drop row store if requested)
@@ -56,7 +57,13 @@ __global__ void __launch_bounds__(256, 2) k_front(FrontArgs fa) {
   constexpr int K1 = 16 * NS1, LDX = K1 + 4, NV = kTM * K1 / 4 / 256;      // float4 of x per thread per tile
   static_assert(NV >= 1 && kTM * LDX <= kTM * kTLD, "x tile must fit the region of the X0 tile");
   __shared__ __attribute__((aligned(16))) float tile[kTM * kTLD];
-  __shared__ __attribute__((aligned(16))) float cstrip[4][8 * kCLD];
+  // Round 6: the K loops split the A tile's limbs ONCE per element (tile_times_image_coop: the block's 256 threads split each K step's 64 x 16 slab into
+  // bf16 planes, every wavefront reads its fragments from them) instead of once per multiplying wavefront: 14.3 -> 13.7 ms at the headline shape, bit-identical
+  // (the matrix-core kernels run at the board's power limit: less VALU / LDS work per MFMA is a higher clock).  The planes (two stages of RowOperand<64>) and
+  // the wave-private strips of the Z0 epilogue share one region: the strips are used after the last K step's barrier only, the planes before it.
+  constexpr int kScratch = 2 * RowOperand<kTM>::BYTES > 4 * 8 * kCLD * 4 ? 2 * RowOperand<kTM>::BYTES : 4 * 8 * kCLD * 4;
+  __shared__ __attribute__((aligned(16))) char scratch[kScratch];
+  float (*cstrip)[8 * kCLD] = reinterpret_cast<float (*)[8 * kCLD]>(scratch);
   __shared__ float rs_tile[2][kTM];   // (two buffers by tile parity: a wavefront may start the next tile's P0 while others still run this tile's epilogue)
                                       // row scales of the tile's rows: a global load per (pass, row) in the Z0 epilogue would expose its latency 16 times
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -98,8 +105,7 @@ __global__ void __launch_bounds__(256, 2) k_front(FrontArgs fa) {
     __syncthreads();
     // ---- P1: X0 pre-activation = tile(x) @ W_in^T
     f32x16 acc[2][2];
-    tile_times_image<NS1, LDX, 2>(tile, fa.image_in, w, lane, acc);
-    __syncthreads();                  // every wavefront has read its last fragment of the x tile
+    tile_times_image_coop<NS1, LDX, 1>(tile, scratch, fa.image_in, w, lane, t, acc);      // (ends with a block barrier: the x tile is dead)
     // ---- P2: accumulators -> [64][260] tile (C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))
     {
       const int l31 = lane & 31, lh = lane >> 5;
@@ -146,8 +152,7 @@ __global__ void __launch_bounds__(256, 2) k_front(FrontArgs fa) {
     }
     __syncthreads();
     // ---- P4: Z0 = rowscale . (tile(X0d) @ W_0) + addend
-    tile_times_image<kNS, kTLD, 2>(tile, fa.image_0, w, lane, acc);
-    __syncthreads();                  // the tile may be overwritten by the next P0 (the strips below are wave-private)
+    tile_times_image_coop<kNS, kTLD, 1>(tile, scratch, fa.image_0, w, lane, t, acc);      // (ends with a block barrier: tile and planes are dead; the strips are wave-private)
     acc_rows_through_strip(acc, cstrip[w], w, lane, [&](int row, int n, const float4& v) {
       const int64_t m = m0 + row;
       if (m < fa.M) {

@@ -102,6 +102,82 @@ __device__ __forceinline__ void tile_times_image(const float* __restrict__ tile,
   for (int r = 0; r < NSTEPS - MAIN; ++r) step(MAIN + r, r, (r + PF) % R);      // (MAIN % R == 0: step s sits in ring slot s % R)
 }
 
+// The same product with the A limbs split ONCE per element instead of once per multiplying wavefront (round 6): before the MFMAs of K step s the
+// block's 256 threads split the tile's 64 x 16 slab of step s + 1 cooperatively (one float4 each: row t >> 2, k quad t & 3) into three bf16 planes in
+// LDS (RowOperand<64>'s layout: 2 KB per plane, two stages = 12 KB), and every wavefront reads its A fragments as bf16 (three ds_read_b128 per
+// 32-row block) — the K loop's limb-split VALU work drops from 4 x (the whole slab per wavefront) to 1 x, for one block barrier per K step.  Same limb
+// values (split4), same limb products in the same order: bit-identical to tile_times_image.  All four wavefronts of the block must call it together.
+// planes: 2 * RowOperand<kTM>::BYTES bytes of LDS.
+template <int NSTEPS, int TLD, int PF = 1>
+__device__ __forceinline__ void tile_times_image_coop(const float* __restrict__ tile, char* __restrict__ planes, const uint4* __restrict__ image, int w, int lane,
+                                                      int t, f32x16 (&acc)[2][2]) {
+  using OA = RowOperand<kTM>;
+  static_assert(OA::NV == 1 && PF >= 1 && PF <= 3 && PF < NSTEPS, "64-row tiles, one float4 of the slab per thread");
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int row = t >> 2, kq = t & 3;
+  const float* a_src = tile + row * TLD + 4 * kq;                                  // this thread's float4 of slab 0
+  const uint32_t woff = row * 32 + (((kq >> 1) ^ ((row >> 3) & 1)) << 4) + ((kq & 1) << 3);      // RowOperand<64>::init's store offset
+  const uint32_t aaddr[2] = {OA::frag_addr(0, lane), OA::frag_addr(32, lane)};
+  auto stage = [&](int s, char* dst) {
+    const float4 x = *reinterpret_cast<const float4*>(a_src + 16 * s);
+    const float v[4] = {x.x, x.y, x.z, x.w};
+    uint2 pl[3];
+    split4(v, pl);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(dst + p * OA::PLANE + woff) = pl[p];
+  };
+  const uint4* bp = image + ((int64_t)(2 * w) * 3) * 64 + lane;
+  uint4 bq[PF + 1][2][3];
+#pragma unroll
+  for (int d = 0; d < PF; ++d) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bq[d][j][p] = bp[j * 192 + p * 64];
+    bp += kNT * 192;
+  }
+  stage(0, planes);
+  __syncthreads();
+  auto step = [&](int s, int cur, int nx) {
+    if (s + PF < NSTEPS) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[nx][j][p] = bp[j * 192 + p * 64];
+    }
+    bp += kNT * 192;
+    const char* S = planes + (s & 1) * OA::BYTES;
+    if (s + 1 < NSTEPS) stage(s + 1, planes + ((s + 1) & 1) * OA::BYTES);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bf16x8 a_lo = OA::frag(S, aaddr[i], 2), a_hi = OA::frag(S, aaddr[i], 0), a_mid = OA::frag(S, aaddr[i], 1);
+#define CB_TG_MFMA2(A_, P_) \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, as_bf16x8(bq[cur][j][P_]), acc[i][j], 0, 0, 0);
+      CB_TG_MFMA2(a_lo, 0)
+      CB_TG_MFMA2(a_hi, 2)
+      CB_TG_MFMA2(a_mid, 1)
+      CB_TG_MFMA2(a_mid, 0)
+      CB_TG_MFMA2(a_hi, 1)
+      CB_TG_MFMA2(a_hi, 0)
+#undef CB_TG_MFMA2
+    }
+    __syncthreads();      // the slab of step s + 1 is staged; every wavefront has read the planes of step s
+  };
+  constexpr int R = PF + 1, MAIN = NSTEPS / R * R;
+#pragma unroll 1
+  for (int s0 = 0; s0 < MAIN; s0 += R) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) step(s0 + r, r, (r + PF) % R);
+  }
+#pragma unroll
+  for (int r = 0; r < NSTEPS - MAIN; ++r) step(MAIN + r, r, (r + PF) % R);
+}
+
 // ---- narrow tail (round 5: the output Linear 256 -> C <= 64 as the tail of the LAST layer's aggregation, GCN.py:133-138) ----------------
 // image layout as above with kNTn = 2 column blocks (columns >= C are zero): image[((s * kNTn + j) * 3 + p) * 64 + lane]
 constexpr int kNTn = 2;
