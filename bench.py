@@ -669,6 +669,9 @@ def main():
         out['config']['backward'] = ('row-sparse: under the masked loss the gradient is exactly zero outside the rows the train rows reach after j hops; the levels '
                                      'of the backward whose support is <= 70 % of the rows (train rows, their neighbours) run on compact matrices and gather only '
                                      'those rows (the claim is verified on the device every step; CB_LOSS_ROWS=0: dense backward, timed beside it as `dense_backward`)')
+        if getattr(graph_obj, 'instage_folds', 0) > 0:
+            out['config']['backward'] += ('; input stage without a pass of its own: the level that writes all rows folds the mix gradients in its epilogue, the input '
+                                          "Linear's weight gradient computes (X0 > 0) * (dropout_bwd(g) + fold) while it stages it (CB_INSTAGE_FOLD=0: the separate pass)")
     out['peak_mem_gb'] = peak_mem / 2 ** 30
     if sharding is not None:
         out['sharding'] = sharding

@@ -62,7 +62,7 @@ class _StackFn(torch.autograd.Function):
         # width) runs on those rows, the last layer's transform on the rows it gathers — S_1 —, and the last HIDDEN layer's aggregation + store on S_1 too
         # (cb_spmm_csr_fused_rows_f32), wherever the plan keeps S_1 compact.
         ro = None
-        if rows_only and bwd and L >= 2 and rows_only_enabled():
+        if rows_only and bwd and L >= 2 and rows_only_enabled() and x.shape[0] >= T.rows_only_min_nodes:
             hint = _plan_hint(graph, loss_rows_, x.shape[0], ag)
             if hint is not None:
                 plan_ = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac)

@@ -396,7 +396,8 @@ def _rows_only_decision(graph, cfg, x, x0, h, ag, bwd, layer_params):
     le_last, sharded = layer_params[3 * (L - 1) + 2], hasattr(graph, 'part')
     # (bf16-stored rows, one GPU: the last layer alone — its sum is taken over the fp32 activations, the layers below keep their bf16-stored Z)
     bf16_last_only = bool(agg_bf16) and not sharded and agg_gemm_eligible(graph, h, False)
-    if not (rows_only and bwd and loss_rows is not None and L >= 2 and (ag or bf16_last_only) and rows_only_enabled()):
+    if not (rows_only and bwd and loss_rows is not None and L >= 2 and (ag or bf16_last_only) and rows_only_enabled()
+            and (sharded or x.shape[0] >= T.rows_only_min_nodes)):
         return none
     if sharded:
         if not (hasattr(graph, 'loss_rows_forward') and ops.loss_rows_enabled() and loss_rows[0].shape[0] == x.shape[0]):

@@ -36,6 +36,10 @@ class Tuning:
     # the source rows' side) once S_1's rows are entered by at least this many edges — below, the Z-first form on S_1 (one kernel) wins on launches.
     # S-arxiv (1.7 * 10^6 edges into S_1): 2.94 -> 3.11 ms/step with the sum first; S-products: 90.1 -> 89.4; S-pl10M (7.4 * 10^7): 125.3 -> 120.9
     sum_first_below_min_edges: int = 1 << 24
+    # rows-only forward: not below this many nodes, even where a replayed step (graph.rowsparse_small_ok) takes the row-sparse backward — the last layer
+    # as aggregate + transform + store + head on the loss rows is four launches for one.  S-pubmed config 2 (19 717 nodes, bf16 rows, hipGraph replay):
+    # 0.795 ms/step with it, 0.752 without (round 6, one box, alternating runs; the round-5 tree the same: 0.803 / 0.748); S-arxiv (169 343): 3.38 -> 2.94 with it
+    rows_only_min_nodes: int = 1 << 16
     # rows-only forward: the rows of the output that the caller promised not to read come back as NaN (True) or as zeros (False).  Costs nothing (the
     # rows are written either way); makes a broken `rows_only` promise loud: whoever reads TeacherGNN.out / res.commonEmb outside the loss rows sees NaN
     rows_only_poison: bool = True

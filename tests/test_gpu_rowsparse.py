@@ -326,6 +326,7 @@ def test_row_sparse_backward_matches_the_unmodified_reference(case, rows_only, m
     from helpers import product_model
     from gnn_tail_generalization_amd import _lib, graph, ops, trunk
     monkeypatch.setattr(tuning.T, 'rowsparse_min_nodes', 0)
+    monkeypatch.setattr(tuning.T, 'rows_only_min_nodes', 0)
     monkeypatch.setattr(tuning.T, 'fwd0_min_edges', 0)                  # (the source-side form at this small size too)
     monkeypatch.setenv('CB_LOSS_ROWS', '1')
     g = load_golden(case)
