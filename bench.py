@@ -607,6 +607,7 @@ def main():
         sharding['rows_only_forward_rank0'] = ({'forwards': int(sg_.rows_only_forwards), 'edges': int(f0_[1].E), 'rows_written': int(f0_[0][0].src.n),
                                                 'halo_rows': int(f0_[1].plan.n_halo), 'halo_rows_full_forward': int(sg_.f.plan.n_halo)}
                                                if f0_ is not None else {'forwards': int(getattr(sg_, 'rows_only_forwards', 0))})
+        sharding['instage_folds_rank0'] = int(getattr(sg_, 'instage_folds', 0))      # backwards whose input stage ran inside the input Linear's weight gradient
         dist.barrier()
         dist.destroy_process_group()
     if rank != 0:

@@ -152,6 +152,8 @@ SIGNATURES = {
     'cb_gemm_tn_instage_workspace_bytes': (_SZ, [_I64, _I64]),
     'cb_gemm_tn_instage_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _P, _P, _I64, _I64, ctypes.c_float, ctypes.c_uint64, ctypes.c_float, ctypes.c_uint64, _P, _I64,
                                               _P, _SZ, _P]),
+    'cb_trunk_layer_bwd_fold_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64, ctypes.c_float, ctypes.c_uint64, _P, _I64, ctypes.c_float, ctypes.c_float, _I32, _P, _P, _P,
+                                                   _P, _P, _P, _SZ, _I32, _P, ctypes.c_float, _P, _P, _SZ, _P]),
     'cb_trunk_layer_bwd_rows_f32': (ctypes.c_int, [_P, _P, _I64, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_uint64, _P, _I64, ctypes.c_float,
                                                    _P, ctypes.c_uint64, ctypes.c_float, _P, _P, _P, _SZ, _P]),
     'cb_id_count_i64': (ctypes.c_int, [_P, _I64, _I64, _P, _P, _P]),

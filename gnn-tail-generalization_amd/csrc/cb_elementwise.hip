@@ -274,6 +274,136 @@ __global__ void __launch_bounds__(kBlock) k_trunk_bwd(const float* __restrict__ 
   }
 }
 
+// The layer kernel above (MODE 0, all rows, fp32 out) for LAYER 0 of the 'Initial' trunk, which also FOLDS the gradients that reach X0 through the mixes
+// (round 6; the elementwise form of cb_spmm_csr_store_bwd_mix_f32's epilogue):
+//   out_m = c_mix * ( keep(seed) * g  +  sum_q keep(seed_q) * g_q[pos_q[r] | r] )        (pos_q null: a dense operand; pos < 0: the row is absent)
+// g is read here anyway; the input stage (cb_gemm_tn_instage_f32) then reads out_m instead of g and every g_q.
+struct FoldOps {
+  int n;
+  const float* g[2];
+  const int* pos[2];
+  uint64_t seed[2];
+  float* out_m;
+  // optional second column sum (cs_partial non-null): over the rows, cs_c * dropout_bwd(g[cs_src]) where cs_bits (mask words of ANOTHER store, indexed by the
+  // node row) has the element's bit — the bias gradient of the store whose backward left a reverse aggregation's epilogue (cb_spmm_csr_store_bwd_f32), which
+  // cb_trunk_input_bwd_multi_cs_f32 took while the input stage was a pass
+  int cs_src;
+  const unsigned long long* cs_bits;
+  float cs_c;
+  float* cs_partial;
+};
+__global__ void __launch_bounds__(kBlock) k_trunk_bwd_fold(const float* __restrict__ g, const unsigned long long* __restrict__ bits, const float* __restrict__ row_scale,
+                                                           float* __restrict__ out, FoldOps fo, int64_t rows, int d, uint32_t thresh, float keep_scale, uint64_t seed,
+                                                           const uint64_t* __restrict__ seed_dev, int64_t row0, float c_act, float c_mix, float* __restrict__ partial) {
+  extern __shared__ float s_red[];
+  const uint64_t sd = seed_dev ? *seed_dev : 0ull;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int tiles = d >> 8;
+  const int64_t rows_per_block = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r_end = min(rows, r_begin + rows_per_block);
+  for (int tile = 0; tile < tiles; ++tile) {
+    const int c = tile * 256 + lane * 4;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float gn[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r_begin + w < r_end) {
+      const int64_t o0 = (r_begin + w) * d + c;
+      gn[0] = __builtin_nontemporal_load(g + o0); gn[1] = __builtin_nontemporal_load(g + o0 + 1);
+      gn[2] = __builtin_nontemporal_load(g + o0 + 2); gn[3] = __builtin_nontemporal_load(g + o0 + 3);
+    }
+    for (int64_t r = r_begin + w; r < r_end; r += kBlock / kWave) {
+      const int64_t off = r * d + c;
+      float gm[4] = {gn[0], gn[1], gn[2], gn[3]};
+      const unsigned long long* bwp = bits + (r * tiles + tile) * 4;
+      unsigned long long bw[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bw[k] = bwp[k];
+      const float sc = row_scale ? row_scale[r] : 1.f;
+      int pq[2] = {-1, -1};      // (wave-uniform) row of operand q that holds node row r, or < 0
+      float u[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (q < fo.n) {
+          const int64_t p = fo.pos[q] ? (int64_t)__builtin_amdgcn_readfirstlane(fo.pos[q][r]) : r;
+          pq[q] = p < 0 ? -1 : 0;
+          if (p >= 0) {
+            const float* gq = fo.g[q] + p * d + c;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[q][k] = __builtin_nontemporal_load(gq + k);
+          }
+        }
+      }
+      if (r + kBlock / kWave < r_end) {
+        const int64_t o1 = off + (int64_t)(kBlock / kWave) * d;
+        gn[0] = __builtin_nontemporal_load(g + o1); gn[1] = __builtin_nontemporal_load(g + o1 + 1);
+        gn[2] = __builtin_nontemporal_load(g + o1 + 2); gn[3] = __builtin_nontemporal_load(g + o1 + 3);
+      }
+      const int64_t quad = ((row0 + r) * d + c) >> 2;
+      if (thresh) {
+        float m[4];
+        keep4(seed + sd, quad, thresh, keep_scale, m);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gm[k] *= m[k];
+      }
+      float mm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (q < fo.n && pq[q] >= 0) {
+          float mq[4] = {1.f, 1.f, 1.f, 1.f};
+          if (thresh) keep4(fo.seed[q] + sd, quad, thresh, keep_scale, mq);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) mm[k] += c_mix * (u[q][k] * mq[k]);
+          if (fo.cs_partial && q == fo.cs_src) {      // (wave-uniform)
+            const unsigned long long* bw2 = fo.cs_bits + (r * tiles + tile) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s2[k] += ((bw2[k] >> lane) & 1ull) ? fo.cs_c * (u[q][k] * mq[k]) : 0.f;
+          }
+        }
+      }
+      float gy[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        mm[k] += c_mix * gm[k];
+        gy[k] = ((bw[k] >> lane) & 1ull) ? c_act * gm[k] : 0.f;
+        s[k] += gy[k];
+      }
+      typedef float f4_t __attribute__((ext_vector_type(4)));
+      const f4_t qo = {gy[0] * sc, gy[1] * sc, gy[2] * sc, gy[3] * sc};
+      __builtin_nontemporal_store(qo, reinterpret_cast<f4_t*>(out + off));
+      const f4_t qm = {mm[0], mm[1], mm[2], mm[3]};
+      __builtin_nontemporal_store(qm, reinterpret_cast<f4_t*>(fo.out_m + off));
+    }
+    if (partial) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s_red[(w * 64 + lane) * 4 + k] = s[k];
+      __syncthreads();
+      if (w == 0) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < kBlock / kWave; ++j)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) t[k] += s_red[(j * 64 + lane) * 4 + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) partial[(int64_t)blockIdx.x * d + c + k] = t[k];
+      }
+      __syncthreads();
+    }
+    if (fo.cs_partial) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s_red[(w * 64 + lane) * 4 + k] = s2[k];
+      __syncthreads();
+      if (w == 0) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < kBlock / kWave; ++j)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) t[k] += s_red[(j * 64 + lane) * 4 + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fo.cs_partial[(int64_t)blockIdx.x * d + c + k] = t[k];
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // Input stage of the trunk backward with the X0-gradient gathered in ONE pass instead of accumulated layer by layer:
 //   gy = ( keep(seed, r, c) * g  +  c_mix * sum_l keep(seed_l, r, c) * g_l ) / (1 - p)  *  (act > 0)
 // g = gradient w.r.t. the dropped X0 that feeds layer 0; g_l = gradient w.r.t. the output of layer l's fused store (the mix
@@ -1010,6 +1140,47 @@ extern "C" int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits,
   CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_colsum_workspace_bytes(rows, d)), CB_E_WORKSPACE, "cb_trunk_layer_bwd_f32: workspace too small");
   return launch_trunk_bwd(0, out_bf16, g, relu_bits, nullptr, row_scale, out, gx0, accumulate, rows, d, drop_p, seed, seed_dev, row0, c_act, c_mix,
                           colsum, ws, ws_bytes, (hipStream_t)stream, nullptr, g2, seed2, c2, g2_pos);
+}
+
+// cb_trunk_layer_bwd_f32 for layer 0 of the 'Initial' trunk (all rows, fp32, no in-place accumulator) which also FOLDS the mix gradients (round 6):
+//   out_m = c_mix * ( dropout_bwd_seed(g) + sum_q dropout_bwd_{mix_seeds[q]}(mix_g[q][mix_pos[q][r] | r]) ),  n_mix <= 2 operands (host arrays; mix_pos[q] NULL: a
+// dense [rows, d] operand; else int32 [rows] positions in a compact one, < 0: absent) — what cb_gemm_tn_instage_f32 reads beside dL/d dropout(X0).  out and
+// colsum exactly as cb_trunk_layer_bwd_f32 (bit-identical).  The elementwise form of cb_spmm_csr_store_bwd_mix_f32's epilogue, for the levels whose reverse
+// aggregation does not carry the store backward (dense levels, mid-size graphs, row shards).
+extern "C" int cb_trunk_layer_bwd_fold_f32(const float* g, const uint64_t* relu_bits, const float* row_scale, float* out, int64_t rows, int64_t d, float drop_p,
+                                           uint64_t seed, const uint64_t* seed_dev, int64_t row0, float c_act, float c_mix, int32_t n_mix, const float* const* mix_g,
+                                           const int32_t* const* mix_pos, const uint64_t* mix_seeds, float* out_m, float* colsum, void* ws, size_t ws_bytes,
+                                           int32_t cs_src, const uint64_t* cs_bits, float cs_c, float* colsum2, void* ws2, size_t ws2_bytes, void* stream) {
+  CB_CHECK_ARG(rows >= 0 && d > 0 && d % 256 == 0 && d < (1 << 20), CB_E_INVALID, "cb_trunk_layer_bwd_fold_f32: d must be a multiple of 256");
+  if (rows == 0) return CB_OK;
+  CB_CHECK_ARG(g && relu_bits && out && out_m && aligned16(g) && aligned16(out) && aligned16(out_m), CB_E_INVALID, "cb_trunk_layer_bwd_fold_f32: null or misaligned pointer");
+  CB_CHECK_ARG(n_mix >= 0 && n_mix <= 2 && (n_mix == 0 || (mix_g && mix_seeds)), CB_E_INVALID, "cb_trunk_layer_bwd_fold_f32: 0..2 mix operands");
+  CB_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, CB_E_INVALID, "cb_trunk_layer_bwd_fold_f32: dropout p out of range");
+  CB_CHECK_ARG(!colsum || (ws && ws_bytes >= cb_colsum_workspace_bytes(rows, d)), CB_E_WORKSPACE, "cb_trunk_layer_bwd_fold_f32: workspace too small");
+  CB_CHECK_ARG(!colsum2 || (cs_src >= 0 && cs_src < n_mix && cs_bits && (uintptr_t)cs_bits % 8 == 0 && ws2 && ws2_bytes >= cb_colsum_workspace_bytes(rows, d)),
+               CB_E_INVALID, "cb_trunk_layer_bwd_fold_f32: the second column sum needs an operand index, its mask words and a workspace");
+  FoldOps fo{};
+  fo.n = n_mix; fo.out_m = out_m;
+  fo.cs_src = cs_src; fo.cs_bits = (const unsigned long long*)cs_bits; fo.cs_c = cs_c; fo.cs_partial = colsum2 ? (float*)ws2 : nullptr;
+  for (int q = 0; q < n_mix; ++q) {
+    CB_CHECK_ARG(mix_g[q] && aligned16(mix_g[q]), CB_E_INVALID, "cb_trunk_layer_bwd_fold_f32: null or misaligned mix operand %d", q);
+    fo.g[q] = mix_g[q]; fo.pos[q] = mix_pos ? mix_pos[q] : nullptr; fo.seed[q] = mix_seeds[q];
+  }
+  int64_t nb = (rows + 63) / 64;
+  if (nb > kMaxBlocks) nb = kMaxBlocks;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_trunk_bwd_fold, dim3((unsigned)nb), dim3(kBlock), kBlock * 4 * sizeof(float), st, g, (const unsigned long long*)relu_bits, row_scale, out, fo, rows,
+                     (int)d, drop_p > 0.f ? dropout_threshold(drop_p) : 0u, 1.f / (1.f - drop_p), seed, seed_dev, row0, c_act, c_mix, colsum ? (float*)ws : nullptr);
+  CB_LAUNCH_CHECK();
+  if (colsum) {
+    hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)d), dim3(kBlock), 0, st, (const float*)ws, (int)nb, (int)d, colsum);
+    CB_LAUNCH_CHECK();
+  }
+  if (colsum2) {
+    hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)d), dim3(kBlock), 0, st, (const float*)ws2, (int)nb, (int)d, colsum2);
+    CB_LAUNCH_CHECK();
+  }
+  return CB_OK;
 }
 
 // cb_trunk_layer_bwd_f32 over a SUBSET of the rows: g and out are compact [n_rows, d] matrices holding rows row_index[0 .. n_rows) of the full

@@ -217,6 +217,37 @@ def _spmm_t(graph, gr):
     return graph.spmm(gr, transpose=True)
 
 
+def _layer_bwd_fold(g, bits, row_scale, p, seed, row0, c_act, c_mix, want_colsum, mix_g, mix_pos, mix_seeds, out=None, cs=None):
+    """cb_trunk_layer_bwd_fold_f32: layer 0's store backward on all rows that also folds the mix gradients — (b * dY', dbias, m) with
+    m = c_mix * (dropout_bwd(g) + sum_q dropout_bwd_q(mix_g[q])); mix_pos[q]: None for a dense operand, else its int32 position map.
+    cs = (index into mix_g, mask words, factor): a fourth result — the column sums of factor * dropout_bwd(mix_g[index]) through those mask words (the bias
+    gradient of a store whose backward left a reverse aggregation's epilogue)."""
+    lib = _lib.load()
+    rows, d = g.shape
+    if out is None:
+        out = torch.empty_like(g)
+    m = torch.empty_like(g)
+    colsum = torch.empty(d, dtype=torch.float32, device=g.device) if want_colsum else None
+    wsb = lib.cb_colsum_workspace_bytes(rows, d) if want_colsum else 0
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=g.device)
+    k = len(mix_g)
+    colsum2 = torch.empty(d, dtype=torch.float32, device=g.device) if cs is not None else None
+    ws2b = lib.cb_colsum_workspace_bytes(rows, d) if cs is not None else 0
+    ws2 = torch.empty(max(ws2b, 16), dtype=torch.uint8, device=g.device) if cs is not None else None
+    with torch.cuda.device(g.device):
+        _lib.check(lib.cb_trunk_layer_bwd_fold_f32(_lib.ptr(g), _lib.ptr(bits), _lib.ptr(row_scale), _lib.ptr(out), rows, d, float(p), ctypes.c_uint64(seed),
+                                                   ops.seed_dev_ptr(), int(row0), float(c_act), float(c_mix), k,
+                                                   (ctypes.c_void_p * max(k, 1))(*[t.data_ptr() for t in mix_g]),
+                                                   (ctypes.c_void_p * max(k, 1))(*[(q.data_ptr() if q is not None else None) for q in mix_pos]),
+                                                   (ctypes.c_uint64 * max(k, 1))(*[int(s_) for s_ in mix_seeds]), _lib.ptr(m), _lib.ptr(colsum), _lib.ptr(ws), wsb,
+                                                   int(cs[0]) if cs is not None else -1, _lib.ptr(cs[1]) if cs is not None else None,
+                                                   float(cs[2]) if cs is not None else 0.0, _lib.ptr(colsum2), _lib.ptr(ws2), ws2b,
+                                                   _lib.stream_ptr()), 'cb_trunk_layer_bwd_fold_f32')
+    if cs is not None:
+        return out, colsum, m, colsum2
+    return out, colsum, m
+
+
 def _layer_bwd(g, bits, row_scale, gx0, accumulate, p, seed, row0, c_act, c_mix, want_colsum, out_bf16=False, out=None, g2=None, seed2=0, c2=0.0, g2_pos=None):
     """cb_trunk_layer_bwd_f32: (b * dY' of the layer's store, dbias).  g2 ('Residual'): the gradient w.r.t. the NEXT layer's stored output, which
     reaches this layer's ReLU output through that layer's mix (c2 = alpha) under that layer's dropout mask (seed2); g2_pos (int32 [rows]): g2 is
@@ -741,12 +772,14 @@ class _Backward:
         # (_layer_source_side) FOLDS every mix gradient known by then into one matrix (cb_spmm_csr_store_bwd_mix_f32: it holds layer 0's in registers, the
         # compact ones of the layers above are gathered per row) and takes layer 0's bias gradient; the input Linear's weight gradient then computes
         # gy = (X0 > 0) * (dropout_bwd(dL/d dropout(X0)) + fold) while it stages it (cb_gemm_tn_instage_f32).  gy's [N, 256] write + read and the n + 1
-        # operand reads of cb_trunk_input_bwd_multi_f32 disappear (S-pl10M: 20 GB per step).  'Initial', one GPU, gathered mix gradients, dropout active,
-        # features staged undropped, no gradient w.r.t. the features.  CB_INSTAGE_FOLD=0: the separate pass.
-        self.fold_ok = (os.environ.get('CB_INSTAGE_FOLD', '1') != '0' and self.gather and not residual and not self.sharded and not agg_bf16 and p > 0
+        # operand reads of cb_trunk_input_bwd_multi_f32 disappear (S-pl10M: 20 GB per step).  'Initial', gathered mix gradients, dropout active,
+        # features staged undropped, no gradient w.r.t. the features; where no reverse aggregation carries layer 0's store backward (dense levels, mid-size graphs,
+        # row shards) that store backward's own pass folds (cb_trunk_layer_bwd_fold_f32, _dx_and_store_bwd).  CB_INSTAGE_FOLD=0: the separate pass.
+        self.fold_ok = (os.environ.get('CB_INSTAGE_FOLD', '1') != '0' and self.gather and not residual and not agg_bf16 and p > 0
                         and ctx.indrop and self.need[3] and not self.need[2] and self.x0_bits is not None and self.h == 256
                         and gemm.mm_tn_instage_supported(self.x0, self.xd, self.x0.shape[0]))
         self.mfold = None      # the folded mix gradients, once a level produced them
+        self.plan_taken = False      # (the fold belongs to the row-sparse plan: the dense backward keeps the passes whose sums are the bit-for-bit witness of rounds 2 - 5)
 
     # -- small helpers -------------------------------------------------------------------------------------------------------------------
     def seed(self, i):
@@ -805,6 +838,20 @@ class _Backward:
                        else colsums[0] if len(colsums) == 1 else torch.stack(colsums).sum(0))
             return g_, gr_, db_, h_
         g_ = g_ready if g_ready is not None else gemm.mm_nn(src, wt, rowscale=rowscale)
+        cs_ = getattr(self, '_cs', [])
+        if (below == 0 and self.fold_ok and self.mfold is None and self.plan_taken and len(self.g_mix) <= 2 and len(cs_) <= 1
+                and all(t.is_contiguous() for t in self.g_mix) and g_.is_contiguous()):
+            # layer 0's store backward as a pass of its own (a level whose reverse aggregation does not carry it): the pass reads layer 0's mix gradient
+            # anyway and folds the ones of the layers above into one matrix (cb_trunk_layer_bwd_fold_f32); the input stage is then computed inside the
+            # input Linear's weight gradient (see __init__)
+            res = _layer_bwd_fold(g_, bits, bnorm, p, sd, row0, 1 - alpha, alpha, want_b, self.g_mix, self.mix_pos, self.seeds_mix,
+                                  out=_exchanged(self.graph, g_.shape[0], g_.shape[1]) if self.sharded else None, cs=cs_[0][:3] if cs_ else None)
+            gr_, db_, self.mfold = res[:3]
+            if cs_:      # (the bias gradient the input-stage pass would have taken for a store whose backward left a reverse aggregation's epilogue)
+                self.grads_layers[3 * cs_[0][3] + 1] = res[3]
+                self._cs = []
+            self.g_mix, self.mix_pos, self.seeds_mix = [], [], []
+            return None, gr_, db_, None
         gr_, db_ = _layer_bwd(g_, bits, bnorm, self.gx0, below != self.L - 1, p, sd, row0, 1 - alpha, alpha, want_b, out_bf16=self.agg_bf16,
                               out=_exchanged(self.graph, g_.shape[0], g_.shape[1]) if (self.sharded and not self.agg_bf16) else None,
                               **self._second(below, g_above, pos_above))
@@ -973,6 +1020,7 @@ class _Backward:
             # a superset of both; every matrix of level j lives on W_j)
             # (count: one use per step — the forward of a rows-only step has looked the plan up already)
             plan = graph.grad_support_plan(hint[0], L, max_frac=T.rowsparse_max_frac, cumulative=self.residual, count=not self.xl_compact)
+        self.plan_taken = plan is not None or bool(self.sh_levels)      # (row shards: the level orientations of the reverse exchange)
         if self.rows_only and plan is None:
             raise RuntimeError('the forward evaluated its last layer on the loss rows (rows_only), but its backward finds no row-support plan: '
                                'CB_LOSS_ROWS / tuning.T / the mask changed between the forward and the backward')

@@ -281,6 +281,18 @@ int cb_trunk_layer_bwd_f32(const float* g, const uint64_t* relu_bits, const floa
  * relu_bits written with bits_relu_only).  g2_pos (may be NULL; int32 [rows of the full matrix]): g2 is a COMPACT matrix of a row-sparse backward —
  * full row r sits at g2_pos[r], absent (= zero) where that is negative. */
 /* (out_bf16 != 0: `out` is a bf16 [rows, d] matrix — gradient rows stored in bf16 for the bf16 aggregation variant.) */
+/* cb_trunk_layer_bwd_f32 for layer 0 of the 'Initial' trunk (all rows, fp32 out, no in-place accumulator) that also FOLDS the gradients the residual mixes send
+ * to X0 (InitialConnection, res_tricks.py:19-23, each under its own store's dropout GCN.py:110,133) — round 6, the elementwise form of
+ * cb_spmm_csr_store_bwd_mix_f32's epilogue for the levels whose reverse aggregation does not carry the store backward:
+ *   out_m = c_mix * ( dropout_bwd_seed(g) + sum_q dropout_bwd_{mix_seeds[q]}(mix_g[q][mix_pos[q][r] | r]) )      n_mix <= 2 operands (host arrays); mix_pos[q] NULL: a
+ * dense [rows, d] operand, else int32 [rows] positions in a compact one (< 0: absent).  out / colsum: exactly cb_trunk_layer_bwd_f32's (bit-identical).  The
+ * input stage then reads out_m beside dL/d dropout(X0): cb_gemm_tn_instage_f32.  colsum2 (may be NULL): the column sums of cs_c * dropout_bwd(mix_g[cs_src]) through
+ * the mask words cs_bits (indexed by the node row) — the bias gradient (GCN.py:253) of a store whose backward cb_spmm_csr_store_bwd_f32 applied, as
+ * cb_trunk_input_bwd_multi_cs_f32 returns it; ws2: cb_colsum_workspace_bytes(rows, d). */
+int cb_trunk_layer_bwd_fold_f32(const float* g, const uint64_t* relu_bits, const float* row_scale, float* out, int64_t rows, int64_t d, float drop_p,
+                                uint64_t seed, const uint64_t* seed_dev, int64_t row0, float c_act, float c_mix, int32_t n_mix, const float* const* mix_g,
+                                const int32_t* const* mix_pos, const uint64_t* mix_seeds, float* out_m, float* colsum, void* ws, size_t ws_bytes, int32_t cs_src,
+                                const uint64_t* cs_bits, float cs_c, float* colsum2, void* ws2, size_t ws2_bytes, void* stream);
 /* The same over a SUBSET of the rows (row-sparse backward: the loss rows): g / out are compact [n_rows, d] matrices holding rows
  * row_index[0 .. n_rows) (ascending) of the full ones; relu_bits / row_scale are the full arrays; the dropout mask is the global row's. */
 int cb_trunk_layer_bwd_rows_f32(const float* g, const int64_t* row_index, int64_t n_rows, const uint64_t* relu_bits, const float* row_scale, float* out,

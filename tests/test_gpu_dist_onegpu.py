@@ -24,6 +24,8 @@ ARGV_NR = ['--dataset=S-pubmed', '--use_special_split=0', '--want_headtail=0', '
            '--manual_assign_GPU=0', '--do_deg_analyze=0', '--force_set_to_best_config=0', '--type_trick=NoResNodeNorm']   # non-residual stack (round 5)
 ARGV_I0 = ['--dataset=S-pubmed', '--use_special_split=0', '--want_headtail=0', '--whetherHasSE=000', '--num_layers=3',
            '--manual_assign_GPU=0', '--do_deg_analyze=0']      # 'Initial' without tables: the rows-only forward on shards (round 5)
+ARGV_ARX = ['--dataset=S-arxiv', '--use_special_split=0', '--want_headtail=0', '--whetherHasSE=000', '--num_layers=3',
+            '--manual_assign_GPU=0', '--do_deg_analyze=0']     # 128 input features, ~85 k rows per rank: the input stage folded into the weight gradient (round 6)
 SEEDS = list(range(7000, 7040))
 STEPS = 3
 
@@ -85,6 +87,10 @@ def _worker(rank, world, port, exchange, overlap, partition, argv, q, wire='f32'
         nores = '--type_trick=NoResNodeNorm' in argv
         if nores:
             assert stack_calls, 'the non-residual stack did not run as its fused node on the shards'
+        if '--dataset=S-arxiv' in argv:
+            # round 6: layer 0's store backward folded the mix gradients on the rank's rows (cb_trunk_layer_bwd_fold_f32) and the input stage ran inside the
+            # input Linear's weight gradient (cb_gemm_tn_instage_f32), whose slab sums are all-reduced like any other gradient
+            assert getattr(t.sgraph, 'instage_folds', 0) == (STEPS if os.environ.get('CB_INSTAGE_FOLD', '1') != '0' else 0), getattr(t.sgraph, 'instage_folds', 0)
         if (argv is ARGV or argv is ARGV_I0 or '--whetherHasSE=111' in argv or '--type_trick=Residual' in argv) and not nores:
             # the fused trunk (S-pubmed: hidden 256, 'Initial'): its backward went through the level orientations of the row-sparse backward
             # (dist.ShardedGraph.support_orients: 10 % train rows -> level 0 keeps a tenth of the reverse edges)
@@ -136,12 +142,14 @@ def _free_port():
     # 'Initial' without tables: the rows-only forward on shards (last layer on the rank's loss rows through loss_rows_forward), cover / three ranks sliced / pull unsliced
     ('halo', '1', 'edges', ARGV_I0, 'f32', 2, '', '1'), ('halo', '1', 'edges', ARGV_I0, 'f32', 3, '3', '1'), ('halo', '1', 'edges', ARGV_I0, 'f32', 2, '', '0'),
     # the non-residual stack (stack.py) on shards: widths F -> H -> H -> C, SE tables on every layer, dropout on the logits
-    ('halo', '1', 'edges', ARGV_NR, 'f32', 2, '', '1'), ('halo', '1', 'edges', ARGV_NR, 'f32', 3, '2', '0'), ('halo', '0', 'rows', ARGV_NR, 'f32', 2, '', '1')],
+    ('halo', '1', 'edges', ARGV_NR, 'f32', 2, '', '1'), ('halo', '1', 'edges', ARGV_NR, 'f32', 3, '2', '0'), ('halo', '0', 'rows', ARGV_NR, 'f32', 2, '', '1'),
+    # the ogbn-arxiv shape (BASELINE config 3) on two ranks: the round-6 input stage (fold pass + weight gradient with the stage inside) on row shards
+    ('halo', '1', 'edges', ARGV_ARX, 'f32', 2, '', '1')],
     ids=['cover-overlap-edges', 'halo-singlepass-rows', 'allgather', 'batchnorm-cover-overlap', 'cover-bf16-wire', 'three-ranks-cover',
          'cover-sliced3', 'three-ranks-cover-sliced4', 'cover-sliced2-bf16-wire', 'batchnorm-cover-sliced2',
          'pull-sliced3', 'pull-three-ranks', 'pull-sliced2-bf16-wire-chunked-producers', 'residual-cover', 'residual-three-ranks-pull-sliced2',
          'rows-only-cover', 'rows-only-three-ranks-cover-sliced3', 'rows-only-pull',
-         'nores-cover', 'nores-three-ranks-pull-sliced2', 'nores-singlepass-rows'])
+         'nores-cover', 'nores-three-ranks-pull-sliced2', 'nores-singlepass-rows', 'arxiv-instage-fold-cover'])
 def test_two_ranks_on_one_gpu_match_single_process(exchange, overlap, partition, argv, wire, world, slices, cover):
     _ranks_match_single_process(exchange, overlap, partition, argv, wire, world, slices, cover, 'gloo')
 
@@ -196,6 +204,13 @@ def _ranks_match_single_process(exchange, overlap, partition, argv, wire, world,
             assert 0 < float((torch.from_numpy(w) - w_ref).abs().max()) <= 2e-2      # Adam steps of size lr: tiny gradient differences move a weight by up to lr per step
             continue
         np.testing.assert_allclose(losses, want, rtol=2e-5)
+        if '--dataset=S-arxiv' in argv:
+            # 1.7 * 10^5 rows: the two runs associate their sums differently (per-rank slabs, halo passes), and where a weight's gradient is zero to rounding
+            # Adam's first steps move it by up to lr either way — a handful of elements; everything else agrees as on the small graphs
+            dw = (torch.from_numpy(w) - w_ref).abs()
+            assert float(dw.max()) <= 3e-3 and float((dw > 1e-5 + 1e-4 * w_ref.abs()).float().mean()) <= 0.01, (float(dw.max()), float((dw > 1e-5).float().mean()))
+            assert float(dw.norm()) <= 2e-3 * float(w_ref.norm())
+            continue
         torch.testing.assert_close(torch.from_numpy(w), w_ref, atol=1e-5, rtol=1e-4)
         if le_ref is not None:
             torch.testing.assert_close(torch.from_numpy(le), le_ref[lo:hi], atol=1e-5, rtol=1e-4)

@@ -89,8 +89,44 @@ def test_reverse_aggregation_folds_the_mix_gradients(n_mix):
     assert none is None and torch.equal(m3, m)
 
 
-@pytest.mark.parametrize('n_loss_rows', [None, 30000])
-def test_training_step_with_the_folded_input_stage(n_loss_rows, monkeypatch):
+@pytest.mark.parametrize('dense_ops', [0, 1])
+def test_store_backward_pass_folds_the_mix_gradients(dense_ops):
+    """cb_trunk_layer_bwd_fold_f32 = cb_trunk_layer_bwd_f32 (same out, same column sums) + the folded mix gradients, with compact and dense operands."""
+    from gnn_tail_generalization_amd import trunk
+    torch.manual_seed(11)
+    n, p, seed, row0, alpha = 200003, 0.1, 777, 4, 0.1
+    g = torch.randn(n, 256, device=DEV)
+    bits = _mask_words(torch.rand(n, 256, device=DEV) < 0.5)
+    scale = torch.rand(n, device=DEV) + 0.5
+    ops_, pos_, seeds_ = [], [], []
+    for q in range(2):
+        if q < dense_ops:
+            ops_.append(torch.randn(n, 256, device=DEV)); pos_.append(None)
+        else:
+            member = torch.rand(n, device=DEV) < (0.1 if q == 0 else 0.45)
+            pos_.append(torch.where(member, torch.cumsum(member, 0, dtype=torch.int32) - 1, torch.full((n,), -1, dtype=torch.int32, device=DEV)).contiguous())
+            ops_.append(torch.randn(int(member.sum()), 256, device=DEV))
+        seeds_.append(2000 + q)
+    gr0, db0 = trunk._layer_bwd(g, bits, scale, None, False, p, seed, row0, 1 - alpha, alpha, True)
+    gr1, db1, m = trunk._layer_bwd_fold(g, bits, scale, p, seed, row0, 1 - alpha, alpha, True, ops_, pos_, seeds_)
+    assert torch.equal(gr0, gr1) and torch.equal(db0, db1)
+    want = g * _keep((n, 256), p, seed, row0 * 256)
+    for t, pos, sd in zip(ops_, pos_, seeds_):
+        full = t if pos is None else torch.zeros(n, 256, device=DEV).index_copy_(0, torch.nonzero(pos >= 0).flatten(), t)
+        want = want + full * _keep((n, 256), p, sd, row0 * 256)
+    want = alpha * want
+    assert float((m - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    # the second column sum: operand 1 under its own dropout, through another store's mask words (what cb_trunk_input_bwd_multi_cs_f32 returns)
+    active2 = torch.rand(n, 256, device=DEV) < 0.4
+    res = trunk._layer_bwd_fold(g, bits, scale, p, seed, row0, 1 - alpha, alpha, True, ops_, pos_, seeds_, cs=(1, _mask_words(active2), 0.9))
+    assert torch.equal(res[0], gr0) and torch.equal(res[2], m)
+    full1 = ops_[1] if pos_[1] is None else torch.zeros(n, 256, device=DEV).index_copy_(0, torch.nonzero(pos_[1] >= 0).flatten(), ops_[1])
+    term = torch.where(active2, 0.9 * full1 * _keep((n, 256), p, seeds_[1], row0 * 256), torch.zeros((), device=DEV))
+    assert float((res[3].double() - term.double().sum(0)).abs().max()) <= 2e-6 * float(term.abs().double().sum(0).max())
+
+
+@pytest.mark.parametrize('n_loss_rows,sum_first', [(None, True), (30000, True), (None, False)])
+def test_training_step_with_the_folded_input_stage(n_loss_rows, sum_first, monkeypatch):
     """The trainer's step (rows-only forward, row-sparse backward, L = 3: level 1 writes all rows and carries layer 0's store backward) with the fold
     against the same step with the separate input-stage pass: the same loss bit for bit, every gradient above the input stage bit for bit, the three
     the fold touches (layer 0's bias, the input Linear's weight and bias) up to the order of their sums."""
@@ -98,7 +134,10 @@ def test_training_step_with_the_folded_input_stage(n_loss_rows, monkeypatch):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_gpu_rowsparse import _step_grads
     from gnn_tail_generalization_amd import gemm
-    monkeypatch.setattr(tuning.T, 'sum_first_below_min_edges', 0)      # (S-pl1M sits below the break-even of the sum-first layer)
+    # sum_first: level 1 runs through its source rows' side and carries layer 0's store backward in its epilogue, which folds (cb_spmm_csr_store_bwd_mix_f32);
+    # else (S-pl1M's own form: it sits below the break-even of the sum-first layer) the store backward is a pass, which folds (cb_trunk_layer_bwd_fold_f32)
+    if sum_first:
+        monkeypatch.setattr(tuning.T, 'sum_first_below_min_edges', 0)
     monkeypatch.setenv('CB_SPMM_STORE_BWD', '1')
     calls = []
     real = gemm.mm_tn_instage
